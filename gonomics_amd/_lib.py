@@ -1,0 +1,182 @@
+"""ctypes binding of the C ABI declared in include/gnx_align.h.
+
+The HIP library is the product: if libgonomics_align_hip.so is missing or a GPU is absent, calls fail
+loudly (GnxError / OSError).  There is no CPU fallback and nothing here ever touches oracle/.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgonomics_align_hip.so")
+
+GNX_OK, GNX_EINVAL, GNX_EBASE, GNX_EEMPTY, GNX_ERANGE, GNX_EDEVICE, GNX_ENOMEM, GNX_ECAPACITY, GNX_ETRACE = range(9)
+GNX_AFFINE_GAP, GNX_CONST_GAP, GNX_AFFINE_GAP_HIGHMEM, GNX_AFFINE_GAP_LOCAL, GNX_CONST_GAP_HIGHMEM = range(5)
+
+EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gnx_free", "gnx_align_batch",
+           "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing"]
+
+
+class GnxCigar(ctypes.Structure):
+    _fields_ = [("run_length", ctypes.c_int64), ("op", ctypes.c_uint8), ("_pad", ctypes.c_uint8 * 7)]
+
+
+CIGAR_DTYPE = np.dtype({"names": ["run_length", "op"], "formats": [np.int64, np.uint8], "offsets": [0, 8], "itemsize": 16})
+
+
+class GnxParams(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int32), ("_reserved", ctypes.c_int32), ("scores", ctypes.c_int64 * 25),
+                ("gap_open", ctypes.c_int64), ("gap_extend", ctypes.c_int64),
+                ("checkersize_i", ctypes.c_int64), ("checkersize_j", ctypes.c_int64)]
+
+
+class GnxTiming(ctypes.Structure):
+    _fields_ = [("fill_ms", ctypes.c_double), ("traceback_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
+                ("cells", ctypes.c_int64), ("n_launches", ctypes.c_int64), ("trace_bytes", ctypes.c_int64)]
+
+
+class GnxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gnx error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises OSError if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        c_p = ctypes.c_void_p
+        i64 = ctypes.c_int64
+        L.gnx_device_count.restype = ctypes.c_int
+        L.gnx_init.argtypes = [ctypes.c_int, i64]
+        L.gnx_init.restype = ctypes.c_int
+        L.gnx_shutdown.restype = None
+        L.gnx_last_error.restype = ctypes.c_char_p
+        L.gnx_free.argtypes = [c_p]
+        L.gnx_free.restype = None
+        L.gnx_align_batch.argtypes = [ctypes.POINTER(GnxParams), i64, c_p, c_p, c_p, c_p, c_p,
+                                      ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
+        L.gnx_align_batch.restype = ctypes.c_int
+        L.gnx_align_batch_windows.argtypes = [ctypes.POINTER(GnxParams), i64, c_p, i64, c_p, c_p, c_p, i64, c_p, c_p, c_p,
+                                              ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
+        L.gnx_align_batch_windows.restype = ctypes.c_int
+        L.gnx_align_pair.argtypes = [ctypes.POINTER(GnxParams), c_p, i64, c_p, i64, ctypes.POINTER(i64),
+                                     ctypes.POINTER(c_p), ctypes.POINTER(i64)]
+        L.gnx_align_pair.restype = ctypes.c_int
+        L.gnx_align_batch_device.argtypes = [ctypes.POINTER(GnxParams), i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                             c_p, c_p, i64, c_p, ctypes.POINTER(i64), c_p]
+        L.gnx_align_batch_device.restype = ctypes.c_int
+        L.gnx_get_timing.argtypes = [ctypes.POINTER(GnxTiming)]
+        L.gnx_get_timing.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != GNX_OK:
+        raise GnxError(rc, lib().gnx_last_error().decode("utf-8", "replace"))
+
+
+def make_params(mode, scores, gap_open, gap_extend=0, checkersize_i=10000, checkersize_j=10000):
+    p = GnxParams()
+    p.mode = mode
+    flat = [int(v) for row in scores for v in row]
+    if len(flat) != 25:
+        raise ValueError("scores must be a 5x5 matrix")
+    for k, v in enumerate(flat):
+        p.scores[k] = v
+    p.gap_open = int(gap_open)
+    p.gap_extend = int(gap_extend)
+    p.checkersize_i = int(checkersize_i)
+    p.checkersize_j = int(checkersize_j)
+    return p
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _take(ops_p, off_p, n_pairs):
+    L = lib()
+    off = np.ctypeslib.as_array(ctypes.cast(off_p, ctypes.POINTER(ctypes.c_int64)), shape=(n_pairs + 1,)).copy()
+    total = int(off[-1])
+    if total:
+        buf = (ctypes.c_char * (total * 16)).from_address(ops_p.value)
+        ops = np.frombuffer(buf, dtype=CIGAR_DTYPE, count=total).copy()
+    else:
+        ops = np.zeros(0, dtype=CIGAR_DTYPE)
+    L.gnx_free(ops_p)
+    L.gnx_free(off_p)
+    return ops, off
+
+
+def align_batch_windows(params, a_buf, a_start, a_len, b_buf, b_start, b_len):
+    """Host-buffer batch over windows of shared buffers.  Returns (scores[int64], ops[CIGAR_DTYPE], off[int64])."""
+    L = lib()
+    a_buf, b_buf = _u8(a_buf), _u8(b_buf)
+    a_start, a_len, b_start, b_len = _i64(a_start), _i64(a_len), _i64(b_start), _i64(b_len)
+    n = int(a_start.shape[0])
+    scores = np.zeros(max(n, 1), dtype=np.int64)
+    ops_p, off_p = ctypes.c_void_p(), ctypes.c_void_p()
+    check(L.gnx_align_batch_windows(ctypes.byref(params), n, a_buf.ctypes.data, a_buf.shape[0], a_start.ctypes.data, a_len.ctypes.data,
+                                    b_buf.ctypes.data, b_buf.shape[0], b_start.ctypes.data, b_len.ctypes.data,
+                                    scores.ctypes.data, ctypes.byref(ops_p), ctypes.byref(off_p)))
+    ops, off = _take(ops_p, off_p, n)
+    return scores[:n], ops, off
+
+
+def align_batch(params, alphas, betas):
+    """Batch of independent pairs given as lists of uint8 arrays (concatenated form of the C ABI)."""
+    L = lib()
+    n = len(alphas)
+    a_off = np.zeros(n + 1, dtype=np.int64)
+    b_off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        a_off[1:] = np.cumsum([len(a) for a in alphas])
+        b_off[1:] = np.cumsum([len(b) for b in betas])
+    a_cat = _u8(np.concatenate([_u8(a) for a in alphas])) if n and a_off[-1] else np.zeros(1, dtype=np.uint8)
+    b_cat = _u8(np.concatenate([_u8(b) for b in betas])) if n and b_off[-1] else np.zeros(1, dtype=np.uint8)
+    scores = np.zeros(max(n, 1), dtype=np.int64)
+    ops_p, off_p = ctypes.c_void_p(), ctypes.c_void_p()
+    check(L.gnx_align_batch(ctypes.byref(params), n, a_cat.ctypes.data, a_off.ctypes.data, b_cat.ctypes.data, b_off.ctypes.data,
+                            scores.ctypes.data, ctypes.byref(ops_p), ctypes.byref(off_p)))
+    ops, off = _take(ops_p, off_p, n)
+    return scores[:n], ops, off
+
+
+def align_pair(params, alpha, beta):
+    L = lib()
+    a, b = _u8(alpha), _u8(beta)
+    score = ctypes.c_int64()
+    nops = ctypes.c_int64()
+    ops_p = ctypes.c_void_p()
+    a_ptr = a.ctypes.data if a.size else None
+    b_ptr = b.ctypes.data if b.size else None
+    check(L.gnx_align_pair(ctypes.byref(params), a_ptr, a.shape[0], b_ptr, b.shape[0], ctypes.byref(score), ctypes.byref(ops_p), ctypes.byref(nops)))
+    total = nops.value
+    if total:
+        buf = (ctypes.c_char * (total * 16)).from_address(ops_p.value)
+        ops = np.frombuffer(buf, dtype=CIGAR_DTYPE, count=total).copy()
+    else:
+        ops = np.zeros(0, dtype=CIGAR_DTYPE)
+    L.gnx_free(ops_p)
+    return score.value, ops
+
+
+def get_timing():
+    t = GnxTiming()
+    check(lib().gnx_get_timing(ctypes.byref(t)))
+    return {"fill_ms": t.fill_ms, "traceback_ms": t.traceback_ms, "total_ms": t.total_ms, "cells": t.cells,
+            "n_launches": t.n_launches, "trace_bytes": t.trace_bytes}

@@ -1,0 +1,898 @@
+// gnx_align.hip -- MI355X (gfx950 / CDNA4) implementation of the gonomics `align` pairwise DP hot path.
+//
+// What is computed (reference semantics, bit-exact):
+//   align/affineGap.go:59-344, align/constGap.go:13-311, align/affineGap_highMem.go:57-223,
+//   align/constGap_highMem.go:11-67, align/align.go:76-90 (tripleMaxTrace tie order M >= I >= D).
+//
+// How (MI355X-first, nothing here is a translation of the Go loops):
+//   * FILL kernel: one 16-lane DPP row per pair (4 pairs per wave64), each lane owns R consecutive DP rows
+//     (alpha), the wave sweeps the columns (beta) as an anti-diagonal wavefront: lane l works on column
+//     t-l at step t.  The only cross-lane traffic is two `row_shr:1` DPP moves per step.  Cells are int32
+//     "keys" = 4*score + tag (tag 3/2/1 = came-from M/I/D), so v_max3_i32 returns value AND argmax with the
+//     reference's tie order, and the 2-bit direction is the low bits of the winner.  Per cell:
+//       h  = max3(M,I,D)            (feeds M of the lower-right neighbour and is the cell's argmax)
+//       rt = max3(M+oe, I+e, D+oe)  (feeds I of the right neighbour)
+//       dn = max3(M+oe, I+oe, D+e)  (feeds D of the lower neighbour)
+//     Direction bits are shifted into 3 accumulators per row with v_alignbit and flushed every 16 steps
+//     as 8 coalesced 16-byte stores per lane (6 bits/cell of HBM write traffic, the algorithmic minimum).
+//     Sequences longer than 16*R rows are processed as strips with a row buffer in HBM in between.
+//   * TRACEBACK kernel (separate launch, one lane per pair): walks the bit-packed direction matrix,
+//     emulating the reference's checkerboard walk (state reset when a tile is left through its top edge,
+//     dropped leading gap on a corner exit) from global coordinates, run-length encodes, two passes
+//     (count, exclusive scan, write) so CIGARs are emitted densely in input order.
+//   * No MFMA: this is an integer max-plus recurrence.  No CPU fallback: every entry point needs the GPU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+#include <algorithm>
+#include "gnx_align.h"
+
+namespace {
+
+constexpr int G = 16;            // lanes per pair (one DPP row)
+constexpr int R = 10;            // DP rows per lane
+constexpr int H = G * R;         // rows per strip
+constexpr int NEG4 = -(1 << 30); // scaled "veryNegNum" (align/align.go:8); finite keys stay above -(1<<29)
+constexpr int QA = 8;            // uint4 stores per lane per flush, affine (3*R=30 dwords -> 32)
+constexpr int QC = 3;            // const gap (R=10 dwords -> 12)
+
+#define DPP_ROW_SHR1 0x111
+#define DPP_ROW_SHL1 0x101
+
+struct PairPlan {
+    int32_t n, m;
+    int32_t words;      // 16-column direction words per strip
+    int32_t strips;     // ceil(n / H)
+    int64_t trace_off;  // in uint4 units, relative to the chunk's trace buffer
+    int64_t hcol_off;   // ints
+    int64_t rowbuf_off; // int2
+};
+
+struct KParams {
+    int sc4[25]; // 4*scores
+    int oe4, e4, o4;
+    int d00_4;   // 4*D(0,0): gapOpen, or 0 with free end gaps
+    int ecol4;   // 4*(column-0 extension): gapExtend, or 0 with free end gaps
+    int g4;      // const gap: 4*gapPen
+};
+
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ int dpp_shr1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHR1, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_shl1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHL1, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned alignbit2(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 2); }
+
+// ------------------------------------------------------------------------------------------------------
+// Affine fill.  LOCAL = free end gaps (AffineGapLocal, affineGap_highMem.go:188-210).
+// ------------------------------------------------------------------------------------------------------
+template <bool LOCAL>
+__global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                         const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                         const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                         KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
+                                                         int2 *__restrict__ rowbuf, int *__restrict__ err) {
+    __shared__ int lds[32 + 64]; // [0..24] 4*score table, [32..95] 4 beta rings of 64 bytes
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    if (lane < 25) lds[lane] = kp.sc4[lane];
+    unsigned char *ring = reinterpret_cast<unsigned char *>(&lds[32]) + g * 64;
+    const char *tabb = reinterpret_cast<const char *>(&lds[0]);
+
+    const int pbase = blockIdx.x * 4;
+    int S_max = 0, m_max = 0, m_min = 0x7fffffff;
+    for (int q = 0; q < 4; q++) {
+        if (pbase + q < n_pairs) {
+            S_max = max(S_max, plans[pbase + q].strips);
+            m_max = max(m_max, plans[pbase + q].m);
+            m_min = min(m_min, plans[pbase + q].m);
+        }
+    }
+    const int p = pbase + g;
+    const bool valid = p < n_pairs;
+    PairPlan pl;
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; }
+    const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    const int Tend = (m_max + 15 + 15) & ~15;
+    const int OE4 = kp.oe4, E4 = kp.e4;
+    int bad = 0;
+
+    for (int s = 0; s < S_max; s++) {
+        const bool gact = valid && s < pl.strips;
+        const int m_eff = gact ? pl.m : 0;
+        const bool store_row = gact && (s + 1 < pl.strips);
+        const int row0 = s * H + l * R; // 0-based index of this lane's first row == 1-based index of the row above it
+        int a20[R], rt[R], hold[R];
+        unsigned accM[R], accI[R], accD[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i0 = row0 + r;
+            int a = 0;
+            if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+            a20[r] = a * 20;
+            const int i = i0 + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
+            const int D1c = kp.d00_4 + i * kp.ecol4 + 1;
+            hold[r] = max3i(NEG4 + 3, NEG4 + 2, D1c);
+            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + 2 + E4, D1c + OE4);
+            accM[r] = 0; accI[r] = 0; accD[r] = 0;
+        }
+        int diag0 = (row0 == 0) ? max3i(3, kp.o4 + 2, kp.d00_4 + 1) : max3i(NEG4 + 3, NEG4 + 2, kp.d00_4 + row0 * kp.ecol4 + 1);
+        int dn_out = 0, h_out = 0;
+        int sq_dn = 0, sq_h = 0;
+        // boundary (row above the strip) for block 0: lane u <- column u+1
+        int qdn, qh, ndn = 0, nh = 0;
+        auto boundary = [&](int c, int &odn, int &oh) {
+            if (s == 0) {
+                const int M3 = NEG4 + 3, I2 = kp.o4 + c * E4 + 2, D1 = NEG4 + 1; // row 0: I(0,c) = gapOpen + c*gapExtend
+                oh = max3i(M3, I2, D1);
+                odn = (LOCAL && c == m_eff) ? oh : max3i(M3 + OE4, I2 + OE4, D1 + E4);
+            } else if (c >= 1 && c <= m_eff) {
+                const int2 v = rowbuf[pl.rowbuf_off + c];
+                odn = v.x; oh = v.y;
+            } else { odn = 0; oh = 0; }
+        };
+        boundary(l + 1, qdn, qh);
+        int nb = 0;
+        { // beta ring: columns 1..16 now, 17..32 prefetched
+            int b0 = 0;
+            if (l < m_eff) { b0 = bp[l]; if (b0 >= 5) { bad = 1; b0 = 4; } }
+            __syncthreads();
+            ring[l & 63] = (unsigned char)b0;
+            if (16 + l < m_eff) { nb = bp[16 + l]; if (nb >= 5) { bad = 1; nb = 4; } }
+        }
+        if (s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        for (int t0 = 0; t0 < Tend; t0 += 16) {
+            // prefetch the boundary of the next block and stage the beta bytes of this one
+            boundary(t0 + 16 + l + 1, ndn, nh);
+            if (t0 > 0) {
+                ring[(t0 + l) & 63] = (unsigned char)nb;
+                nb = 0;
+                if (t0 + 16 + l < m_eff) { nb = bp[t0 + 16 + l]; if (nb >= 5) { bad = 1; nb = 4; } }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int u = 0; u < 16; u++) {
+                const int t = t0 + u + 1;
+                const int j = t - l;
+                const int up_dn = dpp_shr1(qdn, dn_out);
+                const int up_h = dpp_shr1(qh, h_out);
+                qdn = dpp_shl1(qdn, qdn);
+                qh = dpp_shl1(qh, qh);
+                if (j >= 1 && j <= m_eff) {
+                    const int b4 = (int)ring[(j - 1) & 63] << 2;
+                    int hd = diag0, dnu = up_dn;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int S4 = *reinterpret_cast<const int *>(tabb + (a20[r] + b4));
+                        const int M3 = (hd | 3) + S4;
+                        const int I2 = (rt[r] & ~3) | 2;
+                        const int D1 = (dnu & ~3) | 1;
+                        accM[r] = alignbit2((unsigned)hd, accM[r]);
+                        accI[r] = alignbit2((unsigned)rt[r], accI[r]);
+                        accD[r] = alignbit2((unsigned)dnu, accD[r]);
+                        const int Moe = M3 + OE4;
+                        const int hnew = max3i(M3, I2, D1);
+                        rt[r] = max3i(Moe, I2 + E4, D1 + OE4);
+                        int dnn = max3i(Moe, I2 + OE4, D1 + E4);
+                        if (LOCAL) dnn = (j == m_eff) ? hnew : dnn; // last column: D(i+1,m) = tmt(M,I,D)(i,m), no penalty
+                        hd = hold[r];
+                        hold[r] = hnew;
+                        dnu = dnn;
+                    }
+                    diag0 = up_h;
+                    dn_out = dnu;
+                    h_out = hold[R - 1];
+                }
+                if (S_max > 1) { sq_dn = dpp_shl1(dn_out, sq_dn); sq_h = dpp_shl1(h_out, sq_h); }
+            }
+            qdn = ndn; qh = nh;
+            // flush 16 steps of direction bits: word w of this strip
+            const int w = t0 >> 4;
+            if (gact && w < pl.words) {
+                const int miss = (t0 + 16 - l) - m_eff; // steps this lane sat idle after its last column
+                const bool fix = miss > 0;
+                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+                unsigned o[32];
+#pragma unroll
+                for (int r = 0; r < R; r++) { o[r] = accM[r]; o[R + r] = accI[r]; o[2 * R + r] = accD[r]; }
+                o[30] = 0; o[31] = 0;
+                if (__any(fix)) {
+#pragma unroll
+                    for (int d = 0; d < 30; d++) o[d] >>= sh;
+                }
+                uint4 *dst = trace + pl.trace_off + ((int64_t)(s * pl.words + w) * QA) * G + l;
+#pragma unroll
+                for (int q = 0; q < QA; q++) dst[q * G] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+            }
+            if (store_row) {
+                const int c = t0 + l - 14;
+                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + c] = make_int2(sq_dn, sq_h);
+            }
+        }
+        if (gact && m_eff >= 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r];
+        }
+        if (S_max > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Constant-gap fill (align/constGap.go:146-157 recurrence).  Keys: diag+s -> tag 3, left+g -> tag 2,
+// up+g -> tag 1; the stored value is the clean (tag-free) key.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                        const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                        const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                        KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
+                                                        int2 *__restrict__ rowbuf, int *__restrict__ err) {
+    __shared__ int lds[32 + 64];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    if (lane < 25) lds[lane] = kp.sc4[lane] + 3; // pre-tagged diagonal candidate
+    unsigned char *ring = reinterpret_cast<unsigned char *>(&lds[32]) + g * 64;
+    const char *tabb = reinterpret_cast<const char *>(&lds[0]);
+    const int pbase = blockIdx.x * 4;
+    int S_max = 0, m_max = 0;
+    for (int q = 0; q < 4; q++) {
+        if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
+    }
+    const int p = pbase + g;
+    const bool valid = p < n_pairs;
+    PairPlan pl;
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; }
+    const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    const int Tend = (m_max + 15 + 15) & ~15;
+    const int GL = kp.g4 + 2, GU = kp.g4 + 1;
+    int bad = 0;
+
+    for (int s = 0; s < S_max; s++) {
+        const bool gact = valid && s < pl.strips;
+        const int m_eff = gact ? pl.m : 0;
+        const bool store_row = gact && (s + 1 < pl.strips);
+        const int row0 = s * H + l * R;
+        int a20[R], val[R];
+        unsigned acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i0 = row0 + r;
+            int a = 0;
+            if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+            a20[r] = a * 20;
+            val[r] = (i0 + 1) * kp.g4; // column 0: i*gapPen
+            acc[r] = 0;
+        }
+        int diag0 = row0 * kp.g4; // V(row above, 0)
+        int v_out = 0, sq_v = 0;
+        int qv, nv = 0;
+        auto boundary = [&](int c, int &ov) {
+            if (s == 0) ov = c * kp.g4; // row 0: j*gapPen
+            else if (c >= 1 && c <= m_eff) ov = rowbuf[pl.rowbuf_off + c].x;
+            else ov = 0;
+        };
+        boundary(l + 1, qv);
+        int nb = 0;
+        {
+            int b0 = 0;
+            if (l < m_eff) { b0 = bp[l]; if (b0 >= 5) { bad = 1; b0 = 4; } }
+            __syncthreads();
+            ring[l & 63] = (unsigned char)b0;
+            if (16 + l < m_eff) { nb = bp[16 + l]; if (nb >= 5) { bad = 1; nb = 4; } }
+        }
+        if (s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int t0 = 0; t0 < Tend; t0 += 16) {
+            boundary(t0 + 16 + l + 1, nv);
+            if (t0 > 0) {
+                ring[(t0 + l) & 63] = (unsigned char)nb;
+                nb = 0;
+                if (t0 + 16 + l < m_eff) { nb = bp[t0 + 16 + l]; if (nb >= 5) { bad = 1; nb = 4; } }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int u = 0; u < 16; u++) {
+                const int t = t0 + u + 1;
+                const int j = t - l;
+                const int up_v = dpp_shr1(qv, v_out);
+                qv = dpp_shl1(qv, qv);
+                if (j >= 1 && j <= m_eff) {
+                    const int b4 = (int)ring[(j - 1) & 63] << 2;
+                    int vd = diag0, vu = up_v;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int S4 = *reinterpret_cast<const int *>(tabb + (a20[r] + b4));
+                        const int k = max3i(vd + S4, val[r] + GL, vu + GU);
+                        acc[r] = alignbit2((unsigned)k, acc[r]);
+                        vd = val[r];
+                        val[r] = k & ~3;
+                        vu = val[r];
+                    }
+                    diag0 = up_v;
+                    v_out = vu;
+                }
+                if (S_max > 1) sq_v = dpp_shl1(v_out, sq_v);
+            }
+            qv = nv;
+            const int w = t0 >> 4;
+            if (gact && w < pl.words) {
+                const int miss = (t0 + 16 - l) - m_eff;
+                const bool fix = miss > 0;
+                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+                unsigned o[12];
+#pragma unroll
+                for (int r = 0; r < R; r++) o[r] = acc[r];
+                o[10] = 0; o[11] = 0;
+                if (__any(fix)) {
+#pragma unroll
+                    for (int d = 0; d < 10; d++) o[d] >>= sh;
+                }
+                uint4 *dst = trace + pl.trace_off + ((int64_t)(s * pl.words + w) * QC) * G + l;
+#pragma unroll
+                for (int q = 0; q < QC; q++) dst[q * G] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+            }
+            if (store_row) {
+                const int c = t0 + l - 14;
+                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + c] = make_int2(sq_v, 0);
+            }
+        }
+        if (gact && m_eff >= 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = val[r];
+        }
+        if (S_max > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Traceback.  One lane per pair.  WRITE=false counts CIGAR runs, WRITE=true emits them (reversed into
+// alignment order) at ops[ops_off[p] ..).  ci/cj = checkerboard sizes (huge for the highMem modes).
+// ------------------------------------------------------------------------------------------------------
+struct TbParams {
+    int64_t ci, cj;
+    int64_t d00, ecol, gap_open, gap_extend; // unscaled, for the empty-sequence closed forms
+    int affine;
+};
+
+template <bool AFFINE>
+__device__ __forceinline__ unsigned load_dir(const uint4 *trace, const PairPlan &pl, int k, int i, int j) {
+    // direction bits of cell (i,j) (1-based) for state k (affine) -- see the flush layout in the fill kernels
+    const int i0 = i - 1;
+    const int s = i0 / H, rem = i0 - s * H;
+    const int l = rem / R, r = rem - l * R;
+    const int t1 = j + l - 1;
+    const int w = t1 >> 4, pos = t1 & 15;
+    const int d = AFFINE ? k * R + r : r;
+    const int Q = AFFINE ? QA : QC;
+    const unsigned *base = reinterpret_cast<const unsigned *>(trace + pl.trace_off + ((int64_t)(s * pl.words + w) * Q + (d >> 2)) * G + l);
+    return (base[d & 3] >> (2 * pos)) & 3u;
+}
+
+template <bool AFFINE, bool WRITE>
+__global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restrict__ plans, int n_pairs, const uint4 *__restrict__ trace,
+                                                       const int *__restrict__ hcol, TbParams tp, int64_t *__restrict__ score_out,
+                                                       int64_t *__restrict__ nops, const int64_t *__restrict__ ops_off,
+                                                       gnx_cigar *__restrict__ ops, int64_t ops_capacity, int *__restrict__ err) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const PairPlan pl = plans[p];
+    int i = pl.n, j = pl.m;
+    int64_t score;
+    int k;
+    if (i > 0 && j > 0) {
+        const int hc = hcol[pl.hcol_off + pl.n - 1];
+        score = (int64_t)(hc >> 2);
+        if (AFFINE) k = 3 - (hc & 3);
+        else k = 0;
+    } else { // highMem modes with an empty sequence: closed forms of row 0 / column 0
+        if (AFFINE) {
+            if (i == 0 && j == 0) { // tmt(0, gapOpen, D00)
+                const int64_t a = 0, b = tp.gap_open, c = tp.d00;
+                if (a >= b && a >= c) { score = a; k = 0; } else if (b >= c) { score = b; k = 1; } else { score = c; k = 2; }
+            } else if (i == 0) { score = tp.gap_open + (int64_t)j * tp.gap_extend; k = 1; }
+            else { score = tp.d00 + (int64_t)i * tp.ecol; k = 2; }
+        } else { score = (int64_t)(i + j) * tp.gap_open; k = 0; }
+    }
+    if (!WRITE) score_out[p] = score;
+
+    int64_t cnt = 0;           // runs emitted so far (traceback order)
+    int cur_op = -1;
+    int64_t cur_run = 0;
+    const int64_t total = WRITE ? nops[p] : 0;
+    const int64_t obase = WRITE ? ops_off[p] : 0;
+    const bool fits = WRITE ? (obase + total <= ops_capacity) : false;
+    auto flush_run = [&]() {
+        if (cur_op >= 0) {
+            if (WRITE && fits) {
+                gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op;
+                for (int z = 0; z < 7; z++) c._pad[z] = 0;
+                ops[obase + (total - 1 - cnt)] = c;
+            }
+            cnt++;
+        }
+    };
+    auto emit = [&](int op, int64_t run) {
+        if (op == cur_op) cur_run += run;
+        else { flush_run(); cur_op = op; cur_run = run; }
+    };
+
+    // tile-local coordinates of the checkerboard walk
+    int64_t li = (i > 0) ? (int64_t)(i - 1) % tp.ci : 0;
+    int64_t lj = (j > 0) ? (int64_t)(j - 1) % tp.cj : 0;
+    bool up_exit = false, left_exit = false;
+    bool walked = false;
+    while (i > 0 && j > 0) {
+        walked = true;
+        int op, tag;
+        if (AFFINE) { op = k; tag = (int)load_dir<true>(trace, pl, k, i, j); }
+        else { tag = (int)load_dir<false>(trace, pl, 0, i, j); op = 3 - tag; }
+        if (tag == 0) { atomicOr(err, 2); break; } // impossible direction: the Go code would log.Fatalf
+        emit(op, 1);
+        up_exit = false; left_exit = false;
+        if (op != 1) { up_exit = (li == 0); li = up_exit ? tp.ci - 1 : li - 1; i--; }
+        if (op != 2) { left_exit = (lj == 0); lj = left_exit ? tp.cj - 1 : lj - 1; j--; }
+        if (AFFINE) {
+            k = 3 - tag;
+            if (up_exit && i > 0 && j > 0) {
+                // quirk Q1 (affineGap.go:305): entering a tile from below restarts in the argmax state of the entry cell
+                int ht;
+                if (j < pl.m) ht = (int)load_dir<true>(trace, pl, 0, i + 1, j + 1);
+                else ht = hcol[pl.hcol_off + i - 1] & 3;
+                k = 3 - ht;
+            }
+        }
+    }
+    // Step 4 (affineGap.go:135-139 / constGap.go:59-63) and the highMem border walks
+    if (walked) {
+        if (!up_exit && left_exit) emit(2, i);
+        else if (up_exit && !left_exit) emit(1, j);
+        // both: corner exit -> nothing (quirk Q2 when it is not the origin)
+    } else { // empty sequence (highMem modes only)
+        if (i == 0 && j > 0) emit(1, j);
+        else if (j == 0 && i > 0) emit(2, i);
+        else { cur_op = 0; cur_run = 0; } // Go: route == [{0 0}]
+    }
+    flush_run();
+    if (!WRITE) nops[p] = cnt;
+    else if (!fits) atomicOr(err, 4);
+}
+
+// exclusive scan of nops[0..n) + carry[0] -> off[0..n], off[n]; carry[0] = off[n] afterwards.  One block.
+__global__ __launch_bounds__(1024) void scan_kernel(const int64_t *__restrict__ nops, int n, int64_t *__restrict__ off, int64_t *__restrict__ carry) {
+    __shared__ int64_t sh[1024];
+    __shared__ int64_t base;
+    if (threadIdx.x == 0) base = carry[0];
+    __syncthreads();
+    for (int start = 0; start < n; start += 1024) {
+        const int idx = start + threadIdx.x;
+        const int64_t v = idx < n ? nops[idx] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int64_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (idx < n) off[idx] = base + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) base += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { off[n] = base; carry[0] = base; }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+void set_err(const char *fmt, const char *a = "", long long b = 0) { snprintf(g_err, sizeof(g_err), fmt, a, b); }
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            snprintf(g_err, sizeof(g_err), "HIP error %s at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return GNX_EDEVICE;                                                                        \
+        }                                                                                              \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return GNX_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; set_err("device allocation of %s%lld bytes failed", "", (long long)bytes); return GNX_ENOMEM; }
+            want = bytes;
+        }
+        cap = want;
+        return GNX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Ctx {
+    std::mutex mu;
+    bool inited = false;
+    int device = -1;
+    int64_t ws_limit = 0;
+    hipStream_t own_stream = nullptr;
+    DevBuf trace, hcol, rowbuf, plans, nops, misc;
+    DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    gnx_timing timing = {};
+};
+Ctx g_ctx;
+
+int ensure_init() {
+    if (g_ctx.inited) return GNX_OK;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { set_err("no HIP device available (this library has no CPU fallback)%s", ""); return GNX_EDEVICE; }
+    int dev = 0;
+    const char *lr = getenv("LOCAL_RANK");
+    if (lr && *lr) dev = atoi(lr) % cnt;
+    HIPCHK(hipSetDevice(dev));
+    g_ctx.device = dev;
+    HIPCHK(hipStreamCreate(&g_ctx.own_stream));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&g_ctx.ev[i]));
+    if (g_ctx.ws_limit <= 0) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        g_ctx.ws_limit = (int64_t)std::min<size_t>(fr / 2, (size_t)64 << 30);
+    }
+    g_ctx.inited = true;
+    return GNX_OK;
+}
+
+int check_params(const gnx_params *p, KParams &kp, TbParams &tp, bool &affine, bool &local, bool &lowmem) {
+    if (!p) { set_err("null params%s", ""); return GNX_EINVAL; }
+    affine = (p->mode == GNX_AFFINE_GAP || p->mode == GNX_AFFINE_GAP_HIGHMEM || p->mode == GNX_AFFINE_GAP_LOCAL);
+    const bool cst = (p->mode == GNX_CONST_GAP || p->mode == GNX_CONST_GAP_HIGHMEM);
+    if (!affine && !cst) { set_err("unknown mode %s%lld", "", (long long)p->mode); return GNX_EINVAL; }
+    local = (p->mode == GNX_AFFINE_GAP_LOCAL);
+    lowmem = (p->mode == GNX_AFFINE_GAP || p->mode == GNX_CONST_GAP);
+    if (lowmem && (p->checkersize_i < 1 || p->checkersize_j < 1)) { set_err("checkersize must be >= 1%s", ""); return GNX_EINVAL; }
+    const int64_t lim = (int64_t)1 << 26;
+    for (int x = 0; x < 25; x++) if (p->scores[x] > lim || p->scores[x] < -lim) { set_err("score out of int32 kernel range%s", ""); return GNX_ERANGE; }
+    if (p->gap_open > lim || p->gap_open < -lim || (affine && (p->gap_extend > lim || p->gap_extend < -lim))) { set_err("gap penalty out of int32 kernel range%s", ""); return GNX_ERANGE; }
+    for (int x = 0; x < 25; x++) kp.sc4[x] = (int)(4 * p->scores[x]);
+    kp.o4 = (int)(4 * p->gap_open);
+    kp.e4 = affine ? (int)(4 * p->gap_extend) : 0;
+    kp.oe4 = kp.o4 + kp.e4;
+    kp.d00_4 = local ? 0 : kp.o4;
+    kp.ecol4 = local ? 0 : kp.e4;
+    kp.g4 = kp.o4;
+    tp.ci = lowmem ? p->checkersize_i : ((int64_t)1 << 62);
+    tp.cj = lowmem ? p->checkersize_j : ((int64_t)1 << 62);
+    tp.d00 = local ? 0 : p->gap_open;
+    tp.ecol = local ? 0 : p->gap_extend;
+    tp.gap_open = p->gap_open;
+    tp.gap_extend = affine ? p->gap_extend : 0;
+    tp.affine = affine ? 1 : 0;
+    return GNX_OK;
+}
+
+int64_t max_abs_pen(const gnx_params *p, bool affine) {
+    int64_t mx = 0;
+    for (int x = 0; x < 25; x++) mx = std::max<int64_t>(mx, llabs((long long)p->scores[x]));
+    if (affine) mx = std::max<int64_t>(mx, llabs((long long)(p->gap_open + p->gap_extend)));
+    mx = std::max<int64_t>(mx, llabs((long long)p->gap_open));
+    if (affine) mx = std::max<int64_t>(mx, llabs((long long)p->gap_extend));
+    return mx;
+}
+
+// The device flow shared by all entry points.  All pointers are device pointers except h_*.
+int run_device(const gnx_params *prm, int64_t n_pairs,
+               const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
+               const int64_t *h_alen, const int64_t *h_blen,
+               int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
+               int64_t *out_total, hipStream_t stream) {
+    Ctx &c = g_ctx;
+    KParams kp; TbParams tp; bool affine, local, lowmem;
+    int rc = check_params(prm, kp, tp, affine, local, lowmem);
+    if (rc) return rc;
+    if (n_pairs < 0 || n_pairs > 0x7ffffff0) { set_err("bad n_pairs%s", ""); return GNX_EINVAL; }
+    c.timing = gnx_timing{};
+    if (n_pairs == 0) {
+        int64_t z = 0;
+        HIPCHK(hipMemcpyAsync(d_ops_off, &z, 8, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (out_total) *out_total = 0;
+        return GNX_OK;
+    }
+    // ---- plan ----
+    const int64_t maxpen = max_abs_pen(prm, affine);
+    const int Q = affine ? QA : QC;
+    std::vector<PairPlan> plans((size_t)n_pairs);
+    std::vector<int64_t> chunk_begin;
+    int64_t cells = 0;
+    {
+        int64_t toff = 0, hoff = 0, roff = 0;
+        chunk_begin.push_back(0);
+        const int64_t trace_limit_u4 = std::max<int64_t>(c.ws_limit / 16, 1);
+        for (int64_t p = 0; p < n_pairs; p++) {
+            const int64_t n = h_alen[p], m = h_blen[p];
+            if (n < 0 || m < 0 || n > 0x3fffffff || m > 0x3fffffff) { set_err("bad sequence length at pair %s%lld", "", (long long)p); return GNX_EINVAL; }
+            if (lowmem && (n < 1 || m < 1)) { set_err("empty sequence at pair %s%lld: the reference never terminates on it", "", (long long)p); return GNX_EEMPTY; }
+            if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) { set_err("pair %s%lld exceeds the int32 DP range", "", (long long)p); return GNX_ERANGE; }
+            PairPlan &pl = plans[(size_t)p];
+            pl.n = (int32_t)n; pl.m = (int32_t)m;
+            pl.strips = (m > 0) ? (int32_t)((n + H - 1) / H) : 0;
+            pl.words = (int32_t)((m + 15 + 15) / 16);
+            const int64_t tsz = (int64_t)pl.strips * pl.words * Q * G;
+            if (tsz > trace_limit_u4) { set_err("pair %s%lld needs more direction-matrix workspace than the limit", "", (long long)p); return GNX_ENOMEM; }
+            if (toff + tsz > trace_limit_u4) { // start a new chunk (keep chunks 4-aligned so waves stay whole)
+                int64_t cb = p & ~(int64_t)3;
+                if (cb <= chunk_begin.back()) cb = p;
+                // re-plan the pairs moved into the new chunk
+                toff = 0; hoff = 0; roff = 0;
+                for (int64_t q2 = cb; q2 < p; q2++) {
+                    PairPlan &pq = plans[(size_t)q2];
+                    pq.trace_off = toff; pq.hcol_off = hoff; pq.rowbuf_off = roff;
+                    toff += (int64_t)pq.strips * pq.words * Q * G; hoff += pq.n; roff += (pq.strips > 1) ? pq.m + 1 : 0;
+                }
+                chunk_begin.push_back(cb);
+            }
+            pl.trace_off = toff; pl.hcol_off = hoff; pl.rowbuf_off = roff;
+            toff += tsz; hoff += n; roff += (pl.strips > 1) ? m + 1 : 0;
+            cells += n * m;
+        }
+        chunk_begin.push_back(n_pairs);
+    }
+    // workspace sizes = max over chunks
+    int64_t max_t = 1, max_h = 1, max_r = 1;
+    for (size_t ch = 0; ch + 1 < chunk_begin.size(); ch++) {
+        int64_t t = 0, h = 0, r = 0;
+        for (int64_t p = chunk_begin[ch]; p < chunk_begin[ch + 1]; p++) {
+            const PairPlan &pl = plans[(size_t)p];
+            t += (int64_t)pl.strips * pl.words * Q * G; h += pl.n; r += (pl.strips > 1) ? pl.m + 1 : 0;
+        }
+        max_t = std::max(max_t, t); max_h = std::max(max_h, h); max_r = std::max(max_r, r);
+    }
+    if ((rc = c.trace.ensure((size_t)max_t * 16))) return rc;
+    if ((rc = c.hcol.ensure((size_t)max_h * 4))) return rc;
+    if ((rc = c.rowbuf.ensure((size_t)max_r * 8))) return rc;
+    if ((rc = c.plans.ensure((size_t)n_pairs * sizeof(PairPlan)))) return rc;
+    if ((rc = c.nops.ensure((size_t)n_pairs * 8))) return rc;
+    if ((rc = c.misc.ensure(64))) return rc;
+    int *d_err = reinterpret_cast<int *>(c.misc.p);
+    int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
+    HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
+    HIPCHK(hipMemcpyAsync(c.plans.p, plans.data(), (size_t)n_pairs * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
+
+    // ---- launches ----
+    double fill_ms = 0, tb_ms = 0;
+    int64_t trace_bytes = 0;
+    HIPCHK(hipEventRecord(c.ev[0], stream));
+    const size_t nchunks = chunk_begin.size() - 1;
+    for (size_t ch = 0; ch < nchunks; ch++) {
+        const int64_t b = chunk_begin[ch], e = chunk_begin[ch + 1];
+        const int np = (int)(e - b);
+        if (np <= 0) continue;
+        const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p) + b;
+        uint4 *dtrace = reinterpret_cast<uint4 *>(c.trace.p);
+        int *dh = reinterpret_cast<int *>(c.hcol.p);
+        int2 *drb = reinterpret_cast<int2 *>(c.rowbuf.p);
+        int64_t *dn = reinterpret_cast<int64_t *>(c.nops.p) + b;
+        const dim3 gridF((unsigned)((np + 3) / 4)), blockF(64);
+        const dim3 gridT((unsigned)((np + 63) / 64)), blockT(64);
+        HIPCHK(hipEventRecord(c.ev[1], stream));
+        if (affine) {
+            if (local) hipLaunchKernelGGL(fill_affine_kernel<true>, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, d_err);
+            else hipLaunchKernelGGL(fill_affine_kernel<false>, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, d_err);
+        } else {
+            hipLaunchKernelGGL(fill_const_kernel, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, d_err);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c.ev[2], stream));
+        if (affine) hipLaunchKernelGGL((traceback_kernel<true, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
+        else hipLaunchKernelGGL((traceback_kernel<false, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, dn, np, d_ops_off + b, d_carry);
+        if (affine) hipLaunchKernelGGL((traceback_kernel<true, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
+        else hipLaunchKernelGGL((traceback_kernel<false, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c.ev[3], stream));
+        if (nchunks > 1 || true) {
+            HIPCHK(hipEventSynchronize(c.ev[3]));
+            float f1 = 0, f2 = 0;
+            HIPCHK(hipEventElapsedTime(&f1, c.ev[1], c.ev[2]));
+            HIPCHK(hipEventElapsedTime(&f2, c.ev[2], c.ev[3]));
+            fill_ms += f1; tb_ms += f2;
+        }
+        for (int64_t p = b; p < e; p++) trace_bytes += (int64_t)plans[(size_t)p].strips * plans[(size_t)p].words * Q * G * 16;
+    }
+    HIPCHK(hipEventRecord(c.ev[2], stream));
+    int h_misc[16];
+    HIPCHK(hipMemcpyAsync(h_misc, c.misc.p, 64, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    float tot = 0;
+    HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[2]));
+    c.timing.fill_ms = fill_ms; c.timing.traceback_ms = tb_ms; c.timing.total_ms = tot;
+    c.timing.cells = cells; c.timing.n_launches = (int64_t)nchunks; c.timing.trace_bytes = trace_bytes;
+    int64_t total;
+    memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
+    if (out_total) *out_total = total;
+    const int ef = h_misc[0];
+    if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
+    if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
+    if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
+    return GNX_OK;
+}
+
+int run_host_windows(const gnx_params *prm, int64_t n_pairs,
+                     const uint8_t *a_buf, int64_t a_len, const int64_t *a_start, const int64_t *a_lens,
+                     const uint8_t *b_buf, int64_t b_len, const int64_t *b_start, const int64_t *b_lens,
+                     int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
+    Ctx &c = g_ctx;
+    if (!prm || n_pairs < 0 || !out_score || !out_ops || !out_ops_off || a_len < 0 || b_len < 0) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    if (n_pairs > 0 && (!a_start || !a_lens || !b_start || !b_lens)) { set_err("null window table%s", ""); return GNX_EINVAL; }
+    for (int64_t p = 0; p < n_pairs; p++) {
+        if (a_start[p] < 0 || a_lens[p] < 0 || a_start[p] + a_lens[p] > a_len || b_start[p] < 0 || b_lens[p] < 0 || b_start[p] + b_lens[p] > b_len) {
+            set_err("window out of bounds at pair %s%lld", "", (long long)p); return GNX_EINVAL;
+        }
+    }
+    int rc;
+    hipStream_t st = c.own_stream;
+    const size_t np = (size_t)std::max<int64_t>(n_pairs, 1);
+    if ((rc = c.in_a.ensure((size_t)a_len + 16))) return rc;
+    if ((rc = c.in_b.ensure((size_t)b_len + 16))) return rc;
+    if ((rc = c.in_as.ensure(np * 8))) return rc;
+    if ((rc = c.in_bs.ensure(np * 8))) return rc;
+    if ((rc = c.out_score.ensure(np * 8))) return rc;
+    if ((rc = c.out_off.ensure((np + 1) * 8))) return rc;
+    if (a_len) HIPCHK(hipMemcpyAsync(c.in_a.p, a_buf, (size_t)a_len, hipMemcpyHostToDevice, st));
+    if (b_len) HIPCHK(hipMemcpyAsync(c.in_b.p, b_buf, (size_t)b_len, hipMemcpyHostToDevice, st));
+    if (n_pairs) {
+        HIPCHK(hipMemcpyAsync(c.in_as.p, a_start, (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c.in_bs.p, b_start, (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
+    }
+    // CIGAR capacity: exact worst case for small batches, a guess (+ one exact retry) for large ones
+    int64_t worst = 0;
+    for (int64_t p = 0; p < n_pairs; p++) worst += a_lens[p] + b_lens[p] + 1;
+    int64_t cap = std::min<int64_t>(worst, std::max<int64_t>((int64_t)1 << 20, 64 * n_pairs));
+    cap = std::max<int64_t>(cap, 1);
+    int64_t total = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = c.out_ops.ensure((size_t)cap * sizeof(gnx_cigar)))) return rc;
+        rc = run_device(prm, n_pairs, (const uint8_t *)c.in_a.p, (const int64_t *)c.in_as.p, (const uint8_t *)c.in_b.p, (const int64_t *)c.in_bs.p,
+                        a_lens, b_lens, (int64_t *)c.out_score.p, (gnx_cigar *)c.out_ops.p, cap, (int64_t *)c.out_off.p, &total, st);
+        if (rc != GNX_ECAPACITY) break;
+        cap = total;
+    }
+    if (rc) return rc;
+    gnx_cigar *ops = (gnx_cigar *)malloc((size_t)std::max<int64_t>(total, 1) * sizeof(gnx_cigar));
+    int64_t *off = (int64_t *)malloc((size_t)(n_pairs + 1) * 8);
+    if (!ops || !off) { free(ops); free(off); set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
+    if (n_pairs) HIPCHK(hipMemcpyAsync(out_score, c.out_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(off, c.out_off.p, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (total) HIPCHK(hipMemcpyAsync(ops, c.out_ops.p, (size_t)total * sizeof(gnx_cigar), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *out_ops = ops; *out_ops_off = off;
+    return GNX_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int gnx_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int gnx_init(int device, int64_t workspace_bytes) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    if (g_ctx.inited) {
+        if (device == g_ctx.device) { if (workspace_bytes > 0) g_ctx.ws_limit = workspace_bytes; return GNX_OK; }
+        set_err("already bound to another device%s", ""); return GNX_EINVAL;
+    }
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { set_err("no HIP device available (this library has no CPU fallback)%s", ""); return GNX_EDEVICE; }
+    if (device < 0 || device >= cnt) { set_err("device index out of range%s", ""); return GNX_EINVAL; }
+    HIPCHK(hipSetDevice(device));
+    g_ctx.device = device;
+    HIPCHK(hipStreamCreate(&g_ctx.own_stream));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&g_ctx.ev[i]));
+    if (workspace_bytes > 0) g_ctx.ws_limit = workspace_bytes;
+    else {
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        g_ctx.ws_limit = (int64_t)std::min<size_t>(fr / 2, (size_t)64 << 30);
+    }
+    g_ctx.inited = true;
+    return GNX_OK;
+}
+
+void gnx_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    if (!g_ctx.inited) return;
+    (void)hipSetDevice(g_ctx.device);
+    (void)hipDeviceSynchronize();
+    DevBuf *bufs[] = {&g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
+                      &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops};
+    for (DevBuf *b : bufs) b->release();
+    for (int i = 0; i < 4; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }
+    if (g_ctx.own_stream) { (void)hipStreamDestroy(g_ctx.own_stream); g_ctx.own_stream = nullptr; }
+    g_ctx.inited = false;
+    g_ctx.ws_limit = 0;
+}
+
+const char *gnx_last_error(void) { return g_err; }
+
+void gnx_free(void *p) { free(p); }
+
+int gnx_align_batch_windows(const gnx_params *p, int64_t n_pairs,
+                            const uint8_t *alpha_buf, int64_t alpha_buf_len, const int64_t *alpha_start, const int64_t *alpha_len,
+                            const uint8_t *beta_buf, int64_t beta_buf_len, const int64_t *beta_start, const int64_t *beta_len,
+                            int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    g_err[0] = 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(g_ctx.device));
+    return run_host_windows(p, n_pairs, alpha_buf, alpha_buf_len, alpha_start, alpha_len, beta_buf, beta_buf_len, beta_start, beta_len,
+                            out_score, out_ops, out_ops_off);
+}
+
+int gnx_align_batch(const gnx_params *p, int64_t n_pairs, const uint8_t *alpha_cat, const int64_t *alpha_off,
+                    const uint8_t *beta_cat, const int64_t *beta_off, int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
+    if (n_pairs < 0 || !alpha_off || !beta_off) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    std::vector<int64_t> al((size_t)n_pairs), bl((size_t)n_pairs);
+    for (int64_t q = 0; q < n_pairs; q++) { al[(size_t)q] = alpha_off[q + 1] - alpha_off[q]; bl[(size_t)q] = beta_off[q + 1] - beta_off[q]; }
+    return gnx_align_batch_windows(p, n_pairs, alpha_cat, alpha_off[n_pairs], alpha_off, al.data(), beta_cat, beta_off[n_pairs], beta_off, bl.data(),
+                                   out_score, out_ops, out_ops_off);
+}
+
+int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const uint8_t *beta, int64_t m,
+                   int64_t *out_score, gnx_cigar **out_ops, int64_t *out_n_ops) {
+    if (!out_n_ops) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    const int64_t zero = 0;
+    int64_t *off = nullptr;
+    int rc = gnx_align_batch_windows(p, 1, alpha, n, &zero, &n, beta, m, &zero, &m, out_score, out_ops, &off);
+    if (rc) return rc;
+    *out_n_ops = off[1];
+    free(off);
+    return GNX_OK;
+}
+
+int gnx_align_batch_device(const gnx_params *p, int64_t n_pairs,
+                           const uint8_t *d_alpha_buf, const int64_t *d_alpha_start, const int64_t *d_alpha_len,
+                           const uint8_t *d_beta_buf, const int64_t *d_beta_start, const int64_t *d_beta_len,
+                           const int64_t *h_alpha_len, const int64_t *h_beta_len,
+                           int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
+                           int64_t *out_total_ops, void *stream) {
+    (void)d_alpha_len; (void)d_beta_len; // lengths are taken from the host copies (planning needs them anyway)
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    g_err[0] = 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(g_ctx.device));
+    if (!p || n_pairs < 0 || !d_score || !d_ops_off || ops_capacity < 0 || (n_pairs > 0 && (!h_alpha_len || !h_beta_len || !d_alpha_start || !d_beta_start))) {
+        set_err("bad argument%s", ""); return GNX_EINVAL;
+    }
+    return run_device(p, n_pairs, d_alpha_buf, d_alpha_start, d_beta_buf, d_beta_start, h_alpha_len, h_beta_len,
+                      d_score, d_ops, ops_capacity, d_ops_off, out_total_ops, (hipStream_t)stream);
+}
+
+int gnx_get_timing(gnx_timing *out) {
+    if (!out) return GNX_EINVAL;
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    *out = g_ctx.timing;
+    return GNX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,138 @@
+/*
+ * gnx_align.h -- C ABI of libgonomics_align_hip.so: the MI355X (gfx950) drop-in for the pairwise DP hot
+ * path of gonomics' `align` package.
+ *
+ * The reference (vertgenlab/gonomics) is pure Go and has no FFI layer.  The boundary it offers for this
+ * path is the exported Go API of package align; each entry point below names the Go function(s) a cgo
+ * shim would route through it (see INTEGRATION.md for the shim):
+ *
+ *   align.AffineGap(alpha, beta []dna.Base, scores [][]int64, gapOpen, gapExtend int64) (int64, []Cigar)
+ *                                                              /root/reference/align/affineGap.go:59
+ *   align.AffineGap_customizeCheckersize(..., checkersize_i, checkersize_j int)        affineGap.go:73
+ *   align.ConstGap(alpha, beta, scores, gapPen) (int64, []Cigar)                        constGap.go:13
+ *   align.ConstGap_customizeCheckersize(..., checkersize_i, checkersize_j int)         constGap.go:73
+ *   align.AffineGap_highMem / align.AffineGapLocal(target, query, ...)      affineGap_highMem.go:99,105
+ *   align.ConstGap_highMem                                                      constGap_highMem.go:11
+ *   align.GoAffineGapLocalEngine (batched, FIFO)                              affineGap_highMem.go:120
+ *
+ * Conventions
+ *   - bases are dna.Base bytes (A=0 C=1 G=2 T=3 N=4; /root/reference/dna/dna.go:5-21); any byte >= 5
+ *     makes the Go code panic (index out of range on the 5x5 matrix) -> here: GNX_EBASE.
+ *   - `scores` is the [][]int64 matrix flattened row-major: scores[alphaBase*5 + betaBase].
+ *   - results are bit-exact with the reference: score (int64) and the run-length CIGAR in alignment
+ *     order, including the low-memory checkerboard traceback quirks for n or m > checkersize.
+ *   - gnx_cigar has the memory layout of Go's align.Cigar{RunLength int64; Op ColType(uint8)} on amd64.
+ *   - inputs are borrowed and never written; outputs returned through gnx_cigar** / int64_t** are
+ *     malloc'd by the library and released with gnx_free().
+ *   - all functions return GNX_OK (0) or a GNX_E* code; gnx_last_error() gives the text (thread local).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry returns GNX_EDEVICE.
+ */
+#ifndef GNX_ALIGN_H
+#define GNX_ALIGN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNX_OK 0
+#define GNX_EINVAL 1    /* bad argument (null pointer, negative size, unknown mode) */
+#define GNX_EBASE 2     /* a base >= 5: the Go code would panic */
+#define GNX_EEMPTY 3    /* empty sequence in a low-memory mode: the Go code would never terminate */
+#define GNX_ERANGE 4    /* lengths x penalties exceed the int32 DP range of the kernels */
+#define GNX_EDEVICE 5   /* no HIP device / HIP runtime error */
+#define GNX_ENOMEM 6    /* host or device allocation failed / workspace too small for one pair */
+#define GNX_ECAPACITY 7 /* caller-provided device CIGAR buffer too small (device entry point) */
+#define GNX_ETRACE 8    /* impossible traceback value: the Go code would log.Fatalf */
+
+/* align.ColType, /root/reference/align/align.go:12-18 */
+#define GNX_COL_M 0
+#define GNX_COL_I 1
+#define GNX_COL_D 2
+
+/* align.Cigar, /root/reference/align/align.go:21-24 */
+typedef struct gnx_cigar {
+    int64_t run_length;
+    uint8_t op;
+    uint8_t _pad[7];
+} gnx_cigar;
+
+typedef enum gnx_mode {
+    GNX_AFFINE_GAP = 0,         /* AffineGap / AffineGap_customizeCheckersize (low-memory checkerboard semantics) */
+    GNX_CONST_GAP = 1,          /* ConstGap / ConstGap_customizeCheckersize */
+    GNX_AFFINE_GAP_HIGHMEM = 2, /* AffineGap_highMem */
+    GNX_AFFINE_GAP_LOCAL = 3,   /* AffineGapLocal(target=alpha, query=beta), GoAffineGapLocalEngine */
+    GNX_CONST_GAP_HIGHMEM = 4   /* ConstGap_highMem */
+} gnx_mode;
+
+typedef struct gnx_params {
+    int32_t mode;          /* gnx_mode */
+    int32_t _reserved;
+    int64_t scores[25];    /* scores[a*5+b] */
+    int64_t gap_open;      /* affine: gapOpen; const: gapPen */
+    int64_t gap_extend;    /* affine: gapExtend; const: ignored */
+    int64_t checkersize_i; /* low-memory modes only; 10000 for AffineGap / ConstGap */
+    int64_t checkersize_j;
+} gnx_params;
+
+/* Per-call kernel timings of the most recent compute call on this thread (HIP events on the stream the
+ * kernels ran on).  cells = sum over pairs of n*m. */
+typedef struct gnx_timing {
+    double fill_ms;      /* DP fill kernel(s): the dominant kernel */
+    double traceback_ms; /* traceback count + scan + write kernels */
+    double total_ms;     /* first launch to last kernel end */
+    int64_t cells;
+    int64_t n_launches;  /* number of fill launches (sub-batches) */
+    int64_t trace_bytes; /* direction-matrix bytes written by the fill kernels */
+} gnx_timing;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------- */
+int gnx_device_count(void);
+/* Bind this process to HIP device `device` (one process per GPU).  workspace_bytes = upper bound for the
+ * library's device scratch (direction matrices etc.); 0 picks a default from free memory. */
+int gnx_init(int device, int64_t workspace_bytes);
+void gnx_shutdown(void);
+const char *gnx_last_error(void);
+void gnx_free(void *p);
+
+/* ---- host-buffer entry points (what the cgo shim binds) ------------------------------------------ */
+/* Batch of independent pairs.  Pair p is alpha_cat[alpha_off[p] .. alpha_off[p+1]) vs
+ * beta_cat[beta_off[p] .. beta_off[p+1]).  Outputs: out_score[n_pairs]; *out_ops = concatenated CIGARs,
+ * (*out_ops_off)[n_pairs+1] their boundaries.  Replaces a serial loop of align.AffineGap* / ConstGap*
+ * calls (cmd/globalAlignmentAnchor/globalAlignmentAnchor.go:352-384) and the FIFO engine
+ * (affineGap_highMem.go:120-179): results are in input order. */
+int gnx_align_batch(const gnx_params *p, int64_t n_pairs,
+                    const uint8_t *alpha_cat, const int64_t *alpha_off,
+                    const uint8_t *beta_cat, const int64_t *beta_off,
+                    int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off);
+
+/* Same, but each sequence is a window (start,len) into a shared buffer, so many pairs may reference one
+ * resident chunk / genome (faChunkAlign-style read-vs-chunk batches). */
+int gnx_align_batch_windows(const gnx_params *p, int64_t n_pairs,
+                            const uint8_t *alpha_buf, int64_t alpha_buf_len, const int64_t *alpha_start, const int64_t *alpha_len,
+                            const uint8_t *beta_buf, int64_t beta_buf_len, const int64_t *beta_start, const int64_t *beta_len,
+                            int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off);
+
+/* One pair == batch of 1: the body of the Go-signature functions. */
+int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const uint8_t *beta, int64_t m,
+                   int64_t *out_score, gnx_cigar **out_ops, int64_t *out_n_ops);
+
+/* ---- device-resident entry point (bench.py, multi-GPU shards) ------------------------------------ */
+/* All d_* pointers are device memory on the bound device; h_* are host copies of the window tables used
+ * for planning.  Kernels are enqueued on `stream` (a hipStream_t, may be NULL) and the call returns
+ * after they finished.  d_ops has room for ops_capacity elements; *out_total_ops receives the number
+ * used (GNX_ECAPACITY if it did not fit). */
+int gnx_align_batch_device(const gnx_params *p, int64_t n_pairs,
+                           const uint8_t *d_alpha_buf, const int64_t *d_alpha_start, const int64_t *d_alpha_len,
+                           const uint8_t *d_beta_buf, const int64_t *d_beta_start, const int64_t *d_beta_len,
+                           const int64_t *h_alpha_len, const int64_t *h_beta_len,
+                           int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
+                           int64_t *out_total_ops, void *stream);
+
+int gnx_get_timing(gnx_timing *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNX_ALIGN_H */

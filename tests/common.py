@@ -1,0 +1,174 @@
+"""Shared helpers for the parity tests: seeded synthetic inputs and golden loaders."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+DATA = os.path.join(GOLDEN, "data")
+
+MATRICES = None
+
+
+def matrices():
+    from gonomics_amd import align
+    return {"Default": align.DefaultScoreMatrix, "HoxD55": align.HoxD55ScoreMatrix,
+            "MouseRat": align.MouseRatScoreMatrix, "HumanChimpTwo": align.HumanChimpTwoScoreMatrix}
+
+
+def tables():
+    with open(os.path.join(GOLDEN, "align_tables.json")) as fh:
+        return json.load(fh)
+
+
+def mutate(rng, seq, sub=0.05, indel=0.01, geo=0.3, alphabet=4):
+    """seq with substitutions and geometric-length indels (deterministic given rng)."""
+    out = []
+    i = 0
+    n = len(seq)
+    while i < n:
+        r = rng.random()
+        if r < indel / 2:  # deletion
+            i += int(rng.geometric(geo))
+            continue
+        if r < indel:  # insertion
+            k = int(rng.geometric(geo))
+            out.extend(rng.integers(0, alphabet, size=k).tolist())
+        b = int(seq[i])
+        if rng.random() < sub:
+            b = int(rng.integers(0, alphabet))
+        out.append(b)
+        i += 1
+    if not out:
+        out = [int(rng.integers(0, alphabet))]
+    return np.asarray(out, dtype=np.uint8)
+
+
+def random_pairs(seed, count, nmin, nmax, mmin, mmax, related=0.7, with_n=True):
+    rng = np.random.default_rng(seed)
+    alphas, betas = [], []
+    alphabet = 5 if with_n else 4
+    for _ in range(count):
+        n = int(rng.integers(nmin, nmax + 1))
+        m = int(rng.integers(mmin, mmax + 1))
+        a = rng.integers(0, alphabet, size=n).astype(np.uint8)
+        if rng.random() < related:
+            b = mutate(rng, a, sub=0.08, indel=0.06, geo=0.4, alphabet=alphabet)
+            if len(b) > mmax:
+                b = b[:mmax]
+            if len(b) < mmin:
+                b = np.concatenate([b, rng.integers(0, alphabet, size=mmin - len(b)).astype(np.uint8)])
+        else:
+            b = rng.integers(0, alphabet, size=m).astype(np.uint8)
+        alphas.append(a)
+        betas.append(b)
+    return alphas, betas
+
+
+def c2_workload(seed, n_pairs, read_len=150, chunk_len=10000):
+    """Config C2: one chunk (0.1 % N), reads sampled at uniform offsets, 1 % subs, 0.2 % indel opens."""
+    rng = np.random.default_rng(seed)
+    chunk = rng.integers(0, 4, size=chunk_len).astype(np.uint8)
+    chunk[rng.random(chunk_len) < 0.001] = 4
+    reads = np.zeros((n_pairs, read_len), dtype=np.uint8)
+    for k in range(n_pairs):
+        off = int(rng.integers(0, chunk_len - read_len - 40))
+        r = mutate(rng, chunk[off:off + read_len + 40], sub=0.01, indel=0.002, geo=0.5, alphabet=4)
+        if len(r) < read_len:
+            r = np.concatenate([r, rng.integers(0, 4, size=read_len - len(r)).astype(np.uint8)])
+        reads[k] = r[:read_len]
+    return reads, chunk
+
+
+def assert_same(res_a, res_b, what=""):
+    sa, oa, fa = res_a
+    sb, ob, fb = res_b
+    assert np.array_equal(sa, sb), "scores differ " + what
+    assert np.array_equal(fa, fb), "cigar offsets differ " + what
+    assert np.array_equal(oa["run_length"], ob["run_length"]), "cigar run lengths differ " + what
+    assert np.array_equal(oa["op"], ob["op"]), "cigar ops differ " + what
+
+
+# ---- callers' serialisation, used to pin results against the reference's golden FILES ----------------
+def read_bed4(path):
+    rows = []
+    with open(path) as fh:
+        for line in fh:
+            f = line.rstrip("\n").split("\t")
+            if len(f) >= 3:
+                rows.append((f[0], int(f[1]), int(f[2])))
+    return rows
+
+
+def cigar_to_beds(aln, first_ins, first_del, chrom):
+    """The BED derivation of cmd/cigarToBed/cigarToBed.go:89-129 (test-side restatement; aln = [(run, op)])."""
+    ins, dele = [], []
+    cur = first_ins - 1
+    for k in range(len(aln) - 1):
+        if aln[k][1] == 0 and aln[k + 1][1] == 1:
+            st = cur + aln[k][0] + 1
+            ins.append("%s\t%d\t%d\tins\n" % (chrom, st, st + aln[k + 1][0]))
+        if aln[k][1] != 2:
+            cur += aln[k][0]
+    cur = first_del - 1
+    for k in range(len(aln) - 1):
+        if aln[k][1] == 0 and aln[k + 1][1] == 1:
+            st = cur + aln[k][0]
+            dele.append("%s\t%d\t%d\tdel\n" % (chrom, st, st + 1))
+        if aln[k][1] != 1:
+            cur += aln[k][0]
+    return "".join(ins), "".join(dele)
+
+
+def anchor_cases(idx):
+    """(alpha, beta, expected_score, expected_cigar_%v) for out_alignment.<idx>.expected.tsv
+    (cmd/globalAlignmentAnchor: regions are BED [start-1, end-1) slices, upper-cased; globalAlignmentAnchor.go:378-381)."""
+    from gonomics_amd import dna, fasta
+    d = os.path.join(DATA, "globalAlignmentAnchor")
+    g1 = fasta.ToMap(fasta.Read(os.path.join(d, "hg38.toy.fa")))
+    g2 = fasta.ToMap(fasta.Read(os.path.join(d, "rheMac10.toy.fa")))
+    b1 = read_bed4(os.path.join(d, "out_hg38_gap.%d.expected.bed" % idx))
+    b2 = read_bed4(os.path.join(d, "out_rheMac10_gap.%d.expected.bed" % idx))
+    cases = []
+    with open(os.path.join(d, "out_alignment.%d.expected.tsv" % idx)) as fh:
+        lines = [ln.rstrip("\n").split("\t") for ln in fh if ln.strip()]
+    assert len(lines) == len(b1) == len(b2)
+    for ln, r1, r2 in zip(lines, b1, b2):
+        assert (ln[0], int(ln[1]), int(ln[2])) == r1 and (ln[4], int(ln[5]), int(ln[6])) == r2
+        a = dna.AllToUpper(g1[r1[0]][r1[1] - 1:r1[2] - 1].copy())
+        b = dna.AllToUpper(g2[r2[0]][r2[1] - 1:r2[2] - 1].copy())
+        cases.append((a, b, int(ln[8]), ln[9]))
+    return cases
+
+
+def fmt_v(route):
+    return "[" + " ".join("{%d %d}" % (r, o) for r, o in route) + "]"
+
+
+def view(alpha, beta, route):
+    """align.View on (run, op) tuples (align/view.go:37-60)."""
+    from gonomics_amd import dna
+    a, b = dna.BasesToString(alpha), dna.BasesToString(beta)
+    one, two = [], []
+    i = j = 0
+    for n, op in route:
+        if op == 0:
+            one.append(a[i:i + n]); two.append(b[j:j + n]); i += n; j += n
+        elif op == 1:
+            one.append("-" * n); two.append(b[j:j + n]); j += n
+        else:
+            one.append(a[i:i + n]); two.append("-" * n); i += n
+    return "".join(one) + "\n" + "".join(two) + "\n"
+
+
+# Appendix B of SURVEY.md: derived (NOT reference-stated) known answers for the checkerboard quirks
+QUIRK_CASES = [
+    ("affine", "Default", -400, -30, 4, "CTCCGTTGCTGCG", "CTCCGTGCGCG", 277, "7M2D4M", "5M1D2M1D4M"),
+    ("affine", "Default", -400, -30, 2, "AGGCTTGGCCACG", "AGGCTGTCACG", 482, "5M2D6M", "4M1D1M1D6M"),
+    ("affine", "Default", -400, -30, 2, "GTTCC", "TTC", -300, "2D3M", "3M"),
+    ("affine", "Default", -400, -30, 2, "AGAACAAGGGGG", "GACAAAGGGG", 251, "2D10M", "10M"),
+    ("affine", "HumanChimpTwo", -600, -150, 2, "ATC", "TAGAGGAGA", -2070, "6I3M", "3M"),
+    ("const", "Default", -430, 0, 2, "GGCC", "CC", -660, "2D2M", "2M"),
+    ("const", "Default", -430, 0, 2, "CTTCAGTAGTCA", "TCAGAGTTCA", -464, "2D10M", "10M"),
+]
