@@ -623,6 +623,11 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         for (int64_t p = 0; p < n_pairs; p++) {
             const int64_t n = h_alen[p], m = h_blen[p];
             if (n < 0 || m < 0 || n > 0x3fffffff || m > 0x3fffffff) { set_err("bad sequence length at pair %s%lld", "", (long long)p); return GNX_EINVAL; }
+            if (lowmem && prm->checkersize_i != prm->checkersize_j && n > prm->checkersize_i) {
+                // the reference indexes its saved columns with checkersize_j where checkersize_i is meant
+                // (affineGap.go:252-254, constGap.go:207): undefined for non-square tiles once n > checkersize_i
+                set_err("non-square checkerboards with n > checkersize_i are undefined in the reference (pair %s%lld)", "", (long long)p); return GNX_EINVAL;
+            }
             if (lowmem && (n < 1 || m < 1)) { set_err("empty sequence at pair %s%lld: the reference never terminates on it", "", (long long)p); return GNX_EEMPTY; }
             if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) { set_err("pair %s%lld exceeds the int32 DP range", "", (long long)p); return GNX_ERANGE; }
             PairPlan &pl = plans[(size_t)p];

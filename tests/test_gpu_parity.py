@@ -1,0 +1,230 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the reference's golden vectors and
+against the CPU oracle on seeded inputs.  Bit-exact: scores and CIGARs (integer work, no tolerance)."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+import oracle
+from gonomics_amd import align, dna, fasta
+
+pytestmark = pytest.mark.gpu
+
+T = common.tables()
+MX = common.matrices()
+
+
+def _route(r):
+    return [(c.RunLength, c.Op) for c in r]
+
+
+# ---- the reference's own tests, re-stated against the drop-in API -------------------------------------
+def test_affine_gap_highmem_view(gpu_lib):  # align/affineGap_test.go:45-55
+    t = T["affineAlignTests"]
+    for c in t["cases"]:
+        a, b = dna.StringToBases(c["seqOne"]), dna.StringToBases(c["seqTwo"])
+        _, cigar = align.AffineGap_highMem(a, b, align.DefaultScoreMatrix, -400, -30)
+        assert align.View(a, b, cigar) == c["aln"]
+
+
+def test_affine_gap_lowmem(gpu_lib):  # align/affineGap_test.go:57-81
+    t = T["affineAlignTests"]
+    for c in t["cases"]:
+        a, b = dna.StringToBases(c["seqOne"]), dna.StringToBases(c["seqTwo"])
+        hs, hr = align.AffineGap_highMem(a, b, align.DefaultScoreMatrix, -400, -30)
+        ls, lr = align.AffineGap(a, b, align.DefaultScoreMatrix, -400, -30)
+        cs, cr = align.AffineGap_customizeCheckersize(a, b, align.DefaultScoreMatrix, -400, -30, 3, 3)
+        assert ls == hs and cs == hs
+        assert lr == hr
+        assert all(cr[k] == hr[k] for k in range(len(cr)))
+        # and exactly what the reference algorithm gives at checkersize 3
+        assert (cs, _route(cr)) == oracle.align_one(oracle.MODE_AFFINE, MX["Default"], -400, -30, a, b, 3, 3)
+
+
+def test_affine_gap_local(gpu_lib):  # align/affineGap_test.go:120-155
+    for c in T["affineLocalTests"]["cases"]:
+        tgt, qry = dna.StringToBases(c["target"]), dna.StringToBases(c["query"])
+        score, cig = align.AffineGapLocal(tgt, qry, align.DefaultScoreMatrix, c["gapOpen"], c["gapExtend"])
+        assert score == c["score"] and align.PrintCigar(cig) == c["cigar"]
+
+
+def test_go_affine_gap_local_engine(gpu_lib):  # align/affineGap_test.go:157-192
+    cases = T["affineLocalEngineTests"]["cases"]
+    inputs, outputs = align.GoAffineGapLocalEngine(align.DefaultScoreMatrix, -600, -150)
+    for c in cases:
+        test = align.TargetQueryPair(Target=dna.StringToBases(c["target"]), Query=dna.StringToBases(c["query"]))
+        inputs.send(test)
+        test = outputs.recv()
+        assert test.Score == c["score"] and align.PrintCigar(test.Cigar) == c["cigar"]
+    # FIFO order when several are in flight
+    for c in cases:
+        inputs.send(align.TargetQueryPair(Target=dna.StringToBases(c["target"]), Query=dna.StringToBases(c["query"])))
+    inputs.close()
+    got = [(r.Score, align.PrintCigar(r.Cigar)) for r in outputs]
+    assert got == [(c["score"], c["cigar"]) for c in cases]
+
+
+def test_const_gap_view(gpu_lib):  # align/view_test.go:28-38
+    t = T["constAlignTests"]
+    for c in t["cases"]:
+        a, b = dna.StringToBases(c["seqOne"]), dna.StringToBases(c["seqTwo"])
+        _, cigar = align.ConstGap(a, b, align.DefaultScoreMatrix, -430)
+        assert align.View(a, b, cigar) == c["aln"]
+        _, hc = align.ConstGap_highMem(a, b, align.DefaultScoreMatrix, -430)
+        assert hc == cigar
+
+
+def test_global_alignment_cmd(gpu_lib):  # cmd/globalAlignment/globalAlignment_test.go:13-40 + faOut fixture
+    t = T["globalAlignmentGraph"]
+    a, b = dna.StringToBases(t["toad"]), dna.StringToBases(t["ahsoka"])
+    _, aln = align.ConstGap(a, b, align.HumanChimpTwoScoreMatrix, -430)
+    assert len(aln) == 3 and align.PrintCigar(aln) == "3M3D3M"
+    d = os.path.join(common.DATA, "globalAlignment")
+    fa1, fa2 = fasta.Read(os.path.join(d, "chelsea.fa"))[0], fasta.Read(os.path.join(d, "eric.fa"))[0]
+    _, aln = align.ConstGap(fa1.Seq, fa2.Seq, align.HumanChimpTwoScoreMatrix, -430)
+    v = align.View(fa1.Seq, fa2.Seq, aln).split("\n")
+    assert ">" + fa1.Name + "\n" + v[0] + "\n>" + fa2.Name + "\n" + v[1] + "\n" == open(os.path.join(d, "faOut_test.fa")).read()
+
+
+@pytest.mark.parametrize("idx", [1, 2])
+def test_global_alignment_anchor_tsv(gpu_lib, idx):  # cmd/globalAlignmentAnchor test: score + %v cigar
+    cases = common.anchor_cases(idx)
+    params = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, align.HumanChimpTwoScoreMatrix, -600, -150, 10000, 10000)
+    res = align.AlignBatch(params, [c[0] for c in cases], [c[1] for c in cases])  # the cmd's loop, batched
+    for (a, b, score, cig), (s, route) in zip(cases, res):
+        assert s == score and align.FormatCigar(route) == cig
+        s1, r1 = align.AffineGap_customizeCheckersize(a, b, align.HumanChimpTwoScoreMatrix, -600, -150, 10000, 10000)
+        assert (s1, r1) == (s, route)
+
+
+def test_cigar_to_bed(gpu_lib):  # cmd/cigarToBed/cigarToBed_test.go: 9x15 and 9673x10000
+    d = os.path.join(common.DATA, "cigarToBed")
+    for sub, f1, f2, fi, fd, ins, dele, exp in [
+        ("sethvsraven", "seth.fa", "raven.fa", 1, 1, "affineGap_sethvsraven_ins.bed", "affineGap_sethvsraven_del.bed", (-1070, 3)),
+        ("firstTest", "testRegion10kb_PanTro6.fa", "testRegion10kb_hg38.fa", 119320000, 116703287,
+         "affineGap_PanTro6vshg38_ins.bed", "affineGap_PanTro6vshg38_del.bed", (790738, 19)),
+    ]:
+        a = dna.AllToUpper(fasta.Read(os.path.join(d, sub, f1))[0].Seq)
+        b = dna.AllToUpper(fasta.Read(os.path.join(d, sub, f2))[0].Seq)
+        s, aln = align.AffineGap(a, b, align.HumanChimpTwoScoreMatrix, -600, -150)
+        gi, gd = common.cigar_to_beds(_route(aln), fi, fd, "chr1")
+        assert gi == open(os.path.join(d, sub, ins)).read()
+        assert gd == open(os.path.join(d, sub, dele)).read()
+        assert (s, len(aln)) == exp
+        assert (s, _route(aln)) == oracle.align_one(oracle.MODE_AFFINE, MX["HumanChimpTwo"], -600, -150, a, b)
+
+
+def test_appendix_b_quirks(gpu_lib):
+    for kind, mx, go, ge, cs, sa, sb, score, high, low in common.QUIRK_CASES:
+        a, b = dna.StringToBases(sa), dna.StringToBases(sb)
+        if kind == "affine":
+            hs, hr = align.AffineGap_highMem(a, b, MX[mx], go, ge)
+            ls, lr = align.AffineGap_customizeCheckersize(a, b, MX[mx], go, ge, cs, cs)
+        else:
+            hs, hr = align.ConstGap_highMem(a, b, MX[mx], go)
+            ls, lr = align.ConstGap_customizeCheckersize(a, b, MX[mx], go, cs, cs)
+        assert (hs, align.PrintCigar(hr)) == (score, high)
+        assert (ls, align.PrintCigar(lr)) == (score, low)
+
+
+# ---- seeded fuzz against the oracle -----------------------------------------------------------------
+def _gpu_batch(gpu_lib, mode, mx, go, ge, alphas, betas, ci=10000, cj=10000):
+    return gpu_lib.align_batch(gpu_lib.make_params(mode, mx, go, ge, ci, cj), alphas, betas)
+
+
+MODES = [(0, "affine"), (1, "const"), (2, "affine_highmem"), (3, "affine_local"), (4, "const_highmem")]
+
+
+@pytest.mark.parametrize("mode,name", MODES)
+def test_fuzz_small(gpu_lib, mode, name):
+    lo = 0 if mode >= 2 else 1
+    alphas, betas = common.random_pairs(1000 + mode, 3000, lo, 48, lo, 48)
+    for mx, go, ge in (("Default", -400, -30), ("HumanChimpTwo", -600, -150), ("HoxD55", -400, -30)):
+        got = _gpu_batch(gpu_lib, mode, MX[mx], go, ge, alphas, betas)
+        exp = oracle.align_batch(mode, MX[mx], go, ge, alphas, betas, threads=8)
+        common.assert_same(got, exp, "%s %s" % (name, mx))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("cs", [2, 3, 5, 7, 16])
+def test_fuzz_multitile_quirks(gpu_lib, mode, cs):
+    alphas, betas = common.random_pairs(2000 + cs, 2000, 1, 60, 1, 60)
+    got = _gpu_batch(gpu_lib, mode, MX["Default"], -400, -30, alphas, betas, cs, cs)
+    exp = oracle.align_batch(mode, MX["Default"], -400, -30, alphas, betas, cs, cs, threads=8)
+    common.assert_same(got, exp)
+    high = oracle.align_batch(mode + (2 if mode == 0 else 3), MX["Default"], -400, -30, alphas, betas, threads=8)
+    assert not np.array_equal(got[2], high[2]) or not np.array_equal(got[1]["run_length"], high[1]["run_length"])
+
+
+@pytest.mark.parametrize("mode,name", MODES)
+def test_fuzz_multistrip(gpu_lib, mode, name):
+    """alpha longer than one 160-row strip (row buffer hand-over between strips), ragged batch."""
+    lo = 0 if mode >= 2 else 1
+    alphas, betas = common.random_pairs(3000 + mode, 96, lo, 700, lo, 500, related=0.8)
+    got = _gpu_batch(gpu_lib, mode, MX["HumanChimpTwo"], -600, -150, alphas, betas)
+    exp = oracle.align_batch(mode, MX["HumanChimpTwo"], -600, -150, alphas, betas, threads=8)
+    common.assert_same(got, exp, name)
+    if mode < 2:
+        got = _gpu_batch(gpu_lib, mode, MX["HumanChimpTwo"], -600, -150, alphas, betas, 100, 100)
+        exp = oracle.align_batch(mode, MX["HumanChimpTwo"], -600, -150, alphas, betas, 100, 100, threads=8)
+        common.assert_same(got, exp, name + " checkersize 100")
+
+
+def test_c1_1kb_pair(gpu_lib):  # config C1: two ~1 kb records, ConstGap + AffineGap
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 4, size=1000).astype(np.uint8)
+    b = common.mutate(rng, a, sub=0.05, indel=0.01, geo=0.3)
+    s, r = align.ConstGap(a, b, align.HumanChimpTwoScoreMatrix, -430)
+    assert (s, _route(r)) == oracle.align_one(oracle.MODE_CONST, MX["HumanChimpTwo"], -430, 0, a, b)
+    s, r = align.AffineGap(a, b, align.HumanChimpTwoScoreMatrix, -600, -150)
+    assert (s, _route(r)) == oracle.align_one(oracle.MODE_AFFINE, MX["HumanChimpTwo"], -600, -150, a, b)
+
+
+def test_c2_reads_vs_chunk(gpu_lib):  # config C2 at a size the oracle finishes in seconds
+    reads, chunk = common.c2_workload(2, 512)
+    n = reads.shape[0]
+    a_start = np.arange(n, dtype=np.int64) * 150
+    a_len = np.full(n, 150, dtype=np.int64)
+    b_start = np.zeros(n, dtype=np.int64)
+    b_len = np.full(n, chunk.shape[0], dtype=np.int64)
+    for mode in (gpu_lib.GNX_AFFINE_GAP, gpu_lib.GNX_CONST_GAP):
+        p = gpu_lib.make_params(mode, align.HumanChimpTwoScoreMatrix, -600 if mode == 0 else -430, -150)
+        got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len)
+        exp = oracle.align_batch_windows(mode, MX["HumanChimpTwo"], -600 if mode == 0 else -430, -150,
+                                         reads.reshape(-1), a_start, a_len, chunk, b_start, b_len, threads=8)
+        common.assert_same(got, exp)
+    # second series: AffineGapLocal(target=chunk, query=read)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_LOCAL, align.HumanChimpTwoScoreMatrix, -600, -150)
+    got = gpu_lib.align_batch_windows(p, chunk, b_start[:64], b_len[:64], reads.reshape(-1), a_start[:64], a_len[:64])
+    exp = oracle.align_batch_windows(oracle.MODE_AFFINE_LOCAL, MX["HumanChimpTwo"], -600, -150,
+                                     chunk, b_start[:64], b_len[:64], reads.reshape(-1), a_start[:64], a_len[:64], threads=8)
+    common.assert_same(got, exp)
+
+
+def test_errors(gpu_lib):
+    a, b = dna.StringToBases("ACGT"), dna.StringToBases("ACGT")
+    with pytest.raises(IndexError):  # lower-case bases index past the 5x5 matrix in Go
+        align.ConstGap(dna.StringToBases("ACgT"), b, align.DefaultScoreMatrix, -430)
+    with pytest.raises(IndexError):
+        align.AffineGap(a, dna.StringToBases("AC-T"), align.DefaultScoreMatrix, -400, -30)
+    with pytest.raises(ValueError):  # the Go loop never terminates on an empty sequence
+        align.AffineGap(np.zeros(0, np.uint8), b, align.DefaultScoreMatrix, -400, -30)
+    with pytest.raises(gpu_lib.GnxError):
+        align.AffineGap(a, b, [[2 ** 40] * 5] * 5, -400, -30)
+    # and the library still works afterwards
+    s, r = align.AffineGap(a, b, align.DefaultScoreMatrix, -400, -30)
+    assert align.PrintCigar(r) == "4M"
+
+
+def test_workspace_chunking(gpu_lib):
+    """A small workspace limit forces several fill launches; results must not change."""
+    alphas, betas = common.random_pairs(77, 600, 20, 200, 20, 300)
+    exp = oracle.align_batch(0, MX["Default"], -400, -30, alphas, betas, threads=8)
+    gpu_lib.check(gpu_lib.lib().gnx_init(0, 4 << 20))
+    try:
+        got = _gpu_batch(gpu_lib, 0, MX["Default"], -400, -30, alphas, betas)
+        assert gpu_lib.get_timing()["n_launches"] > 1
+    finally:
+        gpu_lib.check(gpu_lib.lib().gnx_init(0, 8 << 30))
+    common.assert_same(got, exp)
