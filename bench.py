@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on MI355X: DP cells/s (+ aligned pairs/s) of the
+affine-gap 150 bp x 10 kb batch (config C2: faChunkAlign-style reads vs one 10 kb chunk,
+align.AffineGap(read, chunk, HumanChimpTwoScoreMatrix, -600, -150)).
+
+A "step" = one pass of the hot path (fill kernel + traceback kernels, CIGARs emitted) over one batch of
+`--pairs` synthetic pairs whose inputs are already resident in HBM.  One process per GPU; for N > 1 the
+driver launches this file under torch.distributed.run: the 10 kb chunk is broadcast from rank 0 over
+RCCL/xGMI once, every rank aligns its own shard of reads (weak scaling, no data-path collective), the
+timed region is bracketed by barrier + synchronize and the max over ranks is reported.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      algorithmic bytes (n + m + ceil(6nm/8) + ceil(6(n+m)/8) + 8 + 16|cigar| per pair)
+                / average fill-kernel duration (HIP events on the launch stream, inside the library)
+  cpu_baseline  the CPU oracle ("port" of the reference algorithm; the Go reference cannot be built here)
+                on all host cores, bounded sample of the same workload
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+READ_LEN = 150
+CHUNK_LEN = 10000
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_workload(seed, n_pairs, chunk=None):
+    """C2 generator, vectorised: reads sampled at uniform offsets of one chunk (0.1 % N), 1 % substitutions,
+    ~0.2 %/base indel opens (one geometric(0.5)-length indel in ~26 % of the reads)."""
+    rng = np.random.default_rng(seed)
+    if chunk is None:
+        chunk = rng.integers(0, 4, size=CHUNK_LEN).astype(np.uint8)
+        chunk[rng.random(CHUNK_LEN) < 0.001] = 4
+    off = rng.integers(0, CHUNK_LEN - READ_LEN - 64, size=n_pairs)
+    x = np.arange(READ_LEN)[None, :]
+    has_indel = rng.random(n_pairs) < 0.26
+    pos = rng.integers(10, READ_LEN - 10, size=n_pairs)
+    ln = np.minimum(rng.geometric(0.5, size=n_pairs), 32)
+    is_del = rng.random(n_pairs) < 0.5
+    shift = np.where(has_indel[:, None] & (x >= pos[:, None]), np.where(is_del, ln, -ln)[:, None], 0)
+    src = off[:, None] + x + shift
+    reads = chunk[np.clip(src, 0, CHUNK_LEN - 1)]
+    ins_mask = has_indel[:, None] & (~is_del)[:, None] & (x >= pos[:, None]) & (x < (pos + ln)[:, None])
+    reads = np.where(ins_mask, rng.integers(0, 4, size=reads.shape), reads)
+    sub = rng.random(reads.shape) < 0.01
+    reads = np.where(sub, rng.integers(0, 4, size=reads.shape), reads).astype(np.uint8)
+    return np.ascontiguousarray(reads), chunk
+
+
+def algorithmic_bytes(n, m, pairs, total_ops):
+    per_pair = n + m + (n * m * 6 + 7) // 8 + ((n + m) * 6 + 7) // 8 + 8
+    return per_pair * pairs + 16 * total_ops
+
+
+def cpu_baseline(reads, chunk, scores, budget_s=15.0):
+    import oracle
+    cores = os.cpu_count() or 1
+    n = READ_LEN
+
+    def run(k, threads):
+        a_start = np.arange(k, dtype=np.int64) * n
+        a_len = np.full(k, n, dtype=np.int64)
+        b_start = np.zeros(k, dtype=np.int64)
+        b_len = np.full(k, chunk.shape[0], dtype=np.int64)
+        t0 = time.perf_counter()
+        oracle.align_batch_windows(oracle.MODE_AFFINE, scores, -600, -150, reads[:k].reshape(-1), a_start, a_len,
+                                   chunk, b_start, b_len, threads=threads)
+        return time.perf_counter() - t0
+
+    run(min(2 * cores, reads.shape[0]), cores)  # warm the allocator arenas / page tables
+    kp = min(4 * cores, reads.shape[0])
+    per_pair = max(run(kp, cores) / kp, 1e-5)  # wall seconds per pair with all cores busy
+    k = int(max(kp, min(reads.shape[0], budget_s / per_pair)))
+    dt = run(k, cores)
+    cells = k * n * chunk.shape[0]
+    return {"value": cells / dt, "unit": "DP cells/s", "cores": cores, "kind": "port",
+            "pairs_per_s": k / dt,
+            "sample": "%d pairs (150x10000, C2 generator) through oracle/gnx_oracle.c or_align_batch, %d threads, %.1f s"
+                      % (k, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=100000, help="pairs per GPU per step (config C2: 100 k)")
+    ap.add_argument("--ws-gb", type=float, default=150.0, help="direction-matrix workspace limit per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--verify", type=int, default=32, help="pairs checked bit-exactly against the oracle after timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gonomics_amd import _lib, align
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    L = _lib.lib()
+    _lib.check(L.gnx_init(local_rank, int(args.ws_gb * (1 << 30))))
+
+    n_pairs = args.pairs
+    # rank 0 owns the chunk; everyone gets it by broadcast (RCCL over xGMI when world > 1)
+    if rank == 0:
+        reads0, chunk_h = make_workload(2, n_pairs)
+    else:
+        chunk_h = np.zeros(CHUNK_LEN, dtype=np.uint8)
+    d_chunk = torch.from_numpy(chunk_h).to(dev)
+    if world > 1:
+        dist.broadcast(d_chunk, src=0)
+        chunk_h = d_chunk.cpu().numpy()
+    reads_h = reads0 if rank == 0 else make_workload(2 + 1000 * rank, n_pairs, chunk_h)[0]
+    d_reads = torch.from_numpy(reads_h.reshape(-1)).to(dev)
+    h_alen = np.full(n_pairs, READ_LEN, dtype=np.int64)
+    h_blen = np.full(n_pairs, CHUNK_LEN, dtype=np.int64)
+    d_as = torch.arange(n_pairs, dtype=torch.int64, device=dev) * READ_LEN
+    d_al = torch.from_numpy(h_alen).to(dev)
+    d_bs = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
+    d_bl = torch.from_numpy(h_blen).to(dev)
+    d_score = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
+    d_off = torch.zeros(n_pairs + 1, dtype=torch.int64, device=dev)
+    cap = 48 * n_pairs
+    d_ops = torch.zeros(cap * 16, dtype=torch.uint8, device=dev)
+    params = _lib.make_params(_lib.GNX_AFFINE_GAP, align.HumanChimpTwoScoreMatrix, -600, -150, 10000, 10000)
+    total_ops = ctypes.c_int64()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        _lib.check(L.gnx_align_batch_device(ctypes.byref(params), n_pairs, d_reads.data_ptr(), d_as.data_ptr(), d_al.data_ptr(),
+                                            d_chunk.data_ptr(), d_bs.data_ptr(), d_bl.data_ptr(),
+                                            h_alen.ctypes.data, h_blen.ctypes.data,
+                                            d_score.data_ptr(), d_ops.data_ptr(), cap, d_off.data_ptr(),
+                                            ctypes.byref(total_ops), ctypes.c_void_p(stream)))
+
+    for _ in range(args.warmup):
+        step()
+    fill_ms, tb_ms, launches = [], [], 0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        tm = _lib.get_timing()
+        fill_ms.append(tm["fill_ms"]); tb_ms.append(tm["traceback_ms"]); launches += tm["n_launches"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- after the timed region: verification + baselines (rank 0) ----
+    ok = True
+    if args.verify > 0:
+        import oracle
+        k = min(args.verify, n_pairs)
+        sc = d_score[:k].cpu().numpy()
+        off = d_off[:k + 1].cpu().numpy()
+        ops = d_ops[:int(off[-1]) * 16].cpu().numpy().view(_lib.CIGAR_DTYPE)
+        a_start = np.arange(k, dtype=np.int64) * READ_LEN
+        exp = oracle.align_batch_windows(oracle.MODE_AFFINE, align.HumanChimpTwoScoreMatrix, -600, -150, reads_h.reshape(-1),
+                                         a_start, h_alen[:k], chunk_h, np.zeros(k, np.int64), h_blen[:k], threads=min(k, os.cpu_count() or 1))
+        ok = bool(np.array_equal(sc, exp[0]) and np.array_equal(off, exp[2]) and np.array_equal(ops["run_length"], exp[1]["run_length"])
+                  and np.array_equal(ops["op"], exp[1]["op"]))
+    if world > 1:
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        ok = bool(f.item())
+        chk = d_score.sum().reshape(1)
+        gathered = [torch.zeros_like(chk) for _ in range(world)] if rank == 0 else None
+        dist.gather(chk, gathered, dst=0)  # final gather of per-rank score checksums
+    if rank == 0:
+        cells_per_step = n_pairs * READ_LEN * CHUNK_LEN * world
+        value = cells_per_step * args.steps / dt
+        fill_avg_ms = float(np.sum(fill_ms)) / max(launches, 1)
+        pairs_per_launch = n_pairs * args.steps / max(launches, 1)
+        abytes = algorithmic_bytes(READ_LEN, CHUNK_LEN, pairs_per_launch, total_ops.value * pairs_per_launch / n_pairs)
+        achieved = abytes / (fill_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "DP cells/sec + aligned pairs/sec, affine-gap 150bp x 10kb batch",
+            "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "C2 faChunkAlign-style: %d x (150 bp read vs one 10 kb chunk) per GPU, align.AffineGap, "
+                                   "HumanChimpTwoScoreMatrix, gapOpen -600, gapExtend -150, score + full CIGAR" % n_pairs,
+                       "pairs_per_gpu": n_pairs, "read_len": READ_LEN, "chunk_len": CHUNK_LEN, "parallelism": "pairs sharded x%d" % world},
+            "pairs_per_s": n_pairs * world * args.steps / dt,
+            "bit_exact_sample": ok,
+            "kernel_ms": {"fill_per_step": float(np.mean(fill_ms)), "traceback_per_step": float(np.mean(tb_ms)),
+                          "fill_launches_per_step": launches / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "fill_affine_kernel<false>", "avg_launch_ms": fill_avg_ms,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "cells_per_s_kernel": pairs_per_launch * READ_LEN * CHUNK_LEN / (fill_avg_ms * 1e-3)},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(reads_h, chunk_h, align.HumanChimpTwoScoreMatrix)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit("bit-exactness check against the oracle FAILED")
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
+#include <malloc.h>
 
 #define OR_OK 0
 #define OR_EINVAL 1  /* reference would hang / panic on this input (empty seq, base >= 5, bad index) */
@@ -524,6 +525,12 @@ int or_align_batch(int mode, const int64_t *sc, int64_t gap_open, int64_t gap_ex
     c.rcs = (int *)calloc((size_t)(n_pairs > 0 ? n_pairs : 1), sizeof(int));
     if (!c.ops || !c.nops || !c.rcs) { free(c.ops); free(c.nops); free(c.rcs); return OR_ENOMEM; }
     if (n_threads < 1) n_threads = 1;
+    /* keep the per-call work arrays (the reference allocates them per call, affineGap.go:20-54,:99) inside the
+     * malloc arenas instead of mmap/munmap-ing ~5 MB per pair: with many threads the kernel's mmap lock would
+     * otherwise serialise the workers, which would understate the CPU baseline. */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_ARENA_MAX, 256);
     if (n_threads == 1) worker(&c);
     else {
         pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
