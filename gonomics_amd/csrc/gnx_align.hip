@@ -29,6 +29,7 @@
 #include <mutex>
 #include <vector>
 #include <algorithm>
+#include <type_traits>
 #include "gnx_align.h"
 
 namespace {
@@ -66,29 +67,46 @@ __device__ __forceinline__ int dpp_shl1(int oldv, int src) { return __builtin_am
 __device__ __forceinline__ unsigned alignbit2(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 2); }
 
 // ------------------------------------------------------------------------------------------------------
-// Affine fill.  LOCAL = free end gaps (AffineGapLocal, affineGap_highMem.go:188-210).
+// Affine fill.
+//   LOCAL = free end gaps (AffineGapLocal, affineGap_highMem.go:188-210)
+//   MULTI = some pair of the launch has more than one 160-row strip (row buffer hand-over code compiled in)
+//   P16   = 4*score fits int16: the per-row score profile is stored as packed int16 pairs in LDS
+//   HFORM = gapOpen <= 0 (every caller): with h = max3(M,I,D) the recurrences collapse to
+//           rt = max(h+oe, I+e), dn = max(h+oe, D+e) with identical values AND identical argmax tags
+//           (oe <= e makes the dropped candidate I+oe / D+oe never a strict winner; ties keep M > I > D).
+//           gfx950 issues v_max_i32/v_max3_i32/v_and_or/v_alignbit/DPP/SDWA and any VALU op with an SGPR
+//           operand at 4 cycles per wave64 but VGPR/immediate add/or at 2 (tools/valu_ubench*.hip), so the
+//           penalties are kept in VGPRs and the h-form trades 2 max3 + 2 adds for 2 max.
+// LDS (dwords): [0,32) 4*score table; then per pair g a profile  prof[b][lane][LW]  (b-stride BST, pair stride
+// PST).  BST = 0 and PST = 16 (mod 32) make the 32 lanes of a ds_read_b32 group hit 32 distinct banks whatever
+// bases they look up (lane stride 5 or 10 dwords is odd/2*odd -> a permutation within a pair, +16 for the
+// second pair of the group fills the complement).
 // ------------------------------------------------------------------------------------------------------
-template <bool LOCAL>
+template <bool P16> struct ProfCfg {
+    static constexpr int LW = P16 ? R / 2 : R;       // dwords per lane per base
+    static constexpr int BST = P16 ? 96 : 160;       // dwords per base (>= 16*LW, multiple of 32)
+    static constexpr int PST = 5 * BST + 16;         // dwords per pair
+};
+
+template <bool LOCAL, bool MULTI, bool P16, bool HFORM>
 __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                          const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                          const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                          KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
                                                          int2 *__restrict__ rowbuf, int *__restrict__ err) {
-    __shared__ int lds[32 + 64]; // [0..24] 4*score table, [32..95] 4 beta rings of 64 bytes
+    using PC = ProfCfg<P16>;
+    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    __shared__ int lds[32 + 4 * PST];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     if (lane < 25) lds[lane] = kp.sc4[lane];
-    unsigned char *ring = reinterpret_cast<unsigned char *>(&lds[32]) + g * 64;
-    const char *tabb = reinterpret_cast<const char *>(&lds[0]);
+    int *prof = &lds[32 + g * PST];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
 
     const int pbase = blockIdx.x * 4;
-    int S_max = 0, m_max = 0, m_min = 0x7fffffff;
+    int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
-        if (pbase + q < n_pairs) {
-            S_max = max(S_max, plans[pbase + q].strips);
-            m_max = max(m_max, plans[pbase + q].m);
-            m_min = min(m_min, plans[pbase + q].m);
-        }
+        if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
     }
     const int p = pbase + g;
     const bool valid = p < n_pairs;
@@ -98,34 +116,56 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4;
+    int vOE4, vE4; // the same constants pinned in VGPRs (2-cycle adds)
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vOE4), "=v"(vE4) : "s"(kp.oe4), "s"(kp.e4));
     int bad = 0;
 
     for (int s = 0; s < S_max; s++) {
         const bool gact = valid && s < pl.strips;
         const int m_eff = gact ? pl.m : 0;
-        const bool store_row = gact && (s + 1 < pl.strips);
+        int m_min = 0x7fffffff; // over the 4 pairs of the wave, this strip (wave-uniform)
+        for (int q = 0; q < 4; q++) m_min = min(m_min, (pbase + q < n_pairs && s < plans[pbase + q].strips) ? plans[pbase + q].m : 0);
+        const bool store_row = MULTI && gact && (s + 1 < pl.strips);
         const int row0 = s * H + l * R; // 0-based index of this lane's first row == 1-based index of the row above it
-        int a20[R], rt[R], hold[R];
+        int rt[R], hold[R];
         unsigned accM[R], accI[R], accD[R];
+        { // score profile of this lane's rows: prof[b][lane][k]
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+            __syncthreads(); // table visible; previous strip's profile no longer read
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) {
+                    int v;
+                    if (P16) v = (lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16);
+                    else v = lds[a5[k] + b];
+                    prof[b * BST + l * LW + k] = v;
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int i0 = row0 + r;
-            int a = 0;
-            if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
-            a20[r] = a * 20;
-            const int i = i0 + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
+            const int i = row0 + r + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
             const int D1c = kp.d00_4 + i * kp.ecol4 + 1;
             hold[r] = max3i(NEG4 + 3, NEG4 + 2, D1c);
             rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + 2 + E4, D1c + OE4);
             accM[r] = 0; accI[r] = 0; accD[r] = 0;
         }
         int diag0 = (row0 == 0) ? max3i(3, kp.o4 + 2, kp.d00_4 + 1) : max3i(NEG4 + 3, NEG4 + 2, kp.d00_4 + row0 * kp.ecol4 + 1);
-        int dn_out = 0, h_out = 0;
+        int dn_out = 0, h_out = 0, b_out = 0;
         int sq_dn = 0, sq_h = 0;
-        // boundary (row above the strip) for block 0: lane u <- column u+1
-        int qdn, qh, ndn = 0, nh = 0;
-        auto boundary = [&](int c, int &odn, int &oh) {
-            if (s == 0) {
+        // boundary queues (row above the strip + beta): lane u holds column t0+u+1 of the current 16-step block
+        int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
+        auto boundary = [&](int c, int &odn, int &oh, int &ob) {
+            if (!MULTI || s == 0) {
                 const int M3 = NEG4 + 3, I2 = kp.o4 + c * E4 + 2, D1 = NEG4 + 1; // row 0: I(0,c) = gapOpen + c*gapExtend
                 oh = max3i(M3, I2, D1);
                 odn = (LOCAL && c == m_eff) ? oh : max3i(M3 + OE4, I2 + OE4, D1 + E4);
@@ -133,74 +173,84 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 const int2 v = rowbuf[pl.rowbuf_off + c];
                 odn = v.x; oh = v.y;
             } else { odn = 0; oh = 0; }
+            int b = 0;
+            if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            ob = b * (BST * 4); // LDS byte offset of the base's profile plane
         };
-        boundary(l + 1, qdn, qh);
-        int nb = 0;
-        { // beta ring: columns 1..16 now, 17..32 prefetched
-            int b0 = 0;
-            if (l < m_eff) { b0 = bp[l]; if (b0 >= 5) { bad = 1; b0 = 4; } }
-            __syncthreads();
-            ring[l & 63] = (unsigned char)b0;
-            if (16 + l < m_eff) { nb = bp[16 + l]; if (nb >= 5) { bad = 1; nb = 4; } }
-        }
-        if (s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (MULTI && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        boundary(l + 1, qdn, qh, qb);
+
+        // one anti-diagonal step; CHECK=false is the steady state (every lane of the wave has a live column)
+        auto step = [&](const int t, auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_dn = dpp_shr1(qdn, dn_out);
+            const int up_h = dpp_shr1(qh, h_out);
+            const int pb = dpp_shr1(qb, b_out);
+            qdn = dpp_shl1(qdn, qdn);
+            qh = dpp_shl1(qh, qh);
+            qb = dpp_shl1(qb, qb);
+            const int j = t - l;
+            b_out = pb;
+            if (!CHECK || (j >= 1 && j <= m_eff)) {
+                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
+                int w[LW];
+#pragma unroll
+                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                int hd = diag0, dnu = up_dn;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    int S4;
+                    if (P16) S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
+                    else S4 = w[r];
+                    const int M3 = (hd | 3) + S4;
+                    const int I2 = (rt[r] & ~3) | 2;
+                    const int D1 = (dnu & ~3) | 1;
+                    accM[r] = alignbit2((unsigned)hd, accM[r]);
+                    accI[r] = alignbit2((unsigned)rt[r], accI[r]);
+                    accD[r] = alignbit2((unsigned)dnu, accD[r]);
+                    const int hnew = max3i(M3, I2, D1);
+                    int dnn;
+                    if (HFORM) {
+                        const int hoe = hnew + vOE4;
+                        rt[r] = max(hoe, I2 + vE4);
+                        dnn = max(hoe, D1 + vE4);
+                    } else {
+                        const int Moe = M3 + vOE4;
+                        rt[r] = max3i(Moe, I2 + vE4, D1 + vOE4);
+                        dnn = max3i(Moe, I2 + vOE4, D1 + vE4);
+                    }
+                    if (LOCAL) dnn = (j == m_eff) ? hnew : dnn; // last column: D(i+1,m) = tmt(M,I,D)(i,m), no penalty
+                    hd = hold[r];
+                    hold[r] = hnew;
+                    dnu = dnn;
+                }
+                diag0 = up_h;
+                dn_out = dnu;
+                h_out = hold[R - 1];
+            }
+            if (MULTI) { sq_dn = dpp_shl1(dn_out, sq_dn); sq_h = dpp_shl1(h_out, sq_h); }
+        };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
-            // prefetch the boundary of the next block and stage the beta bytes of this one
-            boundary(t0 + 16 + l + 1, ndn, nh);
-            if (t0 > 0) {
-                ring[(t0 + l) & 63] = (unsigned char)nb;
-                nb = 0;
-                if (t0 + 16 + l < m_eff) { nb = bp[t0 + 16 + l]; if (nb >= 5) { bad = 1; nb = 4; } }
-            }
-            __syncthreads();
+            boundary(t0 + 16 + l + 1, ndn, nh, nb); // prefetch the next block's boundary
+            if (t0 >= 16 && t0 + 16 <= m_min) {
+#pragma unroll 2
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+            } else {
 #pragma unroll 1
-            for (int u = 0; u < 16; u++) {
-                const int t = t0 + u + 1;
-                const int j = t - l;
-                const int up_dn = dpp_shr1(qdn, dn_out);
-                const int up_h = dpp_shr1(qh, h_out);
-                qdn = dpp_shl1(qdn, qdn);
-                qh = dpp_shl1(qh, qh);
-                if (j >= 1 && j <= m_eff) {
-                    const int b4 = (int)ring[(j - 1) & 63] << 2;
-                    int hd = diag0, dnu = up_dn;
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const int S4 = *reinterpret_cast<const int *>(tabb + (a20[r] + b4));
-                        const int M3 = (hd | 3) + S4;
-                        const int I2 = (rt[r] & ~3) | 2;
-                        const int D1 = (dnu & ~3) | 1;
-                        accM[r] = alignbit2((unsigned)hd, accM[r]);
-                        accI[r] = alignbit2((unsigned)rt[r], accI[r]);
-                        accD[r] = alignbit2((unsigned)dnu, accD[r]);
-                        const int Moe = M3 + OE4;
-                        const int hnew = max3i(M3, I2, D1);
-                        rt[r] = max3i(Moe, I2 + E4, D1 + OE4);
-                        int dnn = max3i(Moe, I2 + OE4, D1 + E4);
-                        if (LOCAL) dnn = (j == m_eff) ? hnew : dnn; // last column: D(i+1,m) = tmt(M,I,D)(i,m), no penalty
-                        hd = hold[r];
-                        hold[r] = hnew;
-                        dnu = dnn;
-                    }
-                    diag0 = up_h;
-                    dn_out = dnu;
-                    h_out = hold[R - 1];
-                }
-                if (S_max > 1) { sq_dn = dpp_shl1(dn_out, sq_dn); sq_h = dpp_shl1(h_out, sq_h); }
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
             }
-            qdn = ndn; qh = nh;
+            qdn = ndn; qh = nh; qb = nb;
             // flush 16 steps of direction bits: word w of this strip
             const int w = t0 >> 4;
             if (gact && w < pl.words) {
                 const int miss = (t0 + 16 - l) - m_eff; // steps this lane sat idle after its last column
-                const bool fix = miss > 0;
                 const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
                 unsigned o[32];
 #pragma unroll
                 for (int r = 0; r < R; r++) { o[r] = accM[r]; o[R + r] = accI[r]; o[2 * R + r] = accD[r]; }
                 o[30] = 0; o[31] = 0;
-                if (__any(fix)) {
+                if (t0 + 16 > m_min) {
 #pragma unroll
                     for (int d = 0; d < 30; d++) o[d] >>= sh;
                 }
@@ -217,8 +267,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
 #pragma unroll
             for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r];
         }
-        if (S_max > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
+        if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     if (bad) atomicOr(err, 1);
 }
@@ -612,6 +661,11 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     }
     // ---- plan ----
     const int64_t maxpen = max_abs_pen(prm, affine);
+    bool p16 = true; // 4*score fits a signed 16-bit profile entry
+    for (int x = 0; x < 25; x++) if (prm->scores[x] > 8191 || prm->scores[x] < -8192) p16 = false;
+    if (!getenv("GNX_FORCE_P16")) p16 = false; // int32 profile: plain 2-cycle VGPR add instead of a 4-cycle SDWA add
+    bool hform = affine && prm->gap_open <= 0;
+    if (getenv("GNX_NO_HFORM")) hform = false;
     const int Q = affine ? QA : QC;
     std::vector<PairPlan> plans((size_t)n_pairs);
     std::vector<int64_t> chunk_begin;
@@ -693,8 +747,23 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const dim3 gridT((unsigned)((np + 63) / 64)), blockT(64);
         HIPCHK(hipEventRecord(c.ev[1], stream));
         if (affine) {
-            if (local) hipLaunchKernelGGL(fill_affine_kernel<true>, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, d_err);
-            else hipLaunchKernelGGL(fill_affine_kernel<false>, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, d_err);
+            bool multi = false;
+            for (int64_t q2 = b; q2 < e; q2++) if (plans[(size_t)q2].strips > 1) { multi = true; break; }
+#define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, d_err)
+#define GNX_LAUNCH_AFF2(L_, M_, P_) do { if (hform) GNX_LAUNCH_AFF(L_, M_, P_, true); else GNX_LAUNCH_AFF(L_, M_, P_, false); } while (0)
+            const int sel = (local ? 4 : 0) | (multi ? 2 : 0) | (p16 ? 1 : 0);
+            switch (sel) {
+            case 0: GNX_LAUNCH_AFF2(false, false, false); break;
+            case 1: GNX_LAUNCH_AFF2(false, false, true); break;
+            case 2: GNX_LAUNCH_AFF2(false, true, false); break;
+            case 3: GNX_LAUNCH_AFF2(false, true, true); break;
+            case 4: GNX_LAUNCH_AFF2(true, false, false); break;
+            case 5: GNX_LAUNCH_AFF2(true, false, true); break;
+            case 6: GNX_LAUNCH_AFF2(true, true, false); break;
+            default: GNX_LAUNCH_AFF2(true, true, true); break;
+            }
+#undef GNX_LAUNCH_AFF2
+#undef GNX_LAUNCH_AFF
         } else {
             hipLaunchKernelGGL(fill_const_kernel, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, d_err);
         }
