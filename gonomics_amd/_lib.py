@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgonomics_align_hip.so")
+LIB_PATH = os.environ.get("GNX_LIB_PATH") or os.path.join(_HERE, "libgonomics_align_hip.so")
 
 GNX_OK, GNX_EINVAL, GNX_EBASE, GNX_EEMPTY, GNX_ERANGE, GNX_EDEVICE, GNX_ENOMEM, GNX_ECAPACITY, GNX_ETRACE = range(9)
 GNX_AFFINE_GAP, GNX_CONST_GAP, GNX_AFFINE_GAP_HIGHMEM, GNX_AFFINE_GAP_LOCAL, GNX_CONST_GAP_HIGHMEM = range(5)

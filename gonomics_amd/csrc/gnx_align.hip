@@ -116,8 +116,13 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4;
-    int vOE4, vE4; // the same constants pinned in VGPRs (2-cycle adds)
-    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vOE4), "=v"(vE4) : "s"(kp.oe4), "s"(kp.e4));
+    // h-form carries X = h + e instead of h (XE = e): then I+e and D+e are one 2-cycle `and` + one 2-cycle add
+    // each and no separate retag is needed; (X|3) + s == M + e because e is a multiple of 4.
+    const int XE = HFORM ? kp.e4 : 0;
+    int vOE4, vE4, vO4, vE4p2, vE4p1; // constants pinned in VGPRs (2-cycle adds)
+    asm volatile("v_mov_b32 %0, %5\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %7\n\tv_mov_b32 %3, %8\n\tv_mov_b32 %4, %9"
+                 : "=v"(vOE4), "=v"(vE4), "=v"(vO4), "=v"(vE4p2), "=v"(vE4p1)
+                 : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4), "s"(kp.e4 + 2), "s"(kp.e4 + 1));
     int bad = 0;
 
     for (int s = 0; s < S_max; s++) {
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         const bool store_row = MULTI && gact && (s + 1 < pl.strips);
         const int row0 = s * H + l * R; // 0-based index of this lane's first row == 1-based index of the row above it
         int rt[R], hold[R];
-        unsigned accM[R], accI[R], accD[R];
+        unsigned acc[3 * R]; // direction accumulators: [0,R) M, [R,2R) I, [2R,3R) D
         { // score profile of this lane's rows: prof[b][lane][k]
             int a5[R];
 #pragma unroll
@@ -155,11 +160,11 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         for (int r = 0; r < R; r++) {
             const int i = row0 + r + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
             const int D1c = kp.d00_4 + i * kp.ecol4 + 1;
-            hold[r] = max3i(NEG4 + 3, NEG4 + 2, D1c);
+            hold[r] = max3i(NEG4 + 3, NEG4 + 2, D1c) + XE;
             rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + 2 + E4, D1c + OE4);
-            accM[r] = 0; accI[r] = 0; accD[r] = 0;
+            acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
         }
-        int diag0 = (row0 == 0) ? max3i(3, kp.o4 + 2, kp.d00_4 + 1) : max3i(NEG4 + 3, NEG4 + 2, kp.d00_4 + row0 * kp.ecol4 + 1);
+        int diag0 = ((row0 == 0) ? max3i(3, kp.o4 + 2, kp.d00_4 + 1) : max3i(NEG4 + 3, NEG4 + 2, kp.d00_4 + row0 * kp.ecol4 + 1)) + XE;
         int dn_out = 0, h_out = 0, b_out = 0;
         int sq_dn = 0, sq_h = 0;
         // boundary queues (row above the strip + beta): lane u holds column t0+u+1 of the current 16-step block
@@ -167,11 +172,12 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         auto boundary = [&](int c, int &odn, int &oh, int &ob) {
             if (!MULTI || s == 0) {
                 const int M3 = NEG4 + 3, I2 = kp.o4 + c * E4 + 2, D1 = NEG4 + 1; // row 0: I(0,c) = gapOpen + c*gapExtend
-                oh = max3i(M3, I2, D1);
-                odn = (LOCAL && c == m_eff) ? oh : max3i(M3 + OE4, I2 + OE4, D1 + E4);
+                const int h0 = max3i(M3, I2, D1);
+                odn = (LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4);
+                oh = h0 + XE;
             } else if (c >= 1 && c <= m_eff) {
                 const int2 v = rowbuf[pl.rowbuf_off + c];
-                odn = v.x; oh = v.y;
+                odn = v.x; oh = v.y; // already in the X domain
             } else { odn = 0; oh = 0; }
             int b = 0;
             if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
@@ -202,24 +208,29 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                     int S4;
                     if (P16) S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
                     else S4 = w[r];
-                    const int M3 = (hd | 3) + S4;
-                    const int I2 = (rt[r] & ~3) | 2;
-                    const int D1 = (dnu & ~3) | 1;
-                    accM[r] = alignbit2((unsigned)hd, accM[r]);
-                    accI[r] = alignbit2((unsigned)rt[r], accI[r]);
-                    accD[r] = alignbit2((unsigned)dnu, accD[r]);
-                    const int hnew = max3i(M3, I2, D1);
-                    int dnn;
+                    acc[r] = alignbit2((unsigned)hd, acc[r]);
+                    acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
+                    acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
+                    int hnew, dnn; // hnew is in the X domain (h + XE)
                     if (HFORM) {
-                        const int hoe = hnew + vOE4;
-                        rt[r] = max(hoe, I2 + vE4);
-                        dnn = max(hoe, D1 + vE4);
+                        const int M3e = (hd | 3) + S4;             // M + e
+                        const int Ie = (rt[r] & ~3) + vE4p2;       // I + e, tag 2
+                        const int De = (dnu & ~3) + vE4p1;         // D + e, tag 1
+                        hnew = max3i(M3e, Ie, De);                 // h + e
+                        const int hoe = hnew + vO4;                // h + oe
+                        rt[r] = max(hoe, Ie);
+                        dnn = max(hoe, De);
+                        if (LOCAL) dnn = (j == m_eff) ? hnew - vE4 : dnn; // last column: D(i+1,m) = tmt(M,I,D)(i,m), no penalty
                     } else {
+                        const int M3 = (hd | 3) + S4;
+                        const int I2 = (rt[r] & ~3) | 2;
+                        const int D1 = (dnu & ~3) | 1;
+                        hnew = max3i(M3, I2, D1);
                         const int Moe = M3 + vOE4;
                         rt[r] = max3i(Moe, I2 + vE4, D1 + vOE4);
                         dnn = max3i(Moe, I2 + vOE4, D1 + vE4);
+                        if (LOCAL) dnn = (j == m_eff) ? hnew : dnn;
                     }
-                    if (LOCAL) dnn = (j == m_eff) ? hnew : dnn; // last column: D(i+1,m) = tmt(M,I,D)(i,m), no penalty
                     hd = hold[r];
                     hold[r] = hnew;
                     dnu = dnn;
@@ -246,17 +257,14 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             if (gact && w < pl.words) {
                 const int miss = (t0 + 16 - l) - m_eff; // steps this lane sat idle after its last column
                 const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
-                unsigned o[32];
+                if (t0 + 16 > m_min) { // drain: a lane that finished early right-aligns its last fields (it never shifts again)
 #pragma unroll
-                for (int r = 0; r < R; r++) { o[r] = accM[r]; o[R + r] = accI[r]; o[2 * R + r] = accD[r]; }
-                o[30] = 0; o[31] = 0;
-                if (t0 + 16 > m_min) {
-#pragma unroll
-                    for (int d = 0; d < 30; d++) o[d] >>= sh;
+                    for (int d = 0; d < 3 * R; d++) acc[d] >>= sh;
                 }
                 uint4 *dst = trace + pl.trace_off + ((int64_t)(s * pl.words + w) * QA) * G + l;
 #pragma unroll
-                for (int q = 0; q < QA; q++) dst[q * G] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                for (int q = 0; q < QA - 1; q++) dst[q * G] = make_uint4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                dst[(QA - 1) * G] = make_uint4(acc[4 * (QA - 1)], acc[4 * (QA - 1) + 1], 0u, 0u);
             }
             if (store_row) {
                 const int c = t0 + l - 14;
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r];
+            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r] - XE;
         }
         if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
@@ -410,18 +418,20 @@ struct TbParams {
     int affine;
 };
 
+// direction word of cell (i,j) (1-based) for plane k (affine: 0/1/2 = M/I/D; const: 0) and the field position
+// of the cell inside it -- see the flush layout in the fill kernels.  Fields of lower columns sit at lower positions.
 template <bool AFFINE>
-__device__ __forceinline__ unsigned load_dir(const uint4 *trace, const PairPlan &pl, int k, int i, int j) {
-    // direction bits of cell (i,j) (1-based) for state k (affine) -- see the flush layout in the fill kernels
+__device__ __forceinline__ unsigned load_word(const uint4 *trace, const PairPlan &pl, int k, int i, int j, int &pos) {
     const int i0 = i - 1;
     const int s = i0 / H, rem = i0 - s * H;
     const int l = rem / R, r = rem - l * R;
     const int t1 = j + l - 1;
-    const int w = t1 >> 4, pos = t1 & 15;
+    const int w = t1 >> 4;
+    pos = t1 & 15;
     const int d = AFFINE ? k * R + r : r;
     const int Q = AFFINE ? QA : QC;
     const unsigned *base = reinterpret_cast<const unsigned *>(trace + pl.trace_off + ((int64_t)(s * pl.words + w) * Q + (d >> 2)) * G + l);
-    return (base[d & 3] >> (2 * pos)) & 3u;
+    return base[d & 3];
 }
 
 template <bool AFFINE, bool WRITE>
@@ -472,27 +482,49 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
         else { flush_run(); cur_op = op; cur_run = run; }
     };
 
-    // tile-local coordinates of the checkerboard walk
-    int64_t li = (i > 0) ? (int64_t)(i - 1) % tp.ci : 0;
-    int64_t lj = (j > 0) ? (int64_t)(j - 1) % tp.cj : 0;
-    bool up_exit = false, left_exit = false;
-    bool walked = false;
+    // The checkerboard walk in global coordinates.  A tile is left through its top edge when the new row index
+    // is a multiple of checkersize_i, through its left edge when the new column index is a multiple of
+    // checkersize_j (affineGap.go:121-127).
+    int64_t li = (i > 0) ? (int64_t)(i - 1) % tp.ci : 0; // tile-local row of the current cell
+    int last_op = -1;
+    const bool walked = (i > 0 && j > 0);
     while (i > 0 && j > 0) {
-        walked = true;
-        int op, tag;
-        if (AFFINE) { op = k; tag = (int)load_dir<true>(trace, pl, k, i, j); }
-        else { tag = (int)load_dir<false>(trace, pl, 0, i, j); op = 3 - tag; }
+        int pos;
+        const unsigned w = load_word<AFFINE>(trace, pl, AFFINE ? k : 0, i, j, pos);
+        int tag = (int)((w >> (2 * pos)) & 3u);
+        const int op = AFFINE ? k : 3 - tag;
         if (tag == 0) { atomicOr(err, 2); break; } // impossible direction: the Go code would log.Fatalf
+        if (op == 1) {
+            // Horizontal run: every cell visited in state I emits one I and moves left; the walk stays in this word
+            // while the fields read "came from I" (tag 2).  Count them with one xor + clz instead of 16 iterations.
+            const int avail = min(pos + 1, j);            // fields of columns >= 1 at positions pos .. pos-avail+1
+            unsigned x = w ^ 0xAAAAAAAAu;
+            if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
+            const int lowcut = pos + 1 - avail;
+            if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+            int steps;
+            if (x == 0) { steps = avail; if (AFFINE) k = 1; }
+            else {
+                const int pnz = (31 - __clz((int)x)) >> 1;  // highest field that is not "from I"
+                tag = (int)((w >> (2 * pnz)) & 3u);
+                if (tag == 0) { atomicOr(err, 2); break; }
+                if (AFFINE) { steps = pos - pnz + 1; k = 3 - tag; } // that cell is still in state I; its source decides the next state
+                else steps = pos - pnz;                            // const gap: that cell is not an I cell
+            }
+            if (steps > 0) { emit(1, steps); j -= steps; last_op = 1; }
+            continue;
+        }
         emit(op, 1);
-        up_exit = false; left_exit = false;
+        last_op = op;
+        bool up_exit = false;
         if (op != 1) { up_exit = (li == 0); li = up_exit ? tp.ci - 1 : li - 1; i--; }
-        if (op != 2) { left_exit = (lj == 0); lj = left_exit ? tp.cj - 1 : lj - 1; j--; }
+        if (op != 2) j--;
         if (AFFINE) {
             k = 3 - tag;
             if (up_exit && i > 0 && j > 0) {
                 // quirk Q1 (affineGap.go:305): entering a tile from below restarts in the argmax state of the entry cell
                 int ht;
-                if (j < pl.m) ht = (int)load_dir<true>(trace, pl, 0, i + 1, j + 1);
+                if (j < pl.m) { int p2; ht = (int)((load_word<true>(trace, pl, 0, i + 1, j + 1, p2) >> (2 * p2)) & 3u); }
                 else ht = hcol[pl.hcol_off + i - 1] & 3;
                 k = 3 - ht;
             }
@@ -500,6 +532,8 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
     }
     // Step 4 (affineGap.go:135-139 / constGap.go:59-63) and the highMem border walks
     if (walked) {
+        const bool up_exit = (last_op != 1) && ((int64_t)i % tp.ci == 0);
+        const bool left_exit = (last_op != 2) && ((int64_t)j % tp.cj == 0);
         if (!up_exit && left_exit) emit(2, i);
         else if (up_exit && !left_exit) emit(1, j);
         // both: corner exit -> nothing (quirk Q2 when it is not the origin)
