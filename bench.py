@@ -101,7 +101,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from gonomics_amd import _lib, align
+    from gonomics_amd import _lib, align, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,7 +124,7 @@ def main():
         chunk_h = np.zeros(CHUNK_LEN, dtype=np.uint8)
     d_chunk = torch.from_numpy(chunk_h).to(dev)
     if world > 1:
-        dist.broadcast(d_chunk, src=0)
+        shard.broadcast_reference(d_chunk, src=0)  # RCCL broadcast over xGMI
         chunk_h = d_chunk.cpu().numpy()
     reads_h = reads0 if rank == 0 else make_workload(2 + 1000 * rank, n_pairs, chunk_h)[0]
     d_reads = torch.from_numpy(reads_h.reshape(-1)).to(dev)
@@ -186,9 +186,11 @@ def main():
         f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         ok = bool(f.item())
-        chk = d_score.sum().reshape(1)
-        gathered = [torch.zeros_like(chk) for _ in range(world)] if rank == 0 else None
-        dist.gather(chk, gathered, dst=0)  # final gather of per-rank score checksums
+        # final gather of scores / CIGAR offsets / CIGAR blob on rank 0, in input order (outside the timed region)
+        n_ops_local = int(d_off[n_pairs].item())
+        gathered = shard.gather_results(d_score, d_ops[: n_ops_local * 16], d_off, dst=0)
+        if rank == 0:
+            ok = ok and gathered[0].numel() == n_pairs * world and int(gathered[2][-1].item()) * 16 == gathered[1].numel()
     if rank == 0:
         cells_per_step = n_pairs * READ_LEN * CHUNK_LEN * world
         value = cells_per_step * args.steps / dt

@@ -1,0 +1,25 @@
+// Compiles against include/gonomics_align.hpp + the C ABI and re-states three of the reference's table tests
+// (align/affineGap_test.go:45-55,120-155; align/view_test.go:28-38) through the C++ host mirror.
+// Exit code 0 = all good, 2 = no GPU (the library has no CPU fallback), 1 = mismatch.
+#include <cstdio>
+#include "gonomics_align.hpp"
+
+int main() {
+    if (gnx_device_count() <= 0) { std::printf("no HIP device: %s\n", "skipping compute"); return 2; }
+    struct T { const char *a, *b, *aln; };
+    const T aff[] = {{"ACGT", "ACGT", "ACGT\nACGT\n"}, {"ACGT", "CGT", "ACGT\n-CGT\n"}, {"CGCGCGCGCG", "CGAAAACGCGTTTTCGCG", "CG----CGCG----CGCG\nCGAAAACGCGTTTTCGCG\n"}};
+    int bad = 0;
+    for (const T &t : aff) {
+        auto a = dna::StringToBases(t.a), b = dna::StringToBases(t.b);
+        auto r = align::AffineGap_highMem(a, b, align::DefaultScoreMatrix(), -400, -30);
+        if (align::View(a, b, r.second) != t.aln) { std::printf("affine mismatch %s %s\n", t.a, t.b); bad++; }
+        auto c = align::ConstGap(a, b, align::DefaultScoreMatrix(), -430);
+        if (align::View(a, b, c.second) != t.aln) { std::printf("const mismatch %s %s\n", t.a, t.b); bad++; }
+    }
+    auto l = align::AffineGapLocal(dna::StringToBases("TCACTTTCGCACGTT"), dna::StringToBases("CACACG"), align::DefaultScoreMatrix(), -600, -150);
+    if (l.first != 460 || align::PrintCigar(l.second) != "7D6M2D") { std::printf("local mismatch\n"); bad++; }
+    try { align::ConstGap(dna::StringToBases("ACgT"), dna::StringToBases("ACGT"), align::DefaultScoreMatrix(), -430); bad++; }
+    catch (const std::out_of_range &) {}
+    std::printf(bad ? "FAILED\n" : "ok\n");
+    return bad ? 1 : 0;
+}
