@@ -198,6 +198,12 @@ def main():
         pairs_per_launch = n_pairs * args.steps / max(launches, 1)
         abytes = algorithmic_bytes(READ_LEN, CHUNK_LEN, pairs_per_launch, total_ops.value * pairs_per_launch / n_pairs)
         achieved = abytes / (fill_avg_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per fill launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as fh:
+                traffic = json.load(fh)["hbm_bytes_per_pair"] * pairs_per_launch
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "DP cells/sec + aligned pairs/sec, affine-gap 150bp x 10kb batch",
             "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,7 +217,8 @@ def main():
             "kernel_ms": {"fill_per_step": float(np.mean(fill_ms)), "traceback_per_step": float(np.mean(tb_ms)),
                           "fill_launches_per_step": launches / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "fill_affine_kernel<false>", "avg_launch_ms": fill_avg_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r1_hbm_traffic.json)",
+                         "kernel": "fill_affine_kernel", "avg_launch_ms": fill_avg_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "cells_per_s_kernel": pairs_per_launch * READ_LEN * CHUNK_LEN / (fill_avg_ms * 1e-3)},
         }
