@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--ws-gb", type=float, default=150.0, help="direction-matrix workspace limit per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--verify", type=int, default=32, help="pairs checked bit-exactly against the oracle after timing")
+    ap.add_argument("--series", default="affine", choices=["affine", "const", "local"],
+                    help="affine = the headline AffineGap(read, chunk); const = ConstGap(read, chunk, -430); "
+                         "local = AffineGapLocal(target=chunk, query=read) (SURVEY 8d second series)")
     args = ap.parse_args()
 
     import torch
@@ -138,17 +141,38 @@ def main():
     d_off = torch.zeros(n_pairs + 1, dtype=torch.int64, device=dev)
     cap = 48 * n_pairs
     d_ops = torch.zeros(cap * 16, dtype=torch.uint8, device=dev)
-    params = _lib.make_params(_lib.GNX_AFFINE_GAP, align.HumanChimpTwoScoreMatrix, -600, -150, 10000, 10000)
+    if args.series == "affine":
+        gmode, omode, go, ge = _lib.GNX_AFFINE_GAP, 0, -600, -150
+    elif args.series == "const":
+        gmode, omode, go, ge = _lib.GNX_CONST_GAP, 1, -430, 0
+    else:
+        gmode, omode, go, ge = _lib.GNX_AFFINE_GAP_LOCAL, 3, -600, -150
+    params = _lib.make_params(gmode, align.HumanChimpTwoScoreMatrix, go, ge, 10000, 10000)
     total_ops = ctypes.c_int64()
     stream = torch.cuda.current_stream().cuda_stream
+    swap = args.series == "local"  # AffineGapLocal(target=chunk, query=read): alpha is the chunk
 
     def step():
+        if swap:
+            _lib.check(L.gnx_align_batch_device(ctypes.byref(params), n_pairs, d_chunk.data_ptr(), d_bs.data_ptr(), d_bl.data_ptr(),
+                                                d_reads.data_ptr(), d_as.data_ptr(), d_al.data_ptr(),
+                                                h_blen.ctypes.data, h_alen.ctypes.data,
+                                                d_score.data_ptr(), d_ops.data_ptr(), cap, d_off.data_ptr(),
+                                                ctypes.byref(total_ops), ctypes.c_void_p(stream)))
+            return
         _lib.check(L.gnx_align_batch_device(ctypes.byref(params), n_pairs, d_reads.data_ptr(), d_as.data_ptr(), d_al.data_ptr(),
                                             d_chunk.data_ptr(), d_bs.data_ptr(), d_bl.data_ptr(),
                                             h_alen.ctypes.data, h_blen.ctypes.data,
                                             d_score.data_ptr(), d_ops.data_ptr(), cap, d_off.data_ptr(),
                                             ctypes.byref(total_ops), ctypes.c_void_p(stream)))
 
+    try:  # one untimed sizing call: const-gap CIGARs have hundreds of runs per pair
+        step()
+    except _lib.GnxError as e:
+        if e.code != _lib.GNX_ECAPACITY:
+            raise
+        cap = int(total_ops.value * 1.05) + 1024
+        d_ops = torch.zeros(cap * 16, dtype=torch.uint8, device=dev)
     for _ in range(args.warmup):
         step()
     fill_ms, tb_ms, launches = [], [], 0
@@ -178,8 +202,12 @@ def main():
         off = d_off[:k + 1].cpu().numpy()
         ops = d_ops[:int(off[-1]) * 16].cpu().numpy().view(_lib.CIGAR_DTYPE)
         a_start = np.arange(k, dtype=np.int64) * READ_LEN
-        exp = oracle.align_batch_windows(oracle.MODE_AFFINE, align.HumanChimpTwoScoreMatrix, -600, -150, reads_h.reshape(-1),
-                                         a_start, h_alen[:k], chunk_h, np.zeros(k, np.int64), h_blen[:k], threads=min(k, os.cpu_count() or 1))
+        if swap:
+            exp = oracle.align_batch_windows(omode, align.HumanChimpTwoScoreMatrix, go, ge, chunk_h, np.zeros(k, np.int64), h_blen[:k],
+                                             reads_h.reshape(-1), a_start, h_alen[:k], threads=min(k, os.cpu_count() or 1))
+        else:
+            exp = oracle.align_batch_windows(omode, align.HumanChimpTwoScoreMatrix, go, ge, reads_h.reshape(-1),
+                                             a_start, h_alen[:k], chunk_h, np.zeros(k, np.int64), h_blen[:k], threads=min(k, os.cpu_count() or 1))
         ok = bool(np.array_equal(sc, exp[0]) and np.array_equal(off, exp[2]) and np.array_equal(ops["run_length"], exp[1]["run_length"])
                   and np.array_equal(ops["op"], exp[1]["op"]))
     if world > 1:
@@ -205,7 +233,8 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         out = {
-            "metric": "DP cells/sec + aligned pairs/sec, affine-gap 150bp x 10kb batch",
+            "metric": "DP cells/sec + aligned pairs/sec, affine-gap 150bp x 10kb batch" if args.series == "affine"
+                      else "DP cells/sec, series=%s (not the headline metric)" % args.series,
             "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
@@ -222,9 +251,11 @@ def main():
                          "algorithmic_bytes_per_launch": abytes,
                          "cells_per_s_kernel": pairs_per_launch * READ_LEN * CHUNK_LEN / (fill_avg_ms * 1e-3)},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and args.series == "affine":
             out["cpu_baseline"] = cpu_baseline(reads_h, chunk_h, align.HumanChimpTwoScoreMatrix)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if args.series != "affine":
+            out["roofline"]["note"] = "algorithmic-byte model is the affine one; use cells_per_s_kernel for this series"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -51,6 +51,7 @@ struct PairPlan {
     int64_t trace_off;  // in uint4 units, relative to the chunk's trace buffer
     int64_t hcol_off;   // ints
     int64_t rowbuf_off; // int2
+    int64_t dcol_off;   // dwords: per strip and lane one word with the last-column direction fields of the lane's R rows
 };
 
 struct KParams {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                                                          const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                          const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                          KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
-                                                         int2 *__restrict__ rowbuf, int *__restrict__ err) {
+                                                         int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int *__restrict__ err) {
     using PC = ProfCfg<P16>;
     constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
     __shared__ int lds[32 + 4 * PST];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const int p = pbase + g;
     const bool valid = p < n_pairs;
     PairPlan pl;
-    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; }
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
     const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
@@ -274,6 +275,13 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         if (gact && m_eff >= 1) {
 #pragma unroll
             for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r] - XE;
+            // last-column D-plane fields of this lane's rows, packed (field r at bits 2r): lets the traceback skip
+            // vertical runs in column m (free end gaps of AffineGapLocal, trailing gaps when alpha is the long one)
+            const int t0f = ((m_eff + l - 1) >> 4) << 4, missf = t0f + 16 - l - m_eff; // 0..15: in-place drain shift
+            unsigned dw = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) dw |= ((acc[2 * R + r] >> (30 - 2 * missf)) & 3u) << (2 * r);
+            dcol[pl.dcol_off + s * G + l] = dw;
         }
         if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
@@ -281,20 +289,25 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Constant-gap fill (align/constGap.go:146-157 recurrence).  Keys: diag+s -> tag 3, left+g -> tag 2,
-// up+g -> tag 1; the stored value is the clean (tag-free) key.
+// Constant-gap fill (align/constGap.go:146-157 recurrence), same wavefront mapping as the affine kernel.
+// Keys: diag+s -> tag 3, left+g -> tag 2, up+g -> tag 1; the stored value is the clean (tag-free) key, so the three
+// candidates are three 2-cycle VGPR adds (the profile holds 4*s+3, the penalties 4*g+2 / 4*g+1 live in VGPRs),
+// one v_max3, one v_and and one v_alignbit per cell.
 // ------------------------------------------------------------------------------------------------------
+template <bool MULTI>
 __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                         const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                         const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                         KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
-                                                        int2 *__restrict__ rowbuf, int *__restrict__ err) {
-    __shared__ int lds[32 + 64];
+                                                        int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int *__restrict__ err) {
+    using PC = ProfCfg<false>;
+    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    __shared__ int lds[32 + 4 * PST];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     if (lane < 25) lds[lane] = kp.sc4[lane] + 3; // pre-tagged diagonal candidate
-    unsigned char *ring = reinterpret_cast<unsigned char *>(&lds[32]) + g * 64;
-    const char *tabb = reinterpret_cast<const char *>(&lds[0]);
+    int *prof = &lds[32 + g * PST];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
     const int pbase = blockIdx.x * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
@@ -303,95 +316,106 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     const int p = pbase + g;
     const bool valid = p < n_pairs;
     PairPlan pl;
-    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; }
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
     const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
-    const int GL = kp.g4 + 2, GU = kp.g4 + 1;
+    int vGL, vGU;
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vGL), "=v"(vGU) : "s"(kp.g4 + 2), "s"(kp.g4 + 1));
     int bad = 0;
 
     for (int s = 0; s < S_max; s++) {
         const bool gact = valid && s < pl.strips;
         const int m_eff = gact ? pl.m : 0;
-        const bool store_row = gact && (s + 1 < pl.strips);
+        int m_min = 0x7fffffff;
+        for (int q = 0; q < 4; q++) m_min = min(m_min, (pbase + q < n_pairs && s < plans[pbase + q].strips) ? plans[pbase + q].m : 0);
+        const bool store_row = MULTI && gact && (s + 1 < pl.strips);
         const int row0 = s * H + l * R;
-        int a20[R], val[R];
+        int val[R];
         unsigned acc[R];
+        {
+            int a5[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int i0 = row0 + r;
-            int a = 0;
-            if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
-            a20[r] = a * 20;
-            val[r] = (i0 + 1) * kp.g4; // column 0: i*gapPen
-            acc[r] = 0;
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = lds[a5[k] + b];
+            }
+            __syncthreads();
         }
+#pragma unroll
+        for (int r = 0; r < R; r++) { val[r] = (row0 + r + 1) * kp.g4; acc[r] = 0; } // column 0: i*gapPen
         int diag0 = row0 * kp.g4; // V(row above, 0)
-        int v_out = 0, sq_v = 0;
-        int qv, nv = 0;
-        auto boundary = [&](int c, int &ov) {
-            if (s == 0) ov = c * kp.g4; // row 0: j*gapPen
+        int v_out = 0, b_out = 0, sq_v = 0;
+        int qv, qb, nv = 0, nb = 0;
+        auto boundary = [&](int c, int &ov, int &ob) {
+            if (!MULTI || s == 0) ov = c * kp.g4; // row 0: j*gapPen
             else if (c >= 1 && c <= m_eff) ov = rowbuf[pl.rowbuf_off + c].x;
             else ov = 0;
+            int b = 0;
+            if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            ob = b * (BST * 4);
         };
-        boundary(l + 1, qv);
-        int nb = 0;
-        {
-            int b0 = 0;
-            if (l < m_eff) { b0 = bp[l]; if (b0 >= 5) { bad = 1; b0 = 4; } }
-            __syncthreads();
-            ring[l & 63] = (unsigned char)b0;
-            if (16 + l < m_eff) { nb = bp[16 + l]; if (nb >= 5) { bad = 1; nb = 4; } }
-        }
-        if (s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (int t0 = 0; t0 < Tend; t0 += 16) {
-            boundary(t0 + 16 + l + 1, nv);
-            if (t0 > 0) {
-                ring[(t0 + l) & 63] = (unsigned char)nb;
-                nb = 0;
-                if (t0 + 16 + l < m_eff) { nb = bp[t0 + 16 + l]; if (nb >= 5) { bad = 1; nb = 4; } }
-            }
-            __syncthreads();
-#pragma unroll 1
-            for (int u = 0; u < 16; u++) {
-                const int t = t0 + u + 1;
-                const int j = t - l;
-                const int up_v = dpp_shr1(qv, v_out);
-                qv = dpp_shl1(qv, qv);
-                if (j >= 1 && j <= m_eff) {
-                    const int b4 = (int)ring[(j - 1) & 63] << 2;
-                    int vd = diag0, vu = up_v;
+        if (MULTI && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        boundary(l + 1, qv, qb);
+
+        auto step = [&](const int t, auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_v = dpp_shr1(qv, v_out);
+            const int pb = dpp_shr1(qb, b_out);
+            qv = dpp_shl1(qv, qv);
+            qb = dpp_shl1(qb, qb);
+            const int j = t - l;
+            b_out = pb;
+            if (!CHECK || (j >= 1 && j <= m_eff)) {
+                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
+                int w[LW];
 #pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const int S4 = *reinterpret_cast<const int *>(tabb + (a20[r] + b4));
-                        const int k = max3i(vd + S4, val[r] + GL, vu + GU);
-                        acc[r] = alignbit2((unsigned)k, acc[r]);
-                        vd = val[r];
-                        val[r] = k & ~3;
-                        vu = val[r];
-                    }
-                    diag0 = up_v;
-                    v_out = vu;
+                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                int vd = diag0, vu = up_v;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int k = max3i(vd + w[r], val[r] + vGL, vu + vGU);
+                    acc[r] = alignbit2((unsigned)k, acc[r]);
+                    vd = val[r];
+                    val[r] = k & ~3;
+                    vu = val[r];
                 }
-                if (S_max > 1) sq_v = dpp_shl1(v_out, sq_v);
+                diag0 = up_v;
+                v_out = vu;
             }
-            qv = nv;
+            if (MULTI) sq_v = dpp_shl1(v_out, sq_v);
+        };
+
+        for (int t0 = 0; t0 < Tend; t0 += 16) {
+            boundary(t0 + 16 + l + 1, nv, nb);
+            if (t0 >= 16 && t0 + 16 <= m_min) {
+#pragma unroll 2
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+            }
+            qv = nv; qb = nb;
             const int w = t0 >> 4;
             if (gact && w < pl.words) {
                 const int miss = (t0 + 16 - l) - m_eff;
-                const bool fix = miss > 0;
                 const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
-                unsigned o[12];
+                if (t0 + 16 > m_min) {
 #pragma unroll
-                for (int r = 0; r < R; r++) o[r] = acc[r];
-                o[10] = 0; o[11] = 0;
-                if (__any(fix)) {
-#pragma unroll
-                    for (int d = 0; d < 10; d++) o[d] >>= sh;
+                    for (int d = 0; d < R; d++) acc[d] >>= sh;
                 }
                 uint4 *dst = trace + pl.trace_off + ((int64_t)(s * pl.words + w) * QC) * G + l;
-#pragma unroll
-                for (int q = 0; q < QC; q++) dst[q * G] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                dst[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                dst[G] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+                dst[2 * G] = make_uint4(acc[8], acc[9], 0u, 0u);
             }
             if (store_row) {
                 const int c = t0 + l - 14;
@@ -401,9 +425,13 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         if (gact && m_eff >= 1) {
 #pragma unroll
             for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = val[r];
+            const int t0f = ((m_eff + l - 1) >> 4) << 4, missf = t0f + 16 - l - m_eff;
+            unsigned dw = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) dw |= ((acc[r] >> (30 - 2 * missf)) & 3u) << (2 * r);
+            dcol[pl.dcol_off + s * G + l] = dw;
         }
-        if (S_max > 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
+        if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     if (bad) atomicOr(err, 1);
 }
@@ -436,7 +464,8 @@ __device__ __forceinline__ unsigned load_word(const uint4 *trace, const PairPlan
 
 template <bool AFFINE, bool WRITE>
 __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restrict__ plans, int n_pairs, const uint4 *__restrict__ trace,
-                                                       const int *__restrict__ hcol, TbParams tp, int64_t *__restrict__ score_out,
+                                                       const int *__restrict__ hcol, const unsigned *__restrict__ dcol, TbParams tp,
+                                                       int64_t *__restrict__ score_out,
                                                        int64_t *__restrict__ nops, const int64_t *__restrict__ ops_off,
                                                        gnx_cigar *__restrict__ ops, int64_t ops_capacity, int *__restrict__ err) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,6 +518,41 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
     int last_op = -1;
     const bool walked = (i > 0 && j > 0);
     while (i > 0 && j > 0) {
+        if (j == pl.m && (!AFFINE || k == 2)) {
+            // Vertical run in the last column: the packed per-lane word holds the fields of R consecutive rows.
+            const int i0 = i - 1, sl = i0 / R, r = i0 - sl * R; // sl = strip*16 + lane
+            const unsigned w = dcol[pl.dcol_off + sl];
+            int tag = (int)((w >> (2 * r)) & 3u);
+            if (tag == 0) { atomicOr(err, 2); break; }
+            if (AFFINE || tag == 1) {
+                int avail = min(r + 1, i);
+                if (li + 1 < (int64_t)avail) avail = (int)(li + 1); // do not run past the tile's top edge (quirk Q1 applies there)
+                unsigned x = w ^ 0x55555555u;                        // fields "from D" (tag 1) become 0
+                if (r < 15) x &= (1u << (2 * r + 2)) - 1u;
+                const int lowcut = r + 1 - avail;
+                if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+                int steps;
+                bool cont = false; // the walk is still in a D cell after the run
+                if (x == 0) { steps = avail; cont = true; }
+                else {
+                    const int rnz = (31 - __clz((int)x)) >> 1;
+                    tag = (int)((w >> (2 * rnz)) & 3u);
+                    if (tag == 0) { atomicOr(err, 2); break; }
+                    if (AFFINE) steps = r - rnz + 1; else { steps = r - rnz; cont = true; }
+                }
+                if (steps > 0) {
+                    emit(2, steps); i -= steps; last_op = 2;
+                    li -= steps;
+                    const bool up_exit = li < 0;
+                    if (up_exit) li += tp.ci;
+                    if (AFFINE) {
+                        k = cont ? 2 : 3 - tag;
+                        if (up_exit && i > 0) k = 3 - (hcol[pl.hcol_off + i - 1] & 3); // quirk Q1, entry cell (i, m)
+                    }
+                    continue;
+                }
+            }
+        }
         int pos;
         const unsigned w = load_word<AFFINE>(trace, pl, AFFINE ? k : 0, i, j, pos);
         int tag = (int)((w >> (2 * pos)) & 3u);
@@ -610,7 +674,7 @@ struct Ctx {
     int device = -1;
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr;
-    DevBuf trace, hcol, rowbuf, plans, nops, misc;
+    DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -705,7 +769,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     std::vector<int64_t> chunk_begin;
     int64_t cells = 0;
     {
-        int64_t toff = 0, hoff = 0, roff = 0;
+        int64_t toff = 0, hoff = 0, roff = 0, doff = 0;
         chunk_begin.push_back(0);
         const int64_t trace_limit_u4 = std::max<int64_t>(c.ws_limit / 16, 1);
         for (int64_t p = 0; p < n_pairs; p++) {
@@ -728,30 +792,31 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
                 int64_t cb = p & ~(int64_t)3;
                 if (cb <= chunk_begin.back()) cb = p;
                 // re-plan the pairs moved into the new chunk
-                toff = 0; hoff = 0; roff = 0;
+                toff = 0; hoff = 0; roff = 0; doff = 0;
                 for (int64_t q2 = cb; q2 < p; q2++) {
                     PairPlan &pq = plans[(size_t)q2];
-                    pq.trace_off = toff; pq.hcol_off = hoff; pq.rowbuf_off = roff;
-                    toff += (int64_t)pq.strips * pq.words * Q * G; hoff += pq.n; roff += (pq.strips > 1) ? pq.m + 1 : 0;
+                    pq.trace_off = toff; pq.hcol_off = hoff; pq.rowbuf_off = roff; pq.dcol_off = doff;
+                    toff += (int64_t)pq.strips * pq.words * Q * G; hoff += pq.n; roff += (pq.strips > 1) ? pq.m + 1 : 0; doff += (int64_t)pq.strips * G;
                 }
                 chunk_begin.push_back(cb);
             }
-            pl.trace_off = toff; pl.hcol_off = hoff; pl.rowbuf_off = roff;
-            toff += tsz; hoff += n; roff += (pl.strips > 1) ? m + 1 : 0;
+            pl.trace_off = toff; pl.hcol_off = hoff; pl.rowbuf_off = roff; pl.dcol_off = doff;
+            toff += tsz; hoff += n; roff += (pl.strips > 1) ? m + 1 : 0; doff += (int64_t)pl.strips * G;
             cells += n * m;
         }
         chunk_begin.push_back(n_pairs);
     }
     // workspace sizes = max over chunks
-    int64_t max_t = 1, max_h = 1, max_r = 1;
+    int64_t max_t = 1, max_h = 1, max_r = 1, max_d = 1;
     for (size_t ch = 0; ch + 1 < chunk_begin.size(); ch++) {
-        int64_t t = 0, h = 0, r = 0;
+        int64_t t = 0, h = 0, r = 0, d = 0;
         for (int64_t p = chunk_begin[ch]; p < chunk_begin[ch + 1]; p++) {
             const PairPlan &pl = plans[(size_t)p];
-            t += (int64_t)pl.strips * pl.words * Q * G; h += pl.n; r += (pl.strips > 1) ? pl.m + 1 : 0;
+            t += (int64_t)pl.strips * pl.words * Q * G; h += pl.n; r += (pl.strips > 1) ? pl.m + 1 : 0; d += (int64_t)pl.strips * G;
         }
-        max_t = std::max(max_t, t); max_h = std::max(max_h, h); max_r = std::max(max_r, r);
+        max_t = std::max(max_t, t); max_h = std::max(max_h, h); max_r = std::max(max_r, r); max_d = std::max(max_d, d);
     }
+    if ((rc = c.dcol.ensure((size_t)max_d * 4))) return rc;
     if ((rc = c.trace.ensure((size_t)max_t * 16))) return rc;
     if ((rc = c.hcol.ensure((size_t)max_h * 4))) return rc;
     if ((rc = c.rowbuf.ensure((size_t)max_r * 8))) return rc;
@@ -776,14 +841,15 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         uint4 *dtrace = reinterpret_cast<uint4 *>(c.trace.p);
         int *dh = reinterpret_cast<int *>(c.hcol.p);
         int2 *drb = reinterpret_cast<int2 *>(c.rowbuf.p);
+        unsigned *ddc = reinterpret_cast<unsigned *>(c.dcol.p);
         int64_t *dn = reinterpret_cast<int64_t *>(c.nops.p) + b;
         const dim3 gridF((unsigned)((np + 3) / 4)), blockF(64);
         const dim3 gridT((unsigned)((np + 63) / 64)), blockT(64);
         HIPCHK(hipEventRecord(c.ev[1], stream));
+        bool multi = false;
+        for (int64_t q2 = b; q2 < e; q2++) if (plans[(size_t)q2].strips > 1) { multi = true; break; }
         if (affine) {
-            bool multi = false;
-            for (int64_t q2 = b; q2 < e; q2++) if (plans[(size_t)q2].strips > 1) { multi = true; break; }
-#define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, d_err)
+#define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err)
 #define GNX_LAUNCH_AFF2(L_, M_, P_) do { if (hform) GNX_LAUNCH_AFF(L_, M_, P_, true); else GNX_LAUNCH_AFF(L_, M_, P_, false); } while (0)
             const int sel = (local ? 4 : 0) | (multi ? 2 : 0) | (p16 ? 1 : 0);
             switch (sel) {
@@ -799,15 +865,16 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
 #undef GNX_LAUNCH_AFF2
 #undef GNX_LAUNCH_AFF
         } else {
-            hipLaunchKernelGGL(fill_const_kernel, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, d_err);
+            if (multi) hipLaunchKernelGGL(fill_const_kernel<true>, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err);
+            else hipLaunchKernelGGL(fill_const_kernel<false>, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
-        if (affine) hipLaunchKernelGGL((traceback_kernel<true, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
-        else hipLaunchKernelGGL((traceback_kernel<false, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
+        if (affine) hipLaunchKernelGGL((traceback_kernel<true, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
+        else hipLaunchKernelGGL((traceback_kernel<false, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, dn, np, d_ops_off + b, d_carry);
-        if (affine) hipLaunchKernelGGL((traceback_kernel<true, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
-        else hipLaunchKernelGGL((traceback_kernel<false, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
+        if (affine) hipLaunchKernelGGL((traceback_kernel<true, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
+        else hipLaunchKernelGGL((traceback_kernel<false, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[3], stream));
         if (nchunks > 1 || true) {
@@ -930,7 +997,7 @@ void gnx_shutdown(void) {
     if (!g_ctx.inited) return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
+    DevBuf *bufs[] = {&g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
                       &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 4; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }

@@ -228,3 +228,51 @@ def test_workspace_chunking(gpu_lib):
     finally:
         gpu_lib.check(gpu_lib.lib().gnx_init(0, 8 << 30))
     common.assert_same(got, exp)
+
+
+def test_c5_scaled_long_read_checkerboards(gpu_lib):
+    """Config C5 scaled to what the oracle finishes in seconds: an ONT-like read inside a longer window, several
+    checkerboards in both directions (quirk-exact tile walk), several 160-row strips."""
+    rng = np.random.default_rng(5)
+    win = rng.integers(0, 4, size=20000).astype(np.uint8)
+    read = common.mutate(rng, win[6000:9000], sub=0.04, indel=0.06, geo=0.5)
+    for mode, go, ge in ((gpu_lib.GNX_CONST_GAP, -430, 0), (gpu_lib.GNX_AFFINE_GAP, -600, -150)):
+        p = gpu_lib.make_params(mode, align.HumanChimpTwoScoreMatrix, go, ge, 1000, 1000)
+        got = gpu_lib.align_batch(p, [read, read[:1500]], [win, win[5000:12000]])
+        exp = oracle.align_batch(mode, MX["HumanChimpTwo"], go, ge, [read, read[:1500]], [win, win[5000:12000]], 1000, 1000, threads=2)
+        common.assert_same(got, exp)
+
+
+def test_full_size_properties(gpu_lib):
+    """Size-independent checks at BASELINE sizes where the oracle is too slow to run in a test: every CIGAR must
+    consume exactly n and m, and re-scoring the CIGAR with the affine model must reproduce the returned score."""
+    reads, chunk = common.c2_workload(9, 4096)
+    n = reads.shape[0]
+    a_start = np.arange(n, dtype=np.int64) * 150
+    a_len = np.full(n, 150, dtype=np.int64)
+    b_start = np.zeros(n, dtype=np.int64)
+    b_len = np.full(n, chunk.shape[0], dtype=np.int64)
+    sc = np.asarray(align.HumanChimpTwoScoreMatrix, dtype=np.int64)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, align.HumanChimpTwoScoreMatrix, -600, -150)
+    scores, ops, off = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len)
+    again = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len)
+    common.assert_same((scores, ops, off), again, "idempotence")
+    for k in range(0, n, 37):
+        route = [(int(r), int(o)) for r, o in zip(ops["run_length"][off[k]:off[k + 1]], ops["op"][off[k]:off[k + 1]])]
+        i = j = 0
+        total = 0
+        prev = -1
+        for run, op in route:
+            assert run > 0 and op != prev
+            prev = op
+            if op == 0:
+                total += int(sc[reads[k, i:i + run], chunk[j:j + run]].sum())
+                i += run; j += run
+            else:
+                total += -600 + -150 * run
+                if op == 1:
+                    j += run
+                else:
+                    i += run
+        assert (i, j) == (150, chunk.shape[0])
+        assert total == int(scores[k])
