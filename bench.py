@@ -76,11 +76,11 @@ def cpu_baseline(reads, chunk, scores, budget_s=15.0):
                                    chunk, b_start, b_len, threads=threads)
         return time.perf_counter() - t0
 
-    run(min(2 * cores, reads.shape[0]), cores)  # warm the allocator arenas / page tables
-    kp = min(4 * cores, reads.shape[0])
-    per_pair = max(run(kp, cores) / kp, 1e-5)  # wall seconds per pair with all cores busy
-    k = int(max(kp, min(reads.shape[0], budget_s / per_pair)))
-    dt = run(k, cores)
+    k = min(4 * cores, reads.shape[0])
+    dt = run(k, cores)  # also warms page tables
+    while dt < budget_s / 2 and k < reads.shape[0]:  # grow the sample until it is ~budget_s of wall time
+        k = min(reads.shape[0], max(k + 1, int(k * min(8.0, 0.9 * budget_s / max(dt, 1e-3)))))
+        dt = run(k, cores)
     cells = k * n * chunk.shape[0]
     return {"value": cells / dt, "unit": "DP cells/s", "cores": cores, "kind": "port",
             "pairs_per_s": k / dt,
@@ -251,7 +251,7 @@ def main():
                          "algorithmic_bytes_per_launch": abytes,
                          "cells_per_s_kernel": pairs_per_launch * READ_LEN * CHUNK_LEN / (fill_avg_ms * 1e-3)},
         }
-        if not args.no_cpu and args.series == "affine":
+        if not args.no_cpu and args.series == "affine" and world == 1:
             out["cpu_baseline"] = cpu_baseline(reads_h, chunk_h, align.HumanChimpTwoScoreMatrix)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if args.series != "affine":

@@ -27,7 +27,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
-#include <malloc.h>
 
 #define OR_OK 0
 #define OR_EINVAL 1  /* reference would hang / panic on this input (empty seq, base >= 5, bad index) */
@@ -42,6 +41,33 @@ typedef struct {
 
 static const int64_t VNN = INT64_MIN / 2; /* align/align.go:8 veryNegNum */
 
+/* Per-thread arena used by the batch driver: the reference allocates its work arrays per call (affineGap.go:20-54,:99);
+ * with hundreds of worker threads that turns into page-fault / mmap-lock contention which would understate the CPU
+ * baseline, so the workers recycle one zero-filled arena per pair instead (the reference's own engine recycles its
+ * buffers the same way, affineGap_highMem.go:29-55).  Outside the batch driver plain calloc/free are used. */
+static __thread char *tl_base = NULL;
+static __thread size_t tl_cap = 0, tl_used = 0;
+static __thread int tl_on = 0;
+
+static void *xcalloc(size_t n, size_t sz) {
+    size_t bytes = (n * sz + 63) & ~(size_t)63;
+    if (tl_on && tl_used + bytes <= tl_cap) {
+        void *p = tl_base + tl_used;
+        tl_used += bytes;
+        memset(p, 0, n * sz);
+        return p;
+    }
+    return calloc(n ? n : 1, sz ? sz : 1);
+}
+static int in_arena(const void *p) { return tl_base && (const char *)p >= tl_base && (const char *)p < tl_base + tl_cap; }
+static void xfree(void *p) { if (p && !in_arena(p)) free(p); }
+static void *xrealloc(void *p, size_t old_bytes, size_t new_bytes) {
+    if (p && !in_arena(p)) return realloc(p, new_bytes);
+    void *q = xcalloc(1, new_bytes);
+    if (q && p) memcpy(q, p, old_bytes);
+    return q;
+}
+
 /* align/align.go:76-84 */
 static inline int64_t tmt(int64_t a, int64_t b, int64_t c, uint8_t *k) {
     if (a >= b && a >= c) { *k = 0; return a; }
@@ -54,13 +80,13 @@ typedef struct { or_cigar *v; int64_t len, cap; } route_t;
 
 static int route_init(route_t *r) { /* route := make([]Cigar, 1) */
     r->cap = 16; r->len = 1;
-    r->v = (or_cigar *)calloc((size_t)r->cap, sizeof(or_cigar));
+    r->v = (or_cigar *)xcalloc((size_t)r->cap, sizeof(or_cigar));
     return r->v ? OR_OK : OR_ENOMEM;
 }
 static int route_append(route_t *r, int64_t run, uint8_t op) {
     if (r->len == r->cap) {
         int64_t nc = r->cap * 2;
-        or_cigar *nv = (or_cigar *)realloc(r->v, (size_t)nc * sizeof(or_cigar));
+        or_cigar *nv = (or_cigar *)xrealloc(r->v, (size_t)r->cap * sizeof(or_cigar), (size_t)nc * sizeof(or_cigar));
         if (!nv) return OR_ENOMEM;
         memset(nv + r->cap, 0, (size_t)(nc - r->cap) * sizeof(or_cigar));
         r->v = nv; r->cap = nc;
@@ -106,7 +132,7 @@ typedef struct {
     int64_t *prep_j[3];            /* [k][idx*(n+1)+i]  trace_prep_j */
 } aff_prep;
 
-static void aff_prep_free(aff_prep *p) { for (int k = 0; k < 3; k++) { free(p->prep_i[k]); free(p->prep_j[k]); } }
+static void aff_prep_free(aff_prep *p) { for (int k = 0; k < 3; k++) { xfree(p->prep_i[k]); xfree(p->prep_j[k]); } }
 
 /* Step 1.  align/affineGap.go:151-207 (+ initAffineScoring :20-39) */
 static int aff_highest_score(const uint8_t *alpha, int64_t n, const uint8_t *beta, int64_t m, const int64_t *sc,
@@ -117,9 +143,9 @@ static int aff_highest_score(const uint8_t *alpha, int64_t n, const uint8_t *bet
     p->n = n; p->m = m; p->ci = ci; p->cj = cj; p->ni = n / ci + 1; p->nj = m / cj + 1;
     for (int k = 0; k < 3; k++) { cur[k] = prev[k] = NULL; }
     for (int k = 0; k < 3; k++) {
-        cur[k] = (int64_t *)calloc((size_t)(m + 1), 8); prev[k] = (int64_t *)calloc((size_t)(m + 1), 8);
-        p->prep_i[k] = (int64_t *)calloc((size_t)(p->ni * (m + 1)), 8);
-        p->prep_j[k] = (int64_t *)calloc((size_t)(p->nj * (n + 1)), 8);
+        cur[k] = (int64_t *)xcalloc((size_t)(m + 1), 8); prev[k] = (int64_t *)xcalloc((size_t)(m + 1), 8);
+        p->prep_i[k] = (int64_t *)xcalloc((size_t)(p->ni * (m + 1)), 8);
+        p->prep_j[k] = (int64_t *)xcalloc((size_t)(p->nj * (n + 1)), 8);
         if (!cur[k] || !prev[k] || !p->prep_i[k] || !p->prep_j[k]) rc = OR_ENOMEM;
     }
     if (rc) goto done;
@@ -158,7 +184,7 @@ static int aff_highest_score(const uint8_t *alpha, int64_t n, const uint8_t *bet
     }
     { uint8_t d; *score = tmt(cur[0][m], cur[1][m], cur[2][m], &d); }
 done:
-    for (int k = 0; k < 3; k++) { free(cur[k]); free(prev[k]); }
+    for (int k = 0; k < 3; k++) { xfree(cur[k]); xfree(prev[k]); }
     if (rc) aff_prep_free(p);
     return rc;
 }
@@ -177,7 +203,7 @@ int or_affine_gap_checkersize(const uint8_t *alpha, int64_t n, const uint8_t *be
     uint8_t *trace[3] = {0, 0, 0};
     int64_t *cur[3] = {0, 0, 0}, *prev[3] = {0, 0, 0};
     route_t route; route.v = NULL;
-    for (int k = 0; k < 3; k++) { trace[k] = (uint8_t *)calloc((size_t)(tsi * tsj), 1); if (!trace[k]) rc = OR_ENOMEM; }
+    for (int k = 0; k < 3; k++) { trace[k] = (uint8_t *)xcalloc((size_t)(tsi * tsj), 1); if (!trace[k]) rc = OR_ENOMEM; }
     if (!rc) rc = route_init(&route);
     int64_t routeIdx = 0;
     int64_t i_min = -2, j_min = -2;
@@ -186,8 +212,8 @@ int or_affine_gap_checkersize(const uint8_t *alpha, int64_t n, const uint8_t *be
     while (!rc && k1 >= 0 && k2 >= 0) {
         /* ---- Step 2: fillTraceback_affineGap :219-273 ---- */
         for (int k = 0; k < 3; k++) {
-            free(cur[k]); free(prev[k]);
-            cur[k] = (int64_t *)calloc((size_t)(m + 1), 8); prev[k] = (int64_t *)malloc((size_t)(m + 1) * 8);
+            xfree(cur[k]); xfree(prev[k]);
+            cur[k] = (int64_t *)xcalloc((size_t)(m + 1), 8); prev[k] = (int64_t *)xcalloc((size_t)(m + 1), 8);
             if (!cur[k] || !prev[k]) { rc = OR_ENOMEM; break; }
             memcpy(prev[k], P.prep_i[k] + k1 * (m + 1), (size_t)(m + 1) * 8);
         }
@@ -244,9 +270,9 @@ int or_affine_gap_checkersize(const uint8_t *alpha, int64_t n, const uint8_t *be
         if (i_min != -1 && j_min == -1) rc = last_cigar(n, m, &route, &routeIdx, 2);
         else if (i_min == -1 && j_min != -1) rc = last_cigar(n, m, &route, &routeIdx, 1);
     }
-    for (int k = 0; k < 3; k++) { free(trace[k]); free(cur[k]); free(prev[k]); }
+    for (int k = 0; k < 3; k++) { xfree(trace[k]); xfree(cur[k]); xfree(prev[k]); }
     aff_prep_free(&P);
-    if (rc) { free(route.v); return rc; }
+    if (rc) { xfree(route.v); return rc; }
     route_reverse(&route);
     *out_score = score; *out_ops = route.v; *out_nops = route.len;
     return OR_OK;
@@ -269,10 +295,10 @@ int or_const_gap_checkersize(const uint8_t *alpha, int64_t n, const uint8_t *bet
     if (!bases_ok(alpha, n) || !bases_ok(beta, m)) return OR_EINVAL;
     int rc = OR_OK;
     const int64_t ni = n / ci + 1, nj = m / cj + 1;
-    int64_t *cur = (int64_t *)calloc((size_t)(m + 1), 8), *prev = (int64_t *)calloc((size_t)(m + 1), 8);
-    int64_t *prep_i = (int64_t *)calloc((size_t)(ni * (m + 1)), 8), *prep_j = (int64_t *)calloc((size_t)(nj * (n + 1)), 8);
+    int64_t *cur = (int64_t *)xcalloc((size_t)(m + 1), 8), *prev = (int64_t *)xcalloc((size_t)(m + 1), 8);
+    int64_t *prep_i = (int64_t *)xcalloc((size_t)(ni * (m + 1)), 8), *prep_j = (int64_t *)xcalloc((size_t)(nj * (n + 1)), 8);
     const int64_t tsi = imin(n, ci), tsj = imin(m, cj);
-    uint8_t *trace = (uint8_t *)calloc((size_t)(tsi * tsj), 1);
+    uint8_t *trace = (uint8_t *)xcalloc((size_t)(tsi * tsj), 1);
     route_t route; route.v = NULL;
     if (!cur || !prev || !prep_i || !prep_j || !trace) rc = OR_ENOMEM;
     if (!rc) rc = route_init(&route);
@@ -347,8 +373,8 @@ int or_const_gap_checkersize(const uint8_t *alpha, int64_t n, const uint8_t *bet
         if (i_min != -1 && j_min == -1) rc = last_cigar(n, m, &route, &routeIdx, 2);
         else if (i_min == -1 && j_min != -1) rc = last_cigar(n, m, &route, &routeIdx, 1);
     }
-    free(cur); free(prev); free(prep_i); free(prep_j); free(trace);
-    if (rc) { free(route.v); return rc; }
+    xfree(cur); xfree(prev); xfree(prep_i); xfree(prep_j); xfree(trace);
+    if (rc) { xfree(route.v); return rc; }
     route_reverse(&route);
     *out_score = score; *out_ops = route.v; *out_nops = route.len;
     return OR_OK;
@@ -373,8 +399,8 @@ int or_affine_gap_highmem(const uint8_t *alpha, int64_t n, const uint8_t *beta, 
     int64_t *cur[3], *prev[3]; uint8_t *trace[3];
     const int64_t W = m + 1;
     for (int k = 0; k < 3; k++) {
-        cur[k] = (int64_t *)calloc((size_t)W, 8); prev[k] = (int64_t *)calloc((size_t)W, 8);
-        trace[k] = (uint8_t *)calloc((size_t)((n + 1) * W), 1);
+        cur[k] = (int64_t *)xcalloc((size_t)W, 8); prev[k] = (int64_t *)xcalloc((size_t)W, 8);
+        trace[k] = (uint8_t *)xcalloc((size_t)((n + 1) * W), 1);
         if (!cur[k] || !prev[k] || !trace[k]) rc = OR_ENOMEM;
     }
     route_t route; route.v = NULL;
@@ -421,8 +447,8 @@ int or_affine_gap_highmem(const uint8_t *alpha, int64_t n, const uint8_t *beta, 
             if (rc) break;
         }
     }
-    for (int k = 0; k < 3; k++) { free(cur[k]); free(prev[k]); free(trace[k]); }
-    if (rc) { free(route.v); return rc; }
+    for (int k = 0; k < 3; k++) { xfree(cur[k]); xfree(prev[k]); xfree(trace[k]); }
+    if (rc) { xfree(route.v); return rc; }
     route_reverse(&route);
     *out_score = maxScore; *out_ops = route.v; *out_nops = route.len;
     return OR_OK;
@@ -435,8 +461,8 @@ int or_const_gap_highmem(const uint8_t *alpha, int64_t n, const uint8_t *beta, i
     if (!bases_ok(alpha, n) || !bases_ok(beta, m)) return OR_EINVAL;
     int rc = OR_OK;
     const int64_t W = m + 1;
-    int64_t *cur = (int64_t *)calloc((size_t)W, 8), *prev = (int64_t *)calloc((size_t)W, 8);
-    uint8_t *trace = (uint8_t *)calloc((size_t)((n + 1) * W), 1);
+    int64_t *cur = (int64_t *)xcalloc((size_t)W, 8), *prev = (int64_t *)xcalloc((size_t)W, 8);
+    uint8_t *trace = (uint8_t *)xcalloc((size_t)((n + 1) * W), 1);
     route_t route; route.v = NULL;
     if (!cur || !prev || !trace) rc = OR_ENOMEM;
     if (!rc) rc = route_init(&route);
@@ -466,8 +492,8 @@ int or_const_gap_highmem(const uint8_t *alpha, int64_t n, const uint8_t *beta, i
             if (rc) break;
         }
     }
-    free(cur); free(prev); free(trace);
-    if (rc) { free(route.v); return rc; }
+    xfree(cur); xfree(prev); xfree(trace);
+    if (rc) { xfree(route.v); return rc; }
     route_reverse(&route);
     *out_score = score; *out_ops = route.v; *out_nops = route.len;
     return OR_OK;
@@ -506,11 +532,29 @@ static int run_one(batch_ctx *c, int64_t p) {
 
 static void *worker(void *arg) {
     batch_ctx *c = (batch_ctx *)arg;
+    /* arena sized for the largest pair of the batch: 3 trace planes + prep arrays + rows, see the functions above */
+    size_t need = 1 << 20;
+    for (int64_t p = 0; p < c->n_pairs; p++) {
+        const int64_t n = c->a_off[p + 1] - c->a_off[p], m = c->b_off[p + 1] - c->b_off[p];
+        const int64_t ti = (c->mode <= 1) ? (n < c->ci ? n : c->ci) : n + 1, tj = (c->mode <= 1) ? (m < c->cj ? m : c->cj) : m + 1;
+        const int64_t ni = (c->mode <= 1) ? n / c->ci + 1 : 0, nj = (c->mode <= 1) ? m / c->cj + 1 : 0;
+        size_t b = (size_t)(3 * ti * tj) + (size_t)(3 * 8 * (ni * (m + 1) + nj * (n + 1))) + (size_t)(16 * 8 * (m + 1)) + (1 << 16);
+        if (b > need) need = b;
+    }
+    if (need <= ((size_t)1 << 30)) { tl_base = (char *)malloc(need); tl_cap = tl_base ? need : 0; }
     for (;;) {
         int64_t p = __sync_fetch_and_add(&c->next, 1);
         if (p >= c->n_pairs) break;
+        tl_used = 0; tl_on = (tl_base != NULL);
         c->rcs[p] = run_one(c, p);
+        tl_on = 0;
+        if (c->rcs[p] == 0 && in_arena(c->ops[p])) { /* the route lives in the arena: move it out */
+            or_cigar *keep = (or_cigar *)malloc((size_t)(c->nops[p] > 0 ? c->nops[p] : 1) * sizeof(or_cigar));
+            if (!keep) c->rcs[p] = OR_ENOMEM; else memcpy(keep, c->ops[p], (size_t)c->nops[p] * sizeof(or_cigar));
+            c->ops[p] = keep;
+        }
     }
+    free(tl_base); tl_base = NULL; tl_cap = 0;
     return NULL;
 }
 
@@ -525,12 +569,6 @@ int or_align_batch(int mode, const int64_t *sc, int64_t gap_open, int64_t gap_ex
     c.rcs = (int *)calloc((size_t)(n_pairs > 0 ? n_pairs : 1), sizeof(int));
     if (!c.ops || !c.nops || !c.rcs) { free(c.ops); free(c.nops); free(c.rcs); return OR_ENOMEM; }
     if (n_threads < 1) n_threads = 1;
-    /* keep the per-call work arrays (the reference allocates them per call, affineGap.go:20-54,:99) inside the
-     * malloc arenas instead of mmap/munmap-ing ~5 MB per pair: with many threads the kernel's mmap lock would
-     * otherwise serialise the workers, which would understate the CPU baseline. */
-    mallopt(M_MMAP_THRESHOLD, 1 << 30);
-    mallopt(M_TRIM_THRESHOLD, 1 << 30);
-    mallopt(M_ARENA_MAX, 256);
     if (n_threads == 1) worker(&c);
     else {
         pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
