@@ -52,7 +52,18 @@ struct PairPlan {
     int64_t hcol_off;   // ints
     int64_t rowbuf_off; // int2
     int64_t dcol_off;   // dwords: per strip and lane one word with the last-column direction fields of the lane's R rows
+    // fast path (short alpha) / window re-fill:
+    int32_t src;        // index of the pair in the a_start / b_start tables (== own index except for window plans)
+    int32_t col_off;    // first column of a window re-fill minus one (0 = whole matrix); multiple of CKW
+    int64_t ckpt_off;   // int2: column checkpoints of the pair, [c-1][row] for column c*CKW
+    int64_t rowi_off;   // dwords: I-plane of row n (one word per 16 steps of the owner lane)
 };
+
+constexpr int CKW = 128;     // column checkpoint spacing of the fast path
+constexpr int FP_SPAN = 192; // a re-fill window is at least this wide (>= 160 rows + typical indels)
+constexpr int FP_PLANES = 3; // rows n, n-1, n-2 keep their I-plane: a trailing gap sits on row n-d when the last d bases match the chunk end
+constexpr int FP_CAP = 64;   // CIGAR runs staged per pair on the fast path (more -> general path)
+constexpr int FP_WWORDS = (FP_SPAN + CKW + 15 + 15) / 16 + 1; // direction words of the widest window
 
 struct KParams {
     int sc4[25]; // 4*scores
@@ -89,12 +100,16 @@ template <bool P16> struct ProfCfg {
     static constexpr int PST = 5 * BST + 16;         // dwords per pair
 };
 
-template <bool LOCAL, bool MULTI, bool P16, bool HFORM>
+template <bool LOCAL, bool MULTI, bool P16, bool HFORM, int FP>
 __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                          const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                          const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                          KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
-                                                         int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int *__restrict__ err) {
+                                                         int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int2 *__restrict__ ckpt,
+                                                         unsigned *__restrict__ rowi, int *__restrict__ err) {
+    // FP = -1: record the full direction matrix (general path and window re-fills).
+    // FP = (n-1) % R: fast-path forward sweep -- no per-cell recording; keeps the I-plane of row n (register
+    //      rt[FP] of the owner lane), a column checkpoint {rt, X} of every row each CKW columns, and h(n,m).
     using PC = ProfCfg<P16>;
     constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
     __shared__ int lds[32 + 4 * PST];
@@ -112,9 +127,9 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const int p = pbase + g;
     const bool valid = p < n_pairs;
     PairPlan pl;
-    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; }
-    const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; }
+    const uint8_t *ap = a_buf + (valid ? a_start[pl.src] : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[pl.src] + pl.col_off : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4;
     // h-form carries X = h + e instead of h (XE = e): then I+e and D+e are one 2-cycle `and` + one 2-cycle add
@@ -157,22 +172,30 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             }
             __syncthreads();
         }
+        const int2 *ck0 = nullptr; // window re-fill: left boundary = column checkpoint col_off / CKW
+        if (FP < 0 && pl.col_off > 0) ck0 = ckpt + pl.ckpt_off + (int64_t)(pl.col_off / CKW - 1) * pl.n;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = row0 + r + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
             const int D1c = kp.d00_4 + i * kp.ecol4 + 1;
             hold[r] = max3i(NEG4 + 3, NEG4 + 2, D1c) + XE;
             rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + 2 + E4, D1c + OE4);
-            acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
+            if (FP < 0 && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x; hold[r] = v.y; }
+            if (FP < 0) { acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0; }
         }
+        unsigned accR[FP_PLANES] = {0u, 0u, 0u}; // fast path: I-planes of rows n-d, registers rt[(FP - d) mod R]
         int diag0 = ((row0 == 0) ? max3i(3, kp.o4 + 2, kp.d00_4 + 1) : max3i(NEG4 + 3, NEG4 + 2, kp.d00_4 + row0 * kp.ecol4 + 1)) + XE;
+        if (FP < 0 && ck0) {
+            if (row0 == 0) diag0 = max3i(NEG4 + 3, kp.o4 + pl.col_off * E4 + 2, NEG4 + 1) + XE; // h(0, col_off)
+            else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y;
+        }
         int dn_out = 0, h_out = 0, b_out = 0;
         int sq_dn = 0, sq_h = 0;
         // boundary queues (row above the strip + beta): lane u holds column t0+u+1 of the current 16-step block
         int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
         auto boundary = [&](int c, int &odn, int &oh, int &ob) {
             if (!MULTI || s == 0) {
-                const int M3 = NEG4 + 3, I2 = kp.o4 + c * E4 + 2, D1 = NEG4 + 1; // row 0: I(0,c) = gapOpen + c*gapExtend
+                const int M3 = NEG4 + 3, I2 = kp.o4 + (pl.col_off + c) * E4 + 2, D1 = NEG4 + 1; // row 0: I(0,c) = gapOpen + c*gapExtend
                 const int h0 = max3i(M3, I2, D1);
                 odn = (LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4);
                 oh = h0 + XE;
@@ -188,8 +211,9 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         boundary(l + 1, qdn, qh, qb);
 
         // one anti-diagonal step; CHECK=false is the steady state (every lane of the wave has a live column)
-        auto step = [&](const int t, auto chk) {
+        auto step = [&](const int t, auto chk, auto ckt) {
             constexpr bool CHECK = decltype(chk)::value;
+            constexpr bool CKPT = decltype(ckt)::value; // this block may cross a checkpoint column
             const int up_dn = dpp_shr1(qdn, dn_out);
             const int up_h = dpp_shr1(qh, h_out);
             const int pb = dpp_shr1(qb, b_out);
@@ -209,9 +233,14 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                     int S4;
                     if (P16) S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
                     else S4 = w[r];
-                    acc[r] = alignbit2((unsigned)hd, acc[r]);
-                    acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
-                    acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
+                    if (FP < 0) {
+                        acc[r] = alignbit2((unsigned)hd, acc[r]);
+                        acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
+                        acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < FP_PLANES; d++) if (r == (FP - d + R) % R) accR[d] = alignbit2((unsigned)rt[r], accR[d]);
+                    }
                     int hnew, dnn; // hnew is in the X domain (h + XE)
                     if (HFORM) {
                         const int M3e = (hd | 3) + S4;             // M + e
@@ -239,23 +268,47 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 diag0 = up_h;
                 dn_out = dnu;
                 h_out = hold[R - 1];
+                if (FP >= 0 && CKPT && (j & (CKW - 1)) == 0 && j < m_eff && gact) { // column checkpoint
+                    int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n + row0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) if (row0 + r < pl.n) ck[r] = make_int2(rt[r], hold[r]);
+                }
             }
             if (MULTI) { sq_dn = dpp_shl1(dn_out, sq_dn); sq_h = dpp_shl1(h_out, sq_h); }
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
             boundary(t0 + 16 + l + 1, ndn, nh, nb); // prefetch the next block's boundary
-            if (t0 >= 16 && t0 + 16 <= m_min) {
+            // the lanes' columns of this block are t0-14 .. t0+16: only blocks containing a multiple of CKW checkpoint
+            const bool ckblk = FP >= 0 && ((t0 + 16) & (CKW - 1)) <= 30;
+            const bool steady = t0 >= 16 && t0 + 16 <= m_min;
+            if (steady && !ckblk) {
 #pragma unroll 2
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{}, std::false_type{});
+            } else if (steady) {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{}, std::true_type{});
+            } else if (FP >= 0) {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{}, std::true_type{});
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{}, std::false_type{});
             }
             qdn = ndn; qh = nh; qb = nb;
             // flush 16 steps of direction bits: word w of this strip
             const int w = t0 >> 4;
-            if (gact && w < pl.words) {
+            if (FP >= 0) {
+                if (gact && w < pl.words) {
+                    const int miss = (t0 + 16 - l) - m_eff;
+                    const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+#pragma unroll
+                    for (int d = 0; d < FP_PLANES; d++) {
+                        accR[d] >>= sh;
+                        if (pl.n - 1 - d >= 0 && l == (pl.n - 1 - d) / R) rowi[pl.rowi_off + (int64_t)d * pl.words + w] = accR[d]; // owner lane of row n-d
+                    }
+                }
+            } else if (gact && w < pl.words) {
                 const int miss = (t0 + 16 - l) - m_eff; // steps this lane sat idle after its last column
                 const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
                 if (t0 + 16 > m_min) { // drain: a lane that finished early right-aligns its last fields (it never shifts again)
@@ -272,7 +325,9 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + c] = make_int2(sq_dn, sq_h);
             }
         }
-        if (gact && m_eff >= 1) {
+        if (FP >= 0) {
+            if (gact && m_eff >= 1 && row0 + FP == pl.n - 1) hcol[pl.hcol_off] = hold[FP >= 0 ? FP : 0] - XE; // h(n, m) only
+        } else if (gact && m_eff >= 1) {
 #pragma unroll
             for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r] - XE;
             // last-column D-plane fields of this lane's rows, packed (field r at bits 2r): lets the traceback skip
@@ -316,7 +371,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     const int p = pbase + g;
     const bool valid = p < n_pairs;
     PairPlan pl;
-    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; }
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
     const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
@@ -488,13 +543,14 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
             else { score = tp.d00 + (int64_t)i * tp.ecol; k = 2; }
         } else { score = (int64_t)(i + j) * tp.gap_open; k = 0; }
     }
-    if (!WRITE) score_out[p] = score;
+    const int po = pl.src; // output slot (== p except for sub-batches routed here by the fast path)
+    if (!WRITE) score_out[po] = score;
 
     int64_t cnt = 0;           // runs emitted so far (traceback order)
     int cur_op = -1;
     int64_t cur_run = 0;
-    const int64_t total = WRITE ? nops[p] : 0;
-    const int64_t obase = WRITE ? ops_off[p] : 0;
+    const int64_t total = WRITE ? nops[po] : 0;
+    const int64_t obase = WRITE ? ops_off[po] : 0;
     const bool fits = WRITE ? (obase + total <= ops_capacity) : false;
     auto flush_run = [&]() {
         if (cur_op >= 0) {
@@ -607,8 +663,168 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
         else { cur_op = 0; cur_run = 0; } // Go: route == [{0 0}]
     }
     flush_run();
-    if (!WRITE) nops[p] = cnt;
+    if (!WRITE) nops[po] = cnt;
     else if (!fits) atomicOr(err, 4);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Fast path (alpha fits one strip, global affine, gapOpen <= 0): traceback by stages.
+//   fp_walk: one lane per pair.  On row n in state I it follows the stored I-plane of row n (the long trailing
+//   gap of a short read against a long chunk) a word at a time; anywhere else it needs full direction bits and
+//   requests a re-fill of the <= FP_SPAN+CKW-1 columns left of the current cell from the nearest column
+//   checkpoint (window plan appended to a list), which fill_affine_kernel<.., FP=-1> computes with the normal
+//   recording; the next fp_walk call continues inside that window.  Row 0 / column 0 end the walk (Step 4).
+//   CIGAR runs are staged per pair in traceback order and reversed into place by fp_compact.
+// Same checkerboard-walk emulation (Q1/Q2) as traceback_kernel.
+// ------------------------------------------------------------------------------------------------------
+struct FpState {
+    int32_t i, j, k, last_op;
+    int32_t cur_op, cnt, status, slot; // status 0 = needs a window, 1 = done; slot = window slot of the last request
+    int64_t cur_run;
+    int64_t li;
+    int32_t j_hi, jc_lo;
+};
+
+template <bool FIRST>
+__global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
+                                                     FpState *__restrict__ states, const int *__restrict__ hcol_fwd,
+                                                     const unsigned *__restrict__ rowi, const int2 *__restrict__ ckpt,
+                                                     const PairPlan *__restrict__ wplans, const uint4 *__restrict__ wtrace,
+                                                     const int *__restrict__ whcol, TbParams tp, gnx_cigar *__restrict__ stage,
+                                                     int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                     int *__restrict__ next_active, int *__restrict__ next_count,
+                                                     PairPlan *__restrict__ next_wplans, int *__restrict__ err) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_active) return;
+    const int p = FIRST ? a : active[a];
+    const PairPlan pl = plans[p];
+    FpState st;
+    PairPlan wp;
+    if (FIRST) {
+        const int hc = hcol_fwd[pl.hcol_off];
+        score_out[p] = (int64_t)(hc >> 2);
+        st.i = pl.n; st.j = pl.m; st.k = 3 - (hc & 3); st.last_op = -1;
+        st.cur_op = -1; st.cnt = 0; st.status = 0; st.slot = -1; st.cur_run = 0;
+        st.li = (int64_t)(pl.n - 1) % tp.ci;
+        st.j_hi = 0; st.jc_lo = 0; // empty window
+        wp = pl;
+    } else {
+        st = states[p];
+        wp = wplans[a];
+    }
+    int i = st.i, j = st.j, k = st.k, last_op = st.last_op, cur_op = st.cur_op, cnt = st.cnt;
+    int64_t cur_run = st.cur_run, li = st.li;
+    gnx_cigar *stg = stage + (int64_t)p * FP_CAP;
+    auto flush_run = [&]() {
+        if (cur_op >= 0) {
+            if (cnt < FP_CAP) { gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op; for (int z = 0; z < 7; z++) c._pad[z] = 0; stg[cnt] = c; }
+            cnt++;
+        }
+    };
+    auto emit = [&](int op, int64_t run) {
+        if (op == cur_op) cur_run += run;
+        else { flush_run(); cur_op = op; cur_run = run; }
+    };
+    bool done = false;
+    while (true) {
+        if (i == 0 || j == 0) { done = true; break; }
+        unsigned w;
+        int pos;
+        const bool on_plane = (k == 1) && (pl.n - i) < FP_PLANES;
+        if (on_plane) { // stored I-plane of row n-d
+            const int t1 = j + (i - 1) / R - 1;
+            w = rowi[pl.rowi_off + (int64_t)(pl.n - i) * pl.words + (t1 >> 4)];
+            pos = t1 & 15;
+        } else if (j > st.jc_lo && j <= st.j_hi) { // inside the current window
+            w = load_word<true>(wtrace, wp, k, i, j - st.jc_lo, pos);
+        } else break; // needs a (new) window
+        int tag = (int)((w >> (2 * pos)) & 3u);
+        if (tag == 0) { atomicOr(err, 2); done = true; break; }
+        if (k == 1) {
+            int avail = min(pos + 1, j);
+            if (!on_plane) avail = min(avail, j - st.jc_lo); // do not run past the window's left edge
+            unsigned x = w ^ 0xAAAAAAAAu;
+            if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
+            const int lowcut = pos + 1 - avail;
+            if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+            int steps;
+            if (x == 0) steps = avail;
+            else {
+                const int pnz = (31 - __clz((int)x)) >> 1;
+                tag = (int)((w >> (2 * pnz)) & 3u);
+                if (tag == 0) { atomicOr(err, 2); done = true; break; }
+                steps = pos - pnz + 1;
+                k = 3 - tag;
+            }
+            emit(1, steps); j -= steps; last_op = 1;
+            continue;
+        }
+        emit(k, 1);
+        last_op = k;
+        bool up_exit = false;
+        if (k != 1) { up_exit = (li == 0); li = up_exit ? tp.ci - 1 : li - 1; i--; }
+        if (k != 2) j--;
+        k = 3 - tag;
+        if (up_exit && i > 0 && j > 0) { // quirk Q1: restart in the argmax state of the entry cell (i, j)
+            int ht;
+            if (j == st.jc_lo) ht = ckpt[pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n + (i - 1)].y & 3; // a checkpoint column
+            else if (j < st.j_hi) { int p2; ht = (int)((load_word<true>(wtrace, wp, 0, i + 1, j + 1 - st.jc_lo, p2) >> (2 * p2)) & 3u); }
+            else ht = whcol[wp.hcol_off + i - 1] & 3;
+            k = 3 - ht;
+        }
+    }
+    if (done) {
+        // Step 4 (affineGap.go:135-139)
+        const bool up_exit = (last_op != 1) && ((int64_t)i % tp.ci == 0);
+        const bool left_exit = (last_op != 2) && ((int64_t)j % tp.cj == 0);
+        if (!up_exit && left_exit) emit(2, i);
+        else if (up_exit && !left_exit) emit(1, j);
+        flush_run();
+        cur_op = -1;
+        nops[p] = cnt;
+        if (cnt > FP_CAP) atomicOr(err, 8);
+        st.status = 1;
+    } else {
+        // request the window (jc_lo, j] : at least FP_SPAN wide, starting on a checkpoint column (or column 0)
+        const int slot = atomicAdd(next_count, 1);
+        int jc = j - FP_SPAN;
+        jc = jc <= 0 ? 0 : (jc / CKW) * CKW;
+        st.j_hi = j; st.jc_lo = jc; st.slot = slot; st.status = 0;
+        next_active[slot] = p;
+        PairPlan q;
+        q.n = pl.n; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = 1;
+        q.trace_off = (int64_t)slot * FP_WWORDS * QA * G; q.hcol_off = (int64_t)slot * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)slot * G;
+        q.src = pl.src; q.col_off = jc; q.ckpt_off = pl.ckpt_off; q.rowi_off = 0;
+        next_wplans[slot] = q;
+    }
+    st.i = i; st.j = j; st.k = k; st.last_op = last_op; st.cur_op = cur_op; st.cnt = cnt; st.cur_run = cur_run; st.li = li;
+    states[p] = st;
+}
+
+// stragglers (the path keeps needing windows): plans for a full-trace pass over those pairs, outputs indexed by src
+__global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
+                                                                  int max_words, FpState *__restrict__ states, PairPlan *__restrict__ out) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_active) return;
+    const int p = active[a];
+    const PairPlan pl = plans[p];
+    PairPlan q = pl;
+    q.strips = 1; q.trace_off = (int64_t)a * max_words * QA * G; q.hcol_off = (int64_t)a * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)a * G;
+    q.src = p; q.col_off = 0;
+    out[a] = q;
+    states[p].status = 2; // staged runs are void
+}
+
+__global__ __launch_bounds__(256) void fp_compact_kernel(int n_pairs, const FpState *__restrict__ states, const gnx_cigar *__restrict__ stage, const int64_t *__restrict__ nops,
+                                                          const int64_t *__restrict__ ops_off, gnx_cigar *__restrict__ ops, int64_t ops_capacity,
+                                                          int *__restrict__ err) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    if (states[p].status == 2) return; // written by the general traceback
+    const int64_t cnt = nops[p], base = ops_off[p];
+    if (base + cnt > ops_capacity) { atomicOr(err, 4); return; }
+    const int64_t m = cnt < FP_CAP ? cnt : FP_CAP;
+    for (int64_t x = 0; x < m; x++) ops[base + (cnt - 1 - x)] = stage[(int64_t)p * FP_CAP + x];
 }
 
 // exclusive scan of nops[0..n) + carry[0] -> off[0..n], off[n]; carry[0] = off[n] afterwards.  One block.
@@ -675,6 +891,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
+    DevBuf fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2];
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -738,6 +955,151 @@ int64_t max_abs_pen(const gnx_params *p, bool affine) {
     return mx;
 }
 
+// Fast path for batches of short-alpha global affine alignments (see fp_walk_kernel).  Returns GNX_OK, an error,
+// or -1 when the batch should go through the general path after all (workspace too small / staging overflow).
+int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
+                  const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
+                  const int64_t *h_alen, const int64_t *h_blen, int rstar,
+                  int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
+                  int64_t *out_total, hipStream_t stream) {
+    Ctx &c = g_ctx;
+    int rc;
+    const int np = (int)n_pairs;
+    std::vector<PairPlan> plans((size_t)n_pairs);
+    int64_t roff = 0, coff = 0, cells = 0;
+    for (int64_t p = 0; p < n_pairs; p++) {
+        PairPlan &pl = plans[(size_t)p];
+        const int64_t n = h_alen[p], m = h_blen[p];
+        pl.n = (int32_t)n; pl.m = (int32_t)m; pl.words = (int32_t)((m + 15 + 15) / 16); pl.strips = 1;
+        pl.trace_off = 0; pl.hcol_off = p; pl.rowbuf_off = 0; pl.dcol_off = 0;
+        pl.src = (int32_t)p; pl.col_off = 0; pl.ckpt_off = coff; pl.rowi_off = roff;
+        roff += (int64_t)FP_PLANES * pl.words; coff += ((m - 1) / CKW) * n; cells += n * m;
+    }
+    const size_t wtrace_b = (size_t)np * FP_WWORDS * QA * G * 16;
+    const size_t need = wtrace_b + (size_t)coff * 8 + (size_t)roff * 4 + (size_t)np * (FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + H * 4 + G * 4 + 32);
+    if ((int64_t)need > c.ws_limit) return -1;
+    if ((rc = c.trace.ensure(wtrace_b))) return rc;
+    if ((rc = c.hcol.ensure((size_t)np * (H + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then window hcol
+    if ((rc = c.dcol.ensure((size_t)np * G * 4))) return rc;
+    if ((rc = c.plans.ensure((size_t)np * sizeof(PairPlan)))) return rc;
+    if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
+    if ((rc = c.misc.ensure(64))) return rc;
+    if ((rc = c.fp_rowi.ensure((size_t)std::max<int64_t>(roff, 1) * 4))) return rc;
+    if ((rc = c.fp_ckpt.ensure((size_t)std::max<int64_t>(coff, 1) * 8))) return rc;
+    if ((rc = c.fp_states.ensure((size_t)np * sizeof(FpState)))) return rc;
+    if ((rc = c.fp_stage.ensure((size_t)np * FP_CAP * sizeof(gnx_cigar)))) return rc;
+    for (int x = 0; x < 2; x++) {
+        if ((rc = c.fp_wplans[x].ensure((size_t)np * sizeof(PairPlan)))) return rc;
+        if ((rc = c.fp_active[x].ensure((size_t)np * 4))) return rc;
+    }
+    int *d_err = reinterpret_cast<int *>(c.misc.p);
+    int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
+    int *d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(c.misc.p) + 32); // two window-request counters
+    HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
+    HIPCHK(hipMemcpyAsync(c.plans.p, plans.data(), (size_t)np * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
+    const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
+    int *d_hfwd = reinterpret_cast<int *>(c.hcol.p);
+    int *d_whcol = d_hfwd + np;
+    uint4 *d_wtrace = reinterpret_cast<uint4 *>(c.trace.p);
+    unsigned *d_wdcol = reinterpret_cast<unsigned *>(c.dcol.p);
+    unsigned *d_rowi = reinterpret_cast<unsigned *>(c.fp_rowi.p);
+    int2 *d_ckpt = reinterpret_cast<int2 *>(c.fp_ckpt.p);
+    FpState *d_st = reinterpret_cast<FpState *>(c.fp_states.p);
+    gnx_cigar *d_stage = reinterpret_cast<gnx_cigar *>(c.fp_stage.p);
+    int64_t *d_nops = reinterpret_cast<int64_t *>(c.nops.p);
+    PairPlan *d_wpl[2] = {reinterpret_cast<PairPlan *>(c.fp_wplans[0].p), reinterpret_cast<PairPlan *>(c.fp_wplans[1].p)};
+    int *d_act[2] = {reinterpret_cast<int *>(c.fp_active[0].p), reinterpret_cast<int *>(c.fp_active[1].p)};
+
+    double fill_ms = 0;
+    float f = 0;
+    const dim3 blockF(64), blockT(64);
+    HIPCHK(hipEventRecord(c.ev[0], stream));
+    {   // forward sweep
+        const dim3 gridF((unsigned)((np + 3) / 4));
+#define GNX_FPF(K_) case K_: hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, K_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, (uint4 *)nullptr, d_hfwd, (int2 *)nullptr, (unsigned *)nullptr, d_ckpt, d_rowi, d_err); break;
+        switch (rstar) { GNX_FPF(0) GNX_FPF(1) GNX_FPF(2) GNX_FPF(3) GNX_FPF(4) GNX_FPF(5) GNX_FPF(6) GNX_FPF(7) GNX_FPF(8) default: GNX_FPF(9) }
+#undef GNX_FPF
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c.ev[1], stream));
+    int cur = 0, n_act = 0, n_fill = 1;
+    hipLaunchKernelGGL(fp_walk_kernel<true>, dim3((unsigned)((np + 63) / 64)), blockT, 0, stream, dpl, (const int *)nullptr, np, d_st, d_hfwd, d_rowi, d_ckpt,
+                       (const PairPlan *)nullptr, d_wtrace, d_whcol, tp, d_stage, d_score, d_nops, d_act[0], d_cnt, d_wpl[0], d_err);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&n_act, d_cnt, 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipEventElapsedTime(&f, c.ev[0], c.ev[1]));
+    fill_ms += f;
+    const int max_it = getenv("GNX_FP_MAXIT") ? atoi(getenv("GNX_FP_MAXIT")) : 2;
+    while (n_act > 0 && n_fill <= max_it) {
+        const int nxt = cur ^ 1;
+        HIPCHK(hipMemsetAsync(d_cnt + nxt, 0, 4, stream));
+        HIPCHK(hipEventRecord(c.ev[1], stream));
+        hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1>), dim3((unsigned)((n_act + 3) / 4)), blockF, 0, stream, d_wpl[cur], n_act, d_a, d_as, d_b, d_bs, kp,
+                           d_wtrace, d_whcol, (int2 *)nullptr, d_wdcol, d_ckpt, (unsigned *)nullptr, d_err);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c.ev[2], stream));
+        hipLaunchKernelGGL(fp_walk_kernel<false>, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, stream, dpl, d_act[cur], n_act, d_st, d_hfwd, d_rowi, d_ckpt,
+                           d_wpl[cur], d_wtrace, d_whcol, tp, d_stage, d_score, d_nops, d_act[nxt], d_cnt + nxt, d_wpl[nxt], d_err);
+        HIPCHK(hipGetLastError());
+        int n_next = 0;
+        HIPCHK(hipMemcpyAsync(&n_next, d_cnt + nxt, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipEventElapsedTime(&f, c.ev[1], c.ev[2]));
+        fill_ms += f;
+        n_fill++;
+        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] iteration %d: %d windows filled in %.3f ms, %d pairs continue\n", n_fill - 1, n_act, f, n_next);
+        n_act = n_next;
+        cur = nxt;
+    }
+    int n_strag = 0, max_words = 1;
+    if (n_act > 0) {
+        // stragglers: full direction matrix for these pairs only (general kernels), counted here, written after the scan
+        n_strag = n_act;
+        for (int64_t p = 0; p < n_pairs; p++) max_words = std::max(max_words, (int)plans[(size_t)p].words);
+        const size_t sb = (size_t)n_strag * max_words * QA * G * 16;
+        if ((int64_t)sb > c.ws_limit) return -1;
+        if (sb > c.trace.cap) { if ((rc = c.trace.ensure(sb))) return rc; d_wtrace = reinterpret_cast<uint4 *>(c.trace.p); }
+        PairPlan *gpl = d_wpl[cur ^ 1];
+        hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_strag + 255) / 256)), dim3(256), 0, stream, dpl, d_act[cur], n_strag, max_words, d_st, gpl);
+        HIPCHK(hipEventRecord(c.ev[1], stream));
+        hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1>), dim3((unsigned)((n_strag + 3) / 4)), blockF, 0, stream, gpl, n_strag, d_a, d_as, d_b, d_bs, kp,
+                           d_wtrace, d_whcol, (int2 *)nullptr, d_wdcol, d_ckpt, (unsigned *)nullptr, d_err);
+        HIPCHK(hipEventRecord(c.ev[2], stream));
+        hipLaunchKernelGGL((traceback_kernel<true, false>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, stream, gpl, n_strag, d_wtrace, d_whcol, d_wdcol, tp, d_score, d_nops,
+                           (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipEventElapsedTime(&f, c.ev[1], c.ev[2]));
+        fill_ms += f;
+        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %d stragglers through the general kernels, fill %.3f ms\n", n_strag, f);
+    }
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, d_nops, np, d_ops_off, d_carry);
+    hipLaunchKernelGGL(fp_compact_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, d_st, d_stage, d_nops, d_ops_off, d_ops, ops_capacity, d_err);
+    if (n_strag > 0)
+        hipLaunchKernelGGL((traceback_kernel<true, true>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, stream, d_wpl[cur ^ 1], n_strag, d_wtrace, d_whcol, d_wdcol, tp, d_score, d_nops,
+                           d_ops_off, d_ops, ops_capacity, d_err);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c.ev[3], stream));
+    int h_misc[16];
+    HIPCHK(hipMemcpyAsync(h_misc, c.misc.p, 64, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    float tot = 0;
+    HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[3]));
+    c.timing.fill_ms = fill_ms; c.timing.traceback_ms = tot - fill_ms; c.timing.total_ms = tot;
+    c.timing.cells = cells; c.timing.n_launches = 1; c.timing.trace_bytes = (int64_t)coff * 8 + (int64_t)roff * 4;
+    int64_t total;
+    memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
+    if (out_total) *out_total = total;
+    const int ef = h_misc[0];
+    if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
+    if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
+    if (ef & 8) return -1; // a CIGAR with more than FP_CAP runs: redo on the general path
+    if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
+    (void)n_fill;
+    return GNX_OK;
+}
+
 // The device flow shared by all entry points.  All pointers are device pointers except h_*.
 int run_device(const gnx_params *prm, int64_t n_pairs,
                const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
@@ -757,8 +1119,25 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         if (out_total) *out_total = 0;
         return GNX_OK;
     }
-    // ---- plan ----
     const int64_t maxpen = max_abs_pen(prm, affine);
+    // ---- fast path: every alpha fits one strip, long beta, global affine with gapOpen <= 0 ----
+    {
+        const char *fpenv = getenv("GNX_FASTPATH");
+        bool fp = affine && !local && prm->gap_open <= 0 && !(fpenv && fpenv[0] == '0');
+        int rstar = -1;
+        for (int64_t p = 0; fp && p < n_pairs; p++) {
+            const int64_t n = h_alen[p], m = h_blen[p];
+            if (n < 1 || n > H || m < (fpenv && fpenv[0] == '2' ? 1 : 768) || m > 0x3fffffff) fp = false;
+            else if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) fp = false;
+            else if (rstar < 0) rstar = (int)((n - 1) % R);
+            else if (rstar != (int)((n - 1) % R)) fp = false;
+        }
+        if (fp) {
+            rc = run_device_fp(kp, tp, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, rstar, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+            if (rc != -1) return rc;
+        }
+    }
+    // ---- plan ----
     bool p16 = true; // 4*score fits a signed 16-bit profile entry
     for (int x = 0; x < 25; x++) if (prm->scores[x] > 8191 || prm->scores[x] < -8192) p16 = false;
     if (!getenv("GNX_FORCE_P16")) p16 = false; // int32 profile: plain 2-cycle VGPR add instead of a 4-cycle SDWA add
@@ -784,6 +1163,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) { set_err("pair %s%lld exceeds the int32 DP range", "", (long long)p); return GNX_ERANGE; }
             PairPlan &pl = plans[(size_t)p];
             pl.n = (int32_t)n; pl.m = (int32_t)m;
+            pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; // src is chunk-relative, set below
             pl.strips = (m > 0) ? (int32_t)((n + H - 1) / H) : 0;
             pl.words = (int32_t)((m + 15 + 15) / 16);
             const int64_t tsz = (int64_t)pl.strips * pl.words * Q * G;
@@ -805,6 +1185,8 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             cells += n * m;
         }
         chunk_begin.push_back(n_pairs);
+        for (size_t ch = 0; ch + 1 < chunk_begin.size(); ch++)
+            for (int64_t p = chunk_begin[ch]; p < chunk_begin[ch + 1]; p++) plans[(size_t)p].src = (int32_t)(p - chunk_begin[ch]);
     }
     // workspace sizes = max over chunks
     int64_t max_t = 1, max_h = 1, max_r = 1, max_d = 1;
@@ -849,7 +1231,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         bool multi = false;
         for (int64_t q2 = b; q2 < e; q2++) if (plans[(size_t)q2].strips > 1) { multi = true; break; }
         if (affine) {
-#define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err)
+#define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_, -1>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, (int2 *)nullptr, (unsigned *)nullptr, d_err)
 #define GNX_LAUNCH_AFF2(L_, M_, P_) do { if (hform) GNX_LAUNCH_AFF(L_, M_, P_, true); else GNX_LAUNCH_AFF(L_, M_, P_, false); } while (0)
             const int sel = (local ? 4 : 0) | (multi ? 2 : 0) | (p16 ? 1 : 0);
             switch (sel) {
@@ -997,7 +1379,8 @@ void gnx_shutdown(void) {
     if (!g_ctx.inited) return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
+    DevBuf *bufs[] = {&g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
+                      &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
                       &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 4; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }
