@@ -61,9 +61,11 @@ struct PairPlan {
 
 constexpr int CKW = 128;     // column checkpoint spacing of the fast path
 constexpr int FP_SPAN = 192; // a re-fill window is at least this wide (>= 160 rows + typical indels)
-constexpr int FP_PLANES = 3; // rows n, n-1, n-2 keep their I-plane: a trailing gap sits on row n-d when the last d bases match the chunk end
+constexpr int FP_PLANES = 4; // rows n .. n-3 keep their I-plane: a trailing gap sits on row n-d when the last d bases match the chunk end
 constexpr int FP_CAP = 64;   // CIGAR runs staged per pair on the fast path (more -> general path)
 constexpr int FP_WWORDS = (FP_SPAN + CKW + 15 + 15) / 16 + 1; // direction words of the widest window
+constexpr int FP_TILE = 1024;                                  // straggler tiles: columns (c*FP_TILE, (c+1)*FP_TILE]
+constexpr int FP_TWORDS = (FP_TILE + 15 + 15) / 16;            // direction words of a tile
 
 struct KParams {
     int sc4[25]; // 4*scores
@@ -100,7 +102,7 @@ template <bool P16> struct ProfCfg {
     static constexpr int PST = 5 * BST + 16;         // dwords per pair
 };
 
-template <bool LOCAL, bool MULTI, bool P16, bool HFORM, int FP>
+template <bool LOCAL, bool MULTI, bool P16, bool HFORM, int FP, bool WIN = false>
 __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                          const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                          const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[pl.src] : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[pl.src] + pl.col_off : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[pl.src] + (WIN ? pl.col_off : 0) : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4;
     // h-form carries X = h + e instead of h (XE = e): then I+e and D+e are one 2-cycle `and` + one 2-cycle add
@@ -173,19 +175,19 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             __syncthreads();
         }
         const int2 *ck0 = nullptr; // window re-fill: left boundary = column checkpoint col_off / CKW
-        if (FP < 0 && pl.col_off > 0) ck0 = ckpt + pl.ckpt_off + (int64_t)(pl.col_off / CKW - 1) * pl.n;
+        if (WIN && pl.col_off > 0) ck0 = ckpt + pl.ckpt_off + (int64_t)(pl.col_off / CKW - 1) * pl.n;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = row0 + r + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
             const int D1c = kp.d00_4 + i * kp.ecol4 + 1;
             hold[r] = max3i(NEG4 + 3, NEG4 + 2, D1c) + XE;
             rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + 2 + E4, D1c + OE4);
-            if (FP < 0 && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x; hold[r] = v.y; }
+            if (WIN && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x; hold[r] = v.y; }
             if (FP < 0) { acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0; }
         }
-        unsigned accR[FP_PLANES] = {0u, 0u, 0u}; // fast path: I-planes of rows n-d, registers rt[(FP - d) mod R]
+        unsigned accR[FP_PLANES] = {0u, 0u, 0u, 0u}; // fast path: I-planes of rows n-d, registers rt[(FP - d) mod R]
         int diag0 = ((row0 == 0) ? max3i(3, kp.o4 + 2, kp.d00_4 + 1) : max3i(NEG4 + 3, NEG4 + 2, kp.d00_4 + row0 * kp.ecol4 + 1)) + XE;
-        if (FP < 0 && ck0) {
+        if (WIN && ck0) {
             if (row0 == 0) diag0 = max3i(NEG4 + 3, kp.o4 + pl.col_off * E4 + 2, NEG4 + 1) + XE; // h(0, col_off)
             else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y;
         }
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
         auto boundary = [&](int c, int &odn, int &oh, int &ob) {
             if (!MULTI || s == 0) {
-                const int M3 = NEG4 + 3, I2 = kp.o4 + (pl.col_off + c) * E4 + 2, D1 = NEG4 + 1; // row 0: I(0,c) = gapOpen + c*gapExtend
+                const int M3 = NEG4 + 3, I2 = kp.o4 + ((WIN ? pl.col_off : 0) + c) * E4 + 2, D1 = NEG4 + 1; // row 0: I(0,c) = gapOpen + c*gapExtend
                 const int h0 = max3i(M3, I2, D1);
                 odn = (LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4);
                 oh = h0 + XE;
@@ -685,7 +687,7 @@ struct FpState {
     int32_t j_hi, jc_lo;
 };
 
-template <bool FIRST>
+template <bool FIRST, bool TILED = false>
 __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
                                                      FpState *__restrict__ states, const int *__restrict__ hcol_fwd,
                                                      const unsigned *__restrict__ rowi, const int2 *__restrict__ ckpt,
@@ -710,8 +712,11 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         wp = pl;
     } else {
         st = states[p];
-        wp = wplans[a];
+        wp = wplans[TILED ? 0 : a];
+        if (TILED) { st.j_hi = 0; st.jc_lo = 0; }
     }
+    // TILED: `a` indexes the straggler; its tiles c = 0.. are the plans [a*tiles_per + c] (tiles_per in wplans[0].rowi_off)
+    const int tiles_per = TILED ? (int)wplans[0].rowi_off : 0;
     int i = st.i, j = st.j, k = st.k, last_op = st.last_op, cur_op = st.cur_op, cnt = st.cnt;
     int64_t cur_run = st.cur_run, li = st.li;
     gnx_cigar *stg = stage + (int64_t)p * FP_CAP;
@@ -737,6 +742,12 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             pos = t1 & 15;
         } else if (j > st.jc_lo && j <= st.j_hi) { // inside the current window
             w = load_word<true>(wtrace, wp, k, i, j - st.jc_lo, pos);
+        } else if (TILED) { // switch to the tile holding column j (all tiles of a straggler are filled)
+            const int c = (j - 1) / FP_TILE;
+            wp = wplans[(int64_t)a * tiles_per + c];
+            st.jc_lo = c * FP_TILE; st.j_hi = st.jc_lo + wp.m;
+            if (j > st.j_hi) { atomicOr(err, 2); done = true; break; }
+            continue;
         } else break; // needs a (new) window
         int tag = (int)((w >> (2 * pos)) & 3u);
         if (tag == 0) { atomicOr(err, 2); done = true; break; }
@@ -801,18 +812,25 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
     states[p] = st;
 }
 
-// stragglers (the path keeps needing windows): plans for a full-trace pass over those pairs, outputs indexed by src
+// stragglers (the path keeps needing windows, e.g. a long gap on a row without a stored plane): every remaining
+// column of such a pair is re-filled as independent FP_TILE-column tiles from the column checkpoints -- one launch,
+// a tile deep instead of a matrix deep -- and fp_walk_kernel<false, true> finishes the walk through them.
 __global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
-                                                                  int max_words, FpState *__restrict__ states, PairPlan *__restrict__ out) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n_active) return;
+                                                                  int tiles_per, const FpState *__restrict__ states, PairPlan *__restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n_active * tiles_per) return;
+    const int a = x / tiles_per, c = x - a * tiles_per;
     const int p = active[a];
     const PairPlan pl = plans[p];
+    const int j_cur = states[p].j;
     PairPlan q = pl;
-    q.strips = 1; q.trace_off = (int64_t)a * max_words * QA * G; q.hcol_off = (int64_t)a * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)a * G;
-    q.src = p; q.col_off = 0;
-    out[a] = q;
-    states[p].status = 2; // staged runs are void
+    const int lo = c * FP_TILE;
+    q.m = (j_cur > lo) ? min(FP_TILE, j_cur - lo) : 0;
+    q.words = (q.m + 15 + 15) / 16; q.strips = q.m > 0 ? 1 : 0;
+    q.trace_off = (int64_t)x * FP_TWORDS * QA * G; q.hcol_off = (int64_t)x * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)x * G;
+    q.src = pl.src; q.col_off = lo;
+    q.rowi_off = (x == 0) ? tiles_per : 0; // plan 0 carries tiles_per for the walk kernel
+    out[x] = q;
 }
 
 __global__ __launch_bounds__(256) void fp_compact_kernel(int n_pairs, const FpState *__restrict__ states, const gnx_cigar *__restrict__ stage, const int64_t *__restrict__ nops,
@@ -820,7 +838,6 @@ __global__ __launch_bounds__(256) void fp_compact_kernel(int n_pairs, const FpSt
                                                           int *__restrict__ err) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
-    if (states[p].status == 2) return; // written by the general traceback
     const int64_t cnt = nops[p], base = ops_off[p];
     if (base + cnt > ops_capacity) { atomicOr(err, 4); return; }
     const int64_t m = cnt < FP_CAP ? cnt : FP_CAP;
@@ -1030,12 +1047,12 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipEventElapsedTime(&f, c.ev[0], c.ev[1]));
     fill_ms += f;
-    const int max_it = getenv("GNX_FP_MAXIT") ? atoi(getenv("GNX_FP_MAXIT")) : 2;
+    const int max_it = getenv("GNX_FP_MAXIT") ? atoi(getenv("GNX_FP_MAXIT")) : 3;
     while (n_act > 0 && n_fill <= max_it) {
         const int nxt = cur ^ 1;
         HIPCHK(hipMemsetAsync(d_cnt + nxt, 0, 4, stream));
         HIPCHK(hipEventRecord(c.ev[1], stream));
-        hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1>), dim3((unsigned)((n_act + 3) / 4)), blockF, 0, stream, d_wpl[cur], n_act, d_a, d_as, d_b, d_bs, kp,
+        hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1, true>), dim3((unsigned)((n_act + 3) / 4)), blockF, 0, stream, d_wpl[cur], n_act, d_a, d_as, d_b, d_bs, kp,
                            d_wtrace, d_whcol, (int2 *)nullptr, d_wdcol, d_ckpt, (unsigned *)nullptr, d_err);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
@@ -1052,33 +1069,45 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
         n_act = n_next;
         cur = nxt;
     }
-    int n_strag = 0, max_words = 1;
     if (n_act > 0) {
-        // stragglers: full direction matrix for these pairs only (general kernels), counted here, written after the scan
-        n_strag = n_act;
-        for (int64_t p = 0; p < n_pairs; p++) max_words = std::max(max_words, (int)plans[(size_t)p].words);
-        const size_t sb = (size_t)n_strag * max_words * QA * G * 16;
-        if ((int64_t)sb > c.ws_limit) return -1;
-        if (sb > c.trace.cap) { if ((rc = c.trace.ensure(sb))) return rc; d_wtrace = reinterpret_cast<uint4 *>(c.trace.p); }
-        PairPlan *gpl = d_wpl[cur ^ 1];
-        hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_strag + 255) / 256)), dim3(256), 0, stream, dpl, d_act[cur], n_strag, max_words, d_st, gpl);
+        const int n_strag = n_act;
+        int64_t m_maxb = 1;
+        for (int64_t p = 0; p < n_pairs; p++) m_maxb = std::max<int64_t>(m_maxb, h_blen[p]);
+        const int tiles_per = (int)((m_maxb + FP_TILE - 1) / FP_TILE);
+        const int64_t n_tiles = (int64_t)n_strag * tiles_per;
+        const size_t tb = (size_t)n_tiles * FP_TWORDS * QA * G * 16;
+        if ((int64_t)tb > c.ws_limit || n_tiles > 0x3fffffff) return -1;
+        DevBuf &tplans = c.rowbuf; // unused on the fast path
+        if ((rc = tplans.ensure((size_t)n_tiles * sizeof(PairPlan)))) return rc;
+        if (tb > c.trace.cap) { if ((rc = c.trace.ensure(tb))) return rc; d_wtrace = reinterpret_cast<uint4 *>(c.trace.p); }
+        if ((size_t)(np + n_tiles * H) * 4 > c.hcol.cap) { // keep the forward h(n,m) values: grow by copy
+            DevBuf nb;
+            if ((rc = nb.ensure((size_t)(np + n_tiles * H) * 4))) return rc;
+            HIPCHK(hipMemcpyAsync(nb.p, c.hcol.p, (size_t)np * 4, hipMemcpyDeviceToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            c.hcol.release(); c.hcol = nb;
+            d_hfwd = reinterpret_cast<int *>(c.hcol.p); d_whcol = d_hfwd + np;
+        }
+        if ((rc = c.dcol.ensure((size_t)n_tiles * G * 4))) return rc;
+        d_wdcol = reinterpret_cast<unsigned *>(c.dcol.p);
+        PairPlan *tpl = reinterpret_cast<PairPlan *>(tplans.p);
+        hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, stream, dpl, d_act[cur], n_strag, tiles_per, d_st, tpl);
         HIPCHK(hipEventRecord(c.ev[1], stream));
-        hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1>), dim3((unsigned)((n_strag + 3) / 4)), blockF, 0, stream, gpl, n_strag, d_a, d_as, d_b, d_bs, kp,
+        hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1, true>), dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, stream, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
                            d_wtrace, d_whcol, (int2 *)nullptr, d_wdcol, d_ckpt, (unsigned *)nullptr, d_err);
         HIPCHK(hipEventRecord(c.ev[2], stream));
-        hipLaunchKernelGGL((traceback_kernel<true, false>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, stream, gpl, n_strag, d_wtrace, d_whcol, d_wdcol, tp, d_score, d_nops,
-                           (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
+        HIPCHK(hipMemsetAsync(d_cnt, 0, 8, stream));
+        hipLaunchKernelGGL((fp_walk_kernel<false, true>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, stream, dpl, d_act[cur], n_strag, d_st, d_hfwd, d_rowi, d_ckpt,
+                           tpl, d_wtrace, d_whcol, tp, d_stage, d_score, d_nops, d_act[cur ^ 1], d_cnt, d_wpl[cur ^ 1], d_err);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipEventElapsedTime(&f, c.ev[1], c.ev[2]));
         fill_ms += f;
-        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %d stragglers through the general kernels, fill %.3f ms\n", n_strag, f);
+        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %d stragglers: %lld tiles of %d columns re-filled in %.3f ms\n", n_strag, (long long)n_tiles, FP_TILE, f);
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, d_nops, np, d_ops_off, d_carry);
     hipLaunchKernelGGL(fp_compact_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, d_st, d_stage, d_nops, d_ops_off, d_ops, ops_capacity, d_err);
-    if (n_strag > 0)
-        hipLaunchKernelGGL((traceback_kernel<true, true>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, stream, d_wpl[cur ^ 1], n_strag, d_wtrace, d_whcol, d_wdcol, tp, d_score, d_nops,
-                           d_ops_off, d_ops, ops_capacity, d_err);
+
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c.ev[3], stream));
     int h_misc[16];
