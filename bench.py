@@ -178,6 +178,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fill_ms, tb_ms, launches = [], [], 0
+    dom_ms, dom_launches, fast_path = 0.0, 0, 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -186,6 +187,7 @@ def main():
         step()
         tm = _lib.get_timing()
         fill_ms.append(tm["fill_ms"]); tb_ms.append(tm["traceback_ms"]); launches += tm["n_launches"]
+        dom_ms += tm["dominant_ms"]; dom_launches += tm["dominant_launches"]; fast_path = tm["fast_path"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -224,14 +226,14 @@ def main():
     if rank == 0:
         cells_per_step = n_pairs * READ_LEN * CHUNK_LEN * world
         value = cells_per_step * args.steps / dt
-        fill_avg_ms = float(np.sum(fill_ms)) / max(launches, 1)
-        pairs_per_launch = n_pairs * args.steps / max(launches, 1)
+        fill_avg_ms = dom_ms / max(dom_launches, 1)  # average duration of the dominant kernel's launches (HIP events)
+        pairs_per_launch = n_pairs * args.steps / max(dom_launches, 1)
         abytes = algorithmic_bytes(READ_LEN, CHUNK_LEN, pairs_per_launch, total_ops.value * pairs_per_launch / n_pairs)
         achieved = abytes / (fill_avg_ms * 1e-3) / 1e9
         traffic = None  # HBM bytes per fill launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
         try:
             with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as fh:
-                traffic = json.load(fh)["hbm_bytes_per_pair"] * pairs_per_launch
+                traffic = json.load(fh)["fast_path" if fast_path else "general_path"]["hbm_bytes_per_pair"] * pairs_per_launch
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -245,11 +247,13 @@ def main():
                        "pairs_per_gpu": n_pairs, "read_len": READ_LEN, "chunk_len": CHUNK_LEN, "parallelism": "pairs sharded x%d" % world},
             "pairs_per_s": n_pairs * world * args.steps / dt,
             "bit_exact_sample": ok,
-            "kernel_ms": {"fill_per_step": float(np.mean(fill_ms)), "traceback_per_step": float(np.mean(tb_ms)),
-                          "fill_launches_per_step": launches / args.steps},
+            "kernel_ms": {"all_fill_kernels_per_step": float(np.mean(fill_ms)), "traceback_and_rest_per_step": float(np.mean(tb_ms)),
+                          "dominant_kernel_per_step": dom_ms / args.steps, "fast_path": bool(fast_path)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r1_hbm_traffic.json)",
-                         "kernel": "fill_affine_kernel", "avg_launch_ms": fill_avg_ms,
+                         "kernel": "fill_affine_kernel<..., FP=%d> (fast-path forward sweep)" % ((READ_LEN - 1) % 10) if fast_path
+                                   else "fill_affine_kernel<..., FP=-1> (full direction matrix)",
+                         "avg_launch_ms": fill_avg_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "cells_per_s_kernel": pairs_per_launch * READ_LEN * CHUNK_LEN / (fill_avg_ms * 1e-3)},
         }

@@ -1047,6 +1047,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipEventElapsedTime(&f, c.ev[0], c.ev[1]));
     fill_ms += f;
+    const double forward_ms = f;
     const int max_it = getenv("GNX_FP_MAXIT") ? atoi(getenv("GNX_FP_MAXIT")) : 3;
     while (n_act > 0 && n_fill <= max_it) {
         const int nxt = cur ^ 1;
@@ -1117,6 +1118,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[3]));
     c.timing.fill_ms = fill_ms; c.timing.traceback_ms = tot - fill_ms; c.timing.total_ms = tot;
     c.timing.cells = cells; c.timing.n_launches = 1; c.timing.trace_bytes = (int64_t)coff * 8 + (int64_t)roff * 4;
+    c.timing.dominant_ms = forward_ms; c.timing.dominant_launches = 1; c.timing.fast_path = 1;
     int64_t total;
     memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
     if (out_total) *out_total = total;
@@ -1305,6 +1307,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[2]));
     c.timing.fill_ms = fill_ms; c.timing.traceback_ms = tb_ms; c.timing.total_ms = tot;
     c.timing.cells = cells; c.timing.n_launches = (int64_t)nchunks; c.timing.trace_bytes = trace_bytes;
+    c.timing.dominant_ms = fill_ms; c.timing.dominant_launches = (int64_t)nchunks; c.timing.fast_path = 0;
     int64_t total;
     memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
     if (out_total) *out_total = total;

@@ -84,7 +84,12 @@ typedef struct gnx_timing {
     double total_ms;     /* first launch to last kernel end */
     int64_t cells;
     int64_t n_launches;  /* number of fill launches (sub-batches) */
-    int64_t trace_bytes; /* direction-matrix bytes written by the fill kernels */
+    int64_t trace_bytes; /* direction-matrix / checkpoint bytes written by the fill kernels */
+    double dominant_ms;  /* summed duration of the dominant kernel's launches (fast path: the forward sweep; general
+                            path: the fill kernel) -- what roofline.achieved is computed from */
+    int64_t dominant_launches;
+    int32_t fast_path;   /* 1 if the short-alpha fast path ran */
+    int32_t _pad;
 } gnx_timing;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
