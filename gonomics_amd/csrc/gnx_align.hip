@@ -244,7 +244,20 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                         for (int d = 0; d < FP_PLANES; d++) if (r == (FP - d + R) % R) accR[d] = alignbit2((unsigned)rt[r], accR[d]);
                     }
                     int hnew, dnn; // hnew is in the X domain (h + XE)
-                    if (HFORM) {
+                    // Fast-path forward sweep: the tag bits only matter where something is recorded (the FP_PLANES plane
+                    // rows, checkpoint columns -> CKPT blocks, h(n,m) on row n).  A tag never changes the VALUE of a max
+                    // (score differences are multiples of 4, tags are < 4), so the other rows skip the or/and cleaning;
+                    // their low bits are junk < 4 and every tagged row re-normalises what it reads.
+                    const bool TAGGED = FP < 0 || CKPT || ((FP - r + R) % R) < FP_PLANES; // folds after unrolling
+                    if (HFORM && !TAGGED) {
+                        const int M3e = hd + S4;
+                        const int Ie = rt[r] + vE4;
+                        const int De = dnu + vE4;
+                        hnew = max3i(M3e, Ie, De);
+                        const int hoe = hnew + vO4;
+                        rt[r] = max(hoe, Ie);
+                        dnn = max(hoe, De);
+                    } else if (HFORM) {
                         const int M3e = (hd | 3) + S4;             // M + e
                         const int Ie = (rt[r] & ~3) + vE4p2;       // I + e, tag 2
                         const int De = (dnu & ~3) + vE4p1;         // D + e, tag 1
