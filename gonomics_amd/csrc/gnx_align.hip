@@ -991,7 +991,8 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
                   const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                   const int64_t *h_alen, const int64_t *h_blen, int rstar,
                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
-                  int64_t *out_total, hipStream_t stream) {
+                  int64_t *out_total, hipStream_t stream, bool first) {
+    // `first` = first sub-batch of a call: later sub-batches keep the error flags and the CIGAR offset carry
     Ctx &c = g_ctx;
     int rc;
     const int np = (int)n_pairs;
@@ -1025,7 +1026,8 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     int *d_err = reinterpret_cast<int *>(c.misc.p);
     int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
     int *d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(c.misc.p) + 32); // two window-request counters
-    HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
+    if (first) HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
+    else HIPCHK(hipMemsetAsync(d_cnt, 0, 8, stream));
     HIPCHK(hipMemcpyAsync(c.plans.p, plans.data(), (size_t)np * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
     const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
     int *d_hfwd = reinterpret_cast<int *>(c.hcol.p);
@@ -1129,9 +1131,10 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     HIPCHK(hipStreamSynchronize(stream));
     float tot = 0;
     HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[3]));
-    c.timing.fill_ms = fill_ms; c.timing.traceback_ms = tot - fill_ms; c.timing.total_ms = tot;
-    c.timing.cells = cells; c.timing.n_launches = 1; c.timing.trace_bytes = (int64_t)coff * 8 + (int64_t)roff * 4;
-    c.timing.dominant_ms = forward_ms; c.timing.dominant_launches = 1; c.timing.fast_path = 1;
+    if (first) c.timing = gnx_timing{};
+    c.timing.fill_ms += fill_ms; c.timing.traceback_ms += tot - fill_ms; c.timing.total_ms += tot;
+    c.timing.cells += cells; c.timing.n_launches += 1; c.timing.trace_bytes += (int64_t)coff * 8 + (int64_t)roff * 4;
+    c.timing.dominant_ms += forward_ms; c.timing.dominant_launches += 1; c.timing.fast_path = 1;
     int64_t total;
     memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
     if (out_total) *out_total = total;
@@ -1177,8 +1180,26 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             else if (rstar != (int)((n - 1) % R)) fp = false;
         }
         if (fp) {
-            rc = run_device_fp(kp, tp, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, rstar, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
-            if (rc != -1) return rc;
+            // sub-batches whose fast-path working set (checkpoints, planes, window slots, staging) fits the workspace
+            const size_t fixed = (size_t)FP_WWORDS * QA * G * 16 + FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + H * 4 + G * 4 + 64;
+            std::vector<int64_t> cb{0};
+            size_t acc_b = 0;
+            const size_t budget = (size_t)(c.ws_limit - c.ws_limit / 8);
+            for (int64_t p = 0; p < n_pairs; p++) {
+                const size_t b = fixed + (size_t)((h_blen[p] - 1) / CKW) * h_alen[p] * 8 + (size_t)FP_PLANES * ((h_blen[p] + 30) / 16) * 4;
+                if (b > budget) { fp = false; break; }
+                if (acc_b + b > budget) { cb.push_back(p); acc_b = 0; }
+                acc_b += b;
+            }
+            cb.push_back(n_pairs);
+            rc = -1;
+            for (size_t ch = 0; fp && ch + 1 < cb.size(); ch++) {
+                const int64_t b = cb[ch], e = cb[ch + 1];
+                rc = run_device_fp(kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rstar, d_score + b, d_ops, ops_capacity,
+                                   d_ops_off + b, out_total, stream, ch == 0);
+                if (rc != GNX_OK) break;
+            }
+            if (fp && rc != -1) return rc;
         }
     }
     // ---- plan ----

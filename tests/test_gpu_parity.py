@@ -276,3 +276,35 @@ def test_full_size_properties(gpu_lib):
                     i += run
         assert (i, j) == (150, chunk.shape[0])
         assert total == int(scores[k])
+
+
+def test_fast_path_chunking_and_fallback(gpu_lib):
+    """Short-alpha batches take the checkpoint/re-fill fast path; with a small workspace it runs in several
+    sub-batches, with GNX_FASTPATH=0 the general path must give the same bits."""
+    reads, chunk = common.c2_workload(21, 600, read_len=150, chunk_len=3000)
+    n = reads.shape[0]
+    a_start = np.arange(n, dtype=np.int64) * 150
+    a_len = np.full(n, 150, dtype=np.int64)
+    b_start = np.zeros(n, dtype=np.int64)
+    b_len = np.full(n, chunk.shape[0], dtype=np.int64)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, align.HumanChimpTwoScoreMatrix, -600, -150)
+    exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len, threads=8)
+    got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len)
+    if os.environ.get("GNX_FASTPATH", "1") != "0":
+        assert gpu_lib.get_timing()["fast_path"] == 1
+    common.assert_same(got, exp, "fast path")
+    gpu_lib.check(gpu_lib.lib().gnx_init(0, 12 << 20))
+    try:
+        got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len)
+        tm = gpu_lib.get_timing()
+        if os.environ.get("GNX_FASTPATH", "1") != "0":
+            assert tm["fast_path"] == 1 and tm["dominant_launches"] > 1
+    finally:
+        gpu_lib.check(gpu_lib.lib().gnx_init(0, 8 << 30))
+    common.assert_same(got, exp, "fast path, chunked")
+    # mixed (n-1) % 10 -> general path, same answers
+    reads2 = [reads[k, :150 - (k % 3)] for k in range(64)]
+    got = gpu_lib.align_batch(p, reads2, [chunk] * 64)
+    assert gpu_lib.get_timing()["fast_path"] == 0
+    exp = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, reads2, [chunk] * 64, threads=8)
+    common.assert_same(got, exp, "mixed lengths")
