@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--ws-gb", type=float, default=150.0, help="direction-matrix workspace limit per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--verify", type=int, default=32, help="pairs checked bit-exactly against the oracle after timing")
+    ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU (with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 (flow check of the N>1 path on a 1-GPU box)")
     ap.add_argument("--series", default="affine", choices=["affine", "const", "local"],
                     help="affine = the headline AffineGap(read, chunk); const = ConstGap(read, chunk, -430); "
                          "local = AffineGapLocal(target=chunk, query=read) (SURVEY 8d second series)")
@@ -113,13 +115,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)
     L = _lib.lib()
-    _lib.check(L.gnx_init(local_rank, int(args.ws_gb * (1 << 30))))
+    ws_gb = args.ws_gb / (world if args.share_gpu else 1)
+    _lib.check(L.gnx_init(dev_index, int(ws_gb * (1 << 30))))
 
     n_pairs = args.pairs
     # rank 0 owns the chunk; everyone gets it by broadcast (RCCL over xGMI when world > 1)
