@@ -708,10 +708,10 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                                                      const int *__restrict__ whcol, TbParams tp, gnx_cigar *__restrict__ stage,
                                                      int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                      int *__restrict__ next_active, int *__restrict__ next_count,
-                                                     PairPlan *__restrict__ next_wplans, int *__restrict__ err) {
+                                                     PairPlan *__restrict__ next_wplans, int *__restrict__ err, int p_base) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_active) return;
-    const int p = FIRST ? a : active[a];
+    const int p = FIRST ? a + p_base : active[a];
     const PairPlan pl = plans[p];
     FpState st;
     PairPlan wp;
@@ -921,9 +921,11 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2];
+    DevBuf fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev2[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
 };
 Ctx g_ctx;
@@ -987,17 +989,17 @@ int64_t max_abs_pen(const gnx_params *p, bool affine) {
 
 // Fast path for batches of short-alpha global affine alignments (see fp_walk_kernel).  Returns GNX_OK, an error,
 // or -1 when the batch should go through the general path after all (workspace too small / staging overflow).
+// `first` = first sub-batch of a call: later sub-batches keep the error flags and the CIGAR offset carry.
 int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
                   const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                   const int64_t *h_alen, const int64_t *h_blen, int rstar,
                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
                   int64_t *out_total, hipStream_t stream, bool first) {
-    // `first` = first sub-batch of a call: later sub-batches keep the error flags and the CIGAR offset carry
     Ctx &c = g_ctx;
     int rc;
     const int np = (int)n_pairs;
     std::vector<PairPlan> plans((size_t)n_pairs);
-    int64_t roff = 0, coff = 0, cells = 0;
+    int64_t roff = 0, coff = 0, cells = 0, m_maxb = 1;
     for (int64_t p = 0; p < n_pairs; p++) {
         PairPlan &pl = plans[(size_t)p];
         const int64_t n = h_alen[p], m = h_blen[p];
@@ -1005,12 +1007,13 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
         pl.trace_off = 0; pl.hcol_off = p; pl.rowbuf_off = 0; pl.dcol_off = 0;
         pl.src = (int32_t)p; pl.col_off = 0; pl.ckpt_off = coff; pl.rowi_off = roff;
         roff += (int64_t)FP_PLANES * pl.words; coff += ((m - 1) / CKW) * n; cells += n * m;
+        m_maxb = std::max(m_maxb, m);
     }
     const size_t wtrace_b = (size_t)np * FP_WWORDS * QA * G * 16;
     const size_t need = wtrace_b + (size_t)coff * 8 + (size_t)roff * 4 + (size_t)np * (FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + H * 4 + G * 4 + 32);
     if ((int64_t)need > c.ws_limit) return -1;
     if ((rc = c.trace.ensure(wtrace_b))) return rc;
-    if ((rc = c.hcol.ensure((size_t)np * (H + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then window hcol
+    if ((rc = c.hcol.ensure((size_t)np * (H + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then the window hcol slots
     if ((rc = c.dcol.ensure((size_t)np * G * 4))) return rc;
     if ((rc = c.plans.ensure((size_t)np * sizeof(PairPlan)))) return rc;
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
@@ -1023,17 +1026,20 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
         if ((rc = c.fp_wplans[x].ensure((size_t)np * sizeof(PairPlan)))) return rc;
         if ((rc = c.fp_active[x].ensure((size_t)np * 4))) return rc;
     }
+    if (!c.stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c.ev2[i]));
+        for (int i = 4; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
+    }
     int *d_err = reinterpret_cast<int *>(c.misc.p);
     int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
-    int *d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(c.misc.p) + 32); // two window-request counters
+    int *d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(c.misc.p) + 32); // window-request counters: [0,1] part A, [2,3] part B
     if (first) HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
-    else HIPCHK(hipMemsetAsync(d_cnt, 0, 8, stream));
+    else HIPCHK(hipMemsetAsync(d_cnt, 0, 16, stream));
     HIPCHK(hipMemcpyAsync(c.plans.p, plans.data(), (size_t)np * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
     const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
     int *d_hfwd = reinterpret_cast<int *>(c.hcol.p);
     int *d_whcol = d_hfwd + np;
-    uint4 *d_wtrace = reinterpret_cast<uint4 *>(c.trace.p);
-    unsigned *d_wdcol = reinterpret_cast<unsigned *>(c.dcol.p);
     unsigned *d_rowi = reinterpret_cast<unsigned *>(c.fp_rowi.p);
     int2 *d_ckpt = reinterpret_cast<int2 *>(c.fp_ckpt.p);
     FpState *d_st = reinterpret_cast<FpState *>(c.fp_states.p);
@@ -1041,100 +1047,132 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     int64_t *d_nops = reinterpret_cast<int64_t *>(c.nops.p);
     PairPlan *d_wpl[2] = {reinterpret_cast<PairPlan *>(c.fp_wplans[0].p), reinterpret_cast<PairPlan *>(c.fp_wplans[1].p)};
     int *d_act[2] = {reinterpret_cast<int *>(c.fp_active[0].p), reinterpret_cast<int *>(c.fp_active[1].p)};
-
-    double fill_ms = 0;
-    float f = 0;
     const dim3 blockF(64), blockT(64);
-    HIPCHK(hipEventRecord(c.ev[0], stream));
-    {   // forward sweep
-        const dim3 gridF((unsigned)((np + 3) / 4));
-#define GNX_FPF(K_) case K_: hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, K_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, (uint4 *)nullptr, d_hfwd, (int2 *)nullptr, (unsigned *)nullptr, d_ckpt, d_rowi, d_err); break;
+    const int max_it = getenv("GNX_FP_MAXIT") ? atoi(getenv("GNX_FP_MAXIT")) : 3;
+    const int tiles_per = (int)((m_maxb + FP_TILE - 1) / FP_TILE);
+    double refill_ms = 0;
+
+    // Optional (GNX_FP_SPLIT=1): sweep the last partial "round" of waves (part B) on a second stream underneath part A's
+    // walk / window stages.  Measured on MI355X it does NOT pay: 98 304 pairs (8 full rounds of 3072 resident waves) take
+    // 41.1 ms and all 100 000 take 41.9 ms -- the dispatcher's staggered wave starts already hide the partial round --
+    // so it is off by default and kept only as an experiment switch.
+    int nA = np;
+    if (getenv("GNX_FP_SPLIT")) {
+        int per_cu = 0, cus = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fill_affine_kernel<false, false, false, true, 9>, 64, 0) != hipSuccess) per_cu = 0;
+        const int64_t slots = (int64_t)per_cu * cus, waves = (np + 3) / 4;
+        if (slots > 0 && waves > slots) {
+            const int64_t rem = waves % slots;
+            if (rem > 0 && rem * 2 < slots) nA = (int)((waves - rem) * 4);
+        }
+    }
+    const int nB = np - nA;
+    auto forward = [&](int p0, int cnt, hipStream_t st) -> int {
+        const dim3 gridF((unsigned)((cnt + 3) / 4));
+#define GNX_FPF(K_) case K_: hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, K_>), gridF, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, (uint4 *)nullptr, d_hfwd, (int2 *)nullptr, (unsigned *)nullptr, d_ckpt, d_rowi, d_err); break;
         switch (rstar) { GNX_FPF(0) GNX_FPF(1) GNX_FPF(2) GNX_FPF(3) GNX_FPF(4) GNX_FPF(5) GNX_FPF(6) GNX_FPF(7) GNX_FPF(8) default: GNX_FPF(9) }
 #undef GNX_FPF
         HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipEventRecord(c.ev[1], stream));
-    int cur = 0, n_act = 0, n_fill = 1;
-    hipLaunchKernelGGL(fp_walk_kernel<true>, dim3((unsigned)((np + 63) / 64)), blockT, 0, stream, dpl, (const int *)nullptr, np, d_st, d_hfwd, d_rowi, d_ckpt,
-                       (const PairPlan *)nullptr, d_wtrace, d_whcol, tp, d_stage, d_score, d_nops, d_act[0], d_cnt, d_wpl[0], d_err);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&n_act, d_cnt, 4, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    HIPCHK(hipEventElapsedTime(&f, c.ev[0], c.ev[1]));
-    fill_ms += f;
-    const double forward_ms = f;
-    const int max_it = getenv("GNX_FP_MAXIT") ? atoi(getenv("GNX_FP_MAXIT")) : 3;
-    while (n_act > 0 && n_fill <= max_it) {
-        const int nxt = cur ^ 1;
-        HIPCHK(hipMemsetAsync(d_cnt + nxt, 0, 4, stream));
-        HIPCHK(hipEventRecord(c.ev[1], stream));
-        hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1, true>), dim3((unsigned)((n_act + 3) / 4)), blockF, 0, stream, d_wpl[cur], n_act, d_a, d_as, d_b, d_bs, kp,
-                           d_wtrace, d_whcol, (int2 *)nullptr, d_wdcol, d_ckpt, (unsigned *)nullptr, d_err);
+        return GNX_OK;
+    };
+    // walk / window stages of the pairs [p0, p0+cnt) on stream `st`; their window slots are [p0, p0+cnt) as well
+    auto post = [&](int p0, int cnt, hipStream_t st, int *cnt2, hipEvent_t e1, hipEvent_t e2) -> int {
+        uint4 *wtr = reinterpret_cast<uint4 *>(c.trace.p) + (int64_t)p0 * FP_WWORDS * QA * G;
+        int *whc = d_whcol + (int64_t)p0 * H;
+        unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * G;
+        int cur = 0, n_act = 0, it = 0;
+        float f = 0;
+        hipLaunchKernelGGL(fp_walk_kernel<true>, dim3((unsigned)((cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_ckpt,
+                           (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, d_wpl[0] + p0, d_err, p0);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c.ev[2], stream));
-        hipLaunchKernelGGL(fp_walk_kernel<false>, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, stream, dpl, d_act[cur], n_act, d_st, d_hfwd, d_rowi, d_ckpt,
-                           d_wpl[cur], d_wtrace, d_whcol, tp, d_stage, d_score, d_nops, d_act[nxt], d_cnt + nxt, d_wpl[nxt], d_err);
-        HIPCHK(hipGetLastError());
-        int n_next = 0;
-        HIPCHK(hipMemcpyAsync(&n_next, d_cnt + nxt, 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        HIPCHK(hipEventElapsedTime(&f, c.ev[1], c.ev[2]));
-        fill_ms += f;
-        n_fill++;
-        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] iteration %d: %d windows filled in %.3f ms, %d pairs continue\n", n_fill - 1, n_act, f, n_next);
-        n_act = n_next;
-        cur = nxt;
-    }
-    if (n_act > 0) {
-        const int n_strag = n_act;
-        int64_t m_maxb = 1;
-        for (int64_t p = 0; p < n_pairs; p++) m_maxb = std::max<int64_t>(m_maxb, h_blen[p]);
-        const int tiles_per = (int)((m_maxb + FP_TILE - 1) / FP_TILE);
-        const int64_t n_tiles = (int64_t)n_strag * tiles_per;
-        const size_t tb = (size_t)n_tiles * FP_TWORDS * QA * G * 16;
-        if ((int64_t)tb > c.ws_limit || n_tiles > 0x3fffffff) return -1;
-        DevBuf &tplans = c.rowbuf; // unused on the fast path
-        if ((rc = tplans.ensure((size_t)n_tiles * sizeof(PairPlan)))) return rc;
-        if (tb > c.trace.cap) { if ((rc = c.trace.ensure(tb))) return rc; d_wtrace = reinterpret_cast<uint4 *>(c.trace.p); }
-        if ((size_t)(np + n_tiles * H) * 4 > c.hcol.cap) { // keep the forward h(n,m) values: grow by copy
-            DevBuf nb;
-            if ((rc = nb.ensure((size_t)(np + n_tiles * H) * 4))) return rc;
-            HIPCHK(hipMemcpyAsync(nb.p, c.hcol.p, (size_t)np * 4, hipMemcpyDeviceToDevice, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            c.hcol.release(); c.hcol = nb;
-            d_hfwd = reinterpret_cast<int *>(c.hcol.p); d_whcol = d_hfwd + np;
+        HIPCHK(hipMemcpyAsync(&n_act, cnt2, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        while (n_act > 0 && it < max_it) {
+            const int nxt = cur ^ 1;
+            HIPCHK(hipMemsetAsync(cnt2 + nxt, 0, 4, st));
+            HIPCHK(hipEventRecord(e1, st));
+            hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1, true>), dim3((unsigned)((n_act + 3) / 4)), blockF, 0, st, d_wpl[cur] + p0, n_act, d_a, d_as, d_b, d_bs, kp,
+                               wtr, whc, (int2 *)nullptr, wdc, d_ckpt, (unsigned *)nullptr, d_err);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(e2, st));
+            hipLaunchKernelGGL(fp_walk_kernel<false>, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_ckpt,
+                               d_wpl[cur] + p0, wtr, whc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, d_wpl[nxt] + p0, d_err, 0);
+            HIPCHK(hipGetLastError());
+            int n_next = 0;
+            HIPCHK(hipMemcpyAsync(&n_next, cnt2 + nxt, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipEventElapsedTime(&f, e1, e2));
+            refill_ms += f;
+            it++;
+            if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] pairs [%d,%d) round %d: %d windows re-filled in %.3f ms, %d pairs continue\n", p0, p0 + cnt, it, n_act, f, n_next);
+            n_act = n_next;
+            cur = nxt;
         }
-        if ((rc = c.dcol.ensure((size_t)n_tiles * G * 4))) return rc;
-        d_wdcol = reinterpret_cast<unsigned *>(c.dcol.p);
-        PairPlan *tpl = reinterpret_cast<PairPlan *>(tplans.p);
-        hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, stream, dpl, d_act[cur], n_strag, tiles_per, d_st, tpl);
-        HIPCHK(hipEventRecord(c.ev[1], stream));
-        hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1, true>), dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, stream, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
-                           d_wtrace, d_whcol, (int2 *)nullptr, d_wdcol, d_ckpt, (unsigned *)nullptr, d_err);
-        HIPCHK(hipEventRecord(c.ev[2], stream));
-        HIPCHK(hipMemsetAsync(d_cnt, 0, 8, stream));
-        hipLaunchKernelGGL((fp_walk_kernel<false, true>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, stream, dpl, d_act[cur], n_strag, d_st, d_hfwd, d_rowi, d_ckpt,
-                           tpl, d_wtrace, d_whcol, tp, d_stage, d_score, d_nops, d_act[cur ^ 1], d_cnt, d_wpl[cur ^ 1], d_err);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(stream));
-        HIPCHK(hipEventElapsedTime(&f, c.ev[1], c.ev[2]));
-        fill_ms += f;
-        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %d stragglers: %lld tiles of %d columns re-filled in %.3f ms\n", n_strag, (long long)n_tiles, FP_TILE, f);
+        if (n_act > 0) { // stragglers: all their remaining columns as independent tiles, one launch
+            const int n_strag = n_act;
+            const int64_t n_tiles = (int64_t)n_strag * tiles_per;
+            const size_t tb = (size_t)n_tiles * FP_TWORDS * QA * G * 16;
+            if ((int64_t)tb > c.ws_limit || n_tiles > 0x3fffffff) return -1;
+            int rc2;
+            if ((rc2 = c.rowbuf.ensure((size_t)n_tiles * sizeof(PairPlan)))) return rc2; // tile plans (rowbuf is unused on this path)
+            if ((rc2 = c.fp_thcol.ensure((size_t)n_tiles * (H + G) * 4))) return rc2;
+            if ((rc2 = c.fp_ttrace.ensure(tb))) return rc2;
+            PairPlan *tpl = reinterpret_cast<PairPlan *>(c.rowbuf.p);
+            int *thc = reinterpret_cast<int *>(c.fp_thcol.p);
+            unsigned *tdc = reinterpret_cast<unsigned *>(thc + n_tiles * H);
+            uint4 *ttr = reinterpret_cast<uint4 *>(c.fp_ttrace.p);
+            hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, dpl, d_act[cur] + p0, n_strag, tiles_per, d_st, tpl);
+            HIPCHK(hipEventRecord(e1, st));
+            hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1, true>), dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, st, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
+                               ttr, thc, (int2 *)nullptr, tdc, d_ckpt, (unsigned *)nullptr, d_err);
+            HIPCHK(hipEventRecord(e2, st));
+            HIPCHK(hipMemsetAsync(cnt2, 0, 8, st));
+            hipLaunchKernelGGL((fp_walk_kernel<false, true>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_strag, d_st, d_hfwd, d_rowi, d_ckpt,
+                               tpl, ttr, thc, tp, d_stage, d_score, d_nops, d_act[cur ^ 1] + p0, cnt2, d_wpl[cur ^ 1] + p0, d_err, 0);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipEventElapsedTime(&f, e1, e2));
+            refill_ms += f;
+            if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] pairs [%d,%d): %d stragglers: %lld tiles of %d columns re-filled in %.3f ms\n", p0, p0 + cnt, n_strag, (long long)n_tiles, FP_TILE, f);
+        }
+        return GNX_OK;
+    };
+
+    HIPCHK(hipEventRecord(c.ev[0], stream));
+    if ((rc = forward(0, nA, stream))) return rc;
+    HIPCHK(hipEventRecord(c.ev[1], stream));
+    if (nB > 0) {
+        HIPCHK(hipStreamWaitEvent(c.stream2, c.ev[1], 0)); // also orders B after the plan upload / memset on `stream`
+        HIPCHK(hipEventRecord(c.ev2[0], c.stream2));
+        if ((rc = forward(nA, nB, c.stream2))) return rc;
+        HIPCHK(hipEventRecord(c.ev2[1], c.stream2));
+    }
+    if ((rc = post(0, nA, stream, d_cnt, c.ev[4], c.ev[5]))) { if (nB > 0) (void)hipStreamSynchronize(c.stream2); return rc; }
+    if (nB > 0) {
+        rc = post(nA, nB, c.stream2, d_cnt + 2, c.ev2[2], c.ev2[3]);
+        HIPCHK(hipStreamSynchronize(c.stream2));
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, d_nops, np, d_ops_off, d_carry);
     hipLaunchKernelGGL(fp_compact_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, d_st, d_stage, d_nops, d_ops_off, d_ops, ops_capacity, d_err);
-
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c.ev[3], stream));
     int h_misc[16];
     HIPCHK(hipMemcpyAsync(h_misc, c.misc.p, 64, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    float tot = 0;
+    float tot = 0, fa = 0, fb = 0;
     HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[3]));
+    HIPCHK(hipEventElapsedTime(&fa, c.ev[0], c.ev[1]));
+    if (nB > 0) HIPCHK(hipEventElapsedTime(&fb, c.ev2[0], c.ev2[1]));
+    const double forward_ms = (double)fa + fb;
+    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] forward sweep: %d pairs %.3f ms%s", nA, fa, nB > 0 ? "" : "\n");
+    if (getenv("GNX_DEBUG") && nB > 0) fprintf(stderr, " + %d pairs %.3f ms on the second stream\n", nB, fb);
     if (first) c.timing = gnx_timing{};
-    c.timing.fill_ms += fill_ms; c.timing.traceback_ms += tot - fill_ms; c.timing.total_ms += tot;
+    c.timing.fill_ms += forward_ms + refill_ms; c.timing.traceback_ms += std::max(0.0, (double)tot - fa - refill_ms); c.timing.total_ms += tot;
     c.timing.cells += cells; c.timing.n_launches += 1; c.timing.trace_bytes += (int64_t)coff * 8 + (int64_t)roff * 4;
-    c.timing.dominant_ms += forward_ms; c.timing.dominant_launches += 1; c.timing.fast_path = 1;
+    c.timing.dominant_ms += forward_ms; c.timing.dominant_launches += (nB > 0) ? 2 : 1; c.timing.fast_path = 1;
     int64_t total;
     memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
     if (out_total) *out_total = total;
@@ -1143,7 +1181,6 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
     if (ef & 8) return -1; // a CIGAR with more than FP_CAP runs: redo on the general path
     if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
-    (void)n_fill;
     return GNX_OK;
 }
 
@@ -1445,12 +1482,15 @@ void gnx_shutdown(void) {
     if (!g_ctx.inited) return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
+    DevBuf *bufs[] = {&g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
                       &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
                       &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 4; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }
     if (g_ctx.own_stream) { (void)hipStreamDestroy(g_ctx.own_stream); g_ctx.own_stream = nullptr; }
+    if (g_ctx.stream2) { (void)hipStreamDestroy(g_ctx.stream2); g_ctx.stream2 = nullptr; }
+    for (int i = 0; i < 4; i++) if (g_ctx.ev2[i]) { (void)hipEventDestroy(g_ctx.ev2[i]); g_ctx.ev2[i] = nullptr; }
+    for (int i = 4; i < 8; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }
     g_ctx.inited = false;
     g_ctx.ws_limit = 0;
 }
