@@ -15,7 +15,8 @@ GNX_OK, GNX_EINVAL, GNX_EBASE, GNX_EEMPTY, GNX_ERANGE, GNX_EDEVICE, GNX_ENOMEM, 
 GNX_AFFINE_GAP, GNX_CONST_GAP, GNX_AFFINE_GAP_HIGHMEM, GNX_AFFINE_GAP_LOCAL, GNX_CONST_GAP_HIGHMEM = range(5)
 
 EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gnx_free", "gnx_align_batch",
-           "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing"]
+           "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing",
+           "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch"]
 
 
 class GnxCigar(ctypes.Structure):
@@ -76,6 +77,12 @@ def lib():
         L.gnx_align_batch_device.argtypes = [ctypes.POINTER(GnxParams), i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                              c_p, c_p, i64, c_p, ctypes.POINTER(i64), c_p]
         L.gnx_align_batch_device.restype = ctypes.c_int
+        L.gnx_affine_gap_chunk_batch.argtypes = [ctypes.POINTER(GnxParams), i64, i64, c_p, c_p, c_p, c_p, c_p,
+                                                 ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
+        L.gnx_affine_gap_chunk_batch.restype = ctypes.c_int
+        L.gnx_multiple_affine_gap_batch.argtypes = [ctypes.POINTER(GnxParams), i64, i64, c_p, c_p, c_p, c_p, i64, c_p, c_p, c_p,
+                                                    ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
+        L.gnx_multiple_affine_gap_batch.restype = ctypes.c_int
         L.gnx_get_timing.argtypes = [ctypes.POINTER(GnxTiming)]
         L.gnx_get_timing.restype = ctypes.c_int
         _lib = L
@@ -154,6 +161,49 @@ def align_batch(params, alphas, betas):
     ops_p, off_p = ctypes.c_void_p(), ctypes.c_void_p()
     check(L.gnx_align_batch(ctypes.byref(params), n, a_cat.ctypes.data, a_off.ctypes.data, b_cat.ctypes.data, b_off.ctypes.data,
                             scores.ctypes.data, ctypes.byref(ops_p), ctypes.byref(off_p)))
+    ops, off = _take(ops_p, off_p, n)
+    return scores[:n], ops, off
+
+
+def affine_gap_chunk_batch(params, chunk_size, alphas, betas):
+    """align.AffineGapChunk over a batch of pairs.  Returns (scores, ops, off)."""
+    L = lib()
+    n = len(alphas)
+    a_off = np.zeros(n + 1, dtype=np.int64)
+    b_off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        a_off[1:] = np.cumsum([len(a) for a in alphas])
+        b_off[1:] = np.cumsum([len(b) for b in betas])
+    a_cat = _u8(np.concatenate([_u8(a) for a in alphas] + [np.zeros(1, np.uint8)]))
+    b_cat = _u8(np.concatenate([_u8(b) for b in betas] + [np.zeros(1, np.uint8)]))
+    scores = np.zeros(max(n, 1), dtype=np.int64)
+    ops_p, off_p = ctypes.c_void_p(), ctypes.c_void_p()
+    check(L.gnx_affine_gap_chunk_batch(ctypes.byref(params), int(chunk_size), n, a_cat.ctypes.data, a_off.ctypes.data, b_cat.ctypes.data,
+                                       b_off.ctypes.data, scores.ctypes.data, ctypes.byref(ops_p), ctypes.byref(off_p)))
+    ops, off = _take(ops_p, off_p, n)
+    return scores[:n], ops, off
+
+
+def multiple_affine_gap_batch(params, chunk_size, groups, pairs):
+    """groups: list of 2-D uint8 arrays (nseq x len, alignment blocks); pairs: list of (a, b) group indices.
+    align.multipleAffineGap (chunk_size 1) / multipleAffineGapChunk for every pair.  Returns (scores, ops, off)."""
+    L = lib()
+    g = len(groups)
+    blocks = [np.ascontiguousarray(x, dtype=np.uint8).reshape(x.shape[0], -1) for x in groups]
+    g_off = np.zeros(g + 1, dtype=np.int64)
+    if g:
+        g_off[1:] = np.cumsum([b.size for b in blocks])
+    g_nseq = np.asarray([b.shape[0] for b in blocks] + [0], dtype=np.int32)
+    g_len = np.asarray([b.shape[1] for b in blocks] + [0], dtype=np.int64)
+    bases = _u8(np.concatenate([b.reshape(-1) for b in blocks] + [np.zeros(1, np.uint8)]))
+    n = len(pairs)
+    pa = np.asarray([a for a, _ in pairs] + [0], dtype=np.int32)
+    pb = np.asarray([b for _, b in pairs] + [0], dtype=np.int32)
+    scores = np.zeros(max(n, 1), dtype=np.int64)
+    ops_p, off_p = ctypes.c_void_p(), ctypes.c_void_p()
+    check(L.gnx_multiple_affine_gap_batch(ctypes.byref(params), int(chunk_size), g, bases.ctypes.data, g_off.ctypes.data, g_nseq.ctypes.data,
+                                          g_len.ctypes.data, n, pa.ctypes.data, pb.ctypes.data, scores.ctypes.data,
+                                          ctypes.byref(ops_p), ctypes.byref(off_p)))
     ops, off = _take(ops_p, off_p, n)
     return scores[:n], ops, off
 

@@ -107,6 +107,79 @@ def AlignBatch(params, alphas, betas):
     return [(int(scores[k]), _to_route(ops[off[k]:off[k + 1]])) for k in range(len(alphas))]
 
 
+def AffineGapChunk(alpha, beta, scores, gapOpen, gapExtend, chunkSize):
+    """align.AffineGapChunk (/root/reference/align/affineGap_highMem.go:227-268)."""
+    try:
+        sc, ops, off = _lib.affine_gap_chunk_batch(_lib.make_params(_lib.GNX_AFFINE_GAP_HIGHMEM, scores, gapOpen, gapExtend), chunkSize, [alpha], [beta])
+    except _lib.GnxError as e:
+        _raise(e)
+    return int(sc[0]), _to_route(ops[off[0]:off[1]])
+
+
+def _groups_to_blocks(groups):
+    return [np.stack([np.asarray(f.Seq, dtype=np.uint8) for f in g]) for g in groups]
+
+
+def multipleAffineGapBatch(groups, pairs, scores, gapOpen, gapExtend, chunkSize=1):
+    """multipleAffineGap / multipleAffineGapChunk (affineGap_highMem.go:270-353) for many pairs of fasta groups at once."""
+    try:
+        sc, ops, off = _lib.multiple_affine_gap_batch(_lib.make_params(_lib.GNX_AFFINE_GAP_HIGHMEM, scores, gapOpen, gapExtend), chunkSize,
+                                                      _groups_to_blocks(groups), pairs)
+    except _lib.GnxError as e:
+        _raise(e)
+    return [(int(sc[k]), _to_route(ops[off[k]:off[k + 1]])) for k in range(len(pairs))]
+
+
+def mergeMultipleAlignments(alpha, beta, route):
+    """align/multiAlign.go:112-153: merge two fasta groups along a cigar (host-side, no DP)."""
+    from .fasta import Fasta
+    total = sum(c.RunLength for c in route)
+    rows = [np.full(total, dna.Gap, dtype=np.uint8) for _ in range(len(alpha) + len(beta))]
+    acol = bcol = col = 0
+    for c in route:
+        n = c.RunLength
+        if c.Op in (ColM, ColD):
+            for k, f in enumerate(alpha):
+                rows[k][col:col + n] = np.asarray(f.Seq, dtype=np.uint8)[acol:acol + n]
+        if c.Op in (ColM, ColI):
+            for k, f in enumerate(beta):
+                rows[len(alpha) + k][col:col + n] = np.asarray(f.Seq, dtype=np.uint8)[bcol:bcol + n]
+        if c.Op != ColI:
+            acol += n
+        if c.Op != ColD:
+            bcol += n
+        col += n
+    return [Fasta(f.Name, rows[k]) for k, f in enumerate(list(alpha) + list(beta))]
+
+
+def _all_seq(records, scoreMatrix, gapOpen, gapExtend, chunkSize, batch_fn):
+    # multiAlign.go:27-78: progressive alignment, merging the best-scoring pair of groups each round
+    # (first strict maximum in x<y order, nearestGroups :27-41); one batched call per round.
+    groups = [[r] for r in records]
+    while len(groups) > 1:
+        pairs = [(x, y) for x in range(len(groups) - 1) for y in range(x + 1, len(groups))]
+        res = batch_fn(groups, pairs, scoreMatrix, gapOpen, gapExtend, chunkSize)
+        best, best_score = None, None
+        for (x, y), (score, route) in zip(pairs, res):
+            if best_score is None or score > best_score:
+                best, best_score = (x, y, route), score
+        x, y, route = best
+        groups[x] = mergeMultipleAlignments(groups[x], groups[y], route)
+        groups[y] = groups[-1]
+        groups = groups[:-1]
+    return groups[0]
+
+
+def AllSeqAffine(records, scoreMatrix, gapOpen, gapExtend):
+    """align.AllSeqAffine (/root/reference/align/multiAlign.go:59-66)."""
+    return _all_seq(records, scoreMatrix, gapOpen, gapExtend, 1, multipleAffineGapBatch)
+
+
+def AllSeqAffineChunk(records, scoreMatrix, gapOpen, gapExtend, chunkSize):
+    """align.AllSeqAffineChunk (/root/reference/align/multiAlign.go:70-78)."""
+    return _all_seq(records, scoreMatrix, gapOpen, gapExtend, chunkSize, multipleAffineGapBatch)
+
+
 class TargetQueryPair:
     """align.TargetQueryPair (affineGap_highMem.go:110-115)."""
     __slots__ = ("Target", "Query", "Score", "Cigar")

@@ -57,6 +57,8 @@ struct PairPlan {
     int32_t col_off;    // first column of a window re-fill minus one (0 = whole matrix); multiple of CKW
     int64_t ckpt_off;   // int2: column checkpoints of the pair, [c-1][row] for column c*CKW
     int64_t rowi_off;   // dwords: I-plane of row n (one word per 16 steps of the owner lane)
+    int64_t s_off;      // SCORED kernels: explicit 4*score matrix of the pair, column-major: S[s_off + (j-1)*s_pitch + (i-1)]
+    int64_t s_pitch;
 };
 
 constexpr int CKW = 128;     // column checkpoint spacing of the fast path
@@ -102,13 +104,15 @@ template <bool P16> struct ProfCfg {
     static constexpr int PST = 5 * BST + 16;         // dwords per pair
 };
 
-template <bool LOCAL, bool MULTI, bool P16, bool HFORM, int FP, bool WIN = false>
+template <bool LOCAL, bool MULTI, bool P16, bool HFORM, int FP, bool WIN = false, bool SCORED = false>
 __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                          const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                          const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                          KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
                                                          int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int2 *__restrict__ ckpt,
-                                                         unsigned *__restrict__ rowi, int *__restrict__ err) {
+                                                         unsigned *__restrict__ rowi, int *__restrict__ err, const int *__restrict__ smat = nullptr) {
+    // SCORED: the substitution score of a cell comes from an explicit per-pair matrix in HBM (chunk / multiple-alignment
+    //      variants, "next" row N1) instead of the LDS profile of alpha x the base of the column; sequences are not read.
     // FP = -1: record the full direction matrix (general path and window re-fills).
     // FP = (n-1) % R: fast-path forward sweep -- no per-cell recording; keeps the I-plane of row n (register
     //      rt[FP] of the owner lane), a column checkpoint {rt, X} of every row each CKW columns, and h(n,m).
@@ -129,9 +133,9 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const int p = pbase + g;
     const bool valid = p < n_pairs;
     PairPlan pl;
-    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; }
-    const uint8_t *ap = a_buf + (valid ? a_start[pl.src] : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[pl.src] + (WIN ? pl.col_off : 0) : 0);
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
+    const uint8_t *ap = SCORED ? nullptr : a_buf + (valid ? a_start[pl.src] : 0);
+    const uint8_t *bp = SCORED ? nullptr : b_buf + (valid ? b_start[pl.src] + (WIN ? pl.col_off : 0) : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4;
     // h-form carries X = h + e instead of h (XE = e): then I+e and D+e are one 2-cycle `and` + one 2-cycle add
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         const int row0 = s * H + l * R; // 0-based index of this lane's first row == 1-based index of the row above it
         int rt[R], hold[R];
         unsigned acc[3 * R]; // direction accumulators: [0,R) M, [R,2R) I, [2R,3R) D
-        { // score profile of this lane's rows: prof[b][lane][k]
+        if (!SCORED) { // score profile of this lane's rows: prof[b][lane][k]
             int a5[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 odn = v.x; oh = v.y; // already in the X domain
             } else { odn = 0; oh = 0; }
             int b = 0;
-            if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            if (!SCORED && c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
             ob = b * (BST * 4); // LDS byte offset of the base's profile plane
         };
         if (MULTI && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -225,7 +229,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             const int j = t - l;
             b_out = pb;
             if (!CHECK || (j >= 1 && j <= m_eff)) {
-                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
+                const int *pw = SCORED ? smat + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0
+                                       : reinterpret_cast<const int *>(prof_lane + pb);
                 int w[LW];
 #pragma unroll
                 for (int k = 0; k < LW; k++) w[k] = pw[k];
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     const int p = pbase + g;
     const bool valid = p < n_pairs;
     PairPlan pl;
-    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; }
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
     const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
@@ -857,6 +862,57 @@ __global__ __launch_bounds__(256) void fp_compact_kernel(int n_pairs, const FpSt
     for (int64_t x = 0; x < m; x++) ops[base + (cnt - 1 - x)] = stage[(int64_t)p * FP_CAP + x];
 }
 
+// ------------------------------------------------------------------------------------------------------
+// N1: per-cell score matrices for the chunk / multiple-alignment variants, one thread per (chunk) cell, written
+// column-major as 4*score.  A "group" is an alignment block: nseq sequences of len bases, sequence-major.
+//   pairwise (AffineGapChunk):      cell = sum_k scores[a[i*c+k]][b[j*c+k]]                       (ungapped.go:7-13)
+//   groups (multipleAffineGap*):    cell = sum_k scoreColumnMatch(column i*c+k, column j*c+k)     (multiAlign.go:82-110)
+//     scoreColumnMatch = (sum over sequence pairs, lower case folded, gap columns skipped) / count, Go integer division
+// ------------------------------------------------------------------------------------------------------
+struct GroupDesc { int64_t off; int32_t nseq; int32_t len; };
+struct ScorePair { int64_t a_off, b_off; int32_t a_nseq, b_nseq, a_len, b_len; int32_t nc, mc; int64_t s_off, s_pitch; };
+
+__global__ __launch_bounds__(256) void score_matrix_kernel(const ScorePair *__restrict__ sp, const uint8_t *__restrict__ bases, KParams kp, int chunk,
+                                                           int groups, int *__restrict__ smat, int *__restrict__ err) {
+    const ScorePair q = sp[blockIdx.y];
+    const int64_t cells = (int64_t)q.nc * q.mc;
+    for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < cells; cell += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(cell % q.nc), j = (int)(cell / q.nc);
+        int64_t total = 0;
+        for (int k = 0; k < chunk; k++) {
+            const int64_t ac = (int64_t)i * chunk + k, bc = (int64_t)j * chunk + k;
+            if (!groups) {
+                const int a = bases[q.a_off + ac], b = bases[q.b_off + bc];
+                if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
+                total += kp.sc4[a * 5 + b] / 4;
+            } else {
+                int64_t sum = 0, count = 0;
+                for (int x = 0; x < q.a_nseq; x++) {
+                    int a = bases[q.a_off + (int64_t)x * q.a_len + ac];
+                    if (a >= 5 && a <= 9) a -= 5;
+                    for (int y = 0; y < q.b_nseq; y++) {
+                        int b = bases[q.b_off + (int64_t)y * q.b_len + bc];
+                        if (b >= 5 && b <= 9) b -= 5;
+                        if (a != 10 && b != 10) {
+                            if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
+                            sum += kp.sc4[a * 5 + b] / 4;
+                            count++;
+                        }
+                    }
+                }
+                if (count == 0) { atomicOr(err, 16); continue; } // Go: integer divide by zero
+                total += sum / count;
+            }
+        }
+        smat[q.s_off + (int64_t)j * q.s_pitch + i] = (int)(4 * total);
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_runs_kernel(gnx_cigar *__restrict__ ops, int64_t total, int64_t factor) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < total) ops[x].run_length *= factor; // expandCigarRunLength, affineGap_highMem.go:91-95
+}
+
 // exclusive scan of nops[0..n) + carry[0] -> off[0..n], off[n]; carry[0] = off[n] afterwards.  One block.
 __global__ __launch_bounds__(1024) void scan_kernel(const int64_t *__restrict__ nops, int n, int64_t *__restrict__ off, int64_t *__restrict__ carry) {
     __shared__ int64_t sh[1024];
@@ -924,7 +980,7 @@ struct Ctx {
     DevBuf fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev2[4] = {nullptr, nullptr, nullptr, nullptr};
-    DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops;
+    DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, sc_pairs, sc_mat, sc_err;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
 };
@@ -1005,7 +1061,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
         const int64_t n = h_alen[p], m = h_blen[p];
         pl.n = (int32_t)n; pl.m = (int32_t)m; pl.words = (int32_t)((m + 15 + 15) / 16); pl.strips = 1;
         pl.trace_off = 0; pl.hcol_off = p; pl.rowbuf_off = 0; pl.dcol_off = 0;
-        pl.src = (int32_t)p; pl.col_off = 0; pl.ckpt_off = coff; pl.rowi_off = roff;
+        pl.src = (int32_t)p; pl.col_off = 0; pl.ckpt_off = coff; pl.rowi_off = roff; pl.s_off = 0; pl.s_pitch = 0;
         roff += (int64_t)FP_PLANES * pl.words; coff += ((m - 1) / CKW) * n; cells += n * m;
         m_maxb = std::max(m_maxb, m);
     }
@@ -1189,11 +1245,13 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
                const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                const int64_t *h_alen, const int64_t *h_blen,
                int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
-               int64_t *out_total, hipStream_t stream) {
+               int64_t *out_total, hipStream_t stream, const int *d_smat = nullptr, const int64_t *h_soff = nullptr) {
+    // d_smat / h_soff: explicit per-cell score matrices (SCORED kernels, N1 variants); the sequences are then unused
     Ctx &c = g_ctx;
     KParams kp; TbParams tp; bool affine, local, lowmem;
     int rc = check_params(prm, kp, tp, affine, local, lowmem);
     if (rc) return rc;
+    if (d_smat && (!affine || local || lowmem)) { set_err("scored mode needs AffineGap_highMem semantics%s", ""); return GNX_EINVAL; }
     if (n_pairs < 0 || n_pairs > 0x7ffffff0) { set_err("bad n_pairs%s", ""); return GNX_EINVAL; }
     c.timing = gnx_timing{};
     if (n_pairs == 0) {
@@ -1207,7 +1265,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     // ---- fast path: every alpha fits one strip, long beta, global affine with gapOpen <= 0 ----
     {
         const char *fpenv = getenv("GNX_FASTPATH");
-        bool fp = affine && !local && prm->gap_open <= 0 && !(fpenv && fpenv[0] == '0');
+        bool fp = affine && !local && !d_smat && prm->gap_open <= 0 && !(fpenv && fpenv[0] == '0');
         int rstar = -1;
         for (int64_t p = 0; fp && p < n_pairs; p++) {
             const int64_t n = h_alen[p], m = h_blen[p];
@@ -1265,7 +1323,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) { set_err("pair %s%lld exceeds the int32 DP range", "", (long long)p); return GNX_ERANGE; }
             PairPlan &pl = plans[(size_t)p];
             pl.n = (int32_t)n; pl.m = (int32_t)m;
-            pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; // src is chunk-relative, set below
+            pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; // src is chunk-relative, set below
             pl.strips = (m > 0) ? (int32_t)((n + H - 1) / H) : 0;
             pl.words = (int32_t)((m + 15 + 15) / 16);
             const int64_t tsz = (int64_t)pl.strips * pl.words * Q * G;
@@ -1283,6 +1341,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
                 chunk_begin.push_back(cb);
             }
             pl.trace_off = toff; pl.hcol_off = hoff; pl.rowbuf_off = roff; pl.dcol_off = doff;
+            if (h_soff) { pl.s_off = h_soff[p]; pl.s_pitch = (int64_t)std::max<int32_t>(pl.strips, 1) * H; }
             toff += tsz; hoff += n; roff += (pl.strips > 1) ? m + 1 : 0; doff += (int64_t)pl.strips * G;
             cells += n * m;
         }
@@ -1335,8 +1394,13 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         if (affine) {
 #define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_, -1>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, (int2 *)nullptr, (unsigned *)nullptr, d_err)
 #define GNX_LAUNCH_AFF2(L_, M_, P_) do { if (hform) GNX_LAUNCH_AFF(L_, M_, P_, true); else GNX_LAUNCH_AFF(L_, M_, P_, false); } while (0)
-            const int sel = (local ? 4 : 0) | (multi ? 2 : 0) | (p16 ? 1 : 0);
+#define GNX_LAUNCH_SC(M_, H_) hipLaunchKernelGGL((fill_affine_kernel<false, M_, false, H_, -1, false, true>), gridF, blockF, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, (int2 *)nullptr, (unsigned *)nullptr, d_err, d_smat)
+            const int sel = d_smat ? 8 : ((local ? 4 : 0) | (multi ? 2 : 0) | (p16 ? 1 : 0));
             switch (sel) {
+            case 8:
+                if (multi) { if (hform) GNX_LAUNCH_SC(true, true); else GNX_LAUNCH_SC(true, false); }
+                else { if (hform) GNX_LAUNCH_SC(false, true); else GNX_LAUNCH_SC(false, false); }
+                break;
             case 0: GNX_LAUNCH_AFF2(false, false, false); break;
             case 1: GNX_LAUNCH_AFF2(false, false, true); break;
             case 2: GNX_LAUNCH_AFF2(false, true, false); break;
@@ -1346,6 +1410,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             case 6: GNX_LAUNCH_AFF2(true, true, false); break;
             default: GNX_LAUNCH_AFF2(true, true, true); break;
             }
+#undef GNX_LAUNCH_SC
 #undef GNX_LAUNCH_AFF2
 #undef GNX_LAUNCH_AFF
         } else {
@@ -1386,6 +1451,75 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
     if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
     if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
+    return GNX_OK;
+}
+
+// N1 host flow: bases (pairwise sequences or alignment blocks) -> score matrices on the device -> SCORED fill + the
+// ordinary highMem traceback -> run lengths times chunk size.  `sp` describes the pairs (offsets into `bases`).
+int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n_pairs, std::vector<ScorePair> &sp,
+                    const uint8_t *bases, int64_t bases_len, int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
+    Ctx &c = g_ctx;
+    if (!prm || !out_score || !out_ops || !out_ops_off || n_pairs < 0 || chunk < 1 || chunk > (1 << 20)) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    if (prm->mode != GNX_AFFINE_GAP_HIGHMEM) { set_err("the chunk / multiple-alignment variants have AffineGap_highMem semantics (mode %s%lld)", "", (long long)GNX_AFFINE_GAP_HIGHMEM); return GNX_EINVAL; }
+    KParams kp0; TbParams tp0; bool aff, loc, low;
+    int rc = check_params(prm, kp0, tp0, aff, loc, low);
+    if (rc) return rc;
+    gnx_params prm2 = *prm; // what the DP sees: gapExtend*chunkSize, |cell score| <= chunkSize*max|score|
+    prm2.gap_extend = prm->gap_extend * chunk;
+    for (int x = 0; x < 25; x++) prm2.scores[x] = prm->scores[x] * chunk;
+    hipStream_t st = c.own_stream;
+    std::vector<int64_t> hn((size_t)n_pairs), hm((size_t)n_pairs), hso((size_t)n_pairs);
+    int64_t stot = 0, worst = 0, maxcells = 1;
+    for (int64_t p = 0; p < n_pairs; p++) {
+        ScorePair &q = sp[(size_t)p];
+        const int64_t strips = std::max<int64_t>((q.nc + H - 1) / H, 1);
+        q.s_pitch = strips * H; q.s_off = stot;
+        stot += (int64_t)q.mc * q.s_pitch;
+        hn[(size_t)p] = q.nc; hm[(size_t)p] = q.mc; hso[(size_t)p] = q.s_off;
+        worst += q.nc + q.mc + 1;
+        maxcells = std::max<int64_t>(maxcells, (int64_t)q.nc * q.mc);
+    }
+    if ((rc = c.in_a.ensure((size_t)bases_len + 16))) return rc;
+    if ((rc = c.sc_pairs.ensure((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(ScorePair)))) return rc;
+    if ((rc = c.sc_mat.ensure((size_t)std::max<int64_t>(stot, 1) * 4))) return rc;
+    if ((rc = c.sc_err.ensure(16))) return rc;
+    const size_t np = (size_t)std::max<int64_t>(n_pairs, 1);
+    if ((rc = c.out_score.ensure(np * 8))) return rc;
+    if ((rc = c.out_off.ensure((np + 1) * 8))) return rc;
+    if (bases_len) HIPCHK(hipMemcpyAsync(c.in_a.p, bases, (size_t)bases_len, hipMemcpyHostToDevice, st));
+    if (n_pairs) HIPCHK(hipMemcpyAsync(c.sc_pairs.p, sp.data(), (size_t)n_pairs * sizeof(ScorePair), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c.sc_err.p, 0, 16, st));
+    for (int64_t b = 0; b < n_pairs; b += 32768) {
+        const unsigned ny = (unsigned)std::min<int64_t>(32768, n_pairs - b);
+        const unsigned nx = (unsigned)std::min<int64_t>((maxcells + 255) / 256, 4096);
+        hipLaunchKernelGGL(score_matrix_kernel, dim3(nx, ny), dim3(256), 0, st, reinterpret_cast<const ScorePair *>(c.sc_pairs.p) + b,
+                           reinterpret_cast<const uint8_t *>(c.in_a.p), kp0, (int)chunk, groups ? 1 : 0, reinterpret_cast<int *>(c.sc_mat.p), reinterpret_cast<int *>(c.sc_err.p));
+    }
+    HIPCHK(hipGetLastError());
+    int sflag[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(sflag, c.sc_err.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (sflag[0] & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
+    if (sflag[0] & 16) { set_err("scoreColumnMatch over gap-only columns: the reference panics (integer divide by zero)%s", ""); return GNX_EINVAL; }
+    int64_t cap = std::max<int64_t>(std::min<int64_t>(worst, std::max<int64_t>((int64_t)1 << 20, 64 * n_pairs)), 1);
+    int64_t total = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = c.out_ops.ensure((size_t)cap * sizeof(gnx_cigar)))) return rc;
+        rc = run_device(&prm2, n_pairs, nullptr, nullptr, nullptr, nullptr, hn.data(), hm.data(), (int64_t *)c.out_score.p, (gnx_cigar *)c.out_ops.p, cap,
+                        (int64_t *)c.out_off.p, &total, st, reinterpret_cast<const int *>(c.sc_mat.p), hso.data());
+        if (rc != GNX_ECAPACITY) break;
+        cap = total;
+    }
+    if (rc) return rc;
+    if (chunk > 1 && total > 0) hipLaunchKernelGGL(scale_runs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (gnx_cigar *)c.out_ops.p, total, chunk);
+    gnx_cigar *ops = (gnx_cigar *)malloc((size_t)std::max<int64_t>(total, 1) * sizeof(gnx_cigar));
+    int64_t *off = (int64_t *)malloc((size_t)(n_pairs + 1) * 8);
+    if (!ops || !off) { free(ops); free(off); set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
+    if (n_pairs) HIPCHK(hipMemcpyAsync(out_score, c.out_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(off, c.out_off.p, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (total) HIPCHK(hipMemcpyAsync(ops, c.out_ops.p, (size_t)total * sizeof(gnx_cigar), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *out_ops = ops; *out_ops_off = off;
     return GNX_OK;
 }
 
@@ -1484,7 +1618,8 @@ void gnx_shutdown(void) {
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
                       &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
-                      &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops};
+                      &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops,
+                      &g_ctx.sc_pairs, &g_ctx.sc_mat, &g_ctx.sc_err};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 4; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }
     if (g_ctx.own_stream) { (void)hipStreamDestroy(g_ctx.own_stream); g_ctx.own_stream = nullptr; }
@@ -1550,6 +1685,65 @@ int gnx_align_batch_device(const gnx_params *p, int64_t n_pairs,
     }
     return run_device(p, n_pairs, d_alpha_buf, d_alpha_start, d_beta_buf, d_beta_start, h_alpha_len, h_beta_len,
                       d_score, d_ops, ops_capacity, d_ops_off, out_total_ops, (hipStream_t)stream);
+}
+
+int gnx_affine_gap_chunk_batch(const gnx_params *p, int64_t chunk_size, int64_t n_pairs,
+                               const uint8_t *alpha_cat, const int64_t *alpha_off, const uint8_t *beta_cat, const int64_t *beta_off,
+                               int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    g_err[0] = 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(g_ctx.device));
+    if (n_pairs < 0 || chunk_size < 1 || (n_pairs > 0 && (!alpha_off || !beta_off))) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    const int64_t la = n_pairs ? alpha_off[n_pairs] : 0, lb = n_pairs ? beta_off[n_pairs] : 0;
+    std::vector<uint8_t> bases((size_t)(la + lb + 1));
+    if (la) memcpy(bases.data(), alpha_cat, (size_t)la);
+    if (lb) memcpy(bases.data() + la, beta_cat, (size_t)lb);
+    std::vector<ScorePair> sp((size_t)n_pairs);
+    for (int64_t q = 0; q < n_pairs; q++) {
+        const int64_t n = alpha_off[q + 1] - alpha_off[q], m = beta_off[q + 1] - beta_off[q];
+        if (n < 0 || m < 0 || n > 0x3fffffff || m > 0x3fffffff) { set_err("bad sequence length at pair %s%lld", "", (long long)q); return GNX_EINVAL; }
+        if (n % chunk_size != 0 || m % chunk_size != 0) { // log.Fatalf in the reference (affineGap_highMem.go:229-234)
+            set_err("pair %s%lld: sequence length is not a multiple of the chunk size", "", (long long)q); return GNX_EINVAL;
+        }
+        ScorePair &s = sp[(size_t)q];
+        s.a_off = alpha_off[q]; s.b_off = la + beta_off[q]; s.a_nseq = 1; s.b_nseq = 1; s.a_len = (int32_t)n; s.b_len = (int32_t)m;
+        s.nc = (int32_t)(n / chunk_size); s.mc = (int32_t)(m / chunk_size); s.s_off = 0; s.s_pitch = 0;
+    }
+    return run_host_scored(p, chunk_size, false, n_pairs, sp, bases.data(), la + lb, out_score, out_ops, out_ops_off);
+}
+
+int gnx_multiple_affine_gap_batch(const gnx_params *p, int64_t chunk_size, int64_t n_groups, const uint8_t *group_bases,
+                                  const int64_t *group_off, const int32_t *group_nseq, const int64_t *group_len,
+                                  int64_t n_pairs, const int32_t *pair_a, const int32_t *pair_b,
+                                  int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    g_err[0] = 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(g_ctx.device));
+    if (n_pairs < 0 || n_groups < 0 || chunk_size < 1 || (n_groups > 0 && (!group_off || !group_nseq || !group_len)) || (n_pairs > 0 && (!pair_a || !pair_b))) {
+        set_err("bad argument%s", ""); return GNX_EINVAL;
+    }
+    for (int64_t g = 0; g < n_groups; g++) {
+        if (group_nseq[g] < 1 || group_len[g] < 0 || group_len[g] > 0x3fffffff || group_off[g + 1] - group_off[g] != (int64_t)group_nseq[g] * group_len[g]) {
+            set_err("group %s%lld: bases do not match nseq x len", "", (long long)g); return GNX_EINVAL;
+        }
+    }
+    std::vector<ScorePair> sp((size_t)n_pairs);
+    for (int64_t q = 0; q < n_pairs; q++) {
+        const int32_t a = pair_a[q], b = pair_b[q];
+        if (a < 0 || b < 0 || a >= n_groups || b >= n_groups) { set_err("pair %s%lld: group index out of range", "", (long long)q); return GNX_EINVAL; }
+        if (group_len[a] % chunk_size != 0 || group_len[b] % chunk_size != 0) { // log.Fatalf (affineGap_highMem.go:310-315)
+            set_err("pair %s%lld: alignment length is not a multiple of the chunk size", "", (long long)q); return GNX_EINVAL;
+        }
+        ScorePair &s = sp[(size_t)q];
+        s.a_off = group_off[a]; s.b_off = group_off[b]; s.a_nseq = group_nseq[a]; s.b_nseq = group_nseq[b];
+        s.a_len = (int32_t)group_len[a]; s.b_len = (int32_t)group_len[b];
+        s.nc = (int32_t)(group_len[a] / chunk_size); s.mc = (int32_t)(group_len[b] / chunk_size); s.s_off = 0; s.s_pitch = 0;
+    }
+    return run_host_scored(p, chunk_size, true, n_pairs, sp, group_bases, n_groups ? group_off[n_groups] : 0, out_score, out_ops, out_ops_off);
 }
 
 int gnx_get_timing(gnx_timing *out) {

@@ -39,3 +39,11 @@ def ToMap(records):
 
 def ToUpper(fa):
     dna.AllToUpper(fa.Seq)
+
+
+def AllAreEqualIgnoreOrder(alpha, beta):
+    """fasta.AllAreEqualIgnoreOrder (/root/reference/fasta/fasta.go): same records (name + sequence) in any order."""
+    if len(alpha) != len(beta):
+        return False
+    key = lambda f: (f.Name, bytes(bytearray(f.Seq)))
+    return sorted(map(key, alpha)) == sorted(map(key, beta))

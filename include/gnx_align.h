@@ -137,6 +137,24 @@ int gnx_align_batch_device(const gnx_params *p, int64_t n_pairs,
 
 int gnx_get_timing(gnx_timing *out);
 
+/* ---- "next" row N1: chunk and multiple-alignment variants (what cmd/faChunkAlign and popgen/dunn.go run) ---- */
+/* align.AffineGapChunk (/root/reference/align/affineGap_highMem.go:227-268): the affine DP over chunks of chunk_size
+ * bases (cell score = ungapped score of two chunks, gapExtend*chunkSize, run lengths in bases).  p->mode must be
+ * GNX_AFFINE_GAP_HIGHMEM.  Lengths that are not multiples of chunk_size -> GNX_EINVAL (the Go code log.Fatalf's). */
+int gnx_affine_gap_chunk_batch(const gnx_params *p, int64_t chunk_size, int64_t n_pairs,
+                               const uint8_t *alpha_cat, const int64_t *alpha_off, const uint8_t *beta_cat, const int64_t *beta_off,
+                               int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off);
+
+/* align.multipleAffineGap (chunk_size 1, affineGap_highMem.go:270-306) and multipleAffineGapChunk (:308-353) on a batch
+ * of pairs of alignment blocks ("groups"): group g holds group_nseq[g] sequences of group_len[g] bases, sequence-major,
+ * at group_bases[group_off[g] ..); bases may be lower case or dna.Gap.  Pair q aligns group pair_a[q] against pair_b[q]
+ * with the column score of align/multiAlign.go:82-110.  This is the inner loop of AllSeqAffine / AllSeqAffineChunk
+ * (multiAlign.go:27-78): one call evaluates all x<y group pairs of a progressive-alignment round. */
+int gnx_multiple_affine_gap_batch(const gnx_params *p, int64_t chunk_size, int64_t n_groups, const uint8_t *group_bases,
+                                  const int64_t *group_off, const int32_t *group_nseq, const int64_t *group_len,
+                                  int64_t n_pairs, const int32_t *pair_a, const int32_t *pair_b,
+                                  int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off);
+
 #ifdef __cplusplus
 }
 #endif

@@ -499,6 +499,132 @@ int or_const_gap_highmem(const uint8_t *alpha, int64_t n, const uint8_t *beta, i
     return OR_OK;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * "Next" row N1: the chunk / multiple-alignment variants.  They are all the same full-matrix affine DP
+ * (initAffineScoringAndTrace + affineTrace, affineGap_highMem.go:13-27,57-89) over a per-cell score:
+ *   AffineGapChunk           affineGap_highMem.go:227-268   cell = ungappedRegionScore of two chunks (ungapped.go:7-13)
+ *   multipleAffineGap        affineGap_highMem.go:270-306   cell = scoreColumnMatch (multiAlign.go:82-102)
+ *   multipleAffineGapChunk   affineGap_highMem.go:308-353   cell = ungappedRegionColumnScore (multiAlign.go:104-110)
+ * gapExtend is multiplied by chunkSize, gapOpen is not; run lengths are multiplied by chunkSize at the end
+ * (expandCigarRunLength :91-95).  or_scored_affine() is that common loop over an explicit n x m score matrix.
+ * ---------------------------------------------------------------------------------------------- */
+static int or_scored_affine(int64_t n, int64_t m, const int64_t *S /* n*m row-major */, int64_t gapOpen, int64_t gapExt,
+                            int64_t *out_score, or_cigar **out_ops, int64_t *out_nops) {
+    int rc = OR_OK;
+    int64_t *cur[3], *prev[3]; uint8_t *trace[3];
+    const int64_t W = m + 1;
+    for (int k = 0; k < 3; k++) {
+        cur[k] = (int64_t *)xcalloc((size_t)W, 8); prev[k] = (int64_t *)xcalloc((size_t)W, 8);
+        trace[k] = (uint8_t *)xcalloc((size_t)((n + 1) * W), 1);
+        if (!cur[k] || !prev[k] || !trace[k]) rc = OR_ENOMEM;
+    }
+    route_t route; route.v = NULL;
+    if (!rc) rc = route_init(&route);
+    for (int64_t i = 0; !rc && i <= n; i++) {
+        for (int64_t j = 0; j < W; j++) {
+            if (i == 0 && j == 0) { cur[0][j] = 0; cur[1][j] = gapOpen; cur[2][j] = gapOpen; }
+            else if (i == 0) { cur[0][j] = VNN; cur[1][j] = gapExt + cur[1][j - 1]; trace[1][i * W + j] = 1; cur[2][j] = VNN; }
+            else if (j == 0) { cur[0][j] = VNN; cur[1][j] = VNN; cur[2][j] = gapExt + prev[2][j]; trace[2][i * W + j] = 2; }
+            else {
+                const int64_t s = S[(i - 1) * m + (j - 1)];
+                cur[0][j] = tmt(s + prev[0][j - 1], s + prev[1][j - 1], s + prev[2][j - 1], &trace[0][i * W + j]);
+                cur[1][j] = tmt(gapOpen + gapExt + cur[0][j - 1], gapExt + cur[1][j - 1], gapOpen + gapExt + cur[2][j - 1], &trace[1][i * W + j]);
+                cur[2][j] = tmt(gapOpen + gapExt + prev[0][j], gapOpen + gapExt + prev[1][j], gapExt + prev[2][j], &trace[2][i * W + j]);
+            }
+        }
+        if (i < n) for (int k = 0; k < 3; k++) { int64_t *t = prev[k]; prev[k] = cur[k]; cur[k] = t; }
+    }
+    int64_t maxScore = 0;
+    if (!rc) { /* affineTrace */
+        uint8_t k;
+        maxScore = tmt(cur[0][m], cur[1][m], cur[2][m], &k);
+        int64_t i = n, j = m, ridx = 0;
+        while (i > 0 || j > 0) {
+            if (route.v[ridx].run == 0) { route.v[ridx].run = 1; route.v[ridx].op = k; }
+            else if (route.v[ridx].op == k) route.v[ridx].run += 1;
+            else { rc = route_append(&route, 1, k); if (rc) break; ridx++; }
+            if (i < 0 || j < 0) { rc = OR_EINVAL; break; }
+            switch (k) {
+            case 0: k = trace[0][i * W + j]; i--; j--; break;
+            case 1: k = trace[1][i * W + j]; j--; break;
+            case 2: k = trace[2][i * W + j]; i--; break;
+            default: rc = OR_ETRACE;
+            }
+            if (rc) break;
+        }
+    }
+    for (int k = 0; k < 3; k++) { xfree(cur[k]); xfree(prev[k]); xfree(trace[k]); }
+    if (rc) { xfree(route.v); return rc; }
+    route_reverse(&route);
+    *out_score = maxScore; *out_ops = route.v; *out_nops = route.len;
+    return OR_OK;
+}
+
+/* multiAlign.go:82-102; returns OR_EINVAL where Go would panic (index out of range / integer divide by zero).
+ * A group is `g` sequences of `len` bases, sequence-major. */
+static int score_column_match(const uint8_t *A, int ga, int64_t la, const uint8_t *B, int gb, int64_t lb,
+                              int64_t acol, int64_t bcol, const int64_t *sc, int64_t *out) {
+    int64_t sum = 0, count = 0;
+    for (int x = 0; x < ga; x++) {
+        uint8_t a = A[x * la + acol];
+        if (a >= 5 && a <= 9) a -= 5;
+        for (int y = 0; y < gb; y++) {
+            uint8_t b = B[y * lb + bcol];
+            if (b >= 5 && b <= 9) b -= 5;
+            if (a != 10 && b != 10) {
+                if (a >= 5 || b >= 5) return OR_EINVAL;
+                sum += sc[a * 5 + b];
+                count++;
+            }
+        }
+    }
+    if (count == 0) return OR_EINVAL;
+    *out = sum / count; /* C and Go both truncate toward zero */
+    return OR_OK;
+}
+
+/* AffineGapChunk (affineGap_highMem.go:227-268) */
+int or_affine_gap_chunk(const uint8_t *alpha, int64_t n, const uint8_t *beta, int64_t m, const int64_t *sc,
+                        int64_t gapOpen, int64_t gapExtend, int64_t chunk,
+                        int64_t *out_score, or_cigar **out_ops, int64_t *out_nops) {
+    if (chunk < 1 || n < 0 || m < 0 || n % chunk != 0 || m % chunk != 0) return OR_EINVAL; /* log.Fatalf in the reference */
+    if (!bases_ok(alpha, n) || !bases_ok(beta, m)) return OR_EINVAL;
+    const int64_t nc = n / chunk, mc = m / chunk;
+    int64_t *S = (int64_t *)calloc((size_t)(nc * mc > 0 ? nc * mc : 1), 8);
+    if (!S) return OR_ENOMEM;
+    for (int64_t i = 0; i < nc; i++)
+        for (int64_t j = 0; j < mc; j++) {
+            int64_t a = 0;
+            for (int64_t k = 0; k < chunk; k++) a += sc[alpha[i * chunk + k] * 5 + beta[j * chunk + k]];
+            S[i * mc + j] = a;
+        }
+    int rc = or_scored_affine(nc, mc, S, gapOpen, gapExtend * chunk, out_score, out_ops, out_nops);
+    free(S);
+    if (!rc) for (int64_t x = 0; x < *out_nops; x++) (*out_ops)[x].run *= chunk;
+    return rc;
+}
+
+/* multipleAffineGap (chunk == 1, :270-306) and multipleAffineGapChunk (:308-353) */
+int or_multiple_affine_gap(const uint8_t *A, int ga, int64_t la, const uint8_t *B, int gb, int64_t lb, const int64_t *sc,
+                           int64_t gapOpen, int64_t gapExtend, int64_t chunk,
+                           int64_t *out_score, or_cigar **out_ops, int64_t *out_nops) {
+    if (chunk < 1 || ga < 1 || gb < 1 || la < 0 || lb < 0 || la % chunk != 0 || lb % chunk != 0) return OR_EINVAL;
+    const int64_t nc = la / chunk, mc = lb / chunk;
+    int64_t *S = (int64_t *)calloc((size_t)(nc * mc > 0 ? nc * mc : 1), 8);
+    if (!S) return OR_ENOMEM;
+    int rc = OR_OK;
+    for (int64_t i = 0; !rc && i < nc; i++)
+        for (int64_t j = 0; !rc && j < mc; j++) {
+            int64_t a = 0, v;
+            for (int64_t k = 0; k < chunk; k++) { rc = score_column_match(A, ga, la, B, gb, lb, i * chunk + k, j * chunk + k, sc, &v); if (rc) break; a += v; }
+            S[i * mc + j] = a;
+        }
+    if (!rc) rc = or_scored_affine(nc, mc, S, gapOpen, gapExtend * chunk, out_score, out_ops, out_nops);
+    free(S);
+    if (!rc) for (int64_t x = 0; x < *out_nops; x++) (*out_ops)[x].run *= chunk;
+    return rc;
+}
+
 void or_free(void *p) { free(p); }
 
 /* ------------------------------------------------------------------------------------------------

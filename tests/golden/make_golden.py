@@ -98,9 +98,10 @@ def main():
         "cmd/cigarToBed/testdata/sethvsraven": ["affineGap_sethvsraven_del.bed", "affineGap_sethvsraven_ins.bed",
                                                 "raven.fa", "seth.fa"],
         "cmd/globalAlignment/testdata": ["chelsea.fa", "eric.fa", "faOut_test.fa"],
+        "align/testdata": ["multiAlignTest.in.fa", "multiAlignTest.in2.fa", "multiAlignTest.expected.fa", "multiAlignTest.expected2.fa"],
     }
     for d, names in copies.items():
-        dst = os.path.join(HERE, "data", d.replace("cmd/", "").replace("/testdata", ""))
+        dst = os.path.join(HERE, "data", d.replace("cmd/", "").replace("/testdata", ""))  # align/testdata -> data/align
         os.makedirs(dst, exist_ok=True)
         for nm in names:
             shutil.copyfile(os.path.join(REF, d, nm), os.path.join(dst, nm))

@@ -34,6 +34,11 @@ def lib():
         L.or_align_batch.argtypes = [ctypes.c_int, c_p, i64, i64, i64, i64, i64, c_p, c_p, c_p, c_p, ctypes.c_int, c_p,
                                      ctypes.POINTER(c_p), c_p]
         L.or_align_batch.restype = ctypes.c_int
+        L.or_affine_gap_chunk.argtypes = [c_p, i64, c_p, i64, c_p, i64, i64, i64, ctypes.POINTER(i64), ctypes.POINTER(c_p), ctypes.POINTER(i64)]
+        L.or_affine_gap_chunk.restype = ctypes.c_int
+        L.or_multiple_affine_gap.argtypes = [c_p, ctypes.c_int, i64, c_p, ctypes.c_int, i64, c_p, i64, i64, i64,
+                                             ctypes.POINTER(i64), ctypes.POINTER(c_p), ctypes.POINTER(i64)]
+        L.or_multiple_affine_gap.restype = ctypes.c_int
         L.or_free.argtypes = [c_p]
         L.or_free.restype = None
         _lib = L
@@ -91,3 +96,38 @@ def align_one(mode, scores, gap_open, gap_extend, alpha, beta, ci=10000, cj=1000
 
 def cigar_str(route):
     return "".join("%d%s" % (r, "MID"[o]) for r, o in route)
+
+
+def _route_out(rc, score, ops_p, nops):
+    if rc != 0:
+        raise OracleError("oracle error %d" % rc)
+    total = nops.value
+    buf = (ctypes.c_char * (max(total, 1) * 16)).from_address(ops_p.value)
+    ops = np.frombuffer(buf, dtype=CIGAR_DTYPE, count=total).copy()
+    lib().or_free(ops_p)
+    return int(score.value), [(int(r), int(o)) for r, o in zip(ops["run_length"], ops["op"])]
+
+
+def affine_gap_chunk(scores, gap_open, gap_extend, chunk, alpha, beta):
+    L = lib()
+    sc = np.ascontiguousarray(np.asarray(scores, dtype=np.int64).reshape(25))
+    a = np.ascontiguousarray(np.concatenate([np.asarray(alpha, np.uint8), np.zeros(1, np.uint8)]))
+    b = np.ascontiguousarray(np.concatenate([np.asarray(beta, np.uint8), np.zeros(1, np.uint8)]))
+    score, nops, ops_p = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_void_p()
+    rc = L.or_affine_gap_chunk(a.ctypes.data, len(alpha), b.ctypes.data, len(beta), sc.ctypes.data, int(gap_open), int(gap_extend), int(chunk),
+                               ctypes.byref(score), ctypes.byref(ops_p), ctypes.byref(nops))
+    return _route_out(rc, score, ops_p, nops)
+
+
+def multiple_affine_gap(scores, gap_open, gap_extend, chunk, block_a, block_b):
+    """block_* : 2-D uint8 arrays (nseq x len)."""
+    L = lib()
+    sc = np.ascontiguousarray(np.asarray(scores, dtype=np.int64).reshape(25))
+    A = np.ascontiguousarray(block_a, dtype=np.uint8)
+    B = np.ascontiguousarray(block_b, dtype=np.uint8)
+    Ab = np.ascontiguousarray(np.concatenate([A.reshape(-1), np.zeros(1, np.uint8)]))
+    Bb = np.ascontiguousarray(np.concatenate([B.reshape(-1), np.zeros(1, np.uint8)]))
+    score, nops, ops_p = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_void_p()
+    rc = L.or_multiple_affine_gap(Ab.ctypes.data, A.shape[0], A.shape[1], Bb.ctypes.data, B.shape[0], B.shape[1], sc.ctypes.data,
+                                  int(gap_open), int(gap_extend), int(chunk), ctypes.byref(score), ctypes.byref(ops_p), ctypes.byref(nops))
+    return _route_out(rc, score, ops_p, nops)
