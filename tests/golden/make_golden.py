@@ -92,7 +92,9 @@ def main():
         "cmd/globalAlignmentAnchor/testdata": ["hg38.toy.fa", "rheMac10.toy.fa", "out_alignment.1.expected.tsv",
                                                "out_alignment.2.expected.tsv", "out_hg38_gap.1.expected.bed",
                                                "out_hg38_gap.2.expected.bed", "out_rheMac10_gap.1.expected.bed",
-                                               "out_rheMac10_gap.2.expected.bed"],
+                                               "out_rheMac10_gap.2.expected.bed", "out_hg38_alignment.1.expected.bed",
+                                               "out_hg38_alignment.2.expected.bed", "out_rheMac10_alignment.1.expected.bed",
+                                               "out_rheMac10_alignment.2.expected.bed"],
         "cmd/cigarToBed/testdata/firstTest": ["affineGap_PanTro6vshg38_del.bed", "affineGap_PanTro6vshg38_ins.bed",
                                               "testRegion10kb_PanTro6.fa", "testRegion10kb_hg38.fa"],
         "cmd/cigarToBed/testdata/sethvsraven": ["affineGap_sethvsraven_del.bed", "affineGap_sethvsraven_ins.bed",
