@@ -104,18 +104,17 @@ template <bool P16> struct ProfCfg {
     static constexpr int PST = 5 * BST + 16;         // dwords per pair
 };
 
-template <bool LOCAL, bool MULTI, bool P16, bool HFORM, int FP, bool WIN = false, bool SCORED = false>
+template <bool LOCAL, bool MULTI, bool P16, bool HFORM, bool WIN = false, bool SCORED = false>
 __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                          const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                          const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                          KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
-                                                         int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int2 *__restrict__ ckpt,
-                                                         unsigned *__restrict__ rowi, int *__restrict__ err, const int *__restrict__ smat = nullptr) {
+                                                         int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, const int2 *__restrict__ ckpt,
+                                                         int *__restrict__ err, const int *__restrict__ smat = nullptr) {
     // SCORED: the substitution score of a cell comes from an explicit per-pair matrix in HBM (chunk / multiple-alignment
     //      variants, "next" row N1) instead of the LDS profile of alpha x the base of the column; sequences are not read.
-    // FP = -1: record the full direction matrix (general path and window re-fills).
-    // FP = (n-1) % R: fast-path forward sweep -- no per-cell recording; keeps the I-plane of row n (register
-    //      rt[FP] of the owner lane), a column checkpoint {rt, X} of every row each CKW columns, and h(n,m).
+    // WIN: window / tile re-fill of the fast path: the left boundary comes from a column checkpoint written by
+    //      fp_sweep_kernel (pl.col_off > 0), the row-0 boundary and the beta window start at column col_off.
     using PC = ProfCfg<P16>;
     constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
     __shared__ int lds[32 + 4 * PST];
@@ -187,9 +186,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             hold[r] = max3i(NEG4 + 3, NEG4 + 2, D1c) + XE;
             rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + 2 + E4, D1c + OE4);
             if (WIN && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x; hold[r] = v.y; }
-            if (FP < 0) { acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0; }
+            acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
         }
-        unsigned accR[FP_PLANES] = {0u, 0u, 0u, 0u}; // fast path: I-planes of rows n-d, registers rt[(FP - d) mod R]
         int diag0 = ((row0 == 0) ? max3i(3, kp.o4 + 2, kp.d00_4 + 1) : max3i(NEG4 + 3, NEG4 + 2, kp.d00_4 + row0 * kp.ecol4 + 1)) + XE;
         if (WIN && ck0) {
             if (row0 == 0) diag0 = max3i(NEG4 + 3, kp.o4 + pl.col_off * E4 + 2, NEG4 + 1) + XE; // h(0, col_off)
@@ -217,9 +215,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         boundary(l + 1, qdn, qh, qb);
 
         // one anti-diagonal step; CHECK=false is the steady state (every lane of the wave has a live column)
-        auto step = [&](const int t, auto chk, auto ckt) {
+        auto step = [&](const int t, auto chk) {
             constexpr bool CHECK = decltype(chk)::value;
-            constexpr bool CKPT = decltype(ckt)::value; // this block may cross a checkpoint column
             const int up_dn = dpp_shr1(qdn, dn_out);
             const int up_h = dpp_shr1(qh, h_out);
             const int pb = dpp_shr1(qb, b_out);
@@ -240,29 +237,11 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                     int S4;
                     if (P16) S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
                     else S4 = w[r];
-                    if (FP < 0) {
-                        acc[r] = alignbit2((unsigned)hd, acc[r]);
-                        acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
-                        acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
-                    } else {
-#pragma unroll
-                        for (int d = 0; d < FP_PLANES; d++) if (r == (FP - d + R) % R) accR[d] = alignbit2((unsigned)rt[r], accR[d]);
-                    }
+                    acc[r] = alignbit2((unsigned)hd, acc[r]);
+                    acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
+                    acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
                     int hnew, dnn; // hnew is in the X domain (h + XE)
-                    // Fast-path forward sweep: the tag bits only matter where something is recorded (the FP_PLANES plane
-                    // rows, checkpoint columns -> CKPT blocks, h(n,m) on row n).  A tag never changes the VALUE of a max
-                    // (score differences are multiples of 4, tags are < 4), so the other rows skip the or/and cleaning;
-                    // their low bits are junk < 4 and every tagged row re-normalises what it reads.
-                    const bool TAGGED = FP < 0 || CKPT || ((FP - r + R) % R) < FP_PLANES; // folds after unrolling
-                    if (HFORM && !TAGGED) {
-                        const int M3e = hd + S4;
-                        const int Ie = rt[r] + vE4;
-                        const int De = dnu + vE4;
-                        hnew = max3i(M3e, Ie, De);
-                        const int hoe = hnew + vO4;
-                        rt[r] = max(hoe, Ie);
-                        dnn = max(hoe, De);
-                    } else if (HFORM) {
+                    if (HFORM) {
                         const int M3e = (hd | 3) + S4;             // M + e
                         const int Ie = (rt[r] & ~3) + vE4p2;       // I + e, tag 2
                         const int De = (dnu & ~3) + vE4p1;         // D + e, tag 1
@@ -288,47 +267,24 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 diag0 = up_h;
                 dn_out = dnu;
                 h_out = hold[R - 1];
-                if (FP >= 0 && CKPT && (j & (CKW - 1)) == 0 && j < m_eff && gact) { // column checkpoint
-                    int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n + row0;
-#pragma unroll
-                    for (int r = 0; r < R; r++) if (row0 + r < pl.n) ck[r] = make_int2(rt[r], hold[r]);
-                }
             }
             if (MULTI) { sq_dn = dpp_shl1(dn_out, sq_dn); sq_h = dpp_shl1(h_out, sq_h); }
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
             boundary(t0 + 16 + l + 1, ndn, nh, nb); // prefetch the next block's boundary
-            // the lanes' columns of this block are t0-14 .. t0+16: only blocks containing a multiple of CKW checkpoint
-            const bool ckblk = FP >= 0 && ((t0 + 16) & (CKW - 1)) <= 30;
             const bool steady = t0 >= 16 && t0 + 16 <= m_min;
-            if (steady && !ckblk) {
+            if (steady) {
 #pragma unroll 2
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{}, std::false_type{});
-            } else if (steady) {
-#pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{}, std::true_type{});
-            } else if (FP >= 0) {
-#pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{}, std::true_type{});
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{}, std::false_type{});
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
             }
             qdn = ndn; qh = nh; qb = nb;
             // flush 16 steps of direction bits: word w of this strip
             const int w = t0 >> 4;
-            if (FP >= 0) {
-                if (gact && w < pl.words) {
-                    const int miss = (t0 + 16 - l) - m_eff;
-                    const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
-#pragma unroll
-                    for (int d = 0; d < FP_PLANES; d++) {
-                        accR[d] >>= sh;
-                        if (pl.n - 1 - d >= 0 && l == (pl.n - 1 - d) / R) rowi[pl.rowi_off + (int64_t)d * pl.words + w] = accR[d]; // owner lane of row n-d
-                    }
-                }
-            } else if (gact && w < pl.words) {
+            if (gact && w < pl.words) {
                 const int miss = (t0 + 16 - l) - m_eff; // steps this lane sat idle after its last column
                 const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
                 if (t0 + 16 > m_min) { // drain: a lane that finished early right-aligns its last fields (it never shifts again)
@@ -345,9 +301,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + c] = make_int2(sq_dn, sq_h);
             }
         }
-        if (FP >= 0) {
-            if (gact && m_eff >= 1 && row0 + FP == pl.n - 1) hcol[pl.hcol_off] = hold[FP >= 0 ? FP : 0] - XE; // h(n, m) only
-        } else if (gact && m_eff >= 1) {
+        if (gact && m_eff >= 1) {
 #pragma unroll
             for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r] - XE;
             // last-column D-plane fields of this lane's rows, packed (field r at bits 2r): lets the traceback skip
@@ -360,6 +314,204 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         }
         if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
+    if (bad) atomicOr(err, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Fast-path forward sweep: 8 lanes x RR rows per pair, 8 pairs per wave64 (global affine, gapOpen <= 0, n <= 8*RR).
+// Same anti-diagonal wavefront as fill_affine_kernel, re-cut for the short-alpha shape:
+//  * REBASED keys.  Every cell quantity V(i,j) in {M, I, D, h} is carried as V' = V - e*(i+j).  The recurrences keep
+//    all their comparisons (each max compares candidates of the same cell, i.e. with the same offset) and become
+//        M'(i,j) = h'(i-1,j-1) + (s - 2e)    I'(i,j+1) = max(h'(i,j) + o, I'(i,j))    D'(i+1,j) = max(h'(i,j) + o, D'(i,j))
+//    (h-form, see fill_affine_kernel): both extensions cost nothing, both opens share h' + o, and every boundary
+//    (row 0, column 0) is a constant: per cell  add, max3, add, max, max  = 16 issue cycles instead of 20.
+//  * rows are RIGHT-ALIGNED: the pair's 8*RR slots end at row n, the first P = 8*RR - n slots are padding that reproduces
+//    row 0 (profile entry -32768 so M never wins; I' = h' = o, D' = 2o are fixed points of the recurrences when o <= 0).
+//    So rows n .. n-3 (whose I-planes are kept, FP_PLANES) are always the last four slots of the last lane: one kernel
+//    for every n, pairs of different length mix freely, and only 4 of RR rows per lane pay the tag arithmetic.
+//  * two pairs per 16-lane DPP row, the second one mirrored (lane 15 is its first lane), so that "value of the previous
+//    lane of my pair" is row_shr:1 on banks 0-1 plus row_shl:1 on banks 2-3 and the lanes without a source keep the
+//    boundary constant passed as `old`.
+//  * int16 score profile (4*(s-2e)) read as 5 ds_read_b64 per step: an LDS read costs the issuing SIMD ~2 cycles + 2 per
+//    returned dword (tools/lds_ubench.hip), so 20 rows cost 30 cycles for 8 pairs instead of 60 for 4.
+// Outputs (what fp_walk_kernel and the window re-fills of fill_affine_kernel<.., WIN> consume): un-rebased, tagged column
+// checkpoints {rt = I(i,j+1), X = h(i,j)+e} of every row every CKW columns, the I-plane words of rows n..n-3
+// (word = step >> 4, field = step & 15 with step = j + 7), and h(n,m).
+// ------------------------------------------------------------------------------------------------------
+constexpr int G8 = 8;
+constexpr int FP8_BST = 96;                // dwords per base plane (>= 8 lanes * 10 dwords, multiple of 32)
+constexpr int FP8_PST = 5 * FP8_BST + 16;  // dwords per pair: == 16 (mod 32), the two pairs of a 16-lane group hit disjoint banks
+constexpr int FP8_LW = 10;                 // dwords per lane per base (20 int16 entries)
+
+// lanes 0-7 of a DPP row: from lane-1; lanes 8-15 (mirrored pair): from lane+1; the first lane of each pair keeps oldv
+__device__ __forceinline__ int dpp_prev8(int oldv, int src) {
+    const int v = __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHR1, 0xf, 0x3, false);
+    return __builtin_amdgcn_update_dpp(v, src, DPP_ROW_SHL1, 0xf, 0xc, false);
+}
+// the opposite direction (queue rotation towards the first lane of the pair)
+__device__ __forceinline__ int dpp_next8(int oldv, int src) {
+    const int v = __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHL1, 0xf, 0x3, false);
+    return __builtin_amdgcn_update_dpp(v, src, DPP_ROW_SHR1, 0xf, 0xc, false);
+}
+
+// 2 waves per SIMD by choice: capping the kernel at 168 VGPRs for a third wave makes the compiler shuffle registers in the
+// unrolled loop and costs 20 % (measured: 32.2 ms vs 38.6-40.6 ms per 100 k pairs); 16 000 B of LDS allow 10 waves per CU.
+template <int RR>
+__global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                      KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
+                                                      unsigned *__restrict__ rowi, int *__restrict__ err) {
+    static_assert(RR <= 2 * FP8_LW && RR > FP_PLANES, "rows per lane");
+    __shared__ int lds[32 + 8 * FP8_PST];
+    const int lane = threadIdx.x;
+    const int g = lane >> 3;
+    const int lp = (lane & 8) ? 15 - (lane & 15) : (lane & 7); // position of the lane inside its pair
+    const int E4 = kp.e4;
+    if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * E4;
+    else if (lane < 32) lds[lane] = -32768; // padding rows: the diagonal candidate never wins
+    int *prof = &lds[32 + g * FP8_PST];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + lp * FP8_LW);
+
+    const int pbase = blockIdx.x * 8;
+    int m_max = 0, m_min = 0x7fffffff;
+    for (int q = 0; q < 8; q++) {
+        const int mq = (pbase + q < n_pairs) ? plans[pbase + q].m : 0;
+        m_max = max(m_max, mq); m_min = min(m_min, mq);
+    }
+    const int p = pbase + g;
+    const bool valid = p < n_pairs;
+    PairPlan pl;
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
+    const uint8_t *ap = a_buf + (valid ? a_start[pl.src] : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[pl.src] : 0);
+    const int m_eff = valid ? pl.m : 0;
+    const int P = G8 * RR - pl.n; // padding slots above row 1
+    const int q0 = lp * RR;       // first slot of this lane; slot q holds row q - P + 1
+    int bad = 0;
+    int vO4, cH, cDN; // constants pinned in VGPRs (2-cycle adds, DPP `old` operands)
+    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vO4), "=v"(cH), "=v"(cDN) : "s"(kp.o4), "s"(kp.o4 + 2), "s"(2 * kp.o4 + 2));
+
+    { // int16 profile of this lane's rows: prof[b][lp][r] = 4*(scores[alpha[row]][b] - 2e), padding -32768
+        int a5[2 * FP8_LW];
+#pragma unroll
+        for (int r = 0; r < 2 * FP8_LW; r++) {
+            int a = 5; // padding
+            const int q = q0 + r;
+            if (r < RR && q >= P) { a = ap[q - P]; if (a >= 5) { bad = 1; a = 4; } }
+            a5[r] = a * 5;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+#pragma unroll
+            for (int k = 0; k < FP8_LW; k++) prof[b * FP8_BST + lp * FP8_LW + k] = (lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16);
+        }
+        __syncthreads();
+    }
+    int rt[RR], hold[RR];
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
+        const int q = q0 + r;
+        // column 0: real row i: h'(i,0) = D'(i,0) = o (tag 1), I'(i,1) = 2o (from D); padding: h' = I' = o; the slot above row 1 is h(0,0) = 0 (tag 3)
+        hold[r] = (q >= P) ? kp.o4 + 1 : (q == P - 1 ? 3 : kp.o4 + 2);
+        rt[r] = (q >= P) ? 2 * kp.o4 + 1 : kp.o4 + 2;
+    }
+    unsigned accR[FP_PLANES] = {0u, 0u, 0u, 0u}; // I-planes of rows n-d = slots RR-1-d of the last lane
+    int diag0 = (q0 == 0) ? (P == 0 ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + 1 : (q0 - 1 == P - 1 ? 3 : kp.o4 + 2));
+    int dn_out = 0, h_out = 0, b_out = 0;
+    auto base_of = [&](int c) { // LDS byte offset of the profile plane of beta[c] (column c, 1-based)
+        int b = 0;
+        if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
+        return b * (FP8_BST * 4);
+    };
+    int qb = base_of(lp), nb = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
+
+    auto step = [&](const int t, auto chk, auto ckt) {
+        constexpr bool CHECK = decltype(chk)::value;
+        constexpr bool CKPT = decltype(ckt)::value; // this half block crosses a checkpoint column: every row carries its tags
+        const int up_dn = dpp_prev8(cDN, dn_out);
+        const int up_h = dpp_prev8(cH, h_out);
+        const int pb = dpp_prev8(qb, b_out);
+        qb = dpp_next8(qb, qb);
+        const int j = t - lp;
+        b_out = pb;
+        if (!CHECK || (j >= 1 && j <= m_eff)) {
+            const int2 *pw = reinterpret_cast<const int2 *>(prof_lane + pb);
+            int w[FP8_LW];
+#pragma unroll
+            for (int k = 0; k < FP8_LW / 2; k++) { const int2 v = pw[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+            int hd = diag0, dnu = up_dn;
+#pragma unroll
+            for (int r = 0; r < RR; r++) {
+                const int S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
+                if (r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
+                int hnew, dnn;
+                if (!CKPT && r < RR - FP_PLANES) { // tag bits are junk < 4 here; they never change the value of a max
+                    const int M = hd + S4;
+                    hnew = max3i(M, rt[r], dnu);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, rt[r]);
+                    dnn = max(ho, dnu);
+                } else {
+                    const int M3 = (hd | 3) + S4;
+                    const int I2 = (rt[r] & ~3) | 2;
+                    const int D1 = (dnu & ~3) | 1;
+                    hnew = max3i(M3, I2, D1);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, I2);
+                    dnn = max(ho, D1);
+                }
+                hd = hold[r];
+                hold[r] = hnew;
+                dnu = dnn;
+            }
+            diag0 = up_h;
+            dn_out = dnu;
+            h_out = hold[RR - 1];
+            if (CKPT && (j & (CKW - 1)) == 0 && j < m_eff && valid) { // column checkpoint, un-rebased: {I(i,j+1), h(i,j)+e}
+                int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n;
+#pragma unroll
+                for (int r = 0; r < RR; r++) {
+                    const int i = q0 + r - P + 1;
+                    const int off = E4 * (i + j + 1);
+                    if (i >= 1) ck[i - 1] = make_int2(rt[r] + off, hold[r] + off);
+                }
+            }
+        }
+    };
+
+    // half blocks of 8 steps t0 .. t0+7 (step t: lane lp is at column t - lp); a plane word is two half blocks
+    const int Tend = ((m_max + G8 - 1) / 16 + 1) * 16;
+    for (int t0 = 0; t0 < Tend; t0 += 8) {
+        nb = base_of(t0 + 8 + lp); // prefetch the next half block's bases
+        const bool ckblk = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
+        const bool steady = t0 >= 8 && t0 + 7 <= m_min;
+        if (steady && !ckblk) {
+#pragma unroll 2
+            for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, std::false_type{});
+        } else if (steady) {
+#pragma unroll 1
+            for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, std::true_type{});
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < 8; u++) step(t0 + u, std::true_type{}, std::true_type{});
+        }
+        qb = nb;
+        if ((t0 & 8) && lp == G8 - 1 && valid) { // the last lane owns rows n..n-3: flush the plane word of steps t0-8 .. t0+7
+            const int w = t0 >> 4;
+            if (w < pl.words) {
+                const int miss = (t0 + 7) - (m_eff + G8 - 1); // steps this lane sat idle after its last column
+                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+#pragma unroll
+                for (int d = 0; d < FP_PLANES; d++) {
+                    accR[d] >>= sh;
+                    if (pl.n - d >= 1) rowi[pl.rowi_off + (int64_t)d * pl.words + w] = accR[d];
+                }
+            }
+        }
+    }
+    if (lp == G8 - 1 && valid && m_eff >= 1) hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); // h(n, m)
     if (bad) atomicOr(err, 1);
 }
 
@@ -692,7 +844,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
 //   fp_walk: one lane per pair.  On row n in state I it follows the stored I-plane of row n (the long trailing
 //   gap of a short read against a long chunk) a word at a time; anywhere else it needs full direction bits and
 //   requests a re-fill of the <= FP_SPAN+CKW-1 columns left of the current cell from the nearest column
-//   checkpoint (window plan appended to a list), which fill_affine_kernel<.., FP=-1> computes with the normal
+//   checkpoint (window plan appended to a list), which fill_affine_kernel<.., WIN> computes with the normal
 //   recording; the next fp_walk call continues inside that window.  Row 0 / column 0 end the walk (Step 4).
 //   CIGAR runs are staged per pair in traceback order and reversed into place by fp_compact.
 // Same checkerboard-walk emulation (Q1/Q2) as traceback_kernel.
@@ -755,7 +907,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         int pos;
         const bool on_plane = (k == 1) && (pl.n - i) < FP_PLANES;
         if (on_plane) { // stored I-plane of row n-d
-            const int t1 = j + (i - 1) / R - 1;
+            const int t1 = j + G8 - 1; // step at which the owner lane (the pair's last) was at column j
             w = rowi[pl.rowi_off + (int64_t)(pl.n - i) * pl.words + (t1 >> 4)];
             pos = t1 & 15;
         } else if (j > st.jc_lo && j <= st.j_hi) { // inside the current window
@@ -978,8 +1130,6 @@ struct Ctx {
     hipStream_t own_stream = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
     DevBuf fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace;
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev2[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, sc_pairs, sc_mat, sc_err;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -1048,9 +1198,10 @@ int64_t max_abs_pen(const gnx_params *p, bool affine) {
 // `first` = first sub-batch of a call: later sub-batches keep the error flags and the CIGAR offset carry.
 int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
                   const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
-                  const int64_t *h_alen, const int64_t *h_blen, int rstar,
+                  const int64_t *h_alen, const int64_t *h_blen, int rows_per_lane,
                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
                   int64_t *out_total, hipStream_t stream, bool first) {
+    // rows_per_lane: 19 (every n <= 152) or 20 (n <= 160) -> fp_sweep_kernel<19 / 20>
     Ctx &c = g_ctx;
     int rc;
     const int np = (int)n_pairs;
@@ -1067,7 +1218,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     }
     const size_t wtrace_b = (size_t)np * FP_WWORDS * QA * G * 16;
     const size_t need = wtrace_b + (size_t)coff * 8 + (size_t)roff * 4 + (size_t)np * (FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + H * 4 + G * 4 + 32);
-    if ((int64_t)need > c.ws_limit) return -1;
+    if ((int64_t)need > c.ws_limit) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] working set %zu B exceeds the workspace limit -> general path\n", need); return -1; }
     if ((rc = c.trace.ensure(wtrace_b))) return rc;
     if ((rc = c.hcol.ensure((size_t)np * (H + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then the window hcol slots
     if ((rc = c.dcol.ensure((size_t)np * G * 4))) return rc;
@@ -1082,14 +1233,10 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
         if ((rc = c.fp_wplans[x].ensure((size_t)np * sizeof(PairPlan)))) return rc;
         if ((rc = c.fp_active[x].ensure((size_t)np * 4))) return rc;
     }
-    if (!c.stream2) {
-        HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
-        for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c.ev2[i]));
-        for (int i = 4; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
-    }
+    if (!c.ev[4]) for (int i = 4; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
     int *d_err = reinterpret_cast<int *>(c.misc.p);
     int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
-    int *d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(c.misc.p) + 32); // window-request counters: [0,1] part A, [2,3] part B
+    int *d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(c.misc.p) + 32); // window-request counters (ping-pong)
     if (first) HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
     else HIPCHK(hipMemsetAsync(d_cnt, 0, 16, stream));
     HIPCHK(hipMemcpyAsync(c.plans.p, plans.data(), (size_t)np * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
@@ -1108,28 +1255,10 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     const int tiles_per = (int)((m_maxb + FP_TILE - 1) / FP_TILE);
     double refill_ms = 0;
 
-    // Optional (GNX_FP_SPLIT=1): sweep the last partial "round" of waves (part B) on a second stream underneath part A's
-    // walk / window stages.  Measured on MI355X it does NOT pay: 98 304 pairs (8 full rounds of 3072 resident waves) take
-    // 41.1 ms and all 100 000 take 41.9 ms -- the dispatcher's staggered wave starts already hide the partial round --
-    // so it is off by default and kept only as an experiment switch.
-    int nA = np;
-    if (getenv("GNX_FP_SPLIT")) {
-        int per_cu = 0, cus = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fill_affine_kernel<false, false, false, true, 9>, 64, 0) != hipSuccess) per_cu = 0;
-        const int64_t slots = (int64_t)per_cu * cus, waves = (np + 3) / 4;
-        if (slots > 0 && waves > slots) {
-            const int64_t rem = waves % slots;
-            if (rem > 0 && rem * 2 < slots) nA = (int)((waves - rem) * 4);
-        }
-    }
-    const int nB = np - nA;
     auto forward = [&](int p0, int cnt, hipStream_t st) -> int {
-        const dim3 gridF((unsigned)((cnt + 3) / 4));
-#define GNX_FPF(K_) case K_: hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, K_>), gridF, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, (uint4 *)nullptr, d_hfwd, (int2 *)nullptr, (unsigned *)nullptr, d_ckpt, d_rowi, d_err); break;
-        switch (rstar) { GNX_FPF(0) GNX_FPF(1) GNX_FPF(2) GNX_FPF(3) GNX_FPF(4) GNX_FPF(5) GNX_FPF(6) GNX_FPF(7) GNX_FPF(8) default: GNX_FPF(9) }
-#undef GNX_FPF
+        const dim3 grid8((unsigned)((cnt + G8 - 1) / G8));
+        if (rows_per_lane == 19) hipLaunchKernelGGL(fp_sweep_kernel<19>, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_err);
+        else hipLaunchKernelGGL(fp_sweep_kernel<20>, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_err);
         HIPCHK(hipGetLastError());
         return GNX_OK;
     };
@@ -1149,8 +1278,8 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
             const int nxt = cur ^ 1;
             HIPCHK(hipMemsetAsync(cnt2 + nxt, 0, 4, st));
             HIPCHK(hipEventRecord(e1, st));
-            hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1, true>), dim3((unsigned)((n_act + 3) / 4)), blockF, 0, st, d_wpl[cur] + p0, n_act, d_a, d_as, d_b, d_bs, kp,
-                               wtr, whc, (int2 *)nullptr, wdc, d_ckpt, (unsigned *)nullptr, d_err);
+            hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, true>), dim3((unsigned)((n_act + 3) / 4)), blockF, 0, st, d_wpl[cur] + p0, n_act, d_a, d_as, d_b, d_bs, kp,
+                               wtr, whc, (int2 *)nullptr, wdc, d_ckpt, d_err);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(e2, st));
             hipLaunchKernelGGL(fp_walk_kernel<false>, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_ckpt,
@@ -1170,7 +1299,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
             const int n_strag = n_act;
             const int64_t n_tiles = (int64_t)n_strag * tiles_per;
             const size_t tb = (size_t)n_tiles * FP_TWORDS * QA * G * 16;
-            if ((int64_t)tb > c.ws_limit || n_tiles > 0x3fffffff) return -1;
+            if ((int64_t)tb > c.ws_limit || n_tiles > 0x3fffffff) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %lld straggler tiles exceed the workspace limit -> general path\n", (long long)n_tiles); return -1; }
             int rc2;
             if ((rc2 = c.rowbuf.ensure((size_t)n_tiles * sizeof(PairPlan)))) return rc2; // tile plans (rowbuf is unused on this path)
             if ((rc2 = c.fp_thcol.ensure((size_t)n_tiles * (H + G) * 4))) return rc2;
@@ -1181,8 +1310,8 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
             uint4 *ttr = reinterpret_cast<uint4 *>(c.fp_ttrace.p);
             hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, dpl, d_act[cur] + p0, n_strag, tiles_per, d_st, tpl);
             HIPCHK(hipEventRecord(e1, st));
-            hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, -1, true>), dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, st, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
-                               ttr, thc, (int2 *)nullptr, tdc, d_ckpt, (unsigned *)nullptr, d_err);
+            hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, true>), dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, st, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
+                               ttr, thc, (int2 *)nullptr, tdc, d_ckpt, d_err);
             HIPCHK(hipEventRecord(e2, st));
             HIPCHK(hipMemsetAsync(cnt2, 0, 8, st));
             hipLaunchKernelGGL((fp_walk_kernel<false, true>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_strag, d_st, d_hfwd, d_rowi, d_ckpt,
@@ -1197,20 +1326,9 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     };
 
     HIPCHK(hipEventRecord(c.ev[0], stream));
-    if ((rc = forward(0, nA, stream))) return rc;
+    if ((rc = forward(0, np, stream))) return rc;
     HIPCHK(hipEventRecord(c.ev[1], stream));
-    if (nB > 0) {
-        HIPCHK(hipStreamWaitEvent(c.stream2, c.ev[1], 0)); // also orders B after the plan upload / memset on `stream`
-        HIPCHK(hipEventRecord(c.ev2[0], c.stream2));
-        if ((rc = forward(nA, nB, c.stream2))) return rc;
-        HIPCHK(hipEventRecord(c.ev2[1], c.stream2));
-    }
-    if ((rc = post(0, nA, stream, d_cnt, c.ev[4], c.ev[5]))) { if (nB > 0) (void)hipStreamSynchronize(c.stream2); return rc; }
-    if (nB > 0) {
-        rc = post(nA, nB, c.stream2, d_cnt + 2, c.ev2[2], c.ev2[3]);
-        HIPCHK(hipStreamSynchronize(c.stream2));
-        if (rc) return rc;
-    }
+    if ((rc = post(0, np, stream, d_cnt, c.ev[4], c.ev[5]))) return rc;
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, d_nops, np, d_ops_off, d_carry);
     hipLaunchKernelGGL(fp_compact_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, d_st, d_stage, d_nops, d_ops_off, d_ops, ops_capacity, d_err);
     HIPCHK(hipGetLastError());
@@ -1218,24 +1336,22 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     int h_misc[16];
     HIPCHK(hipMemcpyAsync(h_misc, c.misc.p, 64, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    float tot = 0, fa = 0, fb = 0;
+    float tot = 0, fa = 0;
     HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[3]));
     HIPCHK(hipEventElapsedTime(&fa, c.ev[0], c.ev[1]));
-    if (nB > 0) HIPCHK(hipEventElapsedTime(&fb, c.ev2[0], c.ev2[1]));
-    const double forward_ms = (double)fa + fb;
-    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] forward sweep: %d pairs %.3f ms%s", nA, fa, nB > 0 ? "" : "\n");
-    if (getenv("GNX_DEBUG") && nB > 0) fprintf(stderr, " + %d pairs %.3f ms on the second stream\n", nB, fb);
+    const double forward_ms = (double)fa;
+    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] forward sweep (fp_sweep_kernel<%d>): %d pairs %.3f ms\n", rows_per_lane, np, fa);
     if (first) c.timing = gnx_timing{};
     c.timing.fill_ms += forward_ms + refill_ms; c.timing.traceback_ms += std::max(0.0, (double)tot - fa - refill_ms); c.timing.total_ms += tot;
     c.timing.cells += cells; c.timing.n_launches += 1; c.timing.trace_bytes += (int64_t)coff * 8 + (int64_t)roff * 4;
-    c.timing.dominant_ms += forward_ms; c.timing.dominant_launches += (nB > 0) ? 2 : 1; c.timing.fast_path = 1;
+    c.timing.dominant_ms += forward_ms; c.timing.dominant_launches += 1; c.timing.fast_path = 1;
     int64_t total;
     memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
     if (out_total) *out_total = total;
     const int ef = h_misc[0];
     if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
     if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
-    if (ef & 8) return -1; // a CIGAR with more than FP_CAP runs: redo on the general path
+    if (ef & 8) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] a CIGAR has more than %d runs -> general path\n", FP_CAP); return -1; } // redo on the general path
     if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
     return GNX_OK;
 }
@@ -1266,14 +1382,17 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     {
         const char *fpenv = getenv("GNX_FASTPATH");
         bool fp = affine && !local && !d_smat && prm->gap_open <= 0 && !(fpenv && fpenv[0] == '0');
-        int rstar = -1;
+        // fp_sweep_kernel keeps an int16 profile of 4*(s - 2e); its padding rows need 4*|gapOpen| well inside int16
+        if (prm->gap_open <= -8000) fp = false;
+        for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * prm->gap_extend); if (v > 32767 || v < -32000) fp = false; }
+        int64_t n_hi = 0;
         for (int64_t p = 0; fp && p < n_pairs; p++) {
             const int64_t n = h_alen[p], m = h_blen[p];
             if (n < 1 || n > H || m < (fpenv && fpenv[0] == '2' ? 1 : 768) || m > 0x3fffffff) fp = false;
             else if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) fp = false;
-            else if (rstar < 0) rstar = (int)((n - 1) % R);
-            else if (rstar != (int)((n - 1) % R)) fp = false;
+            n_hi = std::max(n_hi, n);
         }
+        const int rows_per_lane = n_hi <= 19 * G8 ? 19 : 20;
         if (fp) {
             // sub-batches whose fast-path working set (checkpoints, planes, window slots, staging) fits the workspace
             const size_t fixed = (size_t)FP_WWORDS * QA * G * 16 + FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + H * 4 + G * 4 + 64;
@@ -1290,7 +1409,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             rc = -1;
             for (size_t ch = 0; fp && ch + 1 < cb.size(); ch++) {
                 const int64_t b = cb[ch], e = cb[ch + 1];
-                rc = run_device_fp(kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rstar, d_score + b, d_ops, ops_capacity,
+                rc = run_device_fp(kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
                                    d_ops_off + b, out_total, stream, ch == 0);
                 if (rc != GNX_OK) break;
             }
@@ -1392,9 +1511,9 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         bool multi = false;
         for (int64_t q2 = b; q2 < e; q2++) if (plans[(size_t)q2].strips > 1) { multi = true; break; }
         if (affine) {
-#define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_, -1>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, (int2 *)nullptr, (unsigned *)nullptr, d_err)
+#define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, (const int2 *)nullptr, d_err)
 #define GNX_LAUNCH_AFF2(L_, M_, P_) do { if (hform) GNX_LAUNCH_AFF(L_, M_, P_, true); else GNX_LAUNCH_AFF(L_, M_, P_, false); } while (0)
-#define GNX_LAUNCH_SC(M_, H_) hipLaunchKernelGGL((fill_affine_kernel<false, M_, false, H_, -1, false, true>), gridF, blockF, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, (int2 *)nullptr, (unsigned *)nullptr, d_err, d_smat)
+#define GNX_LAUNCH_SC(M_, H_) hipLaunchKernelGGL((fill_affine_kernel<false, M_, false, H_, false, true>), gridF, blockF, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, (const int2 *)nullptr, d_err, d_smat)
             const int sel = d_smat ? 8 : ((local ? 4 : 0) | (multi ? 2 : 0) | (p16 ? 1 : 0));
             switch (sel) {
             case 8:
@@ -1623,8 +1742,6 @@ void gnx_shutdown(void) {
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 4; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }
     if (g_ctx.own_stream) { (void)hipStreamDestroy(g_ctx.own_stream); g_ctx.own_stream = nullptr; }
-    if (g_ctx.stream2) { (void)hipStreamDestroy(g_ctx.stream2); g_ctx.stream2 = nullptr; }
-    for (int i = 0; i < 4; i++) if (g_ctx.ev2[i]) { (void)hipEventDestroy(g_ctx.ev2[i]); g_ctx.ev2[i] = nullptr; }
     for (int i = 4; i < 8; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }
     g_ctx.inited = false;
     g_ctx.ws_limit = 0;

@@ -20,7 +20,7 @@ def Read(filename):
     with open(filename) as fh:
         for line in fh:
             line = line.rstrip("\r\n")
-            if not line:
+            if not line or line.startswith("#"):  # fileio.EasyNextRealLine skips comment lines
                 continue
             if line.startswith(">"):
                 if name is not None:
@@ -34,7 +34,27 @@ def Read(filename):
 
 
 def ToMap(records):
-    return {r.Name: r.Seq for r in records}
+    m = {}
+    for r in records:
+        if r.Name in m:
+            raise RuntimeError("%s used for multiple fasta records. record names must be unique." % r.Name)
+        m[r.Name] = r.Seq
+    return m
+
+
+def WriteFasta(fh, rec, lineLength=50):
+    """fasta.WriteFasta (/root/reference/fasta/fasta.go:163-177): name line, then lines of lineLength bases."""
+    fh.write(">%s\n" % rec.Name)
+    s = dna.BasesToString(rec.Seq)
+    for i in range(0, len(s), lineLength):
+        fh.write(s[i:i + lineLength] + "\n")
+
+
+def Write(filename, records):
+    """fasta.Write (fasta.go:147-152): line length 50."""
+    with open(filename, "w") as fh:
+        for rec in records:
+            WriteFasta(fh, rec, 50)
 
 
 def ToUpper(fa):

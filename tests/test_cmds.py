@@ -76,3 +76,13 @@ def test_cmds_on_gpu(gpu_lib, tmp_path):
     _check_global_alignment(tmp_path)
     _check_cigar_to_bed(tmp_path)
     _check_anchor(tmp_path)
+
+
+def test_fasta_write_matches_reference_layout(tmp_path):
+    """fasta.Write (line length 50) reproduces the reference-written multi-fasta fixtures byte for byte."""
+    from gonomics_amd import fasta
+    for nm in ("multiAlignTest.expected.fa", "multiAlignTest.expected2.fa"):
+        src = os.path.join(D, "align", nm)
+        out = str(tmp_path / nm)
+        fasta.Write(out, fasta.Read(src))
+        assert filecmp.cmp(out, src, shallow=False)

@@ -297,14 +297,58 @@ def test_fast_path_chunking_and_fallback(gpu_lib):
     try:
         got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len)
         tm = gpu_lib.get_timing()
-        if os.environ.get("GNX_FASTPATH", "1") != "0":
+        if os.environ.get("GNX_FASTPATH", "1") != "0" and "GNX_FP_MAXIT" not in os.environ:  # (MAXIT=0 needs more tile workspace than 12 MB)
             assert tm["fast_path"] == 1 and tm["dominant_launches"] > 1
     finally:
         gpu_lib.check(gpu_lib.lib().gnx_init(0, 8 << 30))
     common.assert_same(got, exp, "fast path, chunked")
-    # mixed (n-1) % 10 -> general path, same answers
+    # mixed read lengths stay on the fast path (rows are right-aligned per pair in fp_sweep_kernel)
     reads2 = [reads[k, :150 - (k % 3)] for k in range(64)]
     got = gpu_lib.align_batch(p, reads2, [chunk] * 64)
-    assert gpu_lib.get_timing()["fast_path"] == 0
+    if os.environ.get("GNX_FASTPATH", "1") != "0":
+        assert gpu_lib.get_timing()["fast_path"] == 1
     exp = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, reads2, [chunk] * 64, threads=8)
     common.assert_same(got, exp, "mixed lengths")
+    # a matrix whose 4*(s - 2e) does not fit the int16 profile of the sweep kernel -> general path, same answers
+    big = [[v * 40 for v in row] for row in align.HumanChimpTwoScoreMatrix]
+    pb = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, big, -600, -150)
+    got = gpu_lib.align_batch(pb, reads2, [chunk] * 64)
+    assert gpu_lib.get_timing()["fast_path"] == 0
+    exp = oracle.align_batch(0, np.asarray(big, dtype=np.int64), -600, -150, reads2, [chunk] * 64, threads=8)
+    common.assert_same(got, exp, "big scores -> general path")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_fast_path_sweep_geometry(gpu_lib, seed, monkeypatch):
+    """fp_sweep_kernel: every alpha length 1..160 (padding slots, 19 and 20 rows per lane, fewer rows than planes),
+    ragged beta lengths around the checkpoint spacing, several penalty sets incl. gapOpen = 0; forced onto the fast path."""
+    monkeypatch.setenv("GNX_FASTPATH", "2")
+    rng = np.random.default_rng(seed)
+    ref = rng.integers(0, 4, size=4000, dtype=np.uint8)
+    ref[rng.integers(0, 4000, size=8)] = 4
+    n_hi = [152, 160, 40][seed - 31]
+    alphas, betas = [], []
+    for k in range(200):
+        n = int(rng.integers(1, n_hi + 1)) if k >= 12 else [1, 2, 3, 4, 5, n_hi, n_hi - 1, 19, 20, 21, 8, n_hi - 8][k]
+        n = max(1, min(n, n_hi))
+        m = int(rng.choice([1, 7, 8, 9, 15, 16, 17, 127, 128, 129, 255, 256, 257, 300, 1000, 1500, 2049]))
+        off = int(rng.integers(0, 4000 - m + 1))
+        beta = ref[off:off + m].copy()
+        pos = int(rng.integers(0, max(1, m - n + 1)))
+        alpha = common.mutate(rng, beta[pos:pos + n], 0.05, 0.02) if m >= n and rng.random() < 0.8 else rng.integers(0, 4, size=n, dtype=np.uint8)
+        alpha = alpha[:n_hi] if alpha.shape[0] > 0 else np.array([1], dtype=np.uint8)
+        alphas.append(alpha); betas.append(beta)
+    for name, go, ge in [("HumanChimpTwo", -600, -150), ("Default", -400, -30), ("HumanChimpTwo", 0, -150), ("Default", -3, 0)]:
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX[name], go, ge)
+        got = gpu_lib.align_batch(p, alphas, betas)
+        # cheap gaps give CIGARs with more than 64 runs, which send the batch back through the general path -- also checked
+        if go == -600:
+            assert gpu_lib.get_timing()["fast_path"] == 1
+        exp = oracle.align_batch(0, MX[name], go, ge, alphas, betas, threads=8)
+        common.assert_same(got, exp, "sweep geometry %s %d %d" % (name, go, ge))
+    # small checkerboards on the fast path: quirks Q1/Q2 through the staged walk
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150, 7, 7)
+    got = gpu_lib.align_batch(p, alphas, betas)
+    exp = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, alphas, betas, ci=7, cj=7, threads=8)
+    common.assert_same(got, exp, "sweep geometry, 7x7 checkerboards")
