@@ -67,7 +67,7 @@ constexpr int FP_PLANES = 4; // rows n .. n-3 keep their I-plane: a trailing gap
 constexpr int FP_CAP = 64;   // CIGAR runs staged per pair on the fast path (more -> general path)
 constexpr int FP_WWORDS = (FP_SPAN + CKW + 15 + 15) / 16 + 1; // direction words of the widest window
 constexpr int FP_TILE = 1024;                                  // straggler tiles: columns (c*FP_TILE, (c+1)*FP_TILE]
-constexpr int FP_TWORDS = (FP_TILE + 15 + 15) / 16;            // direction words of a tile
+constexpr int FP_TWORDS = (FP_TILE + CKW + 15 + 15) / 16;      // direction words of a tile (plus the checkpoint interval it starts early)
 
 struct KParams {
     int sc4[25]; // 4*scores
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
 
     auto step = [&](const int t, auto chk, auto ckt) {
         constexpr bool CHECK = decltype(chk)::value;
-        constexpr bool CKPT = decltype(ckt)::value; // this half block crosses a checkpoint column: every row carries its tags
+        constexpr bool CKPT = decltype(ckt)::value; // this half block crosses a checkpoint column
         const int up_dn = dpp_prev8(cDN, dn_out);
         const int up_h = dpp_prev8(cH, h_out);
         const int pb = dpp_prev8(qb, b_out);
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
                 const int S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
                 if (r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
                 int hnew, dnn;
-                if (!CKPT && r < RR - FP_PLANES) { // tag bits are junk < 4 here; they never change the value of a max
+                if (r < RR - FP_PLANES) { // tag bits are junk < 4 here; they never change the value of a max
                     const int M = hd + S4;
                     hnew = max3i(M, rt[r], dnu);
                     const int ho = hnew + vO4;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
             diag0 = up_h;
             dn_out = dnu;
             h_out = hold[RR - 1];
-            if (CKPT && (j & (CKW - 1)) == 0 && j < m_eff && valid) { // column checkpoint, un-rebased: {I(i,j+1), h(i,j)+e}
+            if (CKPT && (j & (CKW - 1)) == 0 && j < m_eff && valid) { // column checkpoint, un-rebased values {I(i,j+1), h(i,j)+e} (tag bits junk)
                 int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n;
 #pragma unroll
                 for (int r = 0; r < RR; r++) {
@@ -901,6 +901,10 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         else { flush_run(); cur_op = op; cur_run = run; }
     };
     bool done = false;
+    // A re-fill that starts from a column checkpoint reproduces every VALUE, but the checkpoint carries no argmax tags
+    // (the sweep computes them only on its plane rows), so the M- and I-plane fields of the re-fill's first column are
+    // not usable: the walk uses a window / tile from its second column on (all of it when it starts at column 0).
+    auto lo_ok = [](int jc_lo) { return jc_lo + (jc_lo > 0 ? 2 : 1); };
     while (true) {
         if (i == 0 || j == 0) { done = true; break; }
         unsigned w;
@@ -910,20 +914,20 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             const int t1 = j + G8 - 1; // step at which the owner lane (the pair's last) was at column j
             w = rowi[pl.rowi_off + (int64_t)(pl.n - i) * pl.words + (t1 >> 4)];
             pos = t1 & 15;
-        } else if (j > st.jc_lo && j <= st.j_hi) { // inside the current window
+        } else if (j >= lo_ok(st.jc_lo) && j <= st.j_hi) { // inside the usable part of the current window
             w = load_word<true>(wtrace, wp, k, i, j - st.jc_lo, pos);
         } else if (TILED) { // switch to the tile holding column j (all tiles of a straggler are filled)
             const int c = (j - 1) / FP_TILE;
             wp = wplans[(int64_t)a * tiles_per + c];
-            st.jc_lo = c * FP_TILE; st.j_hi = st.jc_lo + wp.m;
-            if (j > st.j_hi) { atomicOr(err, 2); done = true; break; }
+            st.jc_lo = wp.col_off; st.j_hi = st.jc_lo + wp.m; // tile c starts one checkpoint before column c*FP_TILE
+            if (j > st.j_hi || j < lo_ok(st.jc_lo)) { atomicOr(err, 2); done = true; break; }
             continue;
         } else break; // needs a (new) window
         int tag = (int)((w >> (2 * pos)) & 3u);
         if (tag == 0) { atomicOr(err, 2); done = true; break; }
         if (k == 1) {
             int avail = min(pos + 1, j);
-            if (!on_plane) avail = min(avail, j - st.jc_lo); // do not run past the window's left edge
+            if (!on_plane) avail = min(avail, j - lo_ok(st.jc_lo) + 1); // do not run past the window's usable left edge
             unsigned x = w ^ 0xAAAAAAAAu;
             if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
             const int lowcut = pos + 1 - avail;
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         k = 3 - tag;
         if (up_exit && i > 0 && j > 0) { // quirk Q1: restart in the argmax state of the entry cell (i, j)
             int ht;
-            if (j == st.jc_lo) ht = ckpt[pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n + (i - 1)].y & 3; // a checkpoint column
+            if (j <= st.jc_lo) { atomicOr(err, 2); done = true; break; } // cannot happen: column jc_lo + 1 is never walked
             else if (j < st.j_hi) { int p2; ht = (int)((load_word<true>(wtrace, wp, 0, i + 1, j + 1 - st.jc_lo, p2) >> (2 * p2)) & 3u); }
             else ht = whcol[wp.hcol_off + i - 1] & 3;
             k = 3 - ht;
@@ -994,11 +998,11 @@ __global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan 
     const PairPlan pl = plans[p];
     const int j_cur = states[p].j;
     PairPlan q = pl;
-    const int lo = c * FP_TILE;
-    q.m = (j_cur > lo) ? min(FP_TILE, j_cur - lo) : 0;
+    const int lo = c * FP_TILE, lo2 = max(0, lo - CKW); // start one checkpoint early: the first re-filled column has no usable tags
+    q.m = (j_cur > lo) ? min(FP_TILE, j_cur - lo) + (lo - lo2) : 0;
     q.words = (q.m + 15 + 15) / 16; q.strips = q.m > 0 ? 1 : 0;
     q.trace_off = (int64_t)x * FP_TWORDS * QA * G; q.hcol_off = (int64_t)x * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)x * G;
-    q.src = pl.src; q.col_off = lo;
+    q.src = pl.src; q.col_off = lo2;
     q.rowi_off = (x == 0) ? tiles_per : 0; // plan 0 carries tiles_per for the walk kernel
     out[x] = q;
 }

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Turn the raw outputs of tools/gpu_round.sh (gpurun_out/<tag>/) into the committed evidence under profiles/:
+  <round>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (kernel names shortened)
+  <round>_pmc_hbm_{fastpath,general}.csv   FETCH_SIZE / WRITE_SIZE rows of the dominant kernel (separate --pmc passes)
+  <round>_hbm_traffic.json   HBM bytes per launch / per pair of the dominant kernel, FETCH_SIZE doubled (gfx950 correction,
+                             MI355X_MICROARCH.md) -- what bench.py reports as roofline.traffic
+  <round>_bench.json         the bench line of the same run
+Usage: python tools/collect_profiles.py gpurun_out/<tag> <round>"""
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    m = re.search(r"::(\w+_kernel)(<[^>(]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+
+
+def pmc_rows(d, kernel_re):
+    rows = []
+    path = os.path.join(d, "pmc_counter_collection.csv")
+    if not os.path.exists(path):
+        return rows
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if re.search(kernel_re, r["Kernel_Name"]):
+                rows.append({"kernel": short(r["Kernel_Name"]), "grid": int(r["Grid_Size"]), "vgpr": int(r["VGPR_Count"]), "lds": int(r["LDS_Block_Size"]),
+                             "counter": r["Counter_Name"], "value": float(r["Counter_Value"])})
+    return rows
+
+
+def main():
+    src, rnd = sys.argv[1], sys.argv[2]
+    prof = os.path.join(ROOT, "profiles")
+    with open(os.path.join(src, "stats", "stats_kernel_stats.csv")) as fh, open(os.path.join(prof, rnd + "_kernel_stats.csv"), "w") as out:
+        rd = csv.reader(fh)
+        wr = csv.writer(out)
+        for k, row in enumerate(rd):
+            if k > 0:
+                row[0] = short(row[0])
+            wr.writerow(row)
+    traffic = {}
+    for key, sub, kre, pairs_field in (("fast_path", "", r"fp_sweep_kernel", 8), ("general_path", "_gen", r"fill_affine_kernel", 4)):
+        allrows = []
+        tot = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            rows = pmc_rows(os.path.join(src, "pmc%s_%s" % (sub, c)), kre)
+            if key == "fast_path":
+                rows = [r for r in rows]
+            allrows += rows
+            if rows:
+                big = max(rows, key=lambda r: r["grid"])  # the forward sweep / full fill is the largest launch
+                tot[c] = sum(r["value"] for r in rows if r["grid"] == big["grid"]) / max(1, sum(1 for r in rows if r["grid"] == big["grid"]))
+                tot["pairs"] = big["grid"] // 64 * pairs_field
+                tot["kernel"] = big["kernel"]
+        if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+            with open(os.path.join(prof, "%s_pmc_hbm_%s.csv" % (rnd, "fastpath" if key == "fast_path" else "general")), "w") as out:
+                wr = csv.writer(out)
+                wr.writerow(["kernel", "grid", "vgpr", "lds", "counter", "value_KB"])
+                for r in allrows:
+                    wr.writerow([r["kernel"], r["grid"], r["vgpr"], r["lds"], r["counter"], r["value"]])
+            hbm = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
+            traffic[key] = {"kernel": tot["kernel"], "pairs_per_launch_upper": tot["pairs"], "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"],
+                            "hbm_bytes_per_launch": hbm, "note": "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; separate --pmc passes, bench.py --steps 1 --warmup 0"}
+    bench = None
+    for nm in ("bench.json", "stats_bench.json"):
+        try:
+            with open(os.path.join(src, nm)) as fh:
+                for line in fh:
+                    if line.startswith("{"):
+                        bench = json.loads(line)
+            if bench:
+                break
+        except OSError:
+            pass
+    pairs = bench["config"]["pairs_per_gpu"] if bench else 100000
+    for v in traffic.values():
+        v["pairs_per_launch"] = pairs
+        v["hbm_bytes_per_pair"] = v["hbm_bytes_per_launch"] / pairs
+        v.pop("pairs_per_launch_upper", None)
+    old = {}
+    tpath = os.path.join(prof, rnd + "_hbm_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            old = json.load(fh)
+    old.update(traffic)
+    with open(tpath, "w") as fh:
+        json.dump(old, fh, indent=1)
+        fh.write("\n")
+    if os.path.exists(os.path.join(src, "bench.json")):
+        shutil.copyfile(os.path.join(src, "bench.json"), os.path.join(prof, rnd + "_bench.json"))
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,10 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $out/stats -o stats --output-for
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python $repo/bench.py --no-cpu --steps 1 --warmup 0 --verify 0 > $out/pmc_$c.json 2> $out/pmc_$c.err
 done
+for c in FETCH_SIZE WRITE_SIZE; do
+  GNX_FASTPATH=0 timeout 900 rocprofv3 --pmc $c -d $out/pmc_gen_$c -o pmc --output-format csv -- python $repo/bench.py --no-cpu --steps 1 --warmup 0 --verify 0 > $out/pmc_gen_$c.json 2> $out/pmc_gen_$c.err
+done
+GNX_FASTPATH=0 timeout 600 python $repo/bench.py --no-cpu > $out/bench_general_path.json 2>> $out/bench.err
 cd $repo
 find $out -name '*.db' -size +20M -delete
 ls -la $out $out/stats 2>/dev/null | head -40

@@ -31,11 +31,15 @@ def main():
         kind = int(rng.integers(0, 6))
         n = int(rng.integers(1, 161))
         cnt = int(rng.integers(1, 40))
-        if kind <= 2:  # fast-path shape: uniform n, long beta (shared chunk or per-pair windows)
+        if kind <= 2:  # fast-path shape: short alpha (uniform or mixed lengths), long beta (shared chunk or per-pair windows)
+            mixed = rng.random() < 0.5
+            n_top = n
             m = int(rng.integers(768, 6000))
             chunk = rng.integers(0, 5 if rng.random() < 0.3 else 4, size=m + 400).astype(np.uint8)
             alphas, betas = [], []
             for _ in range(cnt):
+                if mixed:
+                    n = int(rng.integers(1, n_top + 1))
                 off = int(rng.integers(0, m - 1))
                 src = chunk[off:off + n + 40]
                 a = common.mutate(rng, src, sub=float(rng.choice([0.0, 0.02, 0.15])), indel=float(rng.choice([0.0, 0.01, 0.08])), geo=0.4)
