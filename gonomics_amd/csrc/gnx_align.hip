@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
                                                       const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                       KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
-                                                      unsigned *__restrict__ rowi, int *__restrict__ err) {
+                                                      unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err) {
     static_assert(RR <= 2 * FP8_LW && RR > FP_PLANES, "rows per lane");
     __shared__ int lds[32 + 8 * FP8_PST];
     const int lane = threadIdx.x;
@@ -418,6 +418,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
         rt[r] = (q >= P) ? 2 * kp.o4 + 1 : kp.o4 + 2;
     }
     unsigned accR[FP_PLANES] = {0u, 0u, 0u, 0u}; // I-planes of rows n-d = slots RR-1-d of the last lane
+    unsigned tailw = 0; // argmax tags of h(n-d, m-x), d, x = 0..3, field 4x + d: lets the walk take its first diagonal steps without a window
     int diag0 = (q0 == 0) ? (P == 0 ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + 1 : (q0 - 1 == P - 1 ? 3 : kp.o4 + 2));
     int dn_out = 0, h_out = 0, b_out = 0;
     auto base_of = [&](int c) { // LDS byte offset of the profile plane of beta[c] (column c, 1-based)
@@ -469,6 +470,10 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
             diag0 = up_h;
             dn_out = dnu;
             h_out = hold[RR - 1];
+            if (CHECK && j + 3 >= m_eff) { // the last four columns (always in a CHECK half block)
+#pragma unroll
+                for (int d = 0; d < FP_PLANES; d++) tailw |= (unsigned)(hold[RR - 1 - d] & 3) << (8 * (m_eff - j) + 2 * d);
+            }
             if (CKPT && (j & (CKW - 1)) == 0 && j < m_eff && valid) { // column checkpoint, un-rebased values {I(i,j+1), h(i,j)+e} (tag bits junk)
                 int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n;
 #pragma unroll
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
             }
         }
     }
-    if (lp == G8 - 1 && valid && m_eff >= 1) hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); // h(n, m)
+    if (lp == G8 - 1 && valid && m_eff >= 1) { hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); tail[pl.hcol_off] = tailw; } // h(n, m)
     if (bad) atomicOr(err, 1);
 }
 
@@ -860,7 +865,7 @@ struct FpState {
 template <bool FIRST, bool TILED = false>
 __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
                                                      FpState *__restrict__ states, const int *__restrict__ hcol_fwd,
-                                                     const unsigned *__restrict__ rowi, const int2 *__restrict__ ckpt,
+                                                     const unsigned *__restrict__ rowi, const unsigned *__restrict__ tail,
                                                      const PairPlan *__restrict__ wplans, const uint4 *__restrict__ wtrace,
                                                      const int *__restrict__ whcol, TbParams tp, gnx_cigar *__restrict__ stage,
                                                      int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
@@ -905,6 +910,10 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
     // (the sweep computes them only on its plane rows), so the M- and I-plane fields of the re-fill's first column are
     // not usable: the walk uses a window / tile from its second column on (all of it when it starts at column 0).
     auto lo_ok = [](int jc_lo) { return jc_lo + (jc_lo > 0 ? 2 : 1); };
+    // argmax tag of h(ii, jj) kept by the sweep for the 4 x 4 cells at the bottom right corner
+    const unsigned tailw = tail[pl.hcol_off];
+    auto tail_ok = [&](int ii, int jj) { return ii >= 1 && jj >= 1 && pl.n - ii < FP_PLANES && pl.m - jj < 4; };
+    auto tail_tag = [&](int ii, int jj) { return (tailw >> (8 * (pl.m - jj) + 2 * (pl.n - ii))) & 3u; };
     while (true) {
         if (i == 0 || j == 0) { done = true; break; }
         unsigned w;
@@ -916,6 +925,8 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             pos = t1 & 15;
         } else if (j >= lo_ok(st.jc_lo) && j <= st.j_hi) { // inside the usable part of the current window
             w = load_word<true>(wtrace, wp, k, i, j - st.jc_lo, pos);
+        } else if (k == 0 && tail_ok(i - 1, j - 1)) { // trM(i,j) = argmax of h(i-1,j-1): a diagonal step in the corner needs no window
+            w = tail_tag(i - 1, j - 1); pos = 0;
         } else if (TILED) { // switch to the tile holding column j (all tiles of a straggler are filled)
             const int c = (j - 1) / FP_TILE;
             wp = wplans[(int64_t)a * tiles_per + c];
@@ -942,6 +953,24 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                 k = 3 - tag;
             }
             emit(1, steps); j -= steps; last_op = 1;
+            if (on_plane && x == 0 && steps == pos + 1) {
+                // the run continues below field 0 of this word: take whole 16-column words while they are all-I, four loads in
+                // flight (a 10 kb trailing gap is 600 dependent loads otherwise).  Only on the stored planes, where the lanes of
+                // a wave are in this state together; inside windows / tiles the extra control flow costs more than it saves.
+                const unsigned *wbase = rowi + pl.rowi_off + (int64_t)(pl.n - i) * pl.words;
+                int wi = ((j + steps + G8 - 1) >> 4) - 1;
+                bool more = true;
+                while (more && wi >= 0 && j >= 16) {
+                    unsigned q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) q[u] = (wi - u >= 0) ? wbase[wi - u] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (more && q[u] == 0xAAAAAAAAu && j >= 16) { emit(1, 16); j -= 16; wi--; }
+                        else more = false;
+                    }
+                }
+            }
             continue;
         }
         emit(k, 1);
@@ -952,7 +981,8 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         k = 3 - tag;
         if (up_exit && i > 0 && j > 0) { // quirk Q1: restart in the argmax state of the entry cell (i, j)
             int ht;
-            if (j <= st.jc_lo) { atomicOr(err, 2); done = true; break; } // cannot happen: column jc_lo + 1 is never walked
+            if (tail_ok(i, j)) ht = (int)tail_tag(i, j);
+            else if (j <= st.jc_lo) { atomicOr(err, 2); done = true; break; } // cannot happen: column jc_lo + 1 is never walked
             else if (j < st.j_hi) { int p2; ht = (int)((load_word<true>(wtrace, wp, 0, i + 1, j + 1 - st.jc_lo, p2) >> (2 * p2)) & 3u); }
             else ht = whcol[wp.hcol_off + i - 1] & 3;
             k = 3 - ht;
@@ -1071,27 +1101,30 @@ __global__ __launch_bounds__(256) void scale_runs_kernel(gnx_cigar *__restrict__
 
 // exclusive scan of nops[0..n) + carry[0] -> off[0..n], off[n]; carry[0] = off[n] afterwards.  One block.
 __global__ __launch_bounds__(1024) void scan_kernel(const int64_t *__restrict__ nops, int n, int64_t *__restrict__ off, int64_t *__restrict__ carry) {
-    __shared__ int64_t sh[1024];
-    __shared__ int64_t base;
-    if (threadIdx.x == 0) base = carry[0];
+    // exclusive scan of the run counts by one block: every thread sums a contiguous slice, the 1024 slice sums are scanned
+    // with __shfl_up (wave level, then the 16 wave totals), then every thread writes the offsets of its slice
+    __shared__ int64_t wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = (n + 1023) / 1024, lo = min(n, (int)threadIdx.x * K), hi = min(n, lo + K);
+    int64_t sum = 0;
+    for (int i = lo; i < hi; i++) sum += nops[i];
+    int64_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    for (int start = 0; start < n; start += 1024) {
-        const int idx = start + threadIdx.x;
-        const int64_t v = idx < n ? nops[idx] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const int64_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if (idx < n) off[idx] = base + sh[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) base += sh[1023];
-        __syncthreads();
+    if (wave == 0) {
+        int64_t t = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { const int64_t u = __shfl_up(t, d, 64); if (lane >= d) t += u; }
+        if (lane < 16) wsum[lane] = t;
     }
-    if (threadIdx.x == 0) { off[n] = base; carry[0] = base; }
+    __syncthreads();
+    const int64_t base = carry[0];
+    int64_t run = base + (wave > 0 ? wsum[wave - 1] : 0) + incl - sum;
+    for (int i = lo; i < hi; i++) { off[i] = run; run += nops[i]; }
+    __syncthreads(); // every thread has read carry[0]
+    if (threadIdx.x == 0) { off[n] = base + wsum[15]; carry[0] = base + wsum[15]; }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1133,7 +1166,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace;
+    DevBuf fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, sc_pairs, sc_mat, sc_err;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -1230,6 +1263,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
     if ((rc = c.misc.ensure(64))) return rc;
     if ((rc = c.fp_rowi.ensure((size_t)std::max<int64_t>(roff, 1) * 4))) return rc;
+    if ((rc = c.fp_tail.ensure((size_t)np * 4))) return rc;
     if ((rc = c.fp_ckpt.ensure((size_t)std::max<int64_t>(coff, 1) * 8))) return rc;
     if ((rc = c.fp_states.ensure((size_t)np * sizeof(FpState)))) return rc;
     if ((rc = c.fp_stage.ensure((size_t)np * FP_CAP * sizeof(gnx_cigar)))) return rc;
@@ -1248,6 +1282,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     int *d_hfwd = reinterpret_cast<int *>(c.hcol.p);
     int *d_whcol = d_hfwd + np;
     unsigned *d_rowi = reinterpret_cast<unsigned *>(c.fp_rowi.p);
+    unsigned *d_tail = reinterpret_cast<unsigned *>(c.fp_tail.p);
     int2 *d_ckpt = reinterpret_cast<int2 *>(c.fp_ckpt.p);
     FpState *d_st = reinterpret_cast<FpState *>(c.fp_states.p);
     gnx_cigar *d_stage = reinterpret_cast<gnx_cigar *>(c.fp_stage.p);
@@ -1261,8 +1296,8 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
 
     auto forward = [&](int p0, int cnt, hipStream_t st) -> int {
         const dim3 grid8((unsigned)((cnt + G8 - 1) / G8));
-        if (rows_per_lane == 19) hipLaunchKernelGGL(fp_sweep_kernel<19>, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_err);
-        else hipLaunchKernelGGL(fp_sweep_kernel<20>, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_err);
+        if (rows_per_lane == 19) hipLaunchKernelGGL(fp_sweep_kernel<19>, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err);
+        else hipLaunchKernelGGL(fp_sweep_kernel<20>, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err);
         HIPCHK(hipGetLastError());
         return GNX_OK;
     };
@@ -1273,7 +1308,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
         unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * G;
         int cur = 0, n_act = 0, it = 0;
         float f = 0;
-        hipLaunchKernelGGL(fp_walk_kernel<true>, dim3((unsigned)((cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_ckpt,
+        hipLaunchKernelGGL(fp_walk_kernel<true>, dim3((unsigned)((cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_tail,
                            (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, d_wpl[0] + p0, d_err, p0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&n_act, cnt2, 4, hipMemcpyDeviceToHost, st));
@@ -1286,7 +1321,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
                                wtr, whc, (int2 *)nullptr, wdc, d_ckpt, d_err);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(e2, st));
-            hipLaunchKernelGGL(fp_walk_kernel<false>, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_ckpt,
+            hipLaunchKernelGGL(fp_walk_kernel<false>, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
                                d_wpl[cur] + p0, wtr, whc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, d_wpl[nxt] + p0, d_err, 0);
             HIPCHK(hipGetLastError());
             int n_next = 0;
@@ -1318,7 +1353,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
                                ttr, thc, (int2 *)nullptr, tdc, d_ckpt, d_err);
             HIPCHK(hipEventRecord(e2, st));
             HIPCHK(hipMemsetAsync(cnt2, 0, 8, st));
-            hipLaunchKernelGGL((fp_walk_kernel<false, true>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_strag, d_st, d_hfwd, d_rowi, d_ckpt,
+            hipLaunchKernelGGL((fp_walk_kernel<false, true>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_strag, d_st, d_hfwd, d_rowi, d_tail,
                                tpl, ttr, thc, tp, d_stage, d_score, d_nops, d_act[cur ^ 1] + p0, cnt2, d_wpl[cur ^ 1] + p0, d_err, 0);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));
@@ -1739,7 +1774,7 @@ void gnx_shutdown(void) {
     if (!g_ctx.inited) return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
+    DevBuf *bufs[] = {&g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
                       &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
                       &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops,
                       &g_ctx.sc_pairs, &g_ctx.sc_mat, &g_ctx.sc_err};
