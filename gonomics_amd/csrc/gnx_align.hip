@@ -1101,30 +1101,31 @@ __global__ __launch_bounds__(256) void scale_runs_kernel(gnx_cigar *__restrict__
 
 // exclusive scan of nops[0..n) + carry[0] -> off[0..n], off[n]; carry[0] = off[n] afterwards.  One block.
 __global__ __launch_bounds__(1024) void scan_kernel(const int64_t *__restrict__ nops, int n, int64_t *__restrict__ off, int64_t *__restrict__ carry) {
-    // exclusive scan of the run counts by one block: every thread sums a contiguous slice, the 1024 slice sums are scanned
-    // with __shfl_up (wave level, then the 16 wave totals), then every thread writes the offsets of its slice
+    // exclusive scan of the run counts, 1024 elements per round: wave-level scans by __shfl_up, then the 16 wave totals
+    // (a one-pass version with a contiguous slice per thread measured slower: 227 us vs 139 us per 100 k elements)
     __shared__ int64_t wsum[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int K = (n + 1023) / 1024, lo = min(n, (int)threadIdx.x * K), hi = min(n, lo + K);
-    int64_t sum = 0;
-    for (int i = lo; i < hi; i++) sum += nops[i];
-    int64_t incl = sum;
+    int64_t base = carry[0];
+    for (int start = 0; start < n; start += 1024) {
+        const int idx = start + threadIdx.x;
+        const int64_t v = idx < n ? nops[idx] : 0;
+        int64_t sum = v;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    if (wave == 0) {
-        int64_t t = lane < 16 ? wsum[lane] : 0;
+        for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(sum, d, 64); if (lane >= d) sum += t; }
+        if (lane == 63) wsum[wave] = sum;
+        __syncthreads();
+        if (wave == 0) {
+            int64_t t = lane < 16 ? wsum[lane] : 0;
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) { const int64_t u = __shfl_up(t, d, 64); if (lane >= d) t += u; }
-        if (lane < 16) wsum[lane] = t;
+            for (int d = 1; d < 16; d <<= 1) { const int64_t u = __shfl_up(t, d, 64); if (lane >= d) t += u; }
+            if (lane < 16) wsum[lane] = t;
+        }
+        __syncthreads();
+        if (idx < n) off[idx] = base + (wave > 0 ? wsum[wave - 1] : 0) + sum - v;
+        base += wsum[15];
+        __syncthreads();
     }
-    __syncthreads();
-    const int64_t base = carry[0];
-    int64_t run = base + (wave > 0 ? wsum[wave - 1] : 0) + incl - sum;
-    for (int i = lo; i < hi; i++) { off[i] = run; run += nops[i]; }
-    __syncthreads(); // every thread has read carry[0]
-    if (threadIdx.x == 0) { off[n] = base + wsum[15]; carry[0] = base + wsum[15]; }
+    if (threadIdx.x == 0) { off[n] = base; carry[0] = base; }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1290,7 +1291,9 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     PairPlan *d_wpl[2] = {reinterpret_cast<PairPlan *>(c.fp_wplans[0].p), reinterpret_cast<PairPlan *>(c.fp_wplans[1].p)};
     int *d_act[2] = {reinterpret_cast<int *>(c.fp_active[0].p), reinterpret_cast<int *>(c.fp_active[1].p)};
     const dim3 blockF(64), blockT(64);
-    const int max_it = getenv("GNX_FP_MAXIT") ? atoi(getenv("GNX_FP_MAXIT")) : 3;
+    // window rounds continue while they pay: a fixed number with GNX_FP_MAXIT, else while more than 4 % of the pairs are waiting
+    // (a round has a fixed latency of ~0.2 ms; the few pairs left over go to the tile re-fill, whose cost is per pair)
+    const int max_it = getenv("GNX_FP_MAXIT") ? atoi(getenv("GNX_FP_MAXIT")) : -1;
     const int tiles_per = (int)((m_maxb + FP_TILE - 1) / FP_TILE);
     double refill_ms = 0;
 
@@ -1313,7 +1316,7 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&n_act, cnt2, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        while (n_act > 0 && it < max_it) {
+        while (n_act > 0 && (max_it >= 0 ? it < max_it : (it == 0 || (int64_t)n_act * 25 > cnt) && it < 16)) {
             const int nxt = cur ^ 1;
             HIPCHK(hipMemsetAsync(cnt2 + nxt, 0, 4, st));
             HIPCHK(hipEventRecord(e1, st));
