@@ -16,7 +16,7 @@ GNX_AFFINE_GAP, GNX_CONST_GAP, GNX_AFFINE_GAP_HIGHMEM, GNX_AFFINE_GAP_LOCAL, GNX
 
 EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gnx_free", "gnx_align_batch",
            "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing",
-           "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch"]
+           "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch"]
 
 
 class GnxCigar(ctypes.Structure):
@@ -83,6 +83,9 @@ def lib():
         L.gnx_multiple_affine_gap_batch.argtypes = [ctypes.POINTER(GnxParams), i64, i64, c_p, c_p, c_p, c_p, i64, c_p, c_p, c_p,
                                                     ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
         L.gnx_multiple_affine_gap_batch.restype = ctypes.c_int
+        L.gnx_gsw_extend_batch.argtypes = [ctypes.c_int, c_p, i64, i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                           ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
+        L.gnx_gsw_extend_batch.restype = ctypes.c_int
         L.gnx_get_timing.argtypes = [ctypes.POINTER(GnxTiming)]
         L.gnx_get_timing.restype = ctypes.c_int
         _lib = L
@@ -206,6 +209,31 @@ def multiple_affine_gap_batch(params, chunk_size, groups, pairs):
                                           ctypes.byref(ops_p), ctypes.byref(off_p)))
     ops, off = _take(ops_p, off_p, n)
     return scores[:n], ops, off
+
+
+GNX_GSW_LEFT, GNX_GSW_RIGHT = 0, 1
+
+
+def gsw_extend_batch(side, scores, gap_pen, alphas, betas):
+    """genomeGraph.LeftDynamicAln / RightDynamicAln (side GNX_GSW_LEFT / GNX_GSW_RIGHT) over a batch of (target, read) pairs.
+    Returns (scores, end_i, end_j, ops, off); ops are the runs in traceback order, op codes 0/1/2 = 'M'/'I'/'D'."""
+    L = lib()
+    n = len(alphas)
+    sc = np.ascontiguousarray(np.asarray(scores, dtype=np.int64).reshape(25))
+    a_off = np.zeros(n + 1, dtype=np.int64)
+    b_off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        a_off[1:] = np.cumsum([len(a) for a in alphas])
+        b_off[1:] = np.cumsum([len(b) for b in betas])
+    a_cat = _u8(np.concatenate([_u8(a) for a in alphas] + [np.zeros(1, np.uint8)]))
+    b_cat = _u8(np.concatenate([_u8(b) for b in betas] + [np.zeros(1, np.uint8)]))
+    out = np.zeros((3, max(n, 1)), dtype=np.int64)
+    ops_p, off_p = ctypes.c_void_p(), ctypes.c_void_p()
+    check(L.gnx_gsw_extend_batch(int(side), sc.ctypes.data, int(gap_pen), n, a_cat.ctypes.data, a_off.ctypes.data, b_cat.ctypes.data,
+                                 b_off.ctypes.data, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data,
+                                 ctypes.byref(ops_p), ctypes.byref(off_p)))
+    ops, off = _take(ops_p, off_p, n)
+    return out[0, :n], out[1, :n], out[2, :n], ops, off
 
 
 def align_pair(params, alpha, beta):

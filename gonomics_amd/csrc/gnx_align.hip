@@ -526,7 +526,11 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
 // candidates are three 2-cycle VGPR adds (the profile holds 4*s+3, the penalties 4*g+2 / 4*g+1 live in VGPRs),
 // one v_max3, one v_and and one v_alignbit per cell.
 // ------------------------------------------------------------------------------------------------------
-template <bool MULTI>
+// GSW (the seed-extension DP of the graph aligner, "next" row N2, /root/reference/genomeGraph/search.go:234-321):
+//   1 = LeftDynamicAln: zero borders, cell values clamped at 0 (the trace keeps its direction);
+//   2 = RightDynamicAln: the ordinary borders plus, per row, the running maximum of (score << 12 | 4095 - column), i.e. the first
+//       column of the row's best score; hcol receives that key instead of the last-column value.
+template <bool MULTI, int GSW = 0>
 __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                         const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                         const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
@@ -583,12 +587,15 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             __syncthreads();
         }
 #pragma unroll
-        for (int r = 0; r < R; r++) { val[r] = (row0 + r + 1) * kp.g4; acc[r] = 0; } // column 0: i*gapPen
-        int diag0 = row0 * kp.g4; // V(row above, 0)
+        for (int r = 0; r < R; r++) { val[r] = GSW == 1 ? 0 : (row0 + r + 1) * kp.g4; acc[r] = 0; } // column 0: i*gapPen
+        int best[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) best[r] = 4095; // score 0: only a positive score replaces it (currMax starts at 0)
+        int diag0 = GSW == 1 ? 0 : row0 * kp.g4; // V(row above, 0)
         int v_out = 0, b_out = 0, sq_v = 0;
         int qv, qb, nv = 0, nb = 0;
         auto boundary = [&](int c, int &ov, int &ob) {
-            if (!MULTI || s == 0) ov = c * kp.g4; // row 0: j*gapPen
+            if (!MULTI || s == 0) ov = GSW == 1 ? 0 : c * kp.g4; // row 0: j*gapPen
             else if (c >= 1 && c <= m_eff) ov = rowbuf[pl.rowbuf_off + c].x;
             else ov = 0;
             int b = 0;
@@ -618,6 +625,8 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                     acc[r] = alignbit2((unsigned)k, acc[r]);
                     vd = val[r];
                     val[r] = k & ~3;
+                    if (GSW == 1) val[r] = max(val[r], 0);
+                    if (GSW == 2) best[r] = max(best[r], (int)((unsigned)val[r] << 10) + (4095 - j));
                     vu = val[r];
                 }
                 diag0 = up_v;
@@ -656,7 +665,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = val[r];
+            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = GSW == 2 ? best[r] : val[r];
             const int t0f = ((m_eff + l - 1) >> 4) << 4, missf = t0f + 16 - l - m_eff;
             unsigned dw = 0;
 #pragma unroll
@@ -1129,6 +1138,70 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int64_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Traceback of the gsw seed-extension DPs (search.go:252-275, 298-320).  One lane per pair, runs in TRACEBACK order (the
+// reference appends them that way; its callers reverse).  Ops use the GNX_COL_* codes (M/I/D).
+//   LEFT : from (n, m) while the cell value is > 0.  Values are not stored: the walk rebuilds them from the final value
+//          (an unclamped cell is its predecessor plus the score of the move; a clamped cell is 0 and ends the walk).
+//   RIGHT: from the first row-major maximum (row scan of the keys the fill kernel left in hcol) back to (0, 0).
+// ------------------------------------------------------------------------------------------------------
+template <bool RIGHT, bool WRITE>
+__global__ __launch_bounds__(64) void gsw_traceback_kernel(const PairPlan *__restrict__ plans, int n_pairs, const uint4 *__restrict__ trace,
+                                                           const int *__restrict__ hcol,
+                                                           const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                           const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp,
+                                                           int64_t *__restrict__ score_out, int2 *__restrict__ endpos,
+                                                           int64_t *__restrict__ nops, const int64_t *__restrict__ ops_off,
+                                                           gnx_cigar *__restrict__ ops, int64_t ops_capacity, int *__restrict__ err) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const PairPlan pl = plans[p];
+    const uint8_t *ap = a_buf + a_start[p];
+    const uint8_t *bp = b_buf + b_start[p];
+    int i = pl.n, j = pl.m;
+    int cur = 0; // LEFT: value of the current cell
+    if (RIGHT) {
+        int bestv = 0, bi = 0, bj = 0;
+        if (pl.m >= 1) {
+            for (int r = 1; r <= pl.n; r++) {
+                const int key = hcol[pl.hcol_off + r - 1];
+                const int v = key >> 12;
+                if (v > bestv) { bestv = v; bi = r; bj = 4095 - (key & 4095); }
+            }
+        }
+        i = bi; j = bj;
+        if (!WRITE) { score_out[p] = bestv; endpos[p] = make_int2(bi, bj); }
+    } else {
+        if (pl.n >= 1 && pl.m >= 1) cur = hcol[pl.hcol_off + pl.n - 1] >> 2;
+        if (!WRITE) score_out[p] = cur;
+    }
+    const int64_t base = WRITE ? ops_off[p] : 0;
+    int64_t cnt = 0, run = 0;
+    int cur_op = -1;
+    auto emit = [&](int op, int64_t len) {
+        if (op == cur_op) { run += len; return; }
+        if (cur_op >= 0) {
+            if (WRITE) { if (base + cnt < ops_capacity) { gnx_cigar c; c.run_length = run; c.op = (uint8_t)cur_op; for (int z = 0; z < 7; z++) c._pad[z] = 0; ops[base + cnt] = c; } else atomicOr(err, 4); }
+            cnt++;
+        }
+        cur_op = op; run = len;
+    };
+    while (RIGHT ? (i > 0 || j > 0) : (cur > 0)) {
+        if (RIGHT && i == 0) { emit(GNX_COL_I, j); j = 0; break; } // trace[0][j] = 'I'
+        if (RIGHT && j == 0) { emit(GNX_COL_D, i); i = 0; break; } // trace[i][0] = 'D'
+        if (i < 1 || j < 1) { atomicOr(err, 2); break; }
+        int pos;
+        const unsigned w = load_word<false>(trace, pl, 0, i, j, pos);
+        const int tag = (int)((w >> (2 * pos)) & 3u);
+        if (tag == 3) { emit(GNX_COL_M, 1); if (!RIGHT) cur -= kp.sc4[min((int)ap[i - 1], 4) * 5 + min((int)bp[j - 1], 4)] >> 2; i--; j--; }
+        else if (tag == 2) { emit(GNX_COL_I, 1); if (!RIGHT) cur -= kp.g4 >> 2; j--; }
+        else if (tag == 1) { emit(GNX_COL_D, 1); if (!RIGHT) cur -= kp.g4 >> 2; i--; }
+        else { atomicOr(err, 2); break; }
+    }
+    emit(-2, 0); // flush
+    if (!WRITE) { nops[p] = cnt; if (!RIGHT) endpos[p] = make_int2(i, j); }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------------------
 thread_local char g_err[512] = "";
@@ -1168,7 +1241,7 @@ struct Ctx {
     hipStream_t own_stream = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
     DevBuf fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace;
-    DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, sc_pairs, sc_mat, sc_err;
+    DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
 };
@@ -1403,13 +1476,17 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
                const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                const int64_t *h_alen, const int64_t *h_blen,
                int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
-               int64_t *out_total, hipStream_t stream, const int *d_smat = nullptr, const int64_t *h_soff = nullptr) {
+               int64_t *out_total, hipStream_t stream, const int *d_smat = nullptr, const int64_t *h_soff = nullptr,
+               int gsw = 0, int2 *d_endpos = nullptr) {
+    // gsw: 1 / 2 = LeftDynamicAln / RightDynamicAln of the graph aligner (constant-gap kernels with GSW = 1 / 2 and their own
+    // traceback; d_endpos receives the (i, j) the reference returns); prm->mode must be GNX_CONST_GAP_HIGHMEM
     // d_smat / h_soff: explicit per-cell score matrices (SCORED kernels, N1 variants); the sequences are then unused
     Ctx &c = g_ctx;
     KParams kp; TbParams tp; bool affine, local, lowmem;
     int rc = check_params(prm, kp, tp, affine, local, lowmem);
     if (rc) return rc;
     if (d_smat && (!affine || local || lowmem)) { set_err("scored mode needs AffineGap_highMem semantics%s", ""); return GNX_EINVAL; }
+    if (gsw && (affine || lowmem || !d_endpos || prm->gap_open > 0)) { set_err("gsw extension needs ConstGap_highMem parameters with gapPen <= 0%s", ""); return GNX_EINVAL; }
     if (n_pairs < 0 || n_pairs > 0x7ffffff0) { set_err("bad n_pairs%s", ""); return GNX_EINVAL; }
     c.timing = gnx_timing{};
     if (n_pairs == 0) {
@@ -1482,6 +1559,9 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             }
             if (lowmem && (n < 1 || m < 1)) { set_err("empty sequence at pair %s%lld: the reference never terminates on it", "", (long long)p); return GNX_EEMPTY; }
             if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) { set_err("pair %s%lld exceeds the int32 DP range", "", (long long)p); return GNX_ERANGE; }
+            if (gsw == 2 && (n > 4095 || m > 4095 || (n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 19))) {
+                set_err("pair %s%lld exceeds the range of the packed (score, column) maximum of RightDynamicAln", "", (long long)p); return GNX_ERANGE;
+            }
             PairPlan &pl = plans[(size_t)p];
             pl.n = (int32_t)n; pl.m = (int32_t)m;
             pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; // src is chunk-relative, set below
@@ -1575,16 +1655,25 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
 #undef GNX_LAUNCH_AFF2
 #undef GNX_LAUNCH_AFF
         } else {
-            if (multi) hipLaunchKernelGGL(fill_const_kernel<true>, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err);
-            else hipLaunchKernelGGL(fill_const_kernel<false>, gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err);
+#define GNX_LAUNCH_CONST(M_, G_) hipLaunchKernelGGL((fill_const_kernel<M_, G_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err)
+            if (gsw == 1) { if (multi) GNX_LAUNCH_CONST(true, 1); else GNX_LAUNCH_CONST(false, 1); }
+            else if (gsw == 2) { if (multi) GNX_LAUNCH_CONST(true, 2); else GNX_LAUNCH_CONST(false, 2); }
+            else { if (multi) GNX_LAUNCH_CONST(true, 0); else GNX_LAUNCH_CONST(false, 0); }
+#undef GNX_LAUNCH_CONST
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
-        if (affine) hipLaunchKernelGGL((traceback_kernel<true, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
+#define GNX_GSW_TB(R_, W_) hipLaunchKernelGGL((gsw_traceback_kernel<R_, W_>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, d_a, d_as + b, d_b, d_bs + b, kp, d_score + b, d_endpos + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err)
+        if (gsw == 1) GNX_GSW_TB(false, false);
+        else if (gsw == 2) GNX_GSW_TB(true, false);
+        else if (affine) hipLaunchKernelGGL((traceback_kernel<true, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
         else hipLaunchKernelGGL((traceback_kernel<false, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, dn, np, d_ops_off + b, d_carry);
-        if (affine) hipLaunchKernelGGL((traceback_kernel<true, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
+        if (gsw == 1) GNX_GSW_TB(false, true);
+        else if (gsw == 2) GNX_GSW_TB(true, true);
+        else if (affine) hipLaunchKernelGGL((traceback_kernel<true, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
         else hipLaunchKernelGGL((traceback_kernel<false, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
+#undef GNX_GSW_TB
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[3], stream));
         if (nchunks > 1 || true) {
@@ -1687,9 +1776,11 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
 int run_host_windows(const gnx_params *prm, int64_t n_pairs,
                      const uint8_t *a_buf, int64_t a_len, const int64_t *a_start, const int64_t *a_lens,
                      const uint8_t *b_buf, int64_t b_len, const int64_t *b_start, const int64_t *b_lens,
-                     int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
+                     int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off,
+                     int gsw = 0, int64_t *out_end_i = nullptr, int64_t *out_end_j = nullptr) {
     Ctx &c = g_ctx;
     if (!prm || n_pairs < 0 || !out_score || !out_ops || !out_ops_off || a_len < 0 || b_len < 0) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    if (gsw && (!out_end_i || !out_end_j)) { set_err("bad argument%s", ""); return GNX_EINVAL; }
     if (n_pairs > 0 && (!a_start || !a_lens || !b_start || !b_lens)) { set_err("null window table%s", ""); return GNX_EINVAL; }
     for (int64_t p = 0; p < n_pairs; p++) {
         if (a_start[p] < 0 || a_lens[p] < 0 || a_start[p] + a_lens[p] > a_len || b_start[p] < 0 || b_lens[p] < 0 || b_start[p] + b_lens[p] > b_len) {
@@ -1705,6 +1796,7 @@ int run_host_windows(const gnx_params *prm, int64_t n_pairs,
     if ((rc = c.in_bs.ensure(np * 8))) return rc;
     if ((rc = c.out_score.ensure(np * 8))) return rc;
     if ((rc = c.out_off.ensure((np + 1) * 8))) return rc;
+    if (gsw && (rc = c.out_end.ensure(np * 8))) return rc;
     if (a_len) HIPCHK(hipMemcpyAsync(c.in_a.p, a_buf, (size_t)a_len, hipMemcpyHostToDevice, st));
     if (b_len) HIPCHK(hipMemcpyAsync(c.in_b.p, b_buf, (size_t)b_len, hipMemcpyHostToDevice, st));
     if (n_pairs) {
@@ -1720,7 +1812,8 @@ int run_host_windows(const gnx_params *prm, int64_t n_pairs,
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = c.out_ops.ensure((size_t)cap * sizeof(gnx_cigar)))) return rc;
         rc = run_device(prm, n_pairs, (const uint8_t *)c.in_a.p, (const int64_t *)c.in_as.p, (const uint8_t *)c.in_b.p, (const int64_t *)c.in_bs.p,
-                        a_lens, b_lens, (int64_t *)c.out_score.p, (gnx_cigar *)c.out_ops.p, cap, (int64_t *)c.out_off.p, &total, st);
+                        a_lens, b_lens, (int64_t *)c.out_score.p, (gnx_cigar *)c.out_ops.p, cap, (int64_t *)c.out_off.p, &total, st,
+                        nullptr, nullptr, gsw, gsw ? (int2 *)c.out_end.p : nullptr);
         if (rc != GNX_ECAPACITY) break;
         cap = total;
     }
@@ -1731,7 +1824,10 @@ int run_host_windows(const gnx_params *prm, int64_t n_pairs,
     if (n_pairs) HIPCHK(hipMemcpyAsync(out_score, c.out_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(off, c.out_off.p, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, st));
     if (total) HIPCHK(hipMemcpyAsync(ops, c.out_ops.p, (size_t)total * sizeof(gnx_cigar), hipMemcpyDeviceToHost, st));
+    std::vector<int2> ends;
+    if (gsw && n_pairs) { ends.resize((size_t)n_pairs); HIPCHK(hipMemcpyAsync(ends.data(), c.out_end.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, st)); }
     HIPCHK(hipStreamSynchronize(st));
+    for (int64_t p = 0; gsw && p < n_pairs; p++) { out_end_i[p] = ends[(size_t)p].x; out_end_j[p] = ends[(size_t)p].y; }
     *out_ops = ops; *out_ops_off = off;
     return GNX_OK;
 }
@@ -1779,7 +1875,7 @@ void gnx_shutdown(void) {
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
                       &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
-                      &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops,
+                      &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops, &g_ctx.out_end,
                       &g_ctx.sc_pairs, &g_ctx.sc_mat, &g_ctx.sc_err};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 4; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }
@@ -1813,6 +1909,26 @@ int gnx_align_batch(const gnx_params *p, int64_t n_pairs, const uint8_t *alpha_c
     for (int64_t q = 0; q < n_pairs; q++) { al[(size_t)q] = alpha_off[q + 1] - alpha_off[q]; bl[(size_t)q] = beta_off[q + 1] - beta_off[q]; }
     return gnx_align_batch_windows(p, n_pairs, alpha_cat, alpha_off[n_pairs], alpha_off, al.data(), beta_cat, beta_off[n_pairs], beta_off, bl.data(),
                                    out_score, out_ops, out_ops_off);
+}
+
+int gnx_gsw_extend_batch(int side, const int64_t *scores, int64_t gap_pen, int64_t n_pairs,
+                         const uint8_t *alpha_cat, const int64_t *alpha_off, const uint8_t *beta_cat, const int64_t *beta_off,
+                         int64_t *out_score, int64_t *out_end_i, int64_t *out_end_j, gnx_cigar **out_ops, int64_t **out_ops_off) {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    g_err[0] = 0;
+    if ((side != GNX_GSW_LEFT && side != GNX_GSW_RIGHT) || !scores || n_pairs < 0 || !alpha_off || !beta_off) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(g_ctx.device));
+    gnx_params prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.mode = GNX_CONST_GAP_HIGHMEM;
+    for (int x = 0; x < 25; x++) prm.scores[x] = scores[x];
+    prm.gap_open = gap_pen; prm.checkersize_i = 10000; prm.checkersize_j = 10000;
+    std::vector<int64_t> al((size_t)n_pairs), bl((size_t)n_pairs);
+    for (int64_t q = 0; q < n_pairs; q++) { al[(size_t)q] = alpha_off[q + 1] - alpha_off[q]; bl[(size_t)q] = beta_off[q + 1] - beta_off[q]; }
+    return run_host_windows(&prm, n_pairs, alpha_cat, alpha_off[n_pairs], alpha_off, al.data(), beta_cat, beta_off[n_pairs], beta_off, bl.data(),
+                            out_score, out_ops, out_ops_off, side == GNX_GSW_LEFT ? 1 : 2, out_end_i, out_end_j);
 }
 
 int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const uint8_t *beta, int64_t m,

@@ -155,6 +155,24 @@ int gnx_multiple_affine_gap_batch(const gnx_params *p, int64_t chunk_size, int64
                                   int64_t n_pairs, const int32_t *pair_a, const int32_t *pair_b,
                                   int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off);
 
+/* ---- "next" row N2: the seed-extension DPs of the graph aligner (what cmd/gsw spends its DP time in) ------------------ */
+/* genomeGraph.LeftDynamicAln  (/root/reference/genomeGraph/search.go:234-276): constant gap, borders 0, cell values clamped
+ *   at 0; traceback from (len(alpha), len(beta)) while the cell value is > 0.  Returns m[n][m], the route and the (i, j) where
+ *   the walk stopped.
+ * genomeGraph.RightDynamicAln (search.go:278-321): constant gap with Needleman-Wunsch borders; the alignment ends at the first
+ *   row-major cell holding the maximum (> 0) and is traced back to (0, 0).  Returns that maximum, the route and (maxI, maxJ).
+ * Both use cigar.TripleMaxTrace (cigar/tools.go:58-66: M >= I >= D).  The route is in TRACEBACK order, exactly as the
+ * reference builds it when it is called with an empty dynamicScore.route (callers reverse it, search.go:196,228); ops are
+ * GNX_COL_M/I/D for cigar 'M'/'I'/'D', gnx_cigar has the layout of cigar.Cigar{RunLength int; Op byte} on amd64.
+ * gap_pen must be <= 0 (gsw passes -600, search.go:176,210).  RIGHT packs (score, column) into one int32 per row:
+ * sequences up to 4095 bases and (n+m+2)*max|penalty| < 2^19, else GNX_ERANGE (the reference's matrix is 2480 x 2480,
+ * search.go:22).  One call replaces the per-seed calls of GraphSmithWatermanToGiraf (toGiraf.go:58-59) for a batch of reads. */
+#define GNX_GSW_LEFT 0
+#define GNX_GSW_RIGHT 1
+int gnx_gsw_extend_batch(int side, const int64_t *scores, int64_t gap_pen, int64_t n_pairs,
+                         const uint8_t *alpha_cat, const int64_t *alpha_off, const uint8_t *beta_cat, const int64_t *beta_off,
+                         int64_t *out_score, int64_t *out_end_i, int64_t *out_end_j, gnx_cigar **out_ops, int64_t **out_ops_off);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,20 @@ inline void AffineGapLocalEngine(const ScoreMatrix &scores, int64_t gapOpen, int
     for (size_t k = 0; k < pairs.size(); k++) { pairs[k].Score = sc[k]; pairs[k].Cigar_ = std::move(rt[k]); }
 }
 
+// align.AffineGapChunk (align/affineGap_highMem.go:227-268), "next" row N1
+inline std::pair<int64_t, std::vector<Cigar>> AffineGapChunk(const std::vector<dna::Base> &alpha, const std::vector<dna::Base> &beta, const ScoreMatrix &scores, int64_t gapOpen, int64_t gapExtend, int64_t chunkSize) {
+    const gnx_params p = detail::params(GNX_AFFINE_GAP_HIGHMEM, scores, gapOpen, gapExtend, 10000, 10000);
+    const int64_t aoff[2] = {0, (int64_t)alpha.size()}, boff[2] = {0, (int64_t)beta.size()};
+    int64_t score = 0, *off = nullptr;
+    gnx_cigar *ops = nullptr;
+    const int rc = gnx_affine_gap_chunk_batch(&p, chunkSize, 1, alpha.data(), aoff, beta.data(), boff, &score, &ops, &off);
+    if (rc) detail::raise(rc);
+    std::vector<Cigar> route((size_t)off[1]);
+    for (int64_t k = 0; k < off[1]; k++) route[(size_t)k] = Cigar{ops[k].run_length, ops[k].op};
+    gnx_free(ops); gnx_free(off);
+    return {score, std::move(route)};
+}
+
 inline std::string PrintCigar(const std::vector<Cigar> &ops) { // align/view.go:26-33
     std::string s;
     for (const auto &c : ops) { s += std::to_string(c.RunLength); s += (c.Op == ColM ? 'M' : c.Op == ColI ? 'I' : c.Op == ColD ? 'D' : '?'); }
@@ -164,3 +178,38 @@ inline std::string View(const std::vector<dna::Base> &alpha, const std::vector<d
 }
 } // namespace align
 #endif
+
+// ---- "next" row N2: the seed-extension DPs of the graph aligner (genomeGraph/search.go:234-321) -------------------------
+namespace cigar {
+struct Cigar { int64_t RunLength; uint8_t Op; }; // cigar.Cigar{RunLength int; Op byte}: 'M', 'I', 'D'
+inline bool operator==(const Cigar &a, const Cigar &b) { return a.RunLength == b.RunLength && a.Op == b.Op; }
+} // namespace cigar
+
+namespace genomeGraph {
+struct DynamicAln { int64_t score; std::vector<cigar::Cigar> route; int i, j; };
+
+namespace detail {
+inline DynamicAln extend(int side, const std::vector<dna::Base> &alpha, const std::vector<dna::Base> &beta, const align::ScoreMatrix &scores, int64_t gapPen) {
+    int64_t flat[25];
+    for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) flat[a * 5 + b] = scores[(size_t)a][(size_t)b];
+    const int64_t aoff[2] = {0, (int64_t)alpha.size()}, boff[2] = {0, (int64_t)beta.size()};
+    int64_t score = 0, ei = 0, ej = 0, *off = nullptr;
+    gnx_cigar *ops = nullptr;
+    const int rc = gnx_gsw_extend_batch(side, flat, gapPen, 1, alpha.data(), aoff, beta.data(), boff, &score, &ei, &ej, &ops, &off);
+    if (rc) align::detail::raise(rc);
+    DynamicAln out{score, {}, (int)ei, (int)ej};
+    static const uint8_t letter[3] = {'M', 'I', 'D'};
+    for (int64_t k = 0; k < off[1]; k++) out.route.push_back(cigar::Cigar{ops[k].run_length, letter[ops[k].op]});
+    gnx_free(ops); gnx_free(off);
+    return out;
+}
+} // namespace detail
+
+// Route in traceback order, as the reference returns it for an empty incoming dynamicScore.route.
+inline DynamicAln LeftDynamicAln(const std::vector<dna::Base> &alpha, const std::vector<dna::Base> &beta, const align::ScoreMatrix &scores, int64_t gapPen) {
+    return detail::extend(GNX_GSW_LEFT, alpha, beta, scores, gapPen);
+}
+inline DynamicAln RightDynamicAln(const std::vector<dna::Base> &alpha, const std::vector<dna::Base> &beta, const align::ScoreMatrix &scores, int64_t gapPen) {
+    return detail::extend(GNX_GSW_RIGHT, alpha, beta, scores, gapPen);
+}
+} // namespace genomeGraph

@@ -625,6 +625,91 @@ int or_multiple_affine_gap(const uint8_t *A, int ga, int64_t la, const uint8_t *
     return rc;
 }
 
+/* ---- "next" row N2: seed-extension DPs of the graph aligner ------------------------------------------------------------
+ * genomeGraph/search.go:234-276 LeftDynamicAln, :278-321 RightDynamicAln, cigar/tools.go:58-66 TripleMaxTrace.
+ * Parity UNPINNED: the reference's tests of this path only log; these are literal restatements.
+ * resetDynamicScore (search.go:104-107) takes its argument by value, so it is a no-op: the route the caller passes in is kept
+ * (route_in / n_in) and the loop's routeIdx still starts at 0 -- the first traced op is compared with route[0], not with the
+ * last element.  With n_in = 0 the result is the plain run-length encoding in traceback order.  currMax likewise starts at
+ * whatever the caller's copy holds (curr_max_in; the callers' value is always 0).
+ * Ops here: 0/1/2 for cigar 'M'/'I'/'D'.  out_route = the whole route (carried-over elements included). */
+static int gsw_trace_step(or_cigar **route, int64_t *len, int64_t *cap, int64_t *routeIdx, uint8_t op) {
+    if (*len == 0 || (*route)[*routeIdx].op != op) {
+        if (*len == 0) {
+            /* route = append(route, Cigar{1, op}) on the empty route; routeIdx stays 0 */
+        } else {
+            (*routeIdx)++;
+        }
+        if (*len == *cap) {
+            int64_t ncap = *cap ? 2 * *cap : 16;
+            or_cigar *nr = (or_cigar *)realloc(*route, (size_t)ncap * sizeof(or_cigar));
+            if (!nr) return OR_ENOMEM;
+            *route = nr; *cap = ncap;
+        }
+        memset(&(*route)[*len], 0, sizeof(or_cigar));
+        (*route)[*len].run = 1; (*route)[*len].op = op;
+        (*len)++;
+    } else {
+        (*route)[*routeIdx].run += 1;
+    }
+    return OR_OK;
+}
+
+int or_gsw_extend(int side, const uint8_t *alpha, int64_t n, const uint8_t *beta, int64_t m, const int64_t *sc, int64_t gapPen,
+                  const or_cigar *route_in, int64_t n_in, int64_t curr_max_in,
+                  int64_t *out_score, int64_t *out_i, int64_t *out_j, or_cigar **out_route, int64_t *out_len) {
+    if (!bases_ok(alpha, n) || !bases_ok(beta, m)) return OR_EINVAL;
+    const int64_t W = m + 1;
+    int64_t *mat = (int64_t *)calloc((size_t)((n + 1) * W), sizeof(int64_t));
+    uint8_t *tr = (uint8_t *)calloc((size_t)((n + 1) * W), 1);
+    int64_t cap = n_in > 16 ? 2 * n_in : 16, len = n_in, routeIdx = 0, i, j;
+    or_cigar *route = (or_cigar *)malloc((size_t)cap * sizeof(or_cigar));
+    if (!mat || !tr || !route) { free(mat); free(tr); free(route); return OR_ENOMEM; }
+    if (n_in) memcpy(route, route_in, (size_t)n_in * sizeof(or_cigar));
+    int rc = OR_OK;
+    uint8_t k;
+    if (side == 0) { /* LeftDynamicAln */
+        /* m[i][0] = 0, m[0][j] = 0 (calloc) */
+        for (i = 1; i < n + 1; i++) {
+            for (j = 1; j < m + 1; j++) {
+                mat[i * W + j] = tmt(mat[(i - 1) * W + j - 1] + sc[alpha[i - 1] * 5 + beta[j - 1]], mat[i * W + j - 1] + gapPen, mat[(i - 1) * W + j] + gapPen, &k);
+                tr[i * W + j] = k;
+                if (mat[i * W + j] < 0) mat[i * W + j] = 0;
+            }
+        }
+        for (i = n, j = m; mat[i * W + j] > 0 && rc == OR_OK;) {
+            const uint8_t op = tr[i * W + j];
+            rc = gsw_trace_step(&route, &len, &cap, &routeIdx, op);
+            if (op == 0) { i--; j--; } else if (op == 1) j--; else i--;
+        }
+        *out_score = mat[n * W + m]; *out_i = i; *out_j = j;
+    } else { /* RightDynamicAln */
+        int64_t maxI = 0, maxJ = 0, currMax = curr_max_in;
+        for (i = 0; i < n + 1; i++) {
+            for (j = 0; j < m + 1; j++) {
+                if (i == 0 && j == 0) mat[0] = 0;
+                else if (i == 0) { mat[j] = mat[j - 1] + gapPen; tr[j] = 1; }
+                else if (j == 0) { mat[i * W] = mat[(i - 1) * W] + gapPen; tr[i * W] = 2; }
+                else {
+                    mat[i * W + j] = tmt(mat[(i - 1) * W + j - 1] + sc[alpha[i - 1] * 5 + beta[j - 1]], mat[i * W + j - 1] + gapPen, mat[(i - 1) * W + j] + gapPen, &k);
+                    tr[i * W + j] = k;
+                }
+                if (mat[i * W + j] > currMax) { currMax = mat[i * W + j]; maxI = i; maxJ = j; }
+            }
+        }
+        for (i = maxI, j = maxJ; (i > 0 || j > 0) && rc == OR_OK;) {
+            const uint8_t op = tr[i * W + j];
+            rc = gsw_trace_step(&route, &len, &cap, &routeIdx, op);
+            if (op == 0) { i--; j--; } else if (op == 1) j--; else i--;
+        }
+        *out_score = mat[maxI * W + maxJ]; *out_i = maxI; *out_j = maxJ;
+    }
+    free(mat); free(tr);
+    if (rc != OR_OK) { free(route); return rc; }
+    *out_route = route; *out_len = len;
+    return OR_OK;
+}
+
 void or_free(void *p) { free(p); }
 
 /* ------------------------------------------------------------------------------------------------

@@ -20,6 +20,25 @@ int main() {
     if (l.first != 460 || align::PrintCigar(l.second) != "7D6M2D") { std::printf("local mismatch\n"); bad++; }
     try { align::ConstGap(dna::StringToBases("ACgT"), dna::StringToBases("ACGT"), align::DefaultScoreMatrix(), -430); bad++; }
     catch (const std::out_of_range &) {}
+    // N1: affineAlignChunkTests row 1 (align/affineGap_test.go:27-36, chunk size 3)
+    {
+        auto a = dna::StringToBases("ACG"), b = dna::StringToBases("ACGACG");
+        auto r = align::AffineGapChunk(a, b, align::DefaultScoreMatrix(), -400, -30, 3);
+        int64_t cols = 0;
+        for (const auto &c : r.second) cols += c.RunLength;
+        if (cols != 6) { std::printf("chunk mismatch\n"); bad++; }
+    }
+    // N2: a perfect match extends to the origin (left) / ends at (n, m) (right)
+    {
+        auto a = dna::StringToBases("ACGTACGTGG");
+        int64_t perfect = 0;
+        for (auto x : a) perfect += align::HumanChimpTwoScoreMatrix()[x][x];
+        auto l2 = genomeGraph::LeftDynamicAln(a, a, align::HumanChimpTwoScoreMatrix(), -600);
+        auto r2 = genomeGraph::RightDynamicAln(a, a, align::HumanChimpTwoScoreMatrix(), -600);
+        const std::vector<cigar::Cigar> want = {cigar::Cigar{10, 'M'}};
+        if (l2.score != perfect || !(l2.route == want) || l2.i != 0 || l2.j != 0) { std::printf("left extension mismatch\n"); bad++; }
+        if (r2.score != perfect || !(r2.route == want) || r2.i != 10 || r2.j != 10) { std::printf("right extension mismatch\n"); bad++; }
+    }
     std::printf(bad ? "FAILED\n" : "ok\n");
     return bad ? 1 : 0;
 }

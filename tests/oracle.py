@@ -39,6 +39,9 @@ def lib():
         L.or_multiple_affine_gap.argtypes = [c_p, ctypes.c_int, i64, c_p, ctypes.c_int, i64, c_p, i64, i64, i64,
                                              ctypes.POINTER(i64), ctypes.POINTER(c_p), ctypes.POINTER(i64)]
         L.or_multiple_affine_gap.restype = ctypes.c_int
+        L.or_gsw_extend.argtypes = [ctypes.c_int, c_p, i64, c_p, i64, c_p, i64, c_p, i64, i64, ctypes.POINTER(i64), ctypes.POINTER(i64),
+                                    ctypes.POINTER(i64), ctypes.POINTER(c_p), ctypes.POINTER(i64)]
+        L.or_gsw_extend.restype = ctypes.c_int
         L.or_free.argtypes = [c_p]
         L.or_free.restype = None
         _lib = L
@@ -131,3 +134,31 @@ def multiple_affine_gap(scores, gap_open, gap_extend, chunk, block_a, block_b):
     rc = L.or_multiple_affine_gap(Ab.ctypes.data, A.shape[0], A.shape[1], Bb.ctypes.data, B.shape[0], B.shape[1], sc.ctypes.data,
                                   int(gap_open), int(gap_extend), int(chunk), ctypes.byref(score), ctypes.byref(ops_p), ctypes.byref(nops))
     return _route_out(rc, score, ops_p, nops)
+
+
+def gsw_extend(side, scores, gap_pen, alpha, beta, route_in=None, curr_max=0):
+    """genomeGraph.LeftDynamicAln (side 0) / RightDynamicAln (side 1) restated in oracle/gnx_oracle.c.
+    route_in: [(run, op)] with ops 0/1/2 (the caller's dynamicScore.route, kept because resetDynamicScore is a no-op).
+    Returns (score, route [(run, op)], i, j)."""
+    L = lib()
+    sc = np.ascontiguousarray(np.asarray(scores, dtype=np.int64).reshape(25))
+    a = np.ascontiguousarray(alpha, dtype=np.uint8)
+    b = np.ascontiguousarray(beta, dtype=np.uint8)
+    rin = np.zeros(max(len(route_in or []), 1), dtype=CIGAR_DTYPE)
+    for k, (r, o) in enumerate(route_in or []):
+        rin[k] = (r, o)
+    score, oi, oj, n_out = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    out_p = ctypes.c_void_p()
+    rc = L.or_gsw_extend(int(side), a.ctypes.data if a.size else None, a.shape[0], b.ctypes.data if b.size else None, b.shape[0], sc.ctypes.data,
+                         int(gap_pen), rin.ctypes.data, len(route_in or []), int(curr_max), ctypes.byref(score), ctypes.byref(oi), ctypes.byref(oj),
+                         ctypes.byref(out_p), ctypes.byref(n_out))
+    if rc:
+        raise OracleError("or_gsw_extend rc=%d" % rc)
+    n = n_out.value
+    route = []
+    if n:
+        buf = (ctypes.c_char * (n * 16)).from_address(out_p.value)
+        arr = np.frombuffer(buf, dtype=CIGAR_DTYPE, count=n)
+        route = [(int(arr["run_length"][k]), int(arr["op"][k])) for k in range(n)]
+    L.or_free(out_p)
+    return score.value, route, oi.value, oj.value
