@@ -66,14 +66,16 @@ def cpu_baseline(reads, chunk, scores, budget_s=15.0):
     cores = os.cpu_count() or 1
     n = READ_LEN
 
+    last = [None]
+
     def run(k, threads):
         a_start = np.arange(k, dtype=np.int64) * n
         a_len = np.full(k, n, dtype=np.int64)
         b_start = np.zeros(k, dtype=np.int64)
         b_len = np.full(k, chunk.shape[0], dtype=np.int64)
         t0 = time.perf_counter()
-        oracle.align_batch_windows(oracle.MODE_AFFINE, scores, -600, -150, reads[:k].reshape(-1), a_start, a_len,
-                                   chunk, b_start, b_len, threads=threads)
+        last[0] = oracle.align_batch_windows(oracle.MODE_AFFINE, scores, -600, -150, reads[:k].reshape(-1), a_start, a_len,
+                                             chunk, b_start, b_len, threads=threads)
         return time.perf_counter() - t0
 
     k = min(4 * cores, reads.shape[0])
@@ -81,10 +83,24 @@ def cpu_baseline(reads, chunk, scores, budget_s=15.0):
     while dt < budget_s / 2 and k < reads.shape[0]:  # grow the sample until it is ~budget_s of wall time
         k = min(reads.shape[0], max(k + 1, int(k * min(8.0, 0.9 * budget_s / max(dt, 1e-3)))))
         dt = run(k, cores)
+    k_min = min(10000, reads.shape[0])  # the sample doubles as the bit-exactness check of the GPU results: at least 10 000 pairs
+    if k < k_min and dt * k_min / k < 3 * budget_s:
+        k = k_min
+        dt = run(k, cores)
+    oracle_results, oracle_k = last[0], k
     cells = k * n * chunk.shape[0]
     k1 = min(8, reads.shape[0])
     dt1 = run(k1, 1)  # context: one thread alone (containers often cap the CPU time of the nominal cores)
-    return {"value": cells / dt, "unit": "DP cells/s", "cores": cores, "kind": "port",
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"_oracle": (oracle_results, oracle_k), "cpu_model": model, "value": cells / dt, "unit": "DP cells/s", "cores": cores, "kind": "port",
             "pairs_per_s": k / dt, "single_thread_cells_per_s": k1 * n * chunk.shape[0] / dt1,
             "sample": "%d pairs (150x10000, C2 generator) through oracle/gnx_oracle.c or_align_batch, %d threads, %.1f s"
                       % (k, cores, dt)}
@@ -253,7 +269,7 @@ def main():
                                    "HumanChimpTwoScoreMatrix, gapOpen -600, gapExtend -150, score + full CIGAR" % n_pairs,
                        "pairs_per_gpu": n_pairs, "read_len": READ_LEN, "chunk_len": CHUNK_LEN, "parallelism": "pairs sharded x%d" % world},
             "pairs_per_s": n_pairs * world * args.steps / dt,
-            "bit_exact_sample": ok,
+            "bit_exact_sample": ok, "bit_exact_pairs_checked": int(min(args.verify, n_pairs)),
             "kernel_ms": {"all_fill_kernels_per_step": float(np.mean(fill_ms)), "traceback_and_rest_per_step": float(np.mean(tb_ms)),
                           "dominant_kernel_per_step": dom_ms / args.steps, "fast_path": bool(fast_path)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -264,9 +280,31 @@ def main():
                          "algorithmic_bytes_per_launch": abytes,
                          "cells_per_s_kernel": pairs_per_launch * READ_LEN * CHUNK_LEN / (fill_avg_ms * 1e-3)},
         }
+        try:  # second ceiling: VALU issue, 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6e12 lane-ops/s
+            with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as fh:
+                fpj = json.load(fh)["fast_path"]
+                vi = fpj.get("valu_insts_per_pair") if fast_path else None
+            if vi:
+                lane_ops = vi * 64.0 * pairs_per_launch / (fill_avg_ms * 1e-3)
+                out["roofline_valu"] = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": 78.6, "unit": "T lane-ops/s", "frac": lane_ops / 78.6e12,
+                                        "valu_insts_per_pair": vi, "valu_busy": fpj.get("valu_busy"),
+                                        "source": "SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE (rocprofv3 --pmc, profiles/r1_pmc_sq.csv)"}
+        except (OSError, KeyError, ValueError):
+            pass
         if not args.no_cpu and args.series == "affine" and world == 1:
-            out["cpu_baseline"] = cpu_baseline(reads_h, chunk_h, align.HumanChimpTwoScoreMatrix)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            cb = cpu_baseline(reads_h, chunk_h, align.HumanChimpTwoScoreMatrix)
+            exp, k = cb.pop("_oracle")
+            # the oracle results of the baseline sample double as the bit-exactness check of the first k GPU results
+            sc = d_score[:k].cpu().numpy()
+            off = d_off[:k + 1].cpu().numpy()
+            ops = d_ops[:int(off[-1]) * 16].cpu().numpy().view(_lib.CIGAR_DTYPE)
+            ok_k = bool(np.array_equal(sc, exp[0]) and np.array_equal(off, exp[2]) and np.array_equal(ops["run_length"], exp[1]["run_length"])
+                        and np.array_equal(ops["op"], exp[1]["op"]))
+            ok = ok and ok_k
+            out["bit_exact_sample"] = ok
+            out["bit_exact_pairs_checked"] = int(k)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = value / cb["value"]
         if args.series != "affine":
             out["roofline"]["note"] = "algorithmic-byte model is the affine one; use cells_per_s_kernel for this series"
         print(json.dumps(out))

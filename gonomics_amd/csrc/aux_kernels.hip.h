@@ -1,0 +1,87 @@
+// aux_kernels.hip.h -- N1 score matrices, run scaling, exclusive scan of the run counts
+// Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).  See DESIGN.md section 4.
+#pragma once
+#include "gnx_common.hip.h"
+
+namespace {
+// ------------------------------------------------------------------------------------------------------
+// N1: per-cell score matrices for the chunk / multiple-alignment variants, one thread per (chunk) cell, written
+// column-major as 4*score.  A "group" is an alignment block: nseq sequences of len bases, sequence-major.
+//   pairwise (AffineGapChunk):      cell = sum_k scores[a[i*c+k]][b[j*c+k]]                       (ungapped.go:7-13)
+//   groups (multipleAffineGap*):    cell = sum_k scoreColumnMatch(column i*c+k, column j*c+k)     (multiAlign.go:82-110)
+//     scoreColumnMatch = (sum over sequence pairs, lower case folded, gap columns skipped) / count, Go integer division
+// ------------------------------------------------------------------------------------------------------
+struct GroupDesc { int64_t off; int32_t nseq; int32_t len; };
+struct ScorePair { int64_t a_off, b_off; int32_t a_nseq, b_nseq, a_len, b_len; int32_t nc, mc; int64_t s_off, s_pitch; };
+
+__global__ __launch_bounds__(256) void score_matrix_kernel(const ScorePair *__restrict__ sp, const uint8_t *__restrict__ bases, KParams kp, int chunk,
+                                                           int groups, int *__restrict__ smat, int *__restrict__ err) {
+    const ScorePair q = sp[blockIdx.y];
+    const int64_t cells = (int64_t)q.nc * q.mc;
+    for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < cells; cell += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(cell % q.nc), j = (int)(cell / q.nc);
+        int64_t total = 0;
+        for (int k = 0; k < chunk; k++) {
+            const int64_t ac = (int64_t)i * chunk + k, bc = (int64_t)j * chunk + k;
+            if (!groups) {
+                const int a = bases[q.a_off + ac], b = bases[q.b_off + bc];
+                if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
+                total += kp.sc4[a * 5 + b] / 4;
+            } else {
+                int64_t sum = 0, count = 0;
+                for (int x = 0; x < q.a_nseq; x++) {
+                    int a = bases[q.a_off + (int64_t)x * q.a_len + ac];
+                    if (a >= 5 && a <= 9) a -= 5;
+                    for (int y = 0; y < q.b_nseq; y++) {
+                        int b = bases[q.b_off + (int64_t)y * q.b_len + bc];
+                        if (b >= 5 && b <= 9) b -= 5;
+                        if (a != 10 && b != 10) {
+                            if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
+                            sum += kp.sc4[a * 5 + b] / 4;
+                            count++;
+                        }
+                    }
+                }
+                if (count == 0) { atomicOr(err, 16); continue; } // Go: integer divide by zero
+                total += sum / count;
+            }
+        }
+        smat[q.s_off + (int64_t)j * q.s_pitch + i] = (int)(4 * total);
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_runs_kernel(gnx_cigar *__restrict__ ops, int64_t total, int64_t factor) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < total) ops[x].run_length *= factor; // expandCigarRunLength, affineGap_highMem.go:91-95
+}
+
+// exclusive scan of nops[0..n) + carry[0] -> off[0..n], off[n]; carry[0] = off[n] afterwards.  One block.
+__global__ __launch_bounds__(1024) void scan_kernel(const int64_t *__restrict__ nops, int n, int64_t *__restrict__ off, int64_t *__restrict__ carry) {
+    // exclusive scan of the run counts, 1024 elements per round: wave-level scans by __shfl_up, then the 16 wave totals
+    // (a one-pass version with a contiguous slice per thread measured slower: 227 us vs 139 us per 100 k elements)
+    __shared__ int64_t wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t base = carry[0];
+    for (int start = 0; start < n; start += 1024) {
+        const int idx = start + threadIdx.x;
+        const int64_t v = idx < n ? nops[idx] : 0;
+        int64_t sum = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(sum, d, 64); if (lane >= d) sum += t; }
+        if (lane == 63) wsum[wave] = sum;
+        __syncthreads();
+        if (wave == 0) {
+            int64_t t = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { const int64_t u = __shfl_up(t, d, 64); if (lane >= d) t += u; }
+            if (lane < 16) wsum[lane] = t;
+        }
+        __syncthreads();
+        if (idx < n) off[idx] = base + (wave > 0 ? wsum[wave - 1] : 0) + sum - v;
+        base += wsum[15];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { off[n] = base; carry[0] = base; }
+}
+
+} // namespace

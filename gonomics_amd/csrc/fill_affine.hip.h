@@ -1,0 +1,242 @@
+// fill_affine.hip.h -- affine-gap fill kernel (16 lanes x 10 rows per pair): full direction matrix, strips, window re-fills, SCORED variant
+// Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).  See DESIGN.md section 4.
+#pragma once
+#include "gnx_common.hip.h"
+
+namespace {
+// ------------------------------------------------------------------------------------------------------
+// Affine fill.
+//   LOCAL = free end gaps (AffineGapLocal, affineGap_highMem.go:188-210)
+//   MULTI = some pair of the launch has more than one 160-row strip (row buffer hand-over code compiled in)
+//   P16   = 4*score fits int16: the per-row score profile is stored as packed int16 pairs in LDS
+//   HFORM = gapOpen <= 0 (every caller): with h = max3(M,I,D) the recurrences collapse to
+//           rt = max(h+oe, I+e), dn = max(h+oe, D+e) with identical values AND identical argmax tags
+//           (oe <= e makes the dropped candidate I+oe / D+oe never a strict winner; ties keep M > I > D).
+//           gfx950 issues v_max_i32/v_max3_i32/v_and_or/v_alignbit/DPP/SDWA and any VALU op with an SGPR
+//           operand at 4 cycles per wave64 but VGPR/immediate add/or at 2 (tools/valu_ubench*.hip), so the
+//           penalties are kept in VGPRs and the h-form trades 2 max3 + 2 adds for 2 max.
+// LDS (dwords): [0,32) 4*score table; then per pair g a profile  prof[b][lane][LW]  (b-stride BST, pair stride
+// PST).  BST = 0 and PST = 16 (mod 32) make the 32 lanes of a ds_read_b32 group hit 32 distinct banks whatever
+// bases they look up (lane stride 5 or 10 dwords is odd/2*odd -> a permutation within a pair, +16 for the
+// second pair of the group fills the complement).
+// ------------------------------------------------------------------------------------------------------
+template <bool P16> struct ProfCfg {
+    static constexpr int LW = P16 ? R / 2 : R;       // dwords per lane per base
+    static constexpr int BST = P16 ? 96 : 160;       // dwords per base (>= 16*LW, multiple of 32)
+    static constexpr int PST = 5 * BST + 16;         // dwords per pair
+};
+
+template <bool LOCAL, bool MULTI, bool P16, bool HFORM, bool WIN = false, bool SCORED = false>
+__global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                         const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                         const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                         KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
+                                                         int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, const int2 *__restrict__ ckpt,
+                                                         int *__restrict__ err, const int *__restrict__ smat = nullptr) {
+    // SCORED: the substitution score of a cell comes from an explicit per-pair matrix in HBM (chunk / multiple-alignment
+    //      variants, "next" row N1) instead of the LDS profile of alpha x the base of the column; sequences are not read.
+    // WIN: window / tile re-fill of the fast path: the left boundary comes from a column checkpoint written by
+    //      fp_sweep_kernel (pl.col_off > 0), the row-0 boundary and the beta window start at column col_off.
+    using PC = ProfCfg<P16>;
+    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    __shared__ int lds[32 + 4 * PST];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    if (lane < 25) lds[lane] = kp.sc4[lane];
+    int *prof = &lds[32 + g * PST];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+
+    const int pbase = blockIdx.x * 4;
+    int S_max = 0, m_max = 0;
+    for (int q = 0; q < 4; q++) {
+        if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
+    }
+    const int p = pbase + g;
+    const bool valid = p < n_pairs;
+    PairPlan pl;
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
+    const uint8_t *ap = SCORED ? nullptr : a_buf + (valid ? a_start[pl.src] : 0);
+    const uint8_t *bp = SCORED ? nullptr : b_buf + (valid ? b_start[pl.src] + (WIN ? pl.col_off : 0) : 0);
+    const int Tend = (m_max + 15 + 15) & ~15;
+    const int OE4 = kp.oe4, E4 = kp.e4;
+    // h-form carries X = h + e instead of h (XE = e): then I+e and D+e are one 2-cycle `and` + one 2-cycle add
+    // each and no separate retag is needed; (X|3) + s == M + e because e is a multiple of 4.
+    const int XE = HFORM ? kp.e4 : 0;
+    int vOE4, vE4, vO4, vE4p2, vE4p1; // constants pinned in VGPRs (2-cycle adds)
+    asm volatile("v_mov_b32 %0, %5\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %7\n\tv_mov_b32 %3, %8\n\tv_mov_b32 %4, %9"
+                 : "=v"(vOE4), "=v"(vE4), "=v"(vO4), "=v"(vE4p2), "=v"(vE4p1)
+                 : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4), "s"(kp.e4 + 2), "s"(kp.e4 + 1));
+    int bad = 0;
+
+    for (int s = 0; s < S_max; s++) {
+        const bool gact = valid && s < pl.strips;
+        const int m_eff = gact ? pl.m : 0;
+        int m_min = 0x7fffffff; // over the 4 pairs of the wave, this strip (wave-uniform)
+        for (int q = 0; q < 4; q++) m_min = min(m_min, (pbase + q < n_pairs && s < plans[pbase + q].strips) ? plans[pbase + q].m : 0);
+        const bool store_row = MULTI && gact && (s + 1 < pl.strips);
+        const int row0 = s * H + l * R; // 0-based index of this lane's first row == 1-based index of the row above it
+        int rt[R], hold[R];
+        unsigned acc[3 * R]; // direction accumulators: [0,R) M, [R,2R) I, [2R,3R) D
+        if (!SCORED) { // score profile of this lane's rows: prof[b][lane][k]
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+            __syncthreads(); // table visible; previous strip's profile no longer read
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) {
+                    int v;
+                    if (P16) v = (lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16);
+                    else v = lds[a5[k] + b];
+                    prof[b * BST + l * LW + k] = v;
+                }
+            }
+            __syncthreads();
+        }
+        const int2 *ck0 = nullptr; // window re-fill: left boundary = column checkpoint col_off / CKW
+        if (WIN && pl.col_off > 0) ck0 = ckpt + pl.ckpt_off + (int64_t)(pl.col_off / CKW - 1) * pl.n;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = row0 + r + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
+            const int D1c = kp.d00_4 + i * kp.ecol4 + 1;
+            hold[r] = max3i(NEG4 + 3, NEG4 + 2, D1c) + XE;
+            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + 2 + E4, D1c + OE4);
+            if (WIN && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x; hold[r] = v.y; }
+            acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
+        }
+        int diag0 = ((row0 == 0) ? max3i(3, kp.o4 + 2, kp.d00_4 + 1) : max3i(NEG4 + 3, NEG4 + 2, kp.d00_4 + row0 * kp.ecol4 + 1)) + XE;
+        if (WIN && ck0) {
+            if (row0 == 0) diag0 = max3i(NEG4 + 3, kp.o4 + pl.col_off * E4 + 2, NEG4 + 1) + XE; // h(0, col_off)
+            else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y;
+        }
+        int dn_out = 0, h_out = 0, b_out = 0;
+        int sq_dn = 0, sq_h = 0;
+        // boundary queues (row above the strip + beta): lane u holds column t0+u+1 of the current 16-step block
+        int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
+        auto boundary = [&](int c, int &odn, int &oh, int &ob) {
+            if (!MULTI || s == 0) {
+                const int M3 = NEG4 + 3, I2 = kp.o4 + ((WIN ? pl.col_off : 0) + c) * E4 + 2, D1 = NEG4 + 1; // row 0: I(0,c) = gapOpen + c*gapExtend
+                const int h0 = max3i(M3, I2, D1);
+                odn = (LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4);
+                oh = h0 + XE;
+            } else if (c >= 1 && c <= m_eff) {
+                const int2 v = rowbuf[pl.rowbuf_off + c];
+                odn = v.x; oh = v.y; // already in the X domain
+            } else { odn = 0; oh = 0; }
+            int b = 0;
+            if (!SCORED && c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            ob = b * (BST * 4); // LDS byte offset of the base's profile plane
+        };
+        if (MULTI && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        boundary(l + 1, qdn, qh, qb);
+
+        // one anti-diagonal step; CHECK=false is the steady state (every lane of the wave has a live column)
+        auto step = [&](const int t, auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_dn = dpp_shr1(qdn, dn_out);
+            const int up_h = dpp_shr1(qh, h_out);
+            const int pb = dpp_shr1(qb, b_out);
+            qdn = dpp_shl1(qdn, qdn);
+            qh = dpp_shl1(qh, qh);
+            qb = dpp_shl1(qb, qb);
+            const int j = t - l;
+            b_out = pb;
+            if (!CHECK || (j >= 1 && j <= m_eff)) {
+                const int *pw = SCORED ? smat + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0
+                                       : reinterpret_cast<const int *>(prof_lane + pb);
+                int w[LW];
+#pragma unroll
+                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                int hd = diag0, dnu = up_dn;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    int S4;
+                    if (P16) S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
+                    else S4 = w[r];
+                    acc[r] = alignbit2((unsigned)hd, acc[r]);
+                    acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
+                    acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
+                    int hnew, dnn; // hnew is in the X domain (h + XE)
+                    if (HFORM) {
+                        const int M3e = (hd | 3) + S4;             // M + e
+                        const int Ie = (rt[r] & ~3) + vE4p2;       // I + e, tag 2
+                        const int De = (dnu & ~3) + vE4p1;         // D + e, tag 1
+                        hnew = max3i(M3e, Ie, De);                 // h + e
+                        const int hoe = hnew + vO4;                // h + oe
+                        rt[r] = max(hoe, Ie);
+                        dnn = max(hoe, De);
+                        if (LOCAL) dnn = (j == m_eff) ? hnew - vE4 : dnn; // last column: D(i+1,m) = tmt(M,I,D)(i,m), no penalty
+                    } else {
+                        const int M3 = (hd | 3) + S4;
+                        const int I2 = (rt[r] & ~3) | 2;
+                        const int D1 = (dnu & ~3) | 1;
+                        hnew = max3i(M3, I2, D1);
+                        const int Moe = M3 + vOE4;
+                        rt[r] = max3i(Moe, I2 + vE4, D1 + vOE4);
+                        dnn = max3i(Moe, I2 + vOE4, D1 + vE4);
+                        if (LOCAL) dnn = (j == m_eff) ? hnew : dnn;
+                    }
+                    hd = hold[r];
+                    hold[r] = hnew;
+                    dnu = dnn;
+                }
+                diag0 = up_h;
+                dn_out = dnu;
+                h_out = hold[R - 1];
+            }
+            if (MULTI) { sq_dn = dpp_shl1(dn_out, sq_dn); sq_h = dpp_shl1(h_out, sq_h); }
+        };
+
+        for (int t0 = 0; t0 < Tend; t0 += 16) {
+            boundary(t0 + 16 + l + 1, ndn, nh, nb); // prefetch the next block's boundary
+            const bool steady = t0 >= 16 && t0 + 16 <= m_min;
+            if (steady) {
+#pragma unroll 2
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+            }
+            qdn = ndn; qh = nh; qb = nb;
+            // flush 16 steps of direction bits: word w of this strip
+            const int w = t0 >> 4;
+            if (gact && w < pl.words) {
+                const int miss = (t0 + 16 - l) - m_eff; // steps this lane sat idle after its last column
+                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+                if (t0 + 16 > m_min) { // drain: a lane that finished early right-aligns its last fields (it never shifts again)
+#pragma unroll
+                    for (int d = 0; d < 3 * R; d++) acc[d] >>= sh;
+                }
+                uint4 *dst = trace + pl.trace_off + ((int64_t)(s * pl.words + w) * QA) * G + l;
+#pragma unroll
+                for (int q = 0; q < QA - 1; q++) dst[q * G] = make_uint4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                dst[(QA - 1) * G] = make_uint4(acc[4 * (QA - 1)], acc[4 * (QA - 1) + 1], 0u, 0u);
+            }
+            if (store_row) {
+                const int c = t0 + l - 14;
+                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + c] = make_int2(sq_dn, sq_h);
+            }
+        }
+        if (gact && m_eff >= 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r] - XE;
+            // last-column D-plane fields of this lane's rows, packed (field r at bits 2r): lets the traceback skip
+            // vertical runs in column m (free end gaps of AffineGapLocal, trailing gaps when alpha is the long one)
+            const int t0f = ((m_eff + l - 1) >> 4) << 4, missf = t0f + 16 - l - m_eff; // 0..15: in-place drain shift
+            unsigned dw = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) dw |= ((acc[2 * R + r] >> (30 - 2 * missf)) & 3u) << (2 * r);
+            dcol[pl.dcol_off + s * G + l] = dw;
+        }
+        if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+} // namespace

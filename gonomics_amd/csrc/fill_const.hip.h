@@ -1,0 +1,164 @@
+// fill_const.hip.h -- constant-gap fill kernel and its GSW (graph-aligner seed extension) variants
+// Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).  See DESIGN.md section 4.
+#pragma once
+#include "gnx_common.hip.h"
+
+namespace {
+// ------------------------------------------------------------------------------------------------------
+// Constant-gap fill (align/constGap.go:146-157 recurrence), same wavefront mapping as the affine kernel.
+// Keys: diag+s -> tag 3, left+g -> tag 2, up+g -> tag 1; the stored value is the clean (tag-free) key, so the three
+// candidates are three 2-cycle VGPR adds (the profile holds 4*s+3, the penalties 4*g+2 / 4*g+1 live in VGPRs),
+// one v_max3, one v_and and one v_alignbit per cell.
+// ------------------------------------------------------------------------------------------------------
+// GSW (the seed-extension DP of the graph aligner, "next" row N2, /root/reference/genomeGraph/search.go:234-321):
+//   1 = LeftDynamicAln: zero borders, cell values clamped at 0 (the trace keeps its direction);
+//   2 = RightDynamicAln: the ordinary borders plus, per row, the running maximum of (score << 12 | 4095 - column), i.e. the first
+//       column of the row's best score; hcol receives that key instead of the last-column value.
+template <bool MULTI, int GSW = 0>
+__global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                        const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                        const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                        KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
+                                                        int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int *__restrict__ err) {
+    using PC = ProfCfg<false>;
+    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    __shared__ int lds[32 + 4 * PST];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    if (lane < 25) lds[lane] = kp.sc4[lane] + 3; // pre-tagged diagonal candidate
+    int *prof = &lds[32 + g * PST];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    const int pbase = blockIdx.x * 4;
+    int S_max = 0, m_max = 0;
+    for (int q = 0; q < 4; q++) {
+        if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
+    }
+    const int p = pbase + g;
+    const bool valid = p < n_pairs;
+    PairPlan pl;
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
+    const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    const int Tend = (m_max + 15 + 15) & ~15;
+    int vGL, vGU;
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vGL), "=v"(vGU) : "s"(kp.g4 + 2), "s"(kp.g4 + 1));
+    int bad = 0;
+
+    for (int s = 0; s < S_max; s++) {
+        const bool gact = valid && s < pl.strips;
+        const int m_eff = gact ? pl.m : 0;
+        int m_min = 0x7fffffff;
+        for (int q = 0; q < 4; q++) m_min = min(m_min, (pbase + q < n_pairs && s < plans[pbase + q].strips) ? plans[pbase + q].m : 0);
+        const bool store_row = MULTI && gact && (s + 1 < pl.strips);
+        const int row0 = s * H + l * R;
+        int val[R];
+        unsigned acc[R];
+        {
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = lds[a5[k] + b];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) { val[r] = GSW == 1 ? 0 : (row0 + r + 1) * kp.g4; acc[r] = 0; } // column 0: i*gapPen
+        int best[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) best[r] = 4095; // score 0: only a positive score replaces it (currMax starts at 0)
+        int diag0 = GSW == 1 ? 0 : row0 * kp.g4; // V(row above, 0)
+        int v_out = 0, b_out = 0, sq_v = 0;
+        int qv, qb, nv = 0, nb = 0;
+        auto boundary = [&](int c, int &ov, int &ob) {
+            if (!MULTI || s == 0) ov = GSW == 1 ? 0 : c * kp.g4; // row 0: j*gapPen
+            else if (c >= 1 && c <= m_eff) ov = rowbuf[pl.rowbuf_off + c].x;
+            else ov = 0;
+            int b = 0;
+            if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            ob = b * (BST * 4);
+        };
+        if (MULTI && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        boundary(l + 1, qv, qb);
+
+        auto step = [&](const int t, auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_v = dpp_shr1(qv, v_out);
+            const int pb = dpp_shr1(qb, b_out);
+            qv = dpp_shl1(qv, qv);
+            qb = dpp_shl1(qb, qb);
+            const int j = t - l;
+            b_out = pb;
+            if (!CHECK || (j >= 1 && j <= m_eff)) {
+                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
+                int w[LW];
+#pragma unroll
+                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                int vd = diag0, vu = up_v;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int k = max3i(vd + w[r], val[r] + vGL, vu + vGU);
+                    acc[r] = alignbit2((unsigned)k, acc[r]);
+                    vd = val[r];
+                    val[r] = k & ~3;
+                    if (GSW == 1) val[r] = max(val[r], 0);
+                    if (GSW == 2) best[r] = max(best[r], (int)((unsigned)val[r] << 10) + (4095 - j));
+                    vu = val[r];
+                }
+                diag0 = up_v;
+                v_out = vu;
+            }
+            if (MULTI) sq_v = dpp_shl1(v_out, sq_v);
+        };
+
+        for (int t0 = 0; t0 < Tend; t0 += 16) {
+            boundary(t0 + 16 + l + 1, nv, nb);
+            if (t0 >= 16 && t0 + 16 <= m_min) {
+#pragma unroll 2
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+            }
+            qv = nv; qb = nb;
+            const int w = t0 >> 4;
+            if (gact && w < pl.words) {
+                const int miss = (t0 + 16 - l) - m_eff;
+                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+                if (t0 + 16 > m_min) {
+#pragma unroll
+                    for (int d = 0; d < R; d++) acc[d] >>= sh;
+                }
+                uint4 *dst = trace + pl.trace_off + ((int64_t)(s * pl.words + w) * QC) * G + l;
+                dst[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                dst[G] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+                dst[2 * G] = make_uint4(acc[8], acc[9], 0u, 0u);
+            }
+            if (store_row) {
+                const int c = t0 + l - 14;
+                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + c] = make_int2(sq_v, 0);
+            }
+        }
+        if (gact && m_eff >= 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = GSW == 2 ? best[r] : val[r];
+            const int t0f = ((m_eff + l - 1) >> 4) << 4, missf = t0f + 16 - l - m_eff;
+            unsigned dw = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) dw |= ((acc[r] >> (30 - 2 * missf)) & 3u) << (2 * r);
+            dcol[pl.dcol_off + s * G + l] = dw;
+        }
+        if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+} // namespace

@@ -1,0 +1,210 @@
+// fp_sweep.hip.h -- fast-path forward sweep (8 lanes x 19/20 rows per pair, rebased keys): the dominant kernel of the headline workload
+// Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).  See DESIGN.md section 4.
+#pragma once
+#include "gnx_common.hip.h"
+
+namespace {
+// ------------------------------------------------------------------------------------------------------
+// Fast-path forward sweep: 8 lanes x RR rows per pair, 8 pairs per wave64 (global affine, gapOpen <= 0, n <= 8*RR).
+// Same anti-diagonal wavefront as fill_affine_kernel, re-cut for the short-alpha shape:
+//  * REBASED keys.  Every cell quantity V(i,j) in {M, I, D, h} is carried as V' = V - e*(i+j).  The recurrences keep
+//    all their comparisons (each max compares candidates of the same cell, i.e. with the same offset) and become
+//        M'(i,j) = h'(i-1,j-1) + (s - 2e)    I'(i,j+1) = max(h'(i,j) + o, I'(i,j))    D'(i+1,j) = max(h'(i,j) + o, D'(i,j))
+//    (h-form, see fill_affine_kernel): both extensions cost nothing, both opens share h' + o, and every boundary
+//    (row 0, column 0) is a constant: per cell  add, max3, add, max, max  = 16 issue cycles instead of 20.
+//  * rows are RIGHT-ALIGNED: the pair's 8*RR slots end at row n, the first P = 8*RR - n slots are padding that reproduces
+//    row 0 (profile entry -32768 so M never wins; I' = h' = o, D' = 2o are fixed points of the recurrences when o <= 0).
+//    So rows n .. n-3 (whose I-planes are kept, FP_PLANES) are always the last four slots of the last lane: one kernel
+//    for every n, pairs of different length mix freely, and only 4 of RR rows per lane pay the tag arithmetic.
+//  * two pairs per 16-lane DPP row, the second one mirrored (lane 15 is its first lane), so that "value of the previous
+//    lane of my pair" is row_shr:1 on banks 0-1 plus row_shl:1 on banks 2-3 and the lanes without a source keep the
+//    boundary constant passed as `old`.
+//  * int16 score profile (4*(s-2e)) read as 5 ds_read_b64 per step: an LDS read costs the issuing SIMD ~2 cycles + 2 per
+//    returned dword (tools/lds_ubench.hip), so 20 rows cost 30 cycles for 8 pairs instead of 60 for 4.
+// Outputs (what fp_walk_kernel and the window re-fills of fill_affine_kernel<.., WIN> consume): un-rebased, tagged column
+// checkpoints {rt = I(i,j+1), X = h(i,j)+e} of every row every CKW columns, the I-plane words of rows n..n-3
+// (word = step >> 4, field = step & 15 with step = j + 7), and h(n,m).
+// ------------------------------------------------------------------------------------------------------
+constexpr int G8 = 8;
+constexpr int FP8_BST = 96;                // dwords per base plane (>= 8 lanes * 10 dwords, multiple of 32)
+constexpr int FP8_PST = 5 * FP8_BST + 16;  // dwords per pair: == 16 (mod 32), the two pairs of a 16-lane group hit disjoint banks
+constexpr int FP8_LW = 10;                 // dwords per lane per base (20 int16 entries)
+
+// lanes 0-7 of a DPP row: from lane-1; lanes 8-15 (mirrored pair): from lane+1; the first lane of each pair keeps oldv
+__device__ __forceinline__ int dpp_prev8(int oldv, int src) {
+    const int v = __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHR1, 0xf, 0x3, false);
+    return __builtin_amdgcn_update_dpp(v, src, DPP_ROW_SHL1, 0xf, 0xc, false);
+}
+// the opposite direction (queue rotation towards the first lane of the pair)
+__device__ __forceinline__ int dpp_next8(int oldv, int src) {
+    const int v = __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHL1, 0xf, 0x3, false);
+    return __builtin_amdgcn_update_dpp(v, src, DPP_ROW_SHR1, 0xf, 0xc, false);
+}
+
+// 2 waves per SIMD by choice: capping the kernel at 168 VGPRs for a third wave makes the compiler shuffle registers in the
+// unrolled loop and costs 20 % (measured: 32.2 ms vs 38.6-40.6 ms per 100 k pairs); 16 000 B of LDS allow 10 waves per CU.
+template <int RR>
+__global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                      KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
+                                                      unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err) {
+    static_assert(RR <= 2 * FP8_LW && RR > FP_PLANES, "rows per lane");
+    __shared__ int lds[32 + 8 * FP8_PST];
+    const int lane = threadIdx.x;
+    const int g = lane >> 3;
+    const int lp = (lane & 8) ? 15 - (lane & 15) : (lane & 7); // position of the lane inside its pair
+    const int E4 = kp.e4;
+    if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * E4;
+    else if (lane < 32) lds[lane] = -32768; // padding rows: the diagonal candidate never wins
+    int *prof = &lds[32 + g * FP8_PST];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + lp * FP8_LW);
+
+    const int pbase = blockIdx.x * 8;
+    int m_max = 0, m_min = 0x7fffffff;
+    for (int q = 0; q < 8; q++) {
+        const int mq = (pbase + q < n_pairs) ? plans[pbase + q].m : 0;
+        m_max = max(m_max, mq); m_min = min(m_min, mq);
+    }
+    const int p = pbase + g;
+    const bool valid = p < n_pairs;
+    PairPlan pl;
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
+    const uint8_t *ap = a_buf + (valid ? a_start[pl.src] : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[pl.src] : 0);
+    const int m_eff = valid ? pl.m : 0;
+    const int P = G8 * RR - pl.n; // padding slots above row 1
+    const int q0 = lp * RR;       // first slot of this lane; slot q holds row q - P + 1
+    int bad = 0;
+    int vO4, cH, cDN; // constants pinned in VGPRs (2-cycle adds, DPP `old` operands)
+    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vO4), "=v"(cH), "=v"(cDN) : "s"(kp.o4), "s"(kp.o4 + 2), "s"(2 * kp.o4 + 2));
+
+    { // int16 profile of this lane's rows: prof[b][lp][r] = 4*(scores[alpha[row]][b] - 2e), padding -32768
+        int a5[2 * FP8_LW];
+#pragma unroll
+        for (int r = 0; r < 2 * FP8_LW; r++) {
+            int a = 5; // padding
+            const int q = q0 + r;
+            if (r < RR && q >= P) { a = ap[q - P]; if (a >= 5) { bad = 1; a = 4; } }
+            a5[r] = a * 5;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+#pragma unroll
+            for (int k = 0; k < FP8_LW; k++) prof[b * FP8_BST + lp * FP8_LW + k] = (lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16);
+        }
+        __syncthreads();
+    }
+    int rt[RR], hold[RR];
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
+        const int q = q0 + r;
+        // column 0: real row i: h'(i,0) = D'(i,0) = o (tag 1), I'(i,1) = 2o (from D); padding: h' = I' = o; the slot above row 1 is h(0,0) = 0 (tag 3)
+        hold[r] = (q >= P) ? kp.o4 + 1 : (q == P - 1 ? 3 : kp.o4 + 2);
+        rt[r] = (q >= P) ? 2 * kp.o4 + 1 : kp.o4 + 2;
+    }
+    unsigned accR[FP_PLANES] = {0u, 0u, 0u, 0u}; // I-planes of rows n-d = slots RR-1-d of the last lane
+    unsigned tailw = 0; // argmax tags of h(n-d, m-x), d, x = 0..3, field 4x + d: lets the walk take its first diagonal steps without a window
+    int diag0 = (q0 == 0) ? (P == 0 ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + 1 : (q0 - 1 == P - 1 ? 3 : kp.o4 + 2));
+    int dn_out = 0, h_out = 0, b_out = 0;
+    auto base_of = [&](int c) { // LDS byte offset of the profile plane of beta[c] (column c, 1-based)
+        int b = 0;
+        if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
+        return b * (FP8_BST * 4);
+    };
+    int qb = base_of(lp), nb = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
+
+    auto step = [&](const int t, auto chk, auto ckt) {
+        constexpr bool CHECK = decltype(chk)::value;
+        constexpr bool CKPT = decltype(ckt)::value; // this half block crosses a checkpoint column
+        const int up_dn = dpp_prev8(cDN, dn_out);
+        const int up_h = dpp_prev8(cH, h_out);
+        const int pb = dpp_prev8(qb, b_out);
+        qb = dpp_next8(qb, qb);
+        const int j = t - lp;
+        b_out = pb;
+        if (!CHECK || (j >= 1 && j <= m_eff)) {
+            const int2 *pw = reinterpret_cast<const int2 *>(prof_lane + pb);
+            int w[FP8_LW];
+#pragma unroll
+            for (int k = 0; k < FP8_LW / 2; k++) { const int2 v = pw[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+            int hd = diag0, dnu = up_dn;
+#pragma unroll
+            for (int r = 0; r < RR; r++) {
+                const int S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
+                if (r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
+                int hnew, dnn;
+                if (r < RR - FP_PLANES) { // tag bits are junk < 4 here; they never change the value of a max
+                    const int M = hd + S4;
+                    hnew = max3i(M, rt[r], dnu);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, rt[r]);
+                    dnn = max(ho, dnu);
+                } else {
+                    const int M3 = (hd | 3) + S4;
+                    const int I2 = (rt[r] & ~3) | 2;
+                    const int D1 = (dnu & ~3) | 1;
+                    hnew = max3i(M3, I2, D1);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, I2);
+                    dnn = max(ho, D1);
+                }
+                hd = hold[r];
+                hold[r] = hnew;
+                dnu = dnn;
+            }
+            diag0 = up_h;
+            dn_out = dnu;
+            h_out = hold[RR - 1];
+            if (CHECK && j + 3 >= m_eff) { // the last four columns (always in a CHECK half block)
+#pragma unroll
+                for (int d = 0; d < FP_PLANES; d++) tailw |= (unsigned)(hold[RR - 1 - d] & 3) << (8 * (m_eff - j) + 2 * d);
+            }
+            if (CKPT && (j & (CKW - 1)) == 0 && j < m_eff && valid) { // column checkpoint, un-rebased values {I(i,j+1), h(i,j)+e} (tag bits junk)
+                int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n;
+#pragma unroll
+                for (int r = 0; r < RR; r++) {
+                    const int i = q0 + r - P + 1;
+                    const int off = E4 * (i + j + 1);
+                    if (i >= 1) ck[i - 1] = make_int2(rt[r] + off, hold[r] + off);
+                }
+            }
+        }
+    };
+
+    // half blocks of 8 steps t0 .. t0+7 (step t: lane lp is at column t - lp); a plane word is two half blocks
+    const int Tend = ((m_max + G8 - 1) / 16 + 1) * 16;
+    for (int t0 = 0; t0 < Tend; t0 += 8) {
+        nb = base_of(t0 + 8 + lp); // prefetch the next half block's bases
+        const bool ckblk = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
+        const bool steady = t0 >= 8 && t0 + 7 <= m_min;
+        if (steady && !ckblk) {
+#pragma unroll 2
+            for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, std::false_type{});
+        } else if (steady) {
+#pragma unroll 1
+            for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, std::true_type{});
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < 8; u++) step(t0 + u, std::true_type{}, std::true_type{});
+        }
+        qb = nb;
+        if ((t0 & 8) && lp == G8 - 1 && valid) { // the last lane owns rows n..n-3: flush the plane word of steps t0-8 .. t0+7
+            const int w = t0 >> 4;
+            if (w < pl.words) {
+                const int miss = (t0 + 7) - (m_eff + G8 - 1); // steps this lane sat idle after its last column
+                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+#pragma unroll
+                for (int d = 0; d < FP_PLANES; d++) {
+                    accR[d] >>= sh;
+                    if (pl.n - d >= 1) rowi[pl.rowi_off + (int64_t)d * pl.words + w] = accR[d];
+                }
+            }
+        }
+    }
+    if (lp == G8 - 1 && valid && m_eff >= 1) { hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); tail[pl.hcol_off] = tailw; } // h(n, m)
+    if (bad) atomicOr(err, 1);
+}
+
+} // namespace

@@ -1,0 +1,211 @@
+// fp_walk.hip.h -- fast-path staged traceback: plane following, window requests, straggler tiles, compaction
+// Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).  See DESIGN.md section 4.
+#pragma once
+#include "traceback.hip.h"
+
+namespace {
+// ------------------------------------------------------------------------------------------------------
+// Fast path (alpha fits one strip, global affine, gapOpen <= 0): traceback by stages.
+//   fp_walk: one lane per pair.  On row n in state I it follows the stored I-plane of row n (the long trailing
+//   gap of a short read against a long chunk) a word at a time; anywhere else it needs full direction bits and
+//   requests a re-fill of the <= FP_SPAN+CKW-1 columns left of the current cell from the nearest column
+//   checkpoint (window plan appended to a list), which fill_affine_kernel<.., WIN> computes with the normal
+//   recording; the next fp_walk call continues inside that window.  Row 0 / column 0 end the walk (Step 4).
+//   CIGAR runs are staged per pair in traceback order and reversed into place by fp_compact.
+// Same checkerboard-walk emulation (Q1/Q2) as traceback_kernel.
+// ------------------------------------------------------------------------------------------------------
+struct FpState {
+    int32_t i, j, k, last_op;
+    int32_t cur_op, cnt, status, slot; // status 0 = needs a window, 1 = done; slot = window slot of the last request
+    int64_t cur_run;
+    int64_t li;
+    int32_t j_hi, jc_lo;
+};
+
+template <bool FIRST, bool TILED = false>
+__global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
+                                                     FpState *__restrict__ states, const int *__restrict__ hcol_fwd,
+                                                     const unsigned *__restrict__ rowi, const unsigned *__restrict__ tail,
+                                                     const PairPlan *__restrict__ wplans, const uint4 *__restrict__ wtrace,
+                                                     const int *__restrict__ whcol, TbParams tp, gnx_cigar *__restrict__ stage,
+                                                     int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                     int *__restrict__ next_active, int *__restrict__ next_count,
+                                                     PairPlan *__restrict__ next_wplans, int *__restrict__ err, int p_base) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_active) return;
+    const int p = FIRST ? a + p_base : active[a];
+    const PairPlan pl = plans[p];
+    FpState st;
+    PairPlan wp;
+    if (FIRST) {
+        const int hc = hcol_fwd[pl.hcol_off];
+        score_out[p] = (int64_t)(hc >> 2);
+        st.i = pl.n; st.j = pl.m; st.k = 3 - (hc & 3); st.last_op = -1;
+        st.cur_op = -1; st.cnt = 0; st.status = 0; st.slot = -1; st.cur_run = 0;
+        st.li = (int64_t)(pl.n - 1) % tp.ci;
+        st.j_hi = 0; st.jc_lo = 0; // empty window
+        wp = pl;
+    } else {
+        st = states[p];
+        wp = wplans[TILED ? 0 : a];
+        if (TILED) { st.j_hi = 0; st.jc_lo = 0; }
+    }
+    // TILED: `a` indexes the straggler; its tiles c = 0.. are the plans [a*tiles_per + c] (tiles_per in wplans[0].rowi_off)
+    const int tiles_per = TILED ? (int)wplans[0].rowi_off : 0;
+    int i = st.i, j = st.j, k = st.k, last_op = st.last_op, cur_op = st.cur_op, cnt = st.cnt;
+    int64_t cur_run = st.cur_run, li = st.li;
+    gnx_cigar *stg = stage + (int64_t)p * FP_CAP;
+    auto flush_run = [&]() {
+        if (cur_op >= 0) {
+            if (cnt < FP_CAP) { gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op; for (int z = 0; z < 7; z++) c._pad[z] = 0; stg[cnt] = c; }
+            cnt++;
+        }
+    };
+    auto emit = [&](int op, int64_t run) {
+        if (op == cur_op) cur_run += run;
+        else { flush_run(); cur_op = op; cur_run = run; }
+    };
+    bool done = false;
+    // A re-fill that starts from a column checkpoint reproduces every VALUE, but the checkpoint carries no argmax tags
+    // (the sweep computes them only on its plane rows), so the M- and I-plane fields of the re-fill's first column are
+    // not usable: the walk uses a window / tile from its second column on (all of it when it starts at column 0).
+    auto lo_ok = [](int jc_lo) { return jc_lo + (jc_lo > 0 ? 2 : 1); };
+    // argmax tag of h(ii, jj) kept by the sweep for the 4 x 4 cells at the bottom right corner
+    const unsigned tailw = tail[pl.hcol_off];
+    auto tail_ok = [&](int ii, int jj) { return ii >= 1 && jj >= 1 && pl.n - ii < FP_PLANES && pl.m - jj < 4; };
+    auto tail_tag = [&](int ii, int jj) { return (tailw >> (8 * (pl.m - jj) + 2 * (pl.n - ii))) & 3u; };
+    while (true) {
+        if (i == 0 || j == 0) { done = true; break; }
+        unsigned w;
+        int pos;
+        const bool on_plane = (k == 1) && (pl.n - i) < FP_PLANES;
+        if (on_plane) { // stored I-plane of row n-d
+            const int t1 = j + G8 - 1; // step at which the owner lane (the pair's last) was at column j
+            w = rowi[pl.rowi_off + (int64_t)(pl.n - i) * pl.words + (t1 >> 4)];
+            pos = t1 & 15;
+        } else if (j >= lo_ok(st.jc_lo) && j <= st.j_hi) { // inside the usable part of the current window
+            w = load_word<true>(wtrace, wp, k, i, j - st.jc_lo, pos);
+        } else if (k == 0 && tail_ok(i - 1, j - 1)) { // trM(i,j) = argmax of h(i-1,j-1): a diagonal step in the corner needs no window
+            w = tail_tag(i - 1, j - 1); pos = 0;
+        } else if (TILED) { // switch to the tile holding column j (all tiles of a straggler are filled)
+            const int c = (j - 1) / FP_TILE;
+            wp = wplans[(int64_t)a * tiles_per + c];
+            st.jc_lo = wp.col_off; st.j_hi = st.jc_lo + wp.m; // tile c starts one checkpoint before column c*FP_TILE
+            if (j > st.j_hi || j < lo_ok(st.jc_lo)) { atomicOr(err, 2); done = true; break; }
+            continue;
+        } else break; // needs a (new) window
+        int tag = (int)((w >> (2 * pos)) & 3u);
+        if (tag == 0) { atomicOr(err, 2); done = true; break; }
+        if (k == 1) {
+            int avail = min(pos + 1, j);
+            if (!on_plane) avail = min(avail, j - lo_ok(st.jc_lo) + 1); // do not run past the window's usable left edge
+            unsigned x = w ^ 0xAAAAAAAAu;
+            if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
+            const int lowcut = pos + 1 - avail;
+            if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+            int steps;
+            if (x == 0) steps = avail;
+            else {
+                const int pnz = (31 - __clz((int)x)) >> 1;
+                tag = (int)((w >> (2 * pnz)) & 3u);
+                if (tag == 0) { atomicOr(err, 2); done = true; break; }
+                steps = pos - pnz + 1;
+                k = 3 - tag;
+            }
+            emit(1, steps); j -= steps; last_op = 1;
+            if (on_plane && x == 0 && steps == pos + 1) {
+                // the run continues below field 0 of this word: take whole 16-column words while they are all-I, four loads in
+                // flight (a 10 kb trailing gap is 600 dependent loads otherwise).  Only on the stored planes, where the lanes of
+                // a wave are in this state together; inside windows / tiles the extra control flow costs more than it saves.
+                const unsigned *wbase = rowi + pl.rowi_off + (int64_t)(pl.n - i) * pl.words;
+                int wi = ((j + steps + G8 - 1) >> 4) - 1;
+                bool more = true;
+                while (more && wi >= 0 && j >= 16) {
+                    unsigned q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) q[u] = (wi - u >= 0) ? wbase[wi - u] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (more && q[u] == 0xAAAAAAAAu && j >= 16) { emit(1, 16); j -= 16; wi--; }
+                        else more = false;
+                    }
+                }
+            }
+            continue;
+        }
+        emit(k, 1);
+        last_op = k;
+        bool up_exit = false;
+        if (k != 1) { up_exit = (li == 0); li = up_exit ? tp.ci - 1 : li - 1; i--; }
+        if (k != 2) j--;
+        k = 3 - tag;
+        if (up_exit && i > 0 && j > 0) { // quirk Q1: restart in the argmax state of the entry cell (i, j)
+            int ht;
+            if (tail_ok(i, j)) ht = (int)tail_tag(i, j);
+            else if (j <= st.jc_lo) { atomicOr(err, 2); done = true; break; } // cannot happen: column jc_lo + 1 is never walked
+            else if (j < st.j_hi) { int p2; ht = (int)((load_word<true>(wtrace, wp, 0, i + 1, j + 1 - st.jc_lo, p2) >> (2 * p2)) & 3u); }
+            else ht = whcol[wp.hcol_off + i - 1] & 3;
+            k = 3 - ht;
+        }
+    }
+    if (done) {
+        // Step 4 (affineGap.go:135-139)
+        const bool up_exit = (last_op != 1) && ((int64_t)i % tp.ci == 0);
+        const bool left_exit = (last_op != 2) && ((int64_t)j % tp.cj == 0);
+        if (!up_exit && left_exit) emit(2, i);
+        else if (up_exit && !left_exit) emit(1, j);
+        flush_run();
+        cur_op = -1;
+        nops[p] = cnt;
+        if (cnt > FP_CAP) atomicOr(err, 8);
+        st.status = 1;
+    } else {
+        // request the window (jc_lo, j] : at least FP_SPAN wide, starting on a checkpoint column (or column 0)
+        const int slot = atomicAdd(next_count, 1);
+        int jc = j - FP_SPAN;
+        jc = jc <= 0 ? 0 : (jc / CKW) * CKW;
+        st.j_hi = j; st.jc_lo = jc; st.slot = slot; st.status = 0;
+        next_active[slot] = p;
+        PairPlan q;
+        q.n = pl.n; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = 1;
+        q.trace_off = (int64_t)slot * FP_WWORDS * QA * G; q.hcol_off = (int64_t)slot * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)slot * G;
+        q.src = pl.src; q.col_off = jc; q.ckpt_off = pl.ckpt_off; q.rowi_off = 0;
+        next_wplans[slot] = q;
+    }
+    st.i = i; st.j = j; st.k = k; st.last_op = last_op; st.cur_op = cur_op; st.cnt = cnt; st.cur_run = cur_run; st.li = li;
+    states[p] = st;
+}
+
+// stragglers (the path keeps needing windows, e.g. a long gap on a row without a stored plane): every remaining
+// column of such a pair is re-filled as independent FP_TILE-column tiles from the column checkpoints -- one launch,
+// a tile deep instead of a matrix deep -- and fp_walk_kernel<false, true> finishes the walk through them.
+__global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
+                                                                  int tiles_per, const FpState *__restrict__ states, PairPlan *__restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n_active * tiles_per) return;
+    const int a = x / tiles_per, c = x - a * tiles_per;
+    const int p = active[a];
+    const PairPlan pl = plans[p];
+    const int j_cur = states[p].j;
+    PairPlan q = pl;
+    const int lo = c * FP_TILE, lo2 = max(0, lo - CKW); // start one checkpoint early: the first re-filled column has no usable tags
+    q.m = (j_cur > lo) ? min(FP_TILE, j_cur - lo) + (lo - lo2) : 0;
+    q.words = (q.m + 15 + 15) / 16; q.strips = q.m > 0 ? 1 : 0;
+    q.trace_off = (int64_t)x * FP_TWORDS * QA * G; q.hcol_off = (int64_t)x * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)x * G;
+    q.src = pl.src; q.col_off = lo2;
+    q.rowi_off = (x == 0) ? tiles_per : 0; // plan 0 carries tiles_per for the walk kernel
+    out[x] = q;
+}
+
+__global__ __launch_bounds__(256) void fp_compact_kernel(int n_pairs, const FpState *__restrict__ states, const gnx_cigar *__restrict__ stage, const int64_t *__restrict__ nops,
+                                                          const int64_t *__restrict__ ops_off, gnx_cigar *__restrict__ ops, int64_t ops_capacity,
+                                                          int *__restrict__ err) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int64_t cnt = nops[p], base = ops_off[p];
+    if (base + cnt > ops_capacity) { atomicOr(err, 4); return; }
+    const int64_t m = cnt < FP_CAP ? cnt : FP_CAP;
+    for (int64_t x = 0; x < m; x++) ops[base + (cnt - 1 - x)] = stage[(int64_t)p * FP_CAP + x];
+}
+
+} // namespace

@@ -21,1185 +21,22 @@
 //     dropped leading gap on a corner exit) from global coordinates, run-length encodes, two passes
 //     (count, exclusive scan, write) so CIGARs are emitted densely in input order.
 //   * No MFMA: this is an integer max-plus recurrence.  No CPU fallback: every entry point needs the GPU.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <mutex>
-#include <vector>
-#include <algorithm>
-#include <type_traits>
-#include "gnx_align.h"
+//
+// Source layout (one translation unit):
+//   gnx_common.hip.h   constants, PairPlan / KParams, helpers
+//   fill_affine.hip.h  fill_affine_kernel        fp_sweep.hip.h   fp_sweep_kernel (dominant kernel of the headline workload)
+//   fill_const.hip.h   fill_const_kernel (+GSW)   traceback.hip.h  traceback_kernel, gsw_traceback_kernel
+//   fp_walk.hip.h      fp_walk_kernel & co        aux_kernels.hip.h score_matrix / scale_runs / scan kernels
+//   gnx_align.hip      host orchestration + C ABI (this file)
+#include "gnx_common.hip.h"
+#include "fill_affine.hip.h"
+#include "fp_sweep.hip.h"
+#include "fill_const.hip.h"
+#include "traceback.hip.h"
+#include "fp_walk.hip.h"
+#include "aux_kernels.hip.h"
 
 namespace {
-
-constexpr int G = 16;            // lanes per pair (one DPP row)
-constexpr int R = 10;            // DP rows per lane
-constexpr int H = G * R;         // rows per strip
-constexpr int NEG4 = -(1 << 30); // scaled "veryNegNum" (align/align.go:8); finite keys stay above -(1<<29)
-constexpr int QA = 8;            // uint4 stores per lane per flush, affine (3*R=30 dwords -> 32)
-constexpr int QC = 3;            // const gap (R=10 dwords -> 12)
-
-#define DPP_ROW_SHR1 0x111
-#define DPP_ROW_SHL1 0x101
-
-struct PairPlan {
-    int32_t n, m;
-    int32_t words;      // 16-column direction words per strip
-    int32_t strips;     // ceil(n / H)
-    int64_t trace_off;  // in uint4 units, relative to the chunk's trace buffer
-    int64_t hcol_off;   // ints
-    int64_t rowbuf_off; // int2
-    int64_t dcol_off;   // dwords: per strip and lane one word with the last-column direction fields of the lane's R rows
-    // fast path (short alpha) / window re-fill:
-    int32_t src;        // index of the pair in the a_start / b_start tables (== own index except for window plans)
-    int32_t col_off;    // first column of a window re-fill minus one (0 = whole matrix); multiple of CKW
-    int64_t ckpt_off;   // int2: column checkpoints of the pair, [c-1][row] for column c*CKW
-    int64_t rowi_off;   // dwords: I-plane of row n (one word per 16 steps of the owner lane)
-    int64_t s_off;      // SCORED kernels: explicit 4*score matrix of the pair, column-major: S[s_off + (j-1)*s_pitch + (i-1)]
-    int64_t s_pitch;
-};
-
-constexpr int CKW = 128;     // column checkpoint spacing of the fast path
-constexpr int FP_SPAN = 192; // a re-fill window is at least this wide (>= 160 rows + typical indels)
-constexpr int FP_PLANES = 4; // rows n .. n-3 keep their I-plane: a trailing gap sits on row n-d when the last d bases match the chunk end
-constexpr int FP_CAP = 64;   // CIGAR runs staged per pair on the fast path (more -> general path)
-constexpr int FP_WWORDS = (FP_SPAN + CKW + 15 + 15) / 16 + 1; // direction words of the widest window
-constexpr int FP_TILE = 1024;                                  // straggler tiles: columns (c*FP_TILE, (c+1)*FP_TILE]
-constexpr int FP_TWORDS = (FP_TILE + CKW + 15 + 15) / 16;      // direction words of a tile (plus the checkpoint interval it starts early)
-
-struct KParams {
-    int sc4[25]; // 4*scores
-    int oe4, e4, o4;
-    int d00_4;   // 4*D(0,0): gapOpen, or 0 with free end gaps
-    int ecol4;   // 4*(column-0 extension): gapExtend, or 0 with free end gaps
-    int g4;      // const gap: 4*gapPen
-};
-
-__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
-__device__ __forceinline__ int dpp_shr1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHR1, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_shl1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHL1, 0xf, 0xf, false); }
-__device__ __forceinline__ unsigned alignbit2(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 2); }
-
-// ------------------------------------------------------------------------------------------------------
-// Affine fill.
-//   LOCAL = free end gaps (AffineGapLocal, affineGap_highMem.go:188-210)
-//   MULTI = some pair of the launch has more than one 160-row strip (row buffer hand-over code compiled in)
-//   P16   = 4*score fits int16: the per-row score profile is stored as packed int16 pairs in LDS
-//   HFORM = gapOpen <= 0 (every caller): with h = max3(M,I,D) the recurrences collapse to
-//           rt = max(h+oe, I+e), dn = max(h+oe, D+e) with identical values AND identical argmax tags
-//           (oe <= e makes the dropped candidate I+oe / D+oe never a strict winner; ties keep M > I > D).
-//           gfx950 issues v_max_i32/v_max3_i32/v_and_or/v_alignbit/DPP/SDWA and any VALU op with an SGPR
-//           operand at 4 cycles per wave64 but VGPR/immediate add/or at 2 (tools/valu_ubench*.hip), so the
-//           penalties are kept in VGPRs and the h-form trades 2 max3 + 2 adds for 2 max.
-// LDS (dwords): [0,32) 4*score table; then per pair g a profile  prof[b][lane][LW]  (b-stride BST, pair stride
-// PST).  BST = 0 and PST = 16 (mod 32) make the 32 lanes of a ds_read_b32 group hit 32 distinct banks whatever
-// bases they look up (lane stride 5 or 10 dwords is odd/2*odd -> a permutation within a pair, +16 for the
-// second pair of the group fills the complement).
-// ------------------------------------------------------------------------------------------------------
-template <bool P16> struct ProfCfg {
-    static constexpr int LW = P16 ? R / 2 : R;       // dwords per lane per base
-    static constexpr int BST = P16 ? 96 : 160;       // dwords per base (>= 16*LW, multiple of 32)
-    static constexpr int PST = 5 * BST + 16;         // dwords per pair
-};
-
-template <bool LOCAL, bool MULTI, bool P16, bool HFORM, bool WIN = false, bool SCORED = false>
-__global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restrict__ plans, int n_pairs,
-                                                         const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
-                                                         const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                                         KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
-                                                         int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, const int2 *__restrict__ ckpt,
-                                                         int *__restrict__ err, const int *__restrict__ smat = nullptr) {
-    // SCORED: the substitution score of a cell comes from an explicit per-pair matrix in HBM (chunk / multiple-alignment
-    //      variants, "next" row N1) instead of the LDS profile of alpha x the base of the column; sequences are not read.
-    // WIN: window / tile re-fill of the fast path: the left boundary comes from a column checkpoint written by
-    //      fp_sweep_kernel (pl.col_off > 0), the row-0 boundary and the beta window start at column col_off.
-    using PC = ProfCfg<P16>;
-    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
-    __shared__ int lds[32 + 4 * PST];
-    const int lane = threadIdx.x;
-    const int g = lane >> 4, l = lane & 15;
-    if (lane < 25) lds[lane] = kp.sc4[lane];
-    int *prof = &lds[32 + g * PST];
-    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
-
-    const int pbase = blockIdx.x * 4;
-    int S_max = 0, m_max = 0;
-    for (int q = 0; q < 4; q++) {
-        if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
-    }
-    const int p = pbase + g;
-    const bool valid = p < n_pairs;
-    PairPlan pl;
-    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
-    const uint8_t *ap = SCORED ? nullptr : a_buf + (valid ? a_start[pl.src] : 0);
-    const uint8_t *bp = SCORED ? nullptr : b_buf + (valid ? b_start[pl.src] + (WIN ? pl.col_off : 0) : 0);
-    const int Tend = (m_max + 15 + 15) & ~15;
-    const int OE4 = kp.oe4, E4 = kp.e4;
-    // h-form carries X = h + e instead of h (XE = e): then I+e and D+e are one 2-cycle `and` + one 2-cycle add
-    // each and no separate retag is needed; (X|3) + s == M + e because e is a multiple of 4.
-    const int XE = HFORM ? kp.e4 : 0;
-    int vOE4, vE4, vO4, vE4p2, vE4p1; // constants pinned in VGPRs (2-cycle adds)
-    asm volatile("v_mov_b32 %0, %5\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %7\n\tv_mov_b32 %3, %8\n\tv_mov_b32 %4, %9"
-                 : "=v"(vOE4), "=v"(vE4), "=v"(vO4), "=v"(vE4p2), "=v"(vE4p1)
-                 : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4), "s"(kp.e4 + 2), "s"(kp.e4 + 1));
-    int bad = 0;
-
-    for (int s = 0; s < S_max; s++) {
-        const bool gact = valid && s < pl.strips;
-        const int m_eff = gact ? pl.m : 0;
-        int m_min = 0x7fffffff; // over the 4 pairs of the wave, this strip (wave-uniform)
-        for (int q = 0; q < 4; q++) m_min = min(m_min, (pbase + q < n_pairs && s < plans[pbase + q].strips) ? plans[pbase + q].m : 0);
-        const bool store_row = MULTI && gact && (s + 1 < pl.strips);
-        const int row0 = s * H + l * R; // 0-based index of this lane's first row == 1-based index of the row above it
-        int rt[R], hold[R];
-        unsigned acc[3 * R]; // direction accumulators: [0,R) M, [R,2R) I, [2R,3R) D
-        if (!SCORED) { // score profile of this lane's rows: prof[b][lane][k]
-            int a5[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int i0 = row0 + r;
-                int a = 0;
-                if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
-                a5[r] = a * 5;
-            }
-            __syncthreads(); // table visible; previous strip's profile no longer read
-#pragma unroll
-            for (int b = 0; b < 5; b++) {
-#pragma unroll
-                for (int k = 0; k < LW; k++) {
-                    int v;
-                    if (P16) v = (lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16);
-                    else v = lds[a5[k] + b];
-                    prof[b * BST + l * LW + k] = v;
-                }
-            }
-            __syncthreads();
-        }
-        const int2 *ck0 = nullptr; // window re-fill: left boundary = column checkpoint col_off / CKW
-        if (WIN && pl.col_off > 0) ck0 = ckpt + pl.ckpt_off + (int64_t)(pl.col_off / CKW - 1) * pl.n;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int i = row0 + r + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
-            const int D1c = kp.d00_4 + i * kp.ecol4 + 1;
-            hold[r] = max3i(NEG4 + 3, NEG4 + 2, D1c) + XE;
-            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + 2 + E4, D1c + OE4);
-            if (WIN && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x; hold[r] = v.y; }
-            acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
-        }
-        int diag0 = ((row0 == 0) ? max3i(3, kp.o4 + 2, kp.d00_4 + 1) : max3i(NEG4 + 3, NEG4 + 2, kp.d00_4 + row0 * kp.ecol4 + 1)) + XE;
-        if (WIN && ck0) {
-            if (row0 == 0) diag0 = max3i(NEG4 + 3, kp.o4 + pl.col_off * E4 + 2, NEG4 + 1) + XE; // h(0, col_off)
-            else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y;
-        }
-        int dn_out = 0, h_out = 0, b_out = 0;
-        int sq_dn = 0, sq_h = 0;
-        // boundary queues (row above the strip + beta): lane u holds column t0+u+1 of the current 16-step block
-        int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
-        auto boundary = [&](int c, int &odn, int &oh, int &ob) {
-            if (!MULTI || s == 0) {
-                const int M3 = NEG4 + 3, I2 = kp.o4 + ((WIN ? pl.col_off : 0) + c) * E4 + 2, D1 = NEG4 + 1; // row 0: I(0,c) = gapOpen + c*gapExtend
-                const int h0 = max3i(M3, I2, D1);
-                odn = (LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4);
-                oh = h0 + XE;
-            } else if (c >= 1 && c <= m_eff) {
-                const int2 v = rowbuf[pl.rowbuf_off + c];
-                odn = v.x; oh = v.y; // already in the X domain
-            } else { odn = 0; oh = 0; }
-            int b = 0;
-            if (!SCORED && c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
-            ob = b * (BST * 4); // LDS byte offset of the base's profile plane
-        };
-        if (MULTI && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        boundary(l + 1, qdn, qh, qb);
-
-        // one anti-diagonal step; CHECK=false is the steady state (every lane of the wave has a live column)
-        auto step = [&](const int t, auto chk) {
-            constexpr bool CHECK = decltype(chk)::value;
-            const int up_dn = dpp_shr1(qdn, dn_out);
-            const int up_h = dpp_shr1(qh, h_out);
-            const int pb = dpp_shr1(qb, b_out);
-            qdn = dpp_shl1(qdn, qdn);
-            qh = dpp_shl1(qh, qh);
-            qb = dpp_shl1(qb, qb);
-            const int j = t - l;
-            b_out = pb;
-            if (!CHECK || (j >= 1 && j <= m_eff)) {
-                const int *pw = SCORED ? smat + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0
-                                       : reinterpret_cast<const int *>(prof_lane + pb);
-                int w[LW];
-#pragma unroll
-                for (int k = 0; k < LW; k++) w[k] = pw[k];
-                int hd = diag0, dnu = up_dn;
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    int S4;
-                    if (P16) S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
-                    else S4 = w[r];
-                    acc[r] = alignbit2((unsigned)hd, acc[r]);
-                    acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
-                    acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
-                    int hnew, dnn; // hnew is in the X domain (h + XE)
-                    if (HFORM) {
-                        const int M3e = (hd | 3) + S4;             // M + e
-                        const int Ie = (rt[r] & ~3) + vE4p2;       // I + e, tag 2
-                        const int De = (dnu & ~3) + vE4p1;         // D + e, tag 1
-                        hnew = max3i(M3e, Ie, De);                 // h + e
-                        const int hoe = hnew + vO4;                // h + oe
-                        rt[r] = max(hoe, Ie);
-                        dnn = max(hoe, De);
-                        if (LOCAL) dnn = (j == m_eff) ? hnew - vE4 : dnn; // last column: D(i+1,m) = tmt(M,I,D)(i,m), no penalty
-                    } else {
-                        const int M3 = (hd | 3) + S4;
-                        const int I2 = (rt[r] & ~3) | 2;
-                        const int D1 = (dnu & ~3) | 1;
-                        hnew = max3i(M3, I2, D1);
-                        const int Moe = M3 + vOE4;
-                        rt[r] = max3i(Moe, I2 + vE4, D1 + vOE4);
-                        dnn = max3i(Moe, I2 + vOE4, D1 + vE4);
-                        if (LOCAL) dnn = (j == m_eff) ? hnew : dnn;
-                    }
-                    hd = hold[r];
-                    hold[r] = hnew;
-                    dnu = dnn;
-                }
-                diag0 = up_h;
-                dn_out = dnu;
-                h_out = hold[R - 1];
-            }
-            if (MULTI) { sq_dn = dpp_shl1(dn_out, sq_dn); sq_h = dpp_shl1(h_out, sq_h); }
-        };
-
-        for (int t0 = 0; t0 < Tend; t0 += 16) {
-            boundary(t0 + 16 + l + 1, ndn, nh, nb); // prefetch the next block's boundary
-            const bool steady = t0 >= 16 && t0 + 16 <= m_min;
-            if (steady) {
-#pragma unroll 2
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
-            } else {
-#pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
-            }
-            qdn = ndn; qh = nh; qb = nb;
-            // flush 16 steps of direction bits: word w of this strip
-            const int w = t0 >> 4;
-            if (gact && w < pl.words) {
-                const int miss = (t0 + 16 - l) - m_eff; // steps this lane sat idle after its last column
-                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
-                if (t0 + 16 > m_min) { // drain: a lane that finished early right-aligns its last fields (it never shifts again)
-#pragma unroll
-                    for (int d = 0; d < 3 * R; d++) acc[d] >>= sh;
-                }
-                uint4 *dst = trace + pl.trace_off + ((int64_t)(s * pl.words + w) * QA) * G + l;
-#pragma unroll
-                for (int q = 0; q < QA - 1; q++) dst[q * G] = make_uint4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-                dst[(QA - 1) * G] = make_uint4(acc[4 * (QA - 1)], acc[4 * (QA - 1) + 1], 0u, 0u);
-            }
-            if (store_row) {
-                const int c = t0 + l - 14;
-                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + c] = make_int2(sq_dn, sq_h);
-            }
-        }
-        if (gact && m_eff >= 1) {
-#pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r] - XE;
-            // last-column D-plane fields of this lane's rows, packed (field r at bits 2r): lets the traceback skip
-            // vertical runs in column m (free end gaps of AffineGapLocal, trailing gaps when alpha is the long one)
-            const int t0f = ((m_eff + l - 1) >> 4) << 4, missf = t0f + 16 - l - m_eff; // 0..15: in-place drain shift
-            unsigned dw = 0;
-#pragma unroll
-            for (int r = 0; r < R; r++) dw |= ((acc[2 * R + r] >> (30 - 2 * missf)) & 3u) << (2 * r);
-            dcol[pl.dcol_off + s * G + l] = dw;
-        }
-        if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    }
-    if (bad) atomicOr(err, 1);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Fast-path forward sweep: 8 lanes x RR rows per pair, 8 pairs per wave64 (global affine, gapOpen <= 0, n <= 8*RR).
-// Same anti-diagonal wavefront as fill_affine_kernel, re-cut for the short-alpha shape:
-//  * REBASED keys.  Every cell quantity V(i,j) in {M, I, D, h} is carried as V' = V - e*(i+j).  The recurrences keep
-//    all their comparisons (each max compares candidates of the same cell, i.e. with the same offset) and become
-//        M'(i,j) = h'(i-1,j-1) + (s - 2e)    I'(i,j+1) = max(h'(i,j) + o, I'(i,j))    D'(i+1,j) = max(h'(i,j) + o, D'(i,j))
-//    (h-form, see fill_affine_kernel): both extensions cost nothing, both opens share h' + o, and every boundary
-//    (row 0, column 0) is a constant: per cell  add, max3, add, max, max  = 16 issue cycles instead of 20.
-//  * rows are RIGHT-ALIGNED: the pair's 8*RR slots end at row n, the first P = 8*RR - n slots are padding that reproduces
-//    row 0 (profile entry -32768 so M never wins; I' = h' = o, D' = 2o are fixed points of the recurrences when o <= 0).
-//    So rows n .. n-3 (whose I-planes are kept, FP_PLANES) are always the last four slots of the last lane: one kernel
-//    for every n, pairs of different length mix freely, and only 4 of RR rows per lane pay the tag arithmetic.
-//  * two pairs per 16-lane DPP row, the second one mirrored (lane 15 is its first lane), so that "value of the previous
-//    lane of my pair" is row_shr:1 on banks 0-1 plus row_shl:1 on banks 2-3 and the lanes without a source keep the
-//    boundary constant passed as `old`.
-//  * int16 score profile (4*(s-2e)) read as 5 ds_read_b64 per step: an LDS read costs the issuing SIMD ~2 cycles + 2 per
-//    returned dword (tools/lds_ubench.hip), so 20 rows cost 30 cycles for 8 pairs instead of 60 for 4.
-// Outputs (what fp_walk_kernel and the window re-fills of fill_affine_kernel<.., WIN> consume): un-rebased, tagged column
-// checkpoints {rt = I(i,j+1), X = h(i,j)+e} of every row every CKW columns, the I-plane words of rows n..n-3
-// (word = step >> 4, field = step & 15 with step = j + 7), and h(n,m).
-// ------------------------------------------------------------------------------------------------------
-constexpr int G8 = 8;
-constexpr int FP8_BST = 96;                // dwords per base plane (>= 8 lanes * 10 dwords, multiple of 32)
-constexpr int FP8_PST = 5 * FP8_BST + 16;  // dwords per pair: == 16 (mod 32), the two pairs of a 16-lane group hit disjoint banks
-constexpr int FP8_LW = 10;                 // dwords per lane per base (20 int16 entries)
-
-// lanes 0-7 of a DPP row: from lane-1; lanes 8-15 (mirrored pair): from lane+1; the first lane of each pair keeps oldv
-__device__ __forceinline__ int dpp_prev8(int oldv, int src) {
-    const int v = __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHR1, 0xf, 0x3, false);
-    return __builtin_amdgcn_update_dpp(v, src, DPP_ROW_SHL1, 0xf, 0xc, false);
-}
-// the opposite direction (queue rotation towards the first lane of the pair)
-__device__ __forceinline__ int dpp_next8(int oldv, int src) {
-    const int v = __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHL1, 0xf, 0x3, false);
-    return __builtin_amdgcn_update_dpp(v, src, DPP_ROW_SHR1, 0xf, 0xc, false);
-}
-
-// 2 waves per SIMD by choice: capping the kernel at 168 VGPRs for a third wave makes the compiler shuffle registers in the
-// unrolled loop and costs 20 % (measured: 32.2 ms vs 38.6-40.6 ms per 100 k pairs); 16 000 B of LDS allow 10 waves per CU.
-template <int RR>
-__global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
-                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
-                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                                      KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
-                                                      unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err) {
-    static_assert(RR <= 2 * FP8_LW && RR > FP_PLANES, "rows per lane");
-    __shared__ int lds[32 + 8 * FP8_PST];
-    const int lane = threadIdx.x;
-    const int g = lane >> 3;
-    const int lp = (lane & 8) ? 15 - (lane & 15) : (lane & 7); // position of the lane inside its pair
-    const int E4 = kp.e4;
-    if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * E4;
-    else if (lane < 32) lds[lane] = -32768; // padding rows: the diagonal candidate never wins
-    int *prof = &lds[32 + g * FP8_PST];
-    const char *prof_lane = reinterpret_cast<const char *>(prof + lp * FP8_LW);
-
-    const int pbase = blockIdx.x * 8;
-    int m_max = 0, m_min = 0x7fffffff;
-    for (int q = 0; q < 8; q++) {
-        const int mq = (pbase + q < n_pairs) ? plans[pbase + q].m : 0;
-        m_max = max(m_max, mq); m_min = min(m_min, mq);
-    }
-    const int p = pbase + g;
-    const bool valid = p < n_pairs;
-    PairPlan pl;
-    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
-    const uint8_t *ap = a_buf + (valid ? a_start[pl.src] : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[pl.src] : 0);
-    const int m_eff = valid ? pl.m : 0;
-    const int P = G8 * RR - pl.n; // padding slots above row 1
-    const int q0 = lp * RR;       // first slot of this lane; slot q holds row q - P + 1
-    int bad = 0;
-    int vO4, cH, cDN; // constants pinned in VGPRs (2-cycle adds, DPP `old` operands)
-    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vO4), "=v"(cH), "=v"(cDN) : "s"(kp.o4), "s"(kp.o4 + 2), "s"(2 * kp.o4 + 2));
-
-    { // int16 profile of this lane's rows: prof[b][lp][r] = 4*(scores[alpha[row]][b] - 2e), padding -32768
-        int a5[2 * FP8_LW];
-#pragma unroll
-        for (int r = 0; r < 2 * FP8_LW; r++) {
-            int a = 5; // padding
-            const int q = q0 + r;
-            if (r < RR && q >= P) { a = ap[q - P]; if (a >= 5) { bad = 1; a = 4; } }
-            a5[r] = a * 5;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < 5; b++) {
-#pragma unroll
-            for (int k = 0; k < FP8_LW; k++) prof[b * FP8_BST + lp * FP8_LW + k] = (lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16);
-        }
-        __syncthreads();
-    }
-    int rt[RR], hold[RR];
-#pragma unroll
-    for (int r = 0; r < RR; r++) {
-        const int q = q0 + r;
-        // column 0: real row i: h'(i,0) = D'(i,0) = o (tag 1), I'(i,1) = 2o (from D); padding: h' = I' = o; the slot above row 1 is h(0,0) = 0 (tag 3)
-        hold[r] = (q >= P) ? kp.o4 + 1 : (q == P - 1 ? 3 : kp.o4 + 2);
-        rt[r] = (q >= P) ? 2 * kp.o4 + 1 : kp.o4 + 2;
-    }
-    unsigned accR[FP_PLANES] = {0u, 0u, 0u, 0u}; // I-planes of rows n-d = slots RR-1-d of the last lane
-    unsigned tailw = 0; // argmax tags of h(n-d, m-x), d, x = 0..3, field 4x + d: lets the walk take its first diagonal steps without a window
-    int diag0 = (q0 == 0) ? (P == 0 ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + 1 : (q0 - 1 == P - 1 ? 3 : kp.o4 + 2));
-    int dn_out = 0, h_out = 0, b_out = 0;
-    auto base_of = [&](int c) { // LDS byte offset of the profile plane of beta[c] (column c, 1-based)
-        int b = 0;
-        if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
-        return b * (FP8_BST * 4);
-    };
-    int qb = base_of(lp), nb = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
-
-    auto step = [&](const int t, auto chk, auto ckt) {
-        constexpr bool CHECK = decltype(chk)::value;
-        constexpr bool CKPT = decltype(ckt)::value; // this half block crosses a checkpoint column
-        const int up_dn = dpp_prev8(cDN, dn_out);
-        const int up_h = dpp_prev8(cH, h_out);
-        const int pb = dpp_prev8(qb, b_out);
-        qb = dpp_next8(qb, qb);
-        const int j = t - lp;
-        b_out = pb;
-        if (!CHECK || (j >= 1 && j <= m_eff)) {
-            const int2 *pw = reinterpret_cast<const int2 *>(prof_lane + pb);
-            int w[FP8_LW];
-#pragma unroll
-            for (int k = 0; k < FP8_LW / 2; k++) { const int2 v = pw[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
-            int hd = diag0, dnu = up_dn;
-#pragma unroll
-            for (int r = 0; r < RR; r++) {
-                const int S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
-                if (r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
-                int hnew, dnn;
-                if (r < RR - FP_PLANES) { // tag bits are junk < 4 here; they never change the value of a max
-                    const int M = hd + S4;
-                    hnew = max3i(M, rt[r], dnu);
-                    const int ho = hnew + vO4;
-                    rt[r] = max(ho, rt[r]);
-                    dnn = max(ho, dnu);
-                } else {
-                    const int M3 = (hd | 3) + S4;
-                    const int I2 = (rt[r] & ~3) | 2;
-                    const int D1 = (dnu & ~3) | 1;
-                    hnew = max3i(M3, I2, D1);
-                    const int ho = hnew + vO4;
-                    rt[r] = max(ho, I2);
-                    dnn = max(ho, D1);
-                }
-                hd = hold[r];
-                hold[r] = hnew;
-                dnu = dnn;
-            }
-            diag0 = up_h;
-            dn_out = dnu;
-            h_out = hold[RR - 1];
-            if (CHECK && j + 3 >= m_eff) { // the last four columns (always in a CHECK half block)
-#pragma unroll
-                for (int d = 0; d < FP_PLANES; d++) tailw |= (unsigned)(hold[RR - 1 - d] & 3) << (8 * (m_eff - j) + 2 * d);
-            }
-            if (CKPT && (j & (CKW - 1)) == 0 && j < m_eff && valid) { // column checkpoint, un-rebased values {I(i,j+1), h(i,j)+e} (tag bits junk)
-                int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n;
-#pragma unroll
-                for (int r = 0; r < RR; r++) {
-                    const int i = q0 + r - P + 1;
-                    const int off = E4 * (i + j + 1);
-                    if (i >= 1) ck[i - 1] = make_int2(rt[r] + off, hold[r] + off);
-                }
-            }
-        }
-    };
-
-    // half blocks of 8 steps t0 .. t0+7 (step t: lane lp is at column t - lp); a plane word is two half blocks
-    const int Tend = ((m_max + G8 - 1) / 16 + 1) * 16;
-    for (int t0 = 0; t0 < Tend; t0 += 8) {
-        nb = base_of(t0 + 8 + lp); // prefetch the next half block's bases
-        const bool ckblk = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
-        const bool steady = t0 >= 8 && t0 + 7 <= m_min;
-        if (steady && !ckblk) {
-#pragma unroll 2
-            for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, std::false_type{});
-        } else if (steady) {
-#pragma unroll 1
-            for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, std::true_type{});
-        } else {
-#pragma unroll 1
-            for (int u = 0; u < 8; u++) step(t0 + u, std::true_type{}, std::true_type{});
-        }
-        qb = nb;
-        if ((t0 & 8) && lp == G8 - 1 && valid) { // the last lane owns rows n..n-3: flush the plane word of steps t0-8 .. t0+7
-            const int w = t0 >> 4;
-            if (w < pl.words) {
-                const int miss = (t0 + 7) - (m_eff + G8 - 1); // steps this lane sat idle after its last column
-                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
-#pragma unroll
-                for (int d = 0; d < FP_PLANES; d++) {
-                    accR[d] >>= sh;
-                    if (pl.n - d >= 1) rowi[pl.rowi_off + (int64_t)d * pl.words + w] = accR[d];
-                }
-            }
-        }
-    }
-    if (lp == G8 - 1 && valid && m_eff >= 1) { hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); tail[pl.hcol_off] = tailw; } // h(n, m)
-    if (bad) atomicOr(err, 1);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Constant-gap fill (align/constGap.go:146-157 recurrence), same wavefront mapping as the affine kernel.
-// Keys: diag+s -> tag 3, left+g -> tag 2, up+g -> tag 1; the stored value is the clean (tag-free) key, so the three
-// candidates are three 2-cycle VGPR adds (the profile holds 4*s+3, the penalties 4*g+2 / 4*g+1 live in VGPRs),
-// one v_max3, one v_and and one v_alignbit per cell.
-// ------------------------------------------------------------------------------------------------------
-// GSW (the seed-extension DP of the graph aligner, "next" row N2, /root/reference/genomeGraph/search.go:234-321):
-//   1 = LeftDynamicAln: zero borders, cell values clamped at 0 (the trace keeps its direction);
-//   2 = RightDynamicAln: the ordinary borders plus, per row, the running maximum of (score << 12 | 4095 - column), i.e. the first
-//       column of the row's best score; hcol receives that key instead of the last-column value.
-template <bool MULTI, int GSW = 0>
-__global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restrict__ plans, int n_pairs,
-                                                        const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
-                                                        const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                                        KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
-                                                        int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int *__restrict__ err) {
-    using PC = ProfCfg<false>;
-    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
-    __shared__ int lds[32 + 4 * PST];
-    const int lane = threadIdx.x;
-    const int g = lane >> 4, l = lane & 15;
-    if (lane < 25) lds[lane] = kp.sc4[lane] + 3; // pre-tagged diagonal candidate
-    int *prof = &lds[32 + g * PST];
-    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
-    const int pbase = blockIdx.x * 4;
-    int S_max = 0, m_max = 0;
-    for (int q = 0; q < 4; q++) {
-        if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
-    }
-    const int p = pbase + g;
-    const bool valid = p < n_pairs;
-    PairPlan pl;
-    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
-    const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
-    const int Tend = (m_max + 15 + 15) & ~15;
-    int vGL, vGU;
-    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vGL), "=v"(vGU) : "s"(kp.g4 + 2), "s"(kp.g4 + 1));
-    int bad = 0;
-
-    for (int s = 0; s < S_max; s++) {
-        const bool gact = valid && s < pl.strips;
-        const int m_eff = gact ? pl.m : 0;
-        int m_min = 0x7fffffff;
-        for (int q = 0; q < 4; q++) m_min = min(m_min, (pbase + q < n_pairs && s < plans[pbase + q].strips) ? plans[pbase + q].m : 0);
-        const bool store_row = MULTI && gact && (s + 1 < pl.strips);
-        const int row0 = s * H + l * R;
-        int val[R];
-        unsigned acc[R];
-        {
-            int a5[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int i0 = row0 + r;
-                int a = 0;
-                if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
-                a5[r] = a * 5;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < 5; b++) {
-#pragma unroll
-                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = lds[a5[k] + b];
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) { val[r] = GSW == 1 ? 0 : (row0 + r + 1) * kp.g4; acc[r] = 0; } // column 0: i*gapPen
-        int best[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) best[r] = 4095; // score 0: only a positive score replaces it (currMax starts at 0)
-        int diag0 = GSW == 1 ? 0 : row0 * kp.g4; // V(row above, 0)
-        int v_out = 0, b_out = 0, sq_v = 0;
-        int qv, qb, nv = 0, nb = 0;
-        auto boundary = [&](int c, int &ov, int &ob) {
-            if (!MULTI || s == 0) ov = GSW == 1 ? 0 : c * kp.g4; // row 0: j*gapPen
-            else if (c >= 1 && c <= m_eff) ov = rowbuf[pl.rowbuf_off + c].x;
-            else ov = 0;
-            int b = 0;
-            if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
-            ob = b * (BST * 4);
-        };
-        if (MULTI && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        boundary(l + 1, qv, qb);
-
-        auto step = [&](const int t, auto chk) {
-            constexpr bool CHECK = decltype(chk)::value;
-            const int up_v = dpp_shr1(qv, v_out);
-            const int pb = dpp_shr1(qb, b_out);
-            qv = dpp_shl1(qv, qv);
-            qb = dpp_shl1(qb, qb);
-            const int j = t - l;
-            b_out = pb;
-            if (!CHECK || (j >= 1 && j <= m_eff)) {
-                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
-                int w[LW];
-#pragma unroll
-                for (int k = 0; k < LW; k++) w[k] = pw[k];
-                int vd = diag0, vu = up_v;
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int k = max3i(vd + w[r], val[r] + vGL, vu + vGU);
-                    acc[r] = alignbit2((unsigned)k, acc[r]);
-                    vd = val[r];
-                    val[r] = k & ~3;
-                    if (GSW == 1) val[r] = max(val[r], 0);
-                    if (GSW == 2) best[r] = max(best[r], (int)((unsigned)val[r] << 10) + (4095 - j));
-                    vu = val[r];
-                }
-                diag0 = up_v;
-                v_out = vu;
-            }
-            if (MULTI) sq_v = dpp_shl1(v_out, sq_v);
-        };
-
-        for (int t0 = 0; t0 < Tend; t0 += 16) {
-            boundary(t0 + 16 + l + 1, nv, nb);
-            if (t0 >= 16 && t0 + 16 <= m_min) {
-#pragma unroll 2
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
-            } else {
-#pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
-            }
-            qv = nv; qb = nb;
-            const int w = t0 >> 4;
-            if (gact && w < pl.words) {
-                const int miss = (t0 + 16 - l) - m_eff;
-                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
-                if (t0 + 16 > m_min) {
-#pragma unroll
-                    for (int d = 0; d < R; d++) acc[d] >>= sh;
-                }
-                uint4 *dst = trace + pl.trace_off + ((int64_t)(s * pl.words + w) * QC) * G + l;
-                dst[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-                dst[G] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
-                dst[2 * G] = make_uint4(acc[8], acc[9], 0u, 0u);
-            }
-            if (store_row) {
-                const int c = t0 + l - 14;
-                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + c] = make_int2(sq_v, 0);
-            }
-        }
-        if (gact && m_eff >= 1) {
-#pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = GSW == 2 ? best[r] : val[r];
-            const int t0f = ((m_eff + l - 1) >> 4) << 4, missf = t0f + 16 - l - m_eff;
-            unsigned dw = 0;
-#pragma unroll
-            for (int r = 0; r < R; r++) dw |= ((acc[r] >> (30 - 2 * missf)) & 3u) << (2 * r);
-            dcol[pl.dcol_off + s * G + l] = dw;
-        }
-        if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    }
-    if (bad) atomicOr(err, 1);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Traceback.  One lane per pair.  WRITE=false counts CIGAR runs, WRITE=true emits them (reversed into
-// alignment order) at ops[ops_off[p] ..).  ci/cj = checkerboard sizes (huge for the highMem modes).
-// ------------------------------------------------------------------------------------------------------
-struct TbParams {
-    int64_t ci, cj;
-    int64_t d00, ecol, gap_open, gap_extend; // unscaled, for the empty-sequence closed forms
-    int affine;
-};
-
-// direction word of cell (i,j) (1-based) for plane k (affine: 0/1/2 = M/I/D; const: 0) and the field position
-// of the cell inside it -- see the flush layout in the fill kernels.  Fields of lower columns sit at lower positions.
-template <bool AFFINE>
-__device__ __forceinline__ unsigned load_word(const uint4 *trace, const PairPlan &pl, int k, int i, int j, int &pos) {
-    const int i0 = i - 1;
-    const int s = i0 / H, rem = i0 - s * H;
-    const int l = rem / R, r = rem - l * R;
-    const int t1 = j + l - 1;
-    const int w = t1 >> 4;
-    pos = t1 & 15;
-    const int d = AFFINE ? k * R + r : r;
-    const int Q = AFFINE ? QA : QC;
-    const unsigned *base = reinterpret_cast<const unsigned *>(trace + pl.trace_off + ((int64_t)(s * pl.words + w) * Q + (d >> 2)) * G + l);
-    return base[d & 3];
-}
-
-template <bool AFFINE, bool WRITE>
-__global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restrict__ plans, int n_pairs, const uint4 *__restrict__ trace,
-                                                       const int *__restrict__ hcol, const unsigned *__restrict__ dcol, TbParams tp,
-                                                       int64_t *__restrict__ score_out,
-                                                       int64_t *__restrict__ nops, const int64_t *__restrict__ ops_off,
-                                                       gnx_cigar *__restrict__ ops, int64_t ops_capacity, int *__restrict__ err) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const PairPlan pl = plans[p];
-    int i = pl.n, j = pl.m;
-    int64_t score;
-    int k;
-    if (i > 0 && j > 0) {
-        const int hc = hcol[pl.hcol_off + pl.n - 1];
-        score = (int64_t)(hc >> 2);
-        if (AFFINE) k = 3 - (hc & 3);
-        else k = 0;
-    } else { // highMem modes with an empty sequence: closed forms of row 0 / column 0
-        if (AFFINE) {
-            if (i == 0 && j == 0) { // tmt(0, gapOpen, D00)
-                const int64_t a = 0, b = tp.gap_open, c = tp.d00;
-                if (a >= b && a >= c) { score = a; k = 0; } else if (b >= c) { score = b; k = 1; } else { score = c; k = 2; }
-            } else if (i == 0) { score = tp.gap_open + (int64_t)j * tp.gap_extend; k = 1; }
-            else { score = tp.d00 + (int64_t)i * tp.ecol; k = 2; }
-        } else { score = (int64_t)(i + j) * tp.gap_open; k = 0; }
-    }
-    const int po = pl.src; // output slot (== p except for sub-batches routed here by the fast path)
-    if (!WRITE) score_out[po] = score;
-
-    int64_t cnt = 0;           // runs emitted so far (traceback order)
-    int cur_op = -1;
-    int64_t cur_run = 0;
-    const int64_t total = WRITE ? nops[po] : 0;
-    const int64_t obase = WRITE ? ops_off[po] : 0;
-    const bool fits = WRITE ? (obase + total <= ops_capacity) : false;
-    auto flush_run = [&]() {
-        if (cur_op >= 0) {
-            if (WRITE && fits) {
-                gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op;
-                for (int z = 0; z < 7; z++) c._pad[z] = 0;
-                ops[obase + (total - 1 - cnt)] = c;
-            }
-            cnt++;
-        }
-    };
-    auto emit = [&](int op, int64_t run) {
-        if (op == cur_op) cur_run += run;
-        else { flush_run(); cur_op = op; cur_run = run; }
-    };
-
-    // The checkerboard walk in global coordinates.  A tile is left through its top edge when the new row index
-    // is a multiple of checkersize_i, through its left edge when the new column index is a multiple of
-    // checkersize_j (affineGap.go:121-127).
-    int64_t li = (i > 0) ? (int64_t)(i - 1) % tp.ci : 0; // tile-local row of the current cell
-    int last_op = -1;
-    const bool walked = (i > 0 && j > 0);
-    while (i > 0 && j > 0) {
-        if (j == pl.m && (!AFFINE || k == 2)) {
-            // Vertical run in the last column: the packed per-lane word holds the fields of R consecutive rows.
-            const int i0 = i - 1, sl = i0 / R, r = i0 - sl * R; // sl = strip*16 + lane
-            const unsigned w = dcol[pl.dcol_off + sl];
-            int tag = (int)((w >> (2 * r)) & 3u);
-            if (tag == 0) { atomicOr(err, 2); break; }
-            if (AFFINE || tag == 1) {
-                int avail = min(r + 1, i);
-                if (li + 1 < (int64_t)avail) avail = (int)(li + 1); // do not run past the tile's top edge (quirk Q1 applies there)
-                unsigned x = w ^ 0x55555555u;                        // fields "from D" (tag 1) become 0
-                if (r < 15) x &= (1u << (2 * r + 2)) - 1u;
-                const int lowcut = r + 1 - avail;
-                if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
-                int steps;
-                bool cont = false; // the walk is still in a D cell after the run
-                if (x == 0) { steps = avail; cont = true; }
-                else {
-                    const int rnz = (31 - __clz((int)x)) >> 1;
-                    tag = (int)((w >> (2 * rnz)) & 3u);
-                    if (tag == 0) { atomicOr(err, 2); break; }
-                    if (AFFINE) steps = r - rnz + 1; else { steps = r - rnz; cont = true; }
-                }
-                if (steps > 0) {
-                    emit(2, steps); i -= steps; last_op = 2;
-                    li -= steps;
-                    const bool up_exit = li < 0;
-                    if (up_exit) li += tp.ci;
-                    if (AFFINE) {
-                        k = cont ? 2 : 3 - tag;
-                        if (up_exit && i > 0) k = 3 - (hcol[pl.hcol_off + i - 1] & 3); // quirk Q1, entry cell (i, m)
-                    }
-                    continue;
-                }
-            }
-        }
-        int pos;
-        const unsigned w = load_word<AFFINE>(trace, pl, AFFINE ? k : 0, i, j, pos);
-        int tag = (int)((w >> (2 * pos)) & 3u);
-        const int op = AFFINE ? k : 3 - tag;
-        if (tag == 0) { atomicOr(err, 2); break; } // impossible direction: the Go code would log.Fatalf
-        if (op == 1) {
-            // Horizontal run: every cell visited in state I emits one I and moves left; the walk stays in this word
-            // while the fields read "came from I" (tag 2).  Count them with one xor + clz instead of 16 iterations.
-            const int avail = min(pos + 1, j);            // fields of columns >= 1 at positions pos .. pos-avail+1
-            unsigned x = w ^ 0xAAAAAAAAu;
-            if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
-            const int lowcut = pos + 1 - avail;
-            if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
-            int steps;
-            if (x == 0) { steps = avail; if (AFFINE) k = 1; }
-            else {
-                const int pnz = (31 - __clz((int)x)) >> 1;  // highest field that is not "from I"
-                tag = (int)((w >> (2 * pnz)) & 3u);
-                if (tag == 0) { atomicOr(err, 2); break; }
-                if (AFFINE) { steps = pos - pnz + 1; k = 3 - tag; } // that cell is still in state I; its source decides the next state
-                else steps = pos - pnz;                            // const gap: that cell is not an I cell
-            }
-            if (steps > 0) { emit(1, steps); j -= steps; last_op = 1; }
-            continue;
-        }
-        emit(op, 1);
-        last_op = op;
-        bool up_exit = false;
-        if (op != 1) { up_exit = (li == 0); li = up_exit ? tp.ci - 1 : li - 1; i--; }
-        if (op != 2) j--;
-        if (AFFINE) {
-            k = 3 - tag;
-            if (up_exit && i > 0 && j > 0) {
-                // quirk Q1 (affineGap.go:305): entering a tile from below restarts in the argmax state of the entry cell
-                int ht;
-                if (j < pl.m) { int p2; ht = (int)((load_word<true>(trace, pl, 0, i + 1, j + 1, p2) >> (2 * p2)) & 3u); }
-                else ht = hcol[pl.hcol_off + i - 1] & 3;
-                k = 3 - ht;
-            }
-        }
-    }
-    // Step 4 (affineGap.go:135-139 / constGap.go:59-63) and the highMem border walks
-    if (walked) {
-        const bool up_exit = (last_op != 1) && ((int64_t)i % tp.ci == 0);
-        const bool left_exit = (last_op != 2) && ((int64_t)j % tp.cj == 0);
-        if (!up_exit && left_exit) emit(2, i);
-        else if (up_exit && !left_exit) emit(1, j);
-        // both: corner exit -> nothing (quirk Q2 when it is not the origin)
-    } else { // empty sequence (highMem modes only)
-        if (i == 0 && j > 0) emit(1, j);
-        else if (j == 0 && i > 0) emit(2, i);
-        else { cur_op = 0; cur_run = 0; } // Go: route == [{0 0}]
-    }
-    flush_run();
-    if (!WRITE) nops[po] = cnt;
-    else if (!fits) atomicOr(err, 4);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Fast path (alpha fits one strip, global affine, gapOpen <= 0): traceback by stages.
-//   fp_walk: one lane per pair.  On row n in state I it follows the stored I-plane of row n (the long trailing
-//   gap of a short read against a long chunk) a word at a time; anywhere else it needs full direction bits and
-//   requests a re-fill of the <= FP_SPAN+CKW-1 columns left of the current cell from the nearest column
-//   checkpoint (window plan appended to a list), which fill_affine_kernel<.., WIN> computes with the normal
-//   recording; the next fp_walk call continues inside that window.  Row 0 / column 0 end the walk (Step 4).
-//   CIGAR runs are staged per pair in traceback order and reversed into place by fp_compact.
-// Same checkerboard-walk emulation (Q1/Q2) as traceback_kernel.
-// ------------------------------------------------------------------------------------------------------
-struct FpState {
-    int32_t i, j, k, last_op;
-    int32_t cur_op, cnt, status, slot; // status 0 = needs a window, 1 = done; slot = window slot of the last request
-    int64_t cur_run;
-    int64_t li;
-    int32_t j_hi, jc_lo;
-};
-
-template <bool FIRST, bool TILED = false>
-__global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
-                                                     FpState *__restrict__ states, const int *__restrict__ hcol_fwd,
-                                                     const unsigned *__restrict__ rowi, const unsigned *__restrict__ tail,
-                                                     const PairPlan *__restrict__ wplans, const uint4 *__restrict__ wtrace,
-                                                     const int *__restrict__ whcol, TbParams tp, gnx_cigar *__restrict__ stage,
-                                                     int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
-                                                     int *__restrict__ next_active, int *__restrict__ next_count,
-                                                     PairPlan *__restrict__ next_wplans, int *__restrict__ err, int p_base) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n_active) return;
-    const int p = FIRST ? a + p_base : active[a];
-    const PairPlan pl = plans[p];
-    FpState st;
-    PairPlan wp;
-    if (FIRST) {
-        const int hc = hcol_fwd[pl.hcol_off];
-        score_out[p] = (int64_t)(hc >> 2);
-        st.i = pl.n; st.j = pl.m; st.k = 3 - (hc & 3); st.last_op = -1;
-        st.cur_op = -1; st.cnt = 0; st.status = 0; st.slot = -1; st.cur_run = 0;
-        st.li = (int64_t)(pl.n - 1) % tp.ci;
-        st.j_hi = 0; st.jc_lo = 0; // empty window
-        wp = pl;
-    } else {
-        st = states[p];
-        wp = wplans[TILED ? 0 : a];
-        if (TILED) { st.j_hi = 0; st.jc_lo = 0; }
-    }
-    // TILED: `a` indexes the straggler; its tiles c = 0.. are the plans [a*tiles_per + c] (tiles_per in wplans[0].rowi_off)
-    const int tiles_per = TILED ? (int)wplans[0].rowi_off : 0;
-    int i = st.i, j = st.j, k = st.k, last_op = st.last_op, cur_op = st.cur_op, cnt = st.cnt;
-    int64_t cur_run = st.cur_run, li = st.li;
-    gnx_cigar *stg = stage + (int64_t)p * FP_CAP;
-    auto flush_run = [&]() {
-        if (cur_op >= 0) {
-            if (cnt < FP_CAP) { gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op; for (int z = 0; z < 7; z++) c._pad[z] = 0; stg[cnt] = c; }
-            cnt++;
-        }
-    };
-    auto emit = [&](int op, int64_t run) {
-        if (op == cur_op) cur_run += run;
-        else { flush_run(); cur_op = op; cur_run = run; }
-    };
-    bool done = false;
-    // A re-fill that starts from a column checkpoint reproduces every VALUE, but the checkpoint carries no argmax tags
-    // (the sweep computes them only on its plane rows), so the M- and I-plane fields of the re-fill's first column are
-    // not usable: the walk uses a window / tile from its second column on (all of it when it starts at column 0).
-    auto lo_ok = [](int jc_lo) { return jc_lo + (jc_lo > 0 ? 2 : 1); };
-    // argmax tag of h(ii, jj) kept by the sweep for the 4 x 4 cells at the bottom right corner
-    const unsigned tailw = tail[pl.hcol_off];
-    auto tail_ok = [&](int ii, int jj) { return ii >= 1 && jj >= 1 && pl.n - ii < FP_PLANES && pl.m - jj < 4; };
-    auto tail_tag = [&](int ii, int jj) { return (tailw >> (8 * (pl.m - jj) + 2 * (pl.n - ii))) & 3u; };
-    while (true) {
-        if (i == 0 || j == 0) { done = true; break; }
-        unsigned w;
-        int pos;
-        const bool on_plane = (k == 1) && (pl.n - i) < FP_PLANES;
-        if (on_plane) { // stored I-plane of row n-d
-            const int t1 = j + G8 - 1; // step at which the owner lane (the pair's last) was at column j
-            w = rowi[pl.rowi_off + (int64_t)(pl.n - i) * pl.words + (t1 >> 4)];
-            pos = t1 & 15;
-        } else if (j >= lo_ok(st.jc_lo) && j <= st.j_hi) { // inside the usable part of the current window
-            w = load_word<true>(wtrace, wp, k, i, j - st.jc_lo, pos);
-        } else if (k == 0 && tail_ok(i - 1, j - 1)) { // trM(i,j) = argmax of h(i-1,j-1): a diagonal step in the corner needs no window
-            w = tail_tag(i - 1, j - 1); pos = 0;
-        } else if (TILED) { // switch to the tile holding column j (all tiles of a straggler are filled)
-            const int c = (j - 1) / FP_TILE;
-            wp = wplans[(int64_t)a * tiles_per + c];
-            st.jc_lo = wp.col_off; st.j_hi = st.jc_lo + wp.m; // tile c starts one checkpoint before column c*FP_TILE
-            if (j > st.j_hi || j < lo_ok(st.jc_lo)) { atomicOr(err, 2); done = true; break; }
-            continue;
-        } else break; // needs a (new) window
-        int tag = (int)((w >> (2 * pos)) & 3u);
-        if (tag == 0) { atomicOr(err, 2); done = true; break; }
-        if (k == 1) {
-            int avail = min(pos + 1, j);
-            if (!on_plane) avail = min(avail, j - lo_ok(st.jc_lo) + 1); // do not run past the window's usable left edge
-            unsigned x = w ^ 0xAAAAAAAAu;
-            if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
-            const int lowcut = pos + 1 - avail;
-            if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
-            int steps;
-            if (x == 0) steps = avail;
-            else {
-                const int pnz = (31 - __clz((int)x)) >> 1;
-                tag = (int)((w >> (2 * pnz)) & 3u);
-                if (tag == 0) { atomicOr(err, 2); done = true; break; }
-                steps = pos - pnz + 1;
-                k = 3 - tag;
-            }
-            emit(1, steps); j -= steps; last_op = 1;
-            if (on_plane && x == 0 && steps == pos + 1) {
-                // the run continues below field 0 of this word: take whole 16-column words while they are all-I, four loads in
-                // flight (a 10 kb trailing gap is 600 dependent loads otherwise).  Only on the stored planes, where the lanes of
-                // a wave are in this state together; inside windows / tiles the extra control flow costs more than it saves.
-                const unsigned *wbase = rowi + pl.rowi_off + (int64_t)(pl.n - i) * pl.words;
-                int wi = ((j + steps + G8 - 1) >> 4) - 1;
-                bool more = true;
-                while (more && wi >= 0 && j >= 16) {
-                    unsigned q[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) q[u] = (wi - u >= 0) ? wbase[wi - u] : 0u;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (more && q[u] == 0xAAAAAAAAu && j >= 16) { emit(1, 16); j -= 16; wi--; }
-                        else more = false;
-                    }
-                }
-            }
-            continue;
-        }
-        emit(k, 1);
-        last_op = k;
-        bool up_exit = false;
-        if (k != 1) { up_exit = (li == 0); li = up_exit ? tp.ci - 1 : li - 1; i--; }
-        if (k != 2) j--;
-        k = 3 - tag;
-        if (up_exit && i > 0 && j > 0) { // quirk Q1: restart in the argmax state of the entry cell (i, j)
-            int ht;
-            if (tail_ok(i, j)) ht = (int)tail_tag(i, j);
-            else if (j <= st.jc_lo) { atomicOr(err, 2); done = true; break; } // cannot happen: column jc_lo + 1 is never walked
-            else if (j < st.j_hi) { int p2; ht = (int)((load_word<true>(wtrace, wp, 0, i + 1, j + 1 - st.jc_lo, p2) >> (2 * p2)) & 3u); }
-            else ht = whcol[wp.hcol_off + i - 1] & 3;
-            k = 3 - ht;
-        }
-    }
-    if (done) {
-        // Step 4 (affineGap.go:135-139)
-        const bool up_exit = (last_op != 1) && ((int64_t)i % tp.ci == 0);
-        const bool left_exit = (last_op != 2) && ((int64_t)j % tp.cj == 0);
-        if (!up_exit && left_exit) emit(2, i);
-        else if (up_exit && !left_exit) emit(1, j);
-        flush_run();
-        cur_op = -1;
-        nops[p] = cnt;
-        if (cnt > FP_CAP) atomicOr(err, 8);
-        st.status = 1;
-    } else {
-        // request the window (jc_lo, j] : at least FP_SPAN wide, starting on a checkpoint column (or column 0)
-        const int slot = atomicAdd(next_count, 1);
-        int jc = j - FP_SPAN;
-        jc = jc <= 0 ? 0 : (jc / CKW) * CKW;
-        st.j_hi = j; st.jc_lo = jc; st.slot = slot; st.status = 0;
-        next_active[slot] = p;
-        PairPlan q;
-        q.n = pl.n; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = 1;
-        q.trace_off = (int64_t)slot * FP_WWORDS * QA * G; q.hcol_off = (int64_t)slot * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)slot * G;
-        q.src = pl.src; q.col_off = jc; q.ckpt_off = pl.ckpt_off; q.rowi_off = 0;
-        next_wplans[slot] = q;
-    }
-    st.i = i; st.j = j; st.k = k; st.last_op = last_op; st.cur_op = cur_op; st.cnt = cnt; st.cur_run = cur_run; st.li = li;
-    states[p] = st;
-}
-
-// stragglers (the path keeps needing windows, e.g. a long gap on a row without a stored plane): every remaining
-// column of such a pair is re-filled as independent FP_TILE-column tiles from the column checkpoints -- one launch,
-// a tile deep instead of a matrix deep -- and fp_walk_kernel<false, true> finishes the walk through them.
-__global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
-                                                                  int tiles_per, const FpState *__restrict__ states, PairPlan *__restrict__ out) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= n_active * tiles_per) return;
-    const int a = x / tiles_per, c = x - a * tiles_per;
-    const int p = active[a];
-    const PairPlan pl = plans[p];
-    const int j_cur = states[p].j;
-    PairPlan q = pl;
-    const int lo = c * FP_TILE, lo2 = max(0, lo - CKW); // start one checkpoint early: the first re-filled column has no usable tags
-    q.m = (j_cur > lo) ? min(FP_TILE, j_cur - lo) + (lo - lo2) : 0;
-    q.words = (q.m + 15 + 15) / 16; q.strips = q.m > 0 ? 1 : 0;
-    q.trace_off = (int64_t)x * FP_TWORDS * QA * G; q.hcol_off = (int64_t)x * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)x * G;
-    q.src = pl.src; q.col_off = lo2;
-    q.rowi_off = (x == 0) ? tiles_per : 0; // plan 0 carries tiles_per for the walk kernel
-    out[x] = q;
-}
-
-__global__ __launch_bounds__(256) void fp_compact_kernel(int n_pairs, const FpState *__restrict__ states, const gnx_cigar *__restrict__ stage, const int64_t *__restrict__ nops,
-                                                          const int64_t *__restrict__ ops_off, gnx_cigar *__restrict__ ops, int64_t ops_capacity,
-                                                          int *__restrict__ err) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const int64_t cnt = nops[p], base = ops_off[p];
-    if (base + cnt > ops_capacity) { atomicOr(err, 4); return; }
-    const int64_t m = cnt < FP_CAP ? cnt : FP_CAP;
-    for (int64_t x = 0; x < m; x++) ops[base + (cnt - 1 - x)] = stage[(int64_t)p * FP_CAP + x];
-}
-
-// ------------------------------------------------------------------------------------------------------
-// N1: per-cell score matrices for the chunk / multiple-alignment variants, one thread per (chunk) cell, written
-// column-major as 4*score.  A "group" is an alignment block: nseq sequences of len bases, sequence-major.
-//   pairwise (AffineGapChunk):      cell = sum_k scores[a[i*c+k]][b[j*c+k]]                       (ungapped.go:7-13)
-//   groups (multipleAffineGap*):    cell = sum_k scoreColumnMatch(column i*c+k, column j*c+k)     (multiAlign.go:82-110)
-//     scoreColumnMatch = (sum over sequence pairs, lower case folded, gap columns skipped) / count, Go integer division
-// ------------------------------------------------------------------------------------------------------
-struct GroupDesc { int64_t off; int32_t nseq; int32_t len; };
-struct ScorePair { int64_t a_off, b_off; int32_t a_nseq, b_nseq, a_len, b_len; int32_t nc, mc; int64_t s_off, s_pitch; };
-
-__global__ __launch_bounds__(256) void score_matrix_kernel(const ScorePair *__restrict__ sp, const uint8_t *__restrict__ bases, KParams kp, int chunk,
-                                                           int groups, int *__restrict__ smat, int *__restrict__ err) {
-    const ScorePair q = sp[blockIdx.y];
-    const int64_t cells = (int64_t)q.nc * q.mc;
-    for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < cells; cell += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(cell % q.nc), j = (int)(cell / q.nc);
-        int64_t total = 0;
-        for (int k = 0; k < chunk; k++) {
-            const int64_t ac = (int64_t)i * chunk + k, bc = (int64_t)j * chunk + k;
-            if (!groups) {
-                const int a = bases[q.a_off + ac], b = bases[q.b_off + bc];
-                if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
-                total += kp.sc4[a * 5 + b] / 4;
-            } else {
-                int64_t sum = 0, count = 0;
-                for (int x = 0; x < q.a_nseq; x++) {
-                    int a = bases[q.a_off + (int64_t)x * q.a_len + ac];
-                    if (a >= 5 && a <= 9) a -= 5;
-                    for (int y = 0; y < q.b_nseq; y++) {
-                        int b = bases[q.b_off + (int64_t)y * q.b_len + bc];
-                        if (b >= 5 && b <= 9) b -= 5;
-                        if (a != 10 && b != 10) {
-                            if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
-                            sum += kp.sc4[a * 5 + b] / 4;
-                            count++;
-                        }
-                    }
-                }
-                if (count == 0) { atomicOr(err, 16); continue; } // Go: integer divide by zero
-                total += sum / count;
-            }
-        }
-        smat[q.s_off + (int64_t)j * q.s_pitch + i] = (int)(4 * total);
-    }
-}
-
-__global__ __launch_bounds__(256) void scale_runs_kernel(gnx_cigar *__restrict__ ops, int64_t total, int64_t factor) {
-    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x < total) ops[x].run_length *= factor; // expandCigarRunLength, affineGap_highMem.go:91-95
-}
-
-// exclusive scan of nops[0..n) + carry[0] -> off[0..n], off[n]; carry[0] = off[n] afterwards.  One block.
-__global__ __launch_bounds__(1024) void scan_kernel(const int64_t *__restrict__ nops, int n, int64_t *__restrict__ off, int64_t *__restrict__ carry) {
-    // exclusive scan of the run counts, 1024 elements per round: wave-level scans by __shfl_up, then the 16 wave totals
-    // (a one-pass version with a contiguous slice per thread measured slower: 227 us vs 139 us per 100 k elements)
-    __shared__ int64_t wsum[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t base = carry[0];
-    for (int start = 0; start < n; start += 1024) {
-        const int idx = start + threadIdx.x;
-        const int64_t v = idx < n ? nops[idx] : 0;
-        int64_t sum = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(sum, d, 64); if (lane >= d) sum += t; }
-        if (lane == 63) wsum[wave] = sum;
-        __syncthreads();
-        if (wave == 0) {
-            int64_t t = lane < 16 ? wsum[lane] : 0;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) { const int64_t u = __shfl_up(t, d, 64); if (lane >= d) t += u; }
-            if (lane < 16) wsum[lane] = t;
-        }
-        __syncthreads();
-        if (idx < n) off[idx] = base + (wave > 0 ? wsum[wave - 1] : 0) + sum - v;
-        base += wsum[15];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { off[n] = base; carry[0] = base; }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Traceback of the gsw seed-extension DPs (search.go:252-275, 298-320).  One lane per pair, runs in TRACEBACK order (the
-// reference appends them that way; its callers reverse).  Ops use the GNX_COL_* codes (M/I/D).
-//   LEFT : from (n, m) while the cell value is > 0.  Values are not stored: the walk rebuilds them from the final value
-//          (an unclamped cell is its predecessor plus the score of the move; a clamped cell is 0 and ends the walk).
-//   RIGHT: from the first row-major maximum (row scan of the keys the fill kernel left in hcol) back to (0, 0).
-// ------------------------------------------------------------------------------------------------------
-template <bool RIGHT, bool WRITE>
-__global__ __launch_bounds__(64) void gsw_traceback_kernel(const PairPlan *__restrict__ plans, int n_pairs, const uint4 *__restrict__ trace,
-                                                           const int *__restrict__ hcol,
-                                                           const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
-                                                           const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp,
-                                                           int64_t *__restrict__ score_out, int2 *__restrict__ endpos,
-                                                           int64_t *__restrict__ nops, const int64_t *__restrict__ ops_off,
-                                                           gnx_cigar *__restrict__ ops, int64_t ops_capacity, int *__restrict__ err) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const PairPlan pl = plans[p];
-    const uint8_t *ap = a_buf + a_start[p];
-    const uint8_t *bp = b_buf + b_start[p];
-    int i = pl.n, j = pl.m;
-    int cur = 0; // LEFT: value of the current cell
-    if (RIGHT) {
-        int bestv = 0, bi = 0, bj = 0;
-        if (pl.m >= 1) {
-            for (int r = 1; r <= pl.n; r++) {
-                const int key = hcol[pl.hcol_off + r - 1];
-                const int v = key >> 12;
-                if (v > bestv) { bestv = v; bi = r; bj = 4095 - (key & 4095); }
-            }
-        }
-        i = bi; j = bj;
-        if (!WRITE) { score_out[p] = bestv; endpos[p] = make_int2(bi, bj); }
-    } else {
-        if (pl.n >= 1 && pl.m >= 1) cur = hcol[pl.hcol_off + pl.n - 1] >> 2;
-        if (!WRITE) score_out[p] = cur;
-    }
-    const int64_t base = WRITE ? ops_off[p] : 0;
-    int64_t cnt = 0, run = 0;
-    int cur_op = -1;
-    auto emit = [&](int op, int64_t len) {
-        if (op == cur_op) { run += len; return; }
-        if (cur_op >= 0) {
-            if (WRITE) { if (base + cnt < ops_capacity) { gnx_cigar c; c.run_length = run; c.op = (uint8_t)cur_op; for (int z = 0; z < 7; z++) c._pad[z] = 0; ops[base + cnt] = c; } else atomicOr(err, 4); }
-            cnt++;
-        }
-        cur_op = op; run = len;
-    };
-    while (RIGHT ? (i > 0 || j > 0) : (cur > 0)) {
-        if (RIGHT && i == 0) { emit(GNX_COL_I, j); j = 0; break; } // trace[0][j] = 'I'
-        if (RIGHT && j == 0) { emit(GNX_COL_D, i); i = 0; break; } // trace[i][0] = 'D'
-        if (i < 1 || j < 1) { atomicOr(err, 2); break; }
-        int pos;
-        const unsigned w = load_word<false>(trace, pl, 0, i, j, pos);
-        const int tag = (int)((w >> (2 * pos)) & 3u);
-        if (tag == 3) { emit(GNX_COL_M, 1); if (!RIGHT) cur -= kp.sc4[min((int)ap[i - 1], 4) * 5 + min((int)bp[j - 1], 4)] >> 2; i--; j--; }
-        else if (tag == 2) { emit(GNX_COL_I, 1); if (!RIGHT) cur -= kp.g4 >> 2; j--; }
-        else if (tag == 1) { emit(GNX_COL_D, 1); if (!RIGHT) cur -= kp.g4 >> 2; i--; }
-        else { atomicOr(err, 2); break; }
-    }
-    emit(-2, 0); // flush
-    if (!WRITE) { nops[p] = cnt; if (!RIGHT) endpos[p] = make_int2(i, j); }
-}
 
 // ------------------------------------------------------------------------------------------------------
 // Host side

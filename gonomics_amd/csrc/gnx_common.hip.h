@@ -1,0 +1,64 @@
+// gnx_common.hip.h -- geometry constants, PairPlan / KParams, DPP and max3 helpers
+// Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).  See DESIGN.md section 4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+#include <algorithm>
+#include <type_traits>
+#include "gnx_align.h"
+
+namespace {
+constexpr int G = 16;            // lanes per pair (one DPP row)
+constexpr int R = 10;            // DP rows per lane
+constexpr int H = G * R;         // rows per strip
+constexpr int NEG4 = -(1 << 30); // scaled "veryNegNum" (align/align.go:8); finite keys stay above -(1<<29)
+constexpr int QA = 8;            // uint4 stores per lane per flush, affine (3*R=30 dwords -> 32)
+constexpr int QC = 3;            // const gap (R=10 dwords -> 12)
+
+#define DPP_ROW_SHR1 0x111
+#define DPP_ROW_SHL1 0x101
+
+struct PairPlan {
+    int32_t n, m;
+    int32_t words;      // 16-column direction words per strip
+    int32_t strips;     // ceil(n / H)
+    int64_t trace_off;  // in uint4 units, relative to the chunk's trace buffer
+    int64_t hcol_off;   // ints
+    int64_t rowbuf_off; // int2
+    int64_t dcol_off;   // dwords: per strip and lane one word with the last-column direction fields of the lane's R rows
+    // fast path (short alpha) / window re-fill:
+    int32_t src;        // index of the pair in the a_start / b_start tables (== own index except for window plans)
+    int32_t col_off;    // first column of a window re-fill minus one (0 = whole matrix); multiple of CKW
+    int64_t ckpt_off;   // int2: column checkpoints of the pair, [c-1][row] for column c*CKW
+    int64_t rowi_off;   // dwords: I-plane of row n (one word per 16 steps of the owner lane)
+    int64_t s_off;      // SCORED kernels: explicit 4*score matrix of the pair, column-major: S[s_off + (j-1)*s_pitch + (i-1)]
+    int64_t s_pitch;
+};
+
+constexpr int CKW = 128;     // column checkpoint spacing of the fast path
+constexpr int FP_SPAN = 192; // a re-fill window is at least this wide (>= 160 rows + typical indels)
+constexpr int FP_PLANES = 4; // rows n .. n-3 keep their I-plane: a trailing gap sits on row n-d when the last d bases match the chunk end
+constexpr int FP_CAP = 64;   // CIGAR runs staged per pair on the fast path (more -> general path)
+constexpr int FP_WWORDS = (FP_SPAN + CKW + 15 + 15) / 16 + 1; // direction words of the widest window
+constexpr int FP_TILE = 1024;                                  // straggler tiles: columns (c*FP_TILE, (c+1)*FP_TILE]
+constexpr int FP_TWORDS = (FP_TILE + CKW + 15 + 15) / 16;      // direction words of a tile (plus the checkpoint interval it starts early)
+
+struct KParams {
+    int sc4[25]; // 4*scores
+    int oe4, e4, o4;
+    int d00_4;   // 4*D(0,0): gapOpen, or 0 with free end gaps
+    int ecol4;   // 4*(column-0 extension): gapExtend, or 0 with free end gaps
+    int g4;      // const gap: 4*gapPen
+};
+
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ int dpp_shr1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHR1, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_shl1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHL1, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned alignbit2(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 2); }
+
+} // namespace

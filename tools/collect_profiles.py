@@ -67,6 +67,36 @@ def main():
             hbm = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
             traffic[key] = {"kernel": tot["kernel"], "pairs_per_launch_upper": tot["pairs"], "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"],
                             "hbm_bytes_per_launch": hbm, "note": "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; separate --pmc passes, bench.py --steps 1 --warmup 0"}
+    # SQ counter passes (32768 pairs): one line per counter for the sweep kernel; VALU instructions per pair feed bench.py's
+    # second (VALU issue) roofline
+    sq = {}
+    kms = {}
+    for gi in (1, 2, 3):
+        path = os.path.join(src, "pmc_sq%d" % gi, "pmc_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                if re.search(r"fp_sweep_kernel", r["Kernel_Name"]):
+                    sq.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                    kms.setdefault(r["Counter_Name"], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    if sq:
+        with open(os.path.join(prof, rnd + "_pmc_sq.csv"), "w") as out:
+            out.write("# rocprofv3 --pmc <SQ counters> passes on bench.py --pairs 32768 --steps 1 --warmup 0: fp_sweep_kernel (4096 waves); "
+                      "SQ_*_CYCLES / WAIT / ACTIVE are in quad-cycles summed over the SEs\n")
+            out.write("counter,value,kernel_ms\n")
+            for k in sorted(sq):
+                out.write("%s,%f,%.3f\n" % (k, sum(sq[k]) / len(sq[k]), sum(kms[k]) / len(kms[k])))
+        if "SQ_INSTS_VALU" in sq and "fast_path" in traffic:
+            traffic["fast_path"]["valu_insts_per_pair"] = sum(sq["SQ_INSTS_VALU"]) / len(sq["SQ_INSTS_VALU"]) / 32768.0
+            traffic["fast_path"]["lds_insts_per_pair"] = sum(sq.get("SQ_INSTS_LDS", [0])) / max(1, len(sq.get("SQ_INSTS_LDS", [0]))) / 32768.0
+            traffic["fast_path"]["lds_bank_conflict_cycles"] = sum(sq.get("SQ_LDS_BANK_CONFLICT", [0])) / max(1, len(sq.get("SQ_LDS_BANK_CONFLICT", [0])))
+            if "SQ_ACTIVE_INST_VALU" in sq and "GRBM_GUI_ACTIVE" in sq:
+                # quad-cycles of VALU activity summed over the 1024 SIMDs vs the kernel's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+                act = sum(sq["SQ_ACTIVE_INST_VALU"]) / len(sq["SQ_ACTIVE_INST_VALU"]) * 4.0
+                cyc = sum(sq["GRBM_GUI_ACTIVE"]) / len(sq["GRBM_GUI_ACTIVE"]) / 8.0
+                traffic["fast_path"]["valu_busy"] = act / (cyc * 1024.0)
+                traffic["fast_path"]["clock_ghz"] = cyc / (sum(kms["GRBM_GUI_ACTIVE"]) / len(kms["GRBM_GUI_ACTIVE"]) * 1e6)
     bench = None
     for nm in ("bench.json", "stats_bench.json"):
         try:
