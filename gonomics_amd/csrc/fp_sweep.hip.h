@@ -115,9 +115,9 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     };
     int qb = base_of(lp), nb = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
 
-    auto step = [&](const int t, auto chk, auto ckt) {
-        constexpr bool CHECK = decltype(chk)::value;
-        constexpr bool CKPT = decltype(ckt)::value; // this half block crosses a checkpoint column
+    auto step = [&](const int t, auto chk, const bool ckflag) {
+        constexpr bool CHECK = decltype(chk)::value; // false: every lane of the wave is inside its matrix (steady state)
+        // ckflag (wave-uniform): this half block crosses a checkpoint column
         const int up_dn = dpp_prev8(cDN, dn_out);
         const int up_h = dpp_prev8(cH, h_out);
         const int pb = dpp_prev8(qb, b_out);
@@ -161,7 +161,9 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
 #pragma unroll
                 for (int d = 0; d < FP_PLANES; d++) tailw |= (unsigned)(hold[RR - 1 - d] & 3) << (8 * (m_eff - j) + 2 * d);
             }
-            if (CKPT && (j & (CKW - 1)) == 0 && j < m_eff && valid) { // column checkpoint, un-rebased values {I(i,j+1), h(i,j)+e} (tag bits junk)
+            if (ckflag) { // wave-uniform: a real scalar branch (the empty asm keeps the per-lane test from being hoisted out of it)
+            asm volatile("" ::: "memory");
+            if ((j & (CKW - 1)) == 0 && j < m_eff && valid) { // column checkpoint, un-rebased values {I(i,j+1), h(i,j)+e} (tag bits junk)
                 int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n;
 #pragma unroll
                 for (int r = 0; r < RR; r++) {
@@ -170,27 +172,14 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
                     if (i >= 1) ck[i - 1] = make_int2(rt[r] + off, hold[r] + off);
                 }
             }
+            }
         }
     };
 
     // half blocks of 8 steps t0 .. t0+7 (step t: lane lp is at column t - lp); a plane word is two half blocks
     const int Tend = ((m_max + G8 - 1) / 16 + 1) * 16;
-    for (int t0 = 0; t0 < Tend; t0 += 8) {
-        nb = base_of(t0 + 8 + lp); // prefetch the next half block's bases
-        const bool ckblk = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
-        const bool steady = t0 >= 8 && t0 + 7 <= m_min;
-        if (steady && !ckblk) {
-#pragma unroll 2
-            for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, std::false_type{});
-        } else if (steady) {
-#pragma unroll 1
-            for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, std::true_type{});
-        } else {
-#pragma unroll 1
-            for (int u = 0; u < 8; u++) step(t0 + u, std::true_type{}, std::true_type{});
-        }
-        qb = nb;
-        if ((t0 & 8) && lp == G8 - 1 && valid) { // the last lane owns rows n..n-3: flush the plane word of steps t0-8 .. t0+7
+    auto flush = [&](int t0) { // the last lane owns rows n..n-3: after the odd half block, store the plane word of steps t0-8 .. t0+7
+        if ((t0 & 8) && lp == G8 - 1 && valid) {
             const int w = t0 >> 4;
             if (w < pl.words) {
                 const int miss = (t0 + 7) - (m_eff + G8 - 1); // steps this lane sat idle after its last column
@@ -202,7 +191,27 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
                 }
             }
         }
+    };
+    auto edge_half_block = [&](int t0) { // head and tail of the sweep: some lanes are outside their matrix
+        nb = base_of(t0 + 8 + lp); // prefetch the next half block's bases
+#pragma unroll 1
+        for (int u = 0; u < 8; u++) step(t0 + u, std::true_type{}, true);
+        qb = nb;
+        flush(t0);
+    };
+    // Three phases, so that the steady loop is ONE loop over half blocks whose state stays in the same registers (separate
+    // inner loops per half-block kind cost ~90 register copies per half block at their boundaries).
+    int t0 = 0;
+    for (; t0 < Tend && !(t0 >= 8 && t0 + 7 <= m_min); t0 += 8) edge_half_block(t0);
+    for (; t0 + 7 <= m_min; t0 += 8) { // steady state: every lane of the wave is inside its matrix
+        nb = base_of(t0 + 8 + lp);
+        const bool ckflag = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
+#pragma unroll
+        for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, ckflag);
+        qb = nb;
+        flush(t0);
     }
+    for (; t0 < Tend; t0 += 8) edge_half_block(t0);
     if (lp == G8 - 1 && valid && m_eff >= 1) { hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); tail[pl.hcol_off] = tailw; } // h(n, m)
     if (bad) atomicOr(err, 1);
 }
