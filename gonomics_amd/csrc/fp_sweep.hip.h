@@ -36,8 +36,8 @@ __device__ __forceinline__ int dpp_prev8(int oldv, int src) {
     return __builtin_amdgcn_update_dpp(v, src, DPP_ROW_SHL1, 0xf, 0xc, false);
 }
 // the opposite direction (queue rotation towards the first lane of the pair)
-__device__ __forceinline__ int dpp_next8(int oldv, int src) {
-    const int v = __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHL1, 0xf, 0x3, false);
+__device__ __forceinline__ int dpp_next8(int src) { // every lane of the two bank groups has a source: no `old` value needed
+    const int v = __builtin_amdgcn_mov_dpp(src, DPP_ROW_SHL1, 0xf, 0x3, false);
     return __builtin_amdgcn_update_dpp(v, src, DPP_ROW_SHR1, 0xf, 0xc, false);
 }
 
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     unsigned tailw = 0; // argmax tags of h(n-d, m-x), d, x = 0..3, field 4x + d: lets the walk take its first diagonal steps without a window
     int diag0 = (q0 == 0) ? (P == 0 ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + 1 : (q0 - 1 == P - 1 ? 3 : kp.o4 + 2));
     int dn_out = 0, h_out = 0, b_out = 0;
+    int up_dn = cDN, up_h = cH;
     auto base_of = [&](int c) { // LDS byte offset of the profile plane of beta[c] (column c, 1-based)
         int b = 0;
         if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
@@ -118,10 +119,12 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     auto step = [&](const int t, auto chk, const bool ckflag) {
         constexpr bool CHECK = decltype(chk)::value; // false: every lane of the wave is inside its matrix (steady state)
         // ckflag (wave-uniform): this half block crosses a checkpoint column
-        const int up_dn = dpp_prev8(cDN, dn_out);
-        const int up_h = dpp_prev8(cH, h_out);
+        // The first lane of a pair keeps the DPP `old` value = the row-0 boundary constant.  Passing the previous step's result
+        // as `old` (its first lane already holds that constant) lets the move happen in place, without a copy of the constant.
+        up_dn = dpp_prev8(up_dn, dn_out);
+        up_h = dpp_prev8(up_h, h_out);
         const int pb = dpp_prev8(qb, b_out);
-        qb = dpp_next8(qb, qb);
+        qb = dpp_next8(qb);
         const int j = t - lp;
         b_out = pb;
         if (!CHECK || (j >= 1 && j <= m_eff)) {
