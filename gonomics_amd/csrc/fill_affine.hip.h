@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             boundary(t0 + 16 + l + 1, ndn, nh, nb); // prefetch the next block's boundary
             const bool steady = t0 >= 16 && t0 + 16 <= m_min;
             if (steady) {
-#pragma unroll 2
+#pragma unroll
                 for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
             } else {
 #pragma unroll 1

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         for (int t0 = 0; t0 < Tend; t0 += 16) {
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
-#pragma unroll 2
+#pragma unroll
                 for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
             } else {
 #pragma unroll 1
