@@ -208,4 +208,24 @@ __global__ __launch_bounds__(256) void fp_compact_kernel(int n_pairs, const FpSt
     for (int64_t x = 0; x < m; x++) ops[base + (cnt - 1 - x)] = stage[(int64_t)p * FP_CAP + x];
 }
 
+// Pairs whose CIGAR has more runs than the staging area holds (FP_CAP) are aligned again on the general path -- only they, not
+// the batch: gather their window starts, and afterwards put their scores / runs where the compaction left the gaps.
+__global__ __launch_bounds__(256) void fp_redo_gather_kernel(const int *__restrict__ idx, int n, const int64_t *__restrict__ as, const int64_t *__restrict__ bs,
+                                                             int64_t *__restrict__ oas, int64_t *__restrict__ obs) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { oas[k] = as[idx[k]]; obs[k] = bs[idx[k]]; }
+}
+__global__ __launch_bounds__(256) void fp_redo_scatter_kernel(const int *__restrict__ idx, int n, const int64_t *__restrict__ sub_score,
+                                                              const int64_t *__restrict__ sub_off, const gnx_cigar *__restrict__ sub_ops,
+                                                              int64_t *__restrict__ score, const int64_t *__restrict__ ops_off, gnx_cigar *__restrict__ ops,
+                                                              int *__restrict__ err) {
+    const int k = blockIdx.x; // one block per pair
+    if (k >= n) return;
+    const int p = idx[k];
+    const int64_t len = sub_off[k + 1] - sub_off[k], base = ops_off[p];
+    if (len != ops_off[p + 1] - base) { if (threadIdx.x == 0) atomicOr(err, 2); return; } // both paths count the same runs
+    if (threadIdx.x == 0) score[p] = sub_score[k];
+    for (int64_t x = threadIdx.x; x < len; x += blockDim.x) ops[base + x] = sub_ops[sub_off[k] + x];
+}
+
 } // namespace

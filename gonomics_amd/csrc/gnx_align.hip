@@ -77,7 +77,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace;
+    DevBuf fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -144,7 +144,11 @@ int64_t max_abs_pen(const gnx_params *p, bool affine) {
 // Fast path for batches of short-alpha global affine alignments (see fp_walk_kernel).  Returns GNX_OK, an error,
 // or -1 when the batch should go through the general path after all (workspace too small / staging overflow).
 // `first` = first sub-batch of a call: later sub-batches keep the error flags and the CIGAR offset carry.
-int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
+int run_device(const gnx_params *prm, int64_t n_pairs, const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
+               const int64_t *h_alen, const int64_t *h_blen, int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
+               int64_t *out_total, hipStream_t stream, const int *d_smat, const int64_t *h_soff, int gsw, int2 *d_endpos, bool no_fast_path);
+
+int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, int64_t n_pairs,
                   const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                   const int64_t *h_alen, const int64_t *h_blen, int rows_per_lane,
                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
@@ -303,8 +307,47 @@ int run_device_fp(const KParams &kp, const TbParams &tp, int64_t n_pairs,
     const int ef = h_misc[0];
     if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
     if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
-    if (ef & 8) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] a CIGAR has more than %d runs -> general path\n", FP_CAP); return -1; } // redo on the general path
     if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
+    if (ef & 8) {
+        // some CIGARs have more than FP_CAP runs: their run counts (and so every offset) are right, their runs were not staged.
+        // Align those pairs again on the general path and put the results in place; the batch goes back only if they are many.
+        std::vector<int64_t> hn((size_t)np);
+        HIPCHK(hipMemcpy(hn.data(), d_nops, (size_t)np * 8, hipMemcpyDeviceToHost));
+        std::vector<int> idx;
+        std::vector<int64_t> sal, sbl;
+        int64_t sub_total = 0;
+        for (int p = 0; p < np; p++) if (hn[(size_t)p] > FP_CAP) { idx.push_back(p); sal.push_back(h_alen[p]); sbl.push_back(h_blen[p]); sub_total += hn[(size_t)p]; }
+        const int ns = (int)idx.size();
+        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %d CIGARs have more than %d runs -> those pairs again on the general path\n", ns, FP_CAP);
+        if (ns > np / 4) return -1;
+        const size_t o_idx = 0, o_as = (size_t)ns * 4 + 64, o_bs = o_as + (size_t)ns * 8, o_sc = o_bs + (size_t)ns * 8, o_off = o_sc + (size_t)ns * 8,
+                     o_ops = ((o_off + (size_t)(ns + 1) * 8 + 63) & ~(size_t)63), bytes = o_ops + (size_t)(sub_total + 1) * sizeof(gnx_cigar);
+        if ((rc = c.fp_redo.ensure(bytes))) return rc;
+        char *rb = reinterpret_cast<char *>(c.fp_redo.p);
+        int *d_idx = reinterpret_cast<int *>(rb + o_idx);
+        int64_t *s_as = reinterpret_cast<int64_t *>(rb + o_as), *s_bs = reinterpret_cast<int64_t *>(rb + o_bs), *s_sc = reinterpret_cast<int64_t *>(rb + o_sc),
+                *s_off = reinterpret_cast<int64_t *>(rb + o_off);
+        gnx_cigar *s_ops = reinterpret_cast<gnx_cigar *>(rb + o_ops);
+        HIPCHK(hipMemcpyAsync(d_idx, idx.data(), (size_t)ns * 4, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(fp_redo_gather_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, d_idx, ns, d_as, d_bs, s_as, s_bs);
+        HIPCHK(hipGetLastError());
+        const gnx_timing saved = c.timing;
+        int64_t tot2 = 0;
+        rc = run_device(prm, ns, d_a, s_as, d_b, s_bs, sal.data(), sbl.data(), s_sc, s_ops, sub_total + 1, s_off, &tot2, stream, nullptr, nullptr, 0, nullptr, true);
+        const double redo_ms = c.timing.total_ms;
+        c.timing = saved;
+        c.timing.traceback_ms += redo_ms; c.timing.total_ms += redo_ms;
+        if (rc) return rc;
+        // the general path used the shared error / carry words: put this call's back (minus the overflow flag)
+        h_misc[0] = ef & ~8;
+        HIPCHK(hipMemcpyAsync(c.misc.p, h_misc, 64, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(fp_redo_scatter_kernel, dim3((unsigned)ns), dim3(256), 0, stream, d_idx, ns, s_sc, s_off, s_ops, d_score, d_ops_off, d_ops, d_err);
+        HIPCHK(hipGetLastError());
+        int e2 = 0;
+        HIPCHK(hipMemcpyAsync(&e2, d_err, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (e2 & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
+    }
     return GNX_OK;
 }
 
@@ -314,7 +357,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
                const int64_t *h_alen, const int64_t *h_blen,
                int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
                int64_t *out_total, hipStream_t stream, const int *d_smat = nullptr, const int64_t *h_soff = nullptr,
-               int gsw = 0, int2 *d_endpos = nullptr) {
+               int gsw = 0, int2 *d_endpos = nullptr, bool no_fast_path = false) {
     // gsw: 1 / 2 = LeftDynamicAln / RightDynamicAln of the graph aligner (constant-gap kernels with GSW = 1 / 2 and their own
     // traceback; d_endpos receives the (i, j) the reference returns); prm->mode must be GNX_CONST_GAP_HIGHMEM
     // d_smat / h_soff: explicit per-cell score matrices (SCORED kernels, N1 variants); the sequences are then unused
@@ -337,7 +380,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     // ---- fast path: every alpha fits one strip, long beta, global affine with gapOpen <= 0 ----
     {
         const char *fpenv = getenv("GNX_FASTPATH");
-        bool fp = affine && !local && !d_smat && prm->gap_open <= 0 && !(fpenv && fpenv[0] == '0');
+        bool fp = affine && !local && !d_smat && !no_fast_path && prm->gap_open <= 0 && !(fpenv && fpenv[0] == '0');
         // fp_sweep_kernel keeps an int16 profile of 4*(s - 2e); its padding rows need 4*|gapOpen| well inside int16
         if (prm->gap_open <= -8000) fp = false;
         for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * prm->gap_extend); if (v > 32767 || v < -32000) fp = false; }
@@ -365,7 +408,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             rc = -1;
             for (size_t ch = 0; fp && ch + 1 < cb.size(); ch++) {
                 const int64_t b = cb[ch], e = cb[ch + 1];
-                rc = run_device_fp(kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
+                rc = run_device_fp(prm, kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
                                    d_ops_off + b, out_total, stream, ch == 0);
                 if (rc != GNX_OK) break;
             }
@@ -710,7 +753,7 @@ void gnx_shutdown(void) {
     if (!g_ctx.inited) return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
+    DevBuf *bufs[] = {&g_ctx.fp_redo, &g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
                       &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
                       &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops, &g_ctx.out_end,
                       &g_ctx.sc_pairs, &g_ctx.sc_mat, &g_ctx.sc_err};

@@ -352,3 +352,27 @@ def test_fast_path_sweep_geometry(gpu_lib, seed, monkeypatch):
     got = gpu_lib.align_batch(p, alphas, betas)
     exp = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, alphas, betas, ci=7, cj=7, threads=8)
     common.assert_same(got, exp, "sweep geometry, 7x7 checkerboards")
+
+
+@pytest.mark.gpu
+def test_fast_path_long_cigars_redo_only_those_pairs(gpu_lib):
+    """A few pairs whose CIGAR has more runs than the fast path stages (64) are aligned again on the general path --
+    the rest of the batch stays on the fast path; scores, offsets and runs must still be those of the oracle."""
+    rng = np.random.default_rng(77)
+    chunk = rng.integers(0, 4, size=1500).astype(np.uint8)
+    alphas, betas = [], []
+    for k in range(96):
+        off = int(rng.integers(0, 1200))
+        if k % 11 == 3:
+            a = chunk[off:off + 280:2][:140].copy()      # every other base: with cheap gaps the alignment alternates M and I
+        else:
+            a = common.mutate(rng, chunk[off:off + 150], 0.02, 0.005)[:150]
+        alphas.append(a); betas.append(chunk)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["Default"], -30, -10)
+    got = gpu_lib.align_batch(p, alphas, betas)
+    if os.environ.get("GNX_FASTPATH", "1") != "0":
+        assert gpu_lib.get_timing()["fast_path"] == 1
+    exp = oracle.align_batch(0, MX["Default"], -30, -10, alphas, betas, threads=8)
+    long_ones = sum(1 for k in range(96) if int(exp[2][k + 1] - exp[2][k]) > 64)
+    assert 1 <= long_ones <= 24
+    common.assert_same(got, exp, "long CIGARs redone on the general path")
