@@ -7,7 +7,15 @@ namespace {
 // ------------------------------------------------------------------------------------------------------
 // Affine fill.
 //   LOCAL = free end gaps (AffineGapLocal, affineGap_highMem.go:188-210)
-//   MULTI = some pair of the launch has more than one 160-row strip (row buffer hand-over code compiled in)
+//   MULTI = some pair of the launch has more than one 160-row strip.  The strips of a pair then run as separate workgroups,
+//           pipelined: block (group of 4 pairs, strip s) reads the bottom row of strip s-1 from the row buffer once the block
+//           before it has published it (strip_prog; release / acquire at agent scope, every RB_PUB steps).  A 20 kb x 100 kb
+//           pair is up to 125 concurrent waves instead of one.  Blocks are ordered (group, strip) and every XCD dispatches
+//           its share in order, so the lowest unfinished block is always resident and never waits: no deadlock; a 5 s
+//           timeout on the spin turns any surprise into an error flag instead of a hang.  An agent-scope release writes the
+//           XCD's dirty L2 lines back (the XCDs' L2s are not coherent with each other), so the direction matrix of such
+//           launches lives in uncached memory -- its stores are full lines that are never read back by the fill -- and the L2
+//           stays clean; the row buffer itself is a few KB per hand-over.
 //   P16   = 4*score fits int16: the per-row score profile is stored as packed int16 pairs in LDS
 //   HFORM = gapOpen <= 0 (every caller): with h = max3(M,I,D) the recurrences collapse to
 //           rt = max(h+oe, I+e), dn = max(h+oe, D+e) with identical values AND identical argmax tags
@@ -32,7 +40,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                                                          const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                          KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
                                                          int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, const int2 *__restrict__ ckpt,
-                                                         int *__restrict__ err, const int *__restrict__ smat = nullptr) {
+                                                         int *__restrict__ err, const int *__restrict__ smat = nullptr,
+                                                         const int2 *__restrict__ strip_map = nullptr, int *__restrict__ strip_prog = nullptr) {
     // SCORED: the substitution score of a cell comes from an explicit per-pair matrix in HBM (chunk / multiple-alignment
     //      variants, "next" row N1) instead of the LDS profile of alpha x the base of the column; sequences are not read.
     // WIN: window / tile re-fill of the fast path: the left boundary comes from a column checkpoint written by
@@ -46,7 +55,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
 
-    const int pbase = blockIdx.x * 4;
+    const int pbase = (MULTI ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -68,7 +77,9 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                  : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4), "s"(kp.e4 + 2), "s"(kp.e4 + 1));
     int bad = 0;
 
-    for (int s = 0; s < S_max; s++) {
+    const int s_lo = MULTI ? strip_map[blockIdx.x].y : 0, s_hi = MULTI ? s_lo + 1 : S_max;
+    const int64_t rb_pitch = (int64_t)pl.m + 1; // row-buffer entries per strip of this pair
+    for (int s = s_lo; s < s_hi; s++) {
         const bool gact = valid && s < pl.strips;
         const int m_eff = gact ? pl.m : 0;
         int m_min = 0x7fffffff; // over the 4 pairs of the wave, this strip (wave-uniform)
@@ -126,14 +137,26 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 odn = (LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4);
                 oh = h0 + XE;
             } else if (c >= 1 && c <= m_eff) {
-                const int2 v = rowbuf[pl.rowbuf_off + c];
+                const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c];
                 odn = v.x; oh = v.y; // already in the X domain
             } else { odn = 0; oh = 0; }
             int b = 0;
             if (!SCORED && c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
             ob = b * (BST * 4); // LDS byte offset of the base's profile plane
         };
-        if (MULTI && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // wait until the block of strip s-1 (the previous block of the grid) has published the row-buffer columns <= cmax;
+        // strip_prog holds the number of columns it has published so far (INT_MAX when it is done)
+        int rb_seen = 0;
+        auto wait_rows = [&](int cmax) {
+            if (MULTI && s > 0 && rb_seen < cmax) {
+                const long long t_begin = wall_clock64();
+                while ((rb_seen = __hip_atomic_load(&strip_prog[blockIdx.x - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < cmax) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; } // 5 s at 100 MHz
+                }
+            }
+        };
+        wait_rows(G);
         boundary(l + 1, qdn, qh, qb);
 
         // one anti-diagonal step; CHECK=false is the steady state (every lane of the wave has a live column)
@@ -194,6 +217,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
+            wait_rows(t0 + 2 * G);
             boundary(t0 + 16 + l + 1, ndn, nh, nb); // prefetch the next block's boundary
             const bool steady = t0 >= 16 && t0 + 16 <= m_min;
             if (steady) {
@@ -220,7 +244,11 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             }
             if (store_row) {
                 const int c = t0 + l - 14;
-                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + c] = make_int2(sq_dn, sq_h);
+                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c] = make_int2(sq_dn, sq_h);
+            }
+            if (MULTI && ((t0 + 16) & (RB_PUB - 1)) == 0) { // publish: the bottom row of this strip is out up to column t0 + 1
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], t0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (gact && m_eff >= 1) {
@@ -234,7 +262,10 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             for (int r = 0; r < R; r++) dw |= ((acc[2 * R + r] >> (30 - 2 * missf)) & 3u) << (2 * r);
             dcol[pl.dcol_off + s * G + l] = dw;
         }
-        if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (MULTI) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (bad) atomicOr(err, 1);
 }

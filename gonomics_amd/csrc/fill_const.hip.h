@@ -19,7 +19,9 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                                                         const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                         const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                         KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
-                                                        int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int *__restrict__ err) {
+                                                        int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int *__restrict__ err,
+                                                        const int2 *__restrict__ strip_map = nullptr, int *__restrict__ strip_prog = nullptr) {
+    // MULTI: one workgroup per (group of 4 pairs, strip), pipelined through the row buffer -- see fill_affine_kernel
     using PC = ProfCfg<false>;
     constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
     __shared__ int lds[32 + 4 * PST];
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     if (lane < 25) lds[lane] = kp.sc4[lane] + 3; // pre-tagged diagonal candidate
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
-    const int pbase = blockIdx.x * 4;
+    const int pbase = (MULTI ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -44,7 +46,9 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vGL), "=v"(vGU) : "s"(kp.g4 + 2), "s"(kp.g4 + 1));
     int bad = 0;
 
-    for (int s = 0; s < S_max; s++) {
+    const int s_lo = MULTI ? strip_map[blockIdx.x].y : 0, s_hi = MULTI ? s_lo + 1 : S_max;
+    const int64_t rb_pitch = (int64_t)pl.m + 1;
+    for (int s = s_lo; s < s_hi; s++) {
         const bool gact = valid && s < pl.strips;
         const int m_eff = gact ? pl.m : 0;
         int m_min = 0x7fffffff;
@@ -80,13 +84,23 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         int qv, qb, nv = 0, nb = 0;
         auto boundary = [&](int c, int &ov, int &ob) {
             if (!MULTI || s == 0) ov = GSW == 1 ? 0 : c * kp.g4; // row 0: j*gapPen
-            else if (c >= 1 && c <= m_eff) ov = rowbuf[pl.rowbuf_off + c].x;
+            else if (c >= 1 && c <= m_eff) ov = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c].x;
             else ov = 0;
             int b = 0;
             if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
             ob = b * (BST * 4);
         };
-        if (MULTI && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        int rb_seen = 0;
+        auto wait_rows = [&](int cmax) {
+            if (MULTI && s > 0 && rb_seen < cmax) {
+                const long long t_begin = wall_clock64();
+                while ((rb_seen = __hip_atomic_load(&strip_prog[blockIdx.x - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < cmax) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; }
+                }
+            }
+        };
+        wait_rows(G);
         boundary(l + 1, qv, qb);
 
         auto step = [&](const int t, auto chk) {
@@ -120,6 +134,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
+            wait_rows(t0 + 2 * G);
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
 #pragma unroll
@@ -144,7 +159,11 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             }
             if (store_row) {
                 const int c = t0 + l - 14;
-                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + c] = make_int2(sq_v, 0);
+                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c] = make_int2(sq_v, 0);
+            }
+            if (MULTI && ((t0 + 16) & (RB_PUB - 1)) == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], t0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (gact && m_eff >= 1) {
@@ -156,7 +175,10 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             for (int r = 0; r < R; r++) dw |= ((acc[r] >> (30 - 2 * missf)) & 3u) << (2 * r);
             dcol[pl.dcol_off + s * G + l] = dw;
         }
-        if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (MULTI) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (bad) atomicOr(err, 1);
 }

@@ -56,10 +56,16 @@ void set_err(const char *fmt, const char *a = "", long long b = 0) { snprintf(g_
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool uncached = false; // hipDeviceMallocUncached: the direction matrix of pipelined multi-strip launches (see fill_affine_kernel)
     int ensure(size_t bytes) {
         if (bytes <= cap) return GNX_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
+        if (uncached) {
+            if (hipExtMallocWithFlags(&p, want, hipDeviceMallocUncached) != hipSuccess) { p = nullptr; set_err("uncached device allocation of %s%lld bytes failed", "", (long long)want); return GNX_ENOMEM; }
+            cap = want;
+            return GNX_OK;
+        }
         if (hipMalloc(&p, want) != hipSuccess) {
             if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; set_err("device allocation of %s%lld bytes failed", "", (long long)bytes); return GNX_ENOMEM; }
             want = bytes;
@@ -77,7 +83,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
+    DevBuf strip_map, trace_uc, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -457,13 +463,13 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
                 for (int64_t q2 = cb; q2 < p; q2++) {
                     PairPlan &pq = plans[(size_t)q2];
                     pq.trace_off = toff; pq.hcol_off = hoff; pq.rowbuf_off = roff; pq.dcol_off = doff;
-                    toff += (int64_t)pq.strips * pq.words * Q * G; hoff += pq.n; roff += (pq.strips > 1) ? pq.m + 1 : 0; doff += (int64_t)pq.strips * G;
+                    toff += (int64_t)pq.strips * pq.words * Q * G; hoff += pq.n; roff += (int64_t)std::max(pq.strips - 1, 0) * (pq.m + 1); doff += (int64_t)pq.strips * G;
                 }
                 chunk_begin.push_back(cb);
             }
             pl.trace_off = toff; pl.hcol_off = hoff; pl.rowbuf_off = roff; pl.dcol_off = doff;
             if (h_soff) { pl.s_off = h_soff[p]; pl.s_pitch = (int64_t)std::max<int32_t>(pl.strips, 1) * H; }
-            toff += tsz; hoff += n; roff += (pl.strips > 1) ? m + 1 : 0; doff += (int64_t)pl.strips * G;
+            toff += tsz; hoff += n; roff += (int64_t)std::max(pl.strips - 1, 0) * (m + 1); doff += (int64_t)pl.strips * G;
             cells += n * m;
         }
         chunk_begin.push_back(n_pairs);
@@ -476,12 +482,16 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         int64_t t = 0, h = 0, r = 0, d = 0;
         for (int64_t p = chunk_begin[ch]; p < chunk_begin[ch + 1]; p++) {
             const PairPlan &pl = plans[(size_t)p];
-            t += (int64_t)pl.strips * pl.words * Q * G; h += pl.n; r += (pl.strips > 1) ? pl.m + 1 : 0; d += (int64_t)pl.strips * G;
+            t += (int64_t)pl.strips * pl.words * Q * G; h += pl.n; r += (int64_t)std::max(pl.strips - 1, 0) * (pl.m + 1); d += (int64_t)pl.strips * G;
         }
         max_t = std::max(max_t, t); max_h = std::max(max_h, h); max_r = std::max(max_r, r); max_d = std::max(max_d, d);
     }
     if ((rc = c.dcol.ensure((size_t)max_d * 4))) return rc;
-    if ((rc = c.trace.ensure((size_t)max_t * 16))) return rc;
+    bool any_multi = false; // multi-strip pairs: pipelined strips, direction matrix in uncached memory (see fill_affine_kernel)
+    for (int64_t p = 0; p < n_pairs && !any_multi; p++) any_multi = plans[(size_t)p].strips > 1;
+    c.trace_uc.uncached = true;
+    DevBuf &trbuf = any_multi ? c.trace_uc : c.trace;
+    if ((rc = trbuf.ensure((size_t)max_t * 16))) return rc;
     if ((rc = c.hcol.ensure((size_t)max_h * 4))) return rc;
     if ((rc = c.rowbuf.ensure((size_t)max_r * 8))) return rc;
     if ((rc = c.plans.ensure((size_t)n_pairs * sizeof(PairPlan)))) return rc;
@@ -502,20 +512,40 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const int np = (int)(e - b);
         if (np <= 0) continue;
         const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p) + b;
-        uint4 *dtrace = reinterpret_cast<uint4 *>(c.trace.p);
+        uint4 *dtrace = reinterpret_cast<uint4 *>(trbuf.p);
         int *dh = reinterpret_cast<int *>(c.hcol.p);
         int2 *drb = reinterpret_cast<int2 *>(c.rowbuf.p);
         unsigned *ddc = reinterpret_cast<unsigned *>(c.dcol.p);
         int64_t *dn = reinterpret_cast<int64_t *>(c.nops.p) + b;
-        const dim3 gridF((unsigned)((np + 3) / 4)), blockF(64);
-        const dim3 gridT((unsigned)((np + 63) / 64)), blockT(64);
-        HIPCHK(hipEventRecord(c.ev[1], stream));
         bool multi = false;
         for (int64_t q2 = b; q2 < e; q2++) if (plans[(size_t)q2].strips > 1) { multi = true; break; }
+        // multi-strip chunks: one workgroup per (group of 4 pairs, strip), pipelined through the row buffer (fill_affine_kernel)
+        const int2 *d_smap = nullptr;
+        int *d_sprog = nullptr;
+        int64_t n_blocks = (np + 3) / 4;
+        if (multi) {
+            std::vector<int2> smap;
+            for (int gq = 0; gq < (np + 3) / 4; gq++) {
+                int smax = 0;
+                for (int q3 = 0; q3 < 4 && gq * 4 + q3 < np; q3++) smax = std::max(smax, (int)plans[(size_t)(b + gq * 4 + q3)].strips);
+                for (int st2 = 0; st2 < smax; st2++) smap.push_back(make_int2(gq, st2));
+            }
+            n_blocks = (int64_t)smap.size();
+            if (n_blocks > 0x7fffffff) { set_err("too many strips in one chunk%s", ""); return GNX_ENOMEM; }
+            if ((rc = c.strip_map.ensure((size_t)std::max<int64_t>(n_blocks, 1) * 12))) return rc;
+            d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
+            d_sprog = reinterpret_cast<int *>(reinterpret_cast<char *>(c.strip_map.p) + (size_t)std::max<int64_t>(n_blocks, 1) * 8);
+            HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)n_blocks * 8, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)std::max<int64_t>(n_blocks, 1) * 4, stream));
+            HIPCHK(hipStreamSynchronize(stream)); // smap is a local
+        }
+        const dim3 gridF((unsigned)n_blocks), blockF(64);
+        const dim3 gridT((unsigned)((np + 63) / 64)), blockT(64);
+        HIPCHK(hipEventRecord(c.ev[1], stream));
         if (affine) {
-#define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, (const int2 *)nullptr, d_err)
+#define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, (const int2 *)nullptr, d_err, (const int *)nullptr, d_smap, d_sprog)
 #define GNX_LAUNCH_AFF2(L_, M_, P_) do { if (hform) GNX_LAUNCH_AFF(L_, M_, P_, true); else GNX_LAUNCH_AFF(L_, M_, P_, false); } while (0)
-#define GNX_LAUNCH_SC(M_, H_) hipLaunchKernelGGL((fill_affine_kernel<false, M_, false, H_, false, true>), gridF, blockF, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, (const int2 *)nullptr, d_err, d_smat)
+#define GNX_LAUNCH_SC(M_, H_) hipLaunchKernelGGL((fill_affine_kernel<false, M_, false, H_, false, true>), gridF, blockF, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, (const int2 *)nullptr, d_err, d_smat, d_smap, d_sprog)
             const int sel = d_smat ? 8 : ((local ? 4 : 0) | (multi ? 2 : 0) | (p16 ? 1 : 0));
             switch (sel) {
             case 8:
@@ -535,7 +565,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
 #undef GNX_LAUNCH_AFF2
 #undef GNX_LAUNCH_AFF
         } else {
-#define GNX_LAUNCH_CONST(M_, G_) hipLaunchKernelGGL((fill_const_kernel<M_, G_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err)
+#define GNX_LAUNCH_CONST(M_, G_) hipLaunchKernelGGL((fill_const_kernel<M_, G_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_sprog)
             if (gsw == 1) { if (multi) GNX_LAUNCH_CONST(true, 1); else GNX_LAUNCH_CONST(false, 1); }
             else if (gsw == 2) { if (multi) GNX_LAUNCH_CONST(true, 2); else GNX_LAUNCH_CONST(false, 2); }
             else { if (multi) GNX_LAUNCH_CONST(true, 0); else GNX_LAUNCH_CONST(false, 0); }
@@ -579,6 +609,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     if (out_total) *out_total = total;
     const int ef = h_misc[0];
     if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
+    if (ef & 16) { set_err("a strip waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
     if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
     if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
     return GNX_OK;
@@ -753,7 +784,7 @@ void gnx_shutdown(void) {
     if (!g_ctx.inited) return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&g_ctx.fp_redo, &g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
+    DevBuf *bufs[] = {&g_ctx.strip_map, &g_ctx.trace_uc, &g_ctx.fp_redo, &g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
                       &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
                       &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops, &g_ctx.out_end,
                       &g_ctx.sc_pairs, &g_ctx.sc_mat, &g_ctx.sc_err};

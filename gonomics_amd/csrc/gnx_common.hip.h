@@ -19,6 +19,10 @@ constexpr int H = G * R;         // rows per strip
 constexpr int NEG4 = -(1 << 30); // scaled "veryNegNum" (align/align.go:8); finite keys stay above -(1<<29)
 constexpr int QA = 8;            // uint4 stores per lane per flush, affine (3*R=30 dwords -> 32)
 constexpr int QC = 3;            // const gap (R=10 dwords -> 12)
+#ifndef GNX_RB_PUB
+#define GNX_RB_PUB 128
+#endif
+constexpr int RB_PUB = GNX_RB_PUB;  // pipelined strips publish their bottom row every RB_PUB steps (power of two, multiple of 16)
 
 #define DPP_ROW_SHR1 0x111
 #define DPP_ROW_SHL1 0x101
