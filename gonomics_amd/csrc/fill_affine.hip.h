@@ -7,7 +7,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------------
 // Affine fill.
 //   LOCAL = free end gaps (AffineGapLocal, affineGap_highMem.go:188-210)
-//   MULTI = some pair of the launch has more than one 160-row strip.  The strips of a pair then run as separate workgroups,
+//   MULTI = some pair of the launch has more than one 160-row strip.  When the launch has too few pairs to fill the GPU with
+//           one wave per 4 pairs (host decision: strip_map != nullptr), the strips of a pair run as separate workgroups,
 //           pipelined: block (group of 4 pairs, strip s) reads the bottom row of strip s-1 from the row buffer once the block
 //           before it has published it (strip_prog; release / acquire at agent scope, every RB_PUB steps).  A 20 kb x 100 kb
 //           pair is up to 125 concurrent waves instead of one.  Blocks are ordered (group, strip) and every XCD dispatches
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
 
-    const int pbase = (MULTI ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
+    const bool piped = MULTI && strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
+    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                  : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4), "s"(kp.e4 + 2), "s"(kp.e4 + 1));
     int bad = 0;
 
-    const int s_lo = MULTI ? strip_map[blockIdx.x].y : 0, s_hi = MULTI ? s_lo + 1 : S_max;
+    const int s_lo = piped ? strip_map[blockIdx.x].y : 0, s_hi = piped ? s_lo + 1 : S_max;
     const int64_t rb_pitch = (int64_t)pl.m + 1; // row-buffer entries per strip of this pair
     for (int s = s_lo; s < s_hi; s++) {
         const bool gact = valid && s < pl.strips;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         // strip_prog holds the number of columns it has published so far (INT_MAX when it is done)
         int rb_seen = 0;
         auto wait_rows = [&](int cmax) {
-            if (MULTI && s > 0 && rb_seen < cmax) {
+            if (piped && s > 0 && rb_seen < cmax) {
                 const long long t_begin = wall_clock64();
                 while ((rb_seen = __hip_atomic_load(&strip_prog[blockIdx.x - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < cmax) {
                     __builtin_amdgcn_s_sleep(32);
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 }
             }
         };
+        if (MULTI && !piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qdn, qh, qb);
 
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 const int c = t0 + l - 14;
                 if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c] = make_int2(sq_dn, sq_h);
             }
-            if (MULTI && ((t0 + 16) & (RB_PUB - 1)) == 0) { // publish: the bottom row of this strip is out up to column t0 + 1
+            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) { // publish: the bottom row of this strip is out up to column t0 + 1
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], t0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -262,10 +265,10 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             for (int r = 0; r < R; r++) dw |= ((acc[2 * R + r] >> (30 - 2 * missf)) & 3u) << (2 * r);
             dcol[pl.dcol_off + s * G + l] = dw;
         }
-        if (MULTI) {
+        if (piped) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        } else if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     if (bad) atomicOr(err, 1);
 }

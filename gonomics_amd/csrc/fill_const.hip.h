@@ -30,7 +30,8 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     if (lane < 25) lds[lane] = kp.sc4[lane] + 3; // pre-tagged diagonal candidate
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
-    const int pbase = (MULTI ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
+    const bool piped = MULTI && strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
+    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vGL), "=v"(vGU) : "s"(kp.g4 + 2), "s"(kp.g4 + 1));
     int bad = 0;
 
-    const int s_lo = MULTI ? strip_map[blockIdx.x].y : 0, s_hi = MULTI ? s_lo + 1 : S_max;
+    const int s_lo = piped ? strip_map[blockIdx.x].y : 0, s_hi = piped ? s_lo + 1 : S_max;
     const int64_t rb_pitch = (int64_t)pl.m + 1;
     for (int s = s_lo; s < s_hi; s++) {
         const bool gact = valid && s < pl.strips;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         };
         int rb_seen = 0;
         auto wait_rows = [&](int cmax) {
-            if (MULTI && s > 0 && rb_seen < cmax) {
+            if (piped && s > 0 && rb_seen < cmax) {
                 const long long t_begin = wall_clock64();
                 while ((rb_seen = __hip_atomic_load(&strip_prog[blockIdx.x - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < cmax) {
                     __builtin_amdgcn_s_sleep(32);
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                 }
             }
         };
+        if (MULTI && !piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qv, qb);
 
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                 const int c = t0 + l - 14;
                 if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c] = make_int2(sq_v, 0);
             }
-            if (MULTI && ((t0 + 16) & (RB_PUB - 1)) == 0) {
+            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], t0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -175,10 +177,10 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             for (int r = 0; r < R; r++) dw |= ((acc[r] >> (30 - 2 * missf)) & 3u) << (2 * r);
             dcol[pl.dcol_off + s * G + l] = dw;
         }
-        if (MULTI) {
+        if (piped) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        } else if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     if (bad) atomicOr(err, 1);
 }

@@ -487,10 +487,17 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         max_t = std::max(max_t, t); max_h = std::max(max_h, h); max_r = std::max(max_r, r); max_d = std::max(max_d, d);
     }
     if ((rc = c.dcol.ensure((size_t)max_d * 4))) return rc;
-    bool any_multi = false; // multi-strip pairs: pipelined strips, direction matrix in uncached memory (see fill_affine_kernel)
-    for (int64_t p = 0; p < n_pairs && !any_multi; p++) any_multi = plans[(size_t)p].strips > 1;
+    // multi-strip pairs in small launches: pipelined strips, direction matrix in uncached memory (see fill_affine_kernel)
+    bool any_piped = false;
+    for (size_t ch = 0; ch + 1 < chunk_begin.size() && !any_piped; ch++) {
+        const int64_t npc = chunk_begin[ch + 1] - chunk_begin[ch];
+        bool mu = false;
+        int64_t mm = 0;
+        for (int64_t p = chunk_begin[ch]; p < chunk_begin[ch + 1]; p++) { mu = mu || plans[(size_t)p].strips > 1; mm = std::max<int64_t>(mm, plans[(size_t)p].m); }
+        any_piped = mu && (npc + 3) / 4 < 3072 && mm >= 8 * RB_PUB;
+    }
     c.trace_uc.uncached = true;
-    DevBuf &trbuf = any_multi ? c.trace_uc : c.trace;
+    DevBuf &trbuf = any_piped ? c.trace_uc : c.trace;
     if ((rc = trbuf.ensure((size_t)max_t * 16))) return rc;
     if ((rc = c.hcol.ensure((size_t)max_h * 4))) return rc;
     if ((rc = c.rowbuf.ensure((size_t)max_r * 8))) return rc;
@@ -523,7 +530,12 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const int2 *d_smap = nullptr;
         int *d_sprog = nullptr;
         int64_t n_blocks = (np + 3) / 4;
-        if (multi) {
+        // pipelined strips pay when one wave per 4 pairs cannot fill the GPU and the strips are long enough to overlap;
+        // with plenty of pairs (or short beta) the strips of a group would only wait for each other
+        int64_t m_maxc = 0;
+        for (int64_t q2 = b; q2 < e; q2++) m_maxc = std::max<int64_t>(m_maxc, plans[(size_t)q2].m);
+        const bool piped = multi && any_piped && n_blocks < 3072 && m_maxc >= 8 * RB_PUB;
+        if (piped) {
             std::vector<int2> smap;
             for (int gq = 0; gq < (np + 3) / 4; gq++) {
                 int smax = 0;
