@@ -223,7 +223,10 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             wait_rows(t0 + 2 * G);
             boundary(t0 + 16 + l + 1, ndn, nh, nb); // prefetch the next block's boundary
             const bool steady = t0 >= 16 && t0 + 16 <= m_min;
-            if (steady) {
+            if (steady && SCORED) { // the per-step HBM loads of the score matrix do better with the shallow unroll (3.2 -> 2.3 ms on tools/bench_n1.py)
+#pragma unroll 2
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+            } else if (steady) {
 #pragma unroll
                 for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
             } else {
