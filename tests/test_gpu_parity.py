@@ -376,3 +376,28 @@ def test_fast_path_long_cigars_redo_only_those_pairs(gpu_lib):
     long_ones = sum(1 for k in range(96) if int(exp[2][k + 1] - exp[2][k]) > 64)
     assert 1 <= long_ones <= 24
     common.assert_same(got, exp, "long CIGARs redone on the general path")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,name", MODES)
+def test_pipelined_strips(gpu_lib, mode, name):
+    """Small launches of multi-strip pairs with beta >= 1024 run their strips as pipelined workgroups (per-strip row buffer,
+    progress words, uncached direction matrix): ragged lengths, one-strip pairs in the same launch, checkerboards, and a launch
+    big enough to fall back to one wave per 4 pairs must all equal the oracle."""
+    lo = 0 if mode >= 2 else 1
+    alphas, betas = common.random_pairs(5000 + mode, 40, lo, 900, 1024, 1500, related=0.8)
+    alphas[3] = alphas[3][:100]            # a one-strip pair inside a pipelined launch
+    alphas[7] = alphas[7][:161]            # two strips, the second one a single row
+    got = _gpu_batch(gpu_lib, mode, MX["HumanChimpTwo"], -600, -150, alphas, betas)
+    exp = oracle.align_batch(mode, MX["HumanChimpTwo"], -600, -150, alphas, betas, threads=8)
+    common.assert_same(got, exp, name + " pipelined")
+    if mode < 2:
+        got = _gpu_batch(gpu_lib, mode, MX["HumanChimpTwo"], -600, -150, alphas, betas, 300, 300)
+        exp = oracle.align_batch(mode, MX["HumanChimpTwo"], -600, -150, alphas, betas, 300, 300, threads=8)
+        common.assert_same(got, exp, name + " pipelined, checkersize 300")
+    # one long pair alone (the cigarToBed shape), and the same launch repeated (progress words are reset per launch)
+    a1, b1 = common.random_pairs(5100 + mode, 1, 2500, 2500, 3000, 3000, related=1.0)
+    for _ in range(2):
+        got = _gpu_batch(gpu_lib, mode, MX["Default"], -400, -30, a1, b1)
+        exp = oracle.align_batch(mode, MX["Default"], -400, -30, a1, b1, threads=1)
+        common.assert_same(got, exp, name + " one long pair")
