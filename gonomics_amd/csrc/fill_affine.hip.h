@@ -14,9 +14,9 @@ namespace {
 //           pair is up to 125 concurrent waves instead of one.  Blocks are ordered (group, strip) and every XCD dispatches
 //           its share in order, so the lowest unfinished block is always resident and never waits: no deadlock; a 5 s
 //           timeout on the spin turns any surprise into an error flag instead of a hang.  An agent-scope release writes the
-//           XCD's dirty L2 lines back (the XCDs' L2s are not coherent with each other), so the direction matrix of such
-//           launches lives in uncached memory -- its stores are full lines that are never read back by the fill -- and the L2
-//           stays clean; the row buffer itself is a few KB per hand-over.
+//           XCD's dirty L2 lines back (the XCDs' L2s are not coherent with each other), so such launches store their
+//           direction words non-temporally -- full lines that the fill never reads back -- and the L2 stays clean; the row
+//           buffer itself is a few KB per hand-over.
 //   P16   = 4*score fits int16: the per-row score profile is stored as packed int16 pairs in LDS
 //   HFORM = gapOpen <= 0 (every caller): with h = max3(M,I,D) the recurrences collapse to
 //           rt = max(h+oe, I+e), dn = max(h+oe, D+e) with identical values AND identical argmax tags
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 }
                 uint4 *dst = trace + pl.trace_off + ((int64_t)(s * pl.words + w) * QA) * G + l;
 #pragma unroll
-                for (int q = 0; q < QA - 1; q++) dst[q * G] = make_uint4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-                dst[(QA - 1) * G] = make_uint4(acc[4 * (QA - 1)], acc[4 * (QA - 1) + 1], 0u, 0u);
+                for (int q = 0; q < QA - 1; q++) trace_store(&dst[q * G], acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], piped);
+                trace_store(&dst[(QA - 1) * G], acc[4 * (QA - 1)], acc[4 * (QA - 1) + 1], 0u, 0u, piped);
             }
             if (store_row) {
                 const int c = t0 + l - 14;

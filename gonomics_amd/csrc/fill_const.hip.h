@@ -155,9 +155,9 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                     for (int d = 0; d < R; d++) acc[d] >>= sh;
                 }
                 uint4 *dst = trace + pl.trace_off + ((int64_t)(s * pl.words + w) * QC) * G + l;
-                dst[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-                dst[G] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
-                dst[2 * G] = make_uint4(acc[8], acc[9], 0u, 0u);
+                trace_store(&dst[0], acc[0], acc[1], acc[2], acc[3], piped);
+                trace_store(&dst[G], acc[4], acc[5], acc[6], acc[7], piped);
+                trace_store(&dst[2 * G], acc[8], acc[9], 0u, 0u, piped);
             }
             if (store_row) {
                 const int c = t0 + l - 14;

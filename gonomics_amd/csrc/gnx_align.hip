@@ -56,16 +56,10 @@ void set_err(const char *fmt, const char *a = "", long long b = 0) { snprintf(g_
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
-    bool uncached = false; // hipDeviceMallocUncached: the direction matrix of pipelined multi-strip launches (see fill_affine_kernel)
     int ensure(size_t bytes) {
         if (bytes <= cap) return GNX_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
-        if (uncached) {
-            if (hipExtMallocWithFlags(&p, want, hipDeviceMallocUncached) != hipSuccess) { p = nullptr; set_err("uncached device allocation of %s%lld bytes failed", "", (long long)want); return GNX_ENOMEM; }
-            cap = want;
-            return GNX_OK;
-        }
         if (hipMalloc(&p, want) != hipSuccess) {
             if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; set_err("device allocation of %s%lld bytes failed", "", (long long)bytes); return GNX_ENOMEM; }
             want = bytes;
@@ -83,7 +77,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf strip_map, trace_uc, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
+    DevBuf strip_map, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -487,17 +481,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         max_t = std::max(max_t, t); max_h = std::max(max_h, h); max_r = std::max(max_r, r); max_d = std::max(max_d, d);
     }
     if ((rc = c.dcol.ensure((size_t)max_d * 4))) return rc;
-    // multi-strip pairs in small launches: pipelined strips, direction matrix in uncached memory (see fill_affine_kernel)
-    bool any_piped = false;
-    for (size_t ch = 0; ch + 1 < chunk_begin.size() && !any_piped; ch++) {
-        const int64_t npc = chunk_begin[ch + 1] - chunk_begin[ch];
-        bool mu = false;
-        int64_t mm = 0;
-        for (int64_t p = chunk_begin[ch]; p < chunk_begin[ch + 1]; p++) { mu = mu || plans[(size_t)p].strips > 1; mm = std::max<int64_t>(mm, plans[(size_t)p].m); }
-        any_piped = mu && (npc + 3) / 4 < 3072 && mm >= 8 * RB_PUB;
-    }
-    c.trace_uc.uncached = true;
-    DevBuf &trbuf = any_piped ? c.trace_uc : c.trace;
+    DevBuf &trbuf = c.trace;
     if ((rc = trbuf.ensure((size_t)max_t * 16))) return rc;
     if ((rc = c.hcol.ensure((size_t)max_h * 4))) return rc;
     if ((rc = c.rowbuf.ensure((size_t)max_r * 8))) return rc;
@@ -534,7 +518,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // with plenty of pairs (or short beta) the strips of a group would only wait for each other
         int64_t m_maxc = 0;
         for (int64_t q2 = b; q2 < e; q2++) m_maxc = std::max<int64_t>(m_maxc, plans[(size_t)q2].m);
-        const bool piped = multi && any_piped && n_blocks < 3072 && m_maxc >= 8 * RB_PUB;
+        const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB;
         if (piped) {
             std::vector<int2> smap;
             for (int gq = 0; gq < (np + 3) / 4; gq++) {
@@ -586,13 +570,22 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
 #define GNX_GSW_TB(R_, W_) hipLaunchKernelGGL((gsw_traceback_kernel<R_, W_>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, d_a, d_as + b, d_b, d_bs + b, kp, d_score + b, d_endpos + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err)
+        // few, long pairs: one wave per pair, diagonal runs 64 cells at a time (traceback_kernel<.., COOP>)
+        int64_t lmax = 0;
+        for (int64_t q2 = b; q2 < e; q2++) lmax = std::max<int64_t>(lmax, std::max<int64_t>(plans[(size_t)q2].n, plans[(size_t)q2].m));
+        const bool coop = !gsw && np <= 2048 && lmax >= 1024;
+        const dim3 gridC((unsigned)np);
         if (gsw == 1) GNX_GSW_TB(false, false);
         else if (gsw == 2) GNX_GSW_TB(true, false);
+        else if (coop && affine) hipLaunchKernelGGL((traceback_kernel<true, false, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
+        else if (coop) hipLaunchKernelGGL((traceback_kernel<false, false, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
         else if (affine) hipLaunchKernelGGL((traceback_kernel<true, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
         else hipLaunchKernelGGL((traceback_kernel<false, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, dn, np, d_ops_off + b, d_carry);
         if (gsw == 1) GNX_GSW_TB(false, true);
         else if (gsw == 2) GNX_GSW_TB(true, true);
+        else if (coop && affine) hipLaunchKernelGGL((traceback_kernel<true, true, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
+        else if (coop) hipLaunchKernelGGL((traceback_kernel<false, true, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
         else if (affine) hipLaunchKernelGGL((traceback_kernel<true, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
         else hipLaunchKernelGGL((traceback_kernel<false, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
 #undef GNX_GSW_TB
@@ -796,7 +789,7 @@ void gnx_shutdown(void) {
     if (!g_ctx.inited) return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&g_ctx.strip_map, &g_ctx.trace_uc, &g_ctx.fp_redo, &g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
+    DevBuf *bufs[] = {&g_ctx.strip_map, &g_ctx.fp_redo, &g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
                       &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
                       &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops, &g_ctx.out_end,
                       &g_ctx.sc_pairs, &g_ctx.sc_mat, &g_ctx.sc_err};

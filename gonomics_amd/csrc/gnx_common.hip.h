@@ -12,6 +12,8 @@
 #include <type_traits>
 #include "gnx_align.h"
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 namespace {
 constexpr int G = 16;            // lanes per pair (one DPP row)
 constexpr int R = 10;            // DP rows per lane
@@ -63,6 +65,13 @@ struct KParams {
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 __device__ __forceinline__ int dpp_shr1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHR1, 0xf, 0xf, false); }
 __device__ __forceinline__ int dpp_shl1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHL1, 0xf, 0xf, false); }
+// direction-matrix store.  Pipelined strips (MULTI kernels, see fill_affine_kernel) publish their bottom row with an agent-scope
+// release, which writes the XCD's dirty L2 lines back: their direction words are stored non-temporally so that they do not pile up
+// as dirty lines (they are full lines that the fill never reads back).
+__device__ __forceinline__ void trace_store(uint4 *dst, unsigned a, unsigned b, unsigned c, unsigned d, bool streaming) {
+    if (streaming) __builtin_nontemporal_store((u32x4){a, b, c, d}, reinterpret_cast<u32x4 *>(dst));
+    else *dst = make_uint4(a, b, c, d);
+}
 __device__ __forceinline__ unsigned alignbit2(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 2); }
 
 } // namespace

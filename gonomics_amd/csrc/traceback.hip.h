@@ -30,14 +30,19 @@ __device__ __forceinline__ unsigned load_word(const uint4 *trace, const PairPlan
     return base[d & 3];
 }
 
-template <bool AFFINE, bool WRITE>
+// COOP: one wave per pair (launches of few, long pairs).  Every lane runs the same walk; a diagonal run is taken 64 cells at a
+// time -- lane t looks at cell (i-t, j-t) and the run goes on while the cells are M cells whose source is M -- instead of
+// ~480 single-lane cycles per cell.  Quirk Q1 changes nothing inside such a run: the entry cell's argmax is M again.
+template <bool AFFINE, bool WRITE, bool COOP = false>
 __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restrict__ plans, int n_pairs, const uint4 *__restrict__ trace,
                                                        const int *__restrict__ hcol, const unsigned *__restrict__ dcol, TbParams tp,
                                                        int64_t *__restrict__ score_out,
                                                        int64_t *__restrict__ nops, const int64_t *__restrict__ ops_off,
                                                        gnx_cigar *__restrict__ ops, int64_t ops_capacity, int *__restrict__ err) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = COOP ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (p >= n_pairs) return;
+    const int lane = threadIdx.x & 63;
+    const bool writer = !COOP || lane == 0;
     const PairPlan pl = plans[p];
     int i = pl.n, j = pl.m;
     int64_t score;
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
         } else { score = (int64_t)(i + j) * tp.gap_open; k = 0; }
     }
     const int po = pl.src; // output slot (== p except for sub-batches routed here by the fast path)
-    if (!WRITE) score_out[po] = score;
+    if (!WRITE && writer) score_out[po] = score;
 
     int64_t cnt = 0;           // runs emitted so far (traceback order)
     int cur_op = -1;
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
     const bool fits = WRITE ? (obase + total <= ops_capacity) : false;
     auto flush_run = [&]() {
         if (cur_op >= 0) {
-            if (WRITE && fits) {
+            if (WRITE && fits && writer) {
                 gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op;
                 for (int z = 0; z < 7; z++) c._pad[z] = 0;
                 ops[obase + (total - 1 - cnt)] = c;
@@ -120,6 +125,19 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
                     }
                     continue;
                 }
+            }
+        }
+        if (COOP && (!AFFINE || k == 0)) { // diagonal run, 64 cells per look
+            const int lim = min(min(i, j), 64);
+            int f = 0;
+            if (lane < lim) { int p2; f = (int)((load_word<AFFINE>(trace, pl, 0, i - lane, j - lane, p2) >> (2 * p2)) & 3u); }
+            const unsigned long long stop = __ballot(!(lane < lim && f == 3));
+            const int T = stop ? __ffsll((long long)stop) - 1 : 64;
+            if (T > 0) {
+                emit(0, T); last_op = 0;
+                i -= T; j -= T;
+                li = ((li - T) % tp.ci + tp.ci) % tp.ci; // T rows up, tile edges included (Q1 restarts in M, the state we are in)
+                continue;
             }
         }
         int pos;
@@ -176,7 +194,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
         else { cur_op = 0; cur_run = 0; } // Go: route == [{0 0}]
     }
     flush_run();
-    if (!WRITE) nops[po] = cnt;
+    if (!WRITE) { if (writer) nops[po] = cnt; }
     else if (!fits) atomicOr(err, 4);
 }
 

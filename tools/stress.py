@@ -28,7 +28,7 @@ def main():
         name, mx = mats[int(rng.integers(len(mats)))]
         go = int(rng.choice([0, -1, -30, -400, -600, -900]))
         ge = int(rng.choice([-1, -30, -55, -150, -400]))
-        kind = int(rng.integers(0, 6))
+        kind = int(rng.integers(0, 7))
         n = int(rng.integers(1, 161))
         cnt = int(rng.integers(1, 40))
         if kind <= 2:  # fast-path shape: short alpha (uniform or mixed lengths), long beta (shared chunk or per-pair windows)
@@ -48,12 +48,23 @@ def main():
                 alphas.append(a[:n])
                 betas.append(chunk[:m] if rng.random() < 0.7 else chunk[int(rng.integers(0, 300)):][:m])
             mode = int(rng.choice([0, 0, 2]))
+        elif kind == 6:  # a few long pairs: pipelined strips + wave-cooperative traceback (general path)
+            cnt = int(rng.integers(1, 6))
+            alphas, betas = common.random_pairs(int(rng.integers(1 << 30)), cnt, 1, 1500, 1024, 2500, related=0.85)
+            mode = int(rng.integers(0, 5))
         else:
             alphas, betas = common.random_pairs(int(rng.integers(1 << 30)), cnt, 1, 300, 1, 900, related=0.7)
             mode = int(rng.integers(0, 5))
         cs = int(rng.choice([10000, 10000, 64, 100, 257, 1000]))
         p = _lib.make_params(mode, mx, go, ge, cs, cs)
-        got = _lib.align_batch(p, alphas, betas)
+        try:
+            got = _lib.align_batch(p, alphas, betas)
+        except _lib.GnxError as ex:
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.savez("gpurun_out/stress_fail.npz", mode=mode, go=go, ge=ge, cs=cs, mx=np.asarray(mx),
+                     alphas=np.array(alphas, dtype=object), betas=np.array(betas, dtype=object))
+            print("ERROR", ex, "kind", kind, "mode", mode, name, go, ge, "cs", cs, "cnt", len(alphas), "n", [len(a) for a in alphas][:8], "m", [len(b) for b in betas][:8])
+            sys.exit(1)
         fp_rounds += _lib.get_timing()["fast_path"]
         exp = oracle.align_batch(mode, mx, go, ge, alphas, betas, cs, cs, threads=8)
         try:
