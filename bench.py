@@ -265,8 +265,10 @@ def main():
             "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "C2 faChunkAlign-style: %d x (150 bp read vs one 10 kb chunk) per GPU, align.AffineGap, "
-                                   "HumanChimpTwoScoreMatrix, gapOpen -600, gapExtend -150, score + full CIGAR" % n_pairs,
+            "config": {"workload": "C2 faChunkAlign-style: %d x (150 bp read vs one 10 kb chunk) per GPU, %s, "
+                                   "HumanChimpTwoScoreMatrix, %s, score + full CIGAR"
+                                   % (n_pairs, {"affine": "align.AffineGap", "const": "align.ConstGap", "local": "align.AffineGapLocal(target=chunk, query=read)"}[args.series],
+                                      "gapPen -430" if args.series == "const" else "gapOpen -600, gapExtend -150"),
                        "pairs_per_gpu": n_pairs, "read_len": READ_LEN, "chunk_len": CHUNK_LEN, "parallelism": "pairs sharded x%d" % world},
             "pairs_per_s": n_pairs * world * args.steps / dt,
             "bit_exact_sample": ok, "bit_exact_pairs_checked": int(min(args.verify, n_pairs)),

@@ -35,7 +35,7 @@ template <bool P16> struct ProfCfg {
     static constexpr int PST = 5 * BST + 16;         // dwords per pair
 };
 
-template <bool LOCAL, bool MULTI, bool P16, bool HFORM, bool WIN = false, bool SCORED = false>
+template <bool LOCAL, bool MULTI, bool P16, bool HFORM, bool WIN = false, bool SCORED = false, bool XP = false>
 __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                          const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                          const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
@@ -47,6 +47,10 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     //      variants, "next" row N1) instead of the LDS profile of alpha x the base of the column; sequences are not read.
     // WIN: window / tile re-fill of the fast path: the left boundary comes from a column checkpoint written by
     //      fp_sweep_kernel (pl.col_off > 0), the row-0 boundary and the beta window start at column col_off.
+    // XP:  window re-fill of the TRANSPOSED free-end-gap fast path (fp_sweep_kernel<.., true>): the gap chains swap their tags
+    //      (tie order M >= D' >= I'), row 0 is free (I'(0,j) = 0) and so is the horizontal step in the last row.
+    static_assert(!XP || (WIN && HFORM && !LOCAL && !MULTI && !SCORED), "XP is a window re-fill variant");
+    constexpr int TI = XP ? 1 : 2, TD = XP ? 2 : 1;
     using PC = ProfCfg<P16>;
     constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
     __shared__ int lds[32 + 4 * PST];
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     int vOE4, vE4, vO4, vE4p2, vE4p1; // constants pinned in VGPRs (2-cycle adds)
     asm volatile("v_mov_b32 %0, %5\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %7\n\tv_mov_b32 %3, %8\n\tv_mov_b32 %4, %9"
                  : "=v"(vOE4), "=v"(vE4), "=v"(vO4), "=v"(vE4p2), "=v"(vE4p1)
-                 : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4), "s"(kp.e4 + 2), "s"(kp.e4 + 1));
+                 : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4), "s"(kp.e4 + TI), "s"(kp.e4 + TD));
     int bad = 0;
 
     const int s_lo = piped ? strip_map[blockIdx.x].y : 0, s_hi = piped ? s_lo + 1 : S_max;
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         for (int q = 0; q < 4; q++) m_min = min(m_min, (pbase + q < n_pairs && s < plans[pbase + q].strips) ? plans[pbase + q].m : 0);
         const bool store_row = MULTI && gact && (s + 1 < pl.strips);
         const int row0 = s * H + l * R; // 0-based index of this lane's first row == 1-based index of the row above it
+        const int r_last = XP ? pl.n - 1 - row0 : -1; // XP: slot of the pair's last row in this lane (if 0 <= r_last < R)
         int rt[R], hold[R];
         unsigned acc[3 * R]; // direction accumulators: [0,R) M, [R,2R) I, [2R,3R) D
         if (!SCORED) { // score profile of this lane's rows: prof[b][lane][k]
@@ -117,15 +122,16 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = row0 + r + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
-            const int D1c = kp.d00_4 + i * kp.ecol4 + 1;
-            hold[r] = max3i(NEG4 + 3, NEG4 + 2, D1c) + XE;
-            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + 2 + E4, D1c + OE4);
+            const int D1c = kp.d00_4 + i * kp.ecol4 + TD;
+            hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c) + XE;
+            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4);
+            if (XP && r == r_last) rt[r] = D1c; // I'(n,1) = h(n,0), no penalty
             if (WIN && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x; hold[r] = v.y; }
             acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
         }
-        int diag0 = ((row0 == 0) ? max3i(3, kp.o4 + 2, kp.d00_4 + 1) : max3i(NEG4 + 3, NEG4 + 2, kp.d00_4 + row0 * kp.ecol4 + 1)) + XE;
+        int diag0 = ((row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD)) + XE;
         if (WIN && ck0) {
-            if (row0 == 0) diag0 = max3i(NEG4 + 3, kp.o4 + pl.col_off * E4 + 2, NEG4 + 1) + XE; // h(0, col_off)
+            if (row0 == 0) diag0 = max3i(NEG4 + 3, (XP ? 0 : kp.o4 + pl.col_off * E4) + TI, NEG4 + TD) + XE; // h(0, col_off)
             else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y;
         }
         int dn_out = 0, h_out = 0, b_out = 0;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
         auto boundary = [&](int c, int &odn, int &oh, int &ob) {
             if (!MULTI || s == 0) {
-                const int M3 = NEG4 + 3, I2 = kp.o4 + ((WIN ? pl.col_off : 0) + c) * E4 + 2, D1 = NEG4 + 1; // row 0: I(0,c) = gapOpen + c*gapExtend
+                const int M3 = NEG4 + 3, I2 = (XP ? 0 : kp.o4 + ((WIN ? pl.col_off : 0) + c) * E4) + TI, D1 = NEG4 + TD; // row 0: I(0,c) = gapOpen + c*gapExtend (XP: free)
                 const int h0 = max3i(M3, I2, D1);
                 odn = (LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4);
                 oh = h0 + XE;
@@ -198,6 +204,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                         rt[r] = max(hoe, Ie);
                         dnn = max(hoe, De);
                         if (LOCAL) dnn = (j == m_eff) ? hnew - vE4 : dnn; // last column: D(i+1,m) = tmt(M,I,D)(i,m), no penalty
+                        if (XP) rt[r] = (r == r_last) ? hnew - vE4 : rt[r]; // transposed: last row, I'(n,j+1) = tmt(M,I',D')(n,j)
                     } else {
                         const int M3 = (hd | 3) + S4;
                         const int I2 = (rt[r] & ~3) | 2;

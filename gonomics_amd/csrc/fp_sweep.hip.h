@@ -21,6 +21,18 @@ namespace {
 //    boundary constant passed as `old`.
 //  * int16 score profile (4*(s-2e)) read as 5 ds_read_b64 per step: an LDS read costs the issuing SIMD ~2 cycles + 2 per
 //    returned dword (tools/lds_ubench.hip), so 20 rows cost 30 cycles for 8 pairs instead of 60 for 4.
+// XP = the same sweep for AffineGapLocal(target = long, query = short), TRANSPOSED: rows = query, columns = target, so that the
+//    short sequence is again the one held in lanes.  The transposed horizontal state I' is the reference's D and the vertical
+//    D' its I, which changes two things:
+//      * tie order M >= D' >= I': the tag constants of the two gap chains swap (I' carries 1, D' carries 2);
+//      * the free end gaps (affineGap_highMem.go:188-210: D(i,0) = 0, and D(i+1,m) = tmt(M,I,D)(i,m) at no cost in the last
+//        column) become a free row 0, h(0,j) = I'(0,j) = 0, and a free horizontal step in the LAST ROW,
+//        I'(n,j+1) = h(n,j) with h's tag.  Rebased, row 0 is R(j) = -e*j: the first lane's boundary values grow by -e per
+//        step (two extra adds); the last row opens its horizontal gap with -e instead of o (a per-lane constant in the last
+//        slot: h' - e > I' always, so the shared max is the reference's single candidate); and the padding slots above row 1
+//        are FAKE ROWS with profile entry -e, whose diagonal candidate R(j-1) - e = R(j) reproduces row 0 column by column
+//        (their gap candidates R(j) + o and R(j-1) + o never exceed it), so the first real row sees exactly row 0 above it.
+//    Needs gapExtend < 0 (strictly) besides gapOpen <= 0.
 // Outputs (what fp_walk_kernel and the window re-fills of fill_affine_kernel<.., WIN> consume): un-rebased, tagged column
 // checkpoints {rt = I(i,j+1), X = h(i,j)+e} of every row every CKW columns, the I-plane words of rows n..n-3
 // (word = step >> 4, field = step & 15 with step = j + 7), and h(n,m).
@@ -43,7 +55,7 @@ __device__ __forceinline__ int dpp_next8(int src) { // every lane of the two ban
 
 // 2 waves per SIMD by choice: capping the kernel at 168 VGPRs for a third wave makes the compiler shuffle registers in the
 // unrolled loop and costs 20 % (measured: 32.2 ms vs 38.6-40.6 ms per 100 k pairs); 16 000 B of LDS allow 10 waves per CU.
-template <int RR>
+template <int RR, bool XP = false>
 __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                       const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
@@ -55,8 +67,9 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     const int g = lane >> 3;
     const int lp = (lane & 8) ? 15 - (lane & 15) : (lane & 7); // position of the lane inside its pair
     const int E4 = kp.e4;
+    constexpr int TI = XP ? 1 : 2, TD = XP ? 2 : 1; // tags of the horizontal / vertical gap state (tie order, see above)
     if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * E4;
-    else if (lane < 32) lds[lane] = -32768; // padding rows: the diagonal candidate never wins
+    else if (lane < 32) lds[lane] = XP ? -E4 : -32768; // padding rows: the diagonal candidate never wins (XP: fake rows that repeat row 0)
     int *prof = &lds[32 + g * FP8_PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + lp * FP8_LW);
 
@@ -77,7 +90,12 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     const int q0 = lp * RR;       // first slot of this lane; slot q holds row q - P + 1
     int bad = 0;
     int vO4, cH, cDN; // constants pinned in VGPRs (2-cycle adds, DPP `old` operands)
-    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vO4), "=v"(cH), "=v"(cDN) : "s"(kp.o4), "s"(kp.o4 + 2), "s"(2 * kp.o4 + 2));
+    // XP: the first lane's boundary is row 0 = R(j) = -e*j: h'(0,t) = R(t), D'(1,t) = R(t) + o at step t, advanced by vInc after
+    // every DPP move (the values below are those of "step -1")
+    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vO4), "=v"(cH), "=v"(cDN)
+                 : "s"(kp.o4), "s"(XP ? E4 + TI : kp.o4 + 2), "s"(XP ? kp.o4 + E4 + TI : 2 * kp.o4 + 2));
+    const int vInc = (XP && lp == 0) ? -E4 : 0;
+    const int vO4L = (XP && lp == G8 - 1) ? -E4 : kp.o4; // horizontal open of the last slot: the last row's step is free (XP)
 
     { // int16 profile of this lane's rows: prof[b][lp][r] = 4*(scores[alpha[row]][b] - 2e), padding -32768
         int a5[2 * FP8_LW];
@@ -100,13 +118,14 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
 #pragma unroll
     for (int r = 0; r < RR; r++) {
         const int q = q0 + r;
-        // column 0: real row i: h'(i,0) = D'(i,0) = o (tag 1), I'(i,1) = 2o (from D); padding: h' = I' = o; the slot above row 1 is h(0,0) = 0 (tag 3)
-        hold[r] = (q >= P) ? kp.o4 + 1 : (q == P - 1 ? 3 : kp.o4 + 2);
-        rt[r] = (q >= P) ? 2 * kp.o4 + 1 : kp.o4 + 2;
+        // column 0: real row i: h'(i,0) = D'(i,0) = o (tag D), I'(i,1) = 2o (from D); padding: h' = I' = o; the slot above row 1 is h(0,0) = 0 (tag 3)
+        // XP: padding = fake rows, h' = R(0) = 0 and an I' that never wins; the last row's I'(n,1) = h(n,0) at no cost
+        hold[r] = (q >= P) ? kp.o4 + TD : ((XP || q == P - 1) ? 3 : kp.o4 + 2);
+        rt[r] = (q >= P) ? kp.o4 + TD + (r == RR - 1 ? vO4L : kp.o4) : (XP ? kp.o4 : kp.o4 + 2);
     }
     unsigned accR[FP_PLANES] = {0u, 0u, 0u, 0u}; // I-planes of rows n-d = slots RR-1-d of the last lane
     unsigned tailw = 0; // argmax tags of h(n-d, m-x), d, x = 0..3, field 4x + d: lets the walk take its first diagonal steps without a window
-    int diag0 = (q0 == 0) ? (P == 0 ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + 1 : (q0 - 1 == P - 1 ? 3 : kp.o4 + 2));
+    int diag0 = (q0 == 0) ? ((XP || P == 0) ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + TD : ((XP || q0 - 1 == P - 1) ? 3 : kp.o4 + 2));
     int dn_out = 0, h_out = 0, b_out = 0;
     int up_dn = cDN, up_h = cH;
     auto base_of = [&](int c) { // LDS byte offset of the profile plane of beta[c] (column c, 1-based)
@@ -123,6 +142,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
         // as `old` (its first lane already holds that constant) lets the move happen in place, without a copy of the constant.
         up_dn = dpp_prev8(up_dn, dn_out);
         up_h = dpp_prev8(up_h, h_out);
+        if (XP) { up_dn += vInc; up_h += vInc; }
         const int pb = dpp_prev8(qb, b_out);
         qb = dpp_next8(qb);
         const int j = t - lp;
@@ -146,10 +166,10 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
                     dnn = max(ho, dnu);
                 } else {
                     const int M3 = (hd | 3) + S4;
-                    const int I2 = (rt[r] & ~3) | 2;
-                    const int D1 = (dnu & ~3) | 1;
+                    const int I2 = (rt[r] & ~3) | TI;
+                    const int D1 = (dnu & ~3) | TD;
                     hnew = max3i(M3, I2, D1);
-                    const int ho = hnew + vO4;
+                    const int ho = hnew + ((XP && r == RR - 1) ? vO4L : vO4);
                     rt[r] = max(ho, I2);
                     dnn = max(ho, D1);
                 }

@@ -13,6 +13,9 @@ namespace {
 //   recording; the next fp_walk call continues inside that window.  Row 0 / column 0 end the walk (Step 4).
 //   CIGAR runs are staged per pair in traceback order and reversed into place by fp_compact.
 // Same checkerboard-walk emulation (Q1/Q2) as traceback_kernel.
+// XP = walk of the transposed free-end-gap sweep (fp_sweep_kernel<.., true>): states stay k = 1 horizontal / 2 vertical, but
+//   the tags of the two gap states are swapped (1 = horizontal I', 2 = vertical D') and a horizontal step is the reference's
+//   ColD, a vertical one its ColI.
 // ------------------------------------------------------------------------------------------------------
 struct FpState {
     int32_t i, j, k, last_op;
@@ -22,7 +25,7 @@ struct FpState {
     int32_t j_hi, jc_lo;
 };
 
-template <bool FIRST, bool TILED = false>
+template <bool FIRST, bool TILED = false, bool XP = false>
 __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
                                                      FpState *__restrict__ states, const int *__restrict__ hcol_fwd,
                                                      const unsigned *__restrict__ rowi, const unsigned *__restrict__ tail,
@@ -35,12 +38,15 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
     if (a >= n_active) return;
     const int p = FIRST ? a + p_base : active[a];
     const PairPlan pl = plans[p];
+    auto k_of = [](int tag) { return XP ? (tag == 3 ? 0 : tag) : 3 - tag; }; // state of a direction tag
+    auto op_of = [](int k) { return XP ? (k == 0 ? 0 : 3 - k) : k; };         // CIGAR op of a step taken in state k
+    constexpr unsigned IRUN = XP ? 0x55555555u : 0xAAAAAAAAu;                // 16 fields "horizontal gap extended"
     FpState st;
     PairPlan wp;
     if (FIRST) {
         const int hc = hcol_fwd[pl.hcol_off];
         score_out[p] = (int64_t)(hc >> 2);
-        st.i = pl.n; st.j = pl.m; st.k = 3 - (hc & 3); st.last_op = -1;
+        st.i = pl.n; st.j = pl.m; st.k = k_of(hc & 3); st.last_op = -1;
         st.cur_op = -1; st.cnt = 0; st.status = 0; st.slot = -1; st.cur_run = 0;
         st.li = (int64_t)(pl.n - 1) % tp.ci;
         st.j_hi = 0; st.jc_lo = 0; // empty window
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         if (k == 1) {
             int avail = min(pos + 1, j);
             if (!on_plane) avail = min(avail, j - lo_ok(st.jc_lo) + 1); // do not run past the window's usable left edge
-            unsigned x = w ^ 0xAAAAAAAAu;
+            unsigned x = w ^ IRUN;
             if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
             const int lowcut = pos + 1 - avail;
             if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
@@ -110,9 +116,9 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                 tag = (int)((w >> (2 * pnz)) & 3u);
                 if (tag == 0) { atomicOr(err, 2); done = true; break; }
                 steps = pos - pnz + 1;
-                k = 3 - tag;
+                k = k_of(tag);
             }
-            emit(1, steps); j -= steps; last_op = 1;
+            emit(op_of(1), steps); j -= steps; last_op = 1;
             if (on_plane && x == 0 && steps == pos + 1) {
                 // the run continues below field 0 of this word: take whole 16-column words while they are all-I, four loads in
                 // flight (a 10 kb trailing gap is 600 dependent loads otherwise).  Only on the stored planes, where the lanes of
@@ -126,34 +132,34 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                     for (int u = 0; u < 4; u++) q[u] = (wi - u >= 0) ? wbase[wi - u] : 0u;
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        if (more && q[u] == 0xAAAAAAAAu && j >= 16) { emit(1, 16); j -= 16; wi--; }
+                        if (more && q[u] == IRUN && j >= 16) { emit(op_of(1), 16); j -= 16; wi--; }
                         else more = false;
                     }
                 }
             }
             continue;
         }
-        emit(k, 1);
+        emit(op_of(k), 1);
         last_op = k;
         bool up_exit = false;
         if (k != 1) { up_exit = (li == 0); li = up_exit ? tp.ci - 1 : li - 1; i--; }
         if (k != 2) j--;
-        k = 3 - tag;
+        k = k_of(tag);
         if (up_exit && i > 0 && j > 0) { // quirk Q1: restart in the argmax state of the entry cell (i, j)
             int ht;
             if (tail_ok(i, j)) ht = (int)tail_tag(i, j);
             else if (j <= st.jc_lo) { atomicOr(err, 2); done = true; break; } // cannot happen: column jc_lo + 1 is never walked
             else if (j < st.j_hi) { int p2; ht = (int)((load_word<true>(wtrace, wp, 0, i + 1, j + 1 - st.jc_lo, p2) >> (2 * p2)) & 3u); }
             else ht = whcol[wp.hcol_off + i - 1] & 3;
-            k = 3 - ht;
+            k = k_of(ht);
         }
     }
     if (done) {
         // Step 4 (affineGap.go:135-139)
         const bool up_exit = (last_op != 1) && ((int64_t)i % tp.ci == 0);
         const bool left_exit = (last_op != 2) && ((int64_t)j % tp.cj == 0);
-        if (!up_exit && left_exit) emit(2, i);
-        else if (up_exit && !left_exit) emit(1, j);
+        if (!up_exit && left_exit) emit(op_of(2), i);
+        else if (up_exit && !left_exit) emit(op_of(1), j);
         flush_run();
         cur_op = -1;
         nops[p] = cnt;

@@ -152,8 +152,10 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                   const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                   const int64_t *h_alen, const int64_t *h_blen, int rows_per_lane,
                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
-                  int64_t *out_total, hipStream_t stream, bool first) {
+                  int64_t *out_total, hipStream_t stream, bool first, bool xp) {
     // rows_per_lane: 19 (every n <= 152) or 20 (n <= 160) -> fp_sweep_kernel<19 / 20>
+    // xp: AffineGapLocal, transposed -- the caller passes the query as "a" (rows) and the target as "b" (columns), and kp holds the
+    //     transposed score table with the column-0 boundary of a global alignment (fp_sweep_kernel<.., true> and friends)
     Ctx &c = g_ctx;
     int rc;
     const int np = (int)n_pairs;
@@ -213,8 +215,8 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
 
     auto forward = [&](int p0, int cnt, hipStream_t st) -> int {
         const dim3 grid8((unsigned)((cnt + G8 - 1) / G8));
-        if (rows_per_lane == 19) hipLaunchKernelGGL(fp_sweep_kernel<19>, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err);
-        else hipLaunchKernelGGL(fp_sweep_kernel<20>, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err);
+        auto k = xp ? (rows_per_lane == 19 ? fp_sweep_kernel<19, true> : fp_sweep_kernel<20, true>) : (rows_per_lane == 19 ? fp_sweep_kernel<19, false> : fp_sweep_kernel<20, false>);
+        hipLaunchKernelGGL(k, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err);
         HIPCHK(hipGetLastError());
         return GNX_OK;
     };
@@ -225,7 +227,11 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * G;
         int cur = 0, n_act = 0, it = 0;
         float f = 0;
-        hipLaunchKernelGGL(fp_walk_kernel<true>, dim3((unsigned)((cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_tail,
+        auto k_first = xp ? fp_walk_kernel<true, false, true> : fp_walk_kernel<true, false, false>;
+        auto k_next = xp ? fp_walk_kernel<false, false, true> : fp_walk_kernel<false, false, false>;
+        auto k_tiled = xp ? fp_walk_kernel<false, true, true> : fp_walk_kernel<false, true, false>;
+        auto k_win = xp ? fill_affine_kernel<false, false, false, true, true, false, true> : fill_affine_kernel<false, false, false, true, true, false, false>;
+        hipLaunchKernelGGL(k_first, dim3((unsigned)((cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_tail,
                            (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, d_wpl[0] + p0, d_err, p0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&n_act, cnt2, 4, hipMemcpyDeviceToHost, st));
@@ -234,11 +240,11 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
             const int nxt = cur ^ 1;
             HIPCHK(hipMemsetAsync(cnt2 + nxt, 0, 4, st));
             HIPCHK(hipEventRecord(e1, st));
-            hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, true>), dim3((unsigned)((n_act + 3) / 4)), blockF, 0, st, d_wpl[cur] + p0, n_act, d_a, d_as, d_b, d_bs, kp,
-                               wtr, whc, (int2 *)nullptr, wdc, d_ckpt, d_err);
+            hipLaunchKernelGGL(k_win, dim3((unsigned)((n_act + 3) / 4)), blockF, 0, st, d_wpl[cur] + p0, n_act, d_a, d_as, d_b, d_bs, kp,
+                               wtr, whc, (int2 *)nullptr, wdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(e2, st));
-            hipLaunchKernelGGL(fp_walk_kernel<false>, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
+            hipLaunchKernelGGL(k_next, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
                                d_wpl[cur] + p0, wtr, whc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, d_wpl[nxt] + p0, d_err, 0);
             HIPCHK(hipGetLastError());
             int n_next = 0;
@@ -266,11 +272,11 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
             uint4 *ttr = reinterpret_cast<uint4 *>(c.fp_ttrace.p);
             hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, dpl, d_act[cur] + p0, n_strag, tiles_per, d_st, tpl);
             HIPCHK(hipEventRecord(e1, st));
-            hipLaunchKernelGGL((fill_affine_kernel<false, false, false, true, true>), dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, st, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
-                               ttr, thc, (int2 *)nullptr, tdc, d_ckpt, d_err);
+            hipLaunchKernelGGL(k_win, dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, st, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
+                               ttr, thc, (int2 *)nullptr, tdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
             HIPCHK(hipEventRecord(e2, st));
             HIPCHK(hipMemsetAsync(cnt2, 0, 8, st));
-            hipLaunchKernelGGL((fp_walk_kernel<false, true>), dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_strag, d_st, d_hfwd, d_rowi, d_tail,
+            hipLaunchKernelGGL(k_tiled, dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_strag, d_st, d_hfwd, d_rowi, d_tail,
                                tpl, ttr, thc, tp, d_stage, d_score, d_nops, d_act[cur ^ 1] + p0, cnt2, d_wpl[cur ^ 1] + p0, d_err, 0);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));
@@ -296,7 +302,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[3]));
     HIPCHK(hipEventElapsedTime(&fa, c.ev[0], c.ev[1]));
     const double forward_ms = (double)fa;
-    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] forward sweep (fp_sweep_kernel<%d>): %d pairs %.3f ms\n", rows_per_lane, np, fa);
+    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] forward sweep (fp_sweep_kernel<%d%s>): %d pairs %.3f ms\n", rows_per_lane, xp ? ", transposed" : "", np, fa);
     if (first) c.timing = gnx_timing{};
     c.timing.fill_ms += forward_ms + refill_ms; c.timing.traceback_ms += std::max(0.0, (double)tot - fa - refill_ms); c.timing.total_ms += tot;
     c.timing.cells += cells; c.timing.n_launches += 1; c.timing.trace_bytes += (int64_t)coff * 8 + (int64_t)roff * 4;
@@ -333,7 +339,8 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         HIPCHK(hipGetLastError());
         const gnx_timing saved = c.timing;
         int64_t tot2 = 0;
-        rc = run_device(prm, ns, d_a, s_as, d_b, s_bs, sal.data(), sbl.data(), s_sc, s_ops, sub_total + 1, s_off, &tot2, stream, nullptr, nullptr, 0, nullptr, true);
+        if (xp) rc = run_device(prm, ns, d_b, s_bs, d_a, s_as, sbl.data(), sal.data(), s_sc, s_ops, sub_total + 1, s_off, &tot2, stream, nullptr, nullptr, 0, nullptr, true);
+        else rc = run_device(prm, ns, d_a, s_as, d_b, s_bs, sal.data(), sbl.data(), s_sc, s_ops, sub_total + 1, s_off, &tot2, stream, nullptr, nullptr, 0, nullptr, true);
         const double redo_ms = c.timing.total_ms;
         c.timing = saved;
         c.timing.traceback_ms += redo_ms; c.timing.total_ms += redo_ms;
@@ -380,13 +387,17 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     // ---- fast path: every alpha fits one strip, long beta, global affine with gapOpen <= 0 ----
     {
         const char *fpenv = getenv("GNX_FASTPATH");
-        bool fp = affine && !local && !d_smat && !no_fast_path && prm->gap_open <= 0 && !(fpenv && fpenv[0] == '0');
+        bool fp = affine && !d_smat && !no_fast_path && prm->gap_open <= 0 && !(fpenv && fpenv[0] == '0');
+        // AffineGapLocal(target, query): the same sweep on the transposed problem (rows = query), see fp_sweep_kernel<.., XP>
+        const bool xp = local;
+        if (xp && (prm->gap_extend >= 0 || prm->gap_extend <= -8000)) fp = false;
+        const int64_t *h_rows = xp ? h_blen : h_alen, *h_cols = xp ? h_alen : h_blen;
         // fp_sweep_kernel keeps an int16 profile of 4*(s - 2e); its padding rows need 4*|gapOpen| well inside int16
         if (prm->gap_open <= -8000) fp = false;
         for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * prm->gap_extend); if (v > 32767 || v < -32000) fp = false; }
         int64_t n_hi = 0;
         for (int64_t p = 0; fp && p < n_pairs; p++) {
-            const int64_t n = h_alen[p], m = h_blen[p];
+            const int64_t n = h_rows[p], m = h_cols[p];
             if (n < 1 || n > H || m < (fpenv && fpenv[0] == '2' ? 1 : 768) || m > 0x3fffffff) fp = false;
             else if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) fp = false;
             n_hi = std::max(n_hi, n);
@@ -399,17 +410,24 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             size_t acc_b = 0;
             const size_t budget = (size_t)(c.ws_limit - c.ws_limit / 8);
             for (int64_t p = 0; p < n_pairs; p++) {
-                const size_t b = fixed + (size_t)((h_blen[p] - 1) / CKW) * h_alen[p] * 8 + (size_t)FP_PLANES * ((h_blen[p] + 30) / 16) * 4;
+                const size_t b = fixed + (size_t)((h_cols[p] - 1) / CKW) * h_rows[p] * 8 + (size_t)FP_PLANES * ((h_cols[p] + 30) / 16) * 4;
                 if (b > budget) { fp = false; break; }
                 if (acc_b + b > budget) { cb.push_back(p); acc_b = 0; }
                 acc_b += b;
             }
             cb.push_back(n_pairs);
             rc = -1;
+            KParams kpx = kp;
+            if (xp) { // transposed score table; column 0 of the transposed problem is the reference's row 0: an ordinary gap
+                for (int a = 0; a < 5; a++) for (int b2 = 0; b2 < 5; b2++) kpx.sc4[a * 5 + b2] = kp.sc4[b2 * 5 + a];
+                kpx.d00_4 = kp.o4; kpx.ecol4 = kp.e4;
+            }
             for (size_t ch = 0; fp && ch + 1 < cb.size(); ch++) {
                 const int64_t b = cb[ch], e = cb[ch + 1];
-                rc = run_device_fp(prm, kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
-                                   d_ops_off + b, out_total, stream, ch == 0);
+                if (xp) rc = run_device_fp(prm, kpx, tp, e - b, d_b, d_bs + b, d_a, d_as + b, h_blen + b, h_alen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
+                                           d_ops_off + b, out_total, stream, ch == 0, true);
+                else rc = run_device_fp(prm, kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
+                                        d_ops_off + b, out_total, stream, ch == 0, false);
                 if (rc != GNX_OK) break;
             }
             if (fp && rc != -1) return rc;

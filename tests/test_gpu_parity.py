@@ -379,10 +379,69 @@ def test_fast_path_long_cigars_redo_only_those_pairs(gpu_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [41, 42, 43])
+def test_fast_path_local_transposed(gpu_lib, seed, monkeypatch):
+    """AffineGapLocal(target = long alpha, query = short beta) runs the fast path on the transposed problem
+    (fp_sweep_kernel<.., XP>: swapped gap tags, free row 0, free last-row step, fake padding rows): every query length
+    1..160, ragged target lengths around the checkpoint spacing, queries placed at the target's ends and in the middle,
+    unrelated queries, several penalty sets; forced onto the fast path for short targets too."""
+    monkeypatch.setenv("GNX_FASTPATH", "2")
+    rng = np.random.default_rng(seed)
+    ref = rng.integers(0, 4, size=4000, dtype=np.uint8)
+    ref[rng.integers(0, 4000, size=8)] = 4
+    q_hi = [152, 160, 40][seed - 41]
+    targets, queries = [], []
+    for k in range(200):
+        n = int(rng.integers(1, q_hi + 1)) if k >= 12 else [1, 2, 3, 4, 5, q_hi, q_hi - 1, 19, 20, 21, 8, q_hi - 8][k]
+        n = max(1, min(n, q_hi))
+        m = int(rng.choice([1, 7, 8, 9, 15, 16, 17, 127, 128, 129, 255, 256, 257, 300, 1000, 1500, 2049]))
+        off = int(rng.integers(0, 4000 - m + 1))
+        target = ref[off:off + m].copy()
+        where = k % 4
+        pos = 0 if where == 0 else (max(0, m - n) if where == 1 else int(rng.integers(0, max(1, m - n + 1))))
+        query = common.mutate(rng, target[pos:pos + n], 0.05, 0.02) if m >= n and rng.random() < 0.8 else rng.integers(0, 4, size=n, dtype=np.uint8)
+        query = query[:q_hi] if query.shape[0] > 0 else np.array([1], dtype=np.uint8)
+        targets.append(target); queries.append(query)
+    for name, go, ge in [("HumanChimpTwo", -600, -150), ("Default", -400, -30), ("HumanChimpTwo", 0, -150), ("MouseRat", -3, -1)]:
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_LOCAL, MX[name], go, ge)
+        got = gpu_lib.align_batch(p, targets, queries)
+        if go == -600:
+            assert gpu_lib.get_timing()["fast_path"] == 1
+        exp = oracle.align_batch(3, MX[name], go, ge, targets, queries, threads=8)
+        common.assert_same(got, exp, "local transposed %s %d %d" % (name, go, ge))
+    # gapExtend = 0 is not eligible (the free last-row step must beat the extension strictly): general path, same answers
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_LOCAL, MX["Default"], -3, 0)
+    got = gpu_lib.align_batch(p, targets[:64], queries[:64])
+    assert gpu_lib.get_timing()["fast_path"] == 0
+    common.assert_same(got, oracle.align_batch(3, MX["Default"], -3, 0, targets[:64], queries[:64], threads=8), "local, gapExtend 0")
+
+
+@pytest.mark.gpu
+def test_fast_path_local_c2_series(gpu_lib):
+    """Second series of C2: AffineGapLocal(target = chunk, query = read), default dispatch."""
+    reads, chunk = common.c2_workload(23, 500, read_len=150, chunk_len=3000)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_LOCAL, align.HumanChimpTwoScoreMatrix, -600, -150)
+    queries = [reads[k, :150 - (k % 5)] for k in range(reads.shape[0])]
+    got = gpu_lib.align_batch(p, [chunk] * len(queries), queries)
+    if os.environ.get("GNX_FASTPATH", "1") != "0":
+        assert gpu_lib.get_timing()["fast_path"] == 1
+    exp = oracle.align_batch(3, MX["HumanChimpTwo"], -600, -150, [chunk] * len(queries), queries, threads=8)
+    common.assert_same(got, exp, "C2 local series")
+    # cheap gaps: some CIGARs overflow the staging area and are redone on the general path in the original orientation
+    rng = np.random.default_rng(78)
+    queries = [(chunk[o:o + 280:2][:140].copy() if k % 11 == 3 else common.mutate(rng, chunk[o:o + 150], 0.02, 0.005)[:150])
+               for k, o in enumerate(rng.integers(0, 2500, size=96))]
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_LOCAL, MX["Default"], -30, -10)
+    got = gpu_lib.align_batch(p, [chunk] * 96, queries)
+    exp = oracle.align_batch(3, MX["Default"], -30, -10, [chunk] * 96, queries, threads=8)
+    common.assert_same(got, exp, "local, long CIGARs redone")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,name", MODES)
 def test_pipelined_strips(gpu_lib, mode, name):
     """Small launches of multi-strip pairs with beta >= 1024 run their strips as pipelined workgroups (per-strip row buffer,
-    progress words, uncached direction matrix): ragged lengths, one-strip pairs in the same launch, checkerboards, and a launch
+    progress words, non-temporal direction stores): ragged lengths, one-strip pairs in the same launch, checkerboards, and a launch
     big enough to fall back to one wave per 4 pairs must all equal the oracle."""
     lo = 0 if mode >= 2 else 1
     alphas, betas = common.random_pairs(5000 + mode, 40, lo, 900, 1024, 1500, related=0.8)

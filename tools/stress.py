@@ -47,7 +47,9 @@ def main():
                     a = np.concatenate([a, rng.integers(0, 4, size=n - len(a)).astype(np.uint8)])
                 alphas.append(a[:n])
                 betas.append(chunk[:m] if rng.random() < 0.7 else chunk[int(rng.integers(0, 300)):][:m])
-            mode = int(rng.choice([0, 0, 2]))
+            mode = int(rng.choice([0, 0, 2, 3, 3]))
+            if mode == 3:  # AffineGapLocal(target, query): the transposed fast path
+                alphas, betas = betas, alphas
         elif kind == 6:  # a few long pairs: pipelined strips + wave-cooperative traceback (general path)
             cnt = int(rng.integers(1, 6))
             alphas, betas = common.random_pairs(int(rng.integers(1 << 30)), cnt, 1, 1500, 1024, 2500, related=0.85)
