@@ -4,22 +4,21 @@
 //   align/affineGap.go:59-344, align/constGap.go:13-311, align/affineGap_highMem.go:57-223,
 //   align/constGap_highMem.go:11-67, align/align.go:76-90 (tripleMaxTrace tie order M >= I >= D).
 //
-// How (MI355X-first, nothing here is a translation of the Go loops):
-//   * FILL kernel: one 16-lane DPP row per pair (4 pairs per wave64), each lane owns R consecutive DP rows
-//     (alpha), the wave sweeps the columns (beta) as an anti-diagonal wavefront: lane l works on column
-//     t-l at step t.  The only cross-lane traffic is two `row_shr:1` DPP moves per step.  Cells are int32
-//     "keys" = 4*score + tag (tag 3/2/1 = came-from M/I/D), so v_max3_i32 returns value AND argmax with the
-//     reference's tie order, and the 2-bit direction is the low bits of the winner.  Per cell:
-//       h  = max3(M,I,D)            (feeds M of the lower-right neighbour and is the cell's argmax)
-//       rt = max3(M+oe, I+e, D+oe)  (feeds I of the right neighbour)
-//       dn = max3(M+oe, I+oe, D+e)  (feeds D of the lower neighbour)
-//     Direction bits are shifted into 3 accumulators per row with v_alignbit and flushed every 16 steps
-//     as 8 coalesced 16-byte stores per lane (6 bits/cell of HBM write traffic, the algorithmic minimum).
-//     Sequences longer than 16*R rows are processed as strips with a row buffer in HBM in between.
-//   * TRACEBACK kernel (separate launch, one lane per pair): walks the bit-packed direction matrix,
-//     emulating the reference's checkerboard walk (state reset when a tile is left through its top edge,
-//     dropped leading gap on a corner exit) from global coordinates, run-length encodes, two passes
-//     (count, exclusive scan, write) so CIGARs are emitted densely in input order.
+// How (MI355X-first, nothing here is a translation of the Go loops; details in DESIGN.md section 4 and in the kernel headers):
+//   * Cells are int32 "keys" = 4*score + tag (tag 3/2/1 = came-from M/I/D), so v_max3_i32 returns value AND argmax with the
+//     reference's tie order, and the 2-bit direction is the low bits of the winner.  With h = max3(M,I,D) and gapOpen <= 0 the
+//     Gotoh recurrences collapse to  rt = max(h+oe, I+e), dn = max(h+oe, D+e)  with identical values and tags ("h-form").
+//   * GENERAL path (any shape): fill kernels with one 16-lane DPP row per pair (4 pairs per wave64), each lane owns R = 10
+//     consecutive DP rows (alpha), the wave sweeps the columns (beta) as an anti-diagonal wavefront; cross-lane traffic is
+//     three `row_shr:1` DPP moves per step.  Direction bits are shifted into accumulators with v_alignbit and flushed every 16
+//     steps as coalesced 16-byte stores (6 bits/cell affine, 2 bits/cell const).  Longer alpha = 160-row strips with a row buffer
+//     in HBM; small launches run the strips as pipelined workgroups.  A separate traceback kernel walks the packed matrix
+//     (one lane per pair, or one wave per pair for long pairs), emulating the reference's checkerboard quirks, two passes
+//     (count, exclusive scan, write) so CIGARs come out densely in input order.
+//   * FAST path (short read x long window, affine; the headline workload; AffineGapLocal runs it transposed): fp_sweep_kernel
+//     computes scores only -- 8 lanes x 19/20 rows per pair, rebased keys (5 VALU instructions per cell), column checkpoints
+//     every 128 columns, the I-planes of the last four rows -- and fp_walk_kernel re-fills just the <= 319 columns around the
+//     path with the general kernel (WIN) to read its direction bits.
 //   * No MFMA: this is an integer max-plus recurrence.  No CPU fallback: every entry point needs the GPU.
 //
 // Source layout (one translation unit):

@@ -88,7 +88,7 @@ typedef struct gnx_timing {
     double dominant_ms;  /* summed duration of the dominant kernel's launches (fast path: the forward sweep; general
                             path: the fill kernel) -- what roofline.achieved is computed from */
     int64_t dominant_launches;
-    int32_t fast_path;   /* 1 if the short-alpha fast path ran */
+    int32_t fast_path;   /* 1 if the fast path ran (short alpha x long beta; AffineGapLocal: short query x long target) */
     int32_t _pad;
 } gnx_timing;
 
