@@ -10,13 +10,11 @@ namespace {
 //   MULTI = some pair of the launch has more than one 160-row strip.  When the launch has too few pairs to fill the GPU with
 //           one wave per 4 pairs (host decision: strip_map != nullptr), the strips of a pair run as separate workgroups,
 //           pipelined: block (group of 4 pairs, strip s) reads the bottom row of strip s-1 from the row buffer once the block
-//           before it has published it (strip_prog; release / acquire at agent scope, every RB_PUB steps).  A 20 kb x 100 kb
+//           before it has published it (strip_prog, every RB_PUB steps; rows and progress word are agent-scope atomics, see rb_store).  A 20 kb x 100 kb
 //           pair is up to 125 concurrent waves instead of one.  Blocks are ordered (group, strip) and every XCD dispatches
 //           its share in order, so the lowest unfinished block is always resident and never waits: no deadlock; a 5 s
-//           timeout on the spin turns any surprise into an error flag instead of a hang.  An agent-scope release writes the
-//           XCD's dirty L2 lines back (the XCDs' L2s are not coherent with each other), so such launches store their
-//           direction words non-temporally -- full lines that the fill never reads back -- and the L2 stays clean; the row
-//           buffer itself is a few KB per hand-over.
+//           timeout on the spin turns any surprise into an error flag instead of a hang.  Such launches store their direction
+//           words non-temporally (full lines that the fill never reads back).
 //   P16   = 4*score fits int16: the per-row score profile is stored as packed int16 pairs in LDS
 //   HFORM = gapOpen <= 0 (every caller): with h = max3(M,I,D) the recurrences collapse to
 //           rt = max(h+oe, I+e), dn = max(h+oe, D+e) with identical values AND identical argmax tags
@@ -145,7 +143,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 odn = (LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4);
                 oh = h0 + XE;
             } else if (c >= 1 && c <= m_eff) {
-                const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c];
+                const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
                 odn = v.x; oh = v.y; // already in the X domain
             } else { odn = 0; oh = 0; }
             int b = 0;
@@ -158,7 +156,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
                 const long long t_begin = wall_clock64();
-                while ((rb_seen = __hip_atomic_load(&strip_prog[blockIdx.x - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < cmax) {
+                while ((rb_seen = rb_progress(&strip_prog[blockIdx.x - 1])) < cmax) {
                     __builtin_amdgcn_s_sleep(32);
                     if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; } // 5 s at 100 MHz
                 }
@@ -257,12 +255,9 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             }
             if (store_row) {
                 const int c = t0 + l - 14;
-                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c] = make_int2(sq_dn, sq_h);
+                if (c >= 1 && c <= m_eff) rb_store(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_dn, sq_h, piped);
             }
-            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) { // publish: the bottom row of this strip is out up to column t0 + 1
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], t0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[blockIdx.x], t0 + 1, lane); // the bottom row of this strip is out up to column t0 + 1
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
@@ -275,10 +270,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             for (int r = 0; r < R; r++) dw |= ((acc[2 * R + r] >> (30 - 2 * missf)) & 3u) << (2 * r);
             dcol[pl.dcol_off + s * G + l] = dw;
         }
-        if (piped) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (piped) rb_publish(&strip_prog[blockIdx.x], 0x7fffffff, lane);
+        else if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     if (bad) atomicOr(err, 1);
 }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         int qv, qb, nv = 0, nb = 0;
         auto boundary = [&](int c, int &ov, int &ob) {
             if (!MULTI || s == 0) ov = GSW == 1 ? 0 : c * kp.g4; // row 0: j*gapPen
-            else if (c >= 1 && c <= m_eff) ov = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c].x;
+            else if (c >= 1 && c <= m_eff) ov = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped).x;
             else ov = 0;
             int b = 0;
             if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
                 const long long t_begin = wall_clock64();
-                while ((rb_seen = __hip_atomic_load(&strip_prog[blockIdx.x - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < cmax) {
+                while ((rb_seen = rb_progress(&strip_prog[blockIdx.x - 1])) < cmax) {
                     __builtin_amdgcn_s_sleep(32);
                     if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; }
                 }
@@ -161,12 +161,9 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             }
             if (store_row) {
                 const int c = t0 + l - 14;
-                if (c >= 1 && c <= m_eff) rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c] = make_int2(sq_v, 0);
+                if (c >= 1 && c <= m_eff) rb_store(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_v, 0, piped);
             }
-            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], t0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[blockIdx.x], t0 + 1, lane);
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
@@ -177,10 +174,8 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             for (int r = 0; r < R; r++) dw |= ((acc[r] >> (30 - 2 * missf)) & 3u) << (2 * r);
             dcol[pl.dcol_off + s * G + l] = dw;
         }
-        if (piped) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0) __hip_atomic_store(&strip_prog[blockIdx.x], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (piped) rb_publish(&strip_prog[blockIdx.x], 0x7fffffff, lane);
+        else if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     if (bad) atomicOr(err, 1);
 }

@@ -535,7 +535,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // with plenty of pairs (or short beta) the strips of a group would only wait for each other
         int64_t m_maxc = 0;
         for (int64_t q2 = b; q2 < e; q2++) m_maxc = std::max<int64_t>(m_maxc, plans[(size_t)q2].m);
-        const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB;
+        const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB && !getenv("GNX_NO_PIPE"); // GNX_NO_PIPE: A/B check of the hand-over protocol
         if (piped) {
             std::vector<int2> smap;
             for (int gq = 0; gq < (np + 3) / 4; gq++) {

@@ -22,7 +22,7 @@ constexpr int NEG4 = -(1 << 30); // scaled "veryNegNum" (align/align.go:8); fini
 constexpr int QA = 8;            // uint4 stores per lane per flush, affine (3*R=30 dwords -> 32)
 constexpr int QC = 3;            // const gap (R=10 dwords -> 12)
 #ifndef GNX_RB_PUB
-#define GNX_RB_PUB 128
+#define GNX_RB_PUB 64
 #endif
 constexpr int RB_PUB = GNX_RB_PUB;  // pipelined strips publish their bottom row every RB_PUB steps (power of two, multiple of 16)
 
@@ -71,6 +71,41 @@ __device__ __forceinline__ int dpp_shl1(int oldv, int src) { return __builtin_am
 __device__ __forceinline__ void trace_store(uint4 *dst, unsigned a, unsigned b, unsigned c, unsigned d, bool streaming) {
     if (streaming) __builtin_nontemporal_store((u32x4){a, b, c, d}, reinterpret_cast<u32x4 *>(dst));
     else *dst = make_uint4(a, b, c, d);
+}
+// Row-buffer hand-over between the pipelined strips of a pair (fill_affine_kernel / fill_const_kernel, MULTI with a strip map).
+// The XCDs' L2 caches are not coherent with each other, so the producer's rows must reach memory and the consumer must not read a
+// stale line.  GNX_RB_FENCE: agent-scope release / acquire fences (L2 write-back + invalidate, ~780 of each per strip of a 100 kb
+// beta -- they serialize per XCD and cap the fill at ~1.1e12 cells/s whatever the number of strips in flight).  Default: the rows
+// themselves are agent-scope relaxed atomics (sc1: write-through stores, loads that bypass the non-coherent lines); the producer
+// waits for its stores to be acknowledged (s_waitcnt vmcnt(0)) before it advances the progress word, the consumer reads rows only
+// after it has seen the progress word.  No cache-wide operation on either side.
+#ifndef GNX_RB_FENCE
+#define GNX_RB_FENCE 0
+#endif
+__device__ __forceinline__ void rb_store(int2 *p, int a, int b, bool piped) {
+    if (piped && !GNX_RB_FENCE)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), ((unsigned long long)(unsigned)b << 32) | (unsigned)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = make_int2(a, b);
+}
+__device__ __forceinline__ int2 rb_load(const int2 *p, bool piped) {
+    if (piped && !GNX_RB_FENCE) {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
+    }
+    return *p;
+}
+// producer: everything stored so far is out; then the progress word
+__device__ __forceinline__ void rb_publish(int *prog, int value, int lane) {
+    if (GNX_RB_FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(prog, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// consumer: progress of the producer (columns published so far)
+__device__ __forceinline__ int rb_progress(const int *prog) {
+    if (GNX_RB_FENCE) return __hip_atomic_load(prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    const int v = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::: "memory"); // row loads stay behind the progress load
+    return v;
 }
 __device__ __forceinline__ unsigned alignbit2(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 2); }
 

@@ -32,7 +32,8 @@ __device__ __forceinline__ unsigned load_word(const uint4 *trace, const PairPlan
 
 // COOP: one wave per pair (launches of few, long pairs).  Every lane runs the same walk; a diagonal run is taken 64 cells at a
 // time -- lane t looks at cell (i-t, j-t) and the run goes on while the cells are M cells whose source is M -- instead of
-// ~480 single-lane cycles per cell.  Quirk Q1 changes nothing inside such a run: the entry cell's argmax is M again.
+// ~480 single-lane cycles per cell.  Quirk Q1 changes nothing inside such a run: the entry cell's argmax is M again.  A horizontal
+// run is taken 64 words (1024 columns) at a time.
 template <bool AFFINE, bool WRITE, bool COOP = false>
 __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restrict__ plans, int n_pairs, const uint4 *__restrict__ trace,
                                                        const int *__restrict__ hcol, const unsigned *__restrict__ dcol, TbParams tp,
@@ -91,6 +92,9 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
     int64_t li = (i > 0) ? (int64_t)(i - 1) % tp.ci : 0; // tile-local row of the current cell
     int last_op = -1;
     const bool walked = (i > 0 && j > 0);
+    bool have_w0 = false; // COOP: w0 / pos0 = plane-0 word and field position of the current cell, from the last diagonal look
+    unsigned w0 = 0;
+    int pos0 = 0;
     while (i > 0 && j > 0) {
         if (j == pl.m && (!AFFINE || k == 2)) {
             // Vertical run in the last column: the packed per-lane word holds the fields of R consecutive rows.
@@ -129,19 +133,25 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
         }
         if (COOP && (!AFFINE || k == 0)) { // diagonal run, 64 cells per look
             const int lim = min(min(i, j), 64);
-            int f = 0;
-            if (lane < lim) { int p2; f = (int)((load_word<AFFINE>(trace, pl, 0, i - lane, j - lane, p2) >> (2 * p2)) & 3u); }
+            int f = 0, p2 = 0;
+            unsigned wv = 0;
+            if (lane < lim) { wv = load_word<AFFINE>(trace, pl, 0, i - lane, j - lane, p2); f = (int)((wv >> (2 * p2)) & 3u); }
             const unsigned long long stop = __ballot(!(lane < lim && f == 3));
             const int T = stop ? __ffsll((long long)stop) - 1 : 64;
+            have_w0 = true; w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)wv); pos0 = __builtin_amdgcn_readfirstlane(p2); // lane 0 looked at (i, j) itself
             if (T > 0) {
+                have_w0 = false;
                 emit(0, T); last_op = 0;
                 i -= T; j -= T;
-                li = ((li - T) % tp.ci + tp.ci) % tp.ci; // T rows up, tile edges included (Q1 restarts in M, the state we are in)
+                li -= T; // T rows up, tile edges included (Q1 restarts in M, the state we are in)
+                if (li < 0) { li %= tp.ci; if (li < 0) li += tp.ci; }
                 continue;
             }
         }
         int pos;
-        const unsigned w = load_word<AFFINE>(trace, pl, AFFINE ? k : 0, i, j, pos);
+        unsigned w;
+        if (COOP && have_w0) { w = w0; pos = pos0; have_w0 = false; } // the diagonal look already fetched this cell's plane-0 word
+        else w = load_word<AFFINE>(trace, pl, AFFINE ? k : 0, i, j, pos);
         int tag = (int)((w >> (2 * pos)) & 3u);
         const int op = AFFINE ? k : 3 - tag;
         if (tag == 0) { atomicOr(err, 2); break; } // impossible direction: the Go code would log.Fatalf
@@ -163,6 +173,23 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
                 else steps = pos - pnz;                            // const gap: that cell is not an I cell
             }
             if (steps > 0) { emit(1, steps); j -= steps; last_op = 1; }
+            if (COOP && x == 0 && j > 0) {
+                // the run reached the low end of its word and goes on: lane t looks at the t-th word further left (16 columns each),
+                // whole words of "came from I" are taken at once -- the 40 kb leading / trailing gaps of a read inside a long
+                // window are ~40 looks instead of 2 500 dependent loads
+                const int i0 = i - 1, s2 = i0 / H, rem = i0 - s2 * H, l2 = rem / R, r2 = rem - l2 * R;
+                const int t1 = j + l2 - 1;
+                if ((t1 & 15) == 15) {
+                    const int d = AFFINE ? R + r2 : r2;
+                    const int wq = (t1 >> 4) - lane;
+                    const bool ok = wq >= 0 && wq * 16 >= l2; // every field of the word is a column >= 1
+                    unsigned wv = 0;
+                    if (ok) wv = reinterpret_cast<const unsigned *>(trace + pl.trace_off + ((int64_t)(s2 * pl.words + wq) * (AFFINE ? QA : QC) + (d >> 2)) * G + l2)[d & 3];
+                    const unsigned long long stop = __ballot(!(ok && wv == 0xAAAAAAAAu));
+                    const int T = stop ? __ffsll((long long)stop) - 1 : 64;
+                    if (T > 0) { emit(1, 16 * (int64_t)T); j -= 16 * T; }
+                }
+            }
             continue;
         }
         emit(op, 1);

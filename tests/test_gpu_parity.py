@@ -460,3 +460,20 @@ def test_pipelined_strips(gpu_lib, mode, name):
         got = _gpu_batch(gpu_lib, mode, MX["Default"], -400, -30, a1, b1)
         exp = oracle.align_batch(mode, MX["Default"], -400, -30, a1, b1, threads=1)
         common.assert_same(got, exp, name + " one long pair")
+    # reads placed inside much longer windows: long leading / trailing horizontal runs, which the wave-cooperative traceback of
+    # small launches takes 64 direction words at a time (and the mirrored shape: long vertical runs)
+    rng = np.random.default_rng(5200 + mode)
+    alphas, betas = [], []
+    for n, m in [(170, 5000), (700, 6000), (1500, 4100), (161, 9000), (320, 1040)]:
+        w = rng.integers(0, 4, size=m).astype(np.uint8)
+        off = int(rng.integers(0, m - n))
+        alphas.append(common.mutate(rng, w[off:off + n], 0.04, 0.03)[:n]); betas.append(w)
+    if mode == 3:  # AffineGapLocal(target, query): keep the query short enough to stay multi-strip on the target side
+        alphas, betas = betas, alphas
+    for go, ge in [(-600, -150), (0, -30)]:
+        got = _gpu_batch(gpu_lib, mode, MX["HumanChimpTwo"], go, ge, alphas, betas)
+        exp = oracle.align_batch(mode, MX["HumanChimpTwo"], go, ge, alphas, betas, threads=5)
+        common.assert_same(got, exp, name + " long gaps %d %d" % (go, ge))
+    got = _gpu_batch(gpu_lib, mode, MX["HumanChimpTwo"], -600, -150, betas, alphas)
+    exp = oracle.align_batch(mode, MX["HumanChimpTwo"], -600, -150, betas, alphas, threads=5)
+    common.assert_same(got, exp, name + " long gaps, mirrored")
