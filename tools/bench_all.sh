@@ -4,4 +4,4 @@ for s in affine const local; do timeout 600 python bench.py --no-cpu --steps 3 -
 GNX_FASTPATH=0 timeout 600 python bench.py --no-cpu --steps 3 2>/dev/null | sed 's/^{"metric": "DP cells\/sec + aligned pairs\/sec, affine-gap 150bp x 10kb batch"/{"metric": "same, general path (GNX_FASTPATH=0)"/'
 timeout 600 python tools/bench_n1.py 2>/dev/null
 timeout 600 python tools/bench_n2.py 200000 2>/dev/null
-timeout 900 python tools/bench_long.py 32 2>/dev/null
+timeout 900 python tools/bench_long.py 256 verify 2>/dev/null

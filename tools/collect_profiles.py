@@ -124,6 +124,19 @@ def main():
         fh.write("\n")
     if os.path.exists(os.path.join(src, "bench.json")):
         shutil.copyfile(os.path.join(src, "bench.json"), os.path.join(prof, rnd + "_bench.json"))
+    for nm, dst in (("all_series.jsonl", "_all_series.jsonl"), ("host_entry.jsonl", "_host_entry.jsonl"), ("bench_general_path.json", "_bench_general_path.json")):
+        if os.path.exists(os.path.join(src, nm)) and os.path.getsize(os.path.join(src, nm)) > 0:
+            shutil.copyfile(os.path.join(src, nm), os.path.join(prof, rnd + dst))
+    if os.path.exists(os.path.join(src, "all_series.jsonl")):  # per-topic views of the same lines
+        with open(os.path.join(src, "all_series.jsonl")) as fh:
+            lines = [ln for ln in fh if ln.startswith("{")]
+        longs = [ln for ln in lines if '"series": "one AffineGap pair' in ln or '"series": "C5 miniature' in ln]
+        n1 = [ln for ln in lines if '"series": "AffineGapChunk' in ln or '"series": "multipleAffineGap' in ln]
+        n2 = [ln for ln in lines if 'DynamicAln' in ln]
+        for part, dst in ((longs, "_long_bench.jsonl"), (n1, "_n1_bench.jsonl"), (n2, "_n2_bench.jsonl")):
+            if part:
+                with open(os.path.join(prof, rnd + dst), "w") as out:
+                    out.writelines(part)
     print(json.dumps(traffic, indent=1))
 
 

@@ -26,6 +26,9 @@ for grp in "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_
   timeout 900 rocprofv3 --pmc $grp -d $out/pmc_sq$g -o pmc --output-format csv -- python $repo/bench.py --no-cpu --steps 1 --warmup 0 --verify 0 --pairs 32768 > $out/pmc_sq$g.json 2> $out/pmc_sq$g.err
 done
 cd $repo
+# the other measured series (regression view): const / local / general path, N1, N2, long pairs, host-buffer entry point
+bash tools/bench_all.sh > $out/all_series.jsonl 2>> $out/bench.err
+timeout 300 python tools/bench_host.py 100000 > $out/host_entry.jsonl 2>> $out/bench.err
 find $out -name '*.db' -size +20M -delete
 ls -la $out $out/stats 2>/dev/null | head -40
 tail -3 $out/pytest_gpu.log; cat $out/smoke.log | tail -1; cat $out/bench.json
