@@ -6,9 +6,15 @@
 namespace {
 // ------------------------------------------------------------------------------------------------------
 // Constant-gap fill (align/constGap.go:146-157 recurrence), same wavefront mapping as the affine kernel.
-// Keys: diag+s -> tag 3, left+g -> tag 2, up+g -> tag 1; the stored value is the clean (tag-free) key, so the three
-// candidates are three 2-cycle VGPR adds (the profile holds 4*s+3, the penalties 4*g+2 / 4*g+1 live in VGPRs),
-// one v_max3, one v_and and one v_alignbit per cell.
+// Keys: diag+s -> tag 3, left+g -> tag 2, up+g -> tag 1.
+// GSW == 0 (the align package's ConstGap): REBASED values V' = V - g*(i+j).  Both gap moves cost nothing, every border is 0,
+// and the value is kept with tag 2 -- it IS the left candidate of the next column; the diagonal candidate is one add of the
+// profile entry 4*(s - 2g) + 1 (tag 2 + 1 = 3), the upper candidate one add of -1 (tag 1): add, add, max3, alignbit, and_or =
+// 5 instructions per cell instead of 6.  Every max compares candidates of one cell (same offset), so values and argmax tags
+// are those of the plain recurrence; the row buffer between strips carries V' as well, hcol is un-rebased when it is stored.
+// GSW != 0: plain values (the clamp at 0 / the running maximum need them): the stored value is the clean (tag-free) key, the
+// three candidates are three VGPR adds (the profile holds 4*s+3, the penalties 4*g+2 / 4*g+1 live in VGPRs), one v_max3, one
+// v_and and one v_alignbit per cell.
 // ------------------------------------------------------------------------------------------------------
 // GSW (the seed-extension DP of the graph aligner, "next" row N2, /root/reference/genomeGraph/search.go:234-321):
 //   1 = LeftDynamicAln: zero borders, cell values clamped at 0 (the trace keeps its direction);
@@ -27,7 +33,8 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     __shared__ int lds[32 + 4 * PST];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
-    if (lane < 25) lds[lane] = kp.sc4[lane] + 3; // pre-tagged diagonal candidate
+    constexpr bool REB = (GSW == 0);
+    if (lane < 25) lds[lane] = REB ? kp.sc4[lane] - 2 * kp.g4 + 1 : kp.sc4[lane] + 3; // pre-tagged diagonal candidate
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
     const bool piped = MULTI && strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
@@ -76,15 +83,15 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             __syncthreads();
         }
 #pragma unroll
-        for (int r = 0; r < R; r++) { val[r] = GSW == 1 ? 0 : (row0 + r + 1) * kp.g4; acc[r] = 0; } // column 0: i*gapPen
+        for (int r = 0; r < R; r++) { val[r] = REB ? 2 : (GSW == 1 ? 0 : (row0 + r + 1) * kp.g4); acc[r] = 0; } // column 0: i*gapPen (rebased: 0, tag 2)
         int best[R];
 #pragma unroll
         for (int r = 0; r < R; r++) best[r] = 4095; // score 0: only a positive score replaces it (currMax starts at 0)
-        int diag0 = GSW == 1 ? 0 : row0 * kp.g4; // V(row above, 0)
+        int diag0 = REB ? 2 : (GSW == 1 ? 0 : row0 * kp.g4); // V(row above, 0)
         int v_out = 0, b_out = 0, sq_v = 0;
         int qv, qb, nv = 0, nb = 0;
         auto boundary = [&](int c, int &ov, int &ob) {
-            if (!MULTI || s == 0) ov = GSW == 1 ? 0 : c * kp.g4; // row 0: j*gapPen
+            if (!MULTI || s == 0) ov = REB ? 2 : (GSW == 1 ? 0 : c * kp.g4); // row 0: j*gapPen (rebased: 0, tag 2)
             else if (c >= 1 && c <= m_eff) ov = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped).x;
             else ov = 0;
             int b = 0;
@@ -121,10 +128,10 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                 int vd = diag0, vu = up_v;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const int k = max3i(vd + w[r], val[r] + vGL, vu + vGU);
+                    const int k = REB ? max3i(vd + w[r], val[r], vu - 1) : max3i(vd + w[r], val[r] + vGL, vu + vGU);
                     acc[r] = alignbit2((unsigned)k, acc[r]);
                     vd = val[r];
-                    val[r] = k & ~3;
+                    val[r] = REB ? ((k & ~3) | 2) : (k & ~3);
                     if (GSW == 1) val[r] = max(val[r], 0);
                     if (GSW == 2) best[r] = max(best[r], (int)((unsigned)val[r] << 10) + (4095 - j));
                     vu = val[r];
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = GSW == 2 ? best[r] : val[r];
+            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = GSW == 2 ? best[r] : (REB ? (val[r] & ~3) + kp.g4 * (row0 + r + 1 + m_eff) : val[r]);
             const int t0f = ((m_eff + l - 1) >> 4) << 4, missf = t0f + 16 - l - m_eff;
             unsigned dw = 0;
 #pragma unroll
