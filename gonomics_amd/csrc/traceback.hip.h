@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
     int64_t li = (i > 0) ? (int64_t)(i - 1) % tp.ci : 0; // tile-local row of the current cell
     int last_op = -1;
     const bool walked = (i > 0 && j > 0);
-    bool have_w0 = false; // COOP: w0 / pos0 = plane-0 word and field position of the current cell, from the last diagonal look
+    bool have_w0 = false; // COOP: w0 / pos0 = plane-0 word and field position of the current cell (i, j), from the last diagonal look
     unsigned w0 = 0;
     int pos0 = 0;
     while (i > 0 && j > 0) {
@@ -131,16 +131,17 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
                 }
             }
         }
-        if (COOP && (!AFFINE || k == 0)) { // diagonal run, 64 cells per look
+        if (COOP && (!AFFINE || k == 0) && !have_w0) { // diagonal run, 64 cells per look (not when the last look already stopped at this cell)
             const int lim = min(min(i, j), 64);
             int f = 0, p2 = 0;
             unsigned wv = 0;
             if (lane < lim) { wv = load_word<AFFINE>(trace, pl, 0, i - lane, j - lane, p2); f = (int)((wv >> (2 * p2)) & 3u); }
             const unsigned long long stop = __ballot(!(lane < lim && f == 3));
             const int T = stop ? __ffsll((long long)stop) - 1 : 64;
-            have_w0 = true; w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)wv); pos0 = __builtin_amdgcn_readfirstlane(p2); // lane 0 looked at (i, j) itself
+            // the cell the run stops at -- lane T's -- is the next one the walk needs: keep its word, skip the next look
+            const int tl = T < lim ? T : 0;
+            have_w0 = T < lim; w0 = (unsigned)__builtin_amdgcn_readlane((int)wv, tl); pos0 = __builtin_amdgcn_readlane(p2, tl);
             if (T > 0) {
-                have_w0 = false;
                 emit(0, T); last_op = 0;
                 i -= T; j -= T;
                 li -= T; // T rows up, tile edges included (Q1 restarts in M, the state we are in)
