@@ -52,8 +52,10 @@ def _gather_var(t, dst, device):
     mx = max(max(sizes), 1)
     pad = torch.zeros(mx, dtype=t.dtype, device=device)
     pad[: t.numel()] = t
-    bufs = [torch.zeros(mx, dtype=t.dtype, device=device) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst)
+    # all_gather rather than gather: the plainest ring collective of RCCL (gather is grouped send/recv); the payloads are a few
+    # MB per rank (scores, offsets, 16-byte CIGAR records), so the extra copies on the other ranks do not matter
+    bufs = [torch.zeros(mx, dtype=t.dtype, device=device) for _ in range(world)]
+    dist.all_gather(bufs, pad)
     if rank != dst:
         return None
     return [b[:s] for b, s in zip(bufs, sizes)]
