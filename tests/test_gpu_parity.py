@@ -438,6 +438,33 @@ def test_fast_path_local_c2_series(gpu_lib):
 
 
 @pytest.mark.gpu
+def test_windows_at_offsets_beyond_4gb(gpu_lib):
+    """Config C3 shape: reads against windows of ONE big resident reference, addressed by 64-bit offsets.  The
+    reference here is 4.3 GB (mostly untouched zero pages) with windows just below / above 2^31 and 2^32: offset arithmetic
+    in the planner and the kernels must be 64-bit.  Fast path (150 x 3000) and general path (300 x 900)."""
+    rng = np.random.default_rng(61)
+    total = (1 << 32) + (1 << 16)
+    ref = np.zeros(total, dtype=np.uint8)
+    spots = [0, (1 << 31) - 5000, (1 << 31) + 17, (1 << 32) - 9000, (1 << 32) + 100]
+    for sp in spots:
+        ref[sp:sp + 12000] = rng.integers(0, 4, size=12000, dtype=np.uint8)
+    for n, m in ((150, 3000), (300, 900)):
+        reads, a_start, a_len, b_start, b_len = [], [], [], [], []
+        for k in range(40):
+            sp = spots[k % len(spots)] + int(rng.integers(0, 12000 - m))
+            pos = int(rng.integers(0, m - n))
+            r = common.mutate(rng, ref[sp + pos:sp + pos + n], 0.03, 0.01)[:n]
+            a_start.append(sum(len(x) for x in reads)); a_len.append(len(r)); reads.append(r)
+            b_start.append(sp); b_len.append(m)
+        a_buf = np.concatenate(reads)
+        a_start, a_len, b_start, b_len = (np.asarray(x, dtype=np.int64) for x in (a_start, a_len, b_start, b_len))
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+        got = gpu_lib.align_batch_windows(p, a_buf, a_start, a_len, ref, b_start, b_len)
+        exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, a_buf, a_start, a_len, ref, b_start, b_len, threads=8)
+        common.assert_same(got, exp, "windows beyond 4 GB, %d x %d" % (n, m))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,name", MODES)
 def test_pipelined_strips(gpu_lib, mode, name):
     """Small launches of multi-strip pairs with beta >= 1024 run their strips as pipelined workgroups (per-strip row buffer,
