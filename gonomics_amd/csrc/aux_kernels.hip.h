@@ -84,4 +84,17 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int64_t *__restrict__ 
     if (threadIdx.x == 0) { off[n] = base; carry[0] = base; }
 }
 
+// single-pass cooperative traceback (traceback_kernel<.., SCR>): runs staged in traceback order -> dense output, alignment order
+__global__ __launch_bounds__(256) void reverse_runs_kernel(const PairPlan *__restrict__ plans, int n_pairs, const gnx_cigar *__restrict__ scr,
+                                                            const int64_t *__restrict__ scr_off, const int64_t *__restrict__ nops,
+                                                            const int64_t *__restrict__ ops_off, gnx_cigar *__restrict__ ops, int64_t ops_capacity,
+                                                            int *__restrict__ err) {
+    const int p = blockIdx.x;
+    if (p >= n_pairs) return;
+    const int po = plans[p].src;
+    const int64_t cnt = nops[po], base = ops_off[po], sb = scr_off[p];
+    if (base + cnt > ops_capacity) { if (threadIdx.x == 0) atomicOr(err, 4); return; }
+    for (int64_t x = threadIdx.x; x < cnt; x += blockDim.x) ops[base + (cnt - 1 - x)] = scr[sb + x];
+}
+
 } // namespace

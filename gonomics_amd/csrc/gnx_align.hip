@@ -76,7 +76,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf strip_map, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
+    DevBuf strip_map, tb_scr, tb_scr_off, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -592,8 +592,26 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         for (int64_t q2 = b; q2 < e; q2++) lmax = std::max<int64_t>(lmax, std::max<int64_t>(plans[(size_t)q2].n, plans[(size_t)q2].m));
         const bool coop = !gsw && np <= 2048 && lmax >= 1024;
         const dim3 gridC((unsigned)np);
+        // ... in a single pass when the staging area (n + m + 2 runs per pair) is small next to the workspace
+        bool scr = false;
+        if (coop && !getenv("GNX_TB_TWO_PASS")) { // (GNX_TB_TWO_PASS: keep the count + write passes, for the tests)
+            std::vector<int64_t> so((size_t)np + 1, 0);
+            for (int q2 = 0; q2 < np; q2++) so[(size_t)q2 + 1] = so[(size_t)q2] + plans[(size_t)(b + q2)].n + plans[(size_t)(b + q2)].m + 2;
+            const size_t sbytes = (size_t)so[(size_t)np] * sizeof(gnx_cigar);
+            if ((int64_t)sbytes <= c.ws_limit / 8) {
+                if ((rc = c.tb_scr.ensure(sbytes))) return rc;
+                if ((rc = c.tb_scr_off.ensure(((size_t)np + 1) * 8))) return rc;
+                HIPCHK(hipMemcpyAsync(c.tb_scr_off.p, so.data(), ((size_t)np + 1) * 8, hipMemcpyHostToDevice, stream));
+                HIPCHK(hipStreamSynchronize(stream)); // so is a local
+                scr = true;
+            }
+        }
+        gnx_cigar *d_scr = reinterpret_cast<gnx_cigar *>(c.tb_scr.p);
+        const int64_t *d_scr_off = reinterpret_cast<const int64_t *>(c.tb_scr_off.p);
         if (gsw == 1) GNX_GSW_TB(false, false);
         else if (gsw == 2) GNX_GSW_TB(true, false);
+        else if (scr && affine) hipLaunchKernelGGL((traceback_kernel<true, false, true, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_scr_off, d_scr, (int64_t)0, d_err);
+        else if (scr) hipLaunchKernelGGL((traceback_kernel<false, false, true, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_scr_off, d_scr, (int64_t)0, d_err);
         else if (coop && affine) hipLaunchKernelGGL((traceback_kernel<true, false, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
         else if (coop) hipLaunchKernelGGL((traceback_kernel<false, false, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
         else if (affine) hipLaunchKernelGGL((traceback_kernel<true, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
@@ -601,6 +619,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, dn, np, d_ops_off + b, d_carry);
         if (gsw == 1) GNX_GSW_TB(false, true);
         else if (gsw == 2) GNX_GSW_TB(true, true);
+        else if (scr) hipLaunchKernelGGL(reverse_runs_kernel, gridC, dim3(256), 0, stream, dpl, np, d_scr, d_scr_off, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
         else if (coop && affine) hipLaunchKernelGGL((traceback_kernel<true, true, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
         else if (coop) hipLaunchKernelGGL((traceback_kernel<false, true, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
         else if (affine) hipLaunchKernelGGL((traceback_kernel<true, true>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
@@ -806,7 +825,7 @@ void gnx_shutdown(void) {
     if (!g_ctx.inited) return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&g_ctx.strip_map, &g_ctx.fp_redo, &g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
+    DevBuf *bufs[] = {&g_ctx.strip_map, &g_ctx.tb_scr, &g_ctx.tb_scr_off, &g_ctx.fp_redo, &g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
                       &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
                       &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops, &g_ctx.out_end,
                       &g_ctx.sc_pairs, &g_ctx.sc_mat, &g_ctx.sc_err};

@@ -34,7 +34,10 @@ __device__ __forceinline__ unsigned load_word(const uint4 *trace, const PairPlan
 // time -- lane t looks at cell (i-t, j-t) and the run goes on while the cells are M cells whose source is M -- instead of
 // ~480 single-lane cycles per cell.  Quirk Q1 changes nothing inside such a run: the entry cell's argmax is M again.  A horizontal
 // run is taken 64 words (1024 columns) at a time.
-template <bool AFFINE, bool WRITE, bool COOP = false>
+// SCR (with COOP, WRITE = false): single pass -- the runs are also written, in traceback order, to a scratch area of n + m + 2
+// entries per pair (`ops` = scratch, `ops_off[p]` = the pair's scratch offset); reverse_runs_kernel puts them in place after the
+// scan.  A latency-bound walk is not worth doing twice.
+template <bool AFFINE, bool WRITE, bool COOP = false, bool SCR = false>
 __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restrict__ plans, int n_pairs, const uint4 *__restrict__ trace,
                                                        const int *__restrict__ hcol, const unsigned *__restrict__ dcol, TbParams tp,
                                                        int64_t *__restrict__ score_out,
@@ -71,8 +74,15 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
     const int64_t total = WRITE ? nops[po] : 0;
     const int64_t obase = WRITE ? ops_off[po] : 0;
     const bool fits = WRITE ? (obase + total <= ops_capacity) : false;
+    static_assert(!SCR || (COOP && !WRITE), "scratch mode is the single-pass cooperative walk");
+    const int64_t sbase = SCR ? ops_off[p] : 0;
     auto flush_run = [&]() {
         if (cur_op >= 0) {
+            if (SCR && writer) {
+                gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op;
+                for (int z = 0; z < 7; z++) c._pad[z] = 0;
+                ops[sbase + cnt] = c;
+            }
             if (WRITE && fits && writer) {
                 gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op;
                 for (int z = 0; z < 7; z++) c._pad[z] = 0;

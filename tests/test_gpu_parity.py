@@ -504,3 +504,10 @@ def test_pipelined_strips(gpu_lib, mode, name):
     got = _gpu_batch(gpu_lib, mode, MX["HumanChimpTwo"], -600, -150, betas, alphas)
     exp = oracle.align_batch(mode, MX["HumanChimpTwo"], -600, -150, betas, alphas, threads=5)
     common.assert_same(got, exp, name + " long gaps, mirrored")
+    # the cooperative walk is a single pass with staged runs by default; the count + write form is the fallback for huge launches
+    os.environ["GNX_TB_TWO_PASS"] = "1"
+    try:
+        got = _gpu_batch(gpu_lib, mode, MX["HumanChimpTwo"], -600, -150, betas, alphas)
+    finally:
+        del os.environ["GNX_TB_TWO_PASS"]
+    common.assert_same(got, exp, name + " long gaps, mirrored, two-pass walk")
