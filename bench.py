@@ -276,7 +276,7 @@ def main():
                           "dominant_kernel_per_step": dom_ms / args.steps, "fast_path": bool(fast_path)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r1_hbm_traffic.json)",
-                         "kernel": "fp_sweep_kernel<%d> (fast-path forward sweep)" % (19 if READ_LEN <= 152 else 20) if fast_path
+                         "kernel": "fp_sweep_kernel<%d, %s> (fast-path forward sweep)" % (19 if READ_LEN <= 152 else 20, "true" if args.series == "local" else "false") if fast_path
                                    else "fill_affine_kernel (full direction matrix)",
                          "avg_launch_ms": fill_avg_ms,
                          "algorithmic_bytes_per_launch": abytes,
