@@ -14,39 +14,49 @@ namespace {
 struct GroupDesc { int64_t off; int32_t nseq; int32_t len; };
 struct ScorePair { int64_t a_off, b_off; int32_t a_nseq, b_nseq, a_len, b_len; int32_t nc, mc; int64_t s_off, s_pitch; };
 
+// S16: every 4*score fits int16 (host check: 4 * chunk * max|score| <= 32767) -- the matrix is stored as int16, which halves the
+// HBM traffic of the SCORED fill (it reads one entry per cell and is bandwidth-bound with 4-byte entries)
+template <bool S16>
 __global__ __launch_bounds__(256) void score_matrix_kernel(const ScorePair *__restrict__ sp, const uint8_t *__restrict__ bases, KParams kp, int chunk,
                                                            int groups, int *__restrict__ smat, int *__restrict__ err) {
+    // block = 64 x 4 threads: x runs over the rows i (the fast index of the column-major matrix), y over 4 columns j;
+    // grid.x strides over the columns, grid.y = pair.  No per-cell division; the 5 x 5 table sits in LDS.
+    __shared__ int sc[25];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid < 25) sc[tid] = kp.sc4[tid] / 4;
+    __syncthreads();
     const ScorePair q = sp[blockIdx.y];
-    const int64_t cells = (int64_t)q.nc * q.mc;
-    for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < cells; cell += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(cell % q.nc), j = (int)(cell / q.nc);
-        int64_t total = 0;
-        for (int k = 0; k < chunk; k++) {
-            const int64_t ac = (int64_t)i * chunk + k, bc = (int64_t)j * chunk + k;
-            if (!groups) {
-                const int a = bases[q.a_off + ac], b = bases[q.b_off + bc];
-                if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
-                total += kp.sc4[a * 5 + b] / 4;
-            } else {
-                int64_t sum = 0, count = 0;
-                for (int x = 0; x < q.a_nseq; x++) {
-                    int a = bases[q.a_off + (int64_t)x * q.a_len + ac];
-                    if (a >= 5 && a <= 9) a -= 5;
-                    for (int y = 0; y < q.b_nseq; y++) {
-                        int b = bases[q.b_off + (int64_t)y * q.b_len + bc];
-                        if (b >= 5 && b <= 9) b -= 5;
-                        if (a != 10 && b != 10) {
-                            if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
-                            sum += kp.sc4[a * 5 + b] / 4;
-                            count++;
+    for (int j = blockIdx.x * 4 + threadIdx.y; j < q.mc; j += gridDim.x * 4) {
+        for (int i = threadIdx.x; i < q.nc; i += 64) {
+            int64_t total = 0;
+            for (int k = 0; k < chunk; k++) {
+                const int64_t ac = (int64_t)i * chunk + k, bc = (int64_t)j * chunk + k;
+                if (!groups) {
+                    const int a = bases[q.a_off + ac], b = bases[q.b_off + bc];
+                    if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
+                    total += sc[a * 5 + b];
+                } else {
+                    int64_t sum = 0, count = 0;
+                    for (int x = 0; x < q.a_nseq; x++) {
+                        int a = bases[q.a_off + (int64_t)x * q.a_len + ac];
+                        if (a >= 5 && a <= 9) a -= 5;
+                        for (int y = 0; y < q.b_nseq; y++) {
+                            int b = bases[q.b_off + (int64_t)y * q.b_len + bc];
+                            if (b >= 5 && b <= 9) b -= 5;
+                            if (a != 10 && b != 10) {
+                                if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
+                                sum += sc[a * 5 + b];
+                                count++;
+                            }
                         }
                     }
+                    if (count == 0) { atomicOr(err, 16); continue; } // Go: integer divide by zero
+                    total += sum / count;
                 }
-                if (count == 0) { atomicOr(err, 16); continue; } // Go: integer divide by zero
-                total += sum / count;
             }
+            if (S16) reinterpret_cast<short *>(smat)[q.s_off + (int64_t)j * q.s_pitch + i] = (short)(4 * total);
+            else smat[q.s_off + (int64_t)j * q.s_pitch + i] = (int)(4 * total);
         }
-        smat[q.s_off + (int64_t)j * q.s_pitch + i] = (int)(4 * total);
     }
 }
 

@@ -178,8 +178,10 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             const int j = t - l;
             b_out = pb;
             if (!CHECK || (j >= 1 && j <= m_eff)) {
-                const int *pw = SCORED ? smat + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0
-                                       : reinterpret_cast<const int *>(prof_lane + pb);
+                // SCORED: the lane's R rows of column j are contiguous in the score matrix (int32 entries, or int16 with P16: s_off, s_pitch and row0 are even)
+                const int *pw = !SCORED ? reinterpret_cast<const int *>(prof_lane + pb)
+                                : P16 ? reinterpret_cast<const int *>(reinterpret_cast<const short *>(smat) + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0)
+                                      : smat + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0;
                 int w[LW];
 #pragma unroll
                 for (int k = 0; k < LW; k++) w[k] = pw[k];

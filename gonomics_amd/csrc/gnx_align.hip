@@ -145,7 +145,7 @@ int64_t max_abs_pen(const gnx_params *p, bool affine) {
 // `first` = first sub-batch of a call: later sub-batches keep the error flags and the CIGAR offset carry.
 int run_device(const gnx_params *prm, int64_t n_pairs, const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                const int64_t *h_alen, const int64_t *h_blen, int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
-               int64_t *out_total, hipStream_t stream, const int *d_smat, const int64_t *h_soff, int gsw, int2 *d_endpos, bool no_fast_path);
+               int64_t *out_total, hipStream_t stream, const int *d_smat, const int64_t *h_soff, int gsw, int2 *d_endpos, bool no_fast_path, bool smat16);
 
 int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, int64_t n_pairs,
                   const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
@@ -338,8 +338,8 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         HIPCHK(hipGetLastError());
         const gnx_timing saved = c.timing;
         int64_t tot2 = 0;
-        if (xp) rc = run_device(prm, ns, d_b, s_bs, d_a, s_as, sbl.data(), sal.data(), s_sc, s_ops, sub_total + 1, s_off, &tot2, stream, nullptr, nullptr, 0, nullptr, true);
-        else rc = run_device(prm, ns, d_a, s_as, d_b, s_bs, sal.data(), sbl.data(), s_sc, s_ops, sub_total + 1, s_off, &tot2, stream, nullptr, nullptr, 0, nullptr, true);
+        if (xp) rc = run_device(prm, ns, d_b, s_bs, d_a, s_as, sbl.data(), sal.data(), s_sc, s_ops, sub_total + 1, s_off, &tot2, stream, nullptr, nullptr, 0, nullptr, true, false);
+        else rc = run_device(prm, ns, d_a, s_as, d_b, s_bs, sal.data(), sbl.data(), s_sc, s_ops, sub_total + 1, s_off, &tot2, stream, nullptr, nullptr, 0, nullptr, true, false);
         const double redo_ms = c.timing.total_ms;
         c.timing = saved;
         c.timing.traceback_ms += redo_ms; c.timing.total_ms += redo_ms;
@@ -363,7 +363,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
                const int64_t *h_alen, const int64_t *h_blen,
                int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
                int64_t *out_total, hipStream_t stream, const int *d_smat = nullptr, const int64_t *h_soff = nullptr,
-               int gsw = 0, int2 *d_endpos = nullptr, bool no_fast_path = false) {
+               int gsw = 0, int2 *d_endpos = nullptr, bool no_fast_path = false, bool smat16 = false) {
     // gsw: 1 / 2 = LeftDynamicAln / RightDynamicAln of the graph aligner (constant-gap kernels with GSW = 1 / 2 and their own
     // traceback; d_endpos receives the (i, j) the reference returns); prm->mode must be GNX_CONST_GAP_HIGHMEM
     // d_smat / h_soff: explicit per-cell score matrices (SCORED kernels, N1 variants); the sequences are then unused
@@ -558,7 +558,8 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         if (affine) {
 #define GNX_LAUNCH_AFF(L_, M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<L_, M_, P_, H_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, (const int2 *)nullptr, d_err, (const int *)nullptr, d_smap, d_sprog)
 #define GNX_LAUNCH_AFF2(L_, M_, P_) do { if (hform) GNX_LAUNCH_AFF(L_, M_, P_, true); else GNX_LAUNCH_AFF(L_, M_, P_, false); } while (0)
-#define GNX_LAUNCH_SC(M_, H_) hipLaunchKernelGGL((fill_affine_kernel<false, M_, false, H_, false, true>), gridF, blockF, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, (const int2 *)nullptr, d_err, d_smat, d_smap, d_sprog)
+#define GNX_LAUNCH_SC1(M_, P_, H_) hipLaunchKernelGGL((fill_affine_kernel<false, M_, P_, H_, false, true>), gridF, blockF, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, (const int2 *)nullptr, d_err, d_smat, d_smap, d_sprog)
+#define GNX_LAUNCH_SC(M_, H_) do { if (smat16) GNX_LAUNCH_SC1(M_, true, H_); else GNX_LAUNCH_SC1(M_, false, H_); } while (0)
             const int sel = d_smat ? 8 : ((local ? 4 : 0) | (multi ? 2 : 0) | (p16 ? 1 : 0));
             switch (sel) {
             case 8:
@@ -575,6 +576,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             default: GNX_LAUNCH_AFF2(true, true, true); break;
             }
 #undef GNX_LAUNCH_SC
+#undef GNX_LAUNCH_SC1
 #undef GNX_LAUNCH_AFF2
 #undef GNX_LAUNCH_AFF
         } else {
@@ -627,7 +629,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
 #undef GNX_GSW_TB
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[3], stream));
-        if (nchunks > 1 || true) {
+        { // per-chunk kernel times (the chunks reuse the workspace, so each one is waited for anyway)
             HIPCHK(hipEventSynchronize(c.ev[3]));
             float f1 = 0, f2 = 0;
             HIPCHK(hipEventElapsedTime(&f1, c.ev[1], c.ev[2]));
@@ -670,8 +672,11 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     prm2.gap_extend = prm->gap_extend * chunk;
     for (int x = 0; x < 25; x++) prm2.scores[x] = prm->scores[x] * chunk;
     hipStream_t st = c.own_stream;
+    int64_t smax = 0; // int16 score matrix when every 4 * cell score fits (a cell is a sum of `chunk` scores, or of averages of scores)
+    for (int x = 0; x < 25; x++) smax = std::max<int64_t>(smax, llabs((long long)prm->scores[x]));
+    const bool s16 = 4 * chunk * smax <= 32767;
     std::vector<int64_t> hn((size_t)n_pairs), hm((size_t)n_pairs), hso((size_t)n_pairs);
-    int64_t stot = 0, worst = 0, maxcells = 1;
+    int64_t stot = 0, worst = 0, maxcols = 1;
     for (int64_t p = 0; p < n_pairs; p++) {
         ScorePair &q = sp[(size_t)p];
         const int64_t strips = std::max<int64_t>((q.nc + H - 1) / H, 1);
@@ -679,7 +684,7 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
         stot += (int64_t)q.mc * q.s_pitch;
         hn[(size_t)p] = q.nc; hm[(size_t)p] = q.mc; hso[(size_t)p] = q.s_off;
         worst += q.nc + q.mc + 1;
-        maxcells = std::max<int64_t>(maxcells, (int64_t)q.nc * q.mc);
+        maxcols = std::max<int64_t>(maxcols, q.mc);
     }
     if ((rc = c.in_a.ensure((size_t)bases_len + 16))) return rc;
     if ((rc = c.sc_pairs.ensure((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(ScorePair)))) return rc;
@@ -693,8 +698,9 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     HIPCHK(hipMemsetAsync(c.sc_err.p, 0, 16, st));
     for (int64_t b = 0; b < n_pairs; b += 32768) {
         const unsigned ny = (unsigned)std::min<int64_t>(32768, n_pairs - b);
-        const unsigned nx = (unsigned)std::min<int64_t>((maxcells + 255) / 256, 4096);
-        hipLaunchKernelGGL(score_matrix_kernel, dim3(nx, ny), dim3(256), 0, st, reinterpret_cast<const ScorePair *>(c.sc_pairs.p) + b,
+        const unsigned nx = (unsigned)std::min<int64_t>((maxcols + 3) / 4, 1024);
+        auto ksm = s16 ? score_matrix_kernel<true> : score_matrix_kernel<false>;
+        hipLaunchKernelGGL(ksm, dim3(nx, ny), dim3(64, 4), 0, st, reinterpret_cast<const ScorePair *>(c.sc_pairs.p) + b,
                            reinterpret_cast<const uint8_t *>(c.in_a.p), kp0, (int)chunk, groups ? 1 : 0, reinterpret_cast<int *>(c.sc_mat.p), reinterpret_cast<int *>(c.sc_err.p));
     }
     HIPCHK(hipGetLastError());
@@ -708,7 +714,7 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = c.out_ops.ensure((size_t)cap * sizeof(gnx_cigar)))) return rc;
         rc = run_device(&prm2, n_pairs, nullptr, nullptr, nullptr, nullptr, hn.data(), hm.data(), (int64_t *)c.out_score.p, (gnx_cigar *)c.out_ops.p, cap,
-                        (int64_t *)c.out_off.p, &total, st, reinterpret_cast<const int *>(c.sc_mat.p), hso.data());
+                        (int64_t *)c.out_off.p, &total, st, reinterpret_cast<const int *>(c.sc_mat.p), hso.data(), 0, nullptr, false, s16);
         if (rc != GNX_ECAPACITY) break;
         cap = total;
     }

@@ -62,6 +62,14 @@ def test_chunk_fuzz_vs_oracle(gpu_lib):
             exp = oracle.affine_gap_chunk(MX["HumanChimpTwo"], -600, -150, chunk, a, b)
             got = (int(sc[k]), [(int(r), int(o)) for r, o in zip(ops["run_length"][off[k]:off[k + 1]], ops["op"][off[k]:off[k + 1]])])
             assert got == exp, (chunk, k)
+    # scores too large for the int16 score matrix (4 * chunk * max|score| > 32767): the int32 matrix, same answers
+    big = [[v * 40 for v in row] for row in align.HumanChimpTwoScoreMatrix]
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_HIGHMEM, big, -24000, -6000)
+    sc, ops, off = gpu_lib.affine_gap_chunk_batch(p, 5, alphas, betas)
+    for k, (a, b) in enumerate(zip(alphas, betas)):
+        exp = oracle.affine_gap_chunk(big, -24000, -6000, 5, a, b)
+        got = (int(sc[k]), [(int(r), int(o)) for r, o in zip(ops["run_length"][off[k]:off[k + 1]], ops["op"][off[k]:off[k + 1]])])
+        assert got == exp, ("int32 matrix", k)
 
 
 def test_groups_fuzz_vs_oracle(gpu_lib):
