@@ -6,7 +6,7 @@
 namespace {
 // ------------------------------------------------------------------------------------------------------
 // N1: per-cell score matrices for the chunk / multiple-alignment variants, one thread per (chunk) cell, written
-// column-major as 4*score.  A "group" is an alignment block: nseq sequences of len bases, sequence-major.
+// column-major as 4*score (+ bias4, see the kernel).  A "group" is an alignment block: nseq sequences of len bases, sequence-major.
 //   pairwise (AffineGapChunk):      cell = sum_k scores[a[i*c+k]][b[j*c+k]]                       (ungapped.go:7-13)
 //   groups (multipleAffineGap*):    cell = sum_k scoreColumnMatch(column i*c+k, column j*c+k)     (multiAlign.go:82-110)
 //     scoreColumnMatch = (sum over sequence pairs, lower case folded, gap columns skipped) / count, Go integer division
@@ -18,7 +18,8 @@ struct ScorePair { int64_t a_off, b_off; int32_t a_nseq, b_nseq, a_len, b_len; i
 // HBM traffic of the SCORED fill (it reads one entry per cell and is bandwidth-bound with 4-byte entries)
 template <bool S16>
 __global__ __launch_bounds__(256) void score_matrix_kernel(const ScorePair *__restrict__ sp, const uint8_t *__restrict__ bases, KParams kp, int chunk,
-                                                           int groups, int *__restrict__ smat, int *__restrict__ err) {
+                                                           int groups, int bias4, int *__restrict__ smat, int *__restrict__ err) {
+    // bias4 = -2 * 4 * gapExtend * chunk when the fill runs on rebased keys (fill_affine_kernel, HFORM), else 0
     // block = 64 x 4 threads: x runs over the rows i (the fast index of the column-major matrix), y over 4 columns j;
     // grid.x strides over the columns, grid.y = pair.  No per-cell division; the 5 x 5 table sits in LDS.
     __shared__ int sc[25];
@@ -54,8 +55,8 @@ __global__ __launch_bounds__(256) void score_matrix_kernel(const ScorePair *__re
                     total += sum / count;
                 }
             }
-            if (S16) reinterpret_cast<short *>(smat)[q.s_off + (int64_t)j * q.s_pitch + i] = (short)(4 * total);
-            else smat[q.s_off + (int64_t)j * q.s_pitch + i] = (int)(4 * total);
+            if (S16) reinterpret_cast<short *>(smat)[q.s_off + (int64_t)j * q.s_pitch + i] = (short)(4 * total + bias4);
+            else smat[q.s_off + (int64_t)j * q.s_pitch + i] = (int)(4 * total) + bias4;
         }
     }
 }

@@ -19,9 +19,13 @@ namespace {
 //   HFORM = gapOpen <= 0 (every caller): with h = max3(M,I,D) the recurrences collapse to
 //           rt = max(h+oe, I+e), dn = max(h+oe, D+e) with identical values AND identical argmax tags
 //           (oe <= e makes the dropped candidate I+oe / D+oe never a strict winner; ties keep M > I > D).
-//           gfx950 issues v_max_i32/v_max3_i32/v_and_or/v_alignbit/DPP/SDWA and any VALU op with an SGPR
-//           operand at 4 cycles per wave64 but VGPR/immediate add/or at 2 (tools/valu_ubench*.hip), so the
-//           penalties are kept in VGPRs and the h-form trades 2 max3 + 2 adds for 2 max.
+//           The h-form runs on REBASED keys V' = V - e*(i+j) (i = row of the pair, j = column of this launch's window), like
+//           fp_sweep_kernel: both extensions cost nothing, both opens share h' + o:
+//               M' = (h'diag | 3) + (s - 2e)   I' = max(h' + o, I')   D' = max(h' + o, D')
+//           i.e. per cell  or, add, and_or, and_or, max3, add, max, max  + 3 v_alignbit = 11 VALU instructions (13 with the
+//           un-rebased h-form, 15 with the literal three-candidate form kept for gapOpen > 0).  Every max compares candidates
+//           of one cell (same offset), so values and tags are the plain recurrence's; the row buffer carries V', hcol is
+//           un-rebased when stored, checkpoints of the sweep are rebased when loaded.
 // LDS (dwords): [0,32) 4*score table; then per pair g a profile  prof[b][lane][LW]  (b-stride BST, pair stride
 // PST).  BST = 0 and PST = 16 (mod 32) make the 32 lanes of a ds_read_b32 group hit 32 distinct banks whatever
 // bases they look up (lane stride 5 or 10 dwords is odd/2*odd -> a permutation within a pair, +16 for the
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     __shared__ int lds[32 + 4 * PST];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
-    if (lane < 25) lds[lane] = kp.sc4[lane];
+    if (lane < 25) lds[lane] = kp.sc4[lane] - (HFORM ? 2 * kp.e4 : 0); // rebased diagonal: s - 2e
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
 
@@ -72,13 +76,10 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const uint8_t *bp = SCORED ? nullptr : b_buf + (valid ? b_start[pl.src] + (WIN ? pl.col_off : 0) : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4;
-    // h-form carries X = h + e instead of h (XE = e): then I+e and D+e are one 2-cycle `and` + one 2-cycle add
-    // each and no separate retag is needed; (X|3) + s == M + e because e is a multiple of 4.
-    const int XE = HFORM ? kp.e4 : 0;
-    int vOE4, vE4, vO4, vE4p2, vE4p1; // constants pinned in VGPRs (2-cycle adds)
-    asm volatile("v_mov_b32 %0, %5\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %7\n\tv_mov_b32 %3, %8\n\tv_mov_b32 %4, %9"
-                 : "=v"(vOE4), "=v"(vE4), "=v"(vO4), "=v"(vE4p2), "=v"(vE4p1)
-                 : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4), "s"(kp.e4 + TI), "s"(kp.e4 + TD));
+    constexpr bool REB = HFORM;   // rebased keys (see above)
+    const int RB = REB ? E4 : 0;  // V' = V - RB*(i + j)
+    int vOE4, vE4, vO4; // constants pinned in VGPRs
+    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vOE4), "=v"(vE4), "=v"(vO4) : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4));
     int bad = 0;
 
     const int s_lo = piped ? strip_map[blockIdx.x].y : 0, s_hi = piped ? s_lo + 1 : S_max;
@@ -120,17 +121,18 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = row0 + r + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
-            const int D1c = kp.d00_4 + i * kp.ecol4 + TD;
-            hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c) + XE;
-            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4);
-            if (XP && r == r_last) rt[r] = D1c; // I'(n,1) = h(n,0), no penalty
-            if (WIN && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x; hold[r] = v.y; }
+            const int D1c = kp.d00_4 + i * kp.ecol4 + TD - RB * i;            // D(i,0), rebased with j = 0
+            hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
+            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;      // I(i,1) = D(i,0) + oe, rebased with j = 1
+            if (XP && r == r_last) rt[r] = D1c - RB; // I'(n,1) = h(n,0), no penalty
+            // checkpoint {I(i,j+1), h(i,j)+e} of the sweep, plain values: both lose e*(i + 1) (window column 0; the e of "h+e" is the other one)
+            if (WIN && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x - RB * (i + 1); hold[r] = v.y - (REB ? RB * (i + 1) : 0); }
             acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
         }
-        int diag0 = ((row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD)) + XE;
+        int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
         if (WIN && ck0) {
-            if (row0 == 0) diag0 = max3i(NEG4 + 3, (XP ? 0 : kp.o4 + pl.col_off * E4) + TI, NEG4 + TD) + XE; // h(0, col_off)
-            else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y;
+            if (row0 == 0) diag0 = max3i(NEG4 + 3, (XP ? 0 : kp.o4 + pl.col_off * E4) + TI, NEG4 + TD); // h(0, col_off)
+            else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y - (REB ? RB * (row0 + 1) : 0);
         }
         int dn_out = 0, h_out = 0, b_out = 0;
         int sq_dn = 0, sq_h = 0;
@@ -138,13 +140,13 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
         auto boundary = [&](int c, int &odn, int &oh, int &ob) {
             if (!MULTI || s == 0) {
-                const int M3 = NEG4 + 3, I2 = (XP ? 0 : kp.o4 + ((WIN ? pl.col_off : 0) + c) * E4) + TI, D1 = NEG4 + TD; // row 0: I(0,c) = gapOpen + c*gapExtend (XP: free)
+                const int M3 = NEG4 + 3, I2 = (XP ? 0 : kp.o4 + ((WIN ? pl.col_off : 0) + c) * E4) + TI - RB * c, D1 = NEG4 + TD; // row 0: I(0,c) = gapOpen + c*gapExtend (XP: free), rebased with i = 0
                 const int h0 = max3i(M3, I2, D1);
-                odn = (LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4);
-                oh = h0 + XE;
+                odn = ((LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4)) - RB; // D(1,c): one row further down
+                oh = h0;
             } else if (c >= 1 && c <= m_eff) {
                 const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
-                odn = v.x; oh = v.y; // already in the X domain
+                odn = v.x; oh = v.y; // rebased like everything else
             } else { odn = 0; oh = 0; }
             int b = 0;
             if (!SCORED && c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
@@ -194,16 +196,16 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                     acc[r] = alignbit2((unsigned)hd, acc[r]);
                     acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
                     acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
-                    int hnew, dnn; // hnew is in the X domain (h + XE)
-                    if (HFORM) {
-                        const int M3e = (hd | 3) + S4;             // M + e
-                        const int Ie = (rt[r] & ~3) + vE4p2;       // I + e, tag 2
-                        const int De = (dnu & ~3) + vE4p1;         // D + e, tag 1
-                        hnew = max3i(M3e, Ie, De);                 // h + e
-                        const int hoe = hnew + vO4;                // h + oe
-                        rt[r] = max(hoe, Ie);
-                        dnn = max(hoe, De);
-                        if (LOCAL) dnn = (j == m_eff) ? hnew - vE4 : dnn; // last column: D(i+1,m) = tmt(M,I,D)(i,m), no penalty
+                    int hnew, dnn;
+                    if (HFORM) { // rebased keys
+                        const int M3 = (hd | 3) + S4;              // S4 = 4*(s - 2e)
+                        const int I2 = (rt[r] & ~3) | TI;
+                        const int D1 = (dnu & ~3) | TD;
+                        hnew = max3i(M3, I2, D1);
+                        const int ho = hnew + vO4;                 // both opens
+                        rt[r] = max(ho, I2);
+                        dnn = max(ho, D1);
+                        if (LOCAL) dnn = (j == m_eff) ? hnew - vE4 : dnn; // last column: D(i+1,m) = tmt(M,I,D)(i,m), no penalty (the -e is the rebase of the next row)
                         if (XP) rt[r] = (r == r_last) ? hnew - vE4 : rt[r]; // transposed: last row, I'(n,j+1) = tmt(M,I',D')(n,j)
                     } else {
                         const int M3 = (hd | 3) + S4;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r] - XE;
+            for (int r = 0; r < R; r++) if (row0 + r < pl.n) hcol[pl.hcol_off + row0 + r] = hold[r] + RB * (row0 + r + 1 + m_eff); // plain h(i, m)
             // last-column D-plane fields of this lane's rows, packed (field r at bits 2r): lets the traceback skip
             // vertical runs in column m (free end gaps of AffineGapLocal, trailing gaps when alpha is the long one)
             const int t0f = ((m_eff + l - 1) >> 4) << 4, missf = t0f + 16 - l - m_eff; // 0..15: in-place drain shift

@@ -434,7 +434,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     }
     // ---- plan ----
     bool p16 = true; // 4*score fits a signed 16-bit profile entry
-    for (int x = 0; x < 25; x++) if (prm->scores[x] > 8191 || prm->scores[x] < -8192) p16 = false;
+    for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * (affine ? prm->gap_extend : 0)); if (v > 32767 || v < -32768) p16 = false; }
     if (!getenv("GNX_FORCE_P16")) p16 = false; // int32 profile: plain 2-cycle VGPR add instead of a 4-cycle SDWA add
     bool hform = affine && prm->gap_open <= 0;
     if (getenv("GNX_NO_HFORM")) hform = false;
@@ -674,7 +674,10 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     hipStream_t st = c.own_stream;
     int64_t smax = 0; // int16 score matrix when every 4 * cell score fits (a cell is a sum of `chunk` scores, or of averages of scores)
     for (int x = 0; x < 25; x++) smax = std::max<int64_t>(smax, llabs((long long)prm->scores[x]));
-    const bool s16 = 4 * chunk * smax <= 32767;
+    // the fill's h-form works on rebased keys: the matrix entries carry the -2e of the diagonal move (e = gapExtend * chunk)
+    const bool hform_sc = prm2.gap_open <= 0 && !getenv("GNX_NO_HFORM");
+    const int64_t bias4 = hform_sc ? -8 * prm2.gap_extend : 0;
+    const bool s16 = 4 * chunk * smax + llabs((long long)bias4) <= 32767;
     std::vector<int64_t> hn((size_t)n_pairs), hm((size_t)n_pairs), hso((size_t)n_pairs);
     int64_t stot = 0, worst = 0, maxcols = 1;
     for (int64_t p = 0; p < n_pairs; p++) {
@@ -701,7 +704,7 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
         const unsigned nx = (unsigned)std::min<int64_t>((maxcols + 3) / 4, 1024);
         auto ksm = s16 ? score_matrix_kernel<true> : score_matrix_kernel<false>;
         hipLaunchKernelGGL(ksm, dim3(nx, ny), dim3(64, 4), 0, st, reinterpret_cast<const ScorePair *>(c.sc_pairs.p) + b,
-                           reinterpret_cast<const uint8_t *>(c.in_a.p), kp0, (int)chunk, groups ? 1 : 0, reinterpret_cast<int *>(c.sc_mat.p), reinterpret_cast<int *>(c.sc_err.p));
+                           reinterpret_cast<const uint8_t *>(c.in_a.p), kp0, (int)chunk, groups ? 1 : 0, (int)bias4, reinterpret_cast<int *>(c.sc_mat.p), reinterpret_cast<int *>(c.sc_err.p));
     }
     HIPCHK(hipGetLastError());
     int sflag[4] = {0, 0, 0, 0};
