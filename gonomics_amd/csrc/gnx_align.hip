@@ -419,13 +419,16 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         if (fp) {
             // sub-batches whose fast-path working set (checkpoints, planes, window slots, staging) fits the workspace
             const size_t fixed = (size_t)FP_WWORDS * QA * G * 16 + FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + H * 4 + G * 4 + 64;
+            // ... of about equal size (a small last sub-batch would leave most of the GPU idle for the length of a sweep wave)
             std::vector<int64_t> cb{0};
-            size_t acc_b = 0;
+            size_t acc_b = 0, total_b = 0;
             const size_t budget = (size_t)(c.ws_limit - c.ws_limit / 8);
-            for (int64_t p = 0; p < n_pairs; p++) {
-                const size_t b = fixed + (size_t)((h_cols[p] - 1) / CKW) * h_rows[p] * 8 + (size_t)FP_PLANES * ((h_cols[p] + 30) / 16) * 4;
-                if (b > budget) { fp = false; break; }
-                if (acc_b + b > budget) { cb.push_back(p); acc_b = 0; }
+            auto pair_bytes = [&](int64_t p) { return fixed + (size_t)((h_cols[p] - 1) / CKW) * h_rows[p] * 8 + (size_t)FP_PLANES * ((h_cols[p] + 30) / 16) * 4; };
+            for (int64_t p = 0; p < n_pairs; p++) { const size_t b = pair_bytes(p); if (b > budget) { fp = false; break; } total_b += b; }
+            const size_t n_sub = (total_b + budget - 1) / budget, target = n_sub ? std::min(budget, total_b / n_sub + (size_t)(1 << 20)) : budget;
+            for (int64_t p = 0; fp && p < n_pairs; p++) {
+                const size_t b = pair_bytes(p);
+                if (acc_b > 0 && acc_b + b > target) { cb.push_back(p); acc_b = 0; } // target <= budget, and no single pair exceeds the budget
                 acc_b += b;
             }
             cb.push_back(n_pairs);
