@@ -20,7 +20,8 @@ namespace {
 //   1 = LeftDynamicAln: zero borders, cell values clamped at 0 (the trace keeps its direction);
 //   2 = RightDynamicAln: the ordinary borders plus, per row, the running maximum of (score << 12 | 4095 - column), i.e. the first
 //       column of the row's best score; hcol receives that key instead of the last-column value.
-template <bool MULTI, int GSW = 0>
+// P16: every profile entry fits int16 (host check): packed profile, half the LDS (24 instead of 12 workgroups per CU)
+template <bool MULTI, int GSW = 0, bool P16 = false>
 __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                         const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                         const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                                                         int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int *__restrict__ err,
                                                         const int2 *__restrict__ strip_map = nullptr, int *__restrict__ strip_prog = nullptr) {
     // MULTI: one workgroup per (group of 4 pairs, strip), pipelined through the row buffer -- see fill_affine_kernel
-    using PC = ProfCfg<false>;
+    using PC = ProfCfg<P16>;
     constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
     __shared__ int lds[32 + 4 * PST];
     const int lane = threadIdx.x;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
 #pragma unroll
             for (int b = 0; b < 5; b++) {
 #pragma unroll
-                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = lds[a5[k] + b];
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
             }
             __syncthreads();
         }
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                 int vd = diag0, vu = up_v;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const int k = REB ? max3i(vd + w[r], val[r], vu - 1) : max3i(vd + w[r], val[r] + vGL, vu + vGU);
+                    const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                    const int k = REB ? max3i(vd + S4, val[r], vu - 1) : max3i(vd + S4, val[r] + vGL, vu + vGU);
                     acc[r] = alignbit2((unsigned)k, acc[r]);
                     vd = val[r];
                     val[r] = REB ? ((k & ~3) | 2) : (k & ~3);

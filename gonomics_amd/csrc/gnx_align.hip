@@ -598,11 +598,18 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
 #undef GNX_LAUNCH_AFF2
 #undef GNX_LAUNCH_AFF
         } else {
-#define GNX_LAUNCH_CONST(M_, G_) hipLaunchKernelGGL((fill_const_kernel<M_, G_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_sprog)
+            // pipelined strips: int16 profile when every entry (4*(s - 2g) + 1 rebased, 4*s + 3 for the gsw variants) fits -- half the
+            // LDS, 24 instead of 12 strips resident per CU (C5 miniature fill 125.7 -> 117.9 ms).  One wave per 4 pairs is paced by
+            // its instruction count and keeps the int32 profile (C2-shaped ConstGap: 5.44e12 vs 5.18e12 cells/s with the SDWA adds).
+            bool cp16 = piped && !getenv("GNX_CONST_P32");
+            for (int x = 0; x < 25; x++) { const int64_t v = gsw ? 4 * prm->scores[x] + 3 : 4 * (prm->scores[x] - 2 * prm->gap_open) + 1; if (v > 32767 || v < -32768) cp16 = false; }
+#define GNX_LAUNCH_CONST1(M_, G_, P_) hipLaunchKernelGGL((fill_const_kernel<M_, G_, P_>), gridF, blockF, 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_sprog)
+#define GNX_LAUNCH_CONST(M_, G_) do { if (cp16) GNX_LAUNCH_CONST1(M_, G_, true); else GNX_LAUNCH_CONST1(M_, G_, false); } while (0)
             if (gsw == 1) { if (multi) GNX_LAUNCH_CONST(true, 1); else GNX_LAUNCH_CONST(false, 1); }
             else if (gsw == 2) { if (multi) GNX_LAUNCH_CONST(true, 2); else GNX_LAUNCH_CONST(false, 2); }
             else { if (multi) GNX_LAUNCH_CONST(true, 0); else GNX_LAUNCH_CONST(false, 0); }
 #undef GNX_LAUNCH_CONST
+#undef GNX_LAUNCH_CONST1
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
