@@ -25,7 +25,11 @@ struct FpState {
     int32_t j_hi, jc_lo;
 };
 
-template <bool FIRST, bool TILED = false, bool XP = false>
+// CW = one WAVE per pair instead of one lane: every lane runs the same walk (lane 0 writes), and the three kinds of long runs are
+//   taken with one cooperative look each -- 64 plane words (1024 columns) of an I-run on a stored plane or inside a tile, 64 cells
+//   of a diagonal run inside a window -- instead of one dependent load per word / per cell.  100 000 waves of a few looks each
+//   finish sooner than 1 563 waves of lanes that each walk alone.
+template <bool FIRST, bool TILED = false, bool XP = false, bool CW = false>
 __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
                                                      FpState *__restrict__ states, const int *__restrict__ hcol_fwd,
                                                      const unsigned *__restrict__ rowi, const unsigned *__restrict__ tail,
@@ -34,8 +38,10 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                                                      int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                      int *__restrict__ next_active, int *__restrict__ next_count,
                                                      PairPlan *__restrict__ next_wplans, int *__restrict__ err, int p_base) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = CW ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (a >= n_active) return;
+    const int lane = threadIdx.x & 63;
+    const bool writer = !CW || lane == 0;
     const int p = FIRST ? a + p_base : active[a];
     const PairPlan pl = plans[p];
     auto k_of = [](int tag) { return XP ? (tag == 3 ? 0 : tag) : 3 - tag; }; // state of a direction tag
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
     PairPlan wp;
     if (FIRST) {
         const int hc = hcol_fwd[pl.hcol_off];
-        score_out[p] = (int64_t)(hc >> 2);
+        if (writer) score_out[p] = (int64_t)(hc >> 2);
         st.i = pl.n; st.j = pl.m; st.k = k_of(hc & 3); st.last_op = -1;
         st.cur_op = -1; st.cnt = 0; st.status = 0; st.slot = -1; st.cur_run = 0;
         st.li = (int64_t)(pl.n - 1) % tp.ci;
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
     gnx_cigar *stg = stage + (int64_t)p * FP_CAP;
     auto flush_run = [&]() {
         if (cur_op >= 0) {
-            if (cnt < FP_CAP) { gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op; for (int z = 0; z < 7; z++) c._pad[z] = 0; stg[cnt] = c; }
+            if (cnt < FP_CAP && writer) { gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op; for (int z = 0; z < 7; z++) c._pad[z] = 0; stg[cnt] = c; }
             cnt++;
         }
     };
@@ -119,6 +125,21 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                 k = k_of(tag);
             }
             emit(op_of(1), steps); j -= steps; last_op = 1;
+            if (CW && TILED && !on_plane && x == 0 && steps == pos + 1 && j >= lo_ok(st.jc_lo)) {
+                // a straggler's long gap on a row without a stored plane: 64 words of its tile per look (lane t takes the t-th word
+                // further left), while they are all-I and lie inside the usable part of the tile
+                const int i0 = i - 1, l2 = i0 / R, r2 = i0 - l2 * R, d = R + r2; // one strip: n <= 160
+                const int t1 = (j - st.jc_lo) + l2 - 1;
+                if ((t1 & 15) == 15) {
+                    const int wq = (t1 >> 4) - lane;
+                    const bool ok = wq >= 0 && 16 * wq - l2 + 1 >= lo_ok(st.jc_lo) - st.jc_lo; // all 16 fields are usable columns
+                    unsigned qv = 0;
+                    if (ok) qv = reinterpret_cast<const unsigned *>(wtrace + wp.trace_off + ((int64_t)wq * QA + (d >> 2)) * G + l2)[d & 3];
+                    const unsigned long long stop = __ballot(!(ok && qv == IRUN));
+                    const int T = stop ? __ffsll((long long)stop) - 1 : 64;
+                    if (T > 0) { emit(op_of(1), 16 * (int64_t)T); j -= 16 * T; }
+                }
+            }
             if (on_plane && x == 0 && steps == pos + 1) {
                 // the run continues below field 0 of this word: take whole 16-column words while they are all-I, four loads in
                 // flight (a 10 kb trailing gap is 600 dependent loads otherwise).  Only on the stored planes, where the lanes of
@@ -126,7 +147,15 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                 const unsigned *wbase = rowi + pl.rowi_off + (int64_t)(pl.n - i) * pl.words;
                 int wi = ((j + steps + G8 - 1) >> 4) - 1;
                 bool more = true;
-                while (more && wi >= 0 && j >= 16) {
+                while (CW && more && wi >= 0 && j >= 16) { // 64 words per look
+                    const int lim = min(min(wi + 1, j >> 4), 64);
+                    const unsigned qv = lane < lim ? wbase[wi - lane] : 0u;
+                    const unsigned long long stop = __ballot(!(lane < lim && qv == IRUN));
+                    const int T = stop ? __ffsll((long long)stop) - 1 : 64;
+                    if (T > 0) { emit(op_of(1), 16 * (int64_t)T); j -= 16 * T; wi -= T; }
+                    more = (T == 64);
+                }
+                while (!CW && more && wi >= 0 && j >= 16) {
                     unsigned q[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) q[u] = (wi - u >= 0) ? wbase[wi - u] : 0u;
@@ -162,24 +191,26 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         else if (up_exit && !left_exit) emit(op_of(1), j);
         flush_run();
         cur_op = -1;
-        nops[p] = cnt;
+        if (writer) nops[p] = cnt;
         if (cnt > FP_CAP) atomicOr(err, 8);
         st.status = 1;
     } else {
         // request the window (jc_lo, j] : at least FP_SPAN wide, starting on a checkpoint column (or column 0)
-        const int slot = atomicAdd(next_count, 1);
+        int slot = 0;
+        if (writer) slot = atomicAdd(next_count, 1);
+        if (CW) slot = __builtin_amdgcn_readfirstlane(slot);
         int jc = j - FP_SPAN;
         jc = jc <= 0 ? 0 : (jc / CKW) * CKW;
         st.j_hi = j; st.jc_lo = jc; st.slot = slot; st.status = 0;
-        next_active[slot] = p;
+        if (writer) next_active[slot] = p;
         PairPlan q;
         q.n = pl.n; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = 1;
         q.trace_off = (int64_t)slot * FP_WWORDS * QA * G; q.hcol_off = (int64_t)slot * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)slot * G;
         q.src = pl.src; q.col_off = jc; q.ckpt_off = pl.ckpt_off; q.rowi_off = 0;
-        next_wplans[slot] = q;
+        if (writer) next_wplans[slot] = q;
     }
     st.i = i; st.j = j; st.k = k; st.last_op = last_op; st.cur_op = cur_op; st.cnt = cnt; st.cur_run = cur_run; st.li = li;
-    states[p] = st;
+    if (writer) states[p] = st;
 }
 
 // stragglers (the path keeps needing windows, e.g. a long gap on a row without a stored plane): every remaining

@@ -240,11 +240,19 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * G;
         int cur = 0, n_act = 0, it = 0;
         float f = 0;
-        auto k_first = xp ? fp_walk_kernel<true, false, true> : fp_walk_kernel<true, false, false>;
-        auto k_next = xp ? fp_walk_kernel<false, false, true> : fp_walk_kernel<false, false, false>;
-        auto k_tiled = xp ? fp_walk_kernel<false, true, true> : fp_walk_kernel<false, true, false>;
+        // The stragglers' walk through their tiles runs one WAVE per pair (lanes that walk alone diverge: 0.80 -> 0.5 ms for 1 700
+        // stragglers, and a long gap is taken 64 tile words per look); the first walk and the window walk stay one lane per pair
+        // (100 000 waves of redundant scalar work cost more than they save: 0.45 -> 1.14 ms).  GNX_WALK_LANE=1: lanes everywhere;
+        // GNX_WALK_CW=1: waves for the first walk as well (A/B runs).
+        const bool cw = !getenv("GNX_WALK_LANE");
+        const bool cw_first = cw && getenv("GNX_WALK_CW");
+        auto k_first = cw_first ? (xp ? fp_walk_kernel<true, false, true, true> : fp_walk_kernel<true, false, false, true>) : (xp ? fp_walk_kernel<true, false, true> : fp_walk_kernel<true, false, false>);
+        const bool cw_next = cw && getenv("GNX_WALK_CWNEXT");
+        auto k_next = cw_next ? (xp ? fp_walk_kernel<false, false, true, true> : fp_walk_kernel<false, false, false, true>) : (xp ? fp_walk_kernel<false, false, true> : fp_walk_kernel<false, false, false>);
+        auto k_tiled = cw ? (xp ? fp_walk_kernel<false, true, true, true> : fp_walk_kernel<false, true, false, true>) : (xp ? fp_walk_kernel<false, true, true> : fp_walk_kernel<false, true, false>);
+        auto wgrid = [&](int n) { return dim3((unsigned)(cw ? n : (n + 63) / 64)); };
         auto k_win = xp ? fill_affine_kernel<false, false, false, true, true, false, true> : fill_affine_kernel<false, false, false, true, true, false, false>;
-        hipLaunchKernelGGL(k_first, dim3((unsigned)((cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_tail,
+        hipLaunchKernelGGL(k_first, dim3((unsigned)(cw_first ? cnt : (cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_tail,
                            (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, d_wpl[0] + p0, d_err, p0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&n_act, cnt2, 4, hipMemcpyDeviceToHost, st));
@@ -257,7 +265,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                                wtr, whc, (int2 *)nullptr, wdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(e2, st));
-            hipLaunchKernelGGL(k_next, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
+            hipLaunchKernelGGL(k_next, dim3((unsigned)(cw_next ? n_act : (n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
                                d_wpl[cur] + p0, wtr, whc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, d_wpl[nxt] + p0, d_err, 0);
             HIPCHK(hipGetLastError());
             int n_next = 0;
@@ -289,7 +297,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                                ttr, thc, (int2 *)nullptr, tdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
             HIPCHK(hipEventRecord(e2, st));
             HIPCHK(hipMemsetAsync(cnt2, 0, 8, st));
-            hipLaunchKernelGGL(k_tiled, dim3((unsigned)((n_strag + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_strag, d_st, d_hfwd, d_rowi, d_tail,
+            hipLaunchKernelGGL(k_tiled, wgrid(n_strag), blockT, 0, st, dpl, d_act[cur] + p0, n_strag, d_st, d_hfwd, d_rowi, d_tail,
                                tpl, ttr, thc, tp, d_stage, d_score, d_nops, d_act[cur ^ 1] + p0, cnt2, d_wpl[cur ^ 1] + p0, d_err, 0);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));
