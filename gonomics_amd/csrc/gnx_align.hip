@@ -76,7 +76,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf strip_map, tb_scr, tb_scr_off, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
+    DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -151,6 +151,20 @@ int64_t max_abs_pen(const gnx_params *p, bool affine) {
 int run_device(const gnx_params *prm, int64_t n_pairs, const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                const int64_t *h_alen, const int64_t *h_blen, int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
                int64_t *out_total, hipStream_t stream, const int *d_smat, const int64_t *h_soff, int gsw, int2 *d_endpos, bool no_fast_path, bool smat16);
+
+// exclusive scan of the run counts: off[0..n], carry[0] in / out (see scan_kernel); three launches when the array is long
+int launch_scan(const int64_t *d_nops, int n, int64_t *d_off, int64_t *d_carry, hipStream_t stream) {
+    Ctx &c = g_ctx;
+    if (n <= 8192) { hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, d_nops, n, d_off, d_carry); return GNX_OK; }
+    const int nb = (n + 1023) / 1024;
+    int rc;
+    if ((rc = c.scan_tmp.ensure((size_t)(2 * nb + 2) * 8))) return rc;
+    int64_t *sums = reinterpret_cast<int64_t *>(c.scan_tmp.p), *boff = sums + nb;
+    hipLaunchKernelGGL(scan_sums_kernel, dim3((unsigned)nb), dim3(1024), 0, stream, d_nops, n, sums);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, sums, nb, boff, d_carry); // boff[nb] = new carry
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(1024), 0, stream, d_nops, n, boff, d_off);
+    return GNX_OK;
+}
 
 int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, int64_t n_pairs,
                   const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
@@ -312,7 +326,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     if ((rc = forward(0, np, stream))) return rc;
     HIPCHK(hipEventRecord(c.ev[1], stream));
     if ((rc = post(0, np, stream, d_cnt, c.ev[4], c.ev[5]))) return rc;
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, d_nops, np, d_ops_off, d_carry);
+    if ((rc = launch_scan(d_nops, np, d_ops_off, d_carry, stream))) return rc;
     hipLaunchKernelGGL(fp_compact_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, d_st, d_stage, d_nops, d_ops_off, d_ops, ops_capacity, d_err);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c.ev[3], stream));
@@ -651,7 +665,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         else if (coop) hipLaunchKernelGGL((traceback_kernel<false, false, true>), gridC, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
         else if (affine) hipLaunchKernelGGL((traceback_kernel<true, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
         else hipLaunchKernelGGL((traceback_kernel<false, false>), gridT, blockT, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score + b, dn, (const int64_t *)nullptr, (gnx_cigar *)nullptr, (int64_t)0, d_err);
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, dn, np, d_ops_off + b, d_carry);
+        if ((rc = launch_scan(dn, (int)np, d_ops_off + b, d_carry, stream))) return rc;
         if (gsw == 1) GNX_GSW_TB(false, true);
         else if (gsw == 2) GNX_GSW_TB(true, true);
         else if (scr) hipLaunchKernelGGL(reverse_runs_kernel, gridC, dim3(256), 0, stream, dpl, np, d_scr, d_scr_off, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
@@ -867,7 +881,7 @@ void gnx_shutdown(void) {
     if (!g_ctx.inited) return;
     (void)hipSetDevice(g_ctx.device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&g_ctx.strip_map, &g_ctx.tb_scr, &g_ctx.tb_scr_off, &g_ctx.fp_redo, &g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
+    DevBuf *bufs[] = {&g_ctx.strip_map, &g_ctx.tb_scr, &g_ctx.tb_scr_off, &g_ctx.scan_tmp, &g_ctx.fp_redo, &g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
                       &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
                       &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops, &g_ctx.out_end,
                       &g_ctx.sc_pairs, &g_ctx.sc_mat, &g_ctx.sc_err};
