@@ -261,8 +261,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         const bool cw = !getenv("GNX_WALK_LANE");
         const bool cw_first = cw && getenv("GNX_WALK_CW");
         auto k_first = cw_first ? (xp ? fp_walk_kernel<true, false, true, true> : fp_walk_kernel<true, false, false, true>) : (xp ? fp_walk_kernel<true, false, true> : fp_walk_kernel<true, false, false>);
-        const bool cw_next = cw && getenv("GNX_WALK_CWNEXT");
-        auto k_next = cw_next ? (xp ? fp_walk_kernel<false, false, true, true> : fp_walk_kernel<false, false, false, true>) : (xp ? fp_walk_kernel<false, false, true> : fp_walk_kernel<false, false, false>);
+        auto k_next = xp ? fp_walk_kernel<false, false, true> : fp_walk_kernel<false, false, false>;
         auto k_tiled = cw ? (xp ? fp_walk_kernel<false, true, true, true> : fp_walk_kernel<false, true, false, true>) : (xp ? fp_walk_kernel<false, true, true> : fp_walk_kernel<false, true, false>);
         auto wgrid = [&](int n) { return dim3((unsigned)(cw ? n : (n + 63) / 64)); };
         auto k_win = xp ? fill_affine_kernel<false, false, false, true, true, false, true> : fill_affine_kernel<false, false, false, true, true, false, false>;
@@ -279,7 +278,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                                wtr, whc, (int2 *)nullptr, wdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(e2, st));
-            hipLaunchKernelGGL(k_next, dim3((unsigned)(cw_next ? n_act : (n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
+            hipLaunchKernelGGL(k_next, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
                                d_wpl[cur] + p0, wtr, whc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, d_wpl[nxt] + p0, d_err, 0);
             HIPCHK(hipGetLastError());
             int n_next = 0;
