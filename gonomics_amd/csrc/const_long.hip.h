@@ -1,0 +1,392 @@
+// const_long.hip.h -- constant-gap alignments WITHOUT a stored direction matrix: score-only sweep with snapshots + fused re-fill / walk
+// Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).  See DESIGN.md section 4.6.
+#pragma once
+#include "fill_affine.hip.h" // ProfCfg
+#include "traceback.hip.h"   // TbParams
+
+namespace {
+// ------------------------------------------------------------------------------------------------------
+// Long constant-gap pairs (config C5: 20 kb reads x 100 kb windows, align/constGap.go:13-68 with 10 000 x 10 000 checkerboards,
+// and ConstGap_highMem): a stored 2-bit direction matrix is 0.5 GB per pair.  Like the reference -- which keeps one row / column per
+// checkerboard and re-computes the checkerboards its path crosses (constGap.go:129-222) -- this path stores only what is needed to
+// re-compute, but at the granularity of the GPU mapping instead of 10 000 x 10 000 tiles:
+//
+//   cl_sweep_kernel   forward pass, SCORE ONLY.  Same wavefront mapping as fill_const_kernel (16 lanes x 10 rows per pair, 160-row
+//                     strips, pipelined strips for small launches) on rebased values V' = V - g*(i+j): per cell  add, max3  -- no
+//                     tags, no direction bits (2 VALU instructions instead of 5).  It keeps
+//                       * the bottom row of every strip (the row buffer the strips hand over anyway), 4 B per column, and
+//                       * a SNAPSHOT of the wavefront every CKC steps: the 10 row values + the diagonal value of every lane, i.e. the
+//                         complete state from which the wave can resume at step c*CKC (wave-uniform, coalesced 768 B per pair).
+//   cl_walk_kernel    traceback, one wave per 4 pairs, everything on the device: for the strip s and snapshot interval c the walk is
+//                     in, RE-FILL the <= CKC steps from the snapshot with the recording recurrence of fill_const_kernel into a
+//                     direction-bit tile in LDS (20 KB per pair), walk inside the tile with LDS latency instead of HBM latency, move
+//                     on to the next tile.  The tiles a path crosses are ~1 % of the matrix.
+//
+// Values and argmax tags of a re-filled tile are those of the full fill (same recurrence from exact state), so the walk sees the
+// bits fill_const_kernel would have stored; the walk itself (run merging, Step 4 with quirk Q2) is traceback_kernel<false>'s.
+// Memory per 20 kb x 100 kb pair: row buffer 50 MB + snapshots 19 MB + run staging 2 MB instead of 500 MB.
+// ------------------------------------------------------------------------------------------------------
+constexpr int CKC = 512;                          // snapshot spacing in wavefront steps (multiple of 16)
+constexpr int CL_WORDS = CKC / 16;                // direction words per lane row and tile
+constexpr int SNAPW = 12;                         // dwords per lane per snapshot: val[R], diag0, pad
+constexpr int CL_DIRG = CL_WORDS * R * G + 16;    // LDS dwords of one pair's tile (+16: neighbouring pairs start in different banks)
+
+__device__ __forceinline__ void rb_store32(int *p, int v, bool piped) {
+    if (piped && !GNX_RB_FENCE) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ int rb_load32(const int *p, bool piped) {
+    if (piped && !GNX_RB_FENCE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+// PairPlan fields used here: n, m, strips, rowbuf_off (ints), ckpt_off (ints: snapshots [c-1][strip][lane][SNAPW]), hcol_off (slot of
+// the final value), src (output slot).
+template <bool P16>
+__global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                      KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
+                                                      int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
+    using PC = ProfCfg<P16>;
+    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    __shared__ int lds[32 + 4 * PST];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.g4; // rebased diagonal move: 4*(s - 2g); every value carries tag 2
+    int *prof = &lds[32 + g * PST];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    const bool piped = strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
+    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
+    int S_max = 0, m_max = 0;
+    for (int q = 0; q < 4; q++) {
+        if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
+    }
+    const int p = pbase + g;
+    const bool valid = p < n_pairs;
+    PairPlan pl;
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
+    const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    const int Tend = (m_max + 15 + 15) & ~15;
+    int bad = 0;
+
+    const int s_lo = piped ? strip_map[blockIdx.x].y : 0, s_hi = piped ? s_lo + 1 : S_max;
+    const int64_t rb_pitch = (int64_t)pl.m + 1;
+    for (int s = s_lo; s < s_hi; s++) {
+        const bool gact = valid && s < pl.strips;
+        const int m_eff = gact ? pl.m : 0;
+        int m_min = 0x7fffffff;
+        for (int q = 0; q < 4; q++) m_min = min(m_min, (pbase + q < n_pairs && s < plans[pbase + q].strips) ? plans[pbase + q].m : 0);
+        const bool store_row = gact && (s + 1 < pl.strips);
+        const int row0 = s * H + l * R;
+        int val[R];
+        {
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) val[r] = 2; // column 0, rebased: 0 (tag 2)
+        int diag0 = 2;
+        int v_out = 0, b_out = 0, sq_v = 0;
+        int qv, qb, nv = 0, nb = 0;
+        auto boundary = [&](int c, int &ov, int &ob) {
+            if (s == 0) ov = 2; // row 0, rebased
+            else if (c >= 1 && c <= m_eff) ov = rb_load32(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
+            else ov = 0;
+            int b = 0;
+            if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            ob = b * (BST * 4);
+        };
+        int rb_seen = 0;
+        auto wait_rows = [&](int cmax) {
+            if (piped && s > 0 && rb_seen < cmax) {
+                const long long t_begin = wall_clock64();
+                while ((rb_seen = rb_progress(&strip_prog[blockIdx.x - 1])) < cmax) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; }
+                }
+            }
+        };
+        if (!piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wait_rows(G);
+        boundary(l + 1, qv, qb);
+
+        auto step = [&](const int t, auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_v = dpp_shr1(qv, v_out);
+            const int pb = dpp_shr1(qb, b_out);
+            qv = dpp_shl1(qv, qv);
+            qb = dpp_shl1(qb, qb);
+            const int j = t - l;
+            b_out = pb;
+            if (!CHECK || (j >= 1 && j <= m_eff)) {
+                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
+                int w[LW];
+#pragma unroll
+                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                int vd = diag0, vu = up_v;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                    const int k = max3i(vd + S4, val[r], vu);
+                    vd = val[r];
+                    val[r] = k;
+                    vu = k;
+                }
+                diag0 = up_v;
+                v_out = vu;
+            }
+            sq_v = dpp_shl1(v_out, sq_v);
+        };
+
+        for (int t0 = 0; t0 < Tend; t0 += 16) {
+            if (t0 > 0 && (t0 & (CKC - 1)) == 0 && gact && t0 <= m_eff + 15) { // snapshot: the state the wave resumes from at step t0
+                uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / CKC - 1) * pl.strips + s) * G + l) * SNAPW);
+                dst[0] = make_uint4((unsigned)val[0], (unsigned)val[1], (unsigned)val[2], (unsigned)val[3]);
+                dst[1] = make_uint4((unsigned)val[4], (unsigned)val[5], (unsigned)val[6], (unsigned)val[7]);
+                dst[2] = make_uint4((unsigned)val[8], (unsigned)val[9], (unsigned)diag0, 0u);
+            }
+            wait_rows(t0 + 2 * G);
+            boundary(t0 + 16 + l + 1, nv, nb);
+            if (t0 >= 16 && t0 + 16 <= m_min) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+            }
+            qv = nv; qb = nb;
+            if (store_row) {
+                const int c = t0 + l - 14;
+                if (c >= 1 && c <= m_eff) rb_store32(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_v, piped);
+            }
+            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[blockIdx.x], t0 + 1, lane);
+        }
+        if (gact && m_eff >= 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (val[r] >> 2) + (kp.g4 >> 2) * (pl.n + m_eff); // plain V(n, m)
+        }
+        if (piped) rb_publish(&strip_prog[blockIdx.x], 0x7fffffff, lane);
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+// One wave per 4 pairs.  Per round every pair (16 lanes) re-fills the tile its walk is in -- strip s = (i-1)/160, steps
+// (c*CKC, j + lane(i)] of that strip's wavefront -- into LDS, then lane 0 of the pair walks inside the tile until it leaves it.
+// Runs are staged in traceback order at scr[scr_off[p] ..] (n + m + 2 entries per pair); reverse_runs_kernel puts them in place.
+template <bool P16>
+__global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                     const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                     const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                     KParams kp, TbParams tp, const int *__restrict__ rowbuf, const int *__restrict__ snap,
+                                                     const int *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                     const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err) {
+    using PC = ProfCfg<P16>;
+    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    __shared__ int lds[32 + 4 * PST + 4 * CL_DIRG];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.g4 + 1; // pre-tagged diagonal candidate (tag 3), see fill_const_kernel
+    int *prof = &lds[32 + g * PST];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + 4 * PST + g * CL_DIRG]);
+    const int p = blockIdx.x * 4 + g;
+    const bool valid = p < n_pairs;
+    PairPlan pl;
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
+    const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    const int64_t rb_pitch = (int64_t)pl.m + 1;
+    const int po = pl.src;
+    int bad = 0;
+    // walker state (lane 0 of the pair)
+    int wi = pl.n, wj = pl.m, wdone = valid ? 0 : 1;
+    int64_t cnt = 0, cur_run = 0;
+    int cur_op = -1, last_op = -1;
+    const int64_t sbase = valid ? scr_off[p] : 0;
+    auto flush_run = [&]() {
+        if (cur_op >= 0) {
+            gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op;
+            for (int z = 0; z < 7; z++) c._pad[z] = 0;
+            scr[sbase + cnt] = c;
+            cnt++;
+        }
+    };
+    auto emit = [&](int op, int64_t run) {
+        if (op == cur_op) cur_run += run;
+        else { flush_run(); cur_op = op; cur_run = run; }
+    };
+
+    while (true) {
+        const int src0 = lane & 48;
+        const int ci = __shfl(wi, src0, 64), cj = __shfl(wj, src0, 64), cdone = __shfl(wdone, src0, 64);
+        if (__all(cdone)) break;
+        const bool gact = !cdone;
+        const int s = gact ? (ci - 1) / H : 0;
+        const int lw = gact ? (ci - 1 - s * H) / R : 0;
+        const int tend = gact ? cj + lw : 0;   // step of the cell the walk is at
+        const int c = gact ? (tend - 1) / CKC : 0;
+        const int tbeg = c * CKC;
+        const int nblk = gact ? (tend - tbeg + 15) >> 4 : 0;
+        int nblk_max = nblk;
+        nblk_max = max(nblk_max, __shfl_xor(nblk_max, 16, 64));
+        nblk_max = max(nblk_max, __shfl_xor(nblk_max, 32, 64));
+        const int m_eff = gact ? pl.m : 0;
+        const int row0 = s * H + l * R;
+        int val[R];
+        unsigned acc[R];
+        {
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+            __syncthreads(); // table visible; the previous round's walk is over
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+            }
+            __syncthreads();
+        }
+        int diag0 = 2;
+#pragma unroll
+        for (int r = 0; r < R; r++) { val[r] = 2; acc[r] = 0; }
+        int v_out = 0, b_out = 0;
+        if (gact && c > 0) { // resume from the snapshot of step tbeg
+            const uint4 *sp = reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G + l) * SNAPW);
+            const uint4 x0 = sp[0], x1 = sp[1], x2 = sp[2];
+            val[0] = (int)x0.x; val[1] = (int)x0.y; val[2] = (int)x0.z; val[3] = (int)x0.w;
+            val[4] = (int)x1.x; val[5] = (int)x1.y; val[6] = (int)x1.z; val[7] = (int)x1.w;
+            val[8] = (int)x2.x; val[9] = (int)x2.y; diag0 = (int)x2.z;
+            v_out = val[R - 1];
+            const int jb = tbeg - l; // the column this lane processed at step tbeg: its base goes to the next lane
+            if (jb >= 1 && jb <= m_eff) { int b = bp[jb - 1]; if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
+        }
+        int qv, qb, nv = 0, nb = 0;
+        auto boundary = [&](int cc, int &ov, int &ob) {
+            if (s == 0) ov = 2;
+            else if (cc >= 1 && cc <= m_eff) ov = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
+            else ov = 0;
+            int b = 0;
+            if (cc >= 1 && cc <= m_eff) { b = bp[cc - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            ob = b * (BST * 4);
+        };
+        boundary(tbeg + l + 1, qv, qb);
+        auto step = [&](const int t, auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_v = dpp_shr1(qv, v_out);
+            const int pb = dpp_shr1(qb, b_out);
+            qv = dpp_shl1(qv, qv);
+            qb = dpp_shl1(qb, qb);
+            const int j = t - l;
+            b_out = pb;
+            if (!CHECK || (j >= 1 && j <= m_eff)) {
+                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
+                int w[LW];
+#pragma unroll
+                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                int vd = diag0, vu = up_v;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                    const int k = max3i(vd + S4, val[r], vu - 1);
+                    acc[r] = alignbit2((unsigned)k, acc[r]);
+                    vd = val[r];
+                    val[r] = (k & ~3) | 2;
+                    vu = val[r];
+                }
+                diag0 = up_v;
+                v_out = vu;
+            }
+        };
+        for (int b = 0; b < nblk_max; b++) {
+            const int t0 = tbeg + 16 * b; // per pair
+            boundary(t0 + 16 + l + 1, nv, nb);
+            if (__all(!gact || (t0 >= 16 && t0 + 16 <= m_eff))) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+            }
+            qv = nv; qb = nb;
+            if (gact && b < nblk) {
+                const int miss = (t0 + 16 - l) - m_eff; // steps this lane sat idle after its last column
+                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) dirg[(b * R + r) * G + l] = acc[r] >> sh;
+            }
+        }
+        __syncthreads();
+        if (l == 0 && gact) {
+            int i = wi, j = wj;
+            while (true) {
+                if (i == 0 || j == 0) { wdone = 1; break; }
+                const int i0 = i - 1 - s * H;
+                if (i0 < 0) break; // left the strip through its top edge
+                const int l2 = i0 / R, r2 = i0 - l2 * R;
+                const int t1 = j + l2 - 1 - tbeg;
+                if (t1 < 0) break; // left the tile through its (skewed) left edge
+                const int pos = t1 & 15;
+                const unsigned w = dirg[((t1 >> 4) * R + r2) * G + l2];
+                int tag = (int)((w >> (2 * pos)) & 3u);
+                if (tag == 0) { atomicOr(err, 2); wdone = 1; break; } // impossible direction: the Go code would log.Fatalf
+                const int op = 3 - tag;
+                if (op == 1) { // horizontal run: count the fields "came from the left" below pos with one xor + clz
+                    const int avail = min(pos + 1, j);
+                    unsigned x = w ^ 0xAAAAAAAAu;
+                    if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
+                    const int lowcut = pos + 1 - avail;
+                    if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+                    int steps;
+                    if (x == 0) steps = avail;
+                    else {
+                        const int pnz = (31 - __clz((int)x)) >> 1;
+                        if (((w >> (2 * pnz)) & 3u) == 0) { atomicOr(err, 2); wdone = 1; break; }
+                        steps = pos - pnz;
+                    }
+                    emit(1, steps); j -= steps; last_op = 1;
+                    continue;
+                }
+                emit(op, 1);
+                last_op = op;
+                i--;
+                if (op == 0) j--;
+            }
+            wi = i; wj = j;
+        }
+    }
+    if (l == 0 && valid) {
+        // Step 4 (constGap.go:59-63): the leading gap is appended only if the walk left through exactly one edge of its last
+        // checkerboard; a corner exit appends nothing, even when it is not the origin (quirk Q2)
+        const bool up_exit = (last_op != 1) && ((int64_t)wi % tp.ci == 0);
+        const bool left_exit = (last_op != 2) && ((int64_t)wj % tp.cj == 0);
+        if (!up_exit && left_exit) emit(2, wi);
+        else if (up_exit && !left_exit) emit(1, wj);
+        flush_run();
+        nops[po] = cnt;
+        score_out[po] = (int64_t)hfin[pl.hcol_off];
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+} // namespace

@@ -26,6 +26,7 @@
 //   fill_affine.hip.h  fill_affine_kernel        fp_sweep.hip.h   fp_sweep_kernel (dominant kernel of the headline workload)
 //   fill_const.hip.h   fill_const_kernel (+GSW)   traceback.hip.h  traceback_kernel, gsw_traceback_kernel
 //   fp_walk.hip.h      fp_walk_kernel & co        aux_kernels.hip.h score_matrix / scale_runs / scan kernels
+//   const_long.hip.h   cl_sweep_kernel / cl_walk_kernel: constant-gap pairs without a stored direction matrix (config C5)
 //   gnx_align.hip      host orchestration + C ABI (this file)
 #include "gnx_common.hip.h"
 #include "fill_affine.hip.h"
@@ -34,6 +35,7 @@
 #include "traceback.hip.h"
 #include "fp_walk.hip.h"
 #include "aux_kernels.hip.h"
+#include "const_long.hip.h"
 
 namespace {
 
@@ -392,6 +394,150 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     return GNX_OK;
 }
 
+// Constant-gap pairs without a stored direction matrix (const_long.hip.h): score-only sweep that keeps the strips' bottom rows and a
+// snapshot of the wavefront every CKC steps, then one fused re-fill + walk kernel.  Every n, m >= 1 (validated by the caller).
+// Returns GNX_OK, an error, or -1 when the batch should take the general path (a single pair exceeds the workspace).
+int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &tp, int64_t n_pairs,
+                     const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
+                     const int64_t *h_alen, const int64_t *h_blen,
+                     int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream) {
+    Ctx &c = g_ctx;
+    int rc;
+    std::vector<PairPlan> plans((size_t)n_pairs);
+    std::vector<int64_t> so((size_t)n_pairs + 1, 0); // staging offsets (runs), chunk-relative; so[chunk end] is unused
+    std::vector<int64_t> chunk_begin{0};
+    int64_t cells = 0, max_rb = 1, max_sn = 1, max_sc = 1;
+    {
+        int64_t rb = 0, sn = 0, sc = 0;
+        const int64_t budget = c.ws_limit - c.ws_limit / 16;
+        auto bytes_of = [](int64_t rb2, int64_t sn2, int64_t sc2) { return 4 * rb2 + 4 * sn2 + (int64_t)sizeof(gnx_cigar) * sc2; };
+        for (int64_t p = 0; p < n_pairs; p++) {
+            const int64_t n = h_alen[p], m = h_blen[p];
+            const int64_t strips = (n + H - 1) / H, ncp = (m + 15) / CKC;
+            const int64_t prb = (strips - 1) * (m + 1), psn = ncp * strips * G * SNAPW, psc = n + m + 2;
+            if (bytes_of(prb, psn, psc) > budget) return -1;
+            if (bytes_of(rb + prb, sn + psn, sc + psc) > budget) { // new chunk, 4-aligned so that waves stay whole
+                int64_t cb = p & ~(int64_t)3;
+                if (cb <= chunk_begin.back()) cb = p;
+                rb = sn = sc = 0;
+                for (int64_t q2 = cb; q2 < p; q2++) {
+                    PairPlan &pq = plans[(size_t)q2];
+                    pq.rowbuf_off = rb; pq.ckpt_off = sn; so[(size_t)q2] = sc; pq.hcol_off = q2 - cb; pq.src = (int32_t)(q2 - cb);
+                    rb += (int64_t)(pq.strips - 1) * (pq.m + 1); sn += (int64_t)((pq.m + 15) / CKC) * pq.strips * G * SNAPW; sc += (int64_t)pq.n + pq.m + 2;
+                }
+                chunk_begin.push_back(cb);
+            }
+            PairPlan &pl = plans[(size_t)p];
+            pl.n = (int32_t)n; pl.m = (int32_t)m; pl.words = 0; pl.strips = (int32_t)strips;
+            pl.trace_off = 0; pl.dcol_off = 0; pl.col_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0;
+            pl.rowbuf_off = rb; pl.ckpt_off = sn; so[(size_t)p] = sc;
+            pl.hcol_off = p - chunk_begin.back(); pl.src = (int32_t)(p - chunk_begin.back());
+            rb += prb; sn += psn; sc += psc;
+            max_rb = std::max(max_rb, rb); max_sn = std::max(max_sn, sn); max_sc = std::max(max_sc, sc);
+            cells += n * m;
+        }
+        chunk_begin.push_back(n_pairs);
+    }
+    int64_t max_np = 1;
+    for (size_t ch = 0; ch + 1 < chunk_begin.size(); ch++) max_np = std::max(max_np, chunk_begin[ch + 1] - chunk_begin[ch]);
+    if ((rc = c.rowbuf.ensure((size_t)max_rb * 4))) return rc;
+    if ((rc = c.fp_ckpt.ensure((size_t)max_sn * 4))) return rc;
+    if ((rc = c.tb_scr.ensure((size_t)max_sc * sizeof(gnx_cigar)))) return rc;
+    if ((rc = c.tb_scr_off.ensure(((size_t)n_pairs + 1) * 8))) return rc;
+    if ((rc = c.hcol.ensure((size_t)max_np * 4))) return rc;
+    c.fpc_ptr = nullptr;
+    if ((rc = c.plans.ensure((size_t)n_pairs * sizeof(PairPlan)))) return rc;
+    if ((rc = c.nops.ensure((size_t)n_pairs * 8))) return rc;
+    if ((rc = c.misc.ensure(64))) return rc;
+    int *d_err = reinterpret_cast<int *>(c.misc.p);
+    int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
+    HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
+    HIPCHK(hipMemcpyAsync(c.plans.p, plans.data(), (size_t)n_pairs * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(c.tb_scr_off.p, so.data(), ((size_t)n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream)); // plans / so are locals
+    // int16 profile when every entry 4*(s - 2g) + 1 fits (half the LDS reads per step); GNX_CL_P16=0/1 overrides for A/B runs
+    bool p16 = true;
+    for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * prm->gap_open) + 1; if (v > 32767 || v < -32768) p16 = false; }
+    if (getenv("GNX_CL_P16")) p16 = p16 && atoi(getenv("GNX_CL_P16")) != 0;
+    double fill_ms = 0, tb_ms = 0;
+    int64_t trace_bytes = 0;
+    HIPCHK(hipEventRecord(c.ev[0], stream));
+    const size_t nchunks = chunk_begin.size() - 1;
+    for (size_t ch = 0; ch < nchunks; ch++) {
+        const int64_t b = chunk_begin[ch], e = chunk_begin[ch + 1];
+        const int np = (int)(e - b);
+        if (np <= 0) continue;
+        const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p) + b;
+        int *drb = reinterpret_cast<int *>(c.rowbuf.p), *dsn = reinterpret_cast<int *>(c.fp_ckpt.p), *dhf = reinterpret_cast<int *>(c.hcol.p);
+        int64_t *dn = reinterpret_cast<int64_t *>(c.nops.p) + b;
+        const int64_t *d_so = reinterpret_cast<const int64_t *>(c.tb_scr_off.p) + b;
+        gnx_cigar *d_scr = reinterpret_cast<gnx_cigar *>(c.tb_scr.p);
+        bool multi = false;
+        int64_t m_maxc = 0;
+        for (int64_t q2 = b; q2 < e; q2++) { if (plans[(size_t)q2].strips > 1) multi = true; m_maxc = std::max<int64_t>(m_maxc, plans[(size_t)q2].m); }
+        int64_t n_blocks = (np + 3) / 4;
+        const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB && !getenv("GNX_NO_PIPE");
+        const int2 *d_smap = nullptr;
+        int *d_sprog = nullptr;
+        if (piped) {
+            std::vector<int2> smap;
+            for (int gq = 0; gq < (np + 3) / 4; gq++) {
+                int smax = 0;
+                for (int q3 = 0; q3 < 4 && gq * 4 + q3 < np; q3++) smax = std::max(smax, (int)plans[(size_t)(b + gq * 4 + q3)].strips);
+                for (int st2 = 0; st2 < smax; st2++) smap.push_back(make_int2(gq, st2));
+            }
+            n_blocks = (int64_t)smap.size();
+            if (n_blocks > 0x7fffffff) { set_err("too many strips in one chunk%s", ""); return GNX_ENOMEM; }
+            if ((rc = c.strip_map.ensure((size_t)std::max<int64_t>(n_blocks, 1) * 12))) return rc;
+            d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
+            d_sprog = reinterpret_cast<int *>(reinterpret_cast<char *>(c.strip_map.p) + (size_t)std::max<int64_t>(n_blocks, 1) * 8);
+            HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)n_blocks * 8, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)std::max<int64_t>(n_blocks, 1) * 4, stream));
+            HIPCHK(hipStreamSynchronize(stream)); // smap is a local
+        }
+        HIPCHK(hipEventRecord(c.ev[1], stream));
+        if (p16) hipLaunchKernelGGL(cl_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        else hipLaunchKernelGGL(cl_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c.ev[2], stream));
+        const dim3 gridW((unsigned)((np + 3) / 4));
+        if (p16) hipLaunchKernelGGL(cl_walk_kernel<true>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
+        else hipLaunchKernelGGL(cl_walk_kernel<false>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
+        HIPCHK(hipGetLastError());
+        if ((rc = launch_scan(dn, np, d_ops_off + b, d_carry, stream))) return rc;
+        hipLaunchKernelGGL(reverse_runs_kernel, dim3((unsigned)np), dim3(256), 0, stream, dpl, np, d_scr, d_so, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c.ev[3], stream));
+        HIPCHK(hipEventSynchronize(c.ev[3])); // the chunks reuse the workspace
+        float f1 = 0, f2 = 0;
+        HIPCHK(hipEventElapsedTime(&f1, c.ev[1], c.ev[2]));
+        HIPCHK(hipEventElapsedTime(&f2, c.ev[2], c.ev[3]));
+        fill_ms += f1; tb_ms += f2;
+        for (int64_t p = b; p < e; p++) {
+            const PairPlan &pl = plans[(size_t)p];
+            trace_bytes += 4 * ((int64_t)(pl.strips - 1) * (pl.m + 1) + (int64_t)((pl.m + 15) / CKC) * pl.strips * G * SNAPW);
+        }
+    }
+    HIPCHK(hipEventRecord(c.ev[2], stream));
+    int h_misc[16];
+    HIPCHK(hipMemcpyAsync(h_misc, c.misc.p, 64, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    float tot = 0;
+    HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[2]));
+    c.timing.fill_ms = fill_ms; c.timing.traceback_ms = tb_ms; c.timing.total_ms = tot;
+    c.timing.cells = cells; c.timing.n_launches = (int64_t)nchunks; c.timing.trace_bytes = trace_bytes;
+    c.timing.dominant_ms = fill_ms; c.timing.dominant_launches = (int64_t)nchunks; c.timing.fast_path = 2;
+    int64_t total;
+    memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
+    if (out_total) *out_total = total;
+    const int ef = h_misc[0];
+    if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
+    if (ef & 16) { set_err("a strip waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
+    if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
+    if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
+    return GNX_OK;
+}
+
 // The device flow shared by all entry points.  All pointers are device pointers except h_*.
 int run_device(const gnx_params *prm, int64_t n_pairs,
                const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
@@ -418,6 +564,18 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         return GNX_OK;
     }
     const int64_t maxpen = max_abs_pen(prm, affine);
+    // ---- validation, the same for every path below ----
+    for (int64_t p = 0; p < n_pairs; p++) {
+        const int64_t n = h_alen[p], m = h_blen[p];
+        if (n < 0 || m < 0 || n > 0x3fffffff || m > 0x3fffffff) { set_err("bad sequence length at pair %s%lld", "", (long long)p); return GNX_EINVAL; }
+        if (lowmem && prm->checkersize_i != prm->checkersize_j && n > prm->checkersize_i) {
+            // the reference indexes its saved columns with checkersize_j where checkersize_i is meant
+            // (affineGap.go:252-254, constGap.go:207): undefined for non-square tiles once n > checkersize_i
+            set_err("non-square checkerboards with n > checkersize_i are undefined in the reference (pair %s%lld)", "", (long long)p); return GNX_EINVAL;
+        }
+        if (lowmem && (n < 1 || m < 1)) { set_err("empty sequence at pair %s%lld: the reference never terminates on it", "", (long long)p); return GNX_EEMPTY; }
+        if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) { set_err("pair %s%lld exceeds the int32 DP range", "", (long long)p); return GNX_ERANGE; }
+    }
     // ---- fast path: every alpha fits one strip, long beta, global affine with gapOpen <= 0 ----
     {
         const char *fpenv = getenv("GNX_FASTPATH");
@@ -468,6 +626,19 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
                 if (rc != GNX_OK) break;
             }
             if (fp && rc != -1) return rc;
+        }
+    }
+    // ---- constant gap without a stored direction matrix (const_long.hip.h): pairs of more than one strip; GNX_CLONG=0 / 2 = never / always ----
+    if (!affine && !gsw && !d_smat) {
+        const char *cl = getenv("GNX_CLONG");
+        bool use = !(cl && cl[0] == '0'), any_multi = false;
+        for (int64_t p = 0; use && p < n_pairs; p++) {
+            if (h_alen[p] < 1 || h_blen[p] < 1) use = false;
+            if (h_alen[p] > H) any_multi = true;
+        }
+        if (use && (any_multi || (cl && cl[0] == '2'))) {
+            rc = run_device_clong(prm, kp, tp, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+            if (rc != -1) return rc;
         }
     }
     // ---- plan ----
