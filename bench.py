@@ -3,21 +3,30 @@
 affine-gap 150 bp x 10 kb batch (config C2: faChunkAlign-style reads vs one 10 kb chunk,
 align.AffineGap(read, chunk, HumanChimpTwoScoreMatrix, -600, -150)).
 
-A "step" = one pass of the hot path (fill kernel + traceback kernels, CIGARs emitted) over one batch of
+A "step" = one pass of the hot path (forward kernel + traceback kernels, CIGARs emitted) over one batch of
 `--pairs` synthetic pairs whose inputs are already resident in HBM.  One process per GPU; for N > 1 the
 driver launches this file under torch.distributed.run: the 10 kb chunk is broadcast from rank 0 over
 RCCL/xGMI once, every rank aligns its own shard of reads (weak scaling, no data-path collective), the
 timed region is bracketed by barrier + synchronize and the max over ranks is reported.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      algorithmic bytes (n + m + ceil(6nm/8) + ceil(6(n+m)/8) + 8 + 16|cigar| per pair)
-                / average fill-kernel duration (HIP events on the launch stream, inside the library)
-  cpu_baseline  the CPU oracle ("port" of the reference algorithm; the Go reference cannot be built here)
-                on all host cores, bounded sample of the same workload
+  roofline      algorithmic bytes (n + m + ceil(b*nm/8) + ceil(b*(n+m)/8) + 8 + 16|cigar| per pair, b = 6 bits affine /
+                2 bits constant gap) / average duration of the dominant kernel's launches (HIP events on the launch stream, inside
+                the library); frac = that kernel alone, frac_step = the whole step, both against the 8.0 TB/s spec peak
+                (frac_vs_measured_copy_bw: against the 6.29 TB/s a copy kernel reaches)
+  host_entry    SURVEY 8d's metric definition: H2D of reads + kernels + D2H of scores / CIGARs through the host-buffer entry
+                point a cgo shim binds; measured after the timed region, never `value`
+  cold_plan     one step whose plans are built and uploaded afresh (the timed steps re-submit one batch: plan cache hits)
+  cpu_baseline  the CPU oracle ("port" of the reference algorithm; the Go reference cannot be built here) on the host
+                cores this process can really use (thread count found by a scaling probe), bounded sample of the same workload
+
+--series long = config C5: ConstGap(20 kb ONT-style read, 100 kb window, -430) with 10 000 x 10 000 checkerboards.
 """
 import argparse
 import ctypes
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -28,27 +37,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-READ_LEN = 150
-CHUNK_LEN = 10000
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0   # ... 6.29 TB/s measured copy bandwidth
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+
+# series -> (gnx mode, oracle mode, gapOpen / gapPen, gapExtend, read length, window length, direction bits per cell, default pairs)
+SERIES = {
+    "affine": dict(mode=0, omode=0, go=-600, ge=-150, n=150, m=10000, bits=6, pairs=100000, shared=True,
+                   call="align.AffineGap", cfg="C2 faChunkAlign-style"),
+    "const": dict(mode=1, omode=1, go=-430, ge=0, n=150, m=10000, bits=2, pairs=100000, shared=True,
+                  call="align.ConstGap", cfg="C2 shape"),
+    "local": dict(mode=3, omode=3, go=-600, ge=-150, n=150, m=10000, bits=6, pairs=100000, shared=True,
+                  call="align.AffineGapLocal(target=chunk, query=read)", cfg="C2 shape"),
+    "long": dict(mode=1, omode=1, go=-430, ge=0, n=20000, m=100000, bits=2, pairs=2048, shared=False,
+                 call="align.ConstGap (10000 x 10000 checkerboards)", cfg="C5 long-read"),
+}
 
 
-def make_workload(seed, n_pairs, chunk=None):
+def make_workload(seed, n_pairs, chunk=None, read_len=150, chunk_len=10000):
     """C2 generator, vectorised: reads sampled at uniform offsets of one chunk (0.1 % N), 1 % substitutions,
     ~0.2 %/base indel opens (one geometric(0.5)-length indel in ~26 % of the reads)."""
     rng = np.random.default_rng(seed)
     if chunk is None:
-        chunk = rng.integers(0, 4, size=CHUNK_LEN).astype(np.uint8)
-        chunk[rng.random(CHUNK_LEN) < 0.001] = 4
-    off = rng.integers(0, CHUNK_LEN - READ_LEN - 64, size=n_pairs)
-    x = np.arange(READ_LEN)[None, :]
+        chunk = rng.integers(0, 4, size=chunk_len).astype(np.uint8)
+        chunk[rng.random(chunk_len) < 0.001] = 4
+    off = rng.integers(0, chunk_len - read_len - 64, size=n_pairs)
+    x = np.arange(read_len)[None, :]
     has_indel = rng.random(n_pairs) < 0.26
-    pos = rng.integers(10, READ_LEN - 10, size=n_pairs)
+    pos = rng.integers(10, read_len - 10, size=n_pairs)
     ln = np.minimum(rng.geometric(0.5, size=n_pairs), 32)
     is_del = rng.random(n_pairs) < 0.5
     shift = np.where(has_indel[:, None] & (x >= pos[:, None]), np.where(is_del, ln, -ln)[:, None], 0)
     src = off[:, None] + x + shift
-    reads = chunk[np.clip(src, 0, CHUNK_LEN - 1)]
+    reads = chunk[np.clip(src, 0, chunk_len - 1)]
     ins_mask = has_indel[:, None] & (~is_del)[:, None] & (x >= pos[:, None]) & (x < (pos + ln)[:, None])
     reads = np.where(ins_mask, rng.integers(0, 4, size=reads.shape), reads)
     sub = rng.random(reads.shape) < 0.01
@@ -56,41 +77,111 @@ def make_workload(seed, n_pairs, chunk=None):
     return np.ascontiguousarray(reads), chunk
 
 
-def algorithmic_bytes(n, m, pairs, total_ops):
-    per_pair = n + m + (n * m * 6 + 7) // 8 + ((n + m) * 6 + 7) // 8 + 8
+def make_long_workload(seed, n_pairs, n=20000, m=100000):
+    """C5 generator: per pair one random 100 kb window and a 20 kb ONT-like read of a slice of it
+    (per source base: 3 % deleted, 4 % substituted, 3 % preceded by a random inserted base).  Returns (reads [P, n], windows [P, m])."""
+    rng = np.random.default_rng(seed)
+    reads = np.zeros((n_pairs, n), dtype=np.uint8)
+    wins = rng.integers(0, 4, size=(n_pairs, m), dtype=np.uint8)
+    span = n + n // 8
+    for p in range(n_pairs):
+        off = int(rng.integers(0, m - span))
+        src = wins[p, off:off + span]
+        r = rng.random(span)
+        keep = r >= 0.03
+        base = np.where(r < 0.07, rng.integers(0, 4, size=span, dtype=np.uint8), src)
+        ins = rng.random(span) < 0.03
+        cnt = keep.astype(np.int64) + ins.astype(np.int64)
+        out = np.repeat(base, cnt)
+        start = np.cumsum(cnt) - cnt
+        out[start[ins]] = rng.integers(0, 4, size=int(ins.sum()), dtype=np.uint8)
+        reads[p] = out[:n]
+    return reads, wins
+
+
+def algorithmic_bytes(n, m, bits, pairs, total_ops):
+    per_pair = n + m + (n * m * bits + 7) // 8 + ((n + m) * bits + 7) // 8 + 8
     return per_pair * pairs + 16 * total_ops
 
 
-def cpu_baseline(reads, chunk, scores, budget_s=15.0):
-    import oracle
-    cores = os.cpu_count() or 1
-    n = READ_LEN
+def kernel_source_hash():
+    """sha256 over the kernel sources: the PMC counters in profiles/ are only valid for the kernels they were taken from"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gonomics_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
+
+def usable_cores():
+    """(nominal, affinity, cgroup quota in cores or None)"""
+    nominal = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = nominal
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q, per = int(f1.read()), int(f2.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    return nominal, aff, quota
+
+
+def cpu_baseline(S, scores, pair_fn, n_avail, budget_s=12.0):
+    """pair_fn(k) -> (alphas, betas) lists of the first k pairs.  Finds by a scaling probe on small C2-shaped samples the thread count
+    beyond which the oracle stops getting faster on this box (containers cap the CPU time of the nominal cores), then times the
+    sample with that many threads."""
+    import oracle
+    nominal, aff, quota = usable_cores()
+    cap = max(1, min(aff, int(math.ceil(quota)) if quota else aff))
     last = [None]
 
     def run(k, threads):
-        a_start = np.arange(k, dtype=np.int64) * n
-        a_len = np.full(k, n, dtype=np.int64)
-        b_start = np.zeros(k, dtype=np.int64)
-        b_len = np.full(k, chunk.shape[0], dtype=np.int64)
+        a, b = pair_fn(k)
         t0 = time.perf_counter()
-        last[0] = oracle.align_batch_windows(oracle.MODE_AFFINE, scores, -600, -150, reads[:k].reshape(-1), a_start, a_len,
-                                             chunk, b_start, b_len, threads=threads)
+        last[0] = oracle.align_batch(S["omode"], scores, S["go"], S["ge"], a, b, 10000, 10000, threads=threads)
         return time.perf_counter() - t0
 
-    k = min(4 * cores, reads.shape[0])
-    dt = run(k, cores)  # also warms page tables
-    while dt < budget_s / 2 and k < reads.shape[0]:  # grow the sample until it is ~budget_s of wall time
-        k = min(reads.shape[0], max(k + 1, int(k * min(8.0, 0.9 * budget_s / max(dt, 1e-3)))))
-        dt = run(k, cores)
-    k_min = min(10000, reads.shape[0])  # the sample doubles as the bit-exactness check of the GPU results: at least 10 000 pairs
-    if k < k_min and dt * k_min / k < 3 * budget_s:
-        k = k_min
-        dt = run(k, cores)
-    oracle_results, oracle_k = last[0], k
-    cells = k * n * chunk.shape[0]
-    k1 = min(8, reads.shape[0])
-    dt1 = run(k1, 1)  # context: one thread alone (containers often cap the CPU time of the nominal cores)
+    # scaling probe (always on the cheap 150 x 10 000 affine shape: a 20 kb x 100 kb pair costs 7 s per thread)
+    rng = np.random.default_rng(99)
+    pa = [rng.integers(0, 4, size=150).astype(np.uint8) for _ in range(4096)]
+    pb = rng.integers(0, 4, size=10000).astype(np.uint8)
+
+    def probe(threads, per_thread):
+        k = min(threads * per_thread, len(pa))
+        t0 = time.perf_counter()
+        oracle.align_batch(0, scores, -600, -150, pa[:k], [pb] * k, 10000, 10000, threads=threads)
+        return k * 150 * 10000 / (time.perf_counter() - t0)
+
+    probe(1, 4)
+    r1 = probe(1, 24)
+    curve = {1: r1}
+    t = 2
+    while t <= cap:
+        curve[t] = probe(t, max(4, 24 // (1 + t // 16)))
+        t *= 2
+    if cap not in curve:
+        curve[cap] = probe(cap, 4)
+    best = max(curve.values())
+    threads = min(t for t, v in curve.items() if v >= 0.9 * best)
+    # the timed sample
+    per_pair_s = S["n"] * S["m"] / (curve[threads] / threads) * (2.0 if S["bits"] == 2 and S["n"] > 160 else 1.0)
+    k = int(max(threads, min(n_avail, budget_s * threads / max(per_pair_s, 1e-9))))
+    k = min(k, n_avail)
+    dt = run(k, threads)
+    cells = k * S["n"] * S["m"]
     model = ""
     try:
         with open("/proc/cpuinfo") as fh:
@@ -100,10 +191,12 @@ def cpu_baseline(reads, chunk, scores, budget_s=15.0):
                     break
     except OSError:
         pass
-    return {"_oracle": (oracle_results, oracle_k), "cpu_model": model, "value": cells / dt, "unit": "DP cells/s", "cores": cores, "kind": "port",
-            "pairs_per_s": k / dt, "single_thread_cells_per_s": k1 * n * chunk.shape[0] / dt1,
-            "sample": "%d pairs (150x10000, C2 generator) through oracle/gnx_oracle.c or_align_batch, %d threads, %.1f s"
-                      % (k, cores, dt)}
+    return {"_oracle": (last[0], k), "cpu_model": model, "value": cells / dt, "unit": "DP cells/s", "cores": threads, "kind": "port",
+            "pairs_per_s": k / dt, "nominal_cores": nominal, "affinity_cores": aff, "cgroup_quota_cores": quota,
+            "single_thread_cells_per_s": r1,
+            "thread_scaling_probe_cells_per_s": {str(t): v for t, v in sorted(curve.items())},
+            "sample": "%d pairs (%dx%d, %s generator) through oracle/gnx_oracle.c or_align_batch, %d threads (the probe's knee: more threads "
+                      "add < 10 %% on this box), %.1f s" % (k, S["n"], S["m"], S["cfg"].split()[0], threads, dt)}
 
 
 def main():
@@ -111,16 +204,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=100000, help="pairs per GPU per step (config C2: 100 k)")
-    ap.add_argument("--ws-gb", type=float, default=150.0, help="direction-matrix workspace limit per GPU")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default: 100 k for the C2 series, 2048 for --series long)")
+    ap.add_argument("--ws-gb", type=float, default=150.0, help="workspace limit per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--verify", type=int, default=32, help="pairs checked bit-exactly against the oracle after timing")
+    ap.add_argument("--no-host", action="store_true", help="skip the host_entry and cold_plan legs")
+    ap.add_argument("--verify", type=int, default=-1, help="pairs checked bit-exactly against the oracle after timing (default 32; 2 for --series long)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU (with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 (flow check of the N>1 path on a 1-GPU box)")
-    ap.add_argument("--series", default="affine", choices=["affine", "const", "local"],
+    ap.add_argument("--series", default="affine", choices=sorted(SERIES),
                     help="affine = the headline AffineGap(read, chunk); const = ConstGap(read, chunk, -430); "
-                         "local = AffineGapLocal(target=chunk, query=read) (SURVEY 8d second series)")
+                         "local = AffineGapLocal(target=chunk, query=read) (SURVEY 8d second series); long = config C5")
     args = ap.parse_args()
+    S = SERIES[args.series]
+    READ_LEN, CHUNK_LEN = S["n"], S["m"]
 
     import torch
     import torch.distributed as dist
@@ -144,54 +240,62 @@ def main():
     ws_gb = args.ws_gb / (world if args.share_gpu else 1)
     _lib.check(L.gnx_init(dev_index, int(ws_gb * (1 << 30))))
 
-    n_pairs = args.pairs
-    # rank 0 owns the chunk; everyone gets it by broadcast (RCCL over xGMI when world > 1)
-    if rank == 0:
-        reads0, chunk_h = make_workload(2, n_pairs)
+    n_pairs = args.pairs or S["pairs"]
+    n_verify = args.verify if args.verify >= 0 else (2 if args.series == "long" else 32)
+    scores = align.HumanChimpTwoScoreMatrix
+    if S["shared"]:
+        # rank 0 owns the chunk; everyone gets it by broadcast (RCCL over xGMI when world > 1)
+        if rank == 0:
+            reads0, chunk_h = make_workload(2, n_pairs)
+        else:
+            chunk_h = np.zeros(CHUNK_LEN, dtype=np.uint8)
+        d_chunk = torch.from_numpy(chunk_h).to(dev)
+        if world > 1:
+            shard.broadcast_reference(d_chunk, src=0)  # RCCL broadcast over xGMI
+            chunk_h = d_chunk.cpu().numpy()
+        reads_h = reads0 if rank == 0 else make_workload(2 + 1000 * rank, n_pairs, chunk_h)[0]
+        h_bs = np.zeros(n_pairs, dtype=np.int64)
+        beta_h = chunk_h
     else:
-        chunk_h = np.zeros(CHUNK_LEN, dtype=np.uint8)
-    d_chunk = torch.from_numpy(chunk_h).to(dev)
-    if world > 1:
-        shard.broadcast_reference(d_chunk, src=0)  # RCCL broadcast over xGMI
-        chunk_h = d_chunk.cpu().numpy()
-    reads_h = reads0 if rank == 0 else make_workload(2 + 1000 * rank, n_pairs, chunk_h)[0]
+        # C5: every pair has its own window (independent pairs; nothing to broadcast)
+        reads_h, wins_h = make_long_workload(5 + 1000 * rank, n_pairs, READ_LEN, CHUNK_LEN)
+        d_chunk = torch.from_numpy(wins_h.reshape(-1)).to(dev)
+        h_bs = np.arange(n_pairs, dtype=np.int64) * CHUNK_LEN
+        beta_h = wins_h.reshape(-1)
     d_reads = torch.from_numpy(reads_h.reshape(-1)).to(dev)
     h_alen = np.full(n_pairs, READ_LEN, dtype=np.int64)
     h_blen = np.full(n_pairs, CHUNK_LEN, dtype=np.int64)
-    d_as = torch.arange(n_pairs, dtype=torch.int64, device=dev) * READ_LEN
+    h_as = np.arange(n_pairs, dtype=np.int64) * READ_LEN
+    d_as = torch.from_numpy(h_as).to(dev)
     d_al = torch.from_numpy(h_alen).to(dev)
-    d_bs = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
+    d_bs = torch.from_numpy(h_bs).to(dev)
     d_bl = torch.from_numpy(h_blen).to(dev)
     d_score = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
     d_off = torch.zeros(n_pairs + 1, dtype=torch.int64, device=dev)
     cap = 48 * n_pairs
     d_ops = torch.zeros(cap * 16, dtype=torch.uint8, device=dev)
-    if args.series == "affine":
-        gmode, omode, go, ge = _lib.GNX_AFFINE_GAP, 0, -600, -150
-    elif args.series == "const":
-        gmode, omode, go, ge = _lib.GNX_CONST_GAP, 1, -430, 0
-    else:
-        gmode, omode, go, ge = _lib.GNX_AFFINE_GAP_LOCAL, 3, -600, -150
-    params = _lib.make_params(gmode, align.HumanChimpTwoScoreMatrix, go, ge, 10000, 10000)
+    gmode, omode, go, ge = S["mode"], S["omode"], S["go"], S["ge"]
+    params = _lib.make_params(gmode, scores, go, ge, 10000, 10000)
     total_ops = ctypes.c_int64()
     stream = torch.cuda.current_stream().cuda_stream
     swap = args.series == "local"  # AffineGapLocal(target=chunk, query=read): alpha is the chunk
 
-    def step():
+    def step(np_=None):
+        k = n_pairs if np_ is None else np_
         if swap:
-            _lib.check(L.gnx_align_batch_device(ctypes.byref(params), n_pairs, d_chunk.data_ptr(), d_bs.data_ptr(), d_bl.data_ptr(),
+            _lib.check(L.gnx_align_batch_device(ctypes.byref(params), k, d_chunk.data_ptr(), d_bs.data_ptr(), d_bl.data_ptr(),
                                                 d_reads.data_ptr(), d_as.data_ptr(), d_al.data_ptr(),
                                                 h_blen.ctypes.data, h_alen.ctypes.data,
                                                 d_score.data_ptr(), d_ops.data_ptr(), cap, d_off.data_ptr(),
                                                 ctypes.byref(total_ops), ctypes.c_void_p(stream)))
             return
-        _lib.check(L.gnx_align_batch_device(ctypes.byref(params), n_pairs, d_reads.data_ptr(), d_as.data_ptr(), d_al.data_ptr(),
+        _lib.check(L.gnx_align_batch_device(ctypes.byref(params), k, d_reads.data_ptr(), d_as.data_ptr(), d_al.data_ptr(),
                                             d_chunk.data_ptr(), d_bs.data_ptr(), d_bl.data_ptr(),
                                             h_alen.ctypes.data, h_blen.ctypes.data,
                                             d_score.data_ptr(), d_ops.data_ptr(), cap, d_off.data_ptr(),
                                             ctypes.byref(total_ops), ctypes.c_void_p(stream)))
 
-    try:  # one untimed sizing call: const-gap CIGARs have hundreds of runs per pair
+    try:  # one untimed sizing call: const-gap CIGARs have hundreds (C5: tens of thousands) of runs per pair
         step()
     except _lib.GnxError as e:
         if e.code != _lib.GNX_ECAPACITY:
@@ -219,24 +323,30 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    step_total_ops = total_ops.value
 
-    # ---- after the timed region: verification + baselines (rank 0) ----
-    ok = True
-    if args.verify > 0:
-        import oracle
-        k = min(args.verify, n_pairs)
+    def fetch(k):
         sc = d_score[:k].cpu().numpy()
         off = d_off[:k + 1].cpu().numpy()
         ops = d_ops[:int(off[-1]) * 16].cpu().numpy().view(_lib.CIGAR_DTYPE)
-        a_start = np.arange(k, dtype=np.int64) * READ_LEN
-        if swap:
-            exp = oracle.align_batch_windows(omode, align.HumanChimpTwoScoreMatrix, go, ge, chunk_h, np.zeros(k, np.int64), h_blen[:k],
-                                             reads_h.reshape(-1), a_start, h_alen[:k], threads=min(k, os.cpu_count() or 1))
-        else:
-            exp = oracle.align_batch_windows(omode, align.HumanChimpTwoScoreMatrix, go, ge, reads_h.reshape(-1),
-                                             a_start, h_alen[:k], chunk_h, np.zeros(k, np.int64), h_blen[:k], threads=min(k, os.cpu_count() or 1))
-        ok = bool(np.array_equal(sc, exp[0]) and np.array_equal(off, exp[2]) and np.array_equal(ops["run_length"], exp[1]["run_length"])
-                  and np.array_equal(ops["op"], exp[1]["op"]))
+        return sc, ops, off
+
+    def pair_lists(k):
+        a = [reads_h[x] for x in range(k)]
+        b = [beta_h[h_bs[x]:h_bs[x] + CHUNK_LEN] for x in range(k)]
+        return (b, a) if swap else (a, b)
+
+    def same(got, exp):
+        return bool(np.array_equal(got[0], exp[0]) and np.array_equal(got[2], exp[2]) and np.array_equal(got[1]["run_length"], exp[1]["run_length"])
+                    and np.array_equal(got[1]["op"], exp[1]["op"]))
+
+    # ---- after the timed region: verification + the other legs (rank 0) ----
+    ok = True
+    if n_verify > 0:
+        import oracle
+        k = min(n_verify, n_pairs)
+        a, b = pair_lists(k)
+        ok = same(fetch(k), oracle.align_batch(omode, scores, go, ge, a, b, 10000, 10000, threads=min(k, os.cpu_count() or 1)))
     if world > 1:
         f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
@@ -249,66 +359,98 @@ def main():
     if rank == 0:
         cells_per_step = n_pairs * READ_LEN * CHUNK_LEN * world
         value = cells_per_step * args.steps / dt
+        ms_per_step = dt / args.steps * 1e3
         fill_avg_ms = dom_ms / max(dom_launches, 1)  # average duration of the dominant kernel's launches (HIP events)
         pairs_per_launch = n_pairs * args.steps / max(dom_launches, 1)
-        abytes = algorithmic_bytes(READ_LEN, CHUNK_LEN, pairs_per_launch, total_ops.value * pairs_per_launch / n_pairs)
+        abytes = algorithmic_bytes(READ_LEN, CHUNK_LEN, S["bits"], pairs_per_launch, step_total_ops * pairs_per_launch / n_pairs)
+        abytes_step = algorithmic_bytes(READ_LEN, CHUNK_LEN, S["bits"], n_pairs, step_total_ops)
         achieved = abytes / (fill_avg_ms * 1e-3) / 1e9
-        traffic = None  # HBM bytes per fill launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+        achieved_step = abytes_step * world / (ms_per_step * 1e-3) / 1e9 / world  # per GPU
+        path = {0: "general_path", 1: "fast_path", 2: "const_long"}[fast_path]
+        kernel = {0: "fill_affine_kernel (full direction matrix)" if S["bits"] == 6 else "fill_const_kernel (full direction matrix)",
+                  1: "fp_sweep_kernel<%d, %s> (fast-path forward sweep)" % (19 if READ_LEN <= 152 else 20, "true" if swap else "false"),
+                  2: "cl_sweep_kernel (score-only constant-gap sweep with wavefront snapshots)"}[fast_path]
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), valid
+        # only for the kernel sources they were taken from
+        traffic, traffic_note, pmc = None, None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as fh:
-                traffic = json.load(fh)["fast_path" if fast_path else "general_path"]["hbm_bytes_per_pair"] * pairs_per_launch
+            with open(TRAFFIC_FILE) as fh:
+                tj = json.load(fh)
+            if tj.get("kernel_source_hash") != kernel_source_hash():
+                traffic_note = "stale: %s was collected at commit %s from other kernel sources" % (os.path.basename(TRAFFIC_FILE), tj.get("commit"))
+            else:
+                pmc = tj.get(args.series, {}).get(path)
+                if pmc:
+                    traffic = pmc["hbm_bytes_per_pair"] * pairs_per_launch
+                    traffic_note = "bytes per launch (PMC, %s, commit %s)" % (os.path.basename(TRAFFIC_FILE), tj.get("commit"))
         except (OSError, KeyError, ValueError):
-            pass
+            traffic_note = "no PMC file"
         out = {
             "metric": "DP cells/sec + aligned pairs/sec, affine-gap 150bp x 10kb batch" if args.series == "affine"
                       else "DP cells/sec, series=%s (not the headline metric)" % args.series,
             "value": value, "unit": "DP cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "C2 faChunkAlign-style: %d x (150 bp read vs one 10 kb chunk) per GPU, %s, "
-                                   "HumanChimpTwoScoreMatrix, %s, score + full CIGAR"
-                                   % (n_pairs, {"affine": "align.AffineGap", "const": "align.ConstGap", "local": "align.AffineGapLocal(target=chunk, query=read)"}[args.series],
-                                      "gapPen -430" if args.series == "const" else "gapOpen -600, gapExtend -150"),
-                       "pairs_per_gpu": n_pairs, "read_len": READ_LEN, "chunk_len": CHUNK_LEN, "parallelism": "pairs sharded x%d" % world},
+            "config": {"workload": "%s: %d x (%d bp read vs %s) per GPU, %s, HumanChimpTwoScoreMatrix, %s, score + full CIGAR"
+                                   % (S["cfg"], n_pairs, READ_LEN, "one 10 kb chunk" if S["shared"] else "its own %d bp window" % CHUNK_LEN, S["call"],
+                                      "gapPen %d" % go if S["bits"] == 2 else "gapOpen %d, gapExtend %d" % (go, ge)),
+                       "pairs_per_gpu": n_pairs, "read_len": READ_LEN, "chunk_len": CHUNK_LEN, "parallelism": "pairs sharded x%d" % world,
+                       "plan_cache": "the timed steps re-submit one batch, so the fast path's per-pair plans are reused on the device (see cold_plan)"},
             "pairs_per_s": n_pairs * world * args.steps / dt,
-            "bit_exact_sample": ok, "bit_exact_pairs_checked": int(min(args.verify, n_pairs)),
+            "bit_exact_sample": ok, "bit_exact_pairs_checked": int(min(n_verify, n_pairs)),
             "kernel_ms": {"all_fill_kernels_per_step": float(np.mean(fill_ms)), "traceback_and_rest_per_step": float(np.mean(tb_ms)),
-                          "dominant_kernel_per_step": dom_ms / args.steps, "fast_path": bool(fast_path)},
+                          "dominant_kernel_per_step": dom_ms / args.steps, "path": path, "launches_per_step": launches / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r1_hbm_traffic.json)",
-                         "kernel": "fp_sweep_kernel<%d, %s> (fast-path forward sweep)" % (19 if READ_LEN <= 152 else 20, "true" if args.series == "local" else "false") if fast_path
-                                   else "fill_affine_kernel (full direction matrix)",
-                         "avg_launch_ms": fill_avg_ms,
-                         "algorithmic_bytes_per_launch": abytes,
-                         "cells_per_s_kernel": pairs_per_launch * READ_LEN * CHUNK_LEN / (fill_avg_ms * 1e-3)},
+                         "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": kernel, "avg_launch_ms": fill_avg_ms,
+                         "algorithmic_bytes_per_launch": abytes, "direction_bits_per_cell": S["bits"],
+                         "cells_per_s_kernel": pairs_per_launch * READ_LEN * CHUNK_LEN / (fill_avg_ms * 1e-3),
+                         "frac_vs_measured_copy_bw": achieved / HBM_COPY_GBS,
+                         "achieved_step": achieved_step, "frac_step": achieved_step / HBM_PEAK_GBS,
+                         "frac_step_vs_measured_copy_bw": achieved_step / HBM_COPY_GBS},
         }
-        try:  # second ceiling: VALU issue, 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6e12 lane-ops/s
-            with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as fh:
-                fpj = json.load(fh)["fast_path"]
-                vi = fpj.get("valu_insts_per_pair") if fast_path else None
-            if vi:
-                lane_ops = vi * 64.0 * pairs_per_launch / (fill_avg_ms * 1e-3)
-                out["roofline_valu"] = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": 78.6, "unit": "T lane-ops/s", "frac": lane_ops / 78.6e12,
-                                        "valu_insts_per_pair": vi, "valu_busy": fpj.get("valu_busy"),
-                                        "source": "SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE (rocprofv3 --pmc, profiles/r1_pmc_sq.csv)"}
-        except (OSError, KeyError, ValueError):
-            pass
-        if not args.no_cpu and args.series == "affine" and world == 1:
-            cb = cpu_baseline(reads_h, chunk_h, align.HumanChimpTwoScoreMatrix)
+        if pmc and pmc.get("valu_insts_per_pair"):
+            # second ceiling: VALU issue, 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6e12 lane-ops/s
+            vi = pmc["valu_insts_per_pair"]
+            lane_ops = vi * 64.0 * pairs_per_launch / (fill_avg_ms * 1e-3)
+            out["roofline_valu"] = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": 78.6, "unit": "T lane-ops/s", "frac": lane_ops / 78.6e12,
+                                    "valu_insts_per_pair": vi, "valu_busy": pmc.get("valu_busy"),
+                                    "source": "SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE (rocprofv3 --pmc, %s)" % os.path.basename(TRAFFIC_FILE)}
+        if not args.no_host and world == 1:
+            # cold plans: a call of another shape first, so that the next full call builds and uploads its plans afresh
+            step(max(n_pairs - 64, 1))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            out["cold_plan"] = {"ms_per_step": (time.perf_counter() - t1) * 1e3, "note": "one step after a call of another shape (no plan reuse)"}
+            # SURVEY 8d's definition of the metric: host buffers in, host buffers out
+            a_buf, b_buf = reads_h.reshape(-1), beta_h
+            hs = []
+            got_h = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                if swap:
+                    got_h = _lib.align_batch_windows(params, b_buf, h_bs, h_blen, a_buf, h_as, h_alen)
+                else:
+                    got_h = _lib.align_batch_windows(params, a_buf, h_as, h_alen, b_buf, h_bs, h_blen)
+                hs.append(time.perf_counter() - t1)
+            hbest = min(hs)
+            same_h = same(got_h, fetch(n_pairs))
+            ok = ok and same_h
+            out["host_entry"] = {"entry": "gnx_align_batch_windows", "value": cells_per_step / hbest, "unit": "DP cells/s", "ms_per_call": hbest * 1e3,
+                                 "all_calls_ms": [x * 1e3 for x in hs], "vs_device_resident": (cells_per_step / hbest) / value,
+                                 "equals_device_results": same_h,
+                                 "includes": "H2D of reads, windows and offset tables, plans, kernels, D2H of scores / offsets / CIGAR runs into malloc'ed host arrays"}
+        if not args.no_cpu and world == 1 and args.series in ("affine", "long"):
+            cb = cpu_baseline(S, scores, pair_lists, n_pairs)
             exp, k = cb.pop("_oracle")
             # the oracle results of the baseline sample double as the bit-exactness check of the first k GPU results
-            sc = d_score[:k].cpu().numpy()
-            off = d_off[:k + 1].cpu().numpy()
-            ops = d_ops[:int(off[-1]) * 16].cpu().numpy().view(_lib.CIGAR_DTYPE)
-            ok_k = bool(np.array_equal(sc, exp[0]) and np.array_equal(off, exp[2]) and np.array_equal(ops["run_length"], exp[1]["run_length"])
-                        and np.array_equal(ops["op"], exp[1]["op"]))
+            ok_k = same(fetch(k), exp)
             ok = ok and ok_k
-            out["bit_exact_sample"] = ok
-            out["bit_exact_pairs_checked"] = int(k)
+            out["bit_exact_pairs_checked"] = int(max(k, min(n_verify, n_pairs)))
             out["cpu_baseline"] = cb
-            out["gpu_over_cpu"] = value / cb["value"]
-        if args.series != "affine":
-            out["roofline"]["note"] = "algorithmic-byte model is the affine one; use cells_per_s_kernel for this series"
+        out["bit_exact_sample"] = ok
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

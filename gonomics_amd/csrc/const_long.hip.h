@@ -19,14 +19,15 @@ namespace {
 //                         complete state from which the wave can resume at step c*CKC (wave-uniform, coalesced 768 B per pair).
 //   cl_walk_kernel    traceback, one wave per 4 pairs, everything on the device: for the strip s and snapshot interval c the walk is
 //                     in, RE-FILL the <= CKC steps from the snapshot with the recording recurrence of fill_const_kernel into a
-//                     direction-bit tile in LDS (20 KB per pair), walk inside the tile with LDS latency instead of HBM latency, move
+//                     direction-bit tile in LDS (18 KB per pair), walk inside the tile with LDS latency instead of HBM latency, move
 //                     on to the next tile.  The tiles a path crosses are ~1 % of the matrix.
 //
 // Values and argmax tags of a re-filled tile are those of the full fill (same recurrence from exact state), so the walk sees the
 // bits fill_const_kernel would have stored; the walk itself (run merging, Step 4 with quirk Q2) is traceback_kernel<false>'s.
 // Memory per 20 kb x 100 kb pair: row buffer 50 MB + snapshots 19 MB + run staging 2 MB instead of 500 MB.
 // ------------------------------------------------------------------------------------------------------
-constexpr int CKC = 512;                          // snapshot spacing in wavefront steps (multiple of 16)
+constexpr int CKC = 448;                          // snapshot spacing in wavefront steps (multiple of 16): the 4 tiles of a walk wave + its
+                                                  // int16 profile are 80 000 B of LDS, two workgroups per CU
 constexpr int CL_WORDS = CKC / 16;                // direction words per lane row and tile
 constexpr int SNAPW = 12;                         // dwords per lane per snapshot: val[R], diag0, pad
 constexpr int CL_DIRG = CL_WORDS * R * G + 16;    // LDS dwords of one pair's tile (+16: neighbouring pairs start in different banks)
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
-            if (t0 > 0 && (t0 & (CKC - 1)) == 0 && gact && t0 <= m_eff + 15) { // snapshot: the state the wave resumes from at step t0
+            if (t0 > 0 && t0 % CKC == 0 && gact && t0 <= m_eff + 15) { // snapshot: the state the wave resumes from at step t0
                 uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / CKC - 1) * pl.strips + s) * G + l) * SNAPW);
                 dst[0] = make_uint4((unsigned)val[0], (unsigned)val[1], (unsigned)val[2], (unsigned)val[3]);
                 dst[1] = make_uint4((unsigned)val[4], (unsigned)val[5], (unsigned)val[6], (unsigned)val[7]);
