@@ -16,7 +16,8 @@ GNX_AFFINE_GAP, GNX_CONST_GAP, GNX_AFFINE_GAP_HIGHMEM, GNX_AFFINE_GAP_LOCAL, GNX
 
 EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gnx_free", "gnx_align_batch",
            "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing",
-           "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch"]
+           "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch",
+           "gnx_init_devices", "gnx_n_devices", "gnx_set_reference", "gnx_set_reference_synthetic", "gnx_align_batch_by_offset"]
 
 
 class GnxCigar(ctypes.Structure):
@@ -86,6 +87,15 @@ def lib():
         L.gnx_gsw_extend_batch.argtypes = [ctypes.c_int, c_p, i64, i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                            ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
         L.gnx_gsw_extend_batch.restype = ctypes.c_int
+        L.gnx_init_devices.argtypes = [ctypes.c_int, c_p, i64]
+        L.gnx_init_devices.restype = ctypes.c_int
+        L.gnx_n_devices.restype = ctypes.c_int
+        L.gnx_set_reference.argtypes = [c_p, i64]
+        L.gnx_set_reference.restype = ctypes.c_int
+        L.gnx_set_reference_synthetic.argtypes = [i64, ctypes.c_uint64]
+        L.gnx_set_reference_synthetic.restype = ctypes.c_int
+        L.gnx_align_batch_by_offset.argtypes = [ctypes.POINTER(GnxParams), i64, c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
+        L.gnx_align_batch_by_offset.restype = ctypes.c_int
         L.gnx_get_timing.argtypes = [ctypes.POINTER(GnxTiming)]
         L.gnx_get_timing.restype = ctypes.c_int
         _lib = L
@@ -145,6 +155,51 @@ def align_batch_windows(params, a_buf, a_start, a_len, b_buf, b_start, b_len):
     check(L.gnx_align_batch_windows(ctypes.byref(params), n, a_buf.ctypes.data, a_buf.shape[0], a_start.ctypes.data, a_len.ctypes.data,
                                     b_buf.ctypes.data, b_buf.shape[0], b_start.ctypes.data, b_len.ctypes.data,
                                     scores.ctypes.data, ctypes.byref(ops_p), ctypes.byref(off_p)))
+    ops, off = _take(ops_p, off_p, n)
+    return scores[:n], ops, off
+
+
+def init_devices(devices=None, workspace_bytes=0):
+    """One context per listed device in this process (gnx_init_devices); devices=None: every visible GPU."""
+    L = lib()
+    if devices is None:
+        check(L.gnx_init_devices(0, None, int(workspace_bytes)))
+    else:
+        d = np.ascontiguousarray(devices, dtype=np.int32)
+        check(L.gnx_init_devices(int(d.shape[0]), d.ctypes.data, int(workspace_bytes)))
+    return L.gnx_n_devices()
+
+
+def set_reference(ref):
+    ref = _u8(ref)
+    check(lib().gnx_set_reference(ref.ctypes.data, ref.shape[0]))
+
+
+def synthetic_reference_bases(start, length, seed):
+    """Host restatement of gnx_set_reference_synthetic for bases [start, start + length) (tests and benchmarks build their oracle
+    inputs from it)."""
+    pos = np.arange(start, start + length, dtype=np.uint64)
+    w = pos >> np.uint64(5)
+    with np.errstate(over="ignore"):
+        x = (np.uint64(seed) ^ w) + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    b = ((x >> (np.uint64(2) * (pos & np.uint64(31)))) & np.uint64(3)).astype(np.uint8)
+    p = pos.astype(np.int64)
+    b[(p % 50000000 < 1000) & (p >= 50000000)] = 4
+    return b
+
+
+def align_batch_by_offset(params, a_cat, a_off, ref_start, ref_len):
+    """Reads (concatenated, a_off[n+1]) against windows of the resident reference.  Returns (scores, ops, off)."""
+    L = lib()
+    a_cat, a_off, ref_start, ref_len = _u8(a_cat), _i64(a_off), _i64(ref_start), _i64(ref_len)
+    n = int(ref_start.shape[0])
+    scores = np.zeros(max(n, 1), dtype=np.int64)
+    ops_p, off_p = ctypes.c_void_p(), ctypes.c_void_p()
+    check(L.gnx_align_batch_by_offset(ctypes.byref(params), n, a_cat.ctypes.data, a_off.ctypes.data, ref_start.ctypes.data, ref_len.ctypes.data,
+                                      scores.ctypes.data, ctypes.byref(ops_p), ctypes.byref(off_p)))
     ops, off = _take(ops_p, off_p, n)
     return scores[:n], ops, off
 

@@ -42,16 +42,19 @@ namespace {
 // ------------------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------------------
+// Error text: thread local (an error belongs to the call that failed), plus a process-wide copy of the most recent one for callers
+// whose runtime may fetch it on another OS thread (cgo without runtime.LockOSThread).
 thread_local char g_err[512] = "";
-void set_err(const char *fmt, const char *a = "", long long b = 0) { snprintf(g_err, sizeof(g_err), fmt, a, b); }
+std::mutex g_lasterr_mu;
+char g_lasterr[512] = "";
+void publish_err() { std::lock_guard<std::mutex> lk(g_lasterr_mu); memcpy(g_lasterr, g_err, sizeof(g_lasterr)); }
+void set_err(const char *fmt, const char *a = "", long long b = 0) { snprintf(g_err, sizeof(g_err), fmt, a, b); publish_err(); }
+void set_err_hip(hipError_t e, const char *file, int line) { snprintf(g_err, sizeof(g_err), "HIP error %s at %s:%d", hipGetErrorString(e), file, line); publish_err(); }
 
 #define HIPCHK(call)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (call);                                                                        \
-        if (e_ != hipSuccess) {                                                                        \
-            snprintf(g_err, sizeof(g_err), "HIP error %s at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); \
-            return GNX_EDEVICE;                                                                        \
-        }                                                                                              \
+        if (e_ != hipSuccess) { set_err_hip(e_, __FILE__, __LINE__); return GNX_EDEVICE; }             \
     } while (0)
 
 struct DevBuf {
@@ -70,16 +73,39 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
+// pinned host staging (hipHostMalloc): copies to / from it are asynchronous DMA, and the stager thread fills it while kernels run
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return GNX_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; set_err("pinned host allocation of %s%lld bytes failed", "", (long long)want); return GNX_ENOMEM; }
+        cap = want;
+        return GNX_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
 
+// One context per device (gnx_init binds context 0; gnx_init_devices creates one per GPU of the node).  A context owns its streams,
+// events and every device buffer; entry points lock the contexts they use, and a context's work always runs on one host thread at a
+// time (the calling thread, or one worker thread per context for the multi-device entry points): t_ctx is that thread's context.
 struct Ctx {
     std::mutex mu;
     bool inited = false;
+    int index = 0;
     int device = -1;
     int64_t ws_limit = 0;
-    hipStream_t own_stream = nullptr;
+    hipStream_t own_stream = nullptr, s_in = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
     DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
+    // pipelined host entry (gnx_host.hip.h): double-buffered inputs, results accumulated on the device, the resident reference
+    DevBuf pin_a[2], pin_as[2], pin_b[2], pin_bs[2], res_score, res_off, res_ops, ref, gat_score, gat_off, gat_ops;
+    PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
+    int64_t ref_len = -1; // >= 0: a reference is resident in `ref`
+    hipEvent_t ev_in[2] = {nullptr, nullptr};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
     // the fast path's plans of the previous call, still in `plans` on the device: batches of a stream of reads keep the same
@@ -88,26 +114,52 @@ struct Ctx {
     int64_t fpc_roff = 0, fpc_coff = 0, fpc_cells = 0, fpc_mmax = 1;
     const void *fpc_ptr = nullptr; // == plans.p while the cached plans are what the device holds
 };
-Ctx g_ctx;
+std::mutex g_ctxs_mu;          // guards the list itself
+std::vector<Ctx *> g_ctxs;     // [0] = the default context; never shrinks while the library is loaded
+thread_local Ctx *t_ctx = nullptr;
+Ctx &ctx_at(int k) {
+    std::lock_guard<std::mutex> lk(g_ctxs_mu);
+    while ((int)g_ctxs.size() <= k) { Ctx *c = new Ctx; c->index = (int)g_ctxs.size(); g_ctxs.push_back(c); }
+    return *g_ctxs[(size_t)k];
+}
+int ctx_count() { std::lock_guard<std::mutex> lk(g_ctxs_mu); int n = 0; for (Ctx *c : g_ctxs) if (c->inited) n++; return n; }
+#define g_ctx (*t_ctx)
+// binds a context to the calling thread for the duration of an entry point (locks it, makes its device current)
+struct CtxScope {
+    Ctx *prev;
+    Ctx &c;
+    std::unique_lock<std::mutex> lk;
+    explicit CtxScope(Ctx &cc) : prev(t_ctx), c(cc), lk(cc.mu) { t_ctx = &cc; }
+    ~CtxScope() { t_ctx = prev; }
+};
 
+int init_ctx(Ctx &c, int device, int64_t workspace_bytes) {
+    HIPCHK(hipSetDevice(device));
+    c.device = device;
+    HIPCHK(hipStreamCreate(&c.own_stream));
+    HIPCHK(hipStreamCreateWithFlags(&c.s_in, hipStreamNonBlocking));
+    for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
+    for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c.ev_in[i], hipEventDisableTiming));
+    if (workspace_bytes > 0) c.ws_limit = workspace_bytes;
+    if (c.ws_limit <= 0) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        c.ws_limit = (int64_t)std::min<size_t>(fr / 2, (size_t)64 << 30);
+    }
+    c.inited = true;
+    return GNX_OK;
+}
+
+// the current context, initialised on first use: context 0 binds device LOCAL_RANK (one process per GPU under torch.distributed.run)
 int ensure_init() {
-    if (g_ctx.inited) return GNX_OK;
+    Ctx &c = g_ctx;
+    if (c.inited) { HIPCHK(hipSetDevice(c.device)); return GNX_OK; }
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { set_err("no HIP device available (this library has no CPU fallback)%s", ""); return GNX_EDEVICE; }
     int dev = 0;
     const char *lr = getenv("LOCAL_RANK");
     if (lr && *lr) dev = atoi(lr) % cnt;
-    HIPCHK(hipSetDevice(dev));
-    g_ctx.device = dev;
-    HIPCHK(hipStreamCreate(&g_ctx.own_stream));
-    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&g_ctx.ev[i]));
-    if (g_ctx.ws_limit <= 0) {
-        size_t fr = 0, tot = 0;
-        HIPCHK(hipMemGetInfo(&fr, &tot));
-        g_ctx.ws_limit = (int64_t)std::min<size_t>(fr / 2, (size_t)64 << 30);
-    }
-    g_ctx.inited = true;
-    return GNX_OK;
+    return init_ctx(c, dev, 0);
 }
 
 int check_params(const gnx_params *p, KParams &kp, TbParams &tp, bool &affine, bool &local, bool &lowmem) {
@@ -211,7 +263,6 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         if ((rc = c.fp_wplans[x].ensure((size_t)np * sizeof(PairPlan)))) return rc;
         if ((rc = c.fp_active[x].ensure((size_t)np * 4))) return rc;
     }
-    if (!c.ev[4]) for (int i = 4; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
     int *d_err = reinterpret_cast<int *>(c.misc.p);
     int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
     int *d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(c.misc.p) + 32); // window-request counters (ping-pong)
@@ -623,7 +674,9 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
                                            d_ops_off + b, out_total, stream, ch == 0, true);
                 else rc = run_device_fp(prm, kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
                                         d_ops_off + b, out_total, stream, ch == 0, false);
-                if (rc != GNX_OK) break;
+                // a CIGAR buffer that is too small does not end the loop: the remaining sub-batches still count their runs (the offset
+                // carry runs through them), so that the total handed back with GNX_ECAPACITY is that of the whole batch
+                if (rc != GNX_OK && rc != GNX_ECAPACITY) break;
             }
             if (fp && rc != -1) return rc;
         }
@@ -1012,6 +1065,8 @@ int run_host_windows(const gnx_params *prm, int64_t n_pairs,
 
 } // namespace
 
+#include "gnx_host.hip.h"
+
 // ------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------
@@ -1024,60 +1079,178 @@ int gnx_device_count(void) {
 }
 
 int gnx_init(int device, int64_t workspace_bytes) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    if (g_ctx.inited) {
-        if (device == g_ctx.device) { if (workspace_bytes > 0) g_ctx.ws_limit = workspace_bytes; return GNX_OK; }
+    std::lock_guard<std::mutex> api(g_api_mu);
+    Ctx &c = ctx_at(0);
+    CtxScope sc(c);
+    g_err[0] = 0;
+    if (c.inited) {
+        if (device == c.device) { if (workspace_bytes > 0) c.ws_limit = workspace_bytes; return GNX_OK; }
         set_err("already bound to another device%s", ""); return GNX_EINVAL;
     }
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { set_err("no HIP device available (this library has no CPU fallback)%s", ""); return GNX_EDEVICE; }
     if (device < 0 || device >= cnt) { set_err("device index out of range%s", ""); return GNX_EINVAL; }
-    HIPCHK(hipSetDevice(device));
-    g_ctx.device = device;
-    HIPCHK(hipStreamCreate(&g_ctx.own_stream));
-    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&g_ctx.ev[i]));
-    if (workspace_bytes > 0) g_ctx.ws_limit = workspace_bytes;
-    else {
-        size_t fr = 0, tot = 0;
-        HIPCHK(hipMemGetInfo(&fr, &tot));
-        g_ctx.ws_limit = (int64_t)std::min<size_t>(fr / 2, (size_t)64 << 30);
+    return init_ctx(c, device, workspace_bytes);
+}
+
+int gnx_init_devices(int n_devices, const int *devices, int64_t workspace_bytes) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    g_err[0] = 0;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { set_err("no HIP device available (this library has no CPU fallback)%s", ""); return GNX_EDEVICE; }
+    if (n_devices <= 0) n_devices = cnt;
+    if (n_devices > 64) { set_err("too many devices%s", ""); return GNX_EINVAL; }
+    std::vector<int> devs((size_t)n_devices);
+    bool distinct = true;
+    for (int k = 0; k < n_devices; k++) {
+        devs[(size_t)k] = devices ? devices[k] : k;
+        if (devs[(size_t)k] < 0 || devs[(size_t)k] >= cnt) { set_err("device index out of range%s", ""); return GNX_EINVAL; }
+        for (int q = 0; q < k; q++) if (devs[(size_t)q] == devs[(size_t)k]) distinct = false;
     }
-    g_ctx.inited = true;
+    if (!g_rccl.comms.empty()) { // a previous set of devices: drop its communicators
+        for (ncclComm_t cm : g_rccl.comms) (void)g_rccl.CommDestroy(cm);
+        g_rccl.comms.clear();
+    }
+    for (int k = 0; k < n_devices; k++) {
+        Ctx &c = ctx_at(k);
+        CtxScope sc(c);
+        if (c.inited) {
+            if (c.device != devs[(size_t)k]) { set_err("context %s%lld is already bound to another device (gnx_shutdown first)", "", (long long)k); return GNX_EINVAL; }
+            if (workspace_bytes > 0) c.ws_limit = workspace_bytes;
+            continue;
+        }
+        int rc = init_ctx(c, devs[(size_t)k], workspace_bytes);
+        if (rc) return rc;
+    }
+    g_nctx = n_devices;
+    g_shared_dev = !distinct;
+    // RCCL communicators, one per context (all in this process).  GNX_RCCL=0: plain peer copies; GNX_RCCL=1: also for one device
+    // (a 1-rank communicator: every RCCL call of the flow still runs, which is what a 1-GPU box can check of the plumbing)
+    const char *re = getenv("GNX_RCCL");
+    const bool want = distinct && !(re && re[0] == '0') && (n_devices > 1 || (re && re[0] == '1'));
+    if (want) {
+        int rc = rccl_load();
+        if (rc) return rc;
+        g_rccl.comms.assign((size_t)n_devices, nullptr);
+        ncclResult_t r = g_rccl.CommInitAll(g_rccl.comms.data(), n_devices, devs.data());
+        if (r != ncclSuccess) { g_rccl.comms.clear(); set_err("ncclCommInitAll failed: %s", g_rccl.GetErrorString(r)); return GNX_EDEVICE; }
+        (void)hipSetDevice(devs[0]);
+    }
     return GNX_OK;
 }
 
+int gnx_n_devices(void) { std::lock_guard<std::mutex> api(g_api_mu); return g_nctx; }
+
 void gnx_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    if (!g_ctx.inited) return;
-    (void)hipSetDevice(g_ctx.device);
-    (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&g_ctx.strip_map, &g_ctx.tb_scr, &g_ctx.tb_scr_off, &g_ctx.scan_tmp, &g_ctx.fp_redo, &g_ctx.fp_tail, &g_ctx.fp_thcol, &g_ctx.fp_ttrace, &g_ctx.fp_rowi, &g_ctx.fp_ckpt, &g_ctx.fp_states, &g_ctx.fp_stage, &g_ctx.fp_wplans[0], &g_ctx.fp_wplans[1], &g_ctx.fp_active[0], &g_ctx.fp_active[1],
-                      &g_ctx.trace, &g_ctx.hcol, &g_ctx.rowbuf, &g_ctx.dcol, &g_ctx.plans, &g_ctx.nops, &g_ctx.misc, &g_ctx.in_a, &g_ctx.in_b,
-                      &g_ctx.in_as, &g_ctx.in_al, &g_ctx.in_bs, &g_ctx.in_bl, &g_ctx.out_score, &g_ctx.out_off, &g_ctx.out_ops, &g_ctx.out_end,
-                      &g_ctx.sc_pairs, &g_ctx.sc_mat, &g_ctx.sc_err};
-    for (DevBuf *b : bufs) b->release();
-    g_ctx.fpc_ptr = nullptr;
-    for (int i = 0; i < 4; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }
-    if (g_ctx.own_stream) { (void)hipStreamDestroy(g_ctx.own_stream); g_ctx.own_stream = nullptr; }
-    for (int i = 4; i < 8; i++) if (g_ctx.ev[i]) { (void)hipEventDestroy(g_ctx.ev[i]); g_ctx.ev[i] = nullptr; }
-    g_ctx.inited = false;
-    g_ctx.ws_limit = 0;
+    std::lock_guard<std::mutex> api(g_api_mu);
+    for (ncclComm_t cm : g_rccl.comms) (void)g_rccl.CommDestroy(cm);
+    g_rccl.comms.clear();
+    int n;
+    { std::lock_guard<std::mutex> lk(g_ctxs_mu); n = (int)g_ctxs.size(); }
+    for (int k = 0; k < n; k++) {
+        Ctx &c = ctx_at(k);
+        CtxScope sc(c);
+        if (!c.inited) continue;
+        (void)hipSetDevice(c.device);
+        (void)hipDeviceSynchronize();
+        DevBuf *bufs[] = {&c.strip_map, &c.tb_scr, &c.tb_scr_off, &c.scan_tmp, &c.fp_redo, &c.fp_tail, &c.fp_thcol, &c.fp_ttrace, &c.fp_rowi, &c.fp_ckpt, &c.fp_states, &c.fp_stage,
+                          &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
+                          &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
+                          &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,
+                          &c.ref, &c.gat_score, &c.gat_off, &c.gat_ops};
+        for (DevBuf *b : bufs) b->release();
+        PinBuf *pins[] = {&c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};
+        for (PinBuf *b : pins) b->release();
+        c.fpc_ptr = nullptr; c.ref_len = -1;
+        for (int i = 0; i < 8; i++) if (c.ev[i]) { (void)hipEventDestroy(c.ev[i]); c.ev[i] = nullptr; }
+        for (int i = 0; i < 2; i++) if (c.ev_in[i]) { (void)hipEventDestroy(c.ev_in[i]); c.ev_in[i] = nullptr; }
+        if (c.own_stream) { (void)hipStreamDestroy(c.own_stream); c.own_stream = nullptr; }
+        if (c.s_in) { (void)hipStreamDestroy(c.s_in); c.s_in = nullptr; }
+        c.inited = false;
+        c.ws_limit = 0;
+        c.device = -1;
+    }
+    g_pool.drain();
+    g_nctx = 1;
+    g_shared_dev = false;
 }
 
-const char *gnx_last_error(void) { return g_err; }
+/* the calling thread's last error; if this thread has none, the most recent error of the process (a cgo caller may fetch the
+ * text on another OS thread than the one that ran the failing call) */
+const char *gnx_last_error(void) {
+    if (g_err[0]) return g_err;
+    static thread_local char copy[512];
+    std::lock_guard<std::mutex> lk(g_lasterr_mu);
+    memcpy(copy, g_lasterr, sizeof(copy));
+    return copy;
+}
 
-void gnx_free(void *p) { free(p); }
+void gnx_free(void *p) { if (p && !g_pool.put(p)) free(p); }
+
+int gnx_set_reference(const uint8_t *ref, int64_t len) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    g_err[0] = 0;
+    if (len < 0 || (len > 0 && !ref)) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    std::vector<void *> dst((size_t)g_nctx, nullptr);
+    for (int d = 0; d < g_nctx; d++) {
+        Ctx &c = ctx_at(d);
+        CtxScope sc(c);
+        int rc = ensure_init();
+        if (rc) return rc;
+        if ((rc = c.ref.ensure((size_t)len + 16))) return rc;
+        c.ref_len = len;
+        dst[(size_t)d] = c.ref.p;
+    }
+    Ctx &c0 = ctx_at(0);
+    { CtxScope sc(c0); HIPCHK(hipSetDevice(c0.device)); if (len) HIPCHK(hipMemcpy(c0.ref.p, ref, (size_t)len, hipMemcpyHostToDevice)); }
+    return broadcast_from_ctx0(c0.ref.p, dst, (size_t)len);
+}
+
+int gnx_set_reference_synthetic(int64_t len, uint64_t seed) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    g_err[0] = 0;
+    if (len < 0) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    std::vector<void *> dst((size_t)g_nctx, nullptr);
+    for (int d = 0; d < g_nctx; d++) {
+        Ctx &c = ctx_at(d);
+        CtxScope sc(c);
+        int rc = ensure_init();
+        if (rc) return rc;
+        if ((rc = c.ref.ensure((size_t)len + 16))) return rc;
+        c.ref_len = len;
+        dst[(size_t)d] = c.ref.p;
+    }
+    Ctx &c0 = ctx_at(0);
+    {
+        CtxScope sc(c0);
+        HIPCHK(hipSetDevice(c0.device));
+        const int64_t words = (len + 31) / 32;
+        if (words) hipLaunchKernelGGL(synth_ref_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c0.own_stream, (uint8_t *)c0.ref.p, len, seed);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c0.own_stream));
+    }
+    return broadcast_from_ctx0(c0.ref.p, dst, (size_t)len);
+}
+
+int gnx_align_batch_by_offset(const gnx_params *p, int64_t n_pairs, const uint8_t *alpha_cat, const int64_t *alpha_off,
+                              const int64_t *ref_start, const int64_t *ref_len,
+                              int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    g_err[0] = 0;
+    if (n_pairs < 0 || !alpha_off || (n_pairs > 0 && (!ref_start || !ref_len))) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    std::vector<int64_t> al((size_t)n_pairs);
+    for (int64_t q = 0; q < n_pairs; q++) al[(size_t)q] = alpha_off[q + 1] - alpha_off[q];
+    return run_host_sharded(p, n_pairs, alpha_cat, alpha_off[n_pairs], alpha_off, al.data(), nullptr, 0, ref_start, ref_len, out_score, out_ops, out_ops_off);
+}
 
 int gnx_align_batch_windows(const gnx_params *p, int64_t n_pairs,
                             const uint8_t *alpha_buf, int64_t alpha_buf_len, const int64_t *alpha_start, const int64_t *alpha_len,
                             const uint8_t *beta_buf, int64_t beta_buf_len, const int64_t *beta_start, const int64_t *beta_len,
                             int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    std::lock_guard<std::mutex> api(g_api_mu);
     g_err[0] = 0;
-    int rc = ensure_init();
-    if (rc) return rc;
-    HIPCHK(hipSetDevice(g_ctx.device));
-    return run_host_windows(p, n_pairs, alpha_buf, alpha_buf_len, alpha_start, alpha_len, beta_buf, beta_buf_len, beta_start, beta_len,
+    static const uint8_t none = 0;
+    return run_host_sharded(p, n_pairs, alpha_buf ? alpha_buf : &none, alpha_buf_len, alpha_start, alpha_len, beta_buf ? beta_buf : &none, beta_buf_len, beta_start, beta_len,
                             out_score, out_ops, out_ops_off);
 }
 
@@ -1093,12 +1266,12 @@ int gnx_align_batch(const gnx_params *p, int64_t n_pairs, const uint8_t *alpha_c
 int gnx_gsw_extend_batch(int side, const int64_t *scores, int64_t gap_pen, int64_t n_pairs,
                          const uint8_t *alpha_cat, const int64_t *alpha_off, const uint8_t *beta_cat, const int64_t *beta_off,
                          int64_t *out_score, int64_t *out_end_i, int64_t *out_end_j, gnx_cigar **out_ops, int64_t **out_ops_off) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    std::lock_guard<std::mutex> api(g_api_mu);
+    CtxScope sc(ctx_at(0));
     g_err[0] = 0;
     if ((side != GNX_GSW_LEFT && side != GNX_GSW_RIGHT) || !scores || n_pairs < 0 || !alpha_off || !beta_off) { set_err("bad argument%s", ""); return GNX_EINVAL; }
     int rc = ensure_init();
     if (rc) return rc;
-    HIPCHK(hipSetDevice(g_ctx.device));
     gnx_params prm;
     memset(&prm, 0, sizeof(prm));
     prm.mode = GNX_CONST_GAP_HIGHMEM;
@@ -1118,7 +1291,7 @@ int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const u
     int rc = gnx_align_batch_windows(p, 1, alpha, n, &zero, &n, beta, m, &zero, &m, out_score, out_ops, &off);
     if (rc) return rc;
     *out_n_ops = off[1];
-    free(off);
+    gnx_free(off);
     return GNX_OK;
 }
 
@@ -1129,11 +1302,11 @@ int gnx_align_batch_device(const gnx_params *p, int64_t n_pairs,
                            int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
                            int64_t *out_total_ops, void *stream) {
     (void)d_alpha_len; (void)d_beta_len; // lengths are taken from the host copies (planning needs them anyway)
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    std::lock_guard<std::mutex> api(g_api_mu);
+    CtxScope sc(ctx_at(0));
     g_err[0] = 0;
     int rc = ensure_init();
     if (rc) return rc;
-    HIPCHK(hipSetDevice(g_ctx.device));
     if (!p || n_pairs < 0 || !d_score || !d_ops_off || ops_capacity < 0 || (n_pairs > 0 && (!h_alpha_len || !h_beta_len || !d_alpha_start || !d_beta_start))) {
         set_err("bad argument%s", ""); return GNX_EINVAL;
     }
@@ -1144,11 +1317,11 @@ int gnx_align_batch_device(const gnx_params *p, int64_t n_pairs,
 int gnx_affine_gap_chunk_batch(const gnx_params *p, int64_t chunk_size, int64_t n_pairs,
                                const uint8_t *alpha_cat, const int64_t *alpha_off, const uint8_t *beta_cat, const int64_t *beta_off,
                                int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    std::lock_guard<std::mutex> api(g_api_mu);
+    CtxScope sc(ctx_at(0));
     g_err[0] = 0;
     int rc = ensure_init();
     if (rc) return rc;
-    HIPCHK(hipSetDevice(g_ctx.device));
     if (n_pairs < 0 || chunk_size < 1 || (n_pairs > 0 && (!alpha_off || !beta_off))) { set_err("bad argument%s", ""); return GNX_EINVAL; }
     const int64_t la = n_pairs ? alpha_off[n_pairs] : 0, lb = n_pairs ? beta_off[n_pairs] : 0;
     std::vector<uint8_t> bases((size_t)(la + lb + 1));
@@ -1172,11 +1345,11 @@ int gnx_multiple_affine_gap_batch(const gnx_params *p, int64_t chunk_size, int64
                                   const int64_t *group_off, const int32_t *group_nseq, const int64_t *group_len,
                                   int64_t n_pairs, const int32_t *pair_a, const int32_t *pair_b,
                                   int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    std::lock_guard<std::mutex> api(g_api_mu);
+    CtxScope sc(ctx_at(0));
     g_err[0] = 0;
     int rc = ensure_init();
     if (rc) return rc;
-    HIPCHK(hipSetDevice(g_ctx.device));
     if (n_pairs < 0 || n_groups < 0 || chunk_size < 1 || (n_groups > 0 && (!group_off || !group_nseq || !group_len)) || (n_pairs > 0 && (!pair_a || !pair_b))) {
         set_err("bad argument%s", ""); return GNX_EINVAL;
     }
@@ -1202,8 +1375,8 @@ int gnx_multiple_affine_gap_batch(const gnx_params *p, int64_t chunk_size, int64
 
 int gnx_get_timing(gnx_timing *out) {
     if (!out) return GNX_EINVAL;
-    std::lock_guard<std::mutex> lk(g_ctx.mu);
-    *out = g_ctx.timing;
+    std::lock_guard<std::mutex> api(g_api_mu);
+    *out = ctx_at(0).timing;
     return GNX_OK;
 }
 

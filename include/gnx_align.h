@@ -24,7 +24,7 @@
  *   - gnx_cigar has the memory layout of Go's align.Cigar{RunLength int64; Op ColType(uint8)} on amd64.
  *   - inputs are borrowed and never written; outputs returned through gnx_cigar** / int64_t** are
  *     malloc'd by the library and released with gnx_free().
- *   - all functions return GNX_OK (0) or a GNX_E* code; gnx_last_error() gives the text (thread local).
+ *   - all functions return GNX_OK (0) or a GNX_E* code; gnx_last_error() gives the text.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry returns GNX_EDEVICE.
  */
 #ifndef GNX_ALIGN_H
@@ -76,8 +76,8 @@ typedef struct gnx_params {
     int64_t checkersize_j;
 } gnx_params;
 
-/* Per-call kernel timings of the most recent compute call on this thread (HIP events on the stream the
- * kernels ran on).  cells = sum over pairs of n*m. */
+/* Per-call kernel timings of the most recent compute call of the process (context 0; with several contexts: the slowest
+ * context's times, cells and bytes summed) -- HIP events on the stream the kernels ran on.  cells = sum over pairs of n*m. */
 typedef struct gnx_timing {
     double fill_ms;      /* DP fill kernel(s): the dominant kernel */
     double traceback_ms; /* traceback count + scan + write kernels */
@@ -88,7 +88,8 @@ typedef struct gnx_timing {
     double dominant_ms;  /* summed duration of the dominant kernel's launches (fast path: the forward sweep; general
                             path: the fill kernel) -- what roofline.achieved is computed from */
     int64_t dominant_launches;
-    int32_t fast_path;   /* 1 if the fast path ran (short alpha x long beta; AffineGapLocal: short query x long target) */
+    int32_t fast_path;   /* 1: the affine fast path ran (short alpha x long beta; AffineGapLocal: short query x long target);
+                            2: the constant-gap path without a stored direction matrix (const_long.hip.h); 0: full direction matrix */
     int32_t _pad;
 } gnx_timing;
 
@@ -97,9 +98,38 @@ int gnx_device_count(void);
 /* Bind this process to HIP device `device` (one process per GPU).  workspace_bytes = upper bound for the
  * library's device scratch (direction matrices etc.); 0 picks a default from free memory. */
 int gnx_init(int device, int64_t workspace_bytes);
+/* One context per GPU inside ONE host process (what a Go program that calls align.* needs in order to use a whole node:
+ * the reference's own parallel drivers are worker pools inside one process, /root/reference/genomeGraph/routines.go:12-65).
+ * devices = NULL: devices 0 .. n_devices-1; n_devices <= 0: every visible GPU.  Afterwards the host-buffer entry points below cut
+ * each batch into contiguous blocks of equal DP cells, one block per context (one worker thread each), upload a shared beta
+ * buffer / the resident reference once and broadcast it with RCCL over xGMI, and gather scores / offsets / CIGARs on device 0
+ * (grouped ncclSend / ncclRecv) in input order.  RCCL (librccl.so) is loaded with dlopen here, never for one GPU.
+ * A device may be listed more than once (flow tests on a 1-GPU box): such contexts exchange by plain copies instead of RCCL.
+ * Environment: GNX_RCCL=0 peer copies instead of RCCL; GNX_RCCL=1 build the communicator even for a single device. */
+int gnx_init_devices(int n_devices, const int *devices, int64_t workspace_bytes_per_device);
+int gnx_n_devices(void);
 void gnx_shutdown(void);
+/* Text of the calling thread's last error; if that thread has none, the most recent error of the process (cgo may run the failing
+ * call and this one on different OS threads unless the shim pins the goroutine). */
 const char *gnx_last_error(void);
 void gnx_free(void *p);
+
+/* ---- resident reference (configs C3 / C4: reads against windows of one genome) ------------------ */
+/* Upload `ref` (dna.Base bytes) once; it stays on the device(s) until the next call or gnx_shutdown.  With several contexts it is
+ * uploaded to device 0 and broadcast over RCCL.  Replaces passing the same target slice to every align.* call of a loop
+ * (/root/reference/cmd/globalAlignmentAnchor/globalAlignmentAnchor.go:352-384 re-reads its two genomes per anchor). */
+int gnx_set_reference(const uint8_t *ref, int64_t len);
+/* Synthetic reference of SURVEY 8d (config C3), generated on the device: base(pos) = 2 bits of splitmix64(seed ^ (pos / 32)) at
+ * bit 2*(pos % 32), with an N run of 1000 bases at every multiple of 5e7 except 0.  For benchmarks and tests (3e9 bases do not
+ * have to cross PCIe); nothing in the reference corresponds to it. */
+int gnx_set_reference_synthetic(int64_t len, uint64_t seed);
+/* Batch of reads (alpha_cat / alpha_off as in gnx_align_batch) against windows (ref_start[p], ref_len[p]) of the resident
+ * reference: beta = reference[ref_start[p] .. ref_start[p] + ref_len[p]).  Only the reads and 16 bytes of window table per pair
+ * cross PCIe.  Large batches are cut into sub-batches whose uploads run under the kernels of the sub-batch before (pinned
+ * staging, second stream); results accumulate on the device and come back in one transfer into pinned memory (gnx_free). */
+int gnx_align_batch_by_offset(const gnx_params *p, int64_t n_pairs, const uint8_t *alpha_cat, const int64_t *alpha_off,
+                              const int64_t *ref_start, const int64_t *ref_len,
+                              int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off);
 
 /* ---- host-buffer entry points (what the cgo shim binds) ------------------------------------------ */
 /* Batch of independent pairs.  Pair p is alpha_cat[alpha_off[p] .. alpha_off[p+1]) vs

@@ -1,0 +1,132 @@
+"""The host-buffer side of the C ABI (csrc/gnx_host.hip.h): pipelined sub-batches, the resident reference, and the multi-context
+(one per GPU) flow -- sharding by DP cells, reference broadcast, ordered gather -- run here with two contexts on ONE device, and
+with a 1-rank RCCL communicator so that every RCCL call of the flow is exercised on a 1-GPU box."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+import oracle
+from gonomics_amd import align
+
+pytestmark = pytest.mark.gpu
+MX = common.matrices()
+
+
+def _c2_batch(seed, n_pairs, chunk_len=4000):
+    reads, chunk = common.c2_workload(seed, n_pairs, read_len=150, chunk_len=chunk_len)
+    a_start = np.arange(n_pairs, dtype=np.int64) * 150
+    a_len = np.full(n_pairs, 150, dtype=np.int64)
+    b_start = np.zeros(n_pairs, dtype=np.int64)
+    b_len = np.full(n_pairs, chunk_len, dtype=np.int64)
+    return reads.reshape(-1), a_start, a_len, chunk, b_start, b_len
+
+
+def test_pipelined_sub_batches(gpu_lib, monkeypatch):
+    """a batch cut into sub-batches (stager thread, pinned staging, second stream) gives what one launch gives; ragged lengths and
+    disjoint per-pair windows travel with their sub-batches"""
+    a, a_start, a_len, chunk, b_start, b_len = _c2_batch(71, 1000)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+    exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, a, a_start, a_len, chunk, b_start, b_len, threads=8)
+    for sub in ("1000000", "256", "96"):
+        monkeypatch.setenv("GNX_HOST_SUB", sub)
+        common.assert_same(gpu_lib.align_batch_windows(p, a, a_start, a_len, chunk, b_start, b_len), exp, "sub " + sub)
+    # a CIGAR buffer that starts too small: ConstGap of the same pairs has ~100 x the runs (the retry path of every sub-batch)
+    pc = gpu_lib.make_params(gpu_lib.GNX_CONST_GAP, MX["HumanChimpTwo"], -430)
+    expc = oracle.align_batch_windows(1, MX["HumanChimpTwo"], -430, 0, a, a_start, a_len, chunk, b_start, b_len, threads=8)
+    common.assert_same(gpu_lib.align_batch_windows(pc, a, a_start, a_len, chunk, b_start, b_len), expc, "const")
+    alphas, betas = common.random_pairs(72, 300, 1, 300, 1, 700)
+    monkeypatch.setenv("GNX_HOST_SUB", "64")
+    for mode, go, ge in ((0, -400, -30), (1, -430, 0), (3, -400, -30)):
+        pm = gpu_lib.make_params(mode, MX["Default"], go, ge)
+        common.assert_same(gpu_lib.align_batch(pm, alphas, betas), oracle.align_batch(mode, MX["Default"], go, ge, alphas, betas, threads=8), "mode %d" % mode)
+
+
+def test_resident_reference(gpu_lib, monkeypatch):
+    """gnx_set_reference + gnx_align_batch_by_offset == the same windows passed as host buffers"""
+    rng = np.random.default_rng(73)
+    ref = rng.integers(0, 4, size=300000).astype(np.uint8)
+    ref[rng.random(ref.shape[0]) < 0.001] = 4
+    n = 600
+    starts = rng.integers(0, ref.shape[0] - 3000, size=n).astype(np.int64)
+    lens = np.full(n, 3000, dtype=np.int64)
+    reads = []
+    for k in range(n):
+        o = int(starts[k]) + int(rng.integers(0, 2800))
+        reads.append(common.mutate(rng, ref[o:o + 190], sub=0.01, indel=0.004, geo=0.5)[:150])
+    a_off = np.zeros(n + 1, dtype=np.int64)
+    a_off[1:] = np.cumsum([len(r) for r in reads])
+    a_cat = np.concatenate(reads)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+    gpu_lib.set_reference(ref)
+    monkeypatch.setenv("GNX_HOST_SUB", "128")
+    got = gpu_lib.align_batch_by_offset(p, a_cat, a_off, starts, lens)
+    exp = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, reads, [ref[s:s + 3000] for s in starts], threads=8)
+    common.assert_same(got, exp)
+    with pytest.raises(gpu_lib.GnxError):  # a window that leaves the reference
+        gpu_lib.align_batch_by_offset(p, a_cat, a_off, starts + ref.shape[0], lens)
+
+
+def test_synthetic_reference_matches_its_host_statement(gpu_lib):
+    """the device-generated reference of config C3 is the pure function of the position that tests / bench.py evaluate on the host"""
+    L = gpu_lib.lib()
+    seed, length = 3, 50003000
+    gpu_lib.check(L.gnx_set_reference_synthetic(length, seed))
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_HIGHMEM, MX["Default"], -400, -30)
+    # read the reference back through alignments: a window aligned against itself is all M with score = sum of diagonal scores
+    starts = np.asarray([0, 31, 49999000, 50000500, 50002000], dtype=np.int64)
+    lens = np.full(starts.shape[0], 900, dtype=np.int64)
+    wins = [gpu_lib.synthetic_reference_bases(int(s), 900, seed) for s in starts]
+    assert (wins[2][:1000] == 4).sum() == 0 and (wins[3] == 4).sum() == 500  # the N run sits at [5e7, 5e7 + 1000)
+    a_off = np.arange(starts.shape[0] + 1, dtype=np.int64) * 900
+    score, ops, off = gpu_lib.align_batch_by_offset(p, np.concatenate(wins), a_off, starts, lens)
+    sc = np.asarray(MX["Default"], dtype=np.int64)
+    for k, w in enumerate(wins):
+        assert int(score[k]) == int(sc[w, w].sum()) and int(off[k + 1] - off[k]) == 1 and int(ops[int(off[k])]["run_length"]) == 900
+
+
+@pytest.mark.parametrize("rccl", ["0", "1"])
+def test_two_contexts_on_one_device(gpu_lib, monkeypatch, rccl):
+    """the N > 1 flow of the C ABI on a 1-GPU box: contexts (0, 0) -> two worker threads, blocks of equal DP cells, the shared chunk /
+    the resident reference copied to the second context, results gathered in input order; must equal the unsharded result.
+    rccl == "1" afterwards runs the single-context flow with a 1-rank RCCL communicator (dlopen, ncclCommInitAll, broadcast)."""
+    L = gpu_lib.lib()
+    a, a_start, a_len, chunk, b_start, b_len = _c2_batch(74, 1500, chunk_len=3000)
+    # ragged: every third read shorter, so that equal DP cells != equal pair counts
+    a_len[::3] = 60
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+    one = gpu_lib.align_batch_windows(p, a, a_start, a_len, chunk, b_start, b_len)
+    tm1 = gpu_lib.get_timing()
+    exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, a, a_start, a_len, chunk, b_start, b_len, threads=8)
+    common.assert_same(one, exp)
+    alphas, betas = common.random_pairs(75, 240, 1, 500, 1, 900)
+    pc = gpu_lib.make_params(gpu_lib.GNX_CONST_GAP, MX["Default"], -430, 0, 7, 7)
+    expc = oracle.align_batch(1, MX["Default"], -430, 0, alphas, betas, 7, 7, threads=8)
+    monkeypatch.setenv("GNX_HOST_SUB", "200")
+    try:
+        gpu_lib.check(L.gnx_shutdown() or 0)
+        monkeypatch.setenv("GNX_RCCL", "0")
+        assert gpu_lib.init_devices([0, 0], 8 << 30) == 2
+        two = gpu_lib.align_batch_windows(p, a, a_start, a_len, chunk, b_start, b_len)
+        tm2 = gpu_lib.get_timing()
+        common.assert_same(two, one, "two contexts, shared chunk")
+        assert tm2["cells"] == tm1["cells"]
+        common.assert_same(gpu_lib.align_batch(pc, alphas, betas), expc, "two contexts, disjoint windows")
+        gpu_lib.set_reference(chunk)
+        a_off = np.concatenate([a_start, [a_start[-1] + 150]])
+        # by_offset takes concatenated reads: use the full-length ones
+        full = np.full(a_len.shape[0], 150, dtype=np.int64)
+        ref_two = gpu_lib.align_batch_by_offset(p, a, a_off, b_start, b_len)
+        common.assert_same(ref_two, oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, a, a_start, full, chunk, b_start, b_len, threads=8),
+                           "two contexts, resident reference")
+        if rccl == "1":
+            gpu_lib.check(L.gnx_shutdown() or 0)
+            monkeypatch.setenv("GNX_RCCL", "1")
+            assert gpu_lib.init_devices([0], 8 << 30) == 1
+            gpu_lib.set_reference(chunk)  # ncclBroadcast on the 1-rank communicator
+            common.assert_same(gpu_lib.align_batch_by_offset(p, a, a_off, b_start, b_len), ref_two, "1-rank RCCL")
+    finally:
+        monkeypatch.delenv("GNX_RCCL", raising=False)
+        L.gnx_shutdown()
+        gpu_lib.check(L.gnx_init(0, 8 << 30))
