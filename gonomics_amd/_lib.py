@@ -178,7 +178,12 @@ def set_reference(ref):
 def synthetic_reference_bases(start, length, seed):
     """Host restatement of gnx_set_reference_synthetic for bases [start, start + length) (tests and benchmarks build their oracle
     inputs from it)."""
-    pos = np.arange(start, start + length, dtype=np.uint64)
+    return synthetic_reference_positions(np.arange(start, start + length, dtype=np.int64), seed)
+
+
+def synthetic_reference_positions(pos, seed):
+    """... for arbitrary positions"""
+    pos = np.asarray(pos).astype(np.uint64)
     w = pos >> np.uint64(5)
     with np.errstate(over="ignore"):
         x = (np.uint64(seed) ^ w) + np.uint64(0x9E3779B97F4A7C15)

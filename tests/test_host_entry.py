@@ -130,3 +130,93 @@ def test_two_contexts_on_one_device(gpu_lib, monkeypatch, rccl):
         monkeypatch.delenv("GNX_RCCL", raising=False)
         L.gnx_shutdown()
         gpu_lib.check(L.gnx_init(0, 8 << 30))
+
+
+def c3_reads(seed, n_pairs, ref_len, ref_seed, window=10000, read_len=150):
+    """config C3: windows at uniform offsets of the synthetic reference, one 150 b read sampled inside each window
+    (1 % substitutions, one geometric(0.5)-length indel in ~26 % of the reads).  Vectorised; returns (reads [P, 150], window starts)."""
+    from gonomics_amd import _lib
+    rng = np.random.default_rng(seed)
+    starts = rng.integers(0, ref_len - window, size=n_pairs).astype(np.int64)
+    off = rng.integers(0, window - read_len - 64, size=n_pairs)
+    x = np.arange(read_len)[None, :]
+    has_indel = rng.random(n_pairs) < 0.26
+    pos = rng.integers(10, read_len - 10, size=n_pairs)
+    ln = np.minimum(rng.geometric(0.5, size=n_pairs), 32)
+    is_del = rng.random(n_pairs) < 0.5
+    shift = np.where(has_indel[:, None] & (x >= pos[:, None]), np.where(is_del, ln, -ln)[:, None], 0)
+    src = (starts + off)[:, None] + np.clip(x + shift, 0, None)
+    reads = np.empty((n_pairs, read_len), dtype=np.uint8)
+    for lo in range(0, n_pairs, 65536):
+        hi = min(n_pairs, lo + 65536)
+        reads[lo:hi] = _lib.synthetic_reference_positions(src[lo:hi].reshape(-1), ref_seed).reshape(hi - lo, read_len)
+    ins_mask = has_indel[:, None] & (~is_del)[:, None] & (x >= pos[:, None]) & (x < (pos + ln)[:, None])
+    reads = np.where(ins_mask, rng.integers(0, 4, size=reads.shape), reads)
+    sub = rng.random(reads.shape) < 0.01
+    reads = np.where(sub, rng.integers(0, 4, size=reads.shape), reads).astype(np.uint8)
+    return np.ascontiguousarray(reads), starts
+
+
+def rescore_affine_batch(reads, starts, ref_seed, window, score, ops, off, scores, go, ge):
+    """size-independent properties of a whole batch, vectorised: per pair (rows consumed, columns consumed, re-scored CIGAR)"""
+    from gonomics_amd import _lib
+    n = reads.shape[0]
+    sc = np.asarray(scores, dtype=np.int64)
+    cnt = np.diff(off)
+    pair = np.repeat(np.arange(n), cnt)
+    run = ops["run_length"].astype(np.int64)
+    op = ops["op"]
+    di = np.where(op != 1, run, 0)
+    dj = np.where(op != 2, run, 0)
+    ci = np.cumsum(di) - di
+    cj = np.cumsum(dj) - dj
+    first = off[:-1]
+    i0 = ci - np.repeat(ci[first], cnt)
+    j0 = cj - np.repeat(cj[first], cnt)
+    rows = np.bincount(pair, weights=di, minlength=n).astype(np.int64)
+    cols = np.bincount(pair, weights=dj, minlength=n).astype(np.int64)
+    total = np.bincount(pair, weights=np.where(op != 0, go + ge * run, 0), minlength=n).astype(np.int64)
+    mm = np.nonzero(op == 0)[0]
+    for lo in range(0, mm.shape[0], 200000):  # expand the M runs in slices
+        sel = mm[lo:lo + 200000]
+        ln = run[sel]
+        idx = np.repeat(np.arange(sel.shape[0]), ln)
+        k = np.arange(int(ln.sum())) - np.repeat(np.cumsum(ln) - ln, ln)
+        pp = pair[sel][idx]
+        a = reads[pp, i0[sel][idx] + k]
+        b = _lib.synthetic_reference_positions(starts[pp] + j0[sel][idx] + k, ref_seed)
+        total += np.bincount(pp, weights=sc[a, b], minlength=n).astype(np.int64)
+    return rows, cols, total
+
+
+def test_c3_one_million_reads_against_a_resident_4gb_reference(gpu_lib):
+    """config C3 through the C ABI a cgo shim binds: 4.4e9-base reference resident on the device (generated there), ONE call with
+    1 048 576 reads at distinct uniform window offsets (8 pipelined sub-batches); every pair property-checked, 10 000 against the oracle"""
+    L = gpu_lib.lib()
+    ref_len, ref_seed, window, n = 4400000000, 33, 10000, 1 << 20
+    sc = MX["HumanChimpTwo"]
+    reads, starts = c3_reads(34, n, ref_len, ref_seed, window)
+    gpu_lib.check(L.gnx_init(0, 60 << 30))
+    try:
+        gpu_lib.check(L.gnx_set_reference_synthetic(ref_len, ref_seed))
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, sc, -600, -150)
+        a_off = np.arange(n + 1, dtype=np.int64) * 150
+        score, ops, off = gpu_lib.align_batch_by_offset(p, reads.reshape(-1), a_off, starts, np.full(n, window, dtype=np.int64))
+        tm = gpu_lib.get_timing()
+    finally:
+        L.gnx_shutdown()
+        gpu_lib.check(L.gnx_init(0, 8 << 30))
+    assert tm["fast_path"] == 1 and tm["cells"] == n * 150 * window
+    assert starts.max() > (1 << 32)  # windows beyond 4 GB offsets
+    rows, cols, total = rescore_affine_batch(reads, starts, ref_seed, window, score, ops, off, sc, -600, -150)
+    assert np.array_equal(rows, np.full(n, 150)) and np.array_equal(cols, np.full(n, window))
+    assert np.array_equal(total, score)
+    k = 10000
+    sel = np.linspace(0, n - 1, k).astype(np.int64)  # spread over every sub-batch
+    wins = [gpu_lib.synthetic_reference_bases(int(starts[x]), window, ref_seed) for x in sel]
+    exp = oracle.align_batch(0, sc, -600, -150, [reads[x] for x in sel], wins, threads=os.cpu_count() or 8)
+    assert np.array_equal(score[sel], exp[0])
+    got_cnt = (off[sel + 1] - off[sel])
+    assert np.array_equal(got_cnt, np.diff(exp[2]))
+    flat = np.concatenate([np.arange(off[x], off[x + 1]) for x in sel])
+    assert np.array_equal(ops["run_length"][flat], exp[1]["run_length"]) and np.array_equal(ops["op"][flat], exp[1]["op"])
