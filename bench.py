@@ -426,7 +426,7 @@ def main():
             out["cold_plan"] = {"ms_per_step": (time.perf_counter() - t1) * 1e3, "note": "one step after a call of another shape (no plan reuse)"}
             # SURVEY 8d's definition of the metric: host buffers in, host buffers out
             a_buf, b_buf = reads_h.reshape(-1), beta_h
-            hs = []
+            hs, hlib = [], []
             got_h = None
             for _ in range(3):
                 t1 = time.perf_counter()
@@ -435,13 +435,14 @@ def main():
                 else:
                     got_h = _lib.align_batch_windows(params, a_buf, h_as, h_alen, b_buf, h_bs, h_blen)
                 hs.append(time.perf_counter() - t1)
-            hbest = min(hs)
+                hlib.append(_lib.get_timing()["host_ms"])
+            hbest = min(hlib) * 1e-3  # wall clock inside the library, entry to return (the Python binding then copies the results once more)
             same_h = same(got_h, fetch(n_pairs))
             ok = ok and same_h
             out["host_entry"] = {"entry": "gnx_align_batch_windows", "value": cells_per_step / hbest, "unit": "DP cells/s", "ms_per_call": hbest * 1e3,
-                                 "all_calls_ms": [x * 1e3 for x in hs], "vs_device_resident": (cells_per_step / hbest) / value,
+                                 "all_calls_ms": hlib, "python_binding_ms": [x * 1e3 for x in hs], "vs_device_resident": (cells_per_step / hbest) / value,
                                  "equals_device_results": same_h,
-                                 "includes": "H2D of reads, windows and offset tables, plans, kernels, D2H of scores / offsets / CIGAR runs into malloc'ed host arrays"}
+                                 "includes": "H2D of reads, windows and offset tables, plans, kernels, D2H of scores / offsets / CIGAR runs into pinned host arrays (gnx_free)"}
         if not args.no_cpu and world == 1 and args.series in ("affine", "long"):
             cb = cpu_baseline(S, scores, pair_lists, n_pairs)
             exp, k = cb.pop("_oracle")

@@ -37,7 +37,7 @@ class GnxTiming(ctypes.Structure):
     _fields_ = [("fill_ms", ctypes.c_double), ("traceback_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
                 ("cells", ctypes.c_int64), ("n_launches", ctypes.c_int64), ("trace_bytes", ctypes.c_int64),
                 ("dominant_ms", ctypes.c_double), ("dominant_launches", ctypes.c_int64), ("fast_path", ctypes.c_int32),
-                ("_pad", ctypes.c_int32)]
+                ("_pad", ctypes.c_int32), ("host_ms", ctypes.c_double), ("stage0_ms", ctypes.c_double), ("fetch_ms", ctypes.c_double)]
 
 
 class GnxError(RuntimeError):
@@ -320,4 +320,5 @@ def get_timing():
     check(lib().gnx_get_timing(ctypes.byref(t)))
     return {"fill_ms": t.fill_ms, "traceback_ms": t.traceback_ms, "total_ms": t.total_ms, "cells": t.cells,
             "n_launches": t.n_launches, "trace_bytes": t.trace_bytes, "dominant_ms": t.dominant_ms,
-            "dominant_launches": t.dominant_launches, "fast_path": t.fast_path}
+            "dominant_launches": t.dominant_launches, "fast_path": t.fast_path, "host_ms": t.host_ms, "stage0_ms": t.stage0_ms,
+            "fetch_ms": t.fetch_ms}

@@ -11,6 +11,7 @@
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <chrono>
 #include <map>
 #include <thread>
 #include <unordered_map>
@@ -206,7 +207,9 @@ int run_host_job(HostJob &j) {
         return GNX_OK;
     };
 
+    const auto t_stage = std::chrono::steady_clock::now();
     if ((rc = stage(0, false))) return rc;
+    const double stage0_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_stage).count();
     int64_t done = 0, total = 0;
     // CIGAR capacity: a guess that fits every workload of the path's callers, grown (with a retry of the sub-batch) when it does not
     int64_t worst = 0;
@@ -255,6 +258,7 @@ int run_host_job(HostJob &j) {
     }
     HIPCHK(hipStreamSynchronize(c.own_stream));
     j.total_ops = total;
+    tsum.stage0_ms = stage0_ms;
     j.timing = tsum;
     c.timing = tsum;
     return GNX_OK;
@@ -304,6 +308,7 @@ int run_host_sharded(const gnx_params *prm, int64_t n_pairs,
                      const uint8_t *a_buf, int64_t a_len_total, const int64_t *a_start, const int64_t *a_lens,
                      const uint8_t *b_buf, int64_t b_len_total, const int64_t *b_start, const int64_t *b_lens,
                      int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
+    const auto t_entry = std::chrono::steady_clock::now();
     if (!prm || n_pairs < 0 || !out_score || !out_ops || !out_ops_off || a_len_total < 0 || b_len_total < 0) { set_err("bad argument%s", ""); return GNX_EINVAL; }
     if (n_pairs > 0 && (!a_start || !a_lens || !b_start || !b_lens)) { set_err("null window table%s", ""); return GNX_EINVAL; }
     const bool resident = (b_buf == nullptr);
@@ -362,6 +367,7 @@ int run_host_sharded(const gnx_params *prm, int64_t n_pairs,
     int64_t total = 0;
     for (int d = 0; d < nc; d++) total += jobs[(size_t)d].total_ops;
     // ---- gather on device 0 (input order == context order), then one D2H into pinned result arrays ----
+    const auto t_fetch = std::chrono::steady_clock::now();
     gnx_cigar *ops = (gnx_cigar *)g_pool.get((size_t)std::max<int64_t>(total, 1) * sizeof(gnx_cigar));
     int64_t *off = (int64_t *)g_pool.get((size_t)(n_pairs + 1) * 8);
     if (!ops || !off) { if (ops) g_pool.put(ops); if (off) g_pool.put(off); set_err("pinned host allocation failed%s", ""); return GNX_ENOMEM; }
@@ -446,7 +452,11 @@ int run_host_sharded(const gnx_params *prm, int64_t n_pairs,
         t.fill_ms = std::max(t.fill_ms, u.fill_ms); t.traceback_ms = std::max(t.traceback_ms, u.traceback_ms); t.total_ms = std::max(t.total_ms, u.total_ms);
         t.dominant_ms = std::max(t.dominant_ms, u.dominant_ms); t.cells += u.cells; t.trace_bytes += u.trace_bytes; t.n_launches += u.n_launches; t.dominant_launches += u.dominant_launches;
     }
+    t.fetch_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fetch).count();
+    t.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
     c0.timing = t;
+    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx host] %lld pairs on %d context(s): call %.3f ms = first upload %.3f + kernels %.3f (device, slowest context) + gather / D2H %.3f + rest\n",
+                                     (long long)n_pairs, nc, t.host_ms, t.stage0_ms, t.total_ms, t.fetch_ms);
     *out_ops = ops; *out_ops_off = off;
     return GNX_OK;
 }

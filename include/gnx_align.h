@@ -91,6 +91,10 @@ typedef struct gnx_timing {
     int32_t fast_path;   /* 1: the affine fast path ran (short alpha x long beta; AffineGapLocal: short query x long target);
                             2: the constant-gap path without a stored direction matrix (const_long.hip.h); 0: full direction matrix */
     int32_t _pad;
+    /* host-buffer entry points only (wall clock inside the library): */
+    double host_ms;      /* entry to return of the whole call */
+    double stage0_ms;    /* exposed upload of the first sub-batch (later ones run under the kernels) */
+    double fetch_ms;     /* gather on device 0 + D2H of scores / offsets / CIGAR runs */
 } gnx_timing;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
