@@ -117,6 +117,10 @@ struct Ctx {
 std::mutex g_ctxs_mu;          // guards the list itself
 std::vector<Ctx *> g_ctxs;     // [0] = the default context; never shrinks while the library is loaded
 thread_local Ctx *t_ctx = nullptr;
+// set while a call is re-run with sequential strips after a pipelined launch timed out waiting for a row buffer (the pipeline relies
+// on workgroups being dispatched in block order; if a driver / partition mode ever breaks that, the call still returns right results)
+thread_local bool t_no_pipe = false;
+bool no_pipe() { return t_no_pipe || getenv("GNX_NO_PIPE") != nullptr; }
 Ctx &ctx_at(int k) {
     std::lock_guard<std::mutex> lk(g_ctxs_mu);
     while ((int)g_ctxs.size() <= k) { Ctx *c = new Ctx; c->index = (int)g_ctxs.size(); g_ctxs.push_back(c); }
@@ -527,7 +531,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         int64_t m_maxc = 0;
         for (int64_t q2 = b; q2 < e; q2++) { if (plans[(size_t)q2].strips > 1) multi = true; m_maxc = std::max<int64_t>(m_maxc, plans[(size_t)q2].m); }
         int64_t n_blocks = (np + 3) / 4;
-        const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB && !getenv("GNX_NO_PIPE");
+        const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB && !no_pipe();
         const int2 *d_smap = nullptr;
         int *d_sprog = nullptr;
         if (piped) {
@@ -583,7 +587,14 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     if (out_total) *out_total = total;
     const int ef = h_misc[0];
     if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
-    if (ef & 16) { set_err("a strip waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
+    if (ef & 16) {
+        if (t_no_pipe) { set_err("a strip waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
+        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx] a pipelined strip timed out: the call runs again with sequential strips\n");
+        t_no_pipe = true;
+        rc = run_device_clong(prm, kp, tp, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+        t_no_pipe = false;
+        return rc;
+    }
     if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
     if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
     return GNX_OK;
@@ -798,7 +809,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // with plenty of pairs (or short beta) the strips of a group would only wait for each other
         int64_t m_maxc = 0;
         for (int64_t q2 = b; q2 < e; q2++) m_maxc = std::max<int64_t>(m_maxc, plans[(size_t)q2].m);
-        const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB && !getenv("GNX_NO_PIPE"); // GNX_NO_PIPE: A/B check of the hand-over protocol
+        const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB && !no_pipe(); // GNX_NO_PIPE: A/B check of the hand-over protocol
         if (piped) {
             std::vector<int2> smap;
             for (int gq = 0; gq < (np + 3) / 4; gq++) {
@@ -922,7 +933,14 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     if (out_total) *out_total = total;
     const int ef = h_misc[0];
     if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
-    if (ef & 16) { set_err("a strip waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
+    if (ef & 16) {
+        if (t_no_pipe) { set_err("a strip waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
+        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx] a pipelined strip timed out: the call runs again with sequential strips\n");
+        t_no_pipe = true;
+        rc = run_device(prm, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, d_smat, h_soff, gsw, d_endpos, no_fast_path, smat16);
+        t_no_pipe = false;
+        return rc;
+    }
     if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
     if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
     return GNX_OK;
@@ -984,23 +1002,25 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     if (sflag[0] & 16) { set_err("scoreColumnMatch over gap-only columns: the reference panics (integer divide by zero)%s", ""); return GNX_EINVAL; }
     int64_t cap = std::max<int64_t>(std::min<int64_t>(worst, std::max<int64_t>((int64_t)1 << 20, 64 * n_pairs)), 1);
     int64_t total = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 8; attempt++) {
         if ((rc = c.out_ops.ensure((size_t)cap * sizeof(gnx_cigar)))) return rc;
         rc = run_device(&prm2, n_pairs, nullptr, nullptr, nullptr, nullptr, hn.data(), hm.data(), (int64_t *)c.out_score.p, (gnx_cigar *)c.out_ops.p, cap,
                         (int64_t *)c.out_off.p, &total, st, reinterpret_cast<const int *>(c.sc_mat.p), hso.data(), 0, nullptr, false, s16);
         if (rc != GNX_ECAPACITY) break;
-        cap = total;
+        cap = std::max(total, cap + 1);
     }
     if (rc) return rc;
     if (chunk > 1 && total > 0) hipLaunchKernelGGL(scale_runs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (gnx_cigar *)c.out_ops.p, total, chunk);
-    gnx_cigar *ops = (gnx_cigar *)malloc((size_t)std::max<int64_t>(total, 1) * sizeof(gnx_cigar));
-    int64_t *off = (int64_t *)malloc((size_t)(n_pairs + 1) * 8);
-    if (!ops || !off) { free(ops); free(off); set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
+    struct HostArr { void *p; explicit HostArr(size_t b) : p(malloc(b)) {} ~HostArr() { free(p); } void *release() { void *q = p; p = nullptr; return q; } };
+    HostArr ops_h((size_t)std::max<int64_t>(total, 1) * sizeof(gnx_cigar)), off_h((size_t)(n_pairs + 1) * 8); // freed on every early return below
+    gnx_cigar *ops = (gnx_cigar *)ops_h.p;
+    int64_t *off = (int64_t *)off_h.p;
+    if (!ops || !off) { set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
     if (n_pairs) HIPCHK(hipMemcpyAsync(out_score, c.out_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(off, c.out_off.p, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, st));
     if (total) HIPCHK(hipMemcpyAsync(ops, c.out_ops.p, (size_t)total * sizeof(gnx_cigar), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    *out_ops = ops; *out_ops_off = off;
+    *out_ops = (gnx_cigar *)ops_h.release(); *out_ops_off = (int64_t *)off_h.release();
     return GNX_OK;
 }
 
@@ -1040,18 +1060,20 @@ int run_host_windows(const gnx_params *prm, int64_t n_pairs,
     int64_t cap = std::min<int64_t>(worst, std::max<int64_t>((int64_t)1 << 20, 64 * n_pairs));
     cap = std::max<int64_t>(cap, 1);
     int64_t total = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 8; attempt++) {
         if ((rc = c.out_ops.ensure((size_t)cap * sizeof(gnx_cigar)))) return rc;
         rc = run_device(prm, n_pairs, (const uint8_t *)c.in_a.p, (const int64_t *)c.in_as.p, (const uint8_t *)c.in_b.p, (const int64_t *)c.in_bs.p,
                         a_lens, b_lens, (int64_t *)c.out_score.p, (gnx_cigar *)c.out_ops.p, cap, (int64_t *)c.out_off.p, &total, st,
                         nullptr, nullptr, gsw, gsw ? (int2 *)c.out_end.p : nullptr);
         if (rc != GNX_ECAPACITY) break;
-        cap = total;
+        cap = std::max(total, cap + 1);
     }
     if (rc) return rc;
-    gnx_cigar *ops = (gnx_cigar *)malloc((size_t)std::max<int64_t>(total, 1) * sizeof(gnx_cigar));
-    int64_t *off = (int64_t *)malloc((size_t)(n_pairs + 1) * 8);
-    if (!ops || !off) { free(ops); free(off); set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
+    struct HostArr { void *p; explicit HostArr(size_t b) : p(malloc(b)) {} ~HostArr() { free(p); } void *release() { void *q = p; p = nullptr; return q; } };
+    HostArr ops_h((size_t)std::max<int64_t>(total, 1) * sizeof(gnx_cigar)), off_h((size_t)(n_pairs + 1) * 8); // freed on every early return below
+    gnx_cigar *ops = (gnx_cigar *)ops_h.p;
+    int64_t *off = (int64_t *)off_h.p;
+    if (!ops || !off) { set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
     if (n_pairs) HIPCHK(hipMemcpyAsync(out_score, c.out_score.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(off, c.out_off.p, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, st));
     if (total) HIPCHK(hipMemcpyAsync(ops, c.out_ops.p, (size_t)total * sizeof(gnx_cigar), hipMemcpyDeviceToHost, st));
@@ -1059,7 +1081,7 @@ int run_host_windows(const gnx_params *prm, int64_t n_pairs,
     if (gsw && n_pairs) { ends.resize((size_t)n_pairs); HIPCHK(hipMemcpyAsync(ends.data(), c.out_end.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, st)); }
     HIPCHK(hipStreamSynchronize(st));
     for (int64_t p = 0; gsw && p < n_pairs; p++) { out_end_i[p] = ends[(size_t)p].x; out_end_j[p] = ends[(size_t)p].y; }
-    *out_ops = ops; *out_ops_off = off;
+    *out_ops = (gnx_cigar *)ops_h.release(); *out_ops_off = (int64_t *)off_h.release();
     return GNX_OK;
 }
 
