@@ -17,7 +17,8 @@ GNX_AFFINE_GAP, GNX_CONST_GAP, GNX_AFFINE_GAP_HIGHMEM, GNX_AFFINE_GAP_LOCAL, GNX
 EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gnx_free", "gnx_align_batch",
            "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing",
            "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch",
-           "gnx_init_devices", "gnx_n_devices", "gnx_set_reference", "gnx_set_reference_synthetic", "gnx_align_batch_by_offset"]
+           "gnx_init_devices", "gnx_n_devices", "gnx_set_reference", "gnx_set_reference_synthetic", "gnx_align_batch_by_offset",
+           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch"]
 
 
 class GnxCigar(ctypes.Structure):
@@ -96,6 +97,12 @@ def lib():
         L.gnx_set_reference_synthetic.restype = ctypes.c_int
         L.gnx_align_batch_by_offset.argtypes = [ctypes.POINTER(GnxParams), i64, c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
         L.gnx_align_batch_by_offset.restype = ctypes.c_int
+        L.gnx_seed_index_build.argtypes = [c_p, c_p, i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(i64)]
+        L.gnx_seed_index_build.restype = ctypes.c_int
+        L.gnx_seed_index_set.argtypes = [c_p, c_p, i64, c_p, c_p, i64, ctypes.c_int]
+        L.gnx_seed_index_set.restype = ctypes.c_int
+        L.gnx_seed_find_batch.argtypes = [c_p, c_p, i64, ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
+        L.gnx_seed_find_batch.restype = ctypes.c_int
         L.gnx_get_timing.argtypes = [ctypes.POINTER(GnxTiming)]
         L.gnx_get_timing.restype = ctypes.c_int
         _lib = L
@@ -322,3 +329,57 @@ def get_timing():
             "n_launches": t.n_launches, "trace_bytes": t.trace_bytes, "dominant_ms": t.dominant_ms,
             "dominant_launches": t.dominant_launches, "fast_path": t.fast_path, "host_ms": t.host_ms, "stage0_ms": t.stage0_ms,
             "fetch_ms": t.fetch_ms}
+
+
+def _cat(seqs):
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    if seqs:
+        off[1:] = np.cumsum([len(x) for x in seqs])
+    cat = _u8(np.concatenate([_u8(x) for x in seqs] + [np.zeros(1, np.uint8)]))
+    return cat, off
+
+
+def seed_index_build(node_seqs, seed_len, seed_step):
+    """k-mers inside nodes -> (keys uint64 sorted, locs uint64) (genomeGraph.IndexGenomeIntoMap without the node-border k-mers)"""
+    L = lib()
+    cat, off = _cat(node_seqs)
+    kp, lp, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+    check(L.gnx_seed_index_build(cat.ctypes.data, off.ctypes.data, len(node_seqs), int(seed_len), int(seed_step), ctypes.byref(kp), ctypes.byref(lp), ctypes.byref(n)))
+    k = n.value
+    if k == 0:
+        return np.zeros(0, np.uint64), np.zeros(0, np.uint64)
+    keys = np.ctypeslib.as_array(ctypes.cast(kp, ctypes.POINTER(ctypes.c_uint64)), shape=(k,)).copy()
+    locs = np.ctypeslib.as_array(ctypes.cast(lp, ctypes.POINTER(ctypes.c_uint64)), shape=(k,)).copy()
+    L.gnx_free(kp)
+    L.gnx_free(lp)
+    return keys, locs
+
+
+SEED_HIT_DTYPE = np.dtype([("read_start", np.int32), ("strand", np.int32), ("node", np.int32), ("node_start", np.int32), ("q_start", np.int32), ("right", np.int32)])
+_seed_set = [None]
+
+
+def seed_find_batch(keys, locs, node_seqs, read_seqs, seed_len):
+    """per read the list of hit tuples (read_start, strand, node, node_start, q_start, right) in the reference's order of discovery"""
+    L = lib()
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    locs = np.ascontiguousarray(locs, dtype=np.uint64)
+    tag = (keys.ctypes.data, locs.ctypes.data, keys.shape[0], id(node_seqs), seed_len)
+    if _seed_set[0] != tag:  # make the index resident once per index object
+        ncat, noff = _cat(node_seqs)
+        check(L.gnx_seed_index_set(keys.ctypes.data, locs.ctypes.data, keys.shape[0], ncat.ctypes.data, noff.ctypes.data, len(node_seqs), int(seed_len)))
+        _seed_set[0] = tag
+    rcat, roff = _cat(read_seqs)
+    hp, op = ctypes.c_void_p(), ctypes.c_void_p()
+    check(L.gnx_seed_find_batch(rcat.ctypes.data, roff.ctypes.data, len(read_seqs), ctypes.byref(hp), ctypes.byref(op)))
+    off = np.ctypeslib.as_array(ctypes.cast(op, ctypes.POINTER(ctypes.c_int64)), shape=(len(read_seqs) + 1,)).copy()
+    total = int(off[-1])
+    if total:
+        buf = (ctypes.c_char * (total * SEED_HIT_DTYPE.itemsize)).from_address(hp.value)
+        hits = np.frombuffer(buf, dtype=SEED_HIT_DTYPE, count=total).copy()
+    else:
+        hits = np.zeros(0, dtype=SEED_HIT_DTYPE)
+    if hp.value:
+        L.gnx_free(hp)
+    L.gnx_free(op)
+    return [[tuple(int(v) for v in h) for h in hits[int(off[r]):int(off[r + 1])]] for r in range(len(read_seqs))]

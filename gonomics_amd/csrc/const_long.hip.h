@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
             if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
             ob = b * (BST * 4);
         };
-        int rb_seen = 0;
+        int rb_seen = 0, pf_seen = 0;
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
                 const long long t_begin = wall_clock64();
@@ -161,6 +161,9 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
                 dst[1] = make_uint4((unsigned)val[4], (unsigned)val[5], (unsigned)val[6], (unsigned)val[7]);
                 dst[2] = make_uint4((unsigned)val[8], (unsigned)val[9], (unsigned)diag0, 0u);
             }
+            // the progress word of the strip above is polled ONE BLOCK AHEAD (the load issued in the previous block lands while its 16
+            // steps run); only a strip that has caught up with its producer falls into the blocking spin of wait_rows
+            if (piped && s > 0) { rb_seen = max(rb_seen, pf_seen); if (rb_seen < t0 + 5 * G) pf_seen = rb_progress(&strip_prog[blockIdx.x - 1]); }
             wait_rows(t0 + 2 * G);
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {

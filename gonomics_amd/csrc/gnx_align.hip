@@ -36,6 +36,7 @@
 #include "fp_walk.hip.h"
 #include "aux_kernels.hip.h"
 #include "const_long.hip.h"
+#include "seed_kernels.hip.h"
 
 namespace {
 
@@ -103,6 +104,9 @@ struct Ctx {
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     // pipelined host entry (gnx_host.hip.h): double-buffered inputs, results accumulated on the device, the resident reference
     DevBuf pin_a[2], pin_as[2], pin_b[2], pin_bs[2], res_score, res_off, res_ops, ref, gat_score, gat_off, gat_ops;
+    // resident seed index of the graph aligner (gnx_seed_index_set)
+    DevBuf sd_keys, sd_locs, sd_nodes, sd_node_off, sd_word_off, sd_words, sd_tmp[8];
+    int64_t sd_n = -1, sd_nodes_n = 0; int sd_seed_len = 0;
     PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
     int64_t ref_len = -1; // >= 0: a reference is resident in `ref`
     hipEvent_t ev_in[2] = {nullptr, nullptr};
@@ -1179,11 +1183,12 @@ void gnx_shutdown(void) {
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,
-                          &c.ref, &c.gat_score, &c.gat_off, &c.gat_ops};
+                          &c.ref, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
+                          &c.sd_tmp[0], &c.sd_tmp[1], &c.sd_tmp[2], &c.sd_tmp[3], &c.sd_tmp[4], &c.sd_tmp[5], &c.sd_tmp[6], &c.sd_tmp[7]};
         for (DevBuf *b : bufs) b->release();
         PinBuf *pins[] = {&c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};
         for (PinBuf *b : pins) b->release();
-        c.fpc_ptr = nullptr; c.ref_len = -1;
+        c.fpc_ptr = nullptr; c.ref_len = -1; c.sd_n = -1;
         for (int i = 0; i < 8; i++) if (c.ev[i]) { (void)hipEventDestroy(c.ev[i]); c.ev[i] = nullptr; }
         for (int i = 0; i < 2; i++) if (c.ev_in[i]) { (void)hipEventDestroy(c.ev_in[i]); c.ev_in[i] = nullptr; }
         if (c.own_stream) { (void)hipStreamDestroy(c.own_stream); c.own_stream = nullptr; }
@@ -1393,6 +1398,172 @@ int gnx_multiple_affine_gap_batch(const gnx_params *p, int64_t chunk_size, int64
         s.nc = (int32_t)(group_len[a] / chunk_size); s.mc = (int32_t)(group_len[b] / chunk_size); s.s_off = 0; s.s_pitch = 0;
     }
     return run_host_scored(p, chunk_size, true, n_pairs, sp, group_bases, n_groups ? group_off[n_groups] : 0, out_score, out_ops, out_ops_off);
+}
+
+/* ---- "next" row N4: seed index and seed search of the graph aligner (see seed_kernels.hip.h) ---- */
+int gnx_seed_index_build(const uint8_t *node_cat, const int64_t *node_off, int64_t n_nodes, int seed_len, int seed_step,
+                         uint64_t **out_keys, uint64_t **out_locs, int64_t *out_n) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    CtxScope sc(ctx_at(0));
+    g_err[0] = 0;
+    if (!node_off || n_nodes < 0 || n_nodes > 0x7ffffff0 || seed_len < 2 || seed_len > 32 || seed_step < 1 || !out_keys || !out_locs || !out_n) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    Ctx &c = g_ctx;
+    hipStream_t st = c.own_stream;
+    std::vector<int64_t> slot_off((size_t)n_nodes + 1, 0);
+    for (int64_t k = 0; k < n_nodes; k++) {
+        const int64_t L = node_off[k + 1] - node_off[k];
+        if (L < 0 || L > 0x7fffffff) { set_err("bad node length at node %s%lld", "", (long long)k); return GNX_EINVAL; }
+        slot_off[(size_t)k + 1] = slot_off[(size_t)k] + (L >= seed_len ? (L - seed_len) / seed_step + 1 : 0);
+    }
+    const int64_t n_slots = slot_off[(size_t)n_nodes], total = n_nodes ? node_off[n_nodes] : 0;
+    *out_keys = nullptr; *out_locs = nullptr; *out_n = 0;
+    if (n_slots == 0) return GNX_OK;
+    DevBuf *t = c.sd_tmp;
+    if ((rc = c.sd_nodes.ensure((size_t)total + 64))) return rc;
+    if ((rc = c.sd_node_off.ensure((size_t)(n_nodes + 1) * 8))) return rc;
+    if ((rc = t[0].ensure((size_t)(n_nodes + 1) * 8))) return rc;   // slot_off
+    if ((rc = t[1].ensure((size_t)n_slots * 8))) return rc;          // keys (all slots)
+    if ((rc = t[2].ensure((size_t)n_slots * 8))) return rc;          // locs
+    if ((rc = t[3].ensure((size_t)n_slots * 4))) return rc;          // flags
+    if ((rc = t[4].ensure((size_t)(n_slots + 1) * 8))) return rc;    // flags as int64, then offsets
+    if ((rc = t[5].ensure((size_t)(n_slots + 1) * 8))) return rc;
+    if ((rc = c.misc.ensure(64))) return rc;
+    HIPCHK(hipMemcpyAsync(c.sd_nodes.p, node_cat, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c.sd_node_off.p, node_off, (size_t)(n_nodes + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(t[0].p, slot_off.data(), (size_t)(n_nodes + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, st));
+    const unsigned gb = (unsigned)((n_slots + 255) / 256);
+    hipLaunchKernelGGL(seed_index_count_kernel, dim3(gb), dim3(256), 0, st, (const uint8_t *)c.sd_nodes.p, (const int64_t *)c.sd_node_off.p, (int)n_nodes, (const int64_t *)t[0].p,
+                       seed_len, seed_step, (uint64_t *)t[1].p, (uint64_t *)t[2].p, (int *)t[3].p, n_slots);
+    hipLaunchKernelGGL(flag_to_i64_kernel, dim3(gb), dim3(256), 0, st, (const int *)t[3].p, n_slots, (int64_t *)t[4].p);
+    HIPCHK(hipGetLastError());
+    int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
+    if (n_slots > 0x7ffffff0) { set_err("too many k-mer positions%s", ""); return GNX_EINVAL; }
+    if ((rc = launch_scan((const int64_t *)t[4].p, (int)n_slots, (int64_t *)t[5].p, d_carry, st))) return rc;
+    int64_t n_kmers = 0;
+    HIPCHK(hipMemcpyAsync(&n_kmers, d_carry, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_kmers == 0) return GNX_OK;
+    if ((rc = t[6].ensure((size_t)n_kmers * 16))) return rc; // compacted keys | locs
+    if ((rc = t[7].ensure((size_t)n_kmers * 16))) return rc; // sorted keys | locs
+    uint64_t *ck = (uint64_t *)t[6].p, *cl = ck + n_kmers, *sk = (uint64_t *)t[7].p, *sl = sk + n_kmers;
+    hipLaunchKernelGGL(seed_index_compact_kernel, dim3(gb), dim3(256), 0, st, (const uint64_t *)t[1].p, (const uint64_t *)t[2].p, (const int *)t[3].p, (const int64_t *)t[5].p, n_slots, ck, cl);
+    HIPCHK(hipGetLastError());
+    size_t tmp_bytes = 0;
+    if (n_kmers > 0x7ffffff0) { set_err("too many k-mers for one sort%s", ""); return GNX_EINVAL; }
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ck, sk, cl, sl, (int)n_kmers, 0, 2 * seed_len, st));
+    if ((rc = t[1].ensure(tmp_bytes + 16))) return rc; // (the per-slot keys are compacted by now)
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(t[1].p, tmp_bytes, ck, sk, cl, sl, (int)n_kmers, 0, 2 * seed_len, st)); // stable: insertion order within a key
+    uint64_t *hk = (uint64_t *)malloc((size_t)n_kmers * 8), *hl = (uint64_t *)malloc((size_t)n_kmers * 8);
+    if (!hk || !hl) { free(hk); free(hl); set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
+    if (hipMemcpyAsync(hk, sk, (size_t)n_kmers * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(hl, sl, (size_t)n_kmers * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { free(hk); free(hl); set_err("D2H of the index failed%s", ""); return GNX_EDEVICE; }
+    *out_keys = hk; *out_locs = hl; *out_n = n_kmers;
+    return GNX_OK;
+}
+
+int gnx_seed_index_set(const uint64_t *keys, const uint64_t *locs, int64_t n_index, const uint8_t *node_cat, const int64_t *node_off, int64_t n_nodes, int seed_len) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    CtxScope sc(ctx_at(0));
+    g_err[0] = 0;
+    if (n_index < 0 || (n_index > 0 && (!keys || !locs)) || !node_off || n_nodes < 0 || n_nodes > 0x7ffffff0 || seed_len < 2 || seed_len > 32) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    Ctx &c = g_ctx;
+    hipStream_t st = c.own_stream;
+    std::vector<int64_t> word_off((size_t)n_nodes + 1, 0);
+    for (int64_t k = 0; k < n_nodes; k++) word_off[(size_t)k + 1] = word_off[(size_t)k] + (node_off[k + 1] - node_off[k] + 31) / 32;
+    const int64_t n_words = word_off[(size_t)n_nodes], total = n_nodes ? node_off[n_nodes] : 0;
+    if ((rc = c.sd_keys.ensure((size_t)std::max<int64_t>(n_index, 1) * 8))) return rc;
+    if ((rc = c.sd_locs.ensure((size_t)std::max<int64_t>(n_index, 1) * 8))) return rc;
+    if ((rc = c.sd_nodes.ensure((size_t)total + 64))) return rc;
+    if ((rc = c.sd_node_off.ensure((size_t)(n_nodes + 1) * 8))) return rc;
+    if ((rc = c.sd_word_off.ensure((size_t)(n_nodes + 1) * 8))) return rc;
+    if ((rc = c.sd_words.ensure((size_t)std::max<int64_t>(n_words, 1) * 8))) return rc;
+    if (n_index) { HIPCHK(hipMemcpyAsync(c.sd_keys.p, keys, (size_t)n_index * 8, hipMemcpyHostToDevice, st)); HIPCHK(hipMemcpyAsync(c.sd_locs.p, locs, (size_t)n_index * 8, hipMemcpyHostToDevice, st)); }
+    if (total) HIPCHK(hipMemcpyAsync(c.sd_nodes.p, node_cat, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c.sd_node_off.p, node_off, (size_t)(n_nodes + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c.sd_word_off.p, word_off.data(), (size_t)(n_nodes + 1) * 8, hipMemcpyHostToDevice, st));
+    if (n_words) hipLaunchKernelGGL(pack_nodes_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, (const uint8_t *)c.sd_nodes.p, (const int64_t *)c.sd_node_off.p,
+                                    (const int64_t *)c.sd_word_off.p, (int)n_nodes, n_words, (uint64_t *)c.sd_words.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st)); // word_off is a local
+    c.sd_n = n_index; c.sd_nodes_n = n_nodes; c.sd_seed_len = seed_len;
+    return GNX_OK;
+}
+
+int gnx_seed_find_batch(const uint8_t *read_cat, const int64_t *read_off, int64_t n_reads, gnx_seed_hit **out_hits, int64_t **out_hit_off) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    CtxScope sc(ctx_at(0));
+    g_err[0] = 0;
+    if (!read_off || n_reads < 0 || n_reads > 0x3ffffff0 || !out_hits || !out_hit_off) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    Ctx &c = g_ctx;
+    if (c.sd_n < 0) { set_err("no resident seed index: call gnx_seed_index_set first%s", ""); return GNX_EINVAL; }
+    hipStream_t st = c.own_stream;
+    const int seed_len = c.sd_seed_len;
+    std::vector<int64_t> slot_off((size_t)n_reads + 1, 0);
+    int64_t maxlen = 0;
+    for (int64_t r = 0; r < n_reads; r++) {
+        const int64_t L = read_off[r + 1] - read_off[r];
+        if (L < 0 || L > 100000) { set_err("bad read length at read %s%lld", "", (long long)r); return GNX_EINVAL; }
+        slot_off[(size_t)r + 1] = slot_off[(size_t)r] + 2 * std::max<int64_t>(L - seed_len + 1, 0);
+        maxlen = std::max(maxlen, L);
+    }
+    const int64_t n_slots = slot_off[(size_t)n_reads], total = n_reads ? read_off[n_reads] : 0;
+    int64_t *hoff = (int64_t *)malloc((size_t)(n_reads + 1) * 8);
+    if (!hoff) { set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
+    struct Guard { void *a, *b; ~Guard() { free(a); free(b); } } guard{hoff, nullptr};
+    *out_hits = nullptr; *out_hit_off = nullptr;
+    if (n_slots == 0) { for (int64_t r = 0; r <= n_reads; r++) hoff[r] = 0; *out_hit_off = hoff; guard.a = nullptr; return GNX_OK; }
+    if (n_slots > 0x7ffffff0) { set_err("too many read positions in one batch%s", ""); return GNX_EINVAL; }
+    const int RW = (int)((maxlen + 31 + 31) / 32);
+    DevBuf *t = c.sd_tmp;
+    if ((rc = t[0].ensure((size_t)total + 64))) return rc;                       // reads
+    if ((rc = t[1].ensure((size_t)total + 64))) return rc;                       // reverse complements
+    if ((rc = t[2].ensure((size_t)(n_reads + 1) * 8))) return rc;                // read_off
+    if ((rc = t[3].ensure((size_t)(n_reads + 1) * 8))) return rc;                // slot_off
+    if ((rc = t[4].ensure((size_t)n_reads * 64 * RW * 8))) return rc;            // rainbows
+    if ((rc = t[5].ensure((size_t)(n_slots + 1) * 8))) return rc;                // counts
+    if ((rc = t[6].ensure((size_t)(n_slots + 1) * 8))) return rc;                // offsets
+    if ((rc = c.misc.ensure(64))) return rc;
+    HIPCHK(hipMemcpyAsync(t[0].p, read_cat, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(t[2].p, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(t[3].p, slot_off.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, st));
+    if (total) hipLaunchKernelGGL(revcomp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint8_t *)t[0].p, (const int64_t *)t[2].p, (int)n_reads, total, (uint8_t *)t[1].p);
+    const int64_t n_rw = n_reads * 64 * RW;
+    hipLaunchKernelGGL(pack_reads_kernel, dim3((unsigned)((n_rw + 255) / 256)), dim3(256), 0, st, (const uint8_t *)t[0].p, (const int64_t *)t[2].p, (int)n_reads, RW, (uint8_t *)t[1].p, (uint64_t *)t[4].p);
+    SeedCtx sx;
+    sx.keys = (const uint64_t *)c.sd_keys.p; sx.locs = (const uint64_t *)c.sd_locs.p; sx.n_index = c.sd_n;
+    sx.node_words = (const uint64_t *)c.sd_words.p; sx.node_off = (const int64_t *)c.sd_node_off.p; sx.word_off = (const int64_t *)c.sd_word_off.p;
+    sx.read_words = (const uint64_t *)t[4].p; sx.read_off = (const int64_t *)t[2].p; sx.RW = RW; sx.seed_len = seed_len;
+    const unsigned gb = (unsigned)((n_slots + 127) / 128);
+    hipLaunchKernelGGL(seed_find_kernel<false>, dim3(gb), dim3(128), 0, st, sx, (const int64_t *)t[3].p, (int)n_reads, n_slots, (int64_t *)t[5].p, (const int64_t *)nullptr, (SeedHit *)nullptr);
+    HIPCHK(hipGetLastError());
+    int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
+    if ((rc = launch_scan((const int64_t *)t[5].p, (int)n_slots, (int64_t *)t[6].p, d_carry, st))) return rc;
+    int64_t n_hits = 0;
+    HIPCHK(hipMemcpyAsync(&n_hits, d_carry, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st)); // slot_off is a local, too
+    if ((rc = t[7].ensure((size_t)std::max<int64_t>(n_hits, 1) * sizeof(SeedHit)))) return rc;
+    if (n_hits) hipLaunchKernelGGL(seed_find_kernel<true>, dim3(gb), dim3(128), 0, st, sx, (const int64_t *)t[3].p, (int)n_reads, n_slots, (int64_t *)nullptr, (const int64_t *)t[6].p, (SeedHit *)t[7].p);
+    HIPCHK(hipGetLastError());
+    gnx_seed_hit *hh = (gnx_seed_hit *)malloc((size_t)std::max<int64_t>(n_hits, 1) * sizeof(gnx_seed_hit));
+    std::vector<int64_t> soff((size_t)n_slots + 1);
+    guard.b = hh;
+    if (!hh) { set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
+    static_assert(sizeof(gnx_seed_hit) == sizeof(SeedHit), "hit layout");
+    if (n_hits) HIPCHK(hipMemcpyAsync(hh, t[7].p, (size_t)n_hits * sizeof(SeedHit), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(soff.data(), t[6].p, (size_t)(n_slots + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int64_t r = 0; r <= n_reads; r++) hoff[r] = soff[(size_t)slot_off[(size_t)r]];
+    *out_hits = hh; *out_hit_off = hoff;
+    guard.a = nullptr; guard.b = nullptr;
+    return GNX_OK;
 }
 
 int gnx_get_timing(gnx_timing *out) {

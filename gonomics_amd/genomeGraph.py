@@ -1,13 +1,39 @@
-"""Host mirror of the seed-extension DPs of the graph aligner ("next" row N2):
-genomeGraph.LeftDynamicAln / RightDynamicAln (/root/reference/genomeGraph/search.go:234-321), batched on the GPU through
-gnx_gsw_extend_batch.  The DP and the traceback run on the device; what stays here is Go slice bookkeeping.
+"""Host mirror of the graph aligner's read path ("next" rows N2 and N4 of SURVEY 8f), batched over the GPU:
 
-The reference's `dynamicScore` argument: resetDynamicScore (search.go:104-107) gets it by value, so it resets nothing -- the
-route the caller passes in is kept and the traced ops are merged into it with a `routeIdx` that restarts at 0 (so the first
-traced op is compared with route[0], the next new one with route[1], ...).  `route` below is that incoming slice; None / empty
-gives the plain run-length encoding in traceback order, which is what GraphSmithWatermanToGiraf's top-level calls see.
+  N2  LeftDynamicAln / RightDynamicAln               /root/reference/genomeGraph/search.go:234-321   -> gnx_gsw_extend_batch
+      LeftAlignTraversal / RightAlignTraversal        search.go:166-232
+      GraphSmithWatermanToGiraf                       genomeGraph/toGiraf.go:17-72                    -> GswBatchToGiraf (this file)
+  N4  IndexGenomeIntoMap                              genomeGraph/index.go:21-59                      -> gnx_seed_index_build
+      seedMapMemPool, extendToTheRightDev / LeftDev   search.go:425-590                               -> gnx_seed_find_batch (+ host for node
+      dnaTwoBit.CountRightMatches / CountLeftMatches  dna/dnaTwoBit/perfectAlign.go:10-85                borders), seed_map_host (all host)
+      seedCouldBeBetter                               index.go:102-121
+
+The DPs and the seed search (hash lookup + exact-match extension: byte / integer work) run on the device for a whole batch of
+reads; what stays here is the reference's bookkeeping: seeds as linked parts across nodes, the per-read loop over sorted seeds with its
+`seedCouldBeBetter` pruning, paths, soft clips.  Reads advance in ROUNDS: every read that still has a seed to try contributes its left and
+right extension to one gnx_gsw_extend_batch call per side and round (a read's seeds are tried one after the other because each
+result moves the pruning bound, exactly like the reference's loop).
+
+PARITY CONTRACT (the reference's own tests of this path only log: UNPINNED):
+  * two-bit words are built like dnaTwoBit.BasesToUint64LeftAln does (`answer | uint64(base)`: an N = 4 spills into the low bit
+    of the base before it inside a 32-base word), so hits and match lengths are those of the reference also for reads / nodes with N;
+  * seed ORDER: <= 100 seeds go through the reference's own heapSortSeeds (search.go:338-370, deterministic, restated literally);
+    more than 100 go through Go's sort.Slice, an unstable pdqsort whose order among equal TotalLength this image cannot observe (no
+    Go toolchain): here they are sorted by TotalLength descending, ties in order of discovery (stable).  Equal-length seeds that
+    reach the same score are interchangeable for the score; which one is reported can differ from Go in that case only;
+  * the route a traversal hands from one sibling branch to the next is carried over like in Go (resetDynamicScore is a no-op on
+    its by-value argument, search.go:104-107); what Go additionally does THROUGH SHARED BACKING ARRAYS when a node has several Prev /
+    Next edges (a later sibling's DP mutating the runs of an earlier best alignment; seeds pointing into the re-used `nextParts`
+    slice, search.go:447-456) is not emulated: for graphs whose extensions never branch the mirror equals the literal restatement
+    (tests/pyref_gsw.py) bit for bit; for branching extensions it implements value semantics.
 """
+import numpy as np
+
 from . import _lib, cigar
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N2 primitives (unchanged API)
+# ---------------------------------------------------------------------------------------------------------------------
 
 
 def _merge_route(route_in, runs):
@@ -49,3 +75,606 @@ def LeftDynamicAln(alpha, beta, scores, gapPen, route=None):
 def RightDynamicAln(alpha, beta, scores, gapPen, route=None):
     """(score, route, maxI, maxJ) -- search.go:278-321"""
     return DynamicAlnBatch("right", [alpha], [beta], scores, gapPen, [route])[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# graph, two-bit words, reads
+# ---------------------------------------------------------------------------------------------------------------------
+M64 = (1 << 64) - 1
+
+
+class TwoBit:
+    """dnaTwoBit.TwoBit: 32 bases per uint64, left aligned (dna/dnaTwoBit/dnaTwoBit.go:10-13, 66-76)"""
+    __slots__ = ("Seq", "Len")
+
+    def __init__(self, bases):
+        b = [int(x) for x in bases]
+        self.Len = len(b)
+        self.Seq = []
+        for start in range(0, len(b), 32):
+            w = 0
+            for x in b[start:start + 32]:
+                w = ((w << 2) | x) & M64  # BasesToUint64LeftAln: an N (4) also sets the low bit of the base before it
+            w = (w << (2 * (32 - len(b[start:start + 32])))) & M64
+            self.Seq.append(w)
+
+
+def NewTwoBitRainbow(bases):
+    """dna/dnaTwoBit/rainbow.go:27-45: the sequence with 0..31 'A's in front, each as a TwoBit"""
+    clone = [int(x) for x in bases]
+    out = []
+    for _ in range(32):
+        out.append(TwoBit(clone))
+        clone = [0] + clone
+    return out
+
+
+def _lz64(x):
+    return 64 - x.bit_length()
+
+
+def _tz64(x):
+    return 64 if x == 0 else (x & -x).bit_length() - 1
+
+
+def CountRightMatches(one, startOne, two, startTwo):
+    """dna/dnaTwoBit/perfectAlign.go:10-49"""
+    offsetOne, offsetTwo = (startOne % 32) * 2, (startTwo % 32) * 2
+    if offsetOne != offsetTwo:
+        raise ValueError("Error: Different offsets when comparing sequences")
+    i, j = startOne // 32, startTwo // 32
+    iEnd, jEnd = (one.Len + 31) // 32, (two.Len + 31) // 32
+    seqDiff = (one.Seq[i] ^ two.Seq[j]) & (M64 >> offsetOne)
+    bitMatches = _lz64(seqDiff)
+    total = bitMatches - offsetOne
+    i, j = i + 1, j + 1
+    while i < iEnd and j < jEnd and bitMatches == 64:
+        bitMatches = _lz64(one.Seq[i] ^ two.Seq[j])
+        total += bitMatches
+        i, j = i + 1, j + 1
+    return min(total // 2, one.Len - startOne, two.Len - startTwo)
+
+
+def CountLeftMatches(one, startOne, two, startTwo):
+    """dna/dnaTwoBit/perfectAlign.go:51-85"""
+    offsetOne, offsetTwo = (startOne % 32) * 2, (startTwo % 32) * 2
+    if offsetOne != offsetTwo:
+        raise ValueError("Different offsets when comparing sequences")
+    firstBitsNoLook = 64 - offsetOne - 2
+    i, j = startOne // 32, startTwo // 32
+    seqDiff = (one.Seq[i] ^ two.Seq[j]) & ((M64 << firstBitsNoLook) & M64)
+    bitMatches = _tz64(seqDiff)
+    total = bitMatches - firstBitsNoLook
+    i, j = i - 1, j - 1
+    while i >= 0 and j >= 0 and bitMatches == 64:
+        bitMatches = _tz64(one.Seq[i] ^ two.Seq[j])
+        total += bitMatches
+        i, j = i - 1, j - 1
+    return total // 2
+
+
+def GetBase(frag, pos):
+    """dnaTwoBit.GetBase"""
+    return (frag.Seq[pos // 32] >> (64 - 2 * (pos % 32 + 1))) & 3
+
+
+class Edge:
+    __slots__ = ("Dest", "Prob")
+
+    def __init__(self, Dest, Prob=1.0):
+        self.Dest, self.Prob = Dest, Prob
+
+
+class Node:
+    """genomeGraph.Node (genomeGraph.go:25-33)"""
+    __slots__ = ("Id", "Seq", "SeqTwoBit", "Prev", "Next")
+
+    def __init__(self, Id, Seq):
+        self.Id = int(Id)
+        self.Seq = np.ascontiguousarray(Seq, dtype=np.uint8)
+        if self.Seq.size and int(self.Seq.max()) > 4:
+            raise ValueError("node bases must be A, C, G, T or N (0..4)")
+        self.SeqTwoBit = TwoBit(self.Seq)
+        self.Prev, self.Next = [], []
+
+
+class GenomeGraph:
+    def __init__(self):
+        self.Nodes = []
+
+
+def AddNode(g, n):
+    if n.Id != len(g.Nodes):
+        raise ValueError("nodes are added in Id order")
+    g.Nodes.append(n)
+    return n
+
+
+def AddEdge(u, v, p=1.0):
+    """genomeGraph.go:118-121"""
+    u.Next.append(Edge(v, p))
+    v.Prev.append(Edge(u, p))
+
+
+_COMP = np.asarray([3, 2, 1, 0, 4], dtype=np.uint8)
+
+
+class FastqBig:
+    """fastq.FastqBig (fastq/fastqBig.go:15-50)"""
+
+    def __init__(self, Name, Seq, Qual=None):
+        self.Name = Name
+        self.Seq = np.ascontiguousarray(Seq, dtype=np.uint8)
+        if self.Seq.size and int(self.Seq.max()) > 4:
+            raise ValueError("read bases must be A, C, G, T or N (0..4)")
+        self.SeqRc = np.ascontiguousarray(_COMP[self.Seq][::-1])
+        self.Qual = Qual
+        self.Rainbow = None
+        self.RainbowRc = None
+
+    def rainbows(self):
+        if self.Rainbow is None:
+            self.Rainbow, self.RainbowRc = NewTwoBitRainbow(self.Seq), NewTwoBitRainbow(self.SeqRc)
+        return self.Rainbow, self.RainbowRc
+
+
+def ChromAndPosToNumber(chrom, start):
+    return (int(chrom) << 32) | int(start)
+
+
+def numberToChromAndPos(code):
+    return int(code) >> 32, int(code) & 0xFFFFFFFF
+
+
+def dnaToNumber(seq, start, end):
+    """align.go:170-177 (`answer << 2 | base`: an N spills like in the two-bit words; IndexGenomeIntoMap skips N k-mers anyway)"""
+    ans = int(seq[start])
+    for i in range(start + 1, end):
+        ans = ((ans << 2) | int(seq[i])) & M64
+    return ans
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N4: index (host statement; the device builds the same (key, location) lists with gnx_seed_index_build)
+# ---------------------------------------------------------------------------------------------------------------------
+def IndexGenomeIntoMap(genome, seedLen, seedStep):
+    """index.go:21-59: {k-mer code: [location codes in insertion order]}"""
+    if seedLen < 2 or seedLen > 32:
+        raise ValueError("Error: seed length needs to be greater than 1 and less than 33.  Got: %d" % seedLen)
+    answer = {}
+
+    def helper(prevSeq, currNode, locationCode):
+        if len(prevSeq) + len(currNode.Seq) >= seedLen:
+            currSeq = list(prevSeq) + [int(x) for x in currNode.Seq[0:seedLen - len(prevSeq)]]
+            if 4 not in currSeq:
+                answer.setdefault(dnaToNumber(currSeq, 0, seedLen), []).append(locationCode)
+        else:
+            for e in currNode.Next:
+                helper(list(prevSeq) + [int(x) for x in currNode.Seq], e.Dest, locationCode)
+
+    for nodeIdx, n in enumerate(genome):
+        seq = n.Seq
+        pos = 0
+        while pos < len(seq) - seedLen + 1:
+            if not (seq[pos:pos + seedLen] == 4).any():
+                answer.setdefault(dnaToNumber(seq, pos, pos + seedLen), []).append(ChromAndPosToNumber(nodeIdx, pos))
+            pos += seedStep
+        while pos < len(seq):
+            loc = ChromAndPosToNumber(nodeIdx, pos)
+            for e in n.Next:
+                helper([int(x) for x in seq[pos:]], e.Dest, loc)
+            pos += seedStep
+    return answer
+
+
+class SeedIndex:
+    """The same index as two sorted arrays (keys ascending, stable: locations of one key in insertion order), built on the device
+    for the k-mers inside nodes (gnx_seed_index_build: one thread per position, radix sort) and merged with the few k-mers that
+    cross node borders (host recursion over Next edges, like indexGenomeIntoMapHelper)."""
+
+    def __init__(self, genome, seedLen, seedStep, device=True):
+        self.seedLen, self.seedStep = seedLen, seedStep
+        if device:
+            keys, locs = _lib.seed_index_build([n.Seq for n in genome], seedLen, seedStep)
+        else:
+            keys, locs = [], []
+        order = []  # (key, insertion rank) for the border k-mers + (host mode) all k-mers
+        if not device:
+            full = IndexGenomeIntoMap(genome, seedLen, seedStep)
+            ks = sorted(full)
+            self.keys = np.asarray([k for k in ks for _ in full[k]], dtype=np.uint64)
+            self.locs = np.asarray([v for k in ks for v in full[k]], dtype=np.uint64)
+            return
+        border = {}
+
+        def helper(prevSeq, currNode, locationCode):
+            if len(prevSeq) + len(currNode.Seq) >= seedLen:
+                currSeq = list(prevSeq) + [int(x) for x in currNode.Seq[0:seedLen - len(prevSeq)]]
+                if 4 not in currSeq:
+                    border.setdefault(dnaToNumber(currSeq, 0, seedLen), []).append(locationCode)
+            else:
+                for e in currNode.Next:
+                    helper(list(prevSeq) + [int(x) for x in currNode.Seq], e.Dest, locationCode)
+
+        for nodeIdx, n in enumerate(genome):
+            L = len(n.Seq)
+            first = 0 if L - seedLen + 1 <= 0 else ((L - seedLen) // seedStep + 1) * seedStep
+            for pos in range(first, L, seedStep):
+                for e in n.Next:
+                    helper([int(x) for x in n.Seq[pos:]], e.Dest, ChromAndPosToNumber(nodeIdx, pos))
+        if border:
+            # insertion order of the reference: by node, inside nodes first, then the node's border positions -> a location code
+            # (node << 32 | pos) sorts exactly like that within one key, because border positions of a node come after its inner ones
+            bk = np.asarray([k for k in border for _ in border[k]], dtype=np.uint64)
+            bl = np.asarray([v for k in border for v in border[k]], dtype=np.uint64)
+            keys = np.concatenate([keys, bk])
+            locs = np.concatenate([locs, bl])
+            o = np.lexsort((locs, keys))
+            keys, locs = keys[o], locs[o]
+        self.keys, self.locs = keys, locs
+
+    def lookup(self, key):
+        lo = int(np.searchsorted(self.keys, np.uint64(key), side="left"))
+        hi = int(np.searchsorted(self.keys, np.uint64(key), side="right"))
+        return [int(x) for x in self.locs[lo:hi]]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N4: seeds
+# ---------------------------------------------------------------------------------------------------------------------
+class SeedDev:
+    """index.go:10-18"""
+    __slots__ = ("TargetId", "TargetStart", "QueryStart", "Length", "PosStrand", "TotalLength", "NextPart")
+
+    def __init__(self, TargetId, TargetStart, QueryStart, Length, PosStrand, TotalLength, NextPart=None):
+        self.TargetId, self.TargetStart, self.QueryStart, self.Length = int(TargetId), int(TargetStart), int(QueryStart), int(Length)
+        self.PosStrand, self.TotalLength, self.NextPart = bool(PosStrand), int(TotalLength), NextPart
+
+    def key(self):
+        """the seed as a tuple of its parts (for comparisons in tests)"""
+        out, s = [], self
+        while s is not None:
+            out.append((s.TargetId, s.TargetStart, s.QueryStart, s.Length, s.PosStrand, s.TotalLength))
+            s = s.NextPart
+        return tuple(out)
+
+
+def getLastPart(a):
+    while a.NextPart is not None:
+        a = a.NextPart
+    return a
+
+
+def getSeedPath(seed):
+    path = [seed.TargetId]
+    if seed.NextPart is not None:
+        path += getSeedPath(seed.NextPart)
+    return path
+
+
+def extendToTheRightDev(node, read, readStart, nodeStart, posStrand):
+    """search.go:425-461 (value semantics for the parts of several Next edges, see the module docstring)"""
+    rb, rbrc = read.rainbows()
+    nodeOffset = nodeStart % 32
+    readOffset = 31 - ((readStart - nodeOffset + 31) % 32)
+    rightMatches = CountRightMatches(node.SeqTwoBit, nodeStart, (rb if posStrand else rbrc)[readOffset], readStart + readOffset)
+    if rightMatches == 0:
+        return []
+    answer = []
+    if readStart + rightMatches < len(read.Seq) and nodeStart + rightMatches == node.SeqTwoBit.Len and len(node.Next) != 0:
+        for e in node.Next:
+            for nxt in extendToTheRightDev(e.Dest, read, readStart + rightMatches, 0, posStrand):
+                answer.append(SeedDev(node.Id, nodeStart, readStart, rightMatches, posStrand, rightMatches + nxt.TotalLength, nxt))
+    if not answer:
+        answer = [SeedDev(node.Id, nodeStart, readStart, rightMatches, posStrand, rightMatches, None)]
+    return answer
+
+
+def _left_helper(node, read, nextPart):
+    """search.go:488-531"""
+    rb, rbrc = read.rainbows()
+    nodePos = node.SeqTwoBit.Len - 1
+    readPos = nextPart.QueryStart - 1
+    nodeOffset = nodePos % 32
+    readOffset = 31 - ((readPos - nodeOffset + 31) % 32)
+    leftMatches = min(readPos + 1, CountLeftMatches(node.SeqTwoBit, nodePos, (rb if nextPart.PosStrand else rbrc)[readOffset], readPos + readOffset))
+    if leftMatches == 0:
+        raise RuntimeError("Error: should not have zero matches to the left")
+    currPart = SeedDev(node.Id, nodePos - (leftMatches - 1), readPos - (leftMatches - 1), leftMatches, nextPart.PosStrand, leftMatches + nextPart.TotalLength, nextPart)
+    answer = []
+    if currPart.QueryStart > 0 and currPart.TargetStart == 0:
+        for e in node.Prev:
+            readBase = GetBase((rb if nextPart.PosStrand else rbrc)[0], currPart.QueryStart - 1)
+            if readBase == GetBase(e.Dest.SeqTwoBit, e.Dest.SeqTwoBit.Len - 1):
+                answer += _left_helper(e.Dest, read, currPart)
+    return answer if answer else [currPart]
+
+
+def extendToTheLeftDev(node, read, currPart):
+    """search.go:463-486"""
+    rb, rbrc = read.rainbows()
+    answer = []
+    if currPart.QueryStart > 0 and currPart.TargetStart == 0:
+        for e in node.Prev:
+            readBase = GetBase((rb if currPart.PosStrand else rbrc)[0], currPart.QueryStart - 1)
+            if readBase == GetBase(e.Dest.SeqTwoBit, e.Dest.SeqTwoBit.Len - 1):
+                answer += _left_helper(e.Dest, read, currPart)
+    return answer if answer else [currPart]
+
+
+def heapSortSeeds(a):
+    """search.go:338-370, literally (a min-heap on TotalLength popped to the back: descending order, its own tie order)"""
+    def heapify(a, n, i):
+        while True:
+            l, r = 2 * i + 1, 2 * i + 2
+            mx = l if (l < n and a[l].TotalLength < a[i].TotalLength) else i
+            if r < n and a[r].TotalLength < a[mx].TotalLength:
+                mx = r
+            if mx == i:
+                return
+            a[i], a[mx] = a[mx], a[i]
+            i = mx
+
+    n = len(a)
+    for i in range(n // 2 - 1, -1, -1):
+        heapify(a, n, i)
+    size = n
+    for i in range(n - 1, 0, -1):
+        a[0], a[i] = a[i], a[0]
+        size -= 1
+        heapify(a, size, 0)
+
+
+def sort_seeds(seeds):
+    """seedMapMemPool's tail (search.go:583-589); see the parity contract for > 100 seeds"""
+    if len(seeds) > 100:
+        seeds.sort(key=lambda s: -s.TotalLength)  # Python's sort is stable: ties stay in order of discovery
+    else:
+        heapSortSeeds(seeds)
+    return seeds
+
+
+def _read_key(rainbow, readStart, seedLen):
+    keyIdx = (readStart + 31) // 32
+    keyOffset = 31 - ((readStart + 31) % 32)
+    return rainbow[keyOffset].Seq[keyIdx] >> (64 - 2 * seedLen)
+
+
+def seed_map_host(index, nodes, read, seedLen):
+    """seedMapMemPool (search.go:549-590) on the host: `index` is a dict (IndexGenomeIntoMap) or a SeedIndex"""
+    rb, rbrc = read.rainbows()
+    look = index.lookup if isinstance(index, SeedIndex) else (lambda k: index.get(k, []))
+    final = []
+    for readStart in range(0, len(read.Seq) - seedLen + 1):
+        for pos_strand, rain in ((True, rb), (False, rbrc)):
+            for code in look(_read_key(rain, readStart, seedLen)):
+                nodeIdx, nodePos = numberToChromAndPos(code)
+                nodeOffset = nodePos % 32
+                readOffset = 31 - ((readStart - nodeOffset + 31) % 32)
+                left = min(readStart + 1, CountLeftMatches(nodes[nodeIdx].SeqTwoBit, nodePos, rain[readOffset], readStart + readOffset))
+                temp = extendToTheRightDev(nodes[nodeIdx], read, readStart - (left - 1), nodePos - (left - 1), pos_strand)
+                if pos_strand:
+                    for t in temp:
+                        final += extendToTheLeftDev(nodes[nodeIdx], read, t)
+                else:
+                    final += temp  # (the reference does not extend minus-strand seeds to the left across nodes)
+    return sort_seeds(final)
+
+
+def seed_map_batch(index, nodes, reads, seedLen):
+    """seedMapMemPool for a batch of reads with the hash lookups and the in-node exact-match extensions on the device
+    (gnx_seed_find_batch: one thread per (read, strand, position)); parts that continue into neighbouring nodes are finished here."""
+    hits = _lib.seed_find_batch(index.keys, index.locs, [n.Seq for n in nodes], [r.Seq for r in reads], seedLen)
+    out = []
+    for r, read in enumerate(reads):
+        final = []
+        for (readStart, strand, nodeIdx, nodeStart, qStart, right) in hits[r]:  # in the reference's order of discovery
+            node = nodes[nodeIdx]
+            pos_strand = strand == 0
+            if right == 0:
+                continue
+            if qStart + right < len(read.Seq) and nodeStart + right == node.SeqTwoBit.Len and len(node.Next) != 0:
+                temp = extendToTheRightDev(node, read, qStart, nodeStart, pos_strand)  # crosses into the next node(s)
+            else:
+                temp = [SeedDev(node.Id, nodeStart, qStart, right, pos_strand, right, None)]
+            if pos_strand:
+                for t in temp:
+                    final += extendToTheLeftDev(node, read, t)
+            else:
+                final += temp
+        out.append(sort_seeds(final))
+    return out
+
+
+def seedCouldBeBetter(seedLen, currBestScore, perfectScore, queryLen, maxMatch, minMatch, leastSevereMismatch, leastSevereMatchMismatchChange):
+    """index.go:102-121 (Go integer division and remainder: operands are non-negative here)"""
+    seeds = queryLen // (seedLen + 1)
+    remainder = queryLen % (seedLen + 1)
+    if seedLen * maxMatch >= currBestScore and perfectScore - ((queryLen - seedLen) * minMatch) >= currBestScore:
+        return True
+    if seedLen * seeds * maxMatch + seeds * leastSevereMismatch >= currBestScore and \
+            perfectScore - remainder * minMatch + seeds * leastSevereMatchMismatchChange >= currBestScore:
+        return True
+    if seedLen * seeds * maxMatch + remainder * maxMatch + (seeds + 1) * leastSevereMismatch >= currBestScore and \
+            perfectScore + (seeds + 1) * leastSevereMatchMismatchChange >= currBestScore:
+        return True
+    return False
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N2: traversals and the per-read driver, as coroutines that yield their DP requests
+# ---------------------------------------------------------------------------------------------------------------------
+def AddPath(allPaths, newPath):
+    if len(allPaths) == 0 or allPaths[-1] != newPath:
+        allPaths.append(newPath)
+    return allPaths
+
+
+def CatPaths(currPaths, newPaths):
+    if len(newPaths) == 0:
+        return currPaths
+    if len(currPaths) == 0:
+        return newPaths
+    currPaths = AddPath(currPaths, newPaths[0])
+    return currPaths + list(newPaths[1:])
+
+
+def _left_target(n, extension, refEnd, seq):
+    """getLeftTargetBases (search.go:135-140)"""
+    take = min(len(seq) + refEnd, extension) - len(seq)
+    return np.concatenate([n.Seq[refEnd - take:refEnd], seq]).astype(np.uint8)
+
+
+def _right_target(n, extension, start, seq):
+    """getRightBases (search.go:142-147)"""
+    take = min(len(seq) + len(n.Seq) - start, extension) - len(seq)
+    return np.concatenate([seq, n.Seq[start:start + take]]).astype(np.uint8)
+
+
+def _left_traversal(n, seq, refEnd, currentPath, extension, read, route):
+    """LeftAlignTraversal (search.go:166-198) as a generator: yields ("left", target, read, route_in), receives (score, route, i, j);
+    returns (alignment, score, targetStart, queryStart, path)"""
+    sSeq = _left_target(n, extension, refEnd, seq)
+    sPath = list(currentPath)  # search.go:174-176 calls AddPath(s.Path, n.Id) and drops its result; s.Path was made with len == cap,
+    #                            so the append went to a new array: the node is never recorded (left and right paths stay empty)
+    if len(seq) + refEnd >= extension or len(n.Prev) == 0:
+        score, aln, tStart, qStart = yield ("left", sSeq, read, route)
+        return aln, score, refEnd - len(sSeq) - len(seq) + tStart, qStart, sPath
+    best = None
+    leftScore = -(1 << 63)
+    for e in n.Prev:
+        route, cs, ts, qs, cpath = yield from _left_traversal(e.Dest, sSeq, len(e.Dest.Seq), sPath, extension, read, route)
+        if cs > leftScore:
+            leftScore = cs
+            best = (route, refEnd - len(sSeq) - len(seq) + ts, qs, cpath)
+    aln, tStart, qStart, path = best
+    aln = list(reversed(aln))
+    path = list(reversed(path))
+    return aln, leftScore, tStart, qStart, path
+
+
+def _right_traversal(n, seq, start, currentPath, extension, read, route):
+    """RightAlignTraversal (search.go:200-232)"""
+    sSeq = _right_target(n, extension, start, seq)
+    sPath = list(currentPath)
+    if len(seq) + len(n.Seq) - start >= extension or len(n.Next) == 0:
+        score, aln, tEnd, qEnd = yield ("right", sSeq, read, route)
+        return aln, score, tEnd + start, qEnd, sPath
+    best = None
+    rightScore = -(1 << 63)
+    for e in n.Next:
+        route, cs, te, qe, cpath = yield from _right_traversal(e.Dest, sSeq, 0, sPath, extension, read, route)
+        if cs > rightScore:
+            rightScore = cs
+            best = (route, te, qe, cpath)
+    aln, tEnd, qEnd, path = best
+    return list(reversed(aln)), rightScore, tEnd + start, qEnd, path
+
+
+def _query_length(cigs):
+    return sum(c.RunLength for c in cigs if c.Op in (cigar.Match, cigar.Insertion, ord("S"), ord("="), ord("X")))
+
+
+def _append_soft_clips(front, lengthOfRead, cigs):
+    """cigar.AppendSoftClips (cigar/tools.go:26-40), literally -- including that a front clip without a back clip returns only the clip"""
+    run = _query_length(cigs)
+    if front == 0 and run >= lengthOfRead:
+        return cigs
+    answer = []
+    if front > 0:
+        answer.append(cigar.Cigar(front, ord("S")))
+    if front + run < lengthOfRead:
+        answer = answer + list(cigs) + [cigar.Cigar(lengthOfRead - front - run, ord("S"))]
+    return answer
+
+
+def _cig_append(alpha, beta):
+    if alpha and alpha[-1].Op == beta.Op:
+        alpha[-1].RunLength += beta.RunLength
+    else:
+        alpha.append(beta)
+    return alpha
+
+
+def _cig_concat(alpha, beta):
+    if len(alpha) == 0:
+        return beta
+    if len(beta) > 0:
+        alpha = _cig_append(alpha, cigar.Cigar(beta[0].RunLength, beta[0].Op))
+        beta = beta[1:]
+    return alpha + list(beta)
+
+
+class Giraf:
+    """giraf.Giraf, the fields GraphSmithWatermanToGiraf fills (giraf/giraf.go:16-33)"""
+
+    def __init__(self, read):
+        self.QName, self.QStart, self.QEnd, self.PosStrand = read.Name, 0, 0, True
+        self.Path = (0, [], 0)  # (TStart, Nodes, TEnd)
+        self.Cigar, self.AlnScore, self.MapQ, self.Seq = None, 0, 255, read.Seq
+
+    def key(self):
+        return (self.QStart, self.QEnd, self.PosStrand, self.Path[0], tuple(self.Path[1]), self.Path[2],
+                None if self.Cigar is None else tuple((c.RunLength, c.Op) for c in self.Cigar), self.AlnScore, bytes(self.Seq))
+
+
+def _read_to_giraf(gg, read, seeds, scoreMatrix):
+    """GraphSmithWatermanToGiraf (toGiraf.go:17-72) for one read, as a generator of DP requests"""
+    sc = np.asarray(scoreMatrix, dtype=np.int64)
+    best = Giraf(read)
+    perfect = int(sc[read.Seq, read.Seq].sum())
+    extension = perfect // 600 + len(read.Seq)
+    # scoreKeeper fields that survive from one seed to the next (resetScoreKeeper gets its argument by value: a no-op): a seed that
+    # covers the whole read re-uses the alignments, paths and queryEnd of the seed before it (toGiraf.go:47-51)
+    leftAln, rightAln, leftPath, rightPath, queryEnd = [], [], [], [], 0
+    for seed in seeds:
+        if not seedCouldBeBetter(seed.TotalLength, best.AlnScore, perfect, len(read.Seq), 100, 90, -196, -296):
+            break
+        tail = getLastPart(seed)
+        currSeq = read.Seq if seed.PosStrand else read.SeqRc
+        seedScore = int(sc[currSeq[seed.QueryStart:tail.QueryStart + tail.Length], currSeq[seed.QueryStart:tail.QueryStart + tail.Length]].sum())
+        if seed.TotalLength == len(currSeq):
+            targetStart, targetEnd, queryStart, currScore = seed.TargetStart, tail.TargetStart + tail.Length, seed.QueryStart, seedScore
+        else:
+            ext = extension - seed.TotalLength
+            leftAln, leftScore, targetStart, queryStart, leftPath = yield from _left_traversal(
+                gg.Nodes[seed.TargetId], np.zeros(0, np.uint8), seed.TargetStart, [], ext, currSeq[:seed.QueryStart], None)
+            rightAln, rightScore, targetEnd, queryEnd, rightPath = yield from _right_traversal(
+                gg.Nodes[tail.TargetId], np.zeros(0, np.uint8), tail.TargetStart + tail.Length, [], ext, currSeq[tail.QueryStart + tail.Length:], None)
+            currScore = leftScore + seedScore + rightScore
+        if currScore > best.AlnScore:
+            best.QStart = queryStart
+            best.QEnd = seed.QueryStart + queryStart + queryEnd + seed.TotalLength - 1
+            best.PosStrand = seed.PosStrand
+            best.Path = (targetStart, CatPaths(CatPaths(list(leftPath), getSeedPath(seed)), list(rightPath)), targetEnd)
+            mid = _cig_append([cigar.Cigar(c.RunLength, c.Op) for c in leftAln], cigar.Cigar(seed.TotalLength, cigar.Match))
+            best.Cigar = _append_soft_clips(queryStart, len(currSeq), _cig_concat(mid, [cigar.Cigar(c.RunLength, c.Op) for c in rightAln]))
+            best.AlnScore = currScore
+            best.Seq = currSeq
+    return best
+
+
+def GswBatchToGiraf(gg, reads, index, seedLen, scoreMatrix, device_seeds=True):
+    """GraphSmithWatermanToGiraf for a batch of reads: seeds from the device (or the host statement), then rounds of batched DPs."""
+    seeds = seed_map_batch(index, gg.Nodes, reads, seedLen) if device_seeds else [seed_map_host(index, gg.Nodes, r, seedLen) for r in reads]
+    gens = [_read_to_giraf(gg, r, s, scoreMatrix) for r, s in zip(reads, seeds)]
+    results = [None] * len(reads)
+    pending = {}
+    for k, g in enumerate(gens):
+        try:
+            pending[k] = next(g)
+        except StopIteration as st:
+            results[k] = st.value
+    while pending:
+        for side in ("left", "right"):
+            ks = [k for k, rq in pending.items() if rq[0] == side]
+            if not ks:
+                continue
+            outs = DynamicAlnBatch(side, [pending[k][1] for k in ks], [pending[k][2] for k in ks], scoreMatrix, -600, [pending[k][3] for k in ks])
+            for k, o in zip(ks, outs):
+                try:
+                    pending[k] = gens[k].send(o)
+                except StopIteration as st:
+                    results[k] = st.value
+                    del pending[k]
+    return results

@@ -207,6 +207,31 @@ int gnx_gsw_extend_batch(int side, const int64_t *scores, int64_t gap_pen, int64
                          const uint8_t *alpha_cat, const int64_t *alpha_off, const uint8_t *beta_cat, const int64_t *beta_off,
                          int64_t *out_score, int64_t *out_end_i, int64_t *out_end_j, gnx_cigar **out_ops, int64_t **out_ops_off);
 
+/* ---- "next" row N4: the seed index and the seed search of the graph aligner (what cmd/gsw does before its DPs) ----------------- */
+/* genomeGraph.IndexGenomeIntoMap (/root/reference/genomeGraph/index.go:21-43) for the k-mers inside nodes: node k is
+ * node_cat[node_off[k] .. node_off[k+1]) (dna.Base bytes, N allowed); positions 0, seed_step, ... of every node; k-mers with an N
+ * are skipped.  Output = the map as two arrays sorted by key (k-mer code, index.go `dnaToNumber`), equal keys in the reference's
+ * insertion order (node, position); locations are `node << 32 | pos` (ChromAndPosToNumber).  malloc'd, gnx_free().  The k-mers
+ * that run across node borders (index.go:34-38) are left to the host, which merges them and calls gnx_seed_index_set. */
+int gnx_seed_index_build(const uint8_t *node_cat, const int64_t *node_off, int64_t n_nodes, int seed_len, int seed_step,
+                         uint64_t **out_keys, uint64_t **out_locs, int64_t *out_n);
+/* Make an index (+ the nodes, packed like dnaTwoBit does it) resident on the device for gnx_seed_find_batch. */
+int gnx_seed_index_set(const uint64_t *keys, const uint64_t *locs, int64_t n_index, const uint8_t *node_cat, const int64_t *node_off,
+                       int64_t n_nodes, int seed_len);
+/* The hash-lookup / exact-match part of genomeGraph.seedMapMemPool (search.go:549-590) for a batch of reads: for every read
+ * position and strand (0 = read, 1 = reverse complement) every index hit, extended to the left inside its node
+ * (dnaTwoBit.CountLeftMatches) and from there to the right (CountRightMatches, the first step of extendToTheRightDev).  Hits of
+ * read r are out_hits[out_hit_off[r] .. out_hit_off[r+1]) in the reference's order of discovery.  A hit whose right end reaches
+ * the end of its node continues into the Next nodes on the host (as does the leftward continuation over Prev edges). */
+typedef struct gnx_seed_hit {
+    int32_t read_start; /* the read position whose k-mer hit */
+    int32_t strand;
+    int32_t node, node_start; /* target of the extended seed part */
+    int32_t q_start;          /* its start in the read (strand 1: in the reverse complement) */
+    int32_t right;            /* its length */
+} gnx_seed_hit;
+int gnx_seed_find_batch(const uint8_t *read_cat, const int64_t *read_off, int64_t n_reads, gnx_seed_hit **out_hits, int64_t **out_hit_off);
+
 #ifdef __cplusplus
 }
 #endif
