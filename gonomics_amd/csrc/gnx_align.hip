@@ -700,11 +700,18 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     if (!affine && !gsw && !d_smat) {
         const char *cl = getenv("GNX_CLONG");
         bool use = !(cl && cl[0] == '0'), any_multi = false;
+        long double cells_ld = 0, dir_bytes = 0;
         for (int64_t p = 0; use && p < n_pairs; p++) {
             if (h_alen[p] < 1 || h_blen[p] < 1) use = false;
             if (h_alen[p] > H) any_multi = true;
+            cells_ld += (long double)h_alen[p] * h_blen[p];
+            dir_bytes += (long double)((h_alen[p] + H - 1) / H) * ((h_blen[p] + 30) / 16) * QC * G * 16;
         }
-        if (use && (any_multi || (cl && cl[0] == '2'))) {
+        // It pays when the pairs are big: the sweep saves ~1.3e-13 s per cell against the recording fill, the fused re-fill + walk
+        // costs ~0.3 us per pair more than the one-lane-per-pair traceback over a stored matrix (tools/bench_shapes.py: 250..3200 x
+        // 10 000 gain 15..45 %, 100 000 pairs of 1000 x 1200 lose 2x) -- or when the stored matrix would not fit the workspace at all.
+        const bool big = cells_ld >= 2.0e6L * (long double)n_pairs || dir_bytes > (long double)c.ws_limit;
+        if (use && ((any_multi && big) || (cl && cl[0] == '2'))) {
             rc = run_device_clong(prm, kp, tp, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
             if (rc != -1) return rc;
         }
