@@ -55,13 +55,24 @@ __device__ __forceinline__ int dpp_next8(int src) { // every lane of the two ban
 
 // 2 waves per SIMD by choice: capping the kernel at 168 VGPRs for a third wave makes the compiler shuffle registers in the
 // unrolled loop and costs 20 % (measured: 32.2 ms vs 38.6-40.6 ms per 100 k pairs); 16 000 B of LDS allow 10 waves per CU.
-template <int RR, bool XP = false>
+// ROLE: reads of 161 .. 320 bases are swept as TWO row blocks of 8 x 20 slots, one launch each (pl.strips == 2):
+//   1 = the TOP block: rows 1 .. n - 160, right-aligned like a short read in 8 x RR slots (RR = 8, 12, 16 or 20: the host picks the
+//       smallest that holds the longest read of the batch); instead of planes / h(n,m) it hands its bottom row down:
+//       rowbuf[rowbuf_off + j] = {D'(n-159, j), h'(n-160, j)}, the two values a next lane would get by DPP (rebased like everything);
+//   2 = the BOTTOM block: rows n - 159 .. n (no padding); its first lane takes the row above it from that buffer instead of the
+//       row-0 constants, eight columns prefetched per half block.  Checkpoints of both blocks are indexed by the row of the pair.
+//   0 = the whole read in one block (n <= 8 * RR).
+template <int RR, bool XP = false, int ROLE = 0>
 __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                       const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                       KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
-                                                      unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err) {
+                                                      unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err,
+                                                      int2 *__restrict__ rowbuf = nullptr) {
     static_assert(RR <= 2 * FP8_LW && RR > FP_PLANES, "rows per lane");
+    static_assert(ROLE == 0 || !XP, "two row blocks: global alignment only");
+    static_assert(ROLE != 2 || RR == 2 * FP8_LW, "the bottom row block is full: 8 x 20 slots");
+    constexpr int BOT = G8 * 2 * FP8_LW; // rows of the bottom block (the top block has the rest, in 8 x RR slots: RR as small as they fit)
     __shared__ int lds[32 + 8 * FP8_PST];
     const int lane = threadIdx.x;
     const int g = lane >> 3;
@@ -83,11 +94,13 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     const bool valid = p < n_pairs;
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
-    const uint8_t *ap = a_buf + (valid ? a_start[pl.src] : 0);
+    const int row_base = ROLE == 2 ? pl.n - BOT : 0;                          // rows of the pair above this block
+    const int n_loc = ROLE == 1 ? pl.n - BOT : (ROLE == 2 ? BOT : pl.n);      // rows in this block
+    const uint8_t *ap = a_buf + (valid ? a_start[pl.src] + row_base : 0);
     const uint8_t *bp = b_buf + (valid ? b_start[pl.src] : 0);
     const int m_eff = valid ? pl.m : 0;
-    const int P = G8 * RR - pl.n; // padding slots above row 1
-    const int q0 = lp * RR;       // first slot of this lane; slot q holds row q - P + 1
+    const int P = G8 * RR - n_loc; // padding slots above row 1
+    const int q0 = lp * RR;        // first slot of this lane; slot q holds row q - P + 1 of the block
     int bad = 0;
     int vO4, cH, cDN; // constants pinned in VGPRs (2-cycle adds, DPP `old` operands)
     // XP: the first lane's boundary is row 0 = R(j) = -e*j: h'(0,t) = R(t), D'(1,t) = R(t) + o at step t, advanced by vInc after
@@ -126,6 +139,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     unsigned accR[FP_PLANES] = {0u, 0u, 0u, 0u}; // I-planes of rows n-d = slots RR-1-d of the last lane
     unsigned tailw = 0; // argmax tags of h(n-d, m-x), d, x = 0..3, field 4x + d: lets the walk take its first diagonal steps without a window
     int diag0 = (q0 == 0) ? ((XP || P == 0) ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + TD : ((XP || q0 - 1 == P - 1) ? 3 : kp.o4 + 2));
+    if (ROLE == 2 && q0 == 0) diag0 = kp.o4 + TD; // the slot above is row n - 160 of the pair, column 0: h' = D' = o
     int dn_out = 0, h_out = 0, b_out = 0;
     int up_dn = cDN, up_h = cH;
     auto base_of = [&](int c) { // LDS byte offset of the profile plane of beta[c] (column c, 1-based)
@@ -135,13 +149,16 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     };
     int qb = base_of(lp), nb = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
 
-    auto step = [&](const int t, auto chk, const bool ckflag) {
+    const int2 *rb_in = (ROLE == 2 && valid) ? rowbuf + pl.rowbuf_off : nullptr; // [j] = what the block above hands down for column j
+    auto rb_at = [&](int c) { return (ROLE == 2 && valid && c >= 1 && c <= m_eff) ? rb_in[c] : make_int2(0, 0); };
+    auto step = [&](const int t, auto chk, const bool ckflag, const int2 bnd) {
         constexpr bool CHECK = decltype(chk)::value; // false: every lane of the wave is inside its matrix (steady state)
         // ckflag (wave-uniform): this half block crosses a checkpoint column
         // The first lane of a pair keeps the DPP `old` value = the row-0 boundary constant.  Passing the previous step's result
         // as `old` (its first lane already holds that constant) lets the move happen in place, without a copy of the constant.
-        up_dn = dpp_prev8(up_dn, dn_out);
-        up_h = dpp_prev8(up_h, h_out);
+        // (ROLE 2: `old` is what the block above left for this step's column of the first lane, j = t.)
+        up_dn = dpp_prev8(ROLE == 2 ? bnd.x : up_dn, dn_out);
+        up_h = dpp_prev8(ROLE == 2 ? bnd.y : up_h, h_out);
         if (XP) { up_dn += vInc; up_h += vInc; }
         const int pb = dpp_prev8(qb, b_out);
         qb = dpp_next8(qb);
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
 #pragma unroll
             for (int r = 0; r < RR; r++) {
                 const int S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
-                if (r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
+                if (ROLE != 1 && r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
                 int hnew, dnn;
                 if (r < RR - FP_PLANES) { // tag bits are junk < 4 here; they never change the value of a max
                     const int M = hd + S4;
@@ -180,7 +197,8 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
             diag0 = up_h;
             dn_out = dnu;
             h_out = hold[RR - 1];
-            if (CHECK && j + 3 >= m_eff) { // the last four columns (always in a CHECK half block)
+            if (ROLE == 1) { if (lp == G8 - 1 && valid) rowbuf[pl.rowbuf_off + j] = make_int2(dn_out, h_out); } // hand the bottom row down
+            if (ROLE != 1 && CHECK && j + 3 >= m_eff) { // the last four columns (always in a CHECK half block)
 #pragma unroll
                 for (int d = 0; d < FP_PLANES; d++) tailw |= (unsigned)(hold[RR - 1 - d] & 3) << (8 * (m_eff - j) + 2 * d);
             }
@@ -190,9 +208,9 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
                 int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n;
 #pragma unroll
                 for (int r = 0; r < RR; r++) {
-                    const int i = q0 + r - P + 1;
+                    const int i = q0 + r - P + 1 + row_base; // row of the pair
                     const int off = E4 * (i + j + 1);
-                    if (i >= 1) ck[i - 1] = make_int2(rt[r] + off, hold[r] + off);
+                    if (i - row_base >= 1) ck[i - 1] = make_int2(rt[r] + off, hold[r] + off);
                 }
             }
             }
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     // half blocks of 8 steps t0 .. t0+7 (step t: lane lp is at column t - lp); a plane word is two half blocks
     const int Tend = ((m_max + G8 - 1) / 16 + 1) * 16;
     auto flush = [&](int t0) { // the last lane owns rows n..n-3: after the odd half block, store the plane word of steps t0-8 .. t0+7
-        if ((t0 & 8) && lp == G8 - 1 && valid) {
+        if (ROLE != 1 && (t0 & 8) && lp == G8 - 1 && valid) {
             const int w = t0 >> 4;
             if (w < pl.words) {
                 const int miss = (t0 + 7) - (m_eff + G8 - 1); // steps this lane sat idle after its last column
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     auto edge_half_block = [&](int t0) { // head and tail of the sweep: some lanes are outside their matrix
         nb = base_of(t0 + 8 + lp); // prefetch the next half block's bases
 #pragma unroll 1
-        for (int u = 0; u < 8; u++) step(t0 + u, std::true_type{}, true);
+        for (int u = 0; u < 8; u++) step(t0 + u, std::true_type{}, true, rb_at(t0 + u));
         qb = nb;
         flush(t0);
     };
@@ -226,16 +244,27 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     // inner loops per half-block kind cost ~90 register copies per half block at their boundaries).
     int t0 = 0;
     for (; t0 < Tend && !(t0 >= 8 && t0 + 7 <= m_min); t0 += 8) edge_half_block(t0);
+    int2 bcur[8], bnxt[8]; // ROLE 2: the row above for the first lane's columns of this / the next half block
+#pragma unroll
+    for (int u = 0; u < 8; u++) { bcur[u] = rb_at(t0 + u); bnxt[u] = make_int2(0, 0); }
     for (; t0 + 7 <= m_min; t0 += 8) { // steady state: every lane of the wave is inside its matrix
         nb = base_of(t0 + 8 + lp);
+        if (ROLE == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) bnxt[u] = rb_at(t0 + 8 + u);
+        }
         const bool ckflag = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
 #pragma unroll
-        for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, ckflag);
+        for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, ckflag, bcur[u]);
         qb = nb;
+        if (ROLE == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) bcur[u] = bnxt[u];
+        }
         flush(t0);
     }
     for (; t0 < Tend; t0 += 8) edge_half_block(t0);
-    if (lp == G8 - 1 && valid && m_eff >= 1) { hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); tail[pl.hcol_off] = tailw; } // h(n, m)
+    if (ROLE != 1 && lp == G8 - 1 && valid && m_eff >= 1) { hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); tail[pl.hcol_off] = tailw; } // h(n, m)
     if (bad) atomicOr(err, 1);
 }
 

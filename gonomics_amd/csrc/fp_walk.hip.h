@@ -128,13 +128,13 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             if (CW && TILED && !on_plane && x == 0 && steps == pos + 1 && j >= lo_ok(st.jc_lo)) {
                 // a straggler's long gap on a row without a stored plane: 64 words of its tile per look (lane t takes the t-th word
                 // further left), while they are all-I and lie inside the usable part of the tile
-                const int i0 = i - 1, l2 = i0 / R, r2 = i0 - l2 * R, d = R + r2; // one strip: n <= 160
+                const int i0 = i - 1, s2 = i0 / H, rem2 = i0 - s2 * H, l2 = rem2 / R, r2 = rem2 - l2 * R, d = R + r2;
                 const int t1 = (j - st.jc_lo) + l2 - 1;
                 if ((t1 & 15) == 15) {
                     const int wq = (t1 >> 4) - lane;
                     const bool ok = wq >= 0 && 16 * wq - l2 + 1 >= lo_ok(st.jc_lo) - st.jc_lo; // all 16 fields are usable columns
                     unsigned qv = 0;
-                    if (ok) qv = reinterpret_cast<const unsigned *>(wtrace + wp.trace_off + ((int64_t)wq * QA + (d >> 2)) * G + l2)[d & 3];
+                    if (ok) qv = reinterpret_cast<const unsigned *>(wtrace + wp.trace_off + ((int64_t)(s2 * wp.words + wq) * QA + (d >> 2)) * G + l2)[d & 3];
                     const unsigned long long stop = __ballot(!(ok && qv == IRUN));
                     const int T = stop ? __ffsll((long long)stop) - 1 : 64;
                     if (T > 0) { emit(op_of(1), 16 * (int64_t)T); j -= 16 * T; }
@@ -204,8 +204,9 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         st.j_hi = j; st.jc_lo = jc; st.slot = slot; st.status = 0;
         if (writer) next_active[slot] = p;
         PairPlan q;
-        q.n = pl.n; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = 1;
-        q.trace_off = (int64_t)slot * FP_WWORDS * QA * G; q.hcol_off = (int64_t)slot * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)slot * G;
+        q.n = pl.n; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = pl.strips; // (2: a read of two row blocks, re-filled as two strips)
+        q.trace_off = (int64_t)slot * FP_WWORDS * QA * G * pl.strips; q.hcol_off = (int64_t)slot * H * pl.strips; q.rowbuf_off = (int64_t)slot * FP_WROW;
+        q.dcol_off = (int64_t)slot * G * pl.strips;
         q.src = pl.src; q.col_off = jc; q.ckpt_off = pl.ckpt_off; q.rowi_off = 0;
         if (writer) next_wplans[slot] = q;
     }
@@ -227,8 +228,9 @@ __global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan 
     PairPlan q = pl;
     const int lo = c * FP_TILE, lo2 = max(0, lo - CKW); // start one checkpoint early: the first re-filled column has no usable tags
     q.m = (j_cur > lo) ? min(FP_TILE, j_cur - lo) + (lo - lo2) : 0;
-    q.words = (q.m + 15 + 15) / 16; q.strips = q.m > 0 ? 1 : 0;
-    q.trace_off = (int64_t)x * FP_TWORDS * QA * G; q.hcol_off = (int64_t)x * H; q.rowbuf_off = 0; q.dcol_off = (int64_t)x * G;
+    q.words = (q.m + 15 + 15) / 16; q.strips = q.m > 0 ? pl.strips : 0;
+    q.trace_off = (int64_t)x * FP_TWORDS * QA * G * pl.strips; q.hcol_off = (int64_t)x * H * pl.strips; q.rowbuf_off = (int64_t)x * FP_TROW;
+    q.dcol_off = (int64_t)x * G * pl.strips;
     q.src = pl.src; q.col_off = lo2;
     q.rowi_off = (x == 0) ? tiles_per : 0; // plan 0 carries tiles_per for the walk kernel
     out[x] = q;

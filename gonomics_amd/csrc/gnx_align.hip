@@ -100,7 +100,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr, s_in = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo;
+    DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo, fp_wrow;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     // pipelined host entry (gnx_host.hip.h): double-buffered inputs, results accumulated on the device, the resident reference
     DevBuf pin_a[2], pin_as[2], pin_b[2], pin_bs[2], res_score, res_off, res_ops, ref, gat_score, gat_off, gat_ops;
@@ -115,7 +115,8 @@ struct Ctx {
     // the fast path's plans of the previous call, still in `plans` on the device: batches of a stream of reads keep the same
     // lengths (C2-C4: every pair 150 x 10 000), and building + uploading 100 k plans (9.6 MB from pageable memory) costs ~0.6 ms
     std::vector<int64_t> fpc_alen, fpc_blen;
-    int64_t fpc_roff = 0, fpc_coff = 0, fpc_cells = 0, fpc_mmax = 1;
+    int64_t fpc_roff = 0, fpc_coff = 0, fpc_cells = 0, fpc_mmax = 1, fpc_rboff = 0;
+    int fpc_strips = 1;
     const void *fpc_ptr = nullptr; // == plans.p while the cached plans are what the device holds
 };
 std::mutex g_ctxs_mu;          // guards the list itself
@@ -232,33 +233,41 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                   const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                   const int64_t *h_alen, const int64_t *h_blen, int rows_per_lane,
                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
-                  int64_t *out_total, hipStream_t stream, bool first, bool xp) {
+                  int64_t *out_total, hipStream_t stream, bool first, bool xp, bool two) {
     // rows_per_lane: 19 (every n <= 152) or 20 (n <= 160) -> fp_sweep_kernel<19 / 20>
+    // two: every read has 161 .. 320 bases: swept as two row blocks (fp_sweep_kernel<20, false, 1 / 2>), windows / tiles re-filled as two strips
     // xp: AffineGapLocal, transposed -- the caller passes the query as "a" (rows) and the target as "b" (columns), and kp holds the
     //     transposed score table with the column-0 boundary of a global alignment (fp_sweep_kernel<.., true> and friends)
     Ctx &c = g_ctx;
     int rc;
     const int np = (int)n_pairs;
-    const bool cached = c.fpc_ptr && c.fpc_ptr == c.plans.p && (int64_t)c.fpc_alen.size() == n_pairs &&
+    const int S = two ? 2 : 1;
+    int64_t top_hi = 1; // two: the longest top block of the batch (rows above the last 160)
+    for (int64_t p = 0; two && p < n_pairs; p++) top_hi = std::max<int64_t>(top_hi, h_alen[p] - H);
+    const bool cached = c.fpc_ptr && c.fpc_ptr == c.plans.p && (int64_t)c.fpc_alen.size() == n_pairs && c.fpc_strips == S &&
                         memcmp(c.fpc_alen.data(), h_alen, (size_t)n_pairs * 8) == 0 && memcmp(c.fpc_blen.data(), h_blen, (size_t)n_pairs * 8) == 0;
     std::vector<PairPlan> plans(cached ? 0 : (size_t)n_pairs);
-    int64_t roff = 0, coff = 0, cells = 0, m_maxb = 1;
-    if (cached) { roff = c.fpc_roff; coff = c.fpc_coff; cells = c.fpc_cells; m_maxb = c.fpc_mmax; }
+    int64_t roff = 0, coff = 0, cells = 0, m_maxb = 1, rboff = 0;
+    if (cached) { roff = c.fpc_roff; coff = c.fpc_coff; cells = c.fpc_cells; m_maxb = c.fpc_mmax; rboff = c.fpc_rboff; }
     for (int64_t p = 0; !cached && p < n_pairs; p++) {
         PairPlan &pl = plans[(size_t)p];
         const int64_t n = h_alen[p], m = h_blen[p];
-        pl.n = (int32_t)n; pl.m = (int32_t)m; pl.words = (int32_t)((m + 15 + 15) / 16); pl.strips = 1;
-        pl.trace_off = 0; pl.hcol_off = p; pl.rowbuf_off = 0; pl.dcol_off = 0;
+        pl.n = (int32_t)n; pl.m = (int32_t)m; pl.words = (int32_t)((m + 15 + 15) / 16); pl.strips = S;
+        pl.trace_off = 0; pl.hcol_off = p; pl.rowbuf_off = rboff; pl.dcol_off = 0;
+        if (two) rboff += m + 1;
         pl.src = (int32_t)p; pl.col_off = 0; pl.ckpt_off = coff; pl.rowi_off = roff; pl.s_off = 0; pl.s_pitch = 0;
         roff += (int64_t)FP_PLANES * pl.words; coff += ((m - 1) / CKW) * n; cells += n * m;
         m_maxb = std::max(m_maxb, m);
     }
-    const size_t wtrace_b = (size_t)np * FP_WWORDS * QA * G * 16;
-    const size_t need = wtrace_b + (size_t)coff * 8 + (size_t)roff * 4 + (size_t)np * (FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + H * 4 + G * 4 + 32);
+    const size_t wtrace_b = (size_t)np * FP_WWORDS * QA * G * 16 * S;
+    const size_t need = wtrace_b + (size_t)coff * 8 + (size_t)roff * 4 + (size_t)rboff * 8 +
+                        (size_t)np * (FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + (size_t)S * (H * 4 + G * 4) + (two ? FP_WROW * 8 : 0) + 32);
     if ((int64_t)need > c.ws_limit) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] working set %zu B exceeds the workspace limit -> general path\n", need); return -1; }
     if ((rc = c.trace.ensure(wtrace_b))) return rc;
-    if ((rc = c.hcol.ensure((size_t)np * (H + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then the window hcol slots
-    if ((rc = c.dcol.ensure((size_t)np * G * 4))) return rc;
+    if ((rc = c.hcol.ensure((size_t)np * (H * S + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then the window hcol slots
+    if ((rc = c.dcol.ensure((size_t)np * G * S * 4))) return rc;
+    if (two && (rc = c.rowbuf.ensure((size_t)rboff * 8))) return rc;        // what the top row block hands to the bottom one
+    if (two && (rc = c.fp_wrow.ensure((size_t)np * FP_WROW * 8))) return rc; // row buffers of the window slots
     if ((rc = c.plans.ensure((size_t)np * sizeof(PairPlan)))) return rc;
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
     if ((rc = c.misc.ensure(64))) return rc;
@@ -281,7 +290,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         HIPCHK(hipMemcpyAsync(c.plans.p, plans.data(), (size_t)np * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream)); // `plans` is pageable: the copy is staged, but do not rely on it
         c.fpc_alen.assign(h_alen, h_alen + n_pairs); c.fpc_blen.assign(h_blen, h_blen + n_pairs);
-        c.fpc_roff = roff; c.fpc_coff = coff; c.fpc_cells = cells; c.fpc_mmax = m_maxb; c.fpc_ptr = c.plans.p;
+        c.fpc_roff = roff; c.fpc_coff = coff; c.fpc_cells = cells; c.fpc_mmax = m_maxb; c.fpc_ptr = c.plans.p; c.fpc_rboff = rboff; c.fpc_strips = S;
     }
     const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
     int *d_hfwd = reinterpret_cast<int *>(c.hcol.p);
@@ -303,16 +312,26 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
 
     auto forward = [&](int p0, int cnt, hipStream_t st) -> int {
         const dim3 grid8((unsigned)((cnt + G8 - 1) / G8));
+        if (two) { // top row block, then the bottom one (it reads what the top one left in the row buffer)
+            int2 *rb = reinterpret_cast<int2 *>(c.rowbuf.p);
+            const int top_rows = (int)(top_hi + G8 - 1) / G8; // slots per lane of the top block: as few as hold the longest read's n - 160 rows
+            auto ktop = top_rows <= 8 ? fp_sweep_kernel<8, false, 1> : (top_rows <= 12 ? fp_sweep_kernel<12, false, 1> : (top_rows <= 16 ? fp_sweep_kernel<16, false, 1> : fp_sweep_kernel<20, false, 1>));
+            hipLaunchKernelGGL(ktop, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, rb);
+            hipLaunchKernelGGL((fp_sweep_kernel<20, false, 2>), grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, rb);
+            HIPCHK(hipGetLastError());
+            return GNX_OK;
+        }
         auto k = xp ? (rows_per_lane == 19 ? fp_sweep_kernel<19, true> : fp_sweep_kernel<20, true>) : (rows_per_lane == 19 ? fp_sweep_kernel<19, false> : fp_sweep_kernel<20, false>);
-        hipLaunchKernelGGL(k, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err);
+        hipLaunchKernelGGL(k, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, (int2 *)nullptr);
         HIPCHK(hipGetLastError());
         return GNX_OK;
     };
     // walk / window stages of the pairs [p0, p0+cnt) on stream `st`; their window slots are [p0, p0+cnt) as well
     auto post = [&](int p0, int cnt, hipStream_t st, int *cnt2, hipEvent_t e1, hipEvent_t e2) -> int {
-        uint4 *wtr = reinterpret_cast<uint4 *>(c.trace.p) + (int64_t)p0 * FP_WWORDS * QA * G;
-        int *whc = d_whcol + (int64_t)p0 * H;
-        unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * G;
+        uint4 *wtr = reinterpret_cast<uint4 *>(c.trace.p) + (int64_t)p0 * FP_WWORDS * QA * G * S;
+        int *whc = d_whcol + (int64_t)p0 * H * S;
+        unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * G * S;
+        int2 *wrb = two ? reinterpret_cast<int2 *>(c.fp_wrow.p) + (int64_t)p0 * FP_WROW : nullptr;
         int cur = 0, n_act = 0, it = 0;
         float f = 0;
         // The stragglers' walk through their tiles runs one WAVE per pair (lanes that walk alone diverge: 0.80 -> 0.5 ms for 1 700
@@ -325,7 +344,8 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         auto k_next = xp ? fp_walk_kernel<false, false, true> : fp_walk_kernel<false, false, false>;
         auto k_tiled = cw ? (xp ? fp_walk_kernel<false, true, true, true> : fp_walk_kernel<false, true, false, true>) : (xp ? fp_walk_kernel<false, true, true> : fp_walk_kernel<false, true, false>);
         auto wgrid = [&](int n) { return dim3((unsigned)(cw ? n : (n + 63) / 64)); };
-        auto k_win = xp ? fill_affine_kernel<false, false, false, true, true, false, true> : fill_affine_kernel<false, false, false, true, true, false, false>;
+        auto k_win = xp ? fill_affine_kernel<false, false, false, true, true, false, true>
+                        : (two ? fill_affine_kernel<false, true, false, true, true, false, false> : fill_affine_kernel<false, false, false, true, true, false, false>);
         hipLaunchKernelGGL(k_first, dim3((unsigned)(cw_first ? cnt : (cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_tail,
                            (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, d_wpl[0] + p0, d_err, p0);
         HIPCHK(hipGetLastError());
@@ -336,7 +356,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
             HIPCHK(hipMemsetAsync(cnt2 + nxt, 0, 4, st));
             HIPCHK(hipEventRecord(e1, st));
             hipLaunchKernelGGL(k_win, dim3((unsigned)((n_act + 3) / 4)), blockF, 0, st, d_wpl[cur] + p0, n_act, d_a, d_as, d_b, d_bs, kp,
-                               wtr, whc, (int2 *)nullptr, wdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
+                               wtr, whc, wrb, wdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(e2, st));
             hipLaunchKernelGGL(k_next, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
@@ -355,20 +375,22 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         if (n_act > 0) { // stragglers: all their remaining columns as independent tiles, one launch
             const int n_strag = n_act;
             const int64_t n_tiles = (int64_t)n_strag * tiles_per;
-            const size_t tb = (size_t)n_tiles * FP_TWORDS * QA * G * 16;
+            const size_t tb = (size_t)n_tiles * FP_TWORDS * QA * G * 16 * S;
             if ((int64_t)tb > c.ws_limit || n_tiles > 0x3fffffff) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %lld straggler tiles exceed the workspace limit -> general path\n", (long long)n_tiles); return -1; }
             int rc2;
-            if ((rc2 = c.rowbuf.ensure((size_t)n_tiles * sizeof(PairPlan)))) return rc2; // tile plans (rowbuf is unused on this path)
-            if ((rc2 = c.fp_thcol.ensure((size_t)n_tiles * (H + G) * 4))) return rc2;
+            if ((rc2 = (two ? c.fp_redo : c.rowbuf).ensure((size_t)n_tiles * sizeof(PairPlan)))) return rc2; // tile plans (in a buffer this path does not use otherwise)
+            if ((rc2 = c.fp_thcol.ensure((size_t)n_tiles * (H + G) * 4 * S))) return rc2;
             if ((rc2 = c.fp_ttrace.ensure(tb))) return rc2;
-            PairPlan *tpl = reinterpret_cast<PairPlan *>(c.rowbuf.p);
+            if (two && (rc2 = c.fp_wrow.ensure((size_t)std::max<int64_t>(n_tiles * FP_TROW, (int64_t)np * FP_WROW) * 8))) return rc2; // (the window rounds are over)
+            PairPlan *tpl = reinterpret_cast<PairPlan *>(two ? c.fp_redo.p : c.rowbuf.p);
             int *thc = reinterpret_cast<int *>(c.fp_thcol.p);
-            unsigned *tdc = reinterpret_cast<unsigned *>(thc + n_tiles * H);
+            unsigned *tdc = reinterpret_cast<unsigned *>(thc + n_tiles * H * S);
+            int2 *trb = two ? reinterpret_cast<int2 *>(c.fp_wrow.p) : nullptr;
             uint4 *ttr = reinterpret_cast<uint4 *>(c.fp_ttrace.p);
             hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, dpl, d_act[cur] + p0, n_strag, tiles_per, d_st, tpl);
             HIPCHK(hipEventRecord(e1, st));
             hipLaunchKernelGGL(k_win, dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, st, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
-                               ttr, thc, (int2 *)nullptr, tdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
+                               ttr, thc, trb, tdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
             HIPCHK(hipEventRecord(e2, st));
             HIPCHK(hipMemsetAsync(cnt2, 0, 8, st));
             hipLaunchKernelGGL(k_tiled, wgrid(n_strag), blockT, 0, st, dpl, d_act[cur] + p0, n_strag, d_st, d_hfwd, d_rowi, d_tail,
@@ -653,22 +675,26 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // fp_sweep_kernel keeps an int16 profile of 4*(s - 2e); its padding rows need 4*|gapOpen| well inside int16
         if (prm->gap_open <= -8000) fp = false;
         for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * prm->gap_extend); if (v > 32767 || v < -32000) fp = false; }
-        int64_t n_hi = 0;
+        int64_t n_hi = 0, n_lo = INT64_MAX;
         for (int64_t p = 0; fp && p < n_pairs; p++) {
             const int64_t n = h_rows[p], m = h_cols[p];
-            if (n < 1 || n > H || m < (fpenv && fpenv[0] == '2' ? 1 : 768) || m > 0x3fffffff) fp = false;
+            if (n < 1 || n > 2 * H || m < (fpenv && fpenv[0] == '2' ? 1 : 768) || m > 0x3fffffff) fp = false;
             else if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) fp = false;
-            n_hi = std::max(n_hi, n);
+            n_hi = std::max(n_hi, n); n_lo = std::min(n_lo, n);
         }
-        const int rows_per_lane = n_hi <= 19 * G8 ? 19 : 20;
+        // reads of 161 .. 320 bases: two row blocks (global AffineGap only; a batch that mixes them with shorter reads takes the general path)
+        const bool two = n_hi > H;
+        if (two && (xp || n_lo <= H)) fp = false;
+        const int rows_per_lane = (two || n_hi > 19 * G8) ? 20 : 19;
         if (fp) {
             // sub-batches whose fast-path working set (checkpoints, planes, window slots, staging) fits the workspace
-            const size_t fixed = (size_t)FP_WWORDS * QA * G * 16 + FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + H * 4 + G * 4 + 64;
+            const size_t fixed = ((size_t)FP_WWORDS * QA * G * 16 + H * 4 + G * 4) * (two ? 2 : 1) + FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + 64 +
+                                 (two ? (size_t)FP_WROW * 8 : 0);
             // ... of about equal size (a small last sub-batch would leave most of the GPU idle for the length of a sweep wave)
             std::vector<int64_t> cb{0};
             size_t acc_b = 0, total_b = 0;
             const size_t budget = (size_t)(c.ws_limit - c.ws_limit / 8);
-            auto pair_bytes = [&](int64_t p) { return fixed + (size_t)((h_cols[p] - 1) / CKW) * h_rows[p] * 8 + (size_t)FP_PLANES * ((h_cols[p] + 30) / 16) * 4; };
+            auto pair_bytes = [&](int64_t p) { return fixed + (size_t)((h_cols[p] - 1) / CKW) * h_rows[p] * 8 + (size_t)FP_PLANES * ((h_cols[p] + 30) / 16) * 4 + (two ? (size_t)(h_cols[p] + 1) * 8 : 0); };
             for (int64_t p = 0; p < n_pairs; p++) { const size_t b = pair_bytes(p); if (b > budget) { fp = false; break; } total_b += b; }
             const size_t n_sub = (total_b + budget - 1) / budget, target = n_sub ? std::min(budget, total_b / n_sub + (size_t)(1 << 20)) : budget;
             for (int64_t p = 0; fp && p < n_pairs; p++) {
@@ -686,9 +712,9 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             for (size_t ch = 0; fp && ch + 1 < cb.size(); ch++) {
                 const int64_t b = cb[ch], e = cb[ch + 1];
                 if (xp) rc = run_device_fp(prm, kpx, tp, e - b, d_b, d_bs + b, d_a, d_as + b, h_blen + b, h_alen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
-                                           d_ops_off + b, out_total, stream, ch == 0, true);
+                                           d_ops_off + b, out_total, stream, ch == 0, true, false);
                 else rc = run_device_fp(prm, kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
-                                        d_ops_off + b, out_total, stream, ch == 0, false);
+                                        d_ops_off + b, out_total, stream, ch == 0, false, two);
                 // a CIGAR buffer that is too small does not end the loop: the remaining sub-batches still count their runs (the offset
                 // carry runs through them), so that the total handed back with GNX_ECAPACITY is that of the whole batch
                 if (rc != GNX_OK && rc != GNX_ECAPACITY) break;
@@ -1186,7 +1212,7 @@ void gnx_shutdown(void) {
         if (!c.inited) continue;
         (void)hipSetDevice(c.device);
         (void)hipDeviceSynchronize();
-        DevBuf *bufs[] = {&c.strip_map, &c.tb_scr, &c.tb_scr_off, &c.scan_tmp, &c.fp_redo, &c.fp_tail, &c.fp_thcol, &c.fp_ttrace, &c.fp_rowi, &c.fp_ckpt, &c.fp_states, &c.fp_stage,
+        DevBuf *bufs[] = {&c.strip_map, &c.tb_scr, &c.tb_scr_off, &c.scan_tmp, &c.fp_redo, &c.fp_wrow, &c.fp_tail, &c.fp_thcol, &c.fp_ttrace, &c.fp_rowi, &c.fp_ckpt, &c.fp_states, &c.fp_stage,
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,

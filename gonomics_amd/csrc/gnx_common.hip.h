@@ -53,6 +53,8 @@ constexpr int FP_CAP = 64;   // CIGAR runs staged per pair on the fast path (mor
 constexpr int FP_WWORDS = (FP_SPAN + CKW + 15 + 15) / 16 + 1; // direction words of the widest window
 constexpr int FP_TILE = 1024;                                  // straggler tiles: columns (c*FP_TILE, (c+1)*FP_TILE]
 constexpr int FP_TWORDS = (FP_TILE + CKW + 15 + 15) / 16;      // direction words of a tile (plus the checkpoint interval it starts early)
+constexpr int FP_WROW = FP_SPAN + CKW + 8;                     // row-buffer entries of a window slot (reads of two row blocks: the re-fill has two strips)
+constexpr int FP_TROW = FP_TILE + CKW + 8;                     // ... of a tile
 
 struct KParams {
     int sc4[25]; // 4*scores

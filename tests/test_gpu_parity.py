@@ -511,3 +511,57 @@ def test_pipelined_strips(gpu_lib, mode, name):
     finally:
         del os.environ["GNX_TB_TWO_PASS"]
     common.assert_same(got, exp, name + " long gaps, mirrored, two-pass walk")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [51, 52, 53])
+def test_fast_path_two_row_blocks(gpu_lib, seed, monkeypatch):
+    """reads of 161 .. 320 bases on the fast path: two row blocks (fp_sweep_kernel<20, false, 1 / 2>: the top block hands its bottom row
+    to the bottom block), windows and straggler tiles re-filled as two strips; every length, ragged windows around the checkpoint
+    spacing, several penalty sets, small checkerboards (quirks Q1 / Q2 across the strip border), forced window / tile rounds"""
+    monkeypatch.setenv("GNX_FASTPATH", "2")
+    rng = np.random.default_rng(seed)
+    ref = rng.integers(0, 4, size=6000, dtype=np.uint8)
+    ref[rng.integers(0, 6000, size=10)] = 4
+    alphas, betas = [], []
+    n_top = {51: 320, 52: 224, 53: 288}[seed]  # the top block runs with 20 / 8 / 16 slots per lane
+    for k in range(180):
+        n = int(rng.integers(161, n_top + 1)) if k >= 8 else min([161, 162, 320, 319, 200, 250, 165, 300][k], n_top)
+        m = int(rng.choice([127, 128, 129, 255, 256, 257, 330, 1000, 1500, 2049, 3000]))
+        off = int(rng.integers(0, 6000 - m + 1))
+        beta = ref[off:off + m].copy()
+        if m >= n and rng.random() < 0.8:
+            pos = int(rng.integers(0, m - n + 1))
+            alpha = common.mutate(rng, beta[pos:pos + n + 20], 0.04, 0.015)
+        else:
+            alpha = rng.integers(0, 4, size=n, dtype=np.uint8)
+        alpha = alpha[:n]
+        if alpha.shape[0] < 161:  # (mutate may have shortened it)
+            alpha = np.concatenate([alpha, rng.integers(0, 4, size=161 - alpha.shape[0], dtype=np.uint8)])
+        alphas.append(alpha); betas.append(beta)
+    for name, go, ge in [("HumanChimpTwo", -600, -150), ("Default", -400, -30), ("HumanChimpTwo", 0, -150)]:
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX[name], go, ge)
+        got = gpu_lib.align_batch(p, alphas, betas)
+        if go == -600:
+            assert gpu_lib.get_timing()["fast_path"] == 1
+        exp = oracle.align_batch(0, MX[name], go, ge, alphas, betas, threads=8)
+        common.assert_same(got, exp, "two row blocks %s %d %d" % (name, go, ge))
+    exp7 = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, alphas, betas, ci=7, cj=7, threads=8)
+    p7 = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150, 7, 7)
+    for maxit in (None, "0", "3"):
+        if maxit is not None:
+            monkeypatch.setenv("GNX_FP_MAXIT", maxit)
+        common.assert_same(gpu_lib.align_batch(p7, alphas, betas), exp7, "two row blocks, 7x7 checkerboards, maxit %s" % maxit)
+    monkeypatch.delenv("GNX_FP_MAXIT", raising=False)
+    # a C2-shaped batch of 250-base reads (the shape this exists for) without the forcing switch
+    monkeypatch.delenv("GNX_FASTPATH", raising=False)
+    reads, chunk = common.c2_workload(seed, 600, read_len=250, chunk_len=5000)
+    a_start = np.arange(600, dtype=np.int64) * 250
+    a_len = np.full(600, 250, dtype=np.int64)
+    b_start = np.zeros(600, dtype=np.int64)
+    b_len = np.full(600, 5000, dtype=np.int64)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+    got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len)
+    assert gpu_lib.get_timing()["fast_path"] == 1
+    exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len, threads=8)
+    common.assert_same(got, exp, "250-base reads")
