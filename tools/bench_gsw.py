@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Measurement for rows N4 / N2-callers (not the headline metric): seed index of a synthetic linear genome on the device, seed search for a
+batch of 150-base reads, and the whole read path (seeds -> traversals -> DPs -> giraf) for a smaller batch.  One JSON line per series."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common  # noqa: E402
+from gonomics_amd import _lib, align, genomeGraph as gg  # noqa: E402
+
+
+def main():
+    L = _lib.lib()
+    _lib.check(L.gnx_init(0, 32 << 30))
+    rng = np.random.default_rng(9)
+    n_nodes, node_len, seed_len, step = 24, 2000000, 32, 32
+    seqs = [rng.integers(0, 4, size=node_len).astype(np.uint8) for _ in range(n_nodes)]
+    t0 = time.perf_counter()
+    keys, locs = _lib.seed_index_build(seqs, seed_len, step)
+    t_build = time.perf_counter() - t0
+    print(json.dumps({"series": "IndexGenomeIntoMap on the device: %d nodes x %d bases, seedLen %d, step %d" % (n_nodes, node_len, seed_len, step),
+                      "kmers": int(keys.shape[0]), "host_call_s": t_build, "bases_per_s": n_nodes * node_len / t_build}), flush=True)
+    n_reads = 100000
+    reads = []
+    for _ in range(n_reads):
+        k = int(rng.integers(0, n_nodes)); o = int(rng.integers(0, node_len - 160))
+        r = seqs[k][o:o + 150].copy()
+        r[rng.random(150) < 0.01] = rng.integers(0, 4)
+        reads.append(r if rng.random() < 0.5 else (3 - r[::-1]).astype(np.uint8))
+    _lib.seed_find_batch(keys, locs, seqs, reads[:1000], seed_len)  # index + nodes resident, warm
+    t0 = time.perf_counter()
+    hits = _lib.seed_find_batch(keys, locs, seqs, reads, seed_len)
+    t_find = time.perf_counter() - t0
+    print(json.dumps({"series": "seed search (hash lookup + exact-match extension) for %d reads of 150 bases, both strands" % n_reads, "hits": int(sum(len(h) for h in hits)),
+                      "host_call_s": t_find, "reads_per_s": n_reads / t_find, "note": "host_call_s includes the Python binding's list building"}), flush=True)
+    # whole read path on a small graph object (Python bookkeeping dominates: this is the mirror of the reference's per-read logic, not a tuned mapper)
+    g = gg.GenomeGraph()
+    for k in range(4):
+        gg.AddNode(g, gg.Node(k, seqs[k][:200000]))
+    index = gg.SeedIndex(g.Nodes, seed_len, step)
+    sub = []
+    for _ in range(2000):
+        k = int(rng.integers(0, 4)); o = int(rng.integers(0, 200000 - 170))
+        sub.append(gg.FastqBig("r", common.mutate(rng, g.Nodes[k].Seq[o:o + 170], 0.02, 0.01)[:150]))
+    t0 = time.perf_counter()
+    out = gg.GswBatchToGiraf(g, sub, index, seed_len, align.HumanChimpTwoScoreMatrix)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"series": "GswBatchToGiraf: %d reads against a 4 x 200 kb graph (device seeds + rounds of batched device DPs)" % len(sub), "mapped": int(sum(o.AlnScore > 0 for o in out)),
+                      "host_call_s": dt, "reads_per_s": len(sub) / dt}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
