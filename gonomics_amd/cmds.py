@@ -5,6 +5,7 @@ side of the DP, byte-identical to the reference's golden output files.
   GlobalAlignment_CigarToBed  /root/reference/cmd/cigarToBed/cigarToBed.go:65-160
   gapToAlignment              /root/reference/cmd/globalAlignmentAnchor/globalAlignmentAnchor.go:321-436
                               (the serial loop of AffineGap_customizeCheckersize calls becomes ONE batched call)
+  faChunkAlign                /root/reference/cmd/faChunkAlign/faChunkAlign.go:18-29
 
 `aligner` parameters default to the GPU path (gonomics_amd.align); tests inject a CPU stand-in to check the I/O logic.
 """
@@ -30,6 +31,16 @@ def globalAlignment(inputFileOne, inputFileTwo, outFileName="", const_gap=None):
         with open(outFileName, "w") as fh:
             fh.write(">" + faOne.Name + "\n" + v[0] + "\n" + ">" + faTwo.Name + "\n" + v[1] + "\n")
     return out
+
+
+def faChunkAlign(inFile, chunkSize, gapOpen, gapExtend, outFile, all_seq_affine_chunk=None):
+    """multi-fasta in -> align.AllSeqAffineChunk(HumanChimpTwoScoreMatrix) -> multi-fasta out (the command negates its -gapOpen /
+    -gapExtend flags before this call: pass the negative penalties)"""
+    fn = all_seq_affine_chunk or align.AllSeqAffineChunk
+    records = fasta.Read(inFile)
+    records = fn(records, align.HumanChimpTwoScoreMatrix, gapOpen, gapExtend, chunkSize)
+    fasta.Write(outFile, records)
+    return records
 
 
 def GlobalAlignment_CigarToBed(inputFileOne, inputFileTwo, outFa, outIns_bed, outDel_bed, FirstPos_InsBed, FirstPos_DelBed, Chrom, affine_gap=None):

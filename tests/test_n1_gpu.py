@@ -99,3 +99,13 @@ def test_n1_errors(gpu_lib):
         align.multipleAffineGapBatch([gap, gap], [(0, 1)], align.DefaultScoreMatrix, -400, -30)
     with pytest.raises(IndexError):  # lower-case bases index past the matrix in the pairwise chunk variant
         align.AffineGapChunk(dna.StringToBases("ACgT"), dna.StringToBases("ACGT"), align.DefaultScoreMatrix, -400, -30, 2)
+
+
+def test_fa_chunk_align_command(gpu_lib, tmp_path):  # cmd/faChunkAlign/faChunkAlign.go:18-29: read multi-fasta, AllSeqAffineChunk(HumanChimpTwo), write
+    from gonomics_amd import cmds
+    out = str(tmp_path / "aligned.fa")
+    records = fasta.Read(os.path.join(D, "multiAlignTest.in.fa"))
+    got = cmds.faChunkAlign(os.path.join(D, "multiAlignTest.in.fa"), 2, -300, -40, out)
+    exp = align.AllSeqAffineChunk(records, align.HumanChimpTwoScoreMatrix, -300, -40, 2)
+    assert fasta.AllAreEqualIgnoreOrder(got, exp) and fasta.AllAreEqualIgnoreOrder(fasta.Read(out), exp)
+    assert len({len(r.Seq) for r in got}) == 1  # an alignment: equal lengths
