@@ -69,8 +69,7 @@ def main():
                 big = max(r["grid"] for r in rows)  # the sweep / full fill is the largest launch of its kind
                 sel = [r for r in rows if r["grid"] == big]
                 # the counter comes back per XCD / dimension instance: one launch = the sum over the rows of one dispatch
-                n_launch = max(1, len(set(r["ms"] for r in sel)))
-                tot[c] = sum(r["value"] for r in sel) / n_launch
+                tot[c] = sum(r["value"] for r in sel) / len(sel)  # one row per launch (the sizing call and the timed step): their mean
                 tot["kernel"] = sel[0]["kernel"]
         if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
             hbm = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
@@ -79,12 +78,14 @@ def main():
             if sqstem:
                 sq, kms = {}, {}
                 for d in glob.glob(os.path.join(src, sqstem + "*")):
-                    for r in pmc_rows(d):
-                        if re.search(kre, r["kernel"]):
+                    rows = [r for r in pmc_rows(d) if re.search(kre, r["kernel"])]
+                    big = max([r["grid"] for r in rows] or [0])
+                    for r in rows:
+                        if r["grid"] == big:
                             sq.setdefault(r["counter"], []).append(r["value"])
                             kms.setdefault(r["counter"], []).append(r["ms"])
                 if sq:
-                    val = {k: sum(v) for k, v in sq.items()}  # summed over the instances of the one launch
+                    val = {k: sum(v) / len(v) for k, v in sq.items()}  # one row per launch and pass: the mean
                     for k in sorted(val):
                         sq_lines.append("%s,%s,%s,%f\n" % (series, tot["kernel"], k, val[k]))
                     if "SQ_INSTS_VALU" in val:
@@ -104,8 +105,8 @@ def main():
             wr.writerow([r["series"], r["path"], r["kernel"], r["grid"], r["counter"], r["value"]])
     if sq_lines:
         with open(os.path.join(prof, rnd + "_pmc_sq.csv"), "w") as out:
-            out.write("# rocprofv3 --pmc <SQ counters> passes (bench.py --steps 1 --warmup 0; affine: --pairs 32768, long: --pairs 1024), summed over the\n"
-                      "# counter instances of the one launch; SQ_*_CYCLES / WAIT / ACTIVE are in quad-cycles\nseries,kernel,counter,value\n")
+            out.write("# rocprofv3 --pmc <SQ counters> passes (bench.py --steps 1 --warmup 0; affine: --pairs 32768, long: --pairs 1024), mean over the\n"
+                      "# launches of the kernel; SQ_*_CYCLES / WAIT / ACTIVE are in quad-cycles\nseries,kernel,counter,value\n")
             out.writelines(sq_lines)
     with open(os.path.join(prof, rnd + "_hbm_traffic.json"), "w") as fh:
         json.dump(traffic, fh, indent=1)
