@@ -20,43 +20,51 @@ template <bool S16>
 __global__ __launch_bounds__(256) void score_matrix_kernel(const ScorePair *__restrict__ sp, const uint8_t *__restrict__ bases, KParams kp, int chunk,
                                                            int groups, int bias4, int *__restrict__ smat, int *__restrict__ err) {
     // bias4 = -2 * 4 * gapExtend * chunk when the fill runs on rebased keys (fill_affine_kernel, HFORM), else 0
-    // block = 64 x 4 threads: x runs over the rows i (the fast index of the column-major matrix), y over 4 columns j;
-    // grid.x strides over the columns, grid.y = pair.  No per-cell division; the 5 x 5 table sits in LDS.
+    // block = 64 x 4 threads: x runs over GROUPS OF FOUR rows i (the fast index of the column-major matrix: one 8- / 16-byte store per
+    // thread and column instead of four 2- / 4-byte ones), y over 4 columns j; grid.x strides over the columns, grid.y = pair.
+    // No per-cell division; the 5 x 5 table sits in LDS.  (Rows nc .. of the last group of four lie inside the pitch and are never read.)
     __shared__ int sc[25];
     const int tid = threadIdx.y * 64 + threadIdx.x;
     if (tid < 25) sc[tid] = kp.sc4[tid] / 4;
     __syncthreads();
     const ScorePair q = sp[blockIdx.y];
     for (int j = blockIdx.x * 4 + threadIdx.y; j < q.mc; j += gridDim.x * 4) {
-        for (int i = threadIdx.x; i < q.nc; i += 64) {
-            int64_t total = 0;
-            for (int k = 0; k < chunk; k++) {
-                const int64_t ac = (int64_t)i * chunk + k, bc = (int64_t)j * chunk + k;
-                if (!groups) {
-                    const int a = bases[q.a_off + ac], b = bases[q.b_off + bc];
-                    if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
-                    total += sc[a * 5 + b];
-                } else {
-                    int64_t sum = 0, count = 0;
-                    for (int x = 0; x < q.a_nseq; x++) {
-                        int a = bases[q.a_off + (int64_t)x * q.a_len + ac];
-                        if (a >= 5 && a <= 9) a -= 5;
-                        for (int y = 0; y < q.b_nseq; y++) {
-                            int b = bases[q.b_off + (int64_t)y * q.b_len + bc];
-                            if (b >= 5 && b <= 9) b -= 5;
-                            if (a != 10 && b != 10) {
-                                if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
-                                sum += sc[a * 5 + b];
-                                count++;
+        for (int i0 = threadIdx.x * 4; i0 < q.nc; i0 += 256) {
+            int out[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = i0 + r;
+                int64_t total = 0;
+                for (int k = 0; i < q.nc && k < chunk; k++) {
+                    const int64_t ac = (int64_t)i * chunk + k, bc = (int64_t)j * chunk + k;
+                    if (!groups) {
+                        const int a = bases[q.a_off + ac], b = bases[q.b_off + bc];
+                        if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
+                        total += sc[a * 5 + b];
+                    } else {
+                        int64_t sum = 0, count = 0;
+                        for (int x = 0; x < q.a_nseq; x++) {
+                            int a = bases[q.a_off + (int64_t)x * q.a_len + ac];
+                            if (a >= 5 && a <= 9) a -= 5;
+                            for (int y = 0; y < q.b_nseq; y++) {
+                                int b = bases[q.b_off + (int64_t)y * q.b_len + bc];
+                                if (b >= 5 && b <= 9) b -= 5;
+                                if (a != 10 && b != 10) {
+                                    if (a >= 5 || b >= 5) { atomicOr(err, 1); continue; }
+                                    sum += sc[a * 5 + b];
+                                    count++;
+                                }
                             }
                         }
+                        if (count == 0) { atomicOr(err, 16); continue; } // Go: integer divide by zero
+                        total += sum / count;
                     }
-                    if (count == 0) { atomicOr(err, 16); continue; } // Go: integer divide by zero
-                    total += sum / count;
                 }
+                out[r] = (int)(4 * total) + bias4;
             }
-            if (S16) reinterpret_cast<short *>(smat)[q.s_off + (int64_t)j * q.s_pitch + i] = (short)(4 * total + bias4);
-            else smat[q.s_off + (int64_t)j * q.s_pitch + i] = (int)(4 * total) + bias4;
+            const int64_t at = q.s_off + (int64_t)j * q.s_pitch + i0; // multiple of 4: s_off and s_pitch are multiples of 160
+            if (S16) *reinterpret_cast<uint2 *>(reinterpret_cast<short *>(smat) + at) = make_uint2((unsigned)(out[0] & 0xffff) | ((unsigned)out[1] << 16), (unsigned)(out[2] & 0xffff) | ((unsigned)out[3] << 16));
+            else *reinterpret_cast<int4 *>(smat + at) = make_int4(out[0], out[1], out[2], out[3]);
         }
     }
 }

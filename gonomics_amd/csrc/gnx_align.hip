@@ -986,7 +986,9 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
 // N1 host flow: bases (pairwise sequences or alignment blocks) -> score matrices on the device -> SCORED fill + the
 // ordinary highMem traceback -> run lengths times chunk size.  `sp` describes the pairs (offsets into `bases`).
 int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n_pairs, std::vector<ScorePair> &sp,
-                    const uint8_t *bases, int64_t bases_len, int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off) {
+                    const uint8_t *bases, int64_t bases_len, int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off,
+                    const uint8_t *bases2 = nullptr, int64_t bases2_len = 0) {
+    // bases2: a second host buffer that follows `bases` on the device (the pairwise entry point: alpha_cat, then beta_cat -- no host copy)
     Ctx &c = g_ctx;
     if (!prm || !out_score || !out_ops || !out_ops_off || n_pairs < 0 || chunk < 1 || chunk > (1 << 20)) { set_err("bad argument%s", ""); return GNX_EINVAL; }
     if (prm->mode != GNX_AFFINE_GAP_HIGHMEM) { set_err("the chunk / multiple-alignment variants have AffineGap_highMem semantics (mode %s%lld)", "", (long long)GNX_AFFINE_GAP_HIGHMEM); return GNX_EINVAL; }
@@ -1014,7 +1016,7 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
         worst += q.nc + q.mc + 1;
         maxcols = std::max<int64_t>(maxcols, q.mc);
     }
-    if ((rc = c.in_a.ensure((size_t)bases_len + 16))) return rc;
+    if ((rc = c.in_a.ensure((size_t)(bases_len + bases2_len) + 16))) return rc;
     if ((rc = c.sc_pairs.ensure((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(ScorePair)))) return rc;
     if ((rc = c.sc_mat.ensure((size_t)std::max<int64_t>(stot, 1) * 4))) return rc;
     if ((rc = c.sc_err.ensure(16))) return rc;
@@ -1022,6 +1024,7 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     if ((rc = c.out_score.ensure(np * 8))) return rc;
     if ((rc = c.out_off.ensure((np + 1) * 8))) return rc;
     if (bases_len) HIPCHK(hipMemcpyAsync(c.in_a.p, bases, (size_t)bases_len, hipMemcpyHostToDevice, st));
+    if (bases2_len) HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(c.in_a.p) + bases_len, bases2, (size_t)bases2_len, hipMemcpyHostToDevice, st));
     if (n_pairs) HIPCHK(hipMemcpyAsync(c.sc_pairs.p, sp.data(), (size_t)n_pairs * sizeof(ScorePair), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(c.sc_err.p, 0, 16, st));
     for (int64_t b = 0; b < n_pairs; b += 32768) {
@@ -1384,9 +1387,6 @@ int gnx_affine_gap_chunk_batch(const gnx_params *p, int64_t chunk_size, int64_t 
     if (rc) return rc;
     if (n_pairs < 0 || chunk_size < 1 || (n_pairs > 0 && (!alpha_off || !beta_off))) { set_err("bad argument%s", ""); return GNX_EINVAL; }
     const int64_t la = n_pairs ? alpha_off[n_pairs] : 0, lb = n_pairs ? beta_off[n_pairs] : 0;
-    std::vector<uint8_t> bases((size_t)(la + lb + 1));
-    if (la) memcpy(bases.data(), alpha_cat, (size_t)la);
-    if (lb) memcpy(bases.data() + la, beta_cat, (size_t)lb);
     std::vector<ScorePair> sp((size_t)n_pairs);
     for (int64_t q = 0; q < n_pairs; q++) {
         const int64_t n = alpha_off[q + 1] - alpha_off[q], m = beta_off[q + 1] - beta_off[q];
@@ -1398,7 +1398,7 @@ int gnx_affine_gap_chunk_batch(const gnx_params *p, int64_t chunk_size, int64_t 
         s.a_off = alpha_off[q]; s.b_off = la + beta_off[q]; s.a_nseq = 1; s.b_nseq = 1; s.a_len = (int32_t)n; s.b_len = (int32_t)m;
         s.nc = (int32_t)(n / chunk_size); s.mc = (int32_t)(m / chunk_size); s.s_off = 0; s.s_pitch = 0;
     }
-    return run_host_scored(p, chunk_size, false, n_pairs, sp, bases.data(), la + lb, out_score, out_ops, out_ops_off);
+    return run_host_scored(p, chunk_size, false, n_pairs, sp, alpha_cat, la, out_score, out_ops, out_ops_off, beta_cat, lb);
 }
 
 int gnx_multiple_affine_gap_batch(const gnx_params *p, int64_t chunk_size, int64_t n_groups, const uint8_t *group_bases,
