@@ -1,0 +1,465 @@
+// affine_long.hip.h -- affine-gap alignments of long alpha WITHOUT a stored direction matrix: score-only sweep + snapshots, fused re-fill / walk
+// Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).  See DESIGN.md section 4.6.
+#pragma once
+#include "const_long.hip.h"
+
+namespace {
+// ------------------------------------------------------------------------------------------------------
+// The scheme of const_long.hip.h for the three-state recurrence (align/affineGap.go:151-273, affineGap_highMem.go:181-223, global
+// modes, gapOpen <= 0): reads longer than the fast path's 320 rows, 1 kb x 1 kb pairs, the 10 kb x 10 kb pair of cmd/cigarToBed.
+//   al_sweep_kernel  score only: the rebased h-form of fill_affine_kernel without tags and without the three accumulators per row
+//                    (add, max3, add, max, max = 5 VALU instructions per cell instead of 11; a lane's last row keeps its tags, 9 instructions).  Keeps the bottom row {dn, h} of every strip
+//                    (the hand-over buffer, 8 B per column) and a snapshot of the wavefront every CKA steps: rt[10], hold[10], the
+//                    diagonal value and the D value last handed to the next lane (24 dwords per lane).
+//   al_walk_kernel   one wave per 4 pairs: re-fill the tile (strip s, steps of snapshot interval c up to one step past the cell the walk
+//                    is at) with the recording recurrence into three 2-bit planes in LDS (17 KB per pair), walk inside it with the state
+//                    machine of traceback_kernel<true> (quirks Q1 / Q2), move on.  The argmax tags of h in the last column -- the
+//                    start state, and quirk Q1 when a checkerboard is left upwards in column m -- come from the re-fill itself: lanes
+//                    that have passed column m leave their keys in LDS.
+// Untagged arithmetic is exact: tag bits are junk < 4 that never changes the value of a max (score differences are multiples of 4);
+// a re-fill resumes from the snapshot's values with fresh tags.
+// ------------------------------------------------------------------------------------------------------
+constexpr int CKA = 128;                          // snapshot spacing in wavefront steps
+constexpr int AL_WORDS = CKA / 16 + 1;            // direction words per plane row of a tile (up to CKA + 4 steps: two unusable, one past the entry cell)
+constexpr int AL_SNAPW = 24;                      // dwords per lane per snapshot
+constexpr int AL_DIRG = AL_WORDS * 3 * R * G + 16; // LDS dwords of one pair's tile
+
+template <bool P16>
+__global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                      KParams kp, int2 *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
+                                                      int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
+    using PC = ProfCfg<P16>;
+    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    constexpr int TI = 2, TD = 1;
+    __shared__ int lds[32 + 4 * PST];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.e4; // rebased diagonal move: 4*(s - 2e)
+    int *prof = &lds[32 + g * PST];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    const bool piped = strip_map != nullptr;
+    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
+    int S_max = 0, m_max = 0;
+    for (int q = 0; q < 4; q++) {
+        if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
+    }
+    const int p = pbase + g;
+    const bool valid = p < n_pairs;
+    PairPlan pl;
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
+    const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    const int Tend = (m_max + 15 + 15) & ~15;
+    const int OE4 = kp.oe4, E4 = kp.e4, RB = kp.e4;
+    int vO4;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
+    int bad = 0;
+
+    const int s_lo = piped ? strip_map[blockIdx.x].y : 0, s_hi = piped ? s_lo + 1 : S_max;
+    const int64_t rb_pitch = (int64_t)pl.m + 1;
+    for (int s = s_lo; s < s_hi; s++) {
+        const bool gact = valid && s < pl.strips;
+        const int m_eff = gact ? pl.m : 0;
+        int m_min = 0x7fffffff;
+        for (int q = 0; q < 4; q++) m_min = min(m_min, (pbase + q < n_pairs && s < plans[pbase + q].strips) ? plans[pbase + q].m : 0);
+        const bool store_row = gact && (s + 1 < pl.strips);
+        const int row0 = s * H + l * R;
+        int rt[R], hold[R];
+        {
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) { // column 0 (fill_affine_kernel): M = I = -inf, D = D00 + i*ecol, rebased
+            const int i = row0 + r + 1;
+            const int D1c = kp.d00_4 + i * kp.ecol4 + TD - RB * i;
+            hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
+            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;
+        }
+        int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
+        int dn_out = 0, h_out = 0, b_out = 0, sq_dn = 0, sq_h = 0;
+        int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
+        auto boundary = [&](int c, int &odn, int &oh, int &ob) {
+            if (s == 0) {
+                const int M3 = NEG4 + 3, I2 = kp.o4 + c * E4 + TI - RB * c, D1 = NEG4 + TD; // row 0: I(0,c) = gapOpen + c*gapExtend
+                oh = max3i(M3, I2, D1);
+                odn = max3i(M3 + OE4, I2 + OE4, D1 + E4) - RB;
+            } else if (c >= 1 && c <= m_eff) {
+                const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
+                odn = v.x; oh = v.y;
+            } else { odn = 0; oh = 0; }
+            int b = 0;
+            if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            ob = b * (BST * 4);
+        };
+        int rb_seen = 0;
+        auto wait_rows = [&](int cmax) {
+            if (piped && s > 0 && rb_seen < cmax) {
+                const long long t_begin = wall_clock64();
+                while ((rb_seen = rb_progress(&strip_prog[blockIdx.x - 1])) < cmax) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; }
+                }
+            }
+        };
+        if (!piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wait_rows(G);
+        boundary(l + 1, qdn, qh, qb);
+
+        auto step = [&](const int t, auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_dn = dpp_shr1(qdn, dn_out);
+            const int up_h = dpp_shr1(qh, h_out);
+            const int pb = dpp_shr1(qb, b_out);
+            qdn = dpp_shl1(qdn, qdn);
+            qh = dpp_shl1(qh, qh);
+            qb = dpp_shl1(qb, qb);
+            const int j = t - l;
+            b_out = pb;
+            if (!CHECK || (j >= 1 && j <= m_eff)) {
+                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
+                int w[LW];
+#pragma unroll
+                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                int hd = diag0, dnu = up_dn;
+#pragma unroll
+                for (int r = 0; r < R - 1; r++) {
+                    const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                    const int hnew = max3i(hd + S4, rt[r], dnu);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, rt[r]);
+                    const int dnn = max(ho, dnu);
+                    hd = hold[r];
+                    hold[r] = hnew;
+                    dnu = dnn;
+                }
+                { // the lane's last row with argmax tags: what the last lane hands to the next strip (row buffer) must carry them -- the
+                  // planes of a strip's first row record where the values from above came from
+                    constexpr int r = R - 1;
+                    int S4;
+                    if constexpr (P16) S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff); else S4 = w[r];
+                    const int M3 = (hd | 3) + S4;
+                    const int I2 = (rt[r] & ~3) | TI;
+                    const int D1 = (dnu & ~3) | TD;
+                    const int hnew = max3i(M3, I2, D1);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, I2);
+                    dnu = max(ho, D1);
+                    hold[r] = hnew;
+                }
+                diag0 = up_h;
+                dn_out = dnu;
+                h_out = hold[R - 1];
+            }
+            sq_dn = dpp_shl1(dn_out, sq_dn);
+            sq_h = dpp_shl1(h_out, sq_h);
+        };
+
+        for (int t0 = 0; t0 < Tend; t0 += 16) {
+            if (t0 > 0 && t0 % CKA == 0 && gact && t0 <= m_eff + 15) { // snapshot: the state the wave resumes from at step t0
+                uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / CKA - 1) * pl.strips + s) * G + l) * AL_SNAPW);
+                dst[0] = make_uint4((unsigned)rt[0], (unsigned)rt[1], (unsigned)rt[2], (unsigned)rt[3]);
+                dst[1] = make_uint4((unsigned)rt[4], (unsigned)rt[5], (unsigned)rt[6], (unsigned)rt[7]);
+                dst[2] = make_uint4((unsigned)rt[8], (unsigned)rt[9], (unsigned)hold[0], (unsigned)hold[1]);
+                dst[3] = make_uint4((unsigned)hold[2], (unsigned)hold[3], (unsigned)hold[4], (unsigned)hold[5]);
+                dst[4] = make_uint4((unsigned)hold[6], (unsigned)hold[7], (unsigned)hold[8], (unsigned)hold[9]);
+                dst[5] = make_uint4((unsigned)diag0, (unsigned)dn_out, 0u, 0u);
+            }
+            wait_rows(t0 + 2 * G);
+            boundary(t0 + 16 + l + 1, ndn, nh, nb);
+            if (t0 >= 16 && t0 + 16 <= m_min) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+            }
+            qdn = ndn; qh = nh; qb = nb;
+            if (store_row) {
+                const int c = t0 + l - 14;
+                if (c >= 1 && c <= m_eff) rb_store(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_dn, sq_h, piped);
+            }
+            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[blockIdx.x], t0 + 1, lane);
+        }
+        if (gact && m_eff >= 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (hold[r] + RB * (pl.n + m_eff)) >> 2; // plain score h(n, m)
+        }
+        if (piped) rb_publish(&strip_prog[blockIdx.x], 0x7fffffff, lane);
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+template <bool P16>
+__global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                     const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                     const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                     KParams kp, TbParams tp, const int2 *__restrict__ rowbuf, const int *__restrict__ snap,
+                                                     const int *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                     const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err) {
+    using PC = ProfCfg<P16>;
+    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    constexpr int TI = 2, TD = 1;
+    __shared__ int lds[32 + 4 * PST + 4 * AL_DIRG + 4 * H];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.e4;
+    int *prof = &lds[32 + g * PST];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + 4 * PST + g * AL_DIRG]);
+    int *hcolT = &lds[32 + 4 * PST + 4 * AL_DIRG + g * H]; // keys h(i, m) of the strip's rows whose lanes have passed column m
+    const int p = blockIdx.x * 4 + g;
+    const bool valid = p < n_pairs;
+    PairPlan pl;
+    if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
+    const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
+    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    const int64_t rb_pitch = (int64_t)pl.m + 1;
+    const int po = pl.src;
+    const int OE4 = kp.oe4, E4 = kp.e4, RB = kp.e4;
+    int vO4;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
+    int bad = 0;
+    // walker state (lane 0 of the pair); pend: the state k is taken from the argmax tag of h(wi, m) once its tile is there (the start,
+    // and quirk Q1 when a checkerboard is left upwards in the last column into another strip)
+    int wi = pl.n, wj = pl.m, wk = 0, wdone = valid ? 0 : 1, pend = 1;
+    int64_t li = (pl.n > 0) ? (int64_t)(pl.n - 1) % tp.ci : 0;
+    int64_t cnt = 0, cur_run = 0;
+    int cur_op = -1, last_op = -1;
+    const int64_t sbase = valid ? scr_off[p] : 0;
+    auto flush_run = [&]() {
+        if (cur_op >= 0) {
+            gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op;
+            for (int z = 0; z < 7; z++) c._pad[z] = 0;
+            scr[sbase + cnt] = c;
+            cnt++;
+        }
+    };
+    auto emit = [&](int op, int64_t run) {
+        if (op == cur_op) cur_run += run;
+        else { flush_run(); cur_op = op; cur_run = run; }
+    };
+
+    while (true) {
+        const int src0 = lane & 48;
+        const int ci = __shfl(wi, src0, 64), cj = __shfl(wj, src0, 64), cdone = __shfl(wdone, src0, 64);
+        if (__all(cdone)) break;
+        const bool gact = !cdone;
+        const int s = gact ? (ci - 1) / H : 0;
+        const int lw = gact ? (ci - 1 - s * H) / R : 0;
+        const int te = gact ? cj + lw : 0;    // step of the cell the walk is at
+        // A snapshot carries values, no argmax tags, so the plane fields of the first two steps after it are not usable (inputs of step 1:
+        // the snapshot's keys; the diagonal input of a lane's first row at step 2: what the lane above handed over before step 1).  The
+        // tile is chosen so that the walk's cell is at least its third step, and the walk leaves it before its second.
+        const int c = (gact && te >= 3) ? (te - 3) / CKA : 0;
+        const int tbeg = c * CKA;
+        const int tmin = c > 0 ? 2 : 0;       // first usable step of the tile, minus one
+        const int tend = te + 1;              // one step further: quirk Q1 looks at the cell to the right of the one a vertical move leaves
+        const int nblk = gact ? (tend - tbeg + 15) >> 4 : 0;
+        int nblk_max = nblk;
+        nblk_max = max(nblk_max, __shfl_xor(nblk_max, 16, 64));
+        nblk_max = max(nblk_max, __shfl_xor(nblk_max, 32, 64));
+        const int m_eff = gact ? pl.m : 0;
+        const int row0 = s * H + l * R;
+        int rt[R], hold[R];
+        unsigned acc[3 * R];
+        {
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (gact && i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+            __syncthreads(); // table visible; the previous round's walk is over
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = row0 + r + 1;
+            const int D1c = kp.d00_4 + i * kp.ecol4 + TD - RB * i;
+            hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
+            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;
+            acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
+        }
+        int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
+        int dn_out = 0, h_out = 0, b_out = 0;
+        if (gact && c > 0) { // resume from the snapshot of step tbeg
+            const uint4 *sp = reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G + l) * AL_SNAPW);
+            const uint4 x0 = sp[0], x1 = sp[1], x2 = sp[2], x3 = sp[3], x4 = sp[4], x5 = sp[5];
+            rt[0] = (int)x0.x; rt[1] = (int)x0.y; rt[2] = (int)x0.z; rt[3] = (int)x0.w; rt[4] = (int)x1.x; rt[5] = (int)x1.y; rt[6] = (int)x1.z; rt[7] = (int)x1.w;
+            rt[8] = (int)x2.x; rt[9] = (int)x2.y; hold[0] = (int)x2.z; hold[1] = (int)x2.w; hold[2] = (int)x3.x; hold[3] = (int)x3.y; hold[4] = (int)x3.z; hold[5] = (int)x3.w;
+            hold[6] = (int)x4.x; hold[7] = (int)x4.y; hold[8] = (int)x4.z; hold[9] = (int)x4.w; diag0 = (int)x5.x; dn_out = (int)x5.y;
+            h_out = hold[R - 1];
+            const int jb = tbeg - l;
+            if (jb >= 1 && jb <= m_eff) { int b = bp[jb - 1]; if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
+        }
+        int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
+        auto boundary = [&](int cc, int &odn, int &oh, int &ob) {
+            if (s == 0) {
+                const int M3 = NEG4 + 3, I2 = kp.o4 + cc * E4 + TI - RB * cc, D1 = NEG4 + TD;
+                oh = max3i(M3, I2, D1);
+                odn = max3i(M3 + OE4, I2 + OE4, D1 + E4) - RB;
+            } else if (cc >= 1 && cc <= m_eff) {
+                const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
+                odn = v.x; oh = v.y;
+            } else { odn = 0; oh = 0; }
+            int b = 0;
+            if (cc >= 1 && cc <= m_eff) { b = bp[cc - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            ob = b * (BST * 4);
+        };
+        boundary(tbeg + l + 1, qdn, qh, qb);
+        auto step = [&](const int t, auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_dn = dpp_shr1(qdn, dn_out);
+            const int up_h = dpp_shr1(qh, h_out);
+            const int pb = dpp_shr1(qb, b_out);
+            qdn = dpp_shl1(qdn, qdn);
+            qh = dpp_shl1(qh, qh);
+            qb = dpp_shl1(qb, qb);
+            const int j = t - l;
+            b_out = pb;
+            if (!CHECK || (j >= 1 && j <= m_eff)) {
+                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
+                int w[LW];
+#pragma unroll
+                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                int hd = diag0, dnu = up_dn;
+#pragma unroll
+                for (int r = 0; r < R; r++) { // the recording h-form of fill_affine_kernel (rebased keys)
+                    const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                    acc[r] = alignbit2((unsigned)hd, acc[r]);
+                    acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
+                    acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
+                    const int M3 = (hd | 3) + S4;
+                    const int I2 = (rt[r] & ~3) | TI;
+                    const int D1 = (dnu & ~3) | TD;
+                    const int hnew = max3i(M3, I2, D1);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, I2);
+                    const int dnn = max(ho, D1);
+                    hd = hold[r];
+                    hold[r] = hnew;
+                    dnu = dnn;
+                }
+                diag0 = up_h;
+                dn_out = dnu;
+                h_out = hold[R - 1];
+            }
+        };
+        for (int b = 0; b < nblk_max; b++) {
+            const int t0 = tbeg + 16 * b; // per pair
+            boundary(t0 + 16 + l + 1, ndn, nh, nb);
+            if (__all(!gact || b >= nblk || (t0 >= 16 && t0 + 16 <= m_eff))) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+            }
+            qdn = ndn; qh = nh; qb = nb;
+            if (gact && b < nblk) {
+                const int miss = (t0 + 16 - l) - m_eff;
+                const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) dirg[((b * 3 + k) * R + r) * G + l] = acc[k * R + r] >> sh;
+                }
+                // after the pair's own last block: lanes that have passed column m hold h(i, m) of their rows (blocks that only other
+                // pairs of the wave still need run unchecked and may spoil the state afterwards)
+                if (b == nblk - 1 && t0 + 16 - l >= m_eff) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) hcolT[l * R + r] = hold[r];
+                }
+            }
+        }
+        __syncthreads();
+        if (l == 0 && gact) {
+            int i = wi, j = wj, k = wk;
+            if (pend) { k = 3 - (hcolT[i - 1 - s * H] & 3); pend = 0; } // (the tile of (i, m) has just been filled: its lane has passed m)
+            while (true) {
+                if (i == 0 || j == 0) { wdone = 1; break; }
+                const int i0 = i - 1 - s * H;
+                if (i0 < 0) break; // left the strip through its top edge
+                const int l2 = i0 / R, r2 = i0 - l2 * R;
+                const int t1 = j + l2 - 1 - tbeg;
+                if (t1 < tmin) break; // left the (usable part of the) tile through its skewed left edge
+                const int pos = t1 & 15;
+                const unsigned w = dirg[(((t1 >> 4) * 3 + k) * R + r2) * G + l2];
+                int tag = (int)((w >> (2 * pos)) & 3u);
+                if (tag == 0) { atomicOr(err, 2); wdone = 1; break; }
+                if (k == 1) { // horizontal run inside this word, see traceback_kernel
+                    int avail = min(pos + 1, j);
+                    if (t1 < 16) avail = min(avail, pos - tmin + 1); // the tile's first word: its first `tmin` fields are not usable
+                    unsigned x = w ^ 0xAAAAAAAAu;
+                    if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
+                    const int lowcut = pos + 1 - avail;
+                    if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+                    int steps;
+                    if (x == 0) steps = avail;
+                    else {
+                        const int pnz = (31 - __clz((int)x)) >> 1;
+                        tag = (int)((w >> (2 * pnz)) & 3u);
+                        if (tag == 0) { atomicOr(err, 2); wdone = 1; break; }
+                        steps = pos - pnz + 1;
+                        k = 3 - tag;
+                    }
+                    emit(1, steps); j -= steps; last_op = 1;
+                    continue;
+                }
+                emit(k, 1);
+                last_op = k;
+                const bool up_exit = (li == 0);
+                li = up_exit ? tp.ci - 1 : li - 1;
+                i--;
+                if (k == 0) j--;
+                k = 3 - tag;
+                if (up_exit && i > 0 && j > 0) { // quirk Q1 (affineGap.go:305): restart in the argmax state of the entry cell (i, j)
+                    if (j < pl.m) { // = the M-plane field of (i+1, j+1): the row the walk just left, at most one step past its cell
+                        const int l3 = (i0) / R, r3 = i0 - l3 * R, t3 = (j + 1) + l3 - 1 - tbeg;
+                        const unsigned w3 = dirg[(((t3 >> 4) * 3 + 0) * R + r3) * G + l3];
+                        k = 3 - (int)((w3 >> (2 * (t3 & 15))) & 3u);
+                    } else if (i - 1 - s * H >= 0 && pl.m + (i - 1 - s * H) / R - 1 - tbeg >= tmin) k = 3 - (hcolT[i - 1 - s * H] & 3);
+                    else pend = 1; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                }
+            }
+            wi = i; wj = j; wk = k;
+        }
+    }
+    if (l == 0 && valid) {
+        // Step 4 (affineGap.go:135-139) -- quirk Q2 when the corner is not the origin
+        const bool up_exit = (last_op != 1) && ((int64_t)wi % tp.ci == 0);
+        const bool left_exit = (last_op != 2) && ((int64_t)wj % tp.cj == 0);
+        if (!up_exit && left_exit) emit(2, wi);
+        else if (up_exit && !left_exit) emit(1, wj);
+        flush_run();
+        nops[po] = cnt;
+        score_out[po] = (int64_t)hfin[pl.hcol_off];
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+} // namespace

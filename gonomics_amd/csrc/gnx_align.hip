@@ -36,6 +36,7 @@
 #include "fp_walk.hip.h"
 #include "aux_kernels.hip.h"
 #include "const_long.hip.h"
+#include "affine_long.hip.h"
 #include "seed_kernels.hip.h"
 
 namespace {
@@ -475,10 +476,10 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     return GNX_OK;
 }
 
-// Constant-gap pairs without a stored direction matrix (const_long.hip.h): score-only sweep that keeps the strips' bottom rows and a
-// snapshot of the wavefront every CKC steps, then one fused re-fill + walk kernel.  Every n, m >= 1 (validated by the caller).
+// Pairs without a stored direction matrix (const_long.hip.h; affine: affine_long.hip.h): score-only sweep that keeps the strips' bottom
+// rows and a snapshot of the wavefront every CKC / CKA steps, then one fused re-fill + walk kernel.  Every n, m >= 1 (validated by the caller).
 // Returns GNX_OK, an error, or -1 when the batch should take the general path (a single pair exceeds the workspace).
-int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &tp, int64_t n_pairs,
+int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &tp, bool affine, int64_t n_pairs,
                      const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                      const int64_t *h_alen, const int64_t *h_blen,
                      int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream) {
@@ -491,11 +492,12 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     {
         int64_t rb = 0, sn = 0, sc = 0;
         const int64_t budget = c.ws_limit - c.ws_limit / 16;
-        auto bytes_of = [](int64_t rb2, int64_t sn2, int64_t sc2) { return 4 * rb2 + 4 * sn2 + (int64_t)sizeof(gnx_cigar) * sc2; };
+        const int64_t rbw = affine ? 8 : 4, ck = affine ? CKA : CKC, snw = affine ? AL_SNAPW : SNAPW; // row-buffer entry bytes, snapshot spacing / dwords
+        auto bytes_of = [&](int64_t rb2, int64_t sn2, int64_t sc2) { return rbw * rb2 + 4 * sn2 + (int64_t)sizeof(gnx_cigar) * sc2; };
         for (int64_t p = 0; p < n_pairs; p++) {
             const int64_t n = h_alen[p], m = h_blen[p];
-            const int64_t strips = (n + H - 1) / H, ncp = (m + 15) / CKC;
-            const int64_t prb = (strips - 1) * (m + 1), psn = ncp * strips * G * SNAPW, psc = n + m + 2;
+            const int64_t strips = (n + H - 1) / H, ncp = (m + 15) / ck;
+            const int64_t prb = (strips - 1) * (m + 1), psn = ncp * strips * G * snw, psc = n + m + 2;
             if (bytes_of(prb, psn, psc) > budget) return -1;
             if (bytes_of(rb + prb, sn + psn, sc + psc) > budget) { // new chunk, 4-aligned so that waves stay whole
                 int64_t cb = p & ~(int64_t)3;
@@ -504,7 +506,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
                 for (int64_t q2 = cb; q2 < p; q2++) {
                     PairPlan &pq = plans[(size_t)q2];
                     pq.rowbuf_off = rb; pq.ckpt_off = sn; so[(size_t)q2] = sc; pq.hcol_off = q2 - cb; pq.src = (int32_t)(q2 - cb);
-                    rb += (int64_t)(pq.strips - 1) * (pq.m + 1); sn += (int64_t)((pq.m + 15) / CKC) * pq.strips * G * SNAPW; sc += (int64_t)pq.n + pq.m + 2;
+                    rb += (int64_t)(pq.strips - 1) * (pq.m + 1); sn += (int64_t)((pq.m + 15) / ck) * pq.strips * G * snw; sc += (int64_t)pq.n + pq.m + 2;
                 }
                 chunk_begin.push_back(cb);
             }
@@ -521,7 +523,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     }
     int64_t max_np = 1;
     for (size_t ch = 0; ch + 1 < chunk_begin.size(); ch++) max_np = std::max(max_np, chunk_begin[ch + 1] - chunk_begin[ch]);
-    if ((rc = c.rowbuf.ensure((size_t)max_rb * 4))) return rc;
+    if ((rc = c.rowbuf.ensure((size_t)max_rb * (affine ? 8 : 4)))) return rc;
     if ((rc = c.fp_ckpt.ensure((size_t)max_sn * 4))) return rc;
     if ((rc = c.tb_scr.ensure((size_t)max_sc * sizeof(gnx_cigar)))) return rc;
     if ((rc = c.tb_scr_off.ensure(((size_t)n_pairs + 1) * 8))) return rc;
@@ -538,7 +540,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     HIPCHK(hipStreamSynchronize(stream)); // plans / so are locals
     // int16 profile when every entry 4*(s - 2g) + 1 fits (half the LDS reads per step); GNX_CL_P16=0/1 overrides for A/B runs
     bool p16 = true;
-    for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * prm->gap_open) + 1; if (v > 32767 || v < -32768) p16 = false; }
+    for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * (affine ? prm->gap_extend : prm->gap_open)) + 1; if (v > 32767 || v < -32768) p16 = false; }
     if (getenv("GNX_CL_P16")) p16 = p16 && atoi(getenv("GNX_CL_P16")) != 0;
     double fill_ms = 0, tb_ms = 0;
     int64_t trace_bytes = 0;
@@ -577,12 +579,17 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             HIPCHK(hipStreamSynchronize(stream)); // smap is a local
         }
         HIPCHK(hipEventRecord(c.ev[1], stream));
-        if (p16) hipLaunchKernelGGL(cl_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
+        if (affine && p16) hipLaunchKernelGGL(al_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
+        else if (affine) hipLaunchKernelGGL(al_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
+        else if (p16) hipLaunchKernelGGL(cl_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
         else hipLaunchKernelGGL(cl_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
         const dim3 gridW((unsigned)((np + 3) / 4));
-        if (p16) hipLaunchKernelGGL(cl_walk_kernel<true>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
+        if (affine && p16) hipLaunchKernelGGL(al_walk_kernel<true>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
+        else if (affine) hipLaunchKernelGGL(al_walk_kernel<false>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
+        else if (p16) hipLaunchKernelGGL(cl_walk_kernel<true>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
         else hipLaunchKernelGGL(cl_walk_kernel<false>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
         HIPCHK(hipGetLastError());
         if ((rc = launch_scan(dn, np, d_ops_off + b, d_carry, stream))) return rc;
@@ -596,7 +603,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         fill_ms += f1; tb_ms += f2;
         for (int64_t p = b; p < e; p++) {
             const PairPlan &pl = plans[(size_t)p];
-            trace_bytes += 4 * ((int64_t)(pl.strips - 1) * (pl.m + 1) + (int64_t)((pl.m + 15) / CKC) * pl.strips * G * SNAPW);
+            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + 15) / (affine ? CKA : CKC)) * pl.strips * G * (affine ? AL_SNAPW : SNAPW);
         }
     }
     HIPCHK(hipEventRecord(c.ev[2], stream));
@@ -617,7 +624,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         if (t_no_pipe) { set_err("a strip waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
         if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx] a pipelined strip timed out: the call runs again with sequential strips\n");
         t_no_pipe = true;
-        rc = run_device_clong(prm, kp, tp, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+        rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
         t_no_pipe = false;
         return rc;
     }
@@ -723,7 +730,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         }
     }
     // ---- constant gap without a stored direction matrix (const_long.hip.h): pairs of more than one strip; GNX_CLONG=0 / 2 = never / always ----
-    if (!affine && !gsw && !d_smat) {
+    if (!gsw && !d_smat && !local && (!affine || (prm->gap_open <= 0 && !getenv("GNX_NO_HFORM")))) { // (GNX_CLONG also governs the affine form, affine_long.hip.h)
         const char *cl = getenv("GNX_CLONG");
         bool use = !(cl && cl[0] == '0'), any_multi = false;
         long double cells_ld = 0, dir_bytes = 0;
@@ -731,14 +738,20 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             if (h_alen[p] < 1 || h_blen[p] < 1) use = false;
             if (h_alen[p] > H) any_multi = true;
             cells_ld += (long double)h_alen[p] * h_blen[p];
-            dir_bytes += (long double)((h_alen[p] + H - 1) / H) * ((h_blen[p] + 30) / 16) * QC * G * 16;
+            dir_bytes += (long double)((h_alen[p] + H - 1) / H) * ((h_blen[p] + 30) / 16) * (affine ? QA : QC) * G * 16;
         }
         // It pays when the pairs are big: the sweep saves ~1.3e-13 s per cell against the recording fill, the fused re-fill + walk
         // costs ~0.3 us per pair more than the one-lane-per-pair traceback over a stored matrix (tools/bench_shapes.py: 250..3200 x
         // 10 000 gain 15..45 %, 100 000 pairs of 1000 x 1200 lose 2x) -- or when the stored matrix would not fit the workspace at all.
-        const bool big = cells_ld >= 2.0e6L * (long double)n_pairs || dir_bytes > (long double)c.ws_limit;
+        // Affine (affine_long.hip.h): a global alignment against a long window crosses every column tile, so the re-fill costs about
+        // 1 / strips of a full fill at the walk kernel's low occupancy: it pays from ~10 strips on, for batches (1600 x 10 000: +21 %,
+        // 3200 x 10 000: +46 %; 480 / 800 x 10 000 and a single 10 kb x 10 kb pair are faster over the stored matrix).
+        long double rows_ld = 0;
+        for (int64_t p = 0; p < n_pairs; p++) rows_ld += (long double)h_alen[p];
+        const bool big = (cells_ld >= 2.0e6L * (long double)n_pairs && (!affine || (rows_ld >= 1600.0L * (long double)n_pairs && n_pairs >= 256))) ||
+                         dir_bytes > (long double)c.ws_limit;
         if (use && ((any_multi && big) || (cl && cl[0] == '2'))) {
-            rc = run_device_clong(prm, kp, tp, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+            rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
             if (rc != -1) return rc;
         }
     }

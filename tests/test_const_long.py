@@ -159,3 +159,53 @@ def test_c5_full_size(gpu_lib):
             ri2, rj2, total2 = rescore_const(reads[x], wins[x][m - rj:], o, sc, g)
             assert total2 + g * (m - rj) == int(score[x])
     assert q2 >= 1
+
+
+@pytest.mark.parametrize("cs", [2, 7, 16, 300, 10000])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_affine_long_fuzz(gpu_lib, monkeypatch, mode, cs):
+    """the same scheme for the three-state recurrence (csrc/affine_long.hip.h): AffineGap with checkerboards of every size (quirks Q1 / Q2,
+    also across strip borders and in the last column) and AffineGap_highMem, ragged batches, several strips and snapshot intervals"""
+    monkeypatch.setenv("GNX_CLONG", "2")
+    for seed, nmax, mmax, count in ((31, 40, 60, 96), (32, 700, 700, 48), (33, 400, 1300, 24)):
+        alphas, betas = _ragged(seed + 100 * cs, count, nmax, mmax)
+        for name, go, ge in (("Default", -400, -30), ("HumanChimpTwo", -600, -150), ("HoxD55", 0, -40)):
+            p = gpu_lib.make_params(mode, MX[name], go, ge, cs, cs)
+            got = gpu_lib.align_batch(p, alphas, betas)
+            assert gpu_lib.get_timing()["fast_path"] == 2
+            exp = oracle.align_batch(mode, MX[name], go, ge, alphas, betas, cs, cs, threads=8)
+            common.assert_same(got, exp, "seed %d %s" % (seed, name))
+
+
+def test_affine_long_big_pairs(gpu_lib, monkeypatch):
+    """reads longer than the fast path's 320 rows against a 10 kb window and one 10 kb x 10 kb pair (cmd/cigarToBed's shape), pipelined
+    strips -- forced (few pairs are faster over the stored matrix); and the natural route: a workspace the stored matrices do not fit"""
+    rng = np.random.default_rng(77)
+    win = rng.integers(0, 4, size=10000).astype(np.uint8)
+    alphas, betas = [], []
+    for n in (400, 900, 1700, 2500):
+        o = int(rng.integers(0, 10000 - n - 50))
+        alphas.append(common.mutate(rng, win[o:o + n + 40], sub=0.02, indel=0.01, geo=0.5)[:n]); betas.append(win)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+    exp = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, alphas, betas, threads=4)
+    a = rng.integers(0, 4, size=9700).astype(np.uint8)
+    b = common.mutate(rng, a, 0.01, 0.003)[:10000]
+    exp1 = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, [a], [b])
+    monkeypatch.setenv("GNX_CLONG", "2")
+    got = gpu_lib.align_batch(p, alphas, betas)
+    assert gpu_lib.get_timing()["fast_path"] == 2
+    common.assert_same(got, exp)
+    got = gpu_lib.align_batch(p, [a], [b])
+    assert gpu_lib.get_timing()["fast_path"] == 2
+    common.assert_same(got, exp1)
+    monkeypatch.delenv("GNX_CLONG")
+    got = gpu_lib.align_batch(p, [a], [b])
+    assert gpu_lib.get_timing()["fast_path"] == 0  # one pair: the stored matrix (73 MB) and the wave-cooperative walk
+    common.assert_same(got, exp1)
+    gpu_lib.check(gpu_lib.lib().gnx_init(0, 32 << 20))
+    try:
+        got = gpu_lib.align_batch(p, [a], [b])
+        assert gpu_lib.get_timing()["fast_path"] == 2  # ... unless it does not fit the workspace
+    finally:
+        gpu_lib.check(gpu_lib.lib().gnx_init(0, 8 << 30))
+    common.assert_same(got, exp1)

@@ -217,8 +217,10 @@ def test_errors(gpu_lib):
     assert align.PrintCigar(r) == "4M"
 
 
-def test_workspace_chunking(gpu_lib):
-    """A small workspace limit forces several fill launches; results must not change."""
+def test_workspace_chunking(gpu_lib, monkeypatch):
+    """A small workspace limit forces several fill launches of the general path; results must not change.  (GNX_CLONG=0: without the
+    switch a batch whose stored matrices do not fit goes to the snapshot path, tests/test_const_long.py)"""
+    monkeypatch.setenv("GNX_CLONG", "0")
     alphas, betas = common.random_pairs(77, 600, 20, 200, 20, 300)
     exp = oracle.align_batch(0, MX["Default"], -400, -30, alphas, betas, threads=8)
     gpu_lib.check(gpu_lib.lib().gnx_init(0, 4 << 20))
