@@ -6,6 +6,8 @@ tag=${1:-r2}
 repo=$PWD
 out=$repo/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
+python -c 'import bench; print(bench.kernel_source_hash())' > $out/kernel_source_hash.txt   # what the counters below are taken from
+echo "${GNX_COMMIT:-unknown}" > $out/commit.txt                                            # (the box has no .git: pass GNX_COMMIT=$(git rev-parse --short HEAD))
 timeout 1500 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest_gpu.log
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > $out/smoke.log 2>&1
 timeout 900 python bench.py > $out/bench.json 2> $out/bench.err
@@ -33,5 +35,6 @@ timeout 600 python tools/bench_host.py 100000 1000000 > $out/host_entry.jsonl 2>
 timeout 600 python tools/bench_shapes.py affine > $out/shapes_affine.jsonl 2>> $out/bench.err
 timeout 600 python tools/bench_shapes.py const > $out/shapes_const.jsonl 2>> $out/bench.err
 timeout 600 python tools/bench_gsw.py > $out/gsw_reads.jsonl 2>> $out/bench.err
+g++ -std=c++17 -O2 -Iinclude -o tools/bench_cabi.bin tools/bench_cabi.cpp gonomics_amd/libgonomics_align_hip.so -Wl,-rpath,$PWD/gonomics_amd -L/opt/rocm/lib -lamdhip64 2>> $out/bench.err && tools/bench_cabi.bin > $out/cabi_n1_n2.jsonl 2>> $out/bench.err
 find $out -name '*.db' -size +20M -delete
 tail -3 $out/pytest_gpu.log; tail -1 $out/smoke.log; cat $out/bench.json | cut -c1-400; cat $out/bench_long.json | cut -c1-400
