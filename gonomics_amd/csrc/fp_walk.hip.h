@@ -267,4 +267,21 @@ __global__ __launch_bounds__(256) void fp_redo_scatter_kernel(const int *__restr
     for (int64_t x = threadIdx.x; x < len; x += blockDim.x) ops[base + x] = sub_ops[sub_off[k] + x];
 }
 
+// A batch that mixes reads of <= 160 and of 161 .. 320 bases is aligned as two uniform sub-batches (each on its fast path) whose
+// results are put back in input order: run counts and scores first, the runs after the scan of the counts.
+__global__ __launch_bounds__(256) void mix_counts_kernel(const int *__restrict__ idx, int n, const int64_t *__restrict__ sub_off, const int64_t *__restrict__ sub_score,
+                                                         int64_t *__restrict__ cnt, int64_t *__restrict__ score) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { const int p = idx[k]; cnt[p] = sub_off[k + 1] - sub_off[k]; score[p] = sub_score[k]; }
+}
+__global__ __launch_bounds__(256) void mix_copy_kernel(const int *__restrict__ idx, int n, const int64_t *__restrict__ sub_off, const gnx_cigar *__restrict__ sub_ops,
+                                                       const int64_t *__restrict__ ops_off, gnx_cigar *__restrict__ ops, int64_t ops_capacity, int *__restrict__ err) {
+    const int k = blockIdx.x; // one block per pair
+    if (k >= n) return;
+    const int p = idx[k];
+    const int64_t len = sub_off[k + 1] - sub_off[k], base = ops_off[p];
+    if (base + len > ops_capacity) { if (threadIdx.x == 0) atomicOr(err, 4); return; }
+    for (int64_t x = threadIdx.x; x < len; x += blockDim.x) ops[base + x] = sub_ops[sub_off[k] + x];
+}
+
 } // namespace

@@ -101,7 +101,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr, s_in = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo, fp_wrow;
+    DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo, fp_wrow, mx_idx, mx_tab, mx_score, mx_off, mx_ops[2];
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     // pipelined host entry (gnx_host.hip.h): double-buffered inputs, results accumulated on the device, the resident reference
     DevBuf pin_a[2], pin_as[2], pin_b[2], pin_bs[2], res_score, res_off, res_ops, ref, gat_score, gat_off, gat_ops;
@@ -689,9 +689,64 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             else if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) fp = false;
             n_hi = std::max(n_hi, n); n_lo = std::min(n_lo, n);
         }
-        // reads of 161 .. 320 bases: two row blocks (global AffineGap only; a batch that mixes them with shorter reads takes the general path)
+        // reads of 161 .. 320 bases: two row blocks (global AffineGap only)
         const bool two = n_hi > H;
-        if (two && (xp || n_lo <= H)) fp = false;
+        if (two && xp) fp = false;
+        if (fp && two && n_lo <= H) {
+            // ... mixed with shorter reads: two uniform sub-batches, each on its fast path, merged back into input order
+            std::vector<int> idx[2];
+            std::vector<int64_t> hal[2], hbl[2];
+            for (int64_t p = 0; p < n_pairs; p++) { const int gq = h_alen[p] > H ? 1 : 0; idx[gq].push_back((int)p); hal[gq].push_back(h_alen[p]); hbl[gq].push_back(h_blen[p]); }
+            if ((rc = c.mx_idx.ensure((size_t)n_pairs * 4))) return rc;
+            if ((rc = c.mx_tab.ensure((size_t)n_pairs * 16))) return rc;
+            if ((rc = c.mx_score.ensure((size_t)n_pairs * 8))) return rc;
+            if ((rc = c.mx_off.ensure((size_t)(n_pairs + 2) * 8))) return rc;
+            if ((rc = c.nops.ensure((size_t)n_pairs * 8))) return rc;
+            if ((rc = c.misc.ensure(64))) return rc;
+            int *d_idx = reinterpret_cast<int *>(c.mx_idx.p);
+            const int n0 = (int)idx[0].size(), n1 = (int)idx[1].size();
+            HIPCHK(hipMemcpyAsync(d_idx, idx[0].data(), (size_t)n0 * 4, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_idx + n0, idx[1].data(), (size_t)n1 * 4, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            gnx_timing tsum = {};
+            int64_t tot[2] = {0, 0};
+            bool capfail = false;
+            for (int gq = 0; gq < 2; gq++) {
+                const int ng = gq ? n1 : n0, *gi = d_idx + (gq ? n0 : 0);
+                int64_t *gas = reinterpret_cast<int64_t *>(c.mx_tab.p) + (gq ? 2 * (int64_t)n0 : 0), *gbs = gas + ng;
+                int64_t *gsc = reinterpret_cast<int64_t *>(c.mx_score.p) + (gq ? n0 : 0), *goff = reinterpret_cast<int64_t *>(c.mx_off.p) + (gq ? n0 + 1 : 0);
+                if ((rc = c.mx_ops[gq].ensure((size_t)std::max<int64_t>(ops_capacity, 1) * sizeof(gnx_cigar)))) return rc;
+                hipLaunchKernelGGL(fp_redo_gather_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream, gi, ng, d_as, d_bs, gas, gbs);
+                HIPCHK(hipGetLastError());
+                rc = run_device(prm, ng, d_a, gas, d_b, gbs, hal[gq].data(), hbl[gq].data(), gsc, reinterpret_cast<gnx_cigar *>(c.mx_ops[gq].p), ops_capacity, goff, &tot[gq], stream);
+                if (rc == GNX_ECAPACITY) capfail = true;
+                else if (rc) return rc;
+                tsum.fill_ms += c.timing.fill_ms; tsum.traceback_ms += c.timing.traceback_ms; tsum.total_ms += c.timing.total_ms; tsum.cells += c.timing.cells;
+                tsum.n_launches += c.timing.n_launches; tsum.trace_bytes += c.timing.trace_bytes; tsum.dominant_ms += c.timing.dominant_ms;
+                tsum.dominant_launches += c.timing.dominant_launches; tsum.fast_path = c.timing.fast_path;
+            }
+            c.timing = tsum;
+            if (out_total) *out_total = tot[0] + tot[1];
+            if (capfail || tot[0] + tot[1] > ops_capacity) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)(tot[0] + tot[1])); return GNX_ECAPACITY; }
+            int *d_err = reinterpret_cast<int *>(c.misc.p);
+            int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
+            int64_t *d_cnt = reinterpret_cast<int64_t *>(c.nops.p);
+            HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
+            for (int gq = 0; gq < 2; gq++) {
+                const int ng = gq ? n1 : n0;
+                hipLaunchKernelGGL(mix_counts_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream, d_idx + (gq ? n0 : 0), ng,
+                                   reinterpret_cast<const int64_t *>(c.mx_off.p) + (gq ? n0 + 1 : 0), reinterpret_cast<const int64_t *>(c.mx_score.p) + (gq ? n0 : 0), d_cnt, d_score);
+            }
+            if ((rc = launch_scan(d_cnt, (int)n_pairs, d_ops_off, d_carry, stream))) return rc;
+            for (int gq = 0; gq < 2; gq++) {
+                const int ng = gq ? n1 : n0;
+                hipLaunchKernelGGL(mix_copy_kernel, dim3((unsigned)ng), dim3(256), 0, stream, d_idx + (gq ? n0 : 0), ng, reinterpret_cast<const int64_t *>(c.mx_off.p) + (gq ? n0 + 1 : 0),
+                                   reinterpret_cast<const gnx_cigar *>(c.mx_ops[gq].p), d_ops_off, d_ops, ops_capacity, d_err);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(stream));
+            return GNX_OK;
+        }
         const int rows_per_lane = (two || n_hi > 19 * G8) ? 20 : 19;
         if (fp) {
             // sub-batches whose fast-path working set (checkpoints, planes, window slots, staging) fits the workspace
@@ -1228,7 +1283,7 @@ void gnx_shutdown(void) {
         if (!c.inited) continue;
         (void)hipSetDevice(c.device);
         (void)hipDeviceSynchronize();
-        DevBuf *bufs[] = {&c.strip_map, &c.tb_scr, &c.tb_scr_off, &c.scan_tmp, &c.fp_redo, &c.fp_wrow, &c.fp_tail, &c.fp_thcol, &c.fp_ttrace, &c.fp_rowi, &c.fp_ckpt, &c.fp_states, &c.fp_stage,
+        DevBuf *bufs[] = {&c.strip_map, &c.tb_scr, &c.tb_scr_off, &c.scan_tmp, &c.fp_redo, &c.fp_wrow, &c.mx_idx, &c.mx_tab, &c.mx_score, &c.mx_off, &c.mx_ops[0], &c.mx_ops[1], &c.fp_tail, &c.fp_thcol, &c.fp_ttrace, &c.fp_rowi, &c.fp_ckpt, &c.fp_states, &c.fp_stage,
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,

@@ -567,3 +567,25 @@ def test_fast_path_two_row_blocks(gpu_lib, seed, monkeypatch):
     assert gpu_lib.get_timing()["fast_path"] == 1
     exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len, threads=8)
     common.assert_same(got, exp, "250-base reads")
+
+
+@pytest.mark.gpu
+def test_fast_path_mixed_read_lengths(gpu_lib, monkeypatch):
+    """a batch that mixes reads of <= 160 and of 161 .. 320 bases: two uniform sub-batches, each on its fast path, merged back into
+    input order (run_device, the block under 'mixed with shorter reads')"""
+    rng = np.random.default_rng(77)
+    reads, chunk = common.c2_workload(77, 900, read_len=320, chunk_len=4000)
+    lens = rng.choice([36, 100, 150, 160, 161, 200, 250, 320], size=900).astype(np.int64)
+    a_start = np.arange(900, dtype=np.int64) * 320
+    b_len = rng.choice([800, 1500, 4000], size=900).astype(np.int64)
+    b_start = rng.integers(0, 4000 - b_len + 1).astype(np.int64)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+    got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, lens, chunk, b_start, b_len)
+    assert gpu_lib.get_timing()["fast_path"] == 1
+    exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads.reshape(-1), a_start, lens, chunk, b_start, b_len, threads=8)
+    common.assert_same(got, exp, "mixed read lengths")
+    # every read in one group: still the uniform paths
+    for sel in (lens <= 160, lens > 160):
+        got1 = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start[sel], lens[sel], chunk, b_start[sel], b_len[sel])
+        exp1 = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads.reshape(-1), a_start[sel], lens[sel], chunk, b_start[sel], b_len[sel], threads=8)
+        common.assert_same(got1, exp1, "uniform sub-batch")
