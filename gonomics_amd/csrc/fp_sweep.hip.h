@@ -60,20 +60,34 @@ __device__ __forceinline__ int dpp_next8(int src) { // every lane of the two ban
 //       smallest that holds the longest read of the batch); instead of planes / h(n,m) it hands its bottom row down:
 //       rowbuf[rowbuf_off + j] = {D'(n-159, j), h'(n-160, j)}, the two values a next lane would get by DPP (rebased like everything);
 //   2 = the BOTTOM block: rows n - 159 .. n (no padding); its first lane takes the row above it from that buffer instead of the
-//       row-0 constants, eight columns prefetched per half block.  Checkpoints of both blocks are indexed by the row of the pair.
+//       row-0 constants: the pair's lanes load the 8 columns of the next half block with one 64-byte request and pass them to the
+//       first lane through a DPP queue, one per step.  Checkpoints of all blocks are indexed by the row of the pair.
+//   3 = a MIDDLE block (reads of more than 320 bases, pl.strips >= 3): 160 rows with `below` blocks under it; takes the row above
+//       like the bottom block and hands its own bottom row down like the top block, IN PLACE in the same row buffer (its first
+//       lane reads column t -- loaded at most 16 columns ahead -- while its last lane hands down the columns up to t - 7).
+//   Blocks that hand their bottom row down stage it in LDS and store 8 columns per half block (64 bytes per pair): per-step 8-byte
+//   stores / loads of the hand-over cost 30 % of the sweep when they are agent-scope (uncached) operations.
 //   0 = the whole read in one block (n <= 8 * RR).
-template <int RR, bool XP = false, int ROLE = 0>
-__global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
-                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
-                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                                      KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
-                                                      unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err,
-                                                      int2 *__restrict__ rowbuf = nullptr) {
+// `below` = row blocks of the pair under this one (top block: pl.strips - 1).  Blocks that hand their bottom row down keep no
+// planes, so none of their rows pays the tag arithmetic.
+// wblk = the wave's index among the waves of its row block (8 pairs each).  piped: the row blocks of a batch run as ONE launch
+// (fp_sweep_levels_kernel), a block following the one above it through the row buffer as that one publishes its progress
+// (prog_out / prog_in: the last step whose hand-over stores are out, INT_MAX at the end; rows and progress word are agent-scope
+// atomics like the general path's strips, see rb_store).
+template <int RR, bool XP, int ROLE>
+__device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int wblk, const PairPlan *__restrict__ plans, int n_pairs,
+                                              const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                              const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                              const KParams &kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
+                                              unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err,
+                                              int2 *__restrict__ rowbuf, const int below, const bool piped, const int *prog_in, int *prog_out) {
     static_assert(RR <= 2 * FP8_LW && RR > FP_PLANES, "rows per lane");
     static_assert(ROLE == 0 || !XP, "two row blocks: global alignment only");
-    static_assert(ROLE != 2 || RR == 2 * FP8_LW, "the bottom row block is full: 8 x 20 slots");
+    static_assert(ROLE < 2 || RR == 2 * FP8_LW, "the bottom and middle row blocks are full: 8 x 20 slots");
+    constexpr bool BOTTOM = (ROLE == 0 || ROLE == 2); // holds row n: planes, corner tags, h(n,m)
+    constexpr bool HANDS = (ROLE == 1 || ROLE == 3);  // hands its bottom row down through the row buffer
+    constexpr bool TAKES = (ROLE >= 2);               // takes the row above it from the row buffer
     constexpr int BOT = G8 * 2 * FP8_LW; // rows of the bottom block (the top block has the rest, in 8 x RR slots: RR as small as they fit)
-    __shared__ int lds[32 + 8 * FP8_PST];
     const int lane = threadIdx.x;
     const int g = lane >> 3;
     const int lp = (lane & 8) ? 15 - (lane & 15) : (lane & 7); // position of the lane inside its pair
@@ -84,7 +98,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     int *prof = &lds[32 + g * FP8_PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + lp * FP8_LW);
 
-    const int pbase = blockIdx.x * 8;
+    const int pbase = wblk * 8;
     int m_max = 0, m_min = 0x7fffffff;
     for (int q = 0; q < 8; q++) {
         const int mq = (pbase + q < n_pairs) ? plans[pbase + q].m : 0;
@@ -94,8 +108,8 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     const bool valid = p < n_pairs;
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
-    const int row_base = ROLE == 2 ? pl.n - BOT : 0;                          // rows of the pair above this block
-    const int n_loc = ROLE == 1 ? pl.n - BOT : (ROLE == 2 ? BOT : pl.n);      // rows in this block
+    const int row_base = TAKES ? pl.n - BOT * (below + 1) : 0;                      // rows of the pair above this block
+    const int n_loc = ROLE == 1 ? pl.n - BOT * below : (TAKES ? BOT : pl.n);        // rows in this block
     const uint8_t *ap = a_buf + (valid ? a_start[pl.src] + row_base : 0);
     const uint8_t *bp = b_buf + (valid ? b_start[pl.src] : 0);
     const int m_eff = valid ? pl.m : 0;
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     unsigned accR[FP_PLANES] = {0u, 0u, 0u, 0u}; // I-planes of rows n-d = slots RR-1-d of the last lane
     unsigned tailw = 0; // argmax tags of h(n-d, m-x), d, x = 0..3, field 4x + d: lets the walk take its first diagonal steps without a window
     int diag0 = (q0 == 0) ? ((XP || P == 0) ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + TD : ((XP || q0 - 1 == P - 1) ? 3 : kp.o4 + 2));
-    if (ROLE == 2 && q0 == 0) diag0 = kp.o4 + TD; // the slot above is row n - 160 of the pair, column 0: h' = D' = o
+    if (TAKES && q0 == 0) diag0 = kp.o4 + TD; // the slot above is a row of the pair, column 0: h' = D' = o
     int dn_out = 0, h_out = 0, b_out = 0;
     int up_dn = cDN, up_h = cH;
     auto base_of = [&](int c) { // LDS byte offset of the profile plane of beta[c] (column c, 1-based)
@@ -149,16 +163,33 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     };
     int qb = base_of(lp), nb = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
 
-    const int2 *rb_in = (ROLE == 2 && valid) ? rowbuf + pl.rowbuf_off : nullptr; // [j] = what the block above hands down for column j
-    auto rb_at = [&](int c) { return (ROLE == 2 && valid && c >= 1 && c <= m_eff) ? rb_in[c] : make_int2(0, 0); };
-    auto step = [&](const int t, auto chk, const bool ckflag, const int2 bnd) {
+    const int2 *rb_in = (TAKES && valid) ? rowbuf + pl.rowbuf_off : nullptr; // [j] = what the block above hands down for column j
+    // the first lane consumes one column per step from a QUEUE across the pair's lanes (like the base queue): lane lp loads column
+    // t0 + lp of a half block -- one 64-byte request per pair -- and the queue moves one lane towards the first lane per step
+    auto rb_at = [&](int c) { return (TAKES && valid && c >= 1 && c <= m_eff) ? rb_load(&rb_in[c], piped) : make_int2(0, 0); };
+    int2 rq = make_int2(0, 0), rqn = make_int2(0, 0);
+    // the last lane stages its bottom row in LDS, one column per step; after a half block lane lp stores column t0 - 7 + lp (64 bytes per pair)
+    int2 *hand = reinterpret_cast<int2 *>(lds + 32 + 8 * FP8_PST) + g * 8;
+    // piped: wait until the block above has handed down the columns <= c (it stores column c at its step c + 7)
+    int rb_seen = 0;
+    auto wait_cols = [&](int c) {
+        if (TAKES && piped && rb_seen < c + G8 - 1) {
+            const long long t_begin = wall_clock64();
+            while ((rb_seen = rb_progress(prog_in)) < c + G8 - 1) {
+                __builtin_amdgcn_s_sleep(32);
+                if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; } // 5 s at 100 MHz
+            }
+        }
+    };
+    auto step = [&](const int t, auto chk, const bool ckflag) {
         constexpr bool CHECK = decltype(chk)::value; // false: every lane of the wave is inside its matrix (steady state)
         // ckflag (wave-uniform): this half block crosses a checkpoint column
         // The first lane of a pair keeps the DPP `old` value = the row-0 boundary constant.  Passing the previous step's result
         // as `old` (its first lane already holds that constant) lets the move happen in place, without a copy of the constant.
-        // (ROLE 2: `old` is what the block above left for this step's column of the first lane, j = t.)
-        up_dn = dpp_prev8(ROLE == 2 ? bnd.x : up_dn, dn_out);
-        up_h = dpp_prev8(ROLE == 2 ? bnd.y : up_h, h_out);
+        // (TAKES: `old` is what the block above left for this step's column of the first lane, j = t.)
+        up_dn = dpp_prev8(TAKES ? rq.x : up_dn, dn_out);
+        up_h = dpp_prev8(TAKES ? rq.y : up_h, h_out);
+        if (TAKES) { rq.x = dpp_next8(rq.x); rq.y = dpp_next8(rq.y); }
         if (XP) { up_dn += vInc; up_h += vInc; }
         const int pb = dpp_prev8(qb, b_out);
         qb = dpp_next8(qb);
@@ -173,9 +204,9 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
 #pragma unroll
             for (int r = 0; r < RR; r++) {
                 const int S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
-                if (ROLE != 1 && r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
+                if (BOTTOM && r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
                 int hnew, dnn;
-                if (r < RR - FP_PLANES) { // tag bits are junk < 4 here; they never change the value of a max
+                if (!BOTTOM || r < RR - FP_PLANES) { // tag bits are junk < 4 here; they never change the value of a max
                     const int M = hd + S4;
                     hnew = max3i(M, rt[r], dnu);
                     const int ho = hnew + vO4;
@@ -197,8 +228,8 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
             diag0 = up_h;
             dn_out = dnu;
             h_out = hold[RR - 1];
-            if (ROLE == 1) { if (lp == G8 - 1 && valid) rowbuf[pl.rowbuf_off + j] = make_int2(dn_out, h_out); } // hand the bottom row down
-            if (ROLE != 1 && CHECK && j + 3 >= m_eff) { // the last four columns (always in a CHECK half block)
+            if (HANDS) { if (lp == G8 - 1) hand[t & 7] = make_int2(dn_out, h_out); } // hand the bottom row down (staged, see hand_down)
+            if (BOTTOM && CHECK && j + 3 >= m_eff) { // the last four columns (always in a CHECK half block)
 #pragma unroll
                 for (int d = 0; d < FP_PLANES; d++) tailw |= (unsigned)(hold[RR - 1 - d] & 3) << (8 * (m_eff - j) + 2 * d);
             }
@@ -220,7 +251,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
     // half blocks of 8 steps t0 .. t0+7 (step t: lane lp is at column t - lp); a plane word is two half blocks
     const int Tend = ((m_max + G8 - 1) / 16 + 1) * 16;
     auto flush = [&](int t0) { // the last lane owns rows n..n-3: after the odd half block, store the plane word of steps t0-8 .. t0+7
-        if (ROLE != 1 && (t0 & 8) && lp == G8 - 1 && valid) {
+        if (BOTTOM && (t0 & 8) && lp == G8 - 1 && valid) {
             const int w = t0 >> 4;
             if (w < pl.words) {
                 const int miss = (t0 + 7) - (m_eff + G8 - 1); // steps this lane sat idle after its last column
@@ -233,39 +264,80 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
             }
         }
     };
+    auto hand_down = [&](int t0) { // after the steps t0 .. t0 + 7: the last lane was at the columns t0 - 7 .. t0
+        if (HANDS) {
+            __syncthreads();
+            const int c = t0 - (G8 - 1) + lp;
+            const int2 v = hand[lp];
+            if (valid && c >= 1 && c <= m_eff) rb_store(&rowbuf[pl.rowbuf_off + c], v.x, v.y, piped);
+            __syncthreads();
+            if (piped && ((t0 + 8) & 31) == 0) rb_publish(prog_out, t0 + 7, lane); // every 32 steps: columns <= t0 are out
+        }
+    };
     auto edge_half_block = [&](int t0) { // head and tail of the sweep: some lanes are outside their matrix
         nb = base_of(t0 + 8 + lp); // prefetch the next half block's bases
+        if (TAKES) { wait_cols(t0 + 15); rqn = rb_at(t0 + 8 + lp); }
 #pragma unroll 1
-        for (int u = 0; u < 8; u++) step(t0 + u, std::true_type{}, true, rb_at(t0 + u));
+        for (int u = 0; u < 8; u++) step(t0 + u, std::true_type{}, true);
         qb = nb;
+        if (TAKES) rq = rqn;
         flush(t0);
+        hand_down(t0);
     };
     // Three phases, so that the steady loop is ONE loop over half blocks whose state stays in the same registers (separate
     // inner loops per half-block kind cost ~90 register copies per half block at their boundaries).
     int t0 = 0;
+    if (TAKES) { wait_cols(7); rq = rb_at(lp); }
     for (; t0 < Tend && !(t0 >= 8 && t0 + 7 <= m_min); t0 += 8) edge_half_block(t0);
-    int2 bcur[8], bnxt[8]; // ROLE 2: the row above for the first lane's columns of this / the next half block
-#pragma unroll
-    for (int u = 0; u < 8; u++) { bcur[u] = rb_at(t0 + u); bnxt[u] = make_int2(0, 0); }
     for (; t0 + 7 <= m_min; t0 += 8) { // steady state: every lane of the wave is inside its matrix
         nb = base_of(t0 + 8 + lp);
-        if (ROLE == 2) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) bnxt[u] = rb_at(t0 + 8 + u);
-        }
+        if (TAKES) { wait_cols(t0 + 15); rqn = rb_at(t0 + 8 + lp); }
         const bool ckflag = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
 #pragma unroll
-        for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, ckflag, bcur[u]);
+        for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, ckflag);
         qb = nb;
-        if (ROLE == 2) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) bcur[u] = bnxt[u];
-        }
+        if (TAKES) rq = rqn;
         flush(t0);
+        hand_down(t0);
     }
     for (; t0 < Tend; t0 += 8) edge_half_block(t0);
-    if (ROLE != 1 && lp == G8 - 1 && valid && m_eff >= 1) { hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); tail[pl.hcol_off] = tailw; } // h(n, m)
+    if (HANDS && piped) rb_publish(prog_out, 0x7fffffff, lane);
+    if (BOTTOM && lp == G8 - 1 && valid && m_eff >= 1) { hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); tail[pl.hcol_off] = tailw; } // h(n, m)
     if (bad) atomicOr(err, 1);
+}
+
+// reads of one row block (n <= 8 * RR)
+template <int RR, bool XP = false>
+__global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                      KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
+                                                      unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err) {
+    __shared__ int lds[32 + 8 * FP8_PST];
+    fp_sweep_body<RR, XP, 0>(lds, (int)blockIdx.x, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, nullptr, 0, false, nullptr, nullptr);
+}
+
+// reads of S >= 2 row blocks: the grid holds n_levels levels of W waves, block index = level-major, level level0 + blockIdx.x / W (0 = top).
+//   piped = 1: ONE launch for all levels (level0 = 0, n_levels = S); wave w of a level follows wave w of the level above through
+//              prog[level * W + w].  Workgroups are dispatched in index order, so a block's producer is always on the GPU before it.
+//              (800 x 10 000, 12 000 pairs: 21.2 ms against 27.8 ms for five launches of 1 500 waves; 32 768 pairs: 51.4 / 52.6 ms.
+//              Level-major order beats wave-major -- the levels of a wave group as grid neighbours, in lockstep -- 51.4 / 54.1 ms.)
+//   piped = 0: one launch per level in turn (n_levels = 1): nothing to wait for (GNX_NO_PIPE, and the fallback after a timeout).
+// RRTOP = slots per lane of the top block (as few as hold the longest read's rows above the full blocks).
+template <int RRTOP>
+__global__ __launch_bounds__(64) void fp_sweep_levels_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                             const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                             const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                             KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
+                                                             unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err,
+                                                             int2 *__restrict__ rowbuf, int S, int W, int level0, int piped, int *__restrict__ prog) {
+    __shared__ int lds[32 + 8 * FP8_PST + 8 * 8 * 2]; // + the staging area of the hand-over (8 pairs x 8 columns x int2)
+    const int lv = (int)blockIdx.x / W, w = (int)blockIdx.x - lv * W, level = level0 + lv, below = S - 1 - level;
+    int *po = prog + (int64_t)level * W + w;
+    const int *pi = po - W;
+    if (level == 0) fp_sweep_body<RRTOP, false, 1>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, nullptr, po);
+    else if (below == 0) fp_sweep_body<2 * FP8_LW, false, 2>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, 0, piped != 0, pi, nullptr);
+    else fp_sweep_body<2 * FP8_LW, false, 3>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, pi, po);
 }
 
 } // namespace

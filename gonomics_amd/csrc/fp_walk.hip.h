@@ -8,7 +8,7 @@ namespace {
 // Fast path (alpha fits one strip, global affine, gapOpen <= 0): traceback by stages.
 //   fp_walk: one lane per pair.  On row n in state I it follows the stored I-plane of row n (the long trailing
 //   gap of a short read against a long chunk) a word at a time; anywhere else it needs full direction bits and
-//   requests a re-fill of the <= FP_SPAN+CKW-1 columns left of the current cell from the nearest column
+//   requests a re-fill of the <= fp_span(strips)+CKW-1 columns left of the current cell from the nearest column
 //   checkpoint (window plan appended to a list), which fill_affine_kernel<.., WIN> computes with the normal
 //   recording; the next fp_walk call continues inside that window.  Row 0 / column 0 end the walk (Step 4).
 //   CIGAR runs are staged per pair in traceback order and reversed into place by fp_compact.
@@ -66,10 +66,11 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
     const int tiles_per = TILED ? (int)wplans[0].rowi_off : 0;
     int i = st.i, j = st.j, k = st.k, last_op = st.last_op, cur_op = st.cur_op, cnt = st.cnt;
     int64_t cur_run = st.cur_run, li = st.li;
-    gnx_cigar *stg = stage + (int64_t)p * FP_CAP;
+    const int cap = fp_cap(pl.strips);
+    gnx_cigar *stg = stage + (int64_t)p * cap;
     auto flush_run = [&]() {
         if (cur_op >= 0) {
-            if (cnt < FP_CAP && writer) { gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op; for (int z = 0; z < 7; z++) c._pad[z] = 0; stg[cnt] = c; }
+            if (cnt < cap && writer) { gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op; for (int z = 0; z < 7; z++) c._pad[z] = 0; stg[cnt] = c; }
             cnt++;
         }
     };
@@ -192,20 +193,20 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         flush_run();
         cur_op = -1;
         if (writer) nops[p] = cnt;
-        if (cnt > FP_CAP) atomicOr(err, 8);
+        if (cnt > cap) atomicOr(err, 8);
         st.status = 1;
     } else {
-        // request the window (jc_lo, j] : at least FP_SPAN wide, starting on a checkpoint column (or column 0)
+        // request the window (jc_lo, j] : at least fp_span(strips) wide, starting on a checkpoint column (or column 0)
         int slot = 0;
         if (writer) slot = atomicAdd(next_count, 1);
         if (CW) slot = __builtin_amdgcn_readfirstlane(slot);
-        int jc = j - FP_SPAN;
+        int jc = j - fp_span(pl.strips);
         jc = jc <= 0 ? 0 : (jc / CKW) * CKW;
         st.j_hi = j; st.jc_lo = jc; st.slot = slot; st.status = 0;
         if (writer) next_active[slot] = p;
         PairPlan q;
-        q.n = pl.n; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = pl.strips; // (2: a read of two row blocks, re-filled as two strips)
-        q.trace_off = (int64_t)slot * FP_WWORDS * QA * G * pl.strips; q.hcol_off = (int64_t)slot * H * pl.strips; q.rowbuf_off = (int64_t)slot * FP_WROW;
+        q.n = pl.n; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = pl.strips; // (a read of several row blocks is re-filled as as many strips)
+        q.trace_off = (int64_t)slot * fp_wwords(pl.strips) * QA * G * pl.strips; q.hcol_off = (int64_t)slot * H * pl.strips; q.rowbuf_off = (int64_t)slot * fp_wrow(pl.strips);
         q.dcol_off = (int64_t)slot * G * pl.strips;
         q.src = pl.src; q.col_off = jc; q.ckpt_off = pl.ckpt_off; q.rowi_off = 0;
         if (writer) next_wplans[slot] = q;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan 
     const int lo = c * FP_TILE, lo2 = max(0, lo - CKW); // start one checkpoint early: the first re-filled column has no usable tags
     q.m = (j_cur > lo) ? min(FP_TILE, j_cur - lo) + (lo - lo2) : 0;
     q.words = (q.m + 15 + 15) / 16; q.strips = q.m > 0 ? pl.strips : 0;
-    q.trace_off = (int64_t)x * FP_TWORDS * QA * G * pl.strips; q.hcol_off = (int64_t)x * H * pl.strips; q.rowbuf_off = (int64_t)x * FP_TROW;
+    q.trace_off = (int64_t)x * FP_TWORDS * QA * G * pl.strips; q.hcol_off = (int64_t)x * H * pl.strips; q.rowbuf_off = (int64_t)x * fp_trow(pl.strips);
     q.dcol_off = (int64_t)x * G * pl.strips;
     q.src = pl.src; q.col_off = lo2;
     q.rowi_off = (x == 0) ? tiles_per : 0; // plan 0 carries tiles_per for the walk kernel
@@ -238,16 +239,16 @@ __global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan 
 
 __global__ __launch_bounds__(256) void fp_compact_kernel(int n_pairs, const FpState *__restrict__ states, const gnx_cigar *__restrict__ stage, const int64_t *__restrict__ nops,
                                                           const int64_t *__restrict__ ops_off, gnx_cigar *__restrict__ ops, int64_t ops_capacity,
-                                                          int *__restrict__ err) {
+                                                          int *__restrict__ err, int cap) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const int64_t cnt = nops[p], base = ops_off[p];
     if (base + cnt > ops_capacity) { atomicOr(err, 4); return; }
-    const int64_t m = cnt < FP_CAP ? cnt : FP_CAP;
-    for (int64_t x = 0; x < m; x++) ops[base + (cnt - 1 - x)] = stage[(int64_t)p * FP_CAP + x];
+    const int64_t m = cnt < cap ? cnt : cap;
+    for (int64_t x = 0; x < m; x++) ops[base + (cnt - 1 - x)] = stage[(int64_t)p * cap + x];
 }
 
-// Pairs whose CIGAR has more runs than the staging area holds (FP_CAP) are aligned again on the general path -- only they, not
+// Pairs whose CIGAR has more runs than the staging area holds (fp_cap(strips)) are aligned again on the general path -- only they, not
 // the batch: gather their window starts, and afterwards put their scores / runs where the compaction left the gaps.
 __global__ __launch_bounds__(256) void fp_redo_gather_kernel(const int *__restrict__ idx, int n, const int64_t *__restrict__ as, const int64_t *__restrict__ bs,
                                                              int64_t *__restrict__ oas, int64_t *__restrict__ obs) {

@@ -101,7 +101,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr, s_in = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo, fp_wrow, mx_idx, mx_tab, mx_score, mx_off, mx_ops[2];
+    DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo, fp_wrow, mx_idx, mx_tab, mx_score, mx_off, mx_ops, fp_prog;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     // pipelined host entry (gnx_host.hip.h): double-buffered inputs, results accumulated on the device, the resident reference
     DevBuf pin_a[2], pin_as[2], pin_b[2], pin_bs[2], res_score, res_off, res_ops, ref, gat_score, gat_off, gat_ops;
@@ -234,17 +234,19 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                   const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                   const int64_t *h_alen, const int64_t *h_blen, int rows_per_lane,
                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
-                  int64_t *out_total, hipStream_t stream, bool first, bool xp, bool two) {
+                  int64_t *out_total, hipStream_t stream, bool first, bool xp, int S) {
     // rows_per_lane: 19 (every n <= 152) or 20 (n <= 160) -> fp_sweep_kernel<19 / 20>
-    // two: every read has 161 .. 320 bases: swept as two row blocks (fp_sweep_kernel<20, false, 1 / 2>), windows / tiles re-filled as two strips
+    // S >= 2: every read has 160 (S - 1) + 1 .. 160 S bases: swept as S row blocks, one launch each (fp_sweep_kernel<.., false, 1>, then
+    //     S - 2 times <20, false, 3>, then <20, false, 2>), windows / tiles re-filled as S strips
     // xp: AffineGapLocal, transposed -- the caller passes the query as "a" (rows) and the target as "b" (columns), and kp holds the
     //     transposed score table with the column-0 boundary of a global alignment (fp_sweep_kernel<.., true> and friends)
     Ctx &c = g_ctx;
     int rc;
     const int np = (int)n_pairs;
-    const int S = two ? 2 : 1;
-    int64_t top_hi = 1; // two: the longest top block of the batch (rows above the last 160)
-    for (int64_t p = 0; two && p < n_pairs; p++) top_hi = std::max<int64_t>(top_hi, h_alen[p] - H);
+    const bool two = S >= 2; // (several row blocks)
+    const int WWORDS = fp_wwords(S), WROW = fp_wrow(S), TROW = fp_trow(S), CAP = fp_cap(S);
+    int64_t top_hi = 1; // S >= 2: the longest top block of the batch (rows above the last 160 (S - 1))
+    for (int64_t p = 0; two && p < n_pairs; p++) top_hi = std::max<int64_t>(top_hi, h_alen[p] - (int64_t)H * (S - 1));
     const bool cached = c.fpc_ptr && c.fpc_ptr == c.plans.p && (int64_t)c.fpc_alen.size() == n_pairs && c.fpc_strips == S &&
                         memcmp(c.fpc_alen.data(), h_alen, (size_t)n_pairs * 8) == 0 && memcmp(c.fpc_blen.data(), h_blen, (size_t)n_pairs * 8) == 0;
     std::vector<PairPlan> plans(cached ? 0 : (size_t)n_pairs);
@@ -260,15 +262,16 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         roff += (int64_t)FP_PLANES * pl.words; coff += ((m - 1) / CKW) * n; cells += n * m;
         m_maxb = std::max(m_maxb, m);
     }
-    const size_t wtrace_b = (size_t)np * FP_WWORDS * QA * G * 16 * S;
+    const size_t wtrace_b = (size_t)np * WWORDS * QA * G * 16 * S;
     const size_t need = wtrace_b + (size_t)coff * 8 + (size_t)roff * 4 + (size_t)rboff * 8 +
-                        (size_t)np * (FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + (size_t)S * (H * 4 + G * 4) + (two ? FP_WROW * 8 : 0) + 32);
+                        (size_t)np * (CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + (size_t)S * (H * 4 + G * 4) + (size_t)WROW * 8 + 32);
     if ((int64_t)need > c.ws_limit) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] working set %zu B exceeds the workspace limit -> general path\n", need); return -1; }
     if ((rc = c.trace.ensure(wtrace_b))) return rc;
     if ((rc = c.hcol.ensure((size_t)np * (H * S + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then the window hcol slots
     if ((rc = c.dcol.ensure((size_t)np * G * S * 4))) return rc;
     if (two && (rc = c.rowbuf.ensure((size_t)rboff * 8))) return rc;        // what the top row block hands to the bottom one
-    if (two && (rc = c.fp_wrow.ensure((size_t)np * FP_WROW * 8))) return rc; // row buffers of the window slots
+    if (two && (rc = c.fp_wrow.ensure((size_t)np * WROW * 8))) return rc; // row buffers of the window slots
+    if (two && (rc = c.fp_prog.ensure((size_t)S * ((np + G8 - 1) / G8) * 4 + 64))) return rc; // progress words of the levels' waves
     if ((rc = c.plans.ensure((size_t)np * sizeof(PairPlan)))) return rc;
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
     if ((rc = c.misc.ensure(64))) return rc;
@@ -276,7 +279,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     if ((rc = c.fp_tail.ensure((size_t)np * 4))) return rc;
     if ((rc = c.fp_ckpt.ensure((size_t)std::max<int64_t>(coff, 1) * 8))) return rc;
     if ((rc = c.fp_states.ensure((size_t)np * sizeof(FpState)))) return rc;
-    if ((rc = c.fp_stage.ensure((size_t)np * FP_CAP * sizeof(gnx_cigar)))) return rc;
+    if ((rc = c.fp_stage.ensure((size_t)np * CAP * sizeof(gnx_cigar)))) return rc;
     for (int x = 0; x < 2; x++) {
         if ((rc = c.fp_wplans[x].ensure((size_t)np * sizeof(PairPlan)))) return rc;
         if ((rc = c.fp_active[x].ensure((size_t)np * 4))) return rc;
@@ -313,26 +316,41 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
 
     auto forward = [&](int p0, int cnt, hipStream_t st) -> int {
         const dim3 grid8((unsigned)((cnt + G8 - 1) / G8));
-        if (two) { // top row block, then the bottom one (it reads what the top one left in the row buffer)
+        if (two) { // S row blocks ("levels"): one launch, each level following the one above it through the row buffer (GNX_NO_PIPE: a launch per level)
             int2 *rb = reinterpret_cast<int2 *>(c.rowbuf.p);
-            const int top_rows = (int)(top_hi + G8 - 1) / G8; // slots per lane of the top block: as few as hold the longest read's n - 160 rows
-            auto ktop = top_rows <= 8 ? fp_sweep_kernel<8, false, 1> : (top_rows <= 12 ? fp_sweep_kernel<12, false, 1> : (top_rows <= 16 ? fp_sweep_kernel<16, false, 1> : fp_sweep_kernel<20, false, 1>));
-            hipLaunchKernelGGL(ktop, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, rb);
-            hipLaunchKernelGGL((fp_sweep_kernel<20, false, 2>), grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, rb);
+            const int top_rows = (int)(top_hi + G8 - 1) / G8; // slots per lane of the top block: as few as hold the longest read's rows above the full blocks
+            auto klev = top_rows <= 8 ? fp_sweep_levels_kernel<8> : (top_rows <= 12 ? fp_sweep_levels_kernel<12> : (top_rows <= 16 ? fp_sweep_levels_kernel<16> : fp_sweep_levels_kernel<20>));
+            const int W = (int)grid8.x;
+            int *prog = reinterpret_cast<int *>(c.fp_prog.p);
+            if (!no_pipe()) {
+                HIPCHK(hipMemsetAsync(prog, 0, (size_t)S * W * 4, st));
+                hipLaunchKernelGGL(klev, dim3((unsigned)(S * W)), blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, rb, S, W, 0, 1, prog);
+                HIPCHK(hipGetLastError());
+                int e = 0; // a level that waited 5 s for the one above it (cannot happen while workgroups start in index order): sweep again, level by level
+                HIPCHK(hipMemcpyAsync(&e, d_err, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (!(e & 16)) return GNX_OK;
+                e &= ~16;
+                HIPCHK(hipMemcpyAsync(d_err, &e, 4, hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] a row block timed out waiting for the one above it -> one launch per level\n");
+            }
+            for (int level = 0; level < S; level++)
+                hipLaunchKernelGGL(klev, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, rb, S, W, level, 0, prog);
             HIPCHK(hipGetLastError());
             return GNX_OK;
         }
         auto k = xp ? (rows_per_lane == 19 ? fp_sweep_kernel<19, true> : fp_sweep_kernel<20, true>) : (rows_per_lane == 19 ? fp_sweep_kernel<19, false> : fp_sweep_kernel<20, false>);
-        hipLaunchKernelGGL(k, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, (int2 *)nullptr);
+        hipLaunchKernelGGL(k, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err);
         HIPCHK(hipGetLastError());
         return GNX_OK;
     };
     // walk / window stages of the pairs [p0, p0+cnt) on stream `st`; their window slots are [p0, p0+cnt) as well
     auto post = [&](int p0, int cnt, hipStream_t st, int *cnt2, hipEvent_t e1, hipEvent_t e2) -> int {
-        uint4 *wtr = reinterpret_cast<uint4 *>(c.trace.p) + (int64_t)p0 * FP_WWORDS * QA * G * S;
+        uint4 *wtr = reinterpret_cast<uint4 *>(c.trace.p) + (int64_t)p0 * WWORDS * QA * G * S;
         int *whc = d_whcol + (int64_t)p0 * H * S;
         unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * G * S;
-        int2 *wrb = two ? reinterpret_cast<int2 *>(c.fp_wrow.p) + (int64_t)p0 * FP_WROW : nullptr;
+        int2 *wrb = two ? reinterpret_cast<int2 *>(c.fp_wrow.p) + (int64_t)p0 * WROW : nullptr;
         int cur = 0, n_act = 0, it = 0;
         float f = 0;
         // The stragglers' walk through their tiles runs one WAVE per pair (lanes that walk alone diverge: 0.80 -> 0.5 ms for 1 700
@@ -382,7 +400,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
             if ((rc2 = (two ? c.fp_redo : c.rowbuf).ensure((size_t)n_tiles * sizeof(PairPlan)))) return rc2; // tile plans (in a buffer this path does not use otherwise)
             if ((rc2 = c.fp_thcol.ensure((size_t)n_tiles * (H + G) * 4 * S))) return rc2;
             if ((rc2 = c.fp_ttrace.ensure(tb))) return rc2;
-            if (two && (rc2 = c.fp_wrow.ensure((size_t)std::max<int64_t>(n_tiles * FP_TROW, (int64_t)np * FP_WROW) * 8))) return rc2; // (the window rounds are over)
+            if (two && (rc2 = c.fp_wrow.ensure((size_t)std::max<int64_t>(n_tiles * TROW, (int64_t)np * WROW) * 8))) return rc2; // (the window rounds are over)
             PairPlan *tpl = reinterpret_cast<PairPlan *>(two ? c.fp_redo.p : c.rowbuf.p);
             int *thc = reinterpret_cast<int *>(c.fp_thcol.p);
             unsigned *tdc = reinterpret_cast<unsigned *>(thc + n_tiles * H * S);
@@ -410,7 +428,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     HIPCHK(hipEventRecord(c.ev[1], stream));
     if ((rc = post(0, np, stream, d_cnt, c.ev[4], c.ev[5]))) return rc;
     if ((rc = launch_scan(d_nops, np, d_ops_off, d_carry, stream))) return rc;
-    hipLaunchKernelGGL(fp_compact_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, d_st, d_stage, d_nops, d_ops_off, d_ops, ops_capacity, d_err);
+    hipLaunchKernelGGL(fp_compact_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, np, d_st, d_stage, d_nops, d_ops_off, d_ops, ops_capacity, d_err, CAP);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c.ev[3], stream));
     int h_misc[16];
@@ -433,16 +451,16 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
     if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
     if (ef & 8) {
-        // some CIGARs have more than FP_CAP runs: their run counts (and so every offset) are right, their runs were not staged.
+        // some CIGARs have more than fp_cap(S) runs: their run counts (and so every offset) are right, their runs were not staged.
         // Align those pairs again on the general path and put the results in place; the batch goes back only if they are many.
         std::vector<int64_t> hn((size_t)np);
         HIPCHK(hipMemcpy(hn.data(), d_nops, (size_t)np * 8, hipMemcpyDeviceToHost));
         std::vector<int> idx;
         std::vector<int64_t> sal, sbl;
         int64_t sub_total = 0;
-        for (int p = 0; p < np; p++) if (hn[(size_t)p] > FP_CAP) { idx.push_back(p); sal.push_back(h_alen[p]); sbl.push_back(h_blen[p]); sub_total += hn[(size_t)p]; }
+        for (int p = 0; p < np; p++) if (hn[(size_t)p] > CAP) { idx.push_back(p); sal.push_back(h_alen[p]); sbl.push_back(h_blen[p]); sub_total += hn[(size_t)p]; }
         const int ns = (int)idx.size();
-        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %d CIGARs have more than %d runs -> those pairs again on the general path\n", ns, FP_CAP);
+        if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %d CIGARs have more than %d runs -> those pairs again on the general path\n", ns, CAP);
         if (ns > np / 4) return -1;
         const size_t o_idx = 0, o_as = (size_t)ns * 4 + 64, o_bs = o_as + (size_t)ns * 8, o_sc = o_bs + (size_t)ns * 8, o_off = o_sc + (size_t)ns * 8,
                      o_ops = ((o_off + (size_t)(ns + 1) * 8 + 63) & ~(size_t)63), bytes = o_ops + (size_t)(sub_total + 1) * sizeof(gnx_cigar);
@@ -682,76 +700,97 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // fp_sweep_kernel keeps an int16 profile of 4*(s - 2e); its padding rows need 4*|gapOpen| well inside int16
         if (prm->gap_open <= -8000) fp = false;
         for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * prm->gap_extend); if (v > 32767 || v < -32000) fp = false; }
-        int64_t n_hi = 0, n_lo = INT64_MAX;
-        for (int64_t p = 0; fp && p < n_pairs; p++) {
-            const int64_t n = h_rows[p], m = h_cols[p];
-            if (n < 1 || n > 2 * H || m < (fpenv && fpenv[0] == '2' ? 1 : 768) || m > 0x3fffffff) fp = false;
-            else if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) fp = false;
-            n_hi = std::max(n_hi, n); n_lo = std::min(n_lo, n);
-        }
-        // reads of 161 .. 320 bases: two row blocks (global AffineGap only)
-        const bool two = n_hi > H;
-        if (two && xp) fp = false;
-        if (fp && two && n_lo <= H) {
-            // ... mixed with shorter reads: two uniform sub-batches, each on its fast path, merged back into input order
-            std::vector<int> idx[2];
-            std::vector<int64_t> hal[2], hbl[2];
-            for (int64_t p = 0; p < n_pairs; p++) { const int gq = h_alen[p] > H ? 1 : 0; idx[gq].push_back((int)p); hal[gq].push_back(h_alen[p]); hbl[gq].push_back(h_blen[p]); }
+        // Row blocks of 160 rows per pair (fp_sweep_kernel's ROLE): 1 = the read fits one block; 2 .. FP_MAXS = swept as that many blocks
+        // (global AffineGap only; from 3 blocks on only against windows of >= 3 n columns: the window re-fill behind the sweep covers
+        // ~n + 100 columns at the general kernel's rate, so a squarish pair would be filled twice); 0 = not for the fast path.
+        const bool forced = fpenv && fpenv[0] == '2'; // no shape rules (tests)
+        auto key_of = [&](int64_t n, int64_t m) -> int {
+            if (n < 1 || m < 1 || m > 0x3fffffff || (n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) return 0;
+            const int64_t Sp = (n + H - 1) / H;
+            if (Sp > FP_MAXS || (xp && Sp > 1)) return 0;
+            if (!forced && (m < 768 || (Sp >= 3 && m < 3 * n))) return 0;
+            return (int)Sp;
+        };
+        int64_t n_hi = 0, cntk[FP_MAXS + 1] = {0};
+        for (int64_t p = 0; fp && p < n_pairs; p++) { cntk[key_of(h_rows[p], h_cols[p])]++; n_hi = std::max(n_hi, h_rows[p]); }
+        int S = 0, distinct = 0;
+        for (int k = 0; k <= FP_MAXS; k++) if (cntk[k]) { distinct++; S = k; }
+        if (distinct == 1 && S == 0) fp = false;
+        // 8 pairs per wave and row block: a small batch of long reads leaves the GPU half empty (the general path runs 4 pairs per wave and strip)
+        if (distinct == 1 && S >= 3 && n_pairs * S < 8192 && !forced) fp = false;
+        if (fp && distinct > 1 && n_pairs < 256 && !forced) fp = false;
+        if (fp && distinct > 1) {
+            // Mixed batch: one uniform sub-batch per number of row blocks, each on its fast path (those not for it: general path),
+            // the results put back into input order
+            std::vector<int> idx[FP_MAXS + 1];
+            std::vector<int64_t> hal[FP_MAXS + 1], hbl[FP_MAXS + 1];
+            for (int64_t p = 0; p < n_pairs; p++) { const int gq = key_of(h_rows[p], h_cols[p]); idx[gq].push_back((int)p); hal[gq].push_back(h_alen[p]); hbl[gq].push_back(h_blen[p]); }
             if ((rc = c.mx_idx.ensure((size_t)n_pairs * 4))) return rc;
             if ((rc = c.mx_tab.ensure((size_t)n_pairs * 16))) return rc;
             if ((rc = c.mx_score.ensure((size_t)n_pairs * 8))) return rc;
-            if ((rc = c.mx_off.ensure((size_t)(n_pairs + 2) * 8))) return rc;
+            if ((rc = c.mx_off.ensure((size_t)(n_pairs + FP_MAXS + 1) * 8))) return rc;
+            if ((rc = c.mx_ops.ensure((size_t)std::max<int64_t>(ops_capacity, 1) * sizeof(gnx_cigar)))) return rc;
             if ((rc = c.nops.ensure((size_t)n_pairs * 8))) return rc;
             if ((rc = c.misc.ensure(64))) return rc;
             int *d_idx = reinterpret_cast<int *>(c.mx_idx.p);
-            const int n0 = (int)idx[0].size(), n1 = (int)idx[1].size();
-            HIPCHK(hipMemcpyAsync(d_idx, idx[0].data(), (size_t)n0 * 4, hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(d_idx + n0, idx[1].data(), (size_t)n1 * 4, hipMemcpyHostToDevice, stream));
+            int64_t g0[FP_MAXS + 2] = {0}; // first pair of each group in the gathered order
+            for (int k = 0; k <= FP_MAXS; k++) {
+                g0[k + 1] = g0[k] + (int64_t)idx[k].size();
+                if (!idx[k].empty()) HIPCHK(hipMemcpyAsync(d_idx + g0[k], idx[k].data(), idx[k].size() * 4, hipMemcpyHostToDevice, stream));
+            }
             HIPCHK(hipStreamSynchronize(stream));
             gnx_timing tsum = {};
-            int64_t tot[2] = {0, 0};
+            int64_t tot_all = 0, obase[FP_MAXS + 1] = {0};
             bool capfail = false;
-            for (int gq = 0; gq < 2; gq++) {
-                const int ng = gq ? n1 : n0, *gi = d_idx + (gq ? n0 : 0);
-                int64_t *gas = reinterpret_cast<int64_t *>(c.mx_tab.p) + (gq ? 2 * (int64_t)n0 : 0), *gbs = gas + ng;
-                int64_t *gsc = reinterpret_cast<int64_t *>(c.mx_score.p) + (gq ? n0 : 0), *goff = reinterpret_cast<int64_t *>(c.mx_off.p) + (gq ? n0 + 1 : 0);
-                if ((rc = c.mx_ops[gq].ensure((size_t)std::max<int64_t>(ops_capacity, 1) * sizeof(gnx_cigar)))) return rc;
+            for (int k = 0; k <= FP_MAXS; k++) {
+                const int ng = (int)idx[k].size();
+                if (!ng) continue;
+                const int *gi = d_idx + g0[k];
+                int64_t *gas = reinterpret_cast<int64_t *>(c.mx_tab.p) + 2 * g0[k], *gbs = gas + ng;
+                int64_t *gsc = reinterpret_cast<int64_t *>(c.mx_score.p) + g0[k], *goff = reinterpret_cast<int64_t *>(c.mx_off.p) + g0[k] + k;
                 hipLaunchKernelGGL(fp_redo_gather_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream, gi, ng, d_as, d_bs, gas, gbs);
                 HIPCHK(hipGetLastError());
-                rc = run_device(prm, ng, d_a, gas, d_b, gbs, hal[gq].data(), hbl[gq].data(), gsc, reinterpret_cast<gnx_cigar *>(c.mx_ops[gq].p), ops_capacity, goff, &tot[gq], stream);
+                obase[k] = std::min(tot_all, ops_capacity);
+                int64_t tg = 0;
+                rc = run_device(prm, ng, d_a, gas, d_b, gbs, hal[k].data(), hbl[k].data(), gsc, reinterpret_cast<gnx_cigar *>(c.mx_ops.p) + obase[k], ops_capacity - obase[k], goff, &tg, stream,
+                                nullptr, nullptr, 0, nullptr, k == 0, false);
                 if (rc == GNX_ECAPACITY) capfail = true;
                 else if (rc) return rc;
+                tot_all += tg;
                 tsum.fill_ms += c.timing.fill_ms; tsum.traceback_ms += c.timing.traceback_ms; tsum.total_ms += c.timing.total_ms; tsum.cells += c.timing.cells;
                 tsum.n_launches += c.timing.n_launches; tsum.trace_bytes += c.timing.trace_bytes; tsum.dominant_ms += c.timing.dominant_ms;
-                tsum.dominant_launches += c.timing.dominant_launches; tsum.fast_path = c.timing.fast_path;
+                tsum.dominant_launches += c.timing.dominant_launches; tsum.fast_path = std::max(tsum.fast_path, c.timing.fast_path);
             }
             c.timing = tsum;
-            if (out_total) *out_total = tot[0] + tot[1];
-            if (capfail || tot[0] + tot[1] > ops_capacity) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)(tot[0] + tot[1])); return GNX_ECAPACITY; }
+            if (out_total) *out_total = tot_all;
+            if (capfail || tot_all > ops_capacity) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)tot_all); return GNX_ECAPACITY; }
             int *d_err = reinterpret_cast<int *>(c.misc.p);
             int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
             int64_t *d_cnt = reinterpret_cast<int64_t *>(c.nops.p);
             HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
-            for (int gq = 0; gq < 2; gq++) {
-                const int ng = gq ? n1 : n0;
-                hipLaunchKernelGGL(mix_counts_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream, d_idx + (gq ? n0 : 0), ng,
-                                   reinterpret_cast<const int64_t *>(c.mx_off.p) + (gq ? n0 + 1 : 0), reinterpret_cast<const int64_t *>(c.mx_score.p) + (gq ? n0 : 0), d_cnt, d_score);
+            for (int k = 0; k <= FP_MAXS; k++) {
+                const int ng = (int)idx[k].size();
+                if (!ng) continue;
+                hipLaunchKernelGGL(mix_counts_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream, d_idx + g0[k], ng,
+                                   reinterpret_cast<const int64_t *>(c.mx_off.p) + g0[k] + k, reinterpret_cast<const int64_t *>(c.mx_score.p) + g0[k], d_cnt, d_score);
             }
             if ((rc = launch_scan(d_cnt, (int)n_pairs, d_ops_off, d_carry, stream))) return rc;
-            for (int gq = 0; gq < 2; gq++) {
-                const int ng = gq ? n1 : n0;
-                hipLaunchKernelGGL(mix_copy_kernel, dim3((unsigned)ng), dim3(256), 0, stream, d_idx + (gq ? n0 : 0), ng, reinterpret_cast<const int64_t *>(c.mx_off.p) + (gq ? n0 + 1 : 0),
-                                   reinterpret_cast<const gnx_cigar *>(c.mx_ops[gq].p), d_ops_off, d_ops, ops_capacity, d_err);
+            for (int k = 0; k <= FP_MAXS; k++) {
+                const int ng = (int)idx[k].size();
+                if (!ng) continue;
+                hipLaunchKernelGGL(mix_copy_kernel, dim3((unsigned)ng), dim3(256), 0, stream, d_idx + g0[k], ng, reinterpret_cast<const int64_t *>(c.mx_off.p) + g0[k] + k,
+                                   reinterpret_cast<const gnx_cigar *>(c.mx_ops.p) + obase[k], d_ops_off, d_ops, ops_capacity, d_err);
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(stream));
             return GNX_OK;
         }
+        const bool two = S >= 2;
         const int rows_per_lane = (two || n_hi > 19 * G8) ? 20 : 19;
         if (fp) {
             // sub-batches whose fast-path working set (checkpoints, planes, window slots, staging) fits the workspace
-            const size_t fixed = ((size_t)FP_WWORDS * QA * G * 16 + H * 4 + G * 4) * (two ? 2 : 1) + FP_CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + 64 +
-                                 (two ? (size_t)FP_WROW * 8 : 0);
+            const size_t fixed = ((size_t)fp_wwords(S) * QA * G * 16 + H * 4 + G * 4) * S + fp_cap(S) * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + 64 +
+                                 (size_t)fp_wrow(S) * 8;
             // ... of about equal size (a small last sub-batch would leave most of the GPU idle for the length of a sweep wave)
             std::vector<int64_t> cb{0};
             size_t acc_b = 0, total_b = 0;
@@ -774,9 +813,9 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             for (size_t ch = 0; fp && ch + 1 < cb.size(); ch++) {
                 const int64_t b = cb[ch], e = cb[ch + 1];
                 if (xp) rc = run_device_fp(prm, kpx, tp, e - b, d_b, d_bs + b, d_a, d_as + b, h_blen + b, h_alen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
-                                           d_ops_off + b, out_total, stream, ch == 0, true, false);
+                                           d_ops_off + b, out_total, stream, ch == 0, true, 1);
                 else rc = run_device_fp(prm, kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
-                                        d_ops_off + b, out_total, stream, ch == 0, false, two);
+                                        d_ops_off + b, out_total, stream, ch == 0, false, S);
                 // a CIGAR buffer that is too small does not end the loop: the remaining sub-batches still count their runs (the offset
                 // carry runs through them), so that the total handed back with GNX_ECAPACITY is that of the whole batch
                 if (rc != GNX_OK && rc != GNX_ECAPACITY) break;
@@ -1283,7 +1322,7 @@ void gnx_shutdown(void) {
         if (!c.inited) continue;
         (void)hipSetDevice(c.device);
         (void)hipDeviceSynchronize();
-        DevBuf *bufs[] = {&c.strip_map, &c.tb_scr, &c.tb_scr_off, &c.scan_tmp, &c.fp_redo, &c.fp_wrow, &c.mx_idx, &c.mx_tab, &c.mx_score, &c.mx_off, &c.mx_ops[0], &c.mx_ops[1], &c.fp_tail, &c.fp_thcol, &c.fp_ttrace, &c.fp_rowi, &c.fp_ckpt, &c.fp_states, &c.fp_stage,
+        DevBuf *bufs[] = {&c.strip_map, &c.tb_scr, &c.tb_scr_off, &c.scan_tmp, &c.fp_redo, &c.fp_wrow, &c.mx_idx, &c.mx_tab, &c.mx_score, &c.mx_off, &c.mx_ops, &c.fp_prog, &c.fp_tail, &c.fp_thcol, &c.fp_ttrace, &c.fp_rowi, &c.fp_ckpt, &c.fp_states, &c.fp_stage,
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,

@@ -589,3 +589,75 @@ def test_fast_path_mixed_read_lengths(gpu_lib, monkeypatch):
         got1 = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start[sel], lens[sel], chunk, b_start[sel], b_len[sel])
         exp1 = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads.reshape(-1), a_start[sel], lens[sel], chunk, b_start[sel], b_len[sel], threads=8)
         common.assert_same(got1, exp1, "uniform sub-batch")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_lo,n_hi", [(61, 321, 480), (62, 481, 640), (63, 1441, 1600), (64, 700, 800)])
+def test_fast_path_many_row_blocks(gpu_lib, seed, n_lo, n_hi, monkeypatch):
+    """reads of 321 .. 1600 bases on the fast path: a top block, middle blocks (fp_sweep_kernel<20, false, 3>: take the row above from the
+    row buffer and hand their own bottom row down in place) and the bottom block; windows and straggler tiles re-filled as S strips.
+    Every number of slots per lane of the top block, ragged windows, several penalty sets, small checkerboards, forced rounds."""
+    monkeypatch.setenv("GNX_FASTPATH", "2")
+    rng = np.random.default_rng(seed)
+    L = 7000
+    ref = rng.integers(0, 4, size=L, dtype=np.uint8)
+    ref[rng.integers(0, L, size=10)] = 4
+    S = (n_hi + 159) // 160
+    alphas, betas = [], []
+    for k in range(96):
+        if (n_hi - 1) // 160 != (n_lo - 1) // 160:  # (seed 64: all in one class anyway)
+            raise AssertionError("bad test parameters")
+        n = int(rng.integers(n_lo, n_hi + 1)) if k >= 4 else [n_lo, n_hi, n_lo + 1, n_hi - 1][k]
+        m = int(rng.choice([n // 2, n, n + 129, 2 * n + 1, 3 * n, 5000]))
+        m = min(m, L)
+        off = int(rng.integers(0, L - m + 1))
+        beta = ref[off:off + m].copy()
+        if m >= n and rng.random() < 0.8:
+            pos = int(rng.integers(0, m - n + 1))
+            alpha = common.mutate(rng, beta[pos:pos + n + 40], 0.04, 0.015)
+        else:
+            alpha = rng.integers(0, 4, size=n, dtype=np.uint8)
+        alpha = alpha[:n]
+        if alpha.shape[0] < n_lo:
+            alpha = np.concatenate([alpha, rng.integers(0, 4, size=n_lo - alpha.shape[0], dtype=np.uint8)])
+        assert (alpha.shape[0] + 159) // 160 == S
+        alphas.append(alpha); betas.append(beta)
+    for name, go, ge in [("HumanChimpTwo", -600, -150), ("Default", -400, -30), ("HumanChimpTwo", 0, -150)]:
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX[name], go, ge)
+        got = gpu_lib.align_batch(p, alphas, betas)
+        if go == -600:
+            assert gpu_lib.get_timing()["fast_path"] == 1
+        exp = oracle.align_batch(0, MX[name], go, ge, alphas, betas, threads=8)
+        common.assert_same(got, exp, "%d row blocks %s %d %d" % (S, name, go, ge))
+    exp7 = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, alphas, betas, ci=7, cj=7, threads=8)
+    p7 = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150, 7, 7)
+    for maxit in (None, "0", "3"):
+        if maxit is not None:
+            monkeypatch.setenv("GNX_FP_MAXIT", maxit)
+        common.assert_same(gpu_lib.align_batch(p7, alphas, betas), exp7, "%d row blocks, 7x7 checkerboards, maxit %s" % (S, maxit))
+    monkeypatch.setenv("GNX_NO_PIPE", "1")  # one launch per row block instead of one launch whose levels follow each other
+    common.assert_same(gpu_lib.align_batch(p7, alphas, betas), exp7, "%d row blocks, a launch per level" % S)
+
+
+@pytest.mark.gpu
+def test_fast_path_row_blocks_natural_routing(gpu_lib):
+    """6400 reads of 330 .. 480 bases against 1500-base windows without any switch: three row blocks by the routing rule of run_device
+    (>= 6144 pairs, windows >= 3 n); and the same batch mixed with shorter reads and with pairs that are not for the fast path."""
+    rng = np.random.default_rng(91)
+    P, L = 6400, 1500
+    reads, chunk = common.c2_workload(91, P, read_len=480, chunk_len=L)
+    lens = rng.integers(330, 481, size=P).astype(np.int64)
+    a_start = np.arange(P, dtype=np.int64) * 480
+    b_start = np.zeros(P, dtype=np.int64)
+    b_len = np.full(P, L, dtype=np.int64)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+    got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, lens, chunk, b_start, b_len)
+    assert gpu_lib.get_timing()["fast_path"] == 1
+    exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads.reshape(-1), a_start, lens, chunk, b_start, b_len, threads=16)
+    common.assert_same(got, exp, "three row blocks, natural routing")
+    # mixed: 1 .. 3 row blocks, and windows too short for the fast path (general path for those)
+    lens2 = rng.choice([100, 150, 200, 320, 400, 480], size=P).astype(np.int64)
+    b_len2 = rng.choice([600, 1000, 1500], size=P).astype(np.int64)
+    got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, lens2, chunk, b_start, b_len2)
+    exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads.reshape(-1), a_start, lens2, chunk, b_start, b_len2, threads=16)
+    common.assert_same(got, exp, "mixed numbers of row blocks")

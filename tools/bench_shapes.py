@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel time of one batch per shape and path (device-resident inputs): where does the constant-gap path without a stored direction matrix
-(GNX_CLONG) / the affine fast path beat the general path?  Usage: python tools/bench_shapes.py [const|affine]"""
+(GNX_CLONG) / the affine fast path beat the general path?  Usage: python tools/bench_shapes.py [const|affine] [n,m,pairs]"""
 import ctypes
 import json
 import os
@@ -24,7 +24,10 @@ def main():
     dev = torch.device("cuda", 0)
     mode, go, ge = (_lib.GNX_CONST_GAP, -430, 0) if kind == "const" else (_lib.GNX_AFFINE_GAP, -600, -150)
     p = _lib.make_params(mode, align.HumanChimpTwoScoreMatrix, go, ge)
-    for n, m, pairs in ((150, 10000, 65536), (250, 10000, 40000), (320, 10000, 32768), (480, 10000, 20000), (800, 10000, 12000), (1600, 10000, 6000), (3200, 10000, 3000), (1000, 1200, 100000)):
+    shapes = ((150, 10000, 65536), (250, 10000, 40000), (320, 10000, 32768), (480, 10000, 20000), (800, 10000, 12000), (1600, 10000, 8192 if kind == "affine" else 6000), (3200, 10000, 3000), (1000, 1200, 100000))
+    if len(sys.argv) > 2:  # one shape: n,m,pairs
+        shapes = (tuple(int(x) for x in sys.argv[2].split(",")),)
+    for n, m, pairs in shapes:
         reads, chunk = bench.make_workload(3, pairs, read_len=n, chunk_len=m)
         d_reads = torch.from_numpy(reads.reshape(-1)).to(dev); d_chunk = torch.from_numpy(chunk).to(dev)
         h_al = np.full(pairs, n, dtype=np.int64); h_bl = np.full(pairs, m, dtype=np.int64)
@@ -37,7 +40,10 @@ def main():
         tot = ctypes.c_int64()
         row = {"kind": kind, "n": n, "m": m, "pairs": pairs}
         res = {}
-        for name, env in (("general", {"GNX_CLONG": "0", "GNX_FASTPATH": "0"}), ("default", {})):
+        variants = [("general", {"GNX_CLONG": "0", "GNX_FASTPATH": "0"}), ("default", {})]
+        if kind == "affine" and n <= 3200 and m >= 3 * n:
+            variants.append(("row_blocks", {"GNX_FASTPATH": "2"}))  # the fast path whatever the routing rule says
+        for name, env in variants:
             for k in ("GNX_CLONG", "GNX_FASTPATH"):
                 os.environ.pop(k, None)
             os.environ.update(env)
