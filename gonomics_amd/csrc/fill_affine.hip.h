@@ -49,6 +49,10 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     //      variants, "next" row N1) instead of the LDS profile of alpha x the base of the column; sequences are not read.
     // WIN: window / tile re-fill of the fast path: the left boundary comes from a column checkpoint written by
     //      fp_sweep_kernel (pl.col_off > 0), the row-0 boundary and the beta window start at column col_off.
+    //      The window holds ONE row block of the sweep: rows pl.s_off + 1 .. pl.s_off + pl.n of the pair (pl.s_off = "row base",
+    //      pl.s_pitch = rows of the whole pair = pitch of its checkpoints).  With a row base the row above the window is what the
+    //      block above handed down in the sweep's row buffer, rowbuf[pl.rowbuf_off + column of the pair] = {D'(base+1,j), h'(base,j)}
+    //      with their argmax tags, rebased by the sweep with the pair's (i + j): + e*(row base + col_off) makes them this launch's.
     // XP:  window re-fill of the TRANSPOSED free-end-gap fast path (fp_sweep_kernel<.., true>): the gap chains swap their tags
     //      (tie order M >= D' >= I'), row 0 is free (I'(0,j) = 0) and so is the horizontal step in the last row.
     static_assert(!XP || (WIN && HFORM && !LOCAL && !MULTI && !SCORED), "XP is a window re-fill variant");
@@ -72,7 +76,9 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const bool valid = p < n_pairs;
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
-    const uint8_t *ap = SCORED ? nullptr : a_buf + (valid ? a_start[pl.src] : 0);
+    const int row_base = WIN ? (int)pl.s_off : 0;                          // rows of the pair above this window
+    const int ck_pitch = (WIN && pl.s_pitch) ? (int)pl.s_pitch : pl.n;    // rows of the whole pair
+    const uint8_t *ap = SCORED ? nullptr : a_buf + (valid ? a_start[pl.src] + row_base : 0);
     const uint8_t *bp = SCORED ? nullptr : b_buf + (valid ? b_start[pl.src] + (WIN ? pl.col_off : 0) : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4;
@@ -117,11 +123,11 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             __syncthreads();
         }
         const int2 *ck0 = nullptr; // window re-fill: left boundary = column checkpoint col_off / CKW
-        if (WIN && pl.col_off > 0) ck0 = ckpt + pl.ckpt_off + (int64_t)(pl.col_off / CKW - 1) * pl.n;
+        if (WIN && pl.col_off > 0) ck0 = ckpt + pl.ckpt_off + (int64_t)(pl.col_off / CKW - 1) * ck_pitch + row_base;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = row0 + r + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
-            const int D1c = kp.d00_4 + i * kp.ecol4 + TD - RB * i;            // D(i,0), rebased with j = 0
+            const int D1c = kp.d00_4 + (i + row_base) * kp.ecol4 + TD - RB * i; // D(i,0) (i + row base = row of the pair), rebased with j = 0
             hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
             rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;      // I(i,1) = D(i,0) + oe, rebased with j = 1
             if (XP && r == r_last) rt[r] = D1c - RB; // I'(n,1) = h(n,0), no penalty
@@ -129,17 +135,24 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             if (WIN && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x - RB * (i + 1); hold[r] = v.y - (REB ? RB * (i + 1) : 0); }
             acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
         }
-        int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
+        const int grow0 = row0 + row_base; // row of the pair above this lane's first row
+        int diag0 = (grow0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + grow0 * kp.ecol4 + TD - RB * row0);
         if (WIN && ck0) {
-            if (row0 == 0) diag0 = max3i(NEG4 + 3, (XP ? 0 : kp.o4 + pl.col_off * E4) + TI, NEG4 + TD); // h(0, col_off)
-            else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y - (REB ? RB * (row0 + 1) : 0);
+            if (grow0 == 0) diag0 = max3i(NEG4 + 3, (XP ? 0 : kp.o4 + pl.col_off * E4) + TI, NEG4 + TD); // h(0, col_off)
+            else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y - (REB ? RB * (row0 + 1) : 0);        // (row0 = 0: the checkpoint of the row above the window)
         }
         int dn_out = 0, h_out = 0, b_out = 0;
         int sq_dn = 0, sq_h = 0;
         // boundary queues (row above the strip + beta): lane u holds column t0+u+1 of the current 16-step block
         int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
         auto boundary = [&](int c, int &odn, int &oh, int &ob) {
-            if (!MULTI || s == 0) {
+            if (WIN && row_base > 0) { // the row the block above handed down in the sweep
+                if (c >= 1 && c <= m_eff) {
+                    const int2 v = rowbuf[pl.rowbuf_off + pl.col_off + c];
+                    const int K = RB * (row_base + pl.col_off);
+                    odn = v.x + K; oh = v.y + K;
+                } else { odn = 0; oh = 0; }
+            } else if (!MULTI || s == 0) {
                 const int M3 = NEG4 + 3, I2 = (XP ? 0 : kp.o4 + ((WIN ? pl.col_off : 0) + c) * E4) + TI - RB * c, D1 = NEG4 + TD; // row 0: I(0,c) = gapOpen + c*gapExtend (XP: free), rebased with i = 0
                 const int h0 = max3i(M3, I2, D1);
                 odn = ((LOCAL && c == m_eff) ? h0 : max3i(M3 + OE4, I2 + OE4, D1 + E4)) - RB; // D(1,c): one row further down

@@ -63,13 +63,15 @@ __device__ __forceinline__ int dpp_next8(int src) { // every lane of the two ban
 //       row-0 constants: the pair's lanes load the 8 columns of the next half block with one 64-byte request and pass them to the
 //       first lane through a DPP queue, one per step.  Checkpoints of all blocks are indexed by the row of the pair.
 //   3 = a MIDDLE block (reads of more than 320 bases, pl.strips >= 3): 160 rows with `below` blocks under it; takes the row above
-//       like the bottom block and hands its own bottom row down like the top block, IN PLACE in the same row buffer (its first
-//       lane reads column t -- loaded at most 16 columns ahead -- while its last lane hands down the columns up to t - 7).
+//       like the bottom block and hands its own bottom row down like the top block.
 //   Blocks that hand their bottom row down stage it in LDS and store 8 columns per half block (64 bytes per pair): per-step 8-byte
 //   stores / loads of the hand-over cost 30 % of the sweep when they are agent-scope (uncached) operations.
 //   0 = the whole read in one block (n <= 8 * RR).
 // `below` = row blocks of the pair under this one (top block: pl.strips - 1).  Blocks that hand their bottom row down keep no
-// planes, so none of their rows pays the tag arithmetic.
+// planes; only their LAST row pays the tag arithmetic, so that the handed-down {D'(r+1,j), h'(r,j)} carry their argmax tags: the
+// window re-fill of the block below (fill_affine_kernel<.., WIN> with a row base) records them as the directions of its first row.
+// Level L (0 = top) writes row L of the pair's row buffer ((strips - 1) rows of m + 1 entries) and reads row L - 1: the rows stay,
+// the walk's re-fills of single blocks start from them.
 // wblk = the wave's index among the waves of its row block (8 pairs each).  piped: the row blocks of a batch run as ONE launch
 // (fp_sweep_levels_kernel), a block following the one above it through the row buffer as that one publishes its progress
 // (prog_out / prog_in: the last step whose hand-over stores are out, INT_MAX at the end; rows and progress word are agent-scope
@@ -163,7 +165,9 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     };
     int qb = base_of(lp), nb = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
 
-    const int2 *rb_in = (TAKES && valid) ? rowbuf + pl.rowbuf_off : nullptr; // [j] = what the block above hands down for column j
+    const int level = pl.strips - 1 - below; // 0 = top block
+    const int2 *rb_in = (TAKES && valid) ? rowbuf + pl.rowbuf_off + (int64_t)(level - 1) * (pl.m + 1) : nullptr; // [j] = what the block above hands down for column j
+    int2 *rb_out = (HANDS && valid) ? rowbuf + pl.rowbuf_off + (int64_t)level * (pl.m + 1) : nullptr;
     // the first lane consumes one column per step from a QUEUE across the pair's lanes (like the base queue): lane lp loads column
     // t0 + lp of a half block -- one 64-byte request per pair -- and the queue moves one lane towards the first lane per step
     auto rb_at = [&](int c) { return (TAKES && valid && c >= 1 && c <= m_eff) ? rb_load(&rb_in[c], piped) : make_int2(0, 0); };
@@ -206,7 +210,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
                 const int S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
                 if (BOTTOM && r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
                 int hnew, dnn;
-                if (!BOTTOM || r < RR - FP_PLANES) { // tag bits are junk < 4 here; they never change the value of a max
+                if (BOTTOM ? r < RR - FP_PLANES : r < RR - 1) { // tag bits are junk < 4 here; they never change the value of a max
                     const int M = hd + S4;
                     hnew = max3i(M, rt[r], dnu);
                     const int ho = hnew + vO4;
@@ -269,7 +273,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
             __syncthreads();
             const int c = t0 - (G8 - 1) + lp;
             const int2 v = hand[lp];
-            if (valid && c >= 1 && c <= m_eff) rb_store(&rowbuf[pl.rowbuf_off + c], v.x, v.y, piped);
+            if (valid && c >= 1 && c <= m_eff) rb_store(&rb_out[c], v.x, v.y, piped);
             __syncthreads();
             if (piped && ((t0 + 8) & 31) == 0) rb_publish(prog_out, t0 + 7, lane); // every 32 steps: columns <= t0 are out
         }

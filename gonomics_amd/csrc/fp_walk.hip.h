@@ -37,7 +37,8 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                                                      const int *__restrict__ whcol, TbParams tp, gnx_cigar *__restrict__ stage,
                                                      int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                      int *__restrict__ next_active, int *__restrict__ next_count,
-                                                     PairPlan *__restrict__ next_wplans, int *__restrict__ err, int p_base) {
+                                                     PairPlan *__restrict__ next_wplans, int *__restrict__ err, int p_base,
+                                                     int *__restrict__ strag_active, int *__restrict__ strag_count, int force_strag) {
     const int a = CW ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (a >= n_active) return;
     const int lane = threadIdx.x & 63;
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         wp = wplans[TILED ? 0 : a];
         if (TILED) { st.j_hi = 0; st.jc_lo = 0; }
     }
+    int wrow = FIRST ? 0 : (int)wp.s_off; // row base of the current window: it holds the rows wrow + 1 .. wrow + wp.n of the pair
     // TILED: `a` indexes the straggler; its tiles c = 0.. are the plans [a*tiles_per + c] (tiles_per in wplans[0].rowi_off)
     const int tiles_per = TILED ? (int)wplans[0].rowi_off : 0;
     int i = st.i, j = st.j, k = st.k, last_op = st.last_op, cur_op = st.cur_op, cnt = st.cnt;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         if (op == cur_op) cur_run += run;
         else { flush_run(); cur_op = op; cur_run = run; }
     };
-    bool done = false;
+    bool done = false, last_win = false;
     // A re-fill that starts from a column checkpoint reproduces every VALUE, but the checkpoint carries no argmax tags
     // (the sweep computes them only on its plane rows), so the M- and I-plane fields of the re-fill's first column are
     // not usable: the walk uses a window / tile from its second column on (all of it when it starts at column 0).
@@ -92,19 +94,23 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         unsigned w;
         int pos;
         const bool on_plane = (k == 1) && (pl.n - i) < FP_PLANES;
+        const bool in_win = !on_plane && j >= lo_ok(st.jc_lo) && j <= st.j_hi && i > wrow && i <= wrow + wp.n;
+        if (on_plane || in_win || (k == 0 && tail_ok(i - 1, j - 1))) last_win = in_win; // was the last step taken inside the window? (then the walk leaves it by walking through it)
         if (on_plane) { // stored I-plane of row n-d
             const int t1 = j + G8 - 1; // step at which the owner lane (the pair's last) was at column j
             w = rowi[pl.rowi_off + (int64_t)(pl.n - i) * pl.words + (t1 >> 4)];
             pos = t1 & 15;
-        } else if (j >= lo_ok(st.jc_lo) && j <= st.j_hi) { // inside the usable part of the current window
-            w = load_word<true>(wtrace, wp, k, i, j - st.jc_lo, pos);
+        } else if (in_win) { // inside the usable part of the current window (one row block)
+            w = load_word<true>(wtrace, wp, k, i - wrow, j - st.jc_lo, pos);
         } else if (k == 0 && tail_ok(i - 1, j - 1)) { // trM(i,j) = argmax of h(i-1,j-1): a diagonal step in the corner needs no window
             w = tail_tag(i - 1, j - 1); pos = 0;
         } else if (TILED) { // switch to the tile holding column j (all tiles of a straggler are filled)
             const int c = (j - 1) / FP_TILE;
+            if (st.j_hi > 0 && !(i > wrow && i <= wrow + wp.n)) break; // left the tiles' row block through its top: the next block needs a window
             wp = wplans[(int64_t)a * tiles_per + c];
+            wrow = (int)wp.s_off;
             st.jc_lo = wp.col_off; st.j_hi = st.jc_lo + wp.m; // tile c starts one checkpoint before column c*FP_TILE
-            if (j > st.j_hi || j < lo_ok(st.jc_lo)) { atomicOr(err, 2); done = true; break; }
+            if (j > st.j_hi || j < lo_ok(st.jc_lo) || !(i > wrow && i <= wrow + wp.n)) { atomicOr(err, 2); done = true; break; }
             continue;
         } else break; // needs a (new) window
         int tag = (int)((w >> (2 * pos)) & 3u);
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             if (CW && TILED && !on_plane && x == 0 && steps == pos + 1 && j >= lo_ok(st.jc_lo)) {
                 // a straggler's long gap on a row without a stored plane: 64 words of its tile per look (lane t takes the t-th word
                 // further left), while they are all-I and lie inside the usable part of the tile
-                const int i0 = i - 1, s2 = i0 / H, rem2 = i0 - s2 * H, l2 = rem2 / R, r2 = rem2 - l2 * R, d = R + r2;
+                const int i0 = i - 1 - wrow, s2 = 0, rem2 = i0, l2 = rem2 / R, r2 = rem2 - l2 * R, d = R + r2;
                 const int t1 = (j - st.jc_lo) + l2 - 1;
                 if ((t1 & 15) == 15) {
                     const int wq = (t1 >> 4) - lane;
@@ -179,8 +185,8 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             int ht;
             if (tail_ok(i, j)) ht = (int)tail_tag(i, j);
             else if (j <= st.jc_lo) { atomicOr(err, 2); done = true; break; } // cannot happen: column jc_lo + 1 is never walked
-            else if (j < st.j_hi) { int p2; ht = (int)((load_word<true>(wtrace, wp, 0, i + 1, j + 1 - st.jc_lo, p2) >> (2 * p2)) & 3u); }
-            else ht = whcol[wp.hcol_off + i - 1] & 3;
+            else if (j < st.j_hi) { int p2; ht = (int)((load_word<true>(wtrace, wp, 0, i + 1 - wrow, j + 1 - st.jc_lo, p2) >> (2 * p2)) & 3u); }
+            else ht = whcol[wp.hcol_off + i - wrow - 1] & 3;
             k = k_of(ht);
         }
     }
@@ -196,20 +202,36 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         if (cnt > cap) atomicOr(err, 8);
         st.status = 1;
     } else {
-        // request the window (jc_lo, j] : at least fp_span(strips) wide, starting on a checkpoint column (or column 0)
-        int slot = 0;
-        if (writer) slot = atomicAdd(next_count, 1);
-        if (CW) slot = __builtin_amdgcn_readfirstlane(slot);
-        int jc = j - fp_span(pl.strips);
-        jc = jc <= 0 ? 0 : (jc / CKW) * CKW;
-        st.j_hi = j; st.jc_lo = jc; st.slot = slot; st.status = 0;
-        if (writer) next_active[slot] = p;
-        PairPlan q;
-        q.n = pl.n; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = pl.strips; // (a read of several row blocks is re-filled as as many strips)
-        q.trace_off = (int64_t)slot * fp_wwords(pl.strips) * QA * G * pl.strips; q.hcol_off = (int64_t)slot * H * pl.strips; q.rowbuf_off = (int64_t)slot * fp_wrow(pl.strips);
-        q.dcol_off = (int64_t)slot * G * pl.strips;
-        q.src = pl.src; q.col_off = jc; q.ckpt_off = pl.ckpt_off; q.rowi_off = 0;
-        if (writer) next_wplans[slot] = q;
+        // The walk needs direction bits of the row block holding row i (blocks are counted from the bottom like the sweep's: block b
+        // = rows n - 160 (b + 1) + 1 .. n - 160 b, the top block has what is left).  Normally a WINDOW (jc_lo, j] of that block: at
+        // least FP_SPAN wide, starting on a checkpoint column (or column 0).  A walk that used up a window without leaving its row
+        // block is in a long gap on a row without a stored plane: a STRAGGLER, all remaining columns of its block are re-filled as tiles.
+        const int b = (pl.n - i) / H, rb = max(0, pl.n - H * (b + 1)), rows = pl.n - H * b - rb;
+        // (a read of one row block: any second request -- a round for a handful of pairs costs more than their tiles)
+        const bool strag = force_strag || (!FIRST && (last_win || pl.strips == 1) && i > wrow && i <= wrow + wp.n);
+        st.status = 0;
+        if (strag && !TILED) {
+            int slot = 0;
+            if (writer) slot = atomicAdd(strag_count, 1);
+            if (CW) slot = __builtin_amdgcn_readfirstlane(slot);
+            if (writer) strag_active[slot] = p;
+            st.j_hi = 0; st.jc_lo = 0; st.slot = slot;
+        } else {
+            int slot = 0;
+            if (writer) slot = atomicAdd(next_count, 1);
+            if (CW) slot = __builtin_amdgcn_readfirstlane(slot);
+            int jc = j - FP_SPAN;
+            jc = jc <= 0 ? 0 : (jc / CKW) * CKW;
+            st.j_hi = j; st.jc_lo = jc; st.slot = slot;
+            if (writer) next_active[slot] = p;
+            PairPlan q;
+            q.n = rows; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = 1;
+            q.trace_off = (int64_t)slot * FP_WWORDS * QA * G; q.hcol_off = (int64_t)slot * H;
+            q.rowbuf_off = pl.rowbuf_off + (int64_t)(pl.strips - 2 - b) * (pl.m + 1); // the row the block above handed down (unused for the top block)
+            q.dcol_off = (int64_t)slot * G;
+            q.src = pl.src; q.col_off = jc; q.ckpt_off = pl.ckpt_off; q.rowi_off = 0; q.s_off = rb; q.s_pitch = pl.n;
+            if (writer) next_wplans[slot] = q;
+        }
     }
     st.i = i; st.j = j; st.k = k; st.last_op = last_op; st.cur_op = cur_op; st.cnt = cnt; st.cur_run = cur_run; st.li = li;
     if (writer) states[p] = st;
@@ -225,15 +247,19 @@ __global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan 
     const int a = x / tiles_per, c = x - a * tiles_per;
     const int p = active[a];
     const PairPlan pl = plans[p];
-    const int j_cur = states[p].j;
+    const int j_cur = states[p].j, i_cur = states[p].i;
+    const int b = (pl.n - i_cur) / H, rb = max(0, pl.n - H * (b + 1)), rows = pl.n - H * b - rb; // the row block of the walk's current row
     PairPlan q = pl;
     const int lo = c * FP_TILE, lo2 = max(0, lo - CKW); // start one checkpoint early: the first re-filled column has no usable tags
+    q.n = rows;
     q.m = (j_cur > lo) ? min(FP_TILE, j_cur - lo) + (lo - lo2) : 0;
-    q.words = (q.m + 15 + 15) / 16; q.strips = q.m > 0 ? pl.strips : 0;
-    q.trace_off = (int64_t)x * FP_TWORDS * QA * G * pl.strips; q.hcol_off = (int64_t)x * H * pl.strips; q.rowbuf_off = (int64_t)x * fp_trow(pl.strips);
-    q.dcol_off = (int64_t)x * G * pl.strips;
+    q.words = (q.m + 15 + 15) / 16; q.strips = q.m > 0 ? 1 : 0;
+    q.trace_off = (int64_t)x * FP_TWORDS * QA * G; q.hcol_off = (int64_t)x * H;
+    q.rowbuf_off = pl.rowbuf_off + (int64_t)(pl.strips - 2 - b) * (pl.m + 1);
+    q.dcol_off = (int64_t)x * G;
     q.src = pl.src; q.col_off = lo2;
     q.rowi_off = (x == 0) ? tiles_per : 0; // plan 0 carries tiles_per for the walk kernel
+    q.s_off = rb; q.s_pitch = pl.n;
     out[x] = q;
 }
 

@@ -101,7 +101,7 @@ struct Ctx {
     int64_t ws_limit = 0;
     hipStream_t own_stream = nullptr, s_in = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
-    DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo, fp_wrow, mx_idx, mx_tab, mx_score, mx_off, mx_ops, fp_prog;
+    DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo, fp_strag, mx_idx, mx_tab, mx_score, mx_off, mx_ops, fp_prog;
     DevBuf in_a, in_b, in_as, in_al, in_bs, in_bl, out_score, out_off, out_ops, out_end, sc_pairs, sc_mat, sc_err;
     // pipelined host entry (gnx_host.hip.h): double-buffered inputs, results accumulated on the device, the resident reference
     DevBuf pin_a[2], pin_as[2], pin_b[2], pin_bs[2], res_score, res_off, res_ops, ref, gat_score, gat_off, gat_ops;
@@ -244,7 +244,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     int rc;
     const int np = (int)n_pairs;
     const bool two = S >= 2; // (several row blocks)
-    const int WWORDS = fp_wwords(S), WROW = fp_wrow(S), TROW = fp_trow(S), CAP = fp_cap(S);
+    const int CAP = fp_cap(S);
     int64_t top_hi = 1; // S >= 2: the longest top block of the batch (rows above the last 160 (S - 1))
     for (int64_t p = 0; two && p < n_pairs; p++) top_hi = std::max<int64_t>(top_hi, h_alen[p] - (int64_t)H * (S - 1));
     const bool cached = c.fpc_ptr && c.fpc_ptr == c.plans.p && (int64_t)c.fpc_alen.size() == n_pairs && c.fpc_strips == S &&
@@ -257,20 +257,20 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         const int64_t n = h_alen[p], m = h_blen[p];
         pl.n = (int32_t)n; pl.m = (int32_t)m; pl.words = (int32_t)((m + 15 + 15) / 16); pl.strips = S;
         pl.trace_off = 0; pl.hcol_off = p; pl.rowbuf_off = rboff; pl.dcol_off = 0;
-        if (two) rboff += m + 1;
+        if (two) rboff += (int64_t)(S - 1) * (m + 1); // the bottom rows of the S - 1 blocks that hand one down
         pl.src = (int32_t)p; pl.col_off = 0; pl.ckpt_off = coff; pl.rowi_off = roff; pl.s_off = 0; pl.s_pitch = 0;
         roff += (int64_t)FP_PLANES * pl.words; coff += ((m - 1) / CKW) * n; cells += n * m;
         m_maxb = std::max(m_maxb, m);
     }
-    const size_t wtrace_b = (size_t)np * WWORDS * QA * G * 16 * S;
+    const size_t wtrace_b = (size_t)np * FP_WWORDS * QA * G * 16;
     const size_t need = wtrace_b + (size_t)coff * 8 + (size_t)roff * 4 + (size_t)rboff * 8 +
-                        (size_t)np * (CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + (size_t)S * (H * 4 + G * 4) + (size_t)WROW * 8 + 32);
+                        (size_t)np * (CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + (size_t)(H * 4 + G * 4) + 40);
     if ((int64_t)need > c.ws_limit) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] working set %zu B exceeds the workspace limit -> general path\n", need); return -1; }
     if ((rc = c.trace.ensure(wtrace_b))) return rc;
-    if ((rc = c.hcol.ensure((size_t)np * (H * S + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then the window hcol slots
-    if ((rc = c.dcol.ensure((size_t)np * G * S * 4))) return rc;
-    if (two && (rc = c.rowbuf.ensure((size_t)rboff * 8))) return rc;        // what the top row block hands to the bottom one
-    if (two && (rc = c.fp_wrow.ensure((size_t)np * WROW * 8))) return rc; // row buffers of the window slots
+    if ((rc = c.hcol.ensure((size_t)np * (H + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then the window hcol slots
+    if ((rc = c.dcol.ensure((size_t)np * G * 4))) return rc;
+    if ((rc = c.fp_strag.ensure((size_t)np * 2 * 4 + 64))) return rc;   // stragglers of this round / of the next one
+    if ((rc = c.rowbuf.ensure((size_t)std::max<int64_t>(rboff, 1) * 8))) return rc;   // what each row block hands to the one below it
     if (two && (rc = c.fp_prog.ensure((size_t)S * ((np + G8 - 1) / G8) * 4 + 64))) return rc; // progress words of the levels' waves
     if ((rc = c.plans.ensure((size_t)np * sizeof(PairPlan)))) return rc;
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
@@ -345,12 +345,17 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         HIPCHK(hipGetLastError());
         return GNX_OK;
     };
-    // walk / window stages of the pairs [p0, p0+cnt) on stream `st`; their window slots are [p0, p0+cnt) as well
+    // walk / window stages of the pairs [p0, p0+cnt) on stream `st`; their window slots are [p0, p0+cnt) as well.
+    // Rounds: re-fill the windows the walks asked for (one row block of one pair each), walk on; a walk that used up its window inside
+    // the same row block is a straggler (a long gap on a row without a stored plane) and gets all remaining columns of that block as
+    // tiles in the same round; walks that leave a row block through its top ask for a window of the block above.  A read of S row
+    // blocks takes S rounds (plus those of its stragglers).  cnt2: [0], [1] = window requests (ping-pong), [2] = stragglers.
     auto post = [&](int p0, int cnt, hipStream_t st, int *cnt2, hipEvent_t e1, hipEvent_t e2) -> int {
-        uint4 *wtr = reinterpret_cast<uint4 *>(c.trace.p) + (int64_t)p0 * WWORDS * QA * G * S;
-        int *whc = d_whcol + (int64_t)p0 * H * S;
-        unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * G * S;
-        int2 *wrb = two ? reinterpret_cast<int2 *>(c.fp_wrow.p) + (int64_t)p0 * WROW : nullptr;
+        uint4 *wtr = reinterpret_cast<uint4 *>(c.trace.p) + (int64_t)p0 * FP_WWORDS * QA * G;
+        int *whc = d_whcol + (int64_t)p0 * H;
+        unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * G;
+        int2 *srb = reinterpret_cast<int2 *>(c.rowbuf.p); // the sweep's row buffer: the rows the blocks handed down
+        int *d_strag = reinterpret_cast<int *>(c.fp_strag.p) + p0;
         int cur = 0, n_act = 0, it = 0;
         float f = 0;
         // The stragglers' walk through their tiles runs one WAVE per pair (lanes that walk alone diverge: 0.80 -> 0.5 ms for 1 700
@@ -363,62 +368,74 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         auto k_next = xp ? fp_walk_kernel<false, false, true> : fp_walk_kernel<false, false, false>;
         auto k_tiled = cw ? (xp ? fp_walk_kernel<false, true, true, true> : fp_walk_kernel<false, true, false, true>) : (xp ? fp_walk_kernel<false, true, true> : fp_walk_kernel<false, true, false>);
         auto wgrid = [&](int n) { return dim3((unsigned)(cw ? n : (n + 63) / 64)); };
-        auto k_win = xp ? fill_affine_kernel<false, false, false, true, true, false, true>
-                        : (two ? fill_affine_kernel<false, true, false, true, true, false, false> : fill_affine_kernel<false, false, false, true, true, false, false>);
+        auto k_win = xp ? fill_affine_kernel<false, false, false, true, true, false, true> : fill_affine_kernel<false, false, false, true, true, false, false>;
+        // GNX_FP_MAXIT = k: after k window rounds every walk that asks for more is treated as a straggler (tests: the tile path for everyone)
+        auto force = [&](int round) { return (max_it >= 0 && round >= max_it) ? 1 : 0; };
+        int h_cnt[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemsetAsync(cnt2, 0, 16, st));
         hipLaunchKernelGGL(k_first, dim3((unsigned)(cw_first ? cnt : (cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_tail,
-                           (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, d_wpl[0] + p0, d_err, p0);
+                           (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, d_wpl[0] + p0, d_err, p0, d_strag, cnt2 + 2, force(0));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&n_act, cnt2, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_cnt, cnt2, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        while (n_act > 0 && (max_it >= 0 ? it < max_it : (it == 0 || (int64_t)n_act * 25 > cnt) && it < 16)) {
+        n_act = h_cnt[0];
+        int n_strag = h_cnt[2];
+        const int max_rounds = 6 * S + 32;
+        while (n_act > 0 || n_strag > 0) {
+            if (it >= max_rounds) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %d pairs still walking after %d rounds -> general path\n", n_act + n_strag, it); return -1; }
+            // n_act window requests in list `cur`, n_strag stragglers; what they ask for next goes to list `nxt`
             const int nxt = cur ^ 1;
+            double round_ms = 0;
             HIPCHK(hipMemsetAsync(cnt2 + nxt, 0, 4, st));
-            HIPCHK(hipEventRecord(e1, st));
-            hipLaunchKernelGGL(k_win, dim3((unsigned)((n_act + 3) / 4)), blockF, 0, st, d_wpl[cur] + p0, n_act, d_a, d_as, d_b, d_bs, kp,
-                               wtr, whc, wrb, wdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(e2, st));
-            hipLaunchKernelGGL(k_next, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
-                               d_wpl[cur] + p0, wtr, whc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, d_wpl[nxt] + p0, d_err, 0);
-            HIPCHK(hipGetLastError());
-            int n_next = 0;
-            HIPCHK(hipMemcpyAsync(&n_next, cnt2 + nxt, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemsetAsync(cnt2 + 2, 0, 4, st));
+            int n_strag2 = 0;
+            if (n_act > 0) {
+                HIPCHK(hipEventRecord(e1, st));
+                hipLaunchKernelGGL(k_win, dim3((unsigned)((n_act + 3) / 4)), blockF, 0, st, d_wpl[cur] + p0, n_act, d_a, d_as, d_b, d_bs, kp,
+                                   wtr, whc, srb, wdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(e2, st));
+                // (its stragglers go to a second list: d_strag holds this round's while they are being served)
+                hipLaunchKernelGGL(k_next, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
+                                   d_wpl[cur] + p0, wtr, whc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, d_wpl[nxt] + p0, d_err, 0,
+                                   d_strag + cnt, cnt2 + 2, force(it + 1));
+                HIPCHK(hipGetLastError());
+            }
+            if (n_strag > 0) { // all remaining columns of the stragglers' row blocks as independent tiles, one launch
+                const int64_t n_tiles = (int64_t)n_strag * tiles_per;
+                const size_t tb = (size_t)n_tiles * FP_TWORDS * QA * G * 16;
+                if ((int64_t)tb > c.ws_limit || n_tiles > 0x3fffffff) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %lld straggler tiles exceed the workspace limit -> general path\n", (long long)n_tiles); return -1; }
+                int rc2;
+                if ((rc2 = c.fp_redo.ensure((size_t)n_tiles * sizeof(PairPlan)))) return rc2; // tile plans (in a buffer this path does not use otherwise)
+                if ((rc2 = c.fp_thcol.ensure((size_t)n_tiles * (H + G) * 4))) return rc2;
+                if ((rc2 = c.fp_ttrace.ensure(tb))) return rc2;
+                PairPlan *tpl = reinterpret_cast<PairPlan *>(c.fp_redo.p);
+                int *thc = reinterpret_cast<int *>(c.fp_thcol.p);
+                unsigned *tdc = reinterpret_cast<unsigned *>(thc + n_tiles * H);
+                uint4 *ttr = reinterpret_cast<uint4 *>(c.fp_ttrace.p);
+                hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, dpl, d_strag, n_strag, tiles_per, d_st, tpl);
+                HIPCHK(hipEventRecord(c.ev[6], st));
+                hipLaunchKernelGGL(k_win, dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, st, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
+                                   ttr, thc, srb, tdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
+                HIPCHK(hipEventRecord(c.ev[7], st));
+                hipLaunchKernelGGL(k_tiled, wgrid(n_strag), blockT, 0, st, dpl, d_strag, n_strag, d_st, d_hfwd, d_rowi, d_tail,
+                                   tpl, ttr, thc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, d_wpl[nxt] + p0, d_err, 0,
+                                   d_strag + cnt, cnt2 + 2, 0);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipMemcpyAsync(h_cnt, cnt2, 16, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            HIPCHK(hipEventElapsedTime(&f, e1, e2));
-            refill_ms += f;
+            if (n_act > 0) { HIPCHK(hipEventElapsedTime(&f, e1, e2)); round_ms += f; }
+            if (n_strag > 0) { HIPCHK(hipEventElapsedTime(&f, c.ev[6], c.ev[7])); round_ms += f; }
+            refill_ms += round_ms;
+            n_strag2 = h_cnt[2];
             it++;
-            if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] pairs [%d,%d) round %d: %d windows re-filled in %.3f ms, %d pairs continue\n", p0, p0 + cnt, it, n_act, f, n_next);
-            n_act = n_next;
+            if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] pairs [%d,%d) round %d: %d windows, %d stragglers (%d tiles of %d columns) re-filled in %.3f ms; next: %d windows, %d stragglers\n",
+                                             p0, p0 + cnt, it, n_act, n_strag, n_strag * tiles_per, FP_TILE, round_ms, h_cnt[nxt], n_strag2);
+            if (n_strag2 > 0) HIPCHK(hipMemcpyAsync(d_strag, d_strag + cnt, (size_t)n_strag2 * 4, hipMemcpyDeviceToDevice, st)); // the next round's stragglers
+            n_act = h_cnt[nxt];
+            n_strag = n_strag2;
             cur = nxt;
-        }
-        if (n_act > 0) { // stragglers: all their remaining columns as independent tiles, one launch
-            const int n_strag = n_act;
-            const int64_t n_tiles = (int64_t)n_strag * tiles_per;
-            const size_t tb = (size_t)n_tiles * FP_TWORDS * QA * G * 16 * S;
-            if ((int64_t)tb > c.ws_limit || n_tiles > 0x3fffffff) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] %lld straggler tiles exceed the workspace limit -> general path\n", (long long)n_tiles); return -1; }
-            int rc2;
-            if ((rc2 = (two ? c.fp_redo : c.rowbuf).ensure((size_t)n_tiles * sizeof(PairPlan)))) return rc2; // tile plans (in a buffer this path does not use otherwise)
-            if ((rc2 = c.fp_thcol.ensure((size_t)n_tiles * (H + G) * 4 * S))) return rc2;
-            if ((rc2 = c.fp_ttrace.ensure(tb))) return rc2;
-            if (two && (rc2 = c.fp_wrow.ensure((size_t)std::max<int64_t>(n_tiles * TROW, (int64_t)np * WROW) * 8))) return rc2; // (the window rounds are over)
-            PairPlan *tpl = reinterpret_cast<PairPlan *>(two ? c.fp_redo.p : c.rowbuf.p);
-            int *thc = reinterpret_cast<int *>(c.fp_thcol.p);
-            unsigned *tdc = reinterpret_cast<unsigned *>(thc + n_tiles * H * S);
-            int2 *trb = two ? reinterpret_cast<int2 *>(c.fp_wrow.p) : nullptr;
-            uint4 *ttr = reinterpret_cast<uint4 *>(c.fp_ttrace.p);
-            hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, dpl, d_act[cur] + p0, n_strag, tiles_per, d_st, tpl);
-            HIPCHK(hipEventRecord(e1, st));
-            hipLaunchKernelGGL(k_win, dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, st, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
-                               ttr, thc, trb, tdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
-            HIPCHK(hipEventRecord(e2, st));
-            HIPCHK(hipMemsetAsync(cnt2, 0, 8, st));
-            hipLaunchKernelGGL(k_tiled, wgrid(n_strag), blockT, 0, st, dpl, d_act[cur] + p0, n_strag, d_st, d_hfwd, d_rowi, d_tail,
-                               tpl, ttr, thc, tp, d_stage, d_score, d_nops, d_act[cur ^ 1] + p0, cnt2, d_wpl[cur ^ 1] + p0, d_err, 0);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));
-            HIPCHK(hipEventElapsedTime(&f, e1, e2));
-            refill_ms += f;
-            if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] pairs [%d,%d): %d stragglers: %lld tiles of %d columns re-filled in %.3f ms\n", p0, p0 + cnt, n_strag, (long long)n_tiles, FP_TILE, f);
         }
         return GNX_OK;
     };
@@ -789,13 +806,12 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const int rows_per_lane = (two || n_hi > 19 * G8) ? 20 : 19;
         if (fp) {
             // sub-batches whose fast-path working set (checkpoints, planes, window slots, staging) fits the workspace
-            const size_t fixed = ((size_t)fp_wwords(S) * QA * G * 16 + H * 4 + G * 4) * S + fp_cap(S) * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + 64 +
-                                 (size_t)fp_wrow(S) * 8;
+            const size_t fixed = (size_t)FP_WWORDS * QA * G * 16 + H * 4 + G * 4 + fp_cap(S) * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + 72;
             // ... of about equal size (a small last sub-batch would leave most of the GPU idle for the length of a sweep wave)
             std::vector<int64_t> cb{0};
             size_t acc_b = 0, total_b = 0;
             const size_t budget = (size_t)(c.ws_limit - c.ws_limit / 8);
-            auto pair_bytes = [&](int64_t p) { return fixed + (size_t)((h_cols[p] - 1) / CKW) * h_rows[p] * 8 + (size_t)FP_PLANES * ((h_cols[p] + 30) / 16) * 4 + (two ? (size_t)(h_cols[p] + 1) * 8 : 0); };
+            auto pair_bytes = [&](int64_t p) { return fixed + (size_t)((h_cols[p] - 1) / CKW) * h_rows[p] * 8 + (size_t)FP_PLANES * ((h_cols[p] + 30) / 16) * 4 + (size_t)(S - 1) * (h_cols[p] + 1) * 8; };
             for (int64_t p = 0; p < n_pairs; p++) { const size_t b = pair_bytes(p); if (b > budget) { fp = false; break; } total_b += b; }
             const size_t n_sub = (total_b + budget - 1) / budget, target = n_sub ? std::min(budget, total_b / n_sub + (size_t)(1 << 20)) : budget;
             for (int64_t p = 0; fp && p < n_pairs; p++) {
@@ -1322,7 +1338,7 @@ void gnx_shutdown(void) {
         if (!c.inited) continue;
         (void)hipSetDevice(c.device);
         (void)hipDeviceSynchronize();
-        DevBuf *bufs[] = {&c.strip_map, &c.tb_scr, &c.tb_scr_off, &c.scan_tmp, &c.fp_redo, &c.fp_wrow, &c.mx_idx, &c.mx_tab, &c.mx_score, &c.mx_off, &c.mx_ops, &c.fp_prog, &c.fp_tail, &c.fp_thcol, &c.fp_ttrace, &c.fp_rowi, &c.fp_ckpt, &c.fp_states, &c.fp_stage,
+        DevBuf *bufs[] = {&c.strip_map, &c.tb_scr, &c.tb_scr_off, &c.scan_tmp, &c.fp_redo, &c.fp_strag, &c.mx_idx, &c.mx_tab, &c.mx_score, &c.mx_off, &c.mx_ops, &c.fp_prog, &c.fp_tail, &c.fp_thcol, &c.fp_ttrace, &c.fp_rowi, &c.fp_ckpt, &c.fp_states, &c.fp_stage,
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,

@@ -47,18 +47,14 @@ struct PairPlan {
 };
 
 constexpr int CKW = 128;     // column checkpoint spacing of the fast path
-constexpr int FP_SPAN = 192; // a re-fill window of a one-block read is at least this wide (>= 160 rows + typical indels)
+constexpr int FP_SPAN = 192; // a re-fill window (one row block of <= 160 rows) is at least this wide: the rows + typical indels
 constexpr int FP_PLANES = 4; // rows n .. n-3 keep their I-plane: a trailing gap sits on row n-d when the last d bases match the chunk end
 constexpr int FP_CAP = 64;   // CIGAR runs staged per pair and row block on the fast path (more -> general path)
 constexpr int FP_MAXS = 10;  // row blocks of 160 rows the fast path sweeps (reads up to 1600 bases; longer ones: snapshot path)
 constexpr int FP_TILE = 1024;                                  // straggler tiles: columns (c*FP_TILE, (c+1)*FP_TILE]
 constexpr int FP_TWORDS = (FP_TILE + CKW + 15 + 15) / 16;      // direction words of a tile (plus the checkpoint interval it starts early)
-// per number of row blocks S (= strips of the window / tile re-fills):
-__host__ __device__ constexpr int fp_span(int S) { return S <= 1 ? FP_SPAN : S * H + 32; }            // least window width: the read's rows + typical indels
-__host__ __device__ constexpr int fp_wwords(int S) { return (fp_span(S) + CKW + 15 + 15) / 16 + 1; }   // direction words of the widest window
-__host__ __device__ constexpr int fp_wrow(int S) { return (S - 1) * (fp_span(S) + CKW + 8); }          // row-buffer entries of a window slot (S - 1 strips hand a row down)
-__host__ __device__ constexpr int fp_trow(int S) { return (S - 1) * (FP_TILE + CKW + 8); }             // ... of a tile
-__host__ __device__ constexpr int fp_cap(int S) { return FP_CAP * (S < 1 ? 1 : S); }                   // staged CIGAR runs per pair
+constexpr int FP_WWORDS = (FP_SPAN + CKW + 15 + 15) / 16 + 1;                                         // direction words of the widest window
+__host__ __device__ constexpr int fp_cap(int S) { return FP_CAP * (S < 1 ? 1 : S); }                   // staged CIGAR runs per pair of S row blocks
 
 struct KParams {
     int sc4[25]; // 4*scores
