@@ -718,14 +718,14 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         if (prm->gap_open <= -8000) fp = false;
         for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * prm->gap_extend); if (v > 32767 || v < -32000) fp = false; }
         // Row blocks of 160 rows per pair (fp_sweep_kernel's ROLE): 1 = the read fits one block; 2 .. FP_MAXS = swept as that many blocks
-        // (global AffineGap only; from 3 blocks on only against windows of >= 3 n columns: the window re-fill behind the sweep covers
-        // ~n + 100 columns at the general kernel's rate, so a squarish pair would be filled twice); 0 = not for the fast path.
+        // (global AffineGap only); 0 = not for the fast path.  The walk re-fills ~256 columns per row block whatever the window
+        // length, so the path pays from ~768 columns on (a third of the cells again at half the sweep's rate).
         const bool forced = fpenv && fpenv[0] == '2'; // no shape rules (tests)
         auto key_of = [&](int64_t n, int64_t m) -> int {
             if (n < 1 || m < 1 || m > 0x3fffffff || (n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) return 0;
             const int64_t Sp = (n + H - 1) / H;
             if (Sp > FP_MAXS || (xp && Sp > 1)) return 0;
-            if (!forced && (m < 768 || (Sp >= 3 && m < 3 * n))) return 0;
+            if (!forced && m < 768) return 0;
             return (int)Sp;
         };
         int64_t n_hi = 0, cntk[FP_MAXS + 1] = {0};

@@ -592,9 +592,9 @@ def test_fast_path_mixed_read_lengths(gpu_lib, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,n_lo,n_hi", [(61, 321, 480), (62, 481, 640), (63, 1441, 1600), (64, 700, 800)])
+@pytest.mark.parametrize("seed,n_lo,n_hi", [(61, 321, 480), (62, 481, 640), (63, 1441, 1600), (64, 700, 800), (65, 3041, 3200)])
 def test_fast_path_many_row_blocks(gpu_lib, seed, n_lo, n_hi, monkeypatch):
-    """reads of 321 .. 1600 bases on the fast path: a top block, middle blocks (fp_sweep_kernel<20, false, 3>: take the row above from the
+    """reads of 321 .. 3200 bases on the fast path: a top block, middle blocks (fp_sweep_kernel<20, false, 3>: take the row above from the
     row buffer and hand their own bottom row down in place) and the bottom block; windows and straggler tiles re-filled as S strips.
     Every number of slots per lane of the top block, ragged windows, several penalty sets, small checkerboards, forced rounds."""
     monkeypatch.setenv("GNX_FASTPATH", "2")
@@ -642,7 +642,7 @@ def test_fast_path_many_row_blocks(gpu_lib, seed, n_lo, n_hi, monkeypatch):
 @pytest.mark.gpu
 def test_fast_path_row_blocks_natural_routing(gpu_lib):
     """6400 reads of 330 .. 480 bases against 1500-base windows without any switch: three row blocks by the routing rule of run_device
-    (>= 6144 pairs, windows >= 3 n); and the same batch mixed with shorter reads and with pairs that are not for the fast path."""
+    (pairs x row blocks >= 8192, windows >= 768 columns); and the same batch mixed with shorter reads and with pairs that are not for the fast path."""
     rng = np.random.default_rng(91)
     P, L = 6400, 1500
     reads, chunk = common.c2_workload(91, P, read_len=480, chunk_len=L)
@@ -661,3 +661,19 @@ def test_fast_path_row_blocks_natural_routing(gpu_lib):
     got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, lens2, chunk, b_start, b_len2)
     exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads.reshape(-1), a_start, lens2, chunk, b_start, b_len2, threads=16)
     common.assert_same(got, exp, "mixed numbers of row blocks")
+
+
+@pytest.mark.gpu
+def test_fast_path_long_reads(gpu_lib, monkeypatch):
+    """AffineGap(20 kb ONT-like read, 100 kb window) on the fast path: 125 row blocks in one launch, 125 walk rounds (SURVEY's C5 shape with
+    the affine recurrence; two pairs are too few for the routing rule, so the path is forced)"""
+    import bench
+    monkeypatch.setenv("GNX_FASTPATH", "2")
+    reads, wins = bench.make_long_workload(5, 2, n=20000, m=100000)
+    alphas = [reads[0], reads[1][:19900]]
+    betas = [wins[0], wins[1][:99000]]
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+    got = gpu_lib.align_batch(p, alphas, betas)
+    assert gpu_lib.get_timing()["fast_path"] == 1
+    exp = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, alphas, betas, threads=2)
+    common.assert_same(got, exp, "20 kb x 100 kb on the fast path")

@@ -24,7 +24,7 @@ def main():
     dev = torch.device("cuda", 0)
     mode, go, ge = (_lib.GNX_CONST_GAP, -430, 0) if kind == "const" else (_lib.GNX_AFFINE_GAP, -600, -150)
     p = _lib.make_params(mode, align.HumanChimpTwoScoreMatrix, go, ge)
-    shapes = ((150, 10000, 65536), (250, 10000, 40000), (320, 10000, 32768), (480, 10000, 20000), (800, 10000, 12000), (1600, 10000, 8192 if kind == "affine" else 6000), (3200, 10000, 3000), (1000, 1200, 100000))
+    shapes = ((150, 10000, 65536), (250, 10000, 40000), (320, 10000, 32768), (480, 10000, 20000), (800, 10000, 12000), (1600, 10000, 8192 if kind == "affine" else 6000), (3200, 10000, 3000), (1000, 1200, 100000)) + (((20000, 100000, 256),) if kind == "affine" else ())
     if len(sys.argv) > 2:  # one shape: n,m,pairs
         shapes = (tuple(int(x) for x in sys.argv[2].split(",")),)
     for n, m, pairs in shapes:
@@ -41,7 +41,7 @@ def main():
         row = {"kind": kind, "n": n, "m": m, "pairs": pairs}
         res = {}
         variants = [("general", {"GNX_CLONG": "0", "GNX_FASTPATH": "0"}), ("default", {})]
-        if kind == "affine" and n <= 3200 and m >= 3 * n:
+        if kind == "affine" and n <= 20480 and m >= 768:
             variants.append(("row_blocks", {"GNX_FASTPATH": "2"}))  # the fast path whatever the routing rule says
         for name, env in variants:
             for k in ("GNX_CLONG", "GNX_FASTPATH"):
