@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the raw outputs of tools/gpu_round.sh (gpurun_out/<tag>/) into the committed evidence under profiles/:
-  <round>_kernel_stats.csv, <round>_kernel_stats_long.csv   rocprofv3 --kernel-trace --stats summaries (kernel names shortened)
+  <round>_kernel_stats.csv, <round>_kernel_stats_long.csv, <round>_kernel_stats_row_blocks.csv   rocprofv3 --kernel-trace --stats summaries (kernel names shortened)
   <round>_pmc_hbm.csv        FETCH_SIZE / WRITE_SIZE rows of the dominant kernels (separate --pmc passes)
   <round>_pmc_sq.csv         SQ counter passes of the two sweep kernels
   <round>_hbm_traffic.json   HBM bytes per pair of the dominant kernel per (series, path), FETCH_SIZE doubled (gfx950 correction,
@@ -40,7 +40,7 @@ def pmc_rows(d):
 def main():
     src, rnd = sys.argv[1], sys.argv[2]
     prof = os.path.join(ROOT, "profiles")
-    for sub, dst in (("stats", "_kernel_stats.csv"), ("stats_long", "_kernel_stats_long.csv")):
+    for sub, dst in (("stats", "_kernel_stats.csv"), ("stats_long", "_kernel_stats_long.csv"), ("stats_rb", "_kernel_stats_row_blocks.csv")):
         for path in glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True):
             with open(path) as fh, open(os.path.join(prof, rnd + dst), "w") as out:
                 wr = csv.writer(out)

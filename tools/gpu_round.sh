@@ -16,6 +16,8 @@ cd /tmp
 Q="--no-cpu --no-host --verify 0"
 timeout 900 rocprofv3 --kernel-trace --stats -d $out/stats -o stats --output-format csv -- python $repo/bench.py $Q --steps 3 --warmup 1 > $out/stats_bench.json 2> $out/stats.err
 timeout 900 rocprofv3 --kernel-trace --stats -d $out/stats_long -o stats --output-format csv -- python $repo/bench.py $Q --series long --pairs 1024 --steps 2 --warmup 1 > $out/stats_long_bench.json 2>> $out/stats.err
+# reads of 800 bases (5 row blocks in one launch: fp_sweep_levels_kernel) and 20 kb x 100 kb (125 row blocks)
+timeout 900 rocprofv3 --kernel-trace --stats -d $out/stats_rb -o stats --output-format csv -- python $repo/tools/bench_shapes.py affine 800,10000,32768 > $out/stats_rb_bench.json 2>> $out/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c -d $out/pmc_fast_$c -o pmc --output-format csv -- python $repo/bench.py $Q --steps 1 --warmup 0 > /dev/null 2> $out/pmc.err
   GNX_FASTPATH=0 timeout 900 rocprofv3 --pmc $c -d $out/pmc_general_$c -o pmc --output-format csv -- python $repo/bench.py $Q --steps 1 --warmup 0 > /dev/null 2>> $out/pmc.err
