@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         for (int q = 0; q < 4; q++) m_min = min(m_min, (pbase + q < n_pairs && s < plans[pbase + q].strips) ? plans[pbase + q].m : 0);
         const bool store_row = MULTI && gact && (s + 1 < pl.strips);
         const int row0 = s * H + l * R; // 0-based index of this lane's first row == 1-based index of the row above it
-        const int r_last = XP ? pl.n - 1 - row0 : -1; // XP: slot of the pair's last row in this lane (if 0 <= r_last < R)
+        const int r_last = (XP && row_base + pl.n == ck_pitch) ? pl.n - 1 - row0 : -1; // XP: slot of the pair's last row in this lane (if 0 <= r_last < R; windows of the bottom row block only)
         int rt[R], hold[R];
         unsigned acc[3 * R]; // direction accumulators: [0,R) M, [R,2R) I, [2R,3R) D
         if (!SCORED) { // score profile of this lane's rows: prof[b][lane][k]

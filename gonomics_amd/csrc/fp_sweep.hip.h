@@ -84,7 +84,6 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
                                               unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err,
                                               int2 *__restrict__ rowbuf, const int below, const bool piped, const int *prog_in, int *prog_out) {
     static_assert(RR <= 2 * FP8_LW && RR > FP_PLANES, "rows per lane");
-    static_assert(ROLE == 0 || !XP, "two row blocks: global alignment only");
     static_assert(ROLE < 2 || RR == 2 * FP8_LW, "the bottom and middle row blocks are full: 8 x 20 slots");
     constexpr bool BOTTOM = (ROLE == 0 || ROLE == 2); // holds row n: planes, corner tags, h(n,m)
     constexpr bool HANDS = (ROLE == 1 || ROLE == 3);  // hands its bottom row down through the row buffer
@@ -123,8 +122,8 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     // every DPP move (the values below are those of "step -1")
     asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vO4), "=v"(cH), "=v"(cDN)
                  : "s"(kp.o4), "s"(XP ? E4 + TI : kp.o4 + 2), "s"(XP ? kp.o4 + E4 + TI : 2 * kp.o4 + 2));
-    const int vInc = (XP && lp == 0) ? -E4 : 0;
-    const int vO4L = (XP && lp == G8 - 1) ? -E4 : kp.o4; // horizontal open of the last slot: the last row's step is free (XP)
+    const int vInc = (XP && !TAKES && lp == 0) ? -E4 : 0;           // (row 0 is above the top block only)
+    const int vO4L = (XP && BOTTOM && lp == G8 - 1) ? -E4 : kp.o4;  // horizontal open of the last slot: the step of the pair's last row is free (XP)
 
     { // int16 profile of this lane's rows: prof[b][lp][r] = 4*(scores[alpha[row]][b] - 2e), padding -32768
         int a5[2 * FP8_LW];
@@ -194,7 +193,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         up_dn = dpp_prev8(TAKES ? rq.x : up_dn, dn_out);
         up_h = dpp_prev8(TAKES ? rq.y : up_h, h_out);
         if (TAKES) { rq.x = dpp_next8(rq.x); rq.y = dpp_next8(rq.y); }
-        if (XP) { up_dn += vInc; up_h += vInc; }
+        if (XP && !TAKES) { up_dn += vInc; up_h += vInc; }
         const int pb = dpp_prev8(qb, b_out);
         qb = dpp_next8(qb);
         const int j = t - lp;
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
 //              Level-major order beats wave-major -- the levels of a wave group as grid neighbours, in lockstep -- 51.4 / 54.1 ms.)
 //   piped = 0: one launch per level in turn (n_levels = 1): nothing to wait for (GNX_NO_PIPE, and the fallback after a timeout).
 // RRTOP = slots per lane of the top block (as few as hold the longest read's rows above the full blocks).
-template <int RRTOP>
+template <int RRTOP, bool XP = false>
 __global__ __launch_bounds__(64) void fp_sweep_levels_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                              const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                              const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
@@ -339,9 +338,9 @@ __global__ __launch_bounds__(64) void fp_sweep_levels_kernel(const PairPlan *__r
     const int lv = (int)blockIdx.x / W, w = (int)blockIdx.x - lv * W, level = level0 + lv, below = S - 1 - level;
     int *po = prog + (int64_t)level * W + w;
     const int *pi = po - W;
-    if (level == 0) fp_sweep_body<RRTOP, false, 1>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, nullptr, po);
-    else if (below == 0) fp_sweep_body<2 * FP8_LW, false, 2>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, 0, piped != 0, pi, nullptr);
-    else fp_sweep_body<2 * FP8_LW, false, 3>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, pi, po);
+    if (level == 0) fp_sweep_body<RRTOP, XP, 1>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, nullptr, po);
+    else if (below == 0) fp_sweep_body<2 * FP8_LW, XP, 2>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, 0, piped != 0, pi, nullptr);
+    else fp_sweep_body<2 * FP8_LW, XP, 3>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, pi, po);
 }
 
 } // namespace

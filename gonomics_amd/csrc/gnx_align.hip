@@ -319,7 +319,8 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         if (two) { // S row blocks ("levels"): one launch, each level following the one above it through the row buffer (GNX_NO_PIPE: a launch per level)
             int2 *rb = reinterpret_cast<int2 *>(c.rowbuf.p);
             const int top_rows = (int)(top_hi + G8 - 1) / G8; // slots per lane of the top block: as few as hold the longest read's rows above the full blocks
-            auto klev = top_rows <= 8 ? fp_sweep_levels_kernel<8> : (top_rows <= 12 ? fp_sweep_levels_kernel<12> : (top_rows <= 16 ? fp_sweep_levels_kernel<16> : fp_sweep_levels_kernel<20>));
+            auto klev = xp ? (top_rows <= 8 ? fp_sweep_levels_kernel<8, true> : (top_rows <= 12 ? fp_sweep_levels_kernel<12, true> : (top_rows <= 16 ? fp_sweep_levels_kernel<16, true> : fp_sweep_levels_kernel<20, true>)))
+                           : (top_rows <= 8 ? fp_sweep_levels_kernel<8> : (top_rows <= 12 ? fp_sweep_levels_kernel<12> : (top_rows <= 16 ? fp_sweep_levels_kernel<16> : fp_sweep_levels_kernel<20>)));
             const int W = (int)grid8.x;
             int *prog = reinterpret_cast<int *>(c.fp_prog.p);
             if (!no_pipe()) {
@@ -718,13 +719,13 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         if (prm->gap_open <= -8000) fp = false;
         for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * prm->gap_extend); if (v > 32767 || v < -32000) fp = false; }
         // Row blocks of 160 rows per pair (fp_sweep_kernel's ROLE): 1 = the read fits one block; 2 .. FP_MAXS = swept as that many blocks
-        // (global AffineGap only); 0 = not for the fast path.  The walk re-fills ~256 columns per row block whatever the window
+        // (AffineGapLocal: of its query, the rows of the transposed problem); 0 = not for the fast path.  The walk re-fills ~256 columns per row block whatever the window
         // length, so the path pays from ~768 columns on (a third of the cells again at half the sweep's rate).
         const bool forced = fpenv && fpenv[0] == '2'; // no shape rules (tests)
         auto key_of = [&](int64_t n, int64_t m) -> int {
             if (n < 1 || m < 1 || m > 0x3fffffff || (n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) return 0;
             const int64_t Sp = (n + H - 1) / H;
-            if (Sp > FP_MAXS || (xp && Sp > 1)) return 0;
+            if (Sp > FP_MAXS) return 0;
             if (!forced && m < 768) return 0;
             return (int)Sp;
         };
@@ -829,7 +830,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             for (size_t ch = 0; fp && ch + 1 < cb.size(); ch++) {
                 const int64_t b = cb[ch], e = cb[ch + 1];
                 if (xp) rc = run_device_fp(prm, kpx, tp, e - b, d_b, d_bs + b, d_a, d_as + b, h_blen + b, h_alen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
-                                           d_ops_off + b, out_total, stream, ch == 0, true, 1);
+                                           d_ops_off + b, out_total, stream, ch == 0, true, S);
                 else rc = run_device_fp(prm, kp, tp, e - b, d_a, d_as + b, d_b, d_bs + b, h_alen + b, h_blen + b, rows_per_lane, d_score + b, d_ops, ops_capacity,
                                         d_ops_off + b, out_total, stream, ch == 0, false, S);
                 // a CIGAR buffer that is too small does not end the loop: the remaining sub-batches still count their runs (the offset

@@ -677,3 +677,47 @@ def test_fast_path_long_reads(gpu_lib, monkeypatch):
     assert gpu_lib.get_timing()["fast_path"] == 1
     exp = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, alphas, betas, threads=2)
     common.assert_same(got, exp, "20 kb x 100 kb on the fast path")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,q_lo,q_hi", [(71, 161, 320), (72, 321, 480), (73, 700, 800)])
+def test_fast_path_local_transposed_row_blocks(gpu_lib, seed, q_lo, q_hi, monkeypatch):
+    """AffineGapLocal with a query of more than 160 bases: the transposed fast path with several row blocks (free row 0 above the top
+    block only, free last-row step in the bottom block only, fake padding rows in the top block); queries at the target's ends and in
+    the middle, unrelated queries, targets shorter than the query, several penalty sets, mixed with short queries."""
+    monkeypatch.setenv("GNX_FASTPATH", "2")
+    rng = np.random.default_rng(seed)
+    L = 5000
+    ref = rng.integers(0, 4, size=L, dtype=np.uint8)
+    ref[rng.integers(0, L, size=8)] = 4
+    targets, queries = [], []
+    for k in range(120):
+        n = int(rng.integers(q_lo, q_hi + 1)) if k >= 4 else [q_lo, q_hi, q_lo + 1, q_hi - 1][k]
+        m = int(rng.choice([n // 3, n - 1, n, n + 127, n + 129, 2 * n + 1, 2049, 4000]))
+        m = max(1, min(m, L))
+        off = int(rng.integers(0, L - m + 1))
+        target = ref[off:off + m].copy()
+        where = k % 4
+        pos = 0 if where == 0 else (max(0, m - n) if where == 1 else int(rng.integers(0, max(1, m - n + 1))))
+        query = common.mutate(rng, target[pos:pos + n + 30], 0.05, 0.02) if m >= n and rng.random() < 0.8 else rng.integers(0, 4, size=n, dtype=np.uint8)
+        query = query[:n]
+        if query.shape[0] < q_lo:
+            query = np.concatenate([query, rng.integers(0, 4, size=q_lo - query.shape[0], dtype=np.uint8)])
+        targets.append(target); queries.append(query)
+    for name, go, ge in [("HumanChimpTwo", -600, -150), ("Default", -400, -30), ("HumanChimpTwo", 0, -150), ("MouseRat", -3, -1)]:
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_LOCAL, MX[name], go, ge)
+        got = gpu_lib.align_batch(p, targets, queries)
+        if go == -600:
+            assert gpu_lib.get_timing()["fast_path"] == 1
+        exp = oracle.align_batch(3, MX[name], go, ge, targets, queries, threads=8)
+        common.assert_same(got, exp, "local transposed, row blocks %s %d %d" % (name, go, ge))
+    # mixed with short queries (sub-batches per number of row blocks), forced straggler rounds, a launch per level
+    queries2 = [q[:int(rng.integers(1, 161))] if k % 3 == 0 else q for k, q in enumerate(queries)]
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_LOCAL, MX["HumanChimpTwo"], -600, -150)
+    exp = oracle.align_batch(3, MX["HumanChimpTwo"], -600, -150, targets, queries2, threads=8)
+    common.assert_same(gpu_lib.align_batch(p, targets, queries2), exp, "local transposed, mixed query lengths")
+    monkeypatch.setenv("GNX_FP_MAXIT", "0")
+    common.assert_same(gpu_lib.align_batch(p, targets, queries2), exp, "local transposed, tiles for everyone")
+    monkeypatch.delenv("GNX_FP_MAXIT")
+    monkeypatch.setenv("GNX_NO_PIPE", "1")
+    common.assert_same(gpu_lib.align_batch(p, targets, queries2), exp, "local transposed, a launch per level")

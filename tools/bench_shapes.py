@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel time of one batch per shape and path (device-resident inputs): where does the constant-gap path without a stored direction matrix
-(GNX_CLONG) / the affine fast path beat the general path?  Usage: python tools/bench_shapes.py [const|affine] [n,m,pairs]"""
+(GNX_CLONG) / the affine fast path beat the general path?  Usage: python tools/bench_shapes.py [const|affine|local] [n,m,pairs]"""
 import ctypes
 import json
 import os
@@ -22,9 +22,11 @@ def main():
     L = _lib.lib()
     _lib.check(L.gnx_init(0, 120 << 30))
     dev = torch.device("cuda", 0)
-    mode, go, ge = (_lib.GNX_CONST_GAP, -430, 0) if kind == "const" else (_lib.GNX_AFFINE_GAP, -600, -150)
+    mode, go, ge = (_lib.GNX_CONST_GAP, -430, 0) if kind == "const" else ((_lib.GNX_AFFINE_GAP_LOCAL if kind == "local" else _lib.GNX_AFFINE_GAP), -600, -150)
     p = _lib.make_params(mode, align.HumanChimpTwoScoreMatrix, go, ge)
     shapes = ((150, 10000, 65536), (250, 10000, 40000), (320, 10000, 32768), (480, 10000, 20000), (800, 10000, 12000), (1600, 10000, 8192 if kind == "affine" else 6000), (3200, 10000, 3000), (1000, 1200, 100000)) + (((20000, 100000, 256),) if kind == "affine" else ())
+    if kind == "local":
+        shapes = ((150, 10000, 65536), (250, 10000, 40000), (800, 10000, 12000), (3200, 10000, 3000))
     if len(sys.argv) > 2:  # one shape: n,m,pairs
         shapes = (tuple(int(x) for x in sys.argv[2].split(",")),)
     for n, m, pairs in shapes:
@@ -41,7 +43,7 @@ def main():
         row = {"kind": kind, "n": n, "m": m, "pairs": pairs}
         res = {}
         variants = [("general", {"GNX_CLONG": "0", "GNX_FASTPATH": "0"}), ("default", {})]
-        if kind == "affine" and n <= 20480 and m >= 768:
+        if kind != "const" and n <= 20480 and m >= 768:
             variants.append(("row_blocks", {"GNX_FASTPATH": "2"}))  # the fast path whatever the routing rule says
         for name, env in variants:
             for k in ("GNX_CLONG", "GNX_FASTPATH"):
@@ -51,8 +53,12 @@ def main():
             for it in range(3):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                rc = L.gnx_align_batch_device(ctypes.byref(p), pairs, d_reads.data_ptr(), d_as.data_ptr(), 0, d_chunk.data_ptr(), d_bs.data_ptr(), 0,
-                                              h_al.ctypes.data, h_bl.ctypes.data, d_score.data_ptr(), d_ops.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(tot), None)
+                if kind == "local":  # AffineGapLocal(target = chunk, query = read)
+                    rc = L.gnx_align_batch_device(ctypes.byref(p), pairs, d_chunk.data_ptr(), d_bs.data_ptr(), 0, d_reads.data_ptr(), d_as.data_ptr(), 0,
+                                                  h_bl.ctypes.data, h_al.ctypes.data, d_score.data_ptr(), d_ops.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(tot), None)
+                else:
+                    rc = L.gnx_align_batch_device(ctypes.byref(p), pairs, d_reads.data_ptr(), d_as.data_ptr(), 0, d_chunk.data_ptr(), d_bs.data_ptr(), 0,
+                                                  h_al.ctypes.data, h_bl.ctypes.data, d_score.data_ptr(), d_ops.data_ptr(), cap, d_off.data_ptr(), ctypes.byref(tot), None)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 _lib.check(rc)

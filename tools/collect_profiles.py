@@ -121,7 +121,7 @@ def main():
         json.dump(traffic, fh, indent=1)
         fh.write("\n")
     for nm, dst in (("bench.json", "_bench.json"), ("bench_long.json", "_bench_long.json"), ("all_series.jsonl", "_all_series.jsonl"), ("host_entry.jsonl", "_host_entry.jsonl"),
-                    ("shapes_affine.jsonl", "_shapes_affine.jsonl"), ("shapes_const.jsonl", "_shapes_const.jsonl"), ("gsw_reads.jsonl", "_gsw_reads.jsonl"), ("cabi_n1_n2.jsonl", "_cabi_n1_n2.jsonl"),
+                    ("shapes_affine.jsonl", "_shapes_affine.jsonl"), ("shapes_const.jsonl", "_shapes_const.jsonl"), ("shapes_local.jsonl", "_shapes_local.jsonl"), ("gsw_reads.jsonl", "_gsw_reads.jsonl"), ("cabi_n1_n2.jsonl", "_cabi_n1_n2.jsonl"),
                     ("pytest_gpu.log", "_pytest_gpu.log")):
         p = os.path.join(src, nm)
         if os.path.exists(p) and os.path.getsize(p) > 0:
