@@ -38,7 +38,8 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                                                      int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                      int *__restrict__ next_active, int *__restrict__ next_count,
                                                      PairPlan *__restrict__ next_wplans, int *__restrict__ err, int p_base,
-                                                     int *__restrict__ strag_active, int *__restrict__ strag_count, int force_strag) {
+                                                     int *__restrict__ strag_active, int *__restrict__ strag_count, int force_strag,
+                                                     const int2 *__restrict__ rowbuf) {
     const int a = CW ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (a >= n_active) return;
     const int lane = threadIdx.x & 63;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             int ht;
             if (tail_ok(i, j)) ht = (int)tail_tag(i, j);
             else if (j <= st.jc_lo) { atomicOr(err, 2); done = true; break; } // cannot happen: column jc_lo + 1 is never walked
+            else if (i == wrow) ht = rowbuf[wp.rowbuf_off + j].y & 3; // the entry cell is in the bottom row of the block above: the key that block handed down
             else if (j < st.j_hi) { int p2; ht = (int)((load_word<true>(wtrace, wp, 0, i + 1 - wrow, j + 1 - st.jc_lo, p2) >> (2 * p2)) & 3u); }
             else ht = whcol[wp.hcol_off + i - wrow - 1] & 3;
             k = k_of(ht);

@@ -721,3 +721,24 @@ def test_fast_path_local_transposed_row_blocks(gpu_lib, seed, q_lo, q_hi, monkey
     monkeypatch.delenv("GNX_FP_MAXIT")
     monkeypatch.setenv("GNX_NO_PIPE", "1")
     common.assert_same(gpu_lib.align_batch(p, targets, queries2), exp, "local transposed, a launch per level")
+
+
+@pytest.mark.gpu
+def test_stress_regression_q1_at_block_top(gpu_lib, monkeypatch):
+    """a batch tools/stress.py found (round 2): 64 x 64 checkerboards, reads of 1 .. 5 row blocks against 568-base windows, tiles for
+    everyone.  A vertical step out of a row block's first row in the first column of a window / tile, on a checkerboard edge (quirk Q1),
+    needs the argmax tag of a cell of the block above: it is the key that block handed down (fp_walk_kernel, `i == wrow`)."""
+    d = np.load(os.path.join(common.DATA, "stress_r2_q1_block_top.npz"), allow_pickle=True)
+    mode, go, ge, cs = int(d["mode"]), int(d["go"]), int(d["ge"]), int(d["cs"])
+    mx = d["mx"]
+    alphas = [np.asarray(a, dtype=np.uint8) for a in d["alphas"]]
+    betas = [np.asarray(b, dtype=np.uint8) for b in d["betas"]]
+    exp = oracle.align_batch(mode, mx, go, ge, alphas, betas, cs, cs, threads=8)
+    p = gpu_lib.make_params(mode, mx, go, ge, cs, cs)
+    monkeypatch.setenv("GNX_FASTPATH", "2")
+    for maxit in ("0", "1", None):
+        if maxit is None:
+            monkeypatch.delenv("GNX_FP_MAXIT")
+        else:
+            monkeypatch.setenv("GNX_FP_MAXIT", maxit)
+        common.assert_same(gpu_lib.align_batch(p, alphas, betas), exp, "stress batch, maxit %s" % maxit)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle stress (not part of the pytest suite): many batch shapes, matrices, penalties and
-checkerboard sizes, biased towards the short-alpha fast path.  Usage: python tools/stress.py [seconds] [seed]"""
+checkerboard sizes, biased towards the fast path (one row block and several).  Usage: python tools/stress.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -28,10 +28,35 @@ def main():
         name, mx = mats[int(rng.integers(len(mats)))]
         go = int(rng.choice([0, -1, -30, -400, -600, -900]))
         ge = int(rng.choice([-1, -30, -55, -150, -400]))
-        kind = int(rng.integers(0, 7))
+        kind = int(rng.integers(0, 10))
         n = int(rng.integers(1, 161))
         cnt = int(rng.integers(1, 40))
-        if kind <= 2:  # fast-path shape: short alpha (uniform or mixed lengths), long beta (shared chunk or per-pair windows)
+        for k in ("GNX_FASTPATH", "GNX_FP_MAXIT", "GNX_NO_PIPE"):
+            os.environ.pop(k, None)
+        if kind >= 7:  # reads of several row blocks on the (forced) fast path: mixed numbers of blocks, both orientations, forced straggler rounds
+            os.environ["GNX_FASTPATH"] = "2"
+            if rng.random() < 0.3:
+                os.environ["GNX_FP_MAXIT"] = str(int(rng.choice([0, 1, 3])))
+            if rng.random() < 0.2:
+                os.environ["GNX_NO_PIPE"] = "1"
+            n_top = int(rng.choice([200, 320, 500, 800, 1300]))
+            uniform = rng.random() < 0.4
+            m = int(rng.integers(300, 5000))
+            chunk = rng.integers(0, 5 if rng.random() < 0.3 else 4, size=m + 1700).astype(np.uint8)
+            alphas, betas = [], []
+            for _ in range(cnt):
+                n = int(rng.integers(max(1, n_top - 150), n_top + 1)) if uniform else int(rng.integers(1, n_top + 1))
+                off = int(rng.integers(0, m - 1))
+                src = chunk[off:off + n + 60]
+                a = common.mutate(rng, src, sub=float(rng.choice([0.0, 0.02, 0.15])), indel=float(rng.choice([0.0, 0.01, 0.08])), geo=0.4)
+                if len(a) < n:
+                    a = np.concatenate([a, rng.integers(0, 4, size=n - len(a)).astype(np.uint8)])
+                alphas.append(a[:n])
+                betas.append(chunk[:m] if rng.random() < 0.7 else chunk[int(rng.integers(0, 300)):][:m])
+            mode = int(rng.choice([0, 0, 2, 3, 3]))
+            if mode == 3:
+                alphas, betas = betas, alphas
+        elif kind <= 2:  # fast-path shape: short alpha (uniform or mixed lengths), long beta (shared chunk or per-pair windows)
             mixed = rng.random() < 0.5
             n_top = n
             m = int(rng.integers(768, 6000))
