@@ -1,0 +1,691 @@
+// gonomics_genomegraph.hpp -- C++ host mirror of the graph aligner's read path over the C ABI of libgonomics_align_hip.so
+// ("next" rows N2 and N4 of SURVEY 8f).  Header-only, C++17.  Same structure and the same parity contract as the Python mirror
+// gonomics_amd/genomeGraph.py (see its module docstring: UNPINNED by the reference's tests; value semantics where Go shares
+// backing arrays between sibling branches; > 100 seeds sorted stably by TotalLength).
+//
+//   N2  LeftDynamicAln / RightDynamicAln               /root/reference/genomeGraph/search.go:234-321   -> gnx_gsw_extend_batch
+//       LeftAlignTraversal / RightAlignTraversal        search.go:166-232                               -> Traversal (explicit stack)
+//       GraphSmithWatermanToGiraf                       genomeGraph/toGiraf.go:17-72                    -> GswBatchToGiraf
+//   N4  IndexGenomeIntoMap                              genomeGraph/index.go:21-59                      -> SeedIndex (gnx_seed_index_build)
+//       seedMapMemPool, extendToTheRightDev / LeftDev   search.go:425-590                               -> seedMapBatch (gnx_seed_find_batch)
+//       dnaTwoBit.CountRightMatches / CountLeftMatches  dna/dnaTwoBit/perfectAlign.go:10-85
+//       seedCouldBeBetter                               index.go:102-121
+//
+// The reference's recursion (a traversal calls the DP at its leaves and hands the route from one sibling branch to the next) is
+// turned inside out here: a traversal is a stack machine that stops whenever it needs a DP, so that the DPs of a whole batch of
+// reads go to the device together, one gnx_gsw_extend_batch call per side and round.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gnx_align.h"
+
+namespace gonomics {
+namespace genomeGraph {
+
+using Bases = std::vector<uint8_t>; // dna.Base: A C G T N = 0 .. 4
+
+inline void gnxCheck(int rc) {
+    if (rc != GNX_OK) throw std::runtime_error(std::string("libgonomics_align_hip: ") + gnx_last_error());
+}
+
+// ---- cigar.Cigar (cigar/cigar.go:15-35): SAM-style ops as bytes ------------------------------------------------------------
+struct Cigar {
+    int64_t RunLength;
+    uint8_t Op; // 'M', 'I', 'D', 'S'
+    bool operator==(const Cigar &o) const { return RunLength == o.RunLength && Op == o.Op; }
+};
+inline uint8_t opFromCol(uint8_t col) { return col == GNX_COL_M ? 'M' : (col == GNX_COL_I ? 'I' : 'D'); }
+
+// ---- dnaTwoBit (dna/dnaTwoBit/dnaTwoBit.go:10-13, 66-76; rainbow.go:27-45; perfectAlign.go) -------------------------------
+struct TwoBit {
+    std::vector<uint64_t> Seq;
+    int Len = 0;
+    TwoBit() = default;
+    explicit TwoBit(const Bases &b) : Len((int)b.size()) {
+        for (size_t start = 0; start < b.size(); start += 32) {
+            uint64_t w = 0;
+            const size_t cnt = std::min<size_t>(32, b.size() - start);
+            for (size_t x = 0; x < cnt; x++) w = (w << 2) | (uint64_t)b[start + x]; // BasesToUint64LeftAln: an N (4) also sets the low bit of the base before it
+            if (cnt < 32) w <<= 2 * (32 - cnt);
+            Seq.push_back(w);
+        }
+    }
+};
+inline std::vector<TwoBit> NewTwoBitRainbow(const Bases &bases) {
+    std::vector<TwoBit> out;
+    Bases clone = bases;
+    for (int k = 0; k < 32; k++) {
+        out.emplace_back(clone);
+        clone.insert(clone.begin(), (uint8_t)0);
+    }
+    return out;
+}
+inline int lz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
+inline int tz64(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
+inline int CountRightMatches(const TwoBit &one, int startOne, const TwoBit &two, int startTwo) {
+    const int offsetOne = (startOne % 32) * 2, offsetTwo = (startTwo % 32) * 2;
+    if (offsetOne != offsetTwo) throw std::runtime_error("Error: Different offsets when comparing sequences");
+    int i = startOne / 32, j = startTwo / 32;
+    const int iEnd = (one.Len + 31) / 32, jEnd = (two.Len + 31) / 32;
+    const uint64_t seqDiff = (one.Seq[i] ^ two.Seq[j]) & (~(uint64_t)0 >> offsetOne);
+    int bitMatches = lz64(seqDiff);
+    int total = bitMatches - offsetOne;
+    i++; j++;
+    while (i < iEnd && j < jEnd && bitMatches == 64) {
+        bitMatches = lz64(one.Seq[i] ^ two.Seq[j]);
+        total += bitMatches;
+        i++; j++;
+    }
+    return std::min(total / 2, std::min(one.Len - startOne, two.Len - startTwo));
+}
+inline int CountLeftMatches(const TwoBit &one, int startOne, const TwoBit &two, int startTwo) {
+    const int offsetOne = (startOne % 32) * 2, offsetTwo = (startTwo % 32) * 2;
+    if (offsetOne != offsetTwo) throw std::runtime_error("Different offsets when comparing sequences");
+    const int firstBitsNoLook = 64 - offsetOne - 2;
+    int i = startOne / 32, j = startTwo / 32;
+    const uint64_t seqDiff = (one.Seq[i] ^ two.Seq[j]) & (firstBitsNoLook >= 64 ? 0 : (~(uint64_t)0 << firstBitsNoLook));
+    int bitMatches = tz64(seqDiff);
+    int total = bitMatches - firstBitsNoLook;
+    i--; j--;
+    while (i >= 0 && j >= 0 && bitMatches == 64) {
+        bitMatches = tz64(one.Seq[i] ^ two.Seq[j]);
+        total += bitMatches;
+        i--; j--;
+    }
+    return total / 2;
+}
+inline int GetBase(const TwoBit &frag, int pos) { return (int)((frag.Seq[pos / 32] >> (64 - 2 * (pos % 32 + 1))) & 3); }
+
+// ---- the graph (genomeGraph/genomeGraph.go:25-47) and reads (fastq/fastqBig.go:15-50) ---------------------------------------
+struct Node;
+struct Edge {
+    Node *Dest;
+    float Prob;
+};
+struct Node {
+    uint32_t Id = 0;
+    Bases Seq;
+    TwoBit SeqTwoBit;
+    std::vector<Edge> Prev, Next;
+};
+struct GenomeGraph {
+    std::vector<std::unique_ptr<Node>> Nodes;
+    Node *AddNode(const Bases &seq) {
+        auto n = std::make_unique<Node>();
+        n->Id = (uint32_t)Nodes.size();
+        n->Seq = seq;
+        n->SeqTwoBit = TwoBit(seq);
+        Nodes.push_back(std::move(n));
+        return Nodes.back().get();
+    }
+    static void AddEdge(Node *u, Node *v, float p = 1.0f) {
+        u->Next.push_back(Edge{v, p});
+        v->Prev.push_back(Edge{u, p});
+    }
+};
+struct FastqBig {
+    std::string Name;
+    Bases Seq, SeqRc;
+    std::vector<TwoBit> Rainbow, RainbowRc;
+    FastqBig(std::string name, const Bases &seq) : Name(std::move(name)), Seq(seq), SeqRc(seq.size()) {
+        static const uint8_t comp[5] = {3, 2, 1, 0, 4};
+        for (size_t k = 0; k < seq.size(); k++) SeqRc[seq.size() - 1 - k] = comp[seq[k]];
+    }
+    void rainbows() {
+        if (Rainbow.empty()) { Rainbow = NewTwoBitRainbow(Seq); RainbowRc = NewTwoBitRainbow(SeqRc); }
+    }
+};
+
+// ---- N4: the index ------------------------------------------------------------------------------------------------------------
+inline uint64_t ChromAndPosToNumber(uint64_t chrom, uint64_t start) { return (chrom << 32) | start; }
+inline uint64_t dnaToNumber(const Bases &seq, size_t start, size_t end) { // align.go:170-177 (`answer << 2 | base`)
+    uint64_t ans = seq[start];
+    for (size_t i = start + 1; i < end; i++) ans = (ans << 2) | (uint64_t)seq[i];
+    return ans;
+}
+inline void packNodes(const GenomeGraph &g, Bases &cat, std::vector<int64_t> &off) {
+    off.assign(1, 0);
+    cat.clear();
+    for (const auto &n : g.Nodes) { cat.insert(cat.end(), n->Seq.begin(), n->Seq.end()); off.push_back((int64_t)cat.size()); }
+    cat.push_back(0); // (never an empty buffer)
+}
+// IndexGenomeIntoMap (index.go:21-59) as two arrays sorted by key, equal keys in the reference's insertion order: the k-mers inside
+// nodes from the device, the few that run across node borders from the host recursion over Next edges (indexGenomeIntoMapHelper).
+struct SeedIndex {
+    int seedLen = 0, seedStep = 0;
+    std::vector<uint64_t> keys, locs;
+    SeedIndex(const GenomeGraph &g, int seed_len, int seed_step) : seedLen(seed_len), seedStep(seed_step) {
+        if (seed_len < 2 || seed_len > 32) throw std::runtime_error("Error: seed length needs to be greater than 1 and less than 33.");
+        Bases cat;
+        std::vector<int64_t> off;
+        packNodes(g, cat, off);
+        uint64_t *k = nullptr, *l = nullptr;
+        int64_t n = 0;
+        gnxCheck(gnx_seed_index_build(cat.data(), off.data(), (int64_t)g.Nodes.size(), seed_len, seed_step, &k, &l, &n));
+        keys.assign(k, k + n);
+        locs.assign(l, l + n);
+        gnx_free(k);
+        gnx_free(l);
+        std::vector<std::pair<uint64_t, uint64_t>> border;
+        for (size_t nodeIdx = 0; nodeIdx < g.Nodes.size(); nodeIdx++) {
+            const Node &nd = *g.Nodes[nodeIdx];
+            const int64_t L = (int64_t)nd.Seq.size();
+            const int64_t first = (L - seed_len + 1 <= 0) ? 0 : ((L - seed_len) / seed_step + 1) * seed_step;
+            for (int64_t pos = first; pos < L; pos += seed_step)
+                for (const Edge &e : nd.Next) helper(Bases(nd.Seq.begin() + pos, nd.Seq.end()), *e.Dest, ChromAndPosToNumber(nodeIdx, (uint64_t)pos), border);
+        }
+        if (!border.empty()) { // a location code (node << 32 | pos) sorts like the reference's insertion order within one key
+            std::vector<std::pair<uint64_t, uint64_t>> all(keys.size());
+            for (size_t x = 0; x < keys.size(); x++) all[x] = {keys[x], locs[x]};
+            all.insert(all.end(), border.begin(), border.end());
+            std::stable_sort(all.begin(), all.end());
+            keys.resize(all.size());
+            locs.resize(all.size());
+            for (size_t x = 0; x < all.size(); x++) { keys[x] = all[x].first; locs[x] = all[x].second; }
+        }
+    }
+
+  private:
+    void helper(Bases prevSeq, const Node &curr, uint64_t loc, std::vector<std::pair<uint64_t, uint64_t>> &out) const {
+        if ((int)(prevSeq.size() + curr.Seq.size()) >= seedLen) {
+            Bases cs = prevSeq;
+            cs.insert(cs.end(), curr.Seq.begin(), curr.Seq.begin() + (seedLen - (int)prevSeq.size()));
+            if (std::find(cs.begin(), cs.end(), (uint8_t)4) == cs.end()) out.push_back({dnaToNumber(cs, 0, (size_t)seedLen), loc});
+        } else {
+            prevSeq.insert(prevSeq.end(), curr.Seq.begin(), curr.Seq.end());
+            for (const Edge &e : curr.Next) helper(prevSeq, *e.Dest, loc, out);
+        }
+    }
+};
+
+// ---- N4: seeds (index.go:10-18, search.go:338-370, 425-590) ----------------------------------------------------------------------
+struct SeedDev;
+using SeedPtr = std::shared_ptr<SeedDev>;
+struct SeedDev {
+    uint32_t TargetId, TargetStart, QueryStart, Length;
+    bool PosStrand;
+    uint32_t TotalLength;
+    SeedPtr NextPart;
+};
+inline SeedPtr mkSeed(uint32_t id, uint32_t ts, uint32_t qs, uint32_t len, bool pos, uint32_t total, SeedPtr next = nullptr) {
+    return std::make_shared<SeedDev>(SeedDev{id, ts, qs, len, pos, total, std::move(next)});
+}
+inline const SeedDev *getLastPart(const SeedDev *a) {
+    while (a->NextPart) a = a->NextPart.get();
+    return a;
+}
+inline std::vector<uint32_t> getSeedPath(const SeedDev *s) {
+    std::vector<uint32_t> p;
+    for (; s; s = s->NextPart.get()) p.push_back(s->TargetId);
+    return p;
+}
+inline std::vector<SeedPtr> extendToTheRightDev(const Node &node, FastqBig &read, int readStart, int nodeStart, bool posStrand) {
+    read.rainbows();
+    const int nodeOffset = nodeStart % 32;
+    const int readOffset = 31 - ((readStart - nodeOffset + 31) % 32);
+    const auto &rain = posStrand ? read.Rainbow : read.RainbowRc;
+    const int rightMatches = CountRightMatches(node.SeqTwoBit, nodeStart, rain[readOffset], readStart + readOffset);
+    std::vector<SeedPtr> answer;
+    if (rightMatches == 0) return answer;
+    if (readStart + rightMatches < (int)read.Seq.size() && nodeStart + rightMatches == node.SeqTwoBit.Len && !node.Next.empty()) {
+        for (const Edge &e : node.Next)
+            for (const SeedPtr &nxt : extendToTheRightDev(*e.Dest, read, readStart + rightMatches, 0, posStrand))
+                answer.push_back(mkSeed(node.Id, nodeStart, readStart, rightMatches, posStrand, rightMatches + nxt->TotalLength, nxt));
+    }
+    if (answer.empty()) answer.push_back(mkSeed(node.Id, nodeStart, readStart, rightMatches, posStrand, rightMatches));
+    return answer;
+}
+inline std::vector<SeedPtr> leftHelper(const Node &node, FastqBig &read, const SeedPtr &nextPart) {
+    read.rainbows();
+    const auto &rain = nextPart->PosStrand ? read.Rainbow : read.RainbowRc;
+    const int nodePos = node.SeqTwoBit.Len - 1;
+    const int readPos = (int)nextPart->QueryStart - 1;
+    const int nodeOffset = nodePos % 32;
+    const int readOffset = 31 - ((readPos - nodeOffset + 31) % 32);
+    const int leftMatches = std::min(readPos + 1, CountLeftMatches(node.SeqTwoBit, nodePos, rain[readOffset], readPos + readOffset));
+    if (leftMatches == 0) throw std::runtime_error("Error: should not have zero matches to the left");
+    SeedPtr currPart = mkSeed(node.Id, nodePos - (leftMatches - 1), readPos - (leftMatches - 1), leftMatches, nextPart->PosStrand, leftMatches + nextPart->TotalLength, nextPart);
+    std::vector<SeedPtr> answer;
+    if (currPart->QueryStart > 0 && currPart->TargetStart == 0) {
+        for (const Edge &e : node.Prev) {
+            const int readBase = GetBase(rain[0], (int)currPart->QueryStart - 1);
+            if (readBase == GetBase(e.Dest->SeqTwoBit, e.Dest->SeqTwoBit.Len - 1)) {
+                auto more = leftHelper(*e.Dest, read, currPart);
+                answer.insert(answer.end(), more.begin(), more.end());
+            }
+        }
+    }
+    if (answer.empty()) answer.push_back(currPart);
+    return answer;
+}
+inline std::vector<SeedPtr> extendToTheLeftDev(const Node &node, FastqBig &read, const SeedPtr &currPart) {
+    read.rainbows();
+    const auto &rain = currPart->PosStrand ? read.Rainbow : read.RainbowRc;
+    std::vector<SeedPtr> answer;
+    if (currPart->QueryStart > 0 && currPart->TargetStart == 0) {
+        for (const Edge &e : node.Prev) {
+            const int readBase = GetBase(rain[0], (int)currPart->QueryStart - 1);
+            if (readBase == GetBase(e.Dest->SeqTwoBit, e.Dest->SeqTwoBit.Len - 1)) {
+                auto more = leftHelper(*e.Dest, read, currPart);
+                answer.insert(answer.end(), more.begin(), more.end());
+            }
+        }
+    }
+    if (answer.empty()) answer.push_back(currPart);
+    return answer;
+}
+inline void heapSortSeeds(std::vector<SeedPtr> &a) { // search.go:338-370, literally
+    auto heapify = [&](int n, int i) {
+        while (true) {
+            const int l = 2 * i + 1, r = 2 * i + 2;
+            int mx = (l < n && a[l]->TotalLength < a[i]->TotalLength) ? l : i;
+            if (r < n && a[r]->TotalLength < a[mx]->TotalLength) mx = r;
+            if (mx == i) return;
+            std::swap(a[i], a[mx]);
+            i = mx;
+        }
+    };
+    const int n = (int)a.size();
+    for (int i = n / 2 - 1; i >= 0; i--) heapify(n, i);
+    int size = n;
+    for (int i = n - 1; i > 0; i--) {
+        std::swap(a[0], a[i]);
+        size--;
+        heapify(size, 0);
+    }
+}
+inline void sortSeeds(std::vector<SeedPtr> &seeds) { // seedMapMemPool's tail (search.go:583-589); > 100: see the parity contract
+    if (seeds.size() > 100) std::stable_sort(seeds.begin(), seeds.end(), [](const SeedPtr &x, const SeedPtr &y) { return x->TotalLength > y->TotalLength; });
+    else heapSortSeeds(seeds);
+}
+// seedMapMemPool for a batch of reads: hash lookups and in-node exact-match extensions on the device, continuation into
+// neighbouring nodes here
+inline std::vector<std::vector<SeedPtr>> seedMapBatch(const SeedIndex &index, const GenomeGraph &g, std::vector<FastqBig> &reads) {
+    Bases ncat, rcat;
+    std::vector<int64_t> noff, roff(1, 0);
+    packNodes(g, ncat, noff);
+    for (const auto &r : reads) { rcat.insert(rcat.end(), r.Seq.begin(), r.Seq.end()); roff.push_back((int64_t)rcat.size()); }
+    rcat.push_back(0);
+    gnxCheck(gnx_seed_index_set(index.keys.data(), index.locs.data(), (int64_t)index.keys.size(), ncat.data(), noff.data(), (int64_t)g.Nodes.size(), index.seedLen));
+    gnx_seed_hit *hits = nullptr;
+    int64_t *hoff = nullptr;
+    gnxCheck(gnx_seed_find_batch(rcat.data(), roff.data(), (int64_t)reads.size(), &hits, &hoff));
+    std::vector<std::vector<SeedPtr>> out(reads.size());
+    for (size_t r = 0; r < reads.size(); r++) {
+        FastqBig &read = reads[r];
+        std::vector<SeedPtr> fin;
+        for (int64_t h = hoff[r]; h < hoff[r + 1]; h++) {
+            const gnx_seed_hit &x = hits[h];
+            const Node &node = *g.Nodes[(size_t)x.node];
+            const bool pos = x.strand == 0;
+            if (x.right == 0) continue;
+            std::vector<SeedPtr> temp;
+            if (x.q_start + x.right < (int)read.Seq.size() && x.node_start + x.right == node.SeqTwoBit.Len && !node.Next.empty())
+                temp = extendToTheRightDev(node, read, x.q_start, x.node_start, pos); // crosses into the next node(s)
+            else temp.push_back(mkSeed(node.Id, (uint32_t)x.node_start, (uint32_t)x.q_start, (uint32_t)x.right, pos, (uint32_t)x.right));
+            if (pos) {
+                for (const SeedPtr &t : temp) {
+                    auto more = extendToTheLeftDev(node, read, t);
+                    fin.insert(fin.end(), more.begin(), more.end());
+                }
+            } else fin.insert(fin.end(), temp.begin(), temp.end()); // (the reference does not extend minus-strand seeds to the left across nodes)
+        }
+        sortSeeds(fin);
+        out[r] = std::move(fin);
+    }
+    gnx_free(hits);
+    gnx_free(hoff);
+    return out;
+}
+inline bool seedCouldBeBetter(int64_t seedLen, int64_t currBestScore, int64_t perfectScore, int64_t queryLen, int64_t maxMatch, int64_t minMatch,
+                              int64_t leastSevereMismatch, int64_t leastSevereMatchMismatchChange) { // index.go:102-121
+    const int64_t seeds = queryLen / (seedLen + 1), remainder = queryLen % (seedLen + 1);
+    if (seedLen * maxMatch >= currBestScore && perfectScore - ((queryLen - seedLen) * minMatch) >= currBestScore) return true;
+    if (seedLen * seeds * maxMatch + seeds * leastSevereMismatch >= currBestScore &&
+        perfectScore - remainder * minMatch + seeds * leastSevereMatchMismatchChange >= currBestScore) return true;
+    if (seedLen * seeds * maxMatch + remainder * maxMatch + (seeds + 1) * leastSevereMismatch >= currBestScore &&
+        perfectScore + (seeds + 1) * leastSevereMatchMismatchChange >= currBestScore) return true;
+    return false;
+}
+
+// ---- N2: the DPs, batched ---------------------------------------------------------------------------------------------------------
+struct DpRequest {
+    int side = GNX_GSW_LEFT;
+    Bases target;
+    const uint8_t *read = nullptr;
+    size_t readLen = 0;
+    std::vector<Cigar> route; // dynamicScore.route on entry (carried over from the sibling branch before, search.go:104-107)
+};
+struct DpResult {
+    int64_t score = 0;
+    std::vector<Cigar> route;
+    int64_t i = 0, j = 0;
+};
+// the route-building loop of search.go:252-262 / 298-308 applied to the traced runs (traceback order)
+inline std::vector<Cigar> mergeRoute(const std::vector<Cigar> &routeIn, const gnx_cigar *runs, int64_t nRuns) {
+    std::vector<Cigar> route = routeIn;
+    size_t idx = 0;
+    for (int64_t k = 0; k < nRuns; k++) {
+        const uint8_t op = opFromCol(runs[k].op);
+        for (int64_t x = 0; x < runs[k].run_length; x++) {
+            if (route.empty()) route.push_back(Cigar{1, op});
+            else if (route[idx].Op == op) route[idx].RunLength++;
+            else { route.push_back(Cigar{1, op}); idx++; }
+        }
+    }
+    return route;
+}
+// LeftDynamicAln / RightDynamicAln (search.go:234-321) for a batch of requests of one side
+inline std::vector<DpResult> DynamicAlnBatch(int side, const std::vector<const DpRequest *> &reqs, const int64_t *scores25, int64_t gapPen) {
+    const size_t n = reqs.size();
+    Bases acat, bcat;
+    std::vector<int64_t> aoff(1, 0), boff(1, 0);
+    for (const DpRequest *r : reqs) {
+        acat.insert(acat.end(), r->target.begin(), r->target.end());
+        aoff.push_back((int64_t)acat.size());
+        bcat.insert(bcat.end(), r->read, r->read + r->readLen);
+        boff.push_back((int64_t)bcat.size());
+    }
+    acat.push_back(0);
+    bcat.push_back(0);
+    std::vector<int64_t> sc(n ? n : 1), ei(n ? n : 1), ej(n ? n : 1);
+    gnx_cigar *ops = nullptr;
+    int64_t *off = nullptr;
+    gnxCheck(gnx_gsw_extend_batch(side, scores25, gapPen, (int64_t)n, acat.data(), aoff.data(), bcat.data(), boff.data(), sc.data(), ei.data(), ej.data(), &ops, &off));
+    std::vector<DpResult> out(n);
+    for (size_t p = 0; p < n; p++) {
+        out[p].score = sc[p]; out[p].i = ei[p]; out[p].j = ej[p];
+        if (!reqs[p]->route.empty()) out[p].route = mergeRoute(reqs[p]->route, ops + off[p], off[p + 1] - off[p]);
+        else {
+            out[p].route.reserve((size_t)(off[p + 1] - off[p]));
+            for (int64_t k = off[p]; k < off[p + 1]; k++) out[p].route.push_back(Cigar{ops[k].run_length, opFromCol(ops[k].op)});
+        }
+    }
+    gnx_free(ops);
+    gnx_free(off);
+    return out;
+}
+
+// ---- N2: LeftAlignTraversal / RightAlignTraversal (search.go:166-232) as a stack machine ---------------------------------------
+struct TraversalResult {
+    std::vector<Cigar> aln;
+    int64_t score = 0, t = 0, q = 0; // left: targetStart, queryStart; right: targetEnd, queryEnd
+    std::vector<uint32_t> path;
+};
+class Traversal {
+  public:
+    DpRequest req;          // valid while advance() returns true
+    TraversalResult result; // valid once advance() returned false
+    void start(bool left, const Node *n, int64_t pos, int64_t extension, const uint8_t *read, size_t readLen) {
+        left_ = left; ext_ = extension; read_ = read; readLen_ = readLen;
+        stack_.clear();
+        push(n, Bases(), pos, {}, {});
+    }
+    // res: the answer to `req` (nullptr on the first call).  true: `req` holds the next DP; false: done, see `result`.
+    bool advance(const DpResult *res) {
+        TraversalResult r;
+        bool haveRet = false;
+        if (res) { // the top frame is a leaf that was waiting for its DP
+            Frame &f = stack_.back();
+            r.aln = res->route; r.score = res->score; r.path = f.sPath;
+            if (left_) { r.t = f.pos - (int64_t)f.sSeq.size() - (int64_t)f.seq.size() + res->i; r.q = res->j; }
+            else { r.t = res->i + f.pos; r.q = res->j; }
+            stack_.pop_back();
+            haveRet = true;
+        } else if (stack_.back().leaf) { issue(stack_.back()); return true; }
+        while (true) {
+            if (haveRet) {
+                if (stack_.empty()) { result = std::move(r); return false; }
+                Frame &f = stack_.back();
+                f.route = r.aln; // the loop variable `route`: what the next sibling's DP starts from
+                if (r.score > f.bestScore) {
+                    f.bestScore = r.score; f.haveBest = true;
+                    f.best = r;
+                    if (left_) f.best.t = f.pos - (int64_t)f.sSeq.size() - (int64_t)f.seq.size() + r.t;
+                }
+                f.child++;
+                haveRet = false;
+            }
+            Frame &f = stack_.back();
+            const auto &edges = left_ ? f.n->Prev : f.n->Next;
+            if (f.child < edges.size()) {
+                const Node *d = edges[f.child].Dest;
+                push(d, f.sSeq, left_ ? (int64_t)d->Seq.size() : 0, f.sPath, f.route);
+                if (stack_.back().leaf) { issue(stack_.back()); return true; }
+            } else { // every branch tried: hand the best one up (search.go:196-198, 228-231: ReverseCigar; the left one reverses its path too)
+                r = std::move(f.best);
+                r.score = f.bestScore;
+                std::reverse(r.aln.begin(), r.aln.end());
+                if (left_) std::reverse(r.path.begin(), r.path.end());
+                else r.t += f.pos;
+                stack_.pop_back();
+                haveRet = true;
+            }
+        }
+    }
+
+  private:
+    struct Frame {
+        const Node *n;
+        Bases seq, sSeq;
+        int64_t pos; // refEnd (left) / start (right)
+        std::vector<uint32_t> sPath;
+        std::vector<Cigar> route;
+        bool leaf;
+        size_t child = 0;
+        int64_t bestScore = INT64_MIN;
+        bool haveBest = false;
+        TraversalResult best;
+    };
+    bool left_ = true;
+    int64_t ext_ = 0;
+    const uint8_t *read_ = nullptr;
+    size_t readLen_ = 0;
+    std::vector<Frame> stack_;
+    void push(const Node *n, const Bases &seq, int64_t pos, const std::vector<uint32_t> &path, const std::vector<Cigar> &route) {
+        Frame f;
+        f.n = n; f.seq = seq; f.pos = pos; f.route = route;
+        f.sPath = path; // search.go:174-176 calls AddPath(s.Path, n.Id) and drops its result: the node is never recorded
+        const int64_t have = (int64_t)seq.size() + (left_ ? pos : (int64_t)n->Seq.size() - pos);
+        int64_t take = std::min(have, ext_) - (int64_t)seq.size();
+        if (take < 0) take = 0;
+        if (left_) { // getLeftTargetBases (search.go:135-140)
+            f.sSeq.assign(n->Seq.begin() + (pos - take), n->Seq.begin() + pos);
+            f.sSeq.insert(f.sSeq.end(), seq.begin(), seq.end());
+            f.leaf = have >= ext_ || n->Prev.empty();
+        } else { // getRightBases (search.go:142-147)
+            f.sSeq = seq;
+            f.sSeq.insert(f.sSeq.end(), n->Seq.begin() + pos, n->Seq.begin() + pos + take);
+            f.leaf = have >= ext_ || n->Next.empty();
+        }
+        stack_.push_back(std::move(f));
+    }
+    void issue(const Frame &f) {
+        req.side = left_ ? GNX_GSW_LEFT : GNX_GSW_RIGHT;
+        req.target = f.sSeq; req.read = read_; req.readLen = readLen_; req.route = f.route;
+    }
+};
+
+// ---- N2: GraphSmithWatermanToGiraf (toGiraf.go:17-72) ------------------------------------------------------------------------------
+struct Giraf { // giraf.Giraf, the fields the function fills (giraf/giraf.go:16-33)
+    std::string QName;
+    int64_t QStart = 0, QEnd = 0;
+    bool PosStrand = true;
+    int64_t TStart = 0, TEnd = 0;
+    std::vector<uint32_t> Nodes;
+    bool hasCigar = false;
+    std::vector<Cigar> Cig;
+    int64_t AlnScore = 0;
+    int MapQ = 255;
+    const Bases *Seq = nullptr;
+};
+inline void AddPath(std::vector<uint32_t> &all, uint32_t p) {
+    if (all.empty() || all.back() != p) all.push_back(p);
+}
+inline std::vector<uint32_t> CatPaths(std::vector<uint32_t> curr, const std::vector<uint32_t> &more) {
+    if (more.empty()) return curr;
+    if (curr.empty()) return more;
+    AddPath(curr, more[0]);
+    curr.insert(curr.end(), more.begin() + 1, more.end());
+    return curr;
+}
+inline int64_t queryLength(const std::vector<Cigar> &c) {
+    int64_t s = 0;
+    for (const Cigar &x : c) if (x.Op == 'M' || x.Op == 'I' || x.Op == 'S' || x.Op == '=' || x.Op == 'X') s += x.RunLength;
+    return s;
+}
+// cigar.AppendSoftClips (cigar/tools.go:26-40), literally -- including that a front clip without a back clip returns only the clip
+inline std::vector<Cigar> appendSoftClips(int64_t front, int64_t lengthOfRead, const std::vector<Cigar> &cigs) {
+    const int64_t run = queryLength(cigs);
+    if (front == 0 && run >= lengthOfRead) return cigs;
+    std::vector<Cigar> answer;
+    if (front > 0) answer.push_back(Cigar{front, 'S'});
+    if (front + run < lengthOfRead) {
+        answer.insert(answer.end(), cigs.begin(), cigs.end());
+        answer.push_back(Cigar{lengthOfRead - front - run, 'S'});
+    }
+    return answer;
+}
+inline void cigAppend(std::vector<Cigar> &alpha, const Cigar &beta) {
+    if (!alpha.empty() && alpha.back().Op == beta.Op) alpha.back().RunLength += beta.RunLength;
+    else alpha.push_back(beta);
+}
+inline std::vector<Cigar> cigConcat(std::vector<Cigar> alpha, const std::vector<Cigar> &beta) {
+    if (alpha.empty()) return beta;
+    size_t from = 0;
+    if (!beta.empty()) { cigAppend(alpha, beta[0]); from = 1; }
+    alpha.insert(alpha.end(), beta.begin() + (long)from, beta.end());
+    return alpha;
+}
+// one read's loop over its sorted seeds, stopping whenever a traversal needs a DP
+class ReadTask {
+  public:
+    Giraf best;
+    DpRequest *req = nullptr; // the pending DP (while advance() returns true)
+    ReadTask(const GenomeGraph &g, const FastqBig &read, std::vector<SeedPtr> seeds, const int64_t *scores25)
+        : g_(g), read_(read), seeds_(std::move(seeds)), sc_(scores25) {
+        best.QName = read.Name; best.Seq = &read.Seq;
+        perfect_ = 0;
+        for (uint8_t b : read.Seq) perfect_ += sc_[b * 5 + b];
+        extension_ = perfect_ / 600 + (int64_t)read.Seq.size();
+    }
+    bool advance(const DpResult *res) {
+        while (true) {
+            if (phase_ == 0) { // next seed
+                if (si_ >= seeds_.size()) return false;
+                seed_ = seeds_[si_].get();
+                if (!seedCouldBeBetter(seed_->TotalLength, best.AlnScore, perfect_, (int64_t)read_.Seq.size(), 100, 90, -196, -296)) return false;
+                tail_ = getLastPart(seed_);
+                currSeq_ = seed_->PosStrand ? &read_.Seq : &read_.SeqRc;
+                seedScore_ = 0;
+                for (uint32_t x = seed_->QueryStart; x < tail_->QueryStart + tail_->Length; x++) seedScore_ += sc_[(*currSeq_)[x] * 5 + (*currSeq_)[x]];
+                if (seed_->TotalLength == currSeq_->size()) {
+                    targetStart_ = seed_->TargetStart; targetEnd_ = tail_->TargetStart + tail_->Length; queryStart_ = seed_->QueryStart;
+                    currScore_ = seedScore_;
+                    finishSeed();
+                    continue;
+                }
+                const int64_t ext = extension_ - seed_->TotalLength;
+                trav_.start(true, g_.Nodes[seed_->TargetId].get(), seed_->TargetStart, ext, currSeq_->data(), seed_->QueryStart);
+                phase_ = 1;
+                if (trav_.advance(nullptr)) { req = &trav_.req; return true; }
+                res = nullptr;
+            }
+            if (phase_ == 1) { // in the left traversal
+                if (res && trav_.advance(res)) { req = &trav_.req; return true; }
+                leftAln_ = trav_.result.aln; leftScore_ = trav_.result.score; targetStart_ = trav_.result.t; queryStart_ = trav_.result.q; leftPath_ = trav_.result.path;
+                const int64_t ext = extension_ - seed_->TotalLength;
+                const size_t from = tail_->QueryStart + tail_->Length;
+                trav_.start(false, g_.Nodes[tail_->TargetId].get(), tail_->TargetStart + tail_->Length, ext, currSeq_->data() + from, currSeq_->size() - from);
+                phase_ = 2;
+                if (trav_.advance(nullptr)) { req = &trav_.req; return true; }
+                res = nullptr;
+            }
+            if (phase_ == 2) { // in the right traversal
+                if (res && trav_.advance(res)) { req = &trav_.req; return true; }
+                rightAln_ = trav_.result.aln; targetEnd_ = trav_.result.t; queryEnd_ = trav_.result.q; rightPath_ = trav_.result.path;
+                currScore_ = leftScore_ + seedScore_ + trav_.result.score;
+                finishSeed();
+                res = nullptr;
+            }
+        }
+    }
+
+  private:
+    const GenomeGraph &g_;
+    const FastqBig &read_;
+    std::vector<SeedPtr> seeds_;
+    const int64_t *sc_;
+    int64_t perfect_ = 0, extension_ = 0;
+    size_t si_ = 0;
+    int phase_ = 0;
+    const SeedDev *seed_ = nullptr, *tail_ = nullptr;
+    const Bases *currSeq_ = nullptr;
+    int64_t seedScore_ = 0, currScore_ = 0, leftScore_ = 0;
+    // scoreKeeper fields that survive from one seed to the next (resetScoreKeeper gets its argument by value: a no-op): a seed that
+    // covers the whole read re-uses the alignments, paths and queryEnd of the seed before it (toGiraf.go:47-51)
+    std::vector<Cigar> leftAln_, rightAln_;
+    std::vector<uint32_t> leftPath_, rightPath_;
+    int64_t targetStart_ = 0, targetEnd_ = 0, queryStart_ = 0, queryEnd_ = 0;
+    Traversal trav_;
+    void finishSeed() {
+        if (currScore_ > best.AlnScore) {
+            best.QStart = queryStart_;
+            best.QEnd = (int64_t)seed_->QueryStart + queryStart_ + queryEnd_ + (int64_t)seed_->TotalLength - 1;
+            best.PosStrand = seed_->PosStrand;
+            best.TStart = targetStart_; best.TEnd = targetEnd_;
+            best.Nodes = CatPaths(CatPaths(leftPath_, getSeedPath(seed_)), rightPath_);
+            std::vector<Cigar> mid = leftAln_;
+            cigAppend(mid, Cigar{(int64_t)seed_->TotalLength, 'M'});
+            best.Cig = appendSoftClips(queryStart_, (int64_t)currSeq_->size(), cigConcat(std::move(mid), rightAln_));
+            best.hasCigar = true;
+            best.AlnScore = currScore_;
+            best.Seq = currSeq_;
+        }
+        si_++;
+        phase_ = 0;
+    }
+};
+// GraphSmithWatermanToGiraf for a batch of reads: seeds from the device, then rounds of batched DPs (gapPen: gsw passes -600)
+inline std::vector<Giraf> GswBatchToGiraf(const GenomeGraph &g, std::vector<FastqBig> &reads, const SeedIndex &index, const int64_t *scores25,
+                                          int64_t gapPen = -600, int *outRounds = nullptr) {
+    auto seeds = seedMapBatch(index, g, reads);
+    std::vector<std::unique_ptr<ReadTask>> tasks;
+    std::vector<size_t> pending;
+    for (size_t k = 0; k < reads.size(); k++) {
+        tasks.push_back(std::make_unique<ReadTask>(g, reads[k], std::move(seeds[k]), scores25));
+        if (tasks.back()->advance(nullptr)) pending.push_back(k);
+    }
+    int rounds = 0;
+    std::vector<char> alive(reads.size(), 0);
+    for (size_t k : pending) alive[k] = 1;
+    size_t n_alive = pending.size();
+    while (n_alive > 0) { // a round: the pending left DPs of all reads in one call, then the right ones (incl. those the left answers led to)
+        for (int side = GNX_GSW_LEFT; side <= GNX_GSW_RIGHT; side++) {
+            std::vector<size_t> ks;
+            std::vector<const DpRequest *> rq;
+            for (size_t k = 0; k < tasks.size(); k++)
+                if (alive[k] && tasks[k]->req->side == side) { ks.push_back(k); rq.push_back(tasks[k]->req); }
+            if (ks.empty()) continue;
+            auto outs = DynamicAlnBatch(side, rq, scores25, gapPen);
+            for (size_t y = 0; y < ks.size(); y++)
+                if (!tasks[ks[y]]->advance(&outs[y])) { alive[ks[y]] = 0; n_alive--; }
+        }
+        rounds++;
+    }
+    if (outRounds) *outRounds = rounds;
+    std::vector<Giraf> out;
+    for (auto &t : tasks) out.push_back(std::move(t->best));
+    return out;
+}
+
+} // namespace genomeGraph
+} // namespace gonomics

@@ -1,0 +1,61 @@
+// The C++ mirror of the graph aligner's read path (include/gonomics_genomegraph.hpp) on a case written by tests/test_gsw_cpp.py:
+//   input  (text): n_nodes, then per node "len b b b ..."; n_edges, then "u v"; n_reads, then per read "len b b ..."; seedLen seedStep; 25 scores
+//   output (text): one line per read: QStart QEnd PosStrand TStart TEnd AlnScore | nodes... | cigar (len op)... | n_seeds
+// and a last line "# index_ms seeds_and_dp_ms rounds" (wall clock of the two stages through the C ABI).
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "gonomics_genomegraph.hpp"
+
+using namespace gonomics::genomeGraph;
+
+static Bases read_bases(std::istream &in) {
+    size_t n;
+    in >> n;
+    Bases b(n);
+    for (size_t k = 0; k < n; k++) { int x; in >> x; b[k] = (uint8_t)x; }
+    return b;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s case.txt out.txt\n", argv[0]); return 64; }
+    if (gnx_init(0, 0) != GNX_OK) { fprintf(stderr, "%s\n", gnx_last_error()); return 2; } // no HIP device: no CPU fallback
+    std::ifstream in(argv[1]);
+    GenomeGraph g;
+    size_t n_nodes, n_edges, n_reads;
+    in >> n_nodes;
+    for (size_t k = 0; k < n_nodes; k++) g.AddNode(read_bases(in));
+    in >> n_edges;
+    for (size_t k = 0; k < n_edges; k++) { size_t u, v; in >> u >> v; GenomeGraph::AddEdge(g.Nodes[u].get(), g.Nodes[v].get()); }
+    in >> n_reads;
+    std::vector<FastqBig> reads;
+    for (size_t k = 0; k < n_reads; k++) reads.emplace_back("read" + std::to_string(k), read_bases(in));
+    int seedLen, seedStep;
+    in >> seedLen >> seedStep;
+    int64_t sc[25];
+    for (int k = 0; k < 25; k++) in >> sc[k];
+    try {
+        auto t0 = std::chrono::steady_clock::now();
+        SeedIndex index(g, seedLen, seedStep);
+        auto t1 = std::chrono::steady_clock::now();
+        int rounds = 0;
+        auto res = GswBatchToGiraf(g, reads, index, sc, -600, &rounds);
+        auto t2 = std::chrono::steady_clock::now();
+        std::ofstream out(argv[2]);
+        for (const Giraf &r : res) {
+            out << r.QStart << ' ' << r.QEnd << ' ' << (r.PosStrand ? 1 : 0) << ' ' << r.TStart << ' ' << r.TEnd << ' ' << r.AlnScore << " |";
+            for (uint32_t n : r.Nodes) out << ' ' << n;
+            out << " |";
+            if (!r.hasCigar) out << " none";
+            for (const Cigar &c : r.Cig) out << ' ' << c.RunLength << ' ' << (int)c.Op;
+            out << " | " << (r.Seq == nullptr ? -1 : (long)r.Seq->size()) << '\n';
+        }
+        out << "# " << std::chrono::duration<double, std::milli>(t1 - t0).count() << ' ' << std::chrono::duration<double, std::milli>(t2 - t1).count() << ' ' << rounds << '\n';
+    } catch (const std::exception &e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,86 @@
+"""The C++ mirror of the graph aligner's read path (include/gonomics_genomegraph.hpp: index, seeds, traversals as stack machines, the
+per-read driver, rounds of batched device DPs through the raw C ABI) against the Python mirror and the literal restatement
+tests/pyref_gsw.py.  Rows N2 (callers) / N4 of SURVEY 8f; parity unpinned by the reference (its tests only log)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import common
+import pyref_gsw as ref
+from test_gsw_reads import build, make_case
+from gonomics_amd import genomeGraph as gg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "gsw_mirror_test.cpp")
+BIN = os.path.join(ROOT, "tests", "cpp", "gsw_mirror_test.bin")
+LIB = os.path.join(ROOT, "gonomics_amd", "libgonomics_align_hip.so")
+MX = common.matrices()
+
+
+def _build():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", BIN, SRC, LIB,
+                           "-Wl,-rpath," + os.path.join(ROOT, "gonomics_amd"), "-L/opt/rocm/lib", "-lamdhip64"])
+
+
+def write_case(path, seqs, edges, reads, seed_len, seed_step, sc):
+    with open(path, "w") as fh:
+        fh.write("%d\n" % len(seqs))
+        for s in seqs:
+            fh.write("%d %s\n" % (len(s), " ".join(str(int(x)) for x in s)))
+        fh.write("%d\n" % len(edges))
+        for u, v in edges:
+            fh.write("%d %d\n" % (u, v))
+        fh.write("%d\n" % len(reads))
+        for r in reads:
+            fh.write("%d %s\n" % (len(r), " ".join(str(int(x)) for x in r)))
+        fh.write("%d %d\n" % (seed_len, seed_step))
+        fh.write(" ".join(str(int(x)) for x in np.asarray(sc, dtype=np.int64).reshape(25)) + "\n")
+
+
+def read_out(path):
+    rows, timing = [], None
+    for line in open(path):
+        if line.startswith("#"):
+            timing = [float(x) for x in line[1:].split()]
+            continue
+        head, nodes, cig, seqlen = [x.strip() for x in line.split("|")]
+        h = [int(x) for x in head.split()]
+        c = None if cig == "none" else tuple((int(a), int(b)) for a, b in zip(cig.split()[0::2], cig.split()[1::2]))
+        rows.append((h[0], h[1], bool(h[2]), h[3], tuple(int(x) for x in nodes.split()), h[4], c, h[5], int(seqlen)))
+    return rows, timing
+
+
+def test_cpp_gsw_mirror_builds_and_refuses_without_gpu(tmp_path):
+    _build()
+    seqs, edges, reads = make_case(7, "linear")
+    write_case(str(tmp_path / "case.txt"), seqs, edges, reads[:2], 16, 1, MX["HumanChimpTwo"])
+    rc = subprocess.call([BIN, str(tmp_path / "case.txt"), str(tmp_path / "out.txt")])
+    assert rc in (0, 2)  # 2 == "no HIP device" (no CPU fallback); 0 on a GPU box
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,seed_len,step", [("linear", 16, 1), ("snp", 16, 1), ("snp", 20, 7)])
+def test_cpp_gsw_mirror_equals_python_mirror(gpu_lib, tmp_path, kind, seed_len, step):
+    _build()
+    seqs, edges, reads = make_case(9, kind)
+    sc = MX["HumanChimpTwo"]
+    write_case(str(tmp_path / "case.txt"), seqs, edges, reads, seed_len, step, sc)
+    assert subprocess.call([BIN, str(tmp_path / "case.txt"), str(tmp_path / "out.txt")]) == 0
+    rows, timing = read_out(str(tmp_path / "out.txt"))
+    assert len(rows) == len(reads) and timing is not None
+    g = build(seqs, edges)
+    index = gg.SeedIndex(g.Nodes, seed_len, step)
+    bigs = [gg.FastqBig("r%d" % k, rd) for k, rd in enumerate(reads)]
+    py = gg.GswBatchToGiraf(g, bigs, index, seed_len, sc)
+    nodes = ref.make_graph(seqs, edges)
+    full = ref.index_genome(nodes, seed_len, step)
+    for k, r in enumerate(py):
+        key = r.key()
+        assert rows[k] == key[:8] + (len(key[8]),), "read %d" % k
+        r2 = ref.make_read(reads[k])  # ... and the sequential restatement on the CPU oracle
+        assert key == ref.giraf_key(ref.read_to_giraf(nodes, r2, ref.seed_map(full, nodes, r2, seed_len), sc)), "read %d" % k

@@ -53,6 +53,27 @@ def main():
     dt = time.perf_counter() - t0
     print(json.dumps({"series": "GswBatchToGiraf: %d reads against a 4 x 200 kb graph (device seeds + rounds of batched device DPs)" % len(sub), "mapped": int(sum(o.AlnScore > 0 for o in out)),
                       "host_call_s": dt, "reads_per_s": len(sub) / dt}), flush=True)
+    # the same read path through the C++ mirror (include/gonomics_genomegraph.hpp) on the same graph, 10x the reads: what a compiled host pays
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gsw_cpp as tc
+    tc._build()
+    more = list(sub)
+    for _ in range(18000):
+        k = int(rng.integers(0, 4)); o = int(rng.integers(0, 200000 - 170))
+        more.append(gg.FastqBig("r", common.mutate(rng, g.Nodes[k].Seq[o:o + 170], 0.02, 0.01)[:150]))
+    with tempfile.TemporaryDirectory() as td:
+        for name, batch in (("2000", sub), ("20000", more)):
+            tc.write_case(os.path.join(td, "case.txt"), [n.Seq for n in g.Nodes], [], [r.Seq for r in batch], seed_len, step, align.HumanChimpTwoScoreMatrix)
+            subprocess.check_call([tc.BIN, os.path.join(td, "case.txt"), os.path.join(td, "out.txt")])
+            rows, timing = tc.read_out(os.path.join(td, "out.txt"))
+            same = None
+            if name == "2000":
+                same = all(rows[k] == out[k].key()[:8] + (len(out[k].key()[8]),) for k in range(len(sub)))
+            print(json.dumps({"series": "GswBatchToGiraf through the C++ mirror: %s reads, same graph" % name, "mapped": int(sum(r[7] > 0 for r in rows)),
+                              "index_ms": timing[0], "seeds_traversals_dps_ms": timing[1], "dp_rounds": int(timing[2]), "reads_per_s": len(batch) / (timing[1] / 1e3),
+                              "equals_python_mirror": same}), flush=True)
 
 
 if __name__ == "__main__":
