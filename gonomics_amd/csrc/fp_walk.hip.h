@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                                                      int *__restrict__ next_active, int *__restrict__ next_count,
                                                      PairPlan *__restrict__ next_wplans, int *__restrict__ err, int p_base,
                                                      int *__restrict__ strag_active, int *__restrict__ strag_count, int force_strag,
-                                                     const int2 *__restrict__ rowbuf) {
+                                                     const int2 *__restrict__ rowbuf, int spec, int wwords) {
     const int a = CW ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (a >= n_active) return;
     const int lane = threadIdx.x & 63;
@@ -61,10 +61,14 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         wp = pl;
     } else {
         st = states[p];
-        wp = wplans[TILED ? 0 : a];
+        wp = wplans[TILED ? 0 : (int64_t)a * spec];
         if (TILED) { st.j_hi = 0; st.jc_lo = 0; }
     }
     int wrow = FIRST ? 0 : (int)wp.s_off; // row base of the current window: it holds the rows wrow + 1 .. wrow + wp.n of the pair
+    // spec > 1 (reads of several row blocks): a request is answered with `spec` windows, plans [a*spec + k]: k = 0 the one asked for,
+    // k >= 1 SPECULATIVE ones for the next row blocks up, placed where a near-diagonal path will enter them (fp_spec_margin).  The walk
+    // takes window k + 1 when it leaves window k through the top and finds its cell inside; else it asks again (a round trip).
+    int kcur = 0;
     // TILED: `a` indexes the straggler; its tiles c = 0.. are the plans [a*tiles_per + c] (tiles_per in wplans[0].rowi_off)
     const int tiles_per = TILED ? (int)wplans[0].rowi_off : 0;
     int i = st.i, j = st.j, k = st.k, last_op = st.last_op, cur_op = st.cur_op, cnt = st.cnt;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         if (op == cur_op) cur_run += run;
         else { flush_run(); cur_op = op; cur_run = run; }
     };
-    bool done = false, last_win = false;
+    bool done = false, last_win = false, no_look = false;
     // A re-fill that starts from a column checkpoint reproduces every VALUE, but the checkpoint carries no argmax tags
     // (the sweep computes them only on its plane rows), so the M- and I-plane fields of the re-fill's first column are
     // not usable: the walk uses a window / tile from its second column on (all of it when it starts at column 0).
@@ -97,6 +101,23 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         const bool on_plane = (k == 1) && (pl.n - i) < FP_PLANES;
         const bool in_win = !on_plane && j >= lo_ok(st.jc_lo) && j <= st.j_hi && i > wrow && i <= wrow + wp.n;
         if (on_plane || in_win || (k == 0 && tail_ok(i - 1, j - 1))) last_win = in_win; // was the last step taken inside the window? (then the walk leaves it by walking through it)
+        if (CW && in_win && k == 0 && !no_look) {
+            // a diagonal run inside the window, 64 cells per look: lane t looks at the cell (i - t, j - t); the run goes on while the cells
+            // are M cells whose source is M.  Quirk Q1 changes nothing inside such a run (the entry cell's argmax is M, the state we are in).
+            const int lim = min(min(i - wrow, j - lo_ok(st.jc_lo) + 1), 64);
+            int f = 0;
+            if (lane < lim) { int p2; f = (int)((load_word<true>(wtrace, wp, 0, i - lane - wrow, j - lane - st.jc_lo, p2) >> (2 * p2)) & 3u); }
+            const unsigned long long stop = __ballot(!(lane < lim && f == 3));
+            const int T = stop ? __ffsll((long long)stop) - 1 : 64;
+            if (T > 0) {
+                emit(op_of(0), T); last_op = 0;
+                i -= T; j -= T;
+                li -= T;
+                if (li < 0) { li %= tp.ci; if (li < 0) li += tp.ci; }
+                continue;
+            }
+            no_look = true; // the cell itself is not part of such a run: one ordinary step, then look again
+        }
         if (on_plane) { // stored I-plane of row n-d
             const int t1 = j + G8 - 1; // step at which the owner lane (the pair's last) was at column j
             w = rowi[pl.rowi_off + (int64_t)(pl.n - i) * pl.words + (t1 >> 4)];
@@ -113,6 +134,14 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             st.jc_lo = wp.col_off; st.j_hi = st.jc_lo + wp.m; // tile c starts one checkpoint before column c*FP_TILE
             if (j > st.j_hi || j < lo_ok(st.jc_lo) || !(i > wrow && i <= wrow + wp.n)) { atomicOr(err, 2); done = true; break; }
             continue;
+        } else if (!FIRST && kcur + 1 < spec) { // the next speculative window: is the walk's cell inside it?
+            const PairPlan nx = wplans[(int64_t)a * spec + kcur + 1];
+            kcur++;
+            if (nx.strips > 0 && i > (int)nx.s_off && i <= (int)nx.s_off + nx.n && j >= lo_ok(nx.col_off) && j <= nx.col_off + nx.m) {
+                wp = nx; wrow = (int)nx.s_off; st.jc_lo = nx.col_off; st.j_hi = nx.col_off + nx.m;
+                continue;
+            }
+            break; // mispredicted (or the row block was used up sideways): ask again
         } else break; // needs a (new) window
         int tag = (int)((w >> (2 * pos)) & 3u);
         if (tag == 0) { atomicOr(err, 2); done = true; break; }
@@ -182,6 +211,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         if (k != 1) { up_exit = (li == 0); li = up_exit ? tp.ci - 1 : li - 1; i--; }
         if (k != 2) j--;
         k = k_of(tag);
+        no_look = false;
         if (up_exit && i > 0 && j > 0) { // quirk Q1: restart in the argmax state of the entry cell (i, j)
             int ht;
             if (tail_ok(i, j)) ht = (int)tail_tag(i, j);
@@ -222,17 +252,26 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             int slot = 0;
             if (writer) slot = atomicAdd(next_count, 1);
             if (CW) slot = __builtin_amdgcn_readfirstlane(slot);
-            int jc = j - FP_SPAN;
-            jc = jc <= 0 ? 0 : (jc / CKW) * CKW;
-            st.j_hi = j; st.jc_lo = jc; st.slot = slot;
             if (writer) next_active[slot] = p;
-            PairPlan q;
-            q.n = rows; q.m = j - jc; q.words = (q.m + 15 + 15) / 16; q.strips = 1;
-            q.trace_off = (int64_t)slot * FP_WWORDS * QA * G; q.hcol_off = (int64_t)slot * H;
-            q.rowbuf_off = pl.rowbuf_off + (int64_t)(pl.strips - 2 - b) * (pl.m + 1); // the row the block above handed down (unused for the top block)
-            q.dcol_off = (int64_t)slot * G;
-            q.src = pl.src; q.col_off = jc; q.ckpt_off = pl.ckpt_off; q.rowi_off = 0; q.s_off = rb; q.s_pitch = pl.n;
-            if (writer) next_wplans[slot] = q;
+            st.slot = slot;
+            for (int k2 = 0; k2 < spec; k2++) {
+                const int bk = b + k2, rbk = max(0, pl.n - H * (bk + 1)), rowsk = pl.n - H * bk - rbk; // (rbk, rowsk: block bk of the pair)
+                // window k2 ends where the path will enter block bk: (i - rb) + 160 (k2 - 1) rows further up, about as many columns to the left
+                const int D = fp_spec_margin(k2);
+                const int je = k2 == 0 ? j : j - ((i - rb) + H * (k2 - 1)) + D;
+                int jc = je - FP_SPAN - 2 * D;
+                jc = jc <= 0 ? 0 : (jc / CKW) * CKW;
+                if (k2 == 0) { st.j_hi = j; st.jc_lo = jc; }
+                PairPlan q;
+                const bool real = bk < pl.strips && je >= 1;
+                q.n = real ? rowsk : 0; q.m = real ? je - jc : 0; q.words = (q.m + 15 + 15) / 16; q.strips = real ? 1 : 0;
+                const int64_t x = (int64_t)slot * spec + k2;
+                q.trace_off = x * wwords * QA * G; q.hcol_off = x * H;
+                q.rowbuf_off = pl.rowbuf_off + (int64_t)(pl.strips - 2 - bk) * (pl.m + 1); // the row the block above handed down (unused for the top block)
+                q.dcol_off = x * G;
+                q.src = pl.src; q.col_off = jc; q.ckpt_off = pl.ckpt_off; q.rowi_off = 0; q.s_off = rbk; q.s_pitch = pl.n;
+                if (writer) next_wplans[x] = q;
+            }
         }
     }
     st.i = i; st.j = j; st.k = k; st.last_op = last_op; st.cur_op = cur_op; st.cnt = cnt; st.cur_run = cur_run; st.li = li;

@@ -262,13 +262,20 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         roff += (int64_t)FP_PLANES * pl.words; coff += ((m - 1) / CKW) * n; cells += n * m;
         m_maxb = std::max(m_maxb, m);
     }
-    const size_t wtrace_b = (size_t)np * FP_WWORDS * QA * G * 16;
+    // windows per request (fp_walk_kernel): reads of several row blocks get speculative windows for the next blocks up as well
+    const char *spenv = getenv("GNX_FP_SPEC");
+    // (batches of up to 32 768 such reads, whose window walk runs one wave per pair: with lanes walking on their own the rounds are
+    // not what costs -- 100 000 x (1000 x 1200): 2.97e12 cells/s with lanes and single windows, 2.71e12 with waves and 4 windows)
+    const bool wide_walk = S > 1 && np <= 32768 && !getenv("GNX_WALK_LANE");
+    const int K = wide_walk ? std::max(1, std::min(std::min(FP_SPEC, S), spenv ? atoi(spenv) : FP_SPEC)) : 1;
+    const int WW = fp_spec_wwords(K);
+    const size_t wtrace_b = (size_t)np * K * WW * QA * G * 16;
     const size_t need = wtrace_b + (size_t)coff * 8 + (size_t)roff * 4 + (size_t)rboff * 8 +
-                        (size_t)np * (CAP * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + (size_t)(H * 4 + G * 4) + 40);
+                        (size_t)np * (CAP * sizeof(gnx_cigar) + sizeof(FpState) + (1 + 2 * K) * sizeof(PairPlan) + (size_t)K * (H * 4 + G * 4) + 40);
     if ((int64_t)need > c.ws_limit) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] working set %zu B exceeds the workspace limit -> general path\n", need); return -1; }
     if ((rc = c.trace.ensure(wtrace_b))) return rc;
-    if ((rc = c.hcol.ensure((size_t)np * (H + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then the window hcol slots
-    if ((rc = c.dcol.ensure((size_t)np * G * 4))) return rc;
+    if ((rc = c.hcol.ensure((size_t)np * ((size_t)K * H + 1) * 4))) return rc;   // [0,np) h(n,m) of the forward sweep, then the window hcol slots
+    if ((rc = c.dcol.ensure((size_t)np * K * G * 4))) return rc;
     if ((rc = c.fp_strag.ensure((size_t)np * 2 * 4 + 64))) return rc;   // stragglers of this round / of the next one
     if ((rc = c.rowbuf.ensure((size_t)std::max<int64_t>(rboff, 1) * 8))) return rc;   // what each row block hands to the one below it
     if (two && (rc = c.fp_prog.ensure((size_t)S * ((np + G8 - 1) / G8) * 4 + 64))) return rc; // progress words of the levels' waves
@@ -281,7 +288,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     if ((rc = c.fp_states.ensure((size_t)np * sizeof(FpState)))) return rc;
     if ((rc = c.fp_stage.ensure((size_t)np * CAP * sizeof(gnx_cigar)))) return rc;
     for (int x = 0; x < 2; x++) {
-        if ((rc = c.fp_wplans[x].ensure((size_t)np * sizeof(PairPlan)))) return rc;
+        if ((rc = c.fp_wplans[x].ensure((size_t)np * K * sizeof(PairPlan)))) return rc;
         if ((rc = c.fp_active[x].ensure((size_t)np * 4))) return rc;
     }
     int *d_err = reinterpret_cast<int *>(c.misc.p);
@@ -352,9 +359,10 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     // tiles in the same round; walks that leave a row block through its top ask for a window of the block above.  A read of S row
     // blocks takes S rounds (plus those of its stragglers).  cnt2: [0], [1] = window requests (ping-pong), [2] = stragglers.
     auto post = [&](int p0, int cnt, hipStream_t st, int *cnt2, hipEvent_t e1, hipEvent_t e2) -> int {
-        uint4 *wtr = reinterpret_cast<uint4 *>(c.trace.p) + (int64_t)p0 * FP_WWORDS * QA * G;
-        int *whc = d_whcol + (int64_t)p0 * H;
-        unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * G;
+        uint4 *wtr = reinterpret_cast<uint4 *>(c.trace.p) + (int64_t)p0 * K * WW * QA * G;
+        int *whc = d_whcol + (int64_t)p0 * K * H;
+        unsigned *wdc = reinterpret_cast<unsigned *>(c.dcol.p) + (int64_t)p0 * K * G;
+        PairPlan *wpl[2] = {d_wpl[0] + (int64_t)p0 * K, d_wpl[1] + (int64_t)p0 * K};
         int2 *srb = reinterpret_cast<int2 *>(c.rowbuf.p); // the sweep's row buffer: the rows the blocks handed down
         int *d_strag = reinterpret_cast<int *>(c.fp_strag.p) + p0;
         int cur = 0, n_act = 0, it = 0;
@@ -366,7 +374,10 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         const bool cw = !getenv("GNX_WALK_LANE");
         const bool cw_first = cw && getenv("GNX_WALK_CW");
         auto k_first = cw_first ? (xp ? fp_walk_kernel<true, false, true, true> : fp_walk_kernel<true, false, false, true>) : (xp ? fp_walk_kernel<true, false, true> : fp_walk_kernel<true, false, false>);
-        auto k_next = xp ? fp_walk_kernel<false, false, true> : fp_walk_kernel<false, false, false>;
+        // reads of several row blocks: the window walk with one wave per pair as well -- a long read's walk is thousands of dependent
+        // loads for a lane on its own, and its diagonal runs are taken 64 cells per look (GNX_WALK_LANE=1: lanes)
+        const bool cw_next = cw && wide_walk;
+        auto k_next = cw_next ? (xp ? fp_walk_kernel<false, false, true, true> : fp_walk_kernel<false, false, false, true>) : (xp ? fp_walk_kernel<false, false, true> : fp_walk_kernel<false, false, false>);
         auto k_tiled = cw ? (xp ? fp_walk_kernel<false, true, true, true> : fp_walk_kernel<false, true, false, true>) : (xp ? fp_walk_kernel<false, true, true> : fp_walk_kernel<false, true, false>);
         auto wgrid = [&](int n) { return dim3((unsigned)(cw ? n : (n + 63) / 64)); };
         auto k_win = xp ? fill_affine_kernel<false, false, false, true, true, false, true> : fill_affine_kernel<false, false, false, true, true, false, false>;
@@ -375,7 +386,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         int h_cnt[4] = {0, 0, 0, 0};
         HIPCHK(hipMemsetAsync(cnt2, 0, 16, st));
         hipLaunchKernelGGL(k_first, dim3((unsigned)(cw_first ? cnt : (cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_tail,
-                           (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, d_wpl[0] + p0, d_err, p0, d_strag, cnt2 + 2, force(0), srb);
+                           (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, wpl[0], d_err, p0, d_strag, cnt2 + 2, force(0), srb, K, WW);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_cnt, cnt2, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -392,14 +403,14 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
             int n_strag2 = 0;
             if (n_act > 0) {
                 HIPCHK(hipEventRecord(e1, st));
-                hipLaunchKernelGGL(k_win, dim3((unsigned)((n_act + 3) / 4)), blockF, 0, st, d_wpl[cur] + p0, n_act, d_a, d_as, d_b, d_bs, kp,
+                hipLaunchKernelGGL(k_win, dim3((unsigned)(((int64_t)n_act * K + 3) / 4)), blockF, 0, st, wpl[cur], n_act * K, d_a, d_as, d_b, d_bs, kp,
                                    wtr, whc, srb, wdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipEventRecord(e2, st));
                 // (its stragglers go to a second list: d_strag holds this round's while they are being served)
-                hipLaunchKernelGGL(k_next, dim3((unsigned)((n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
-                                   d_wpl[cur] + p0, wtr, whc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, d_wpl[nxt] + p0, d_err, 0,
-                                   d_strag + cnt, cnt2 + 2, force(it + 1), srb);
+                hipLaunchKernelGGL(k_next, dim3((unsigned)(cw_next ? n_act : (n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
+                                   wpl[cur], wtr, whc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, wpl[nxt], d_err, 0,
+                                   d_strag + cnt, cnt2 + 2, force(it + 1), srb, K, WW);
                 HIPCHK(hipGetLastError());
             }
             if (n_strag > 0) { // all remaining columns of the stragglers' row blocks as independent tiles, one launch
@@ -420,8 +431,8 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                                    ttr, thc, srb, tdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
                 HIPCHK(hipEventRecord(c.ev[7], st));
                 hipLaunchKernelGGL(k_tiled, wgrid(n_strag), blockT, 0, st, dpl, d_strag, n_strag, d_st, d_hfwd, d_rowi, d_tail,
-                                   tpl, ttr, thc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, d_wpl[nxt] + p0, d_err, 0,
-                                   d_strag + cnt, cnt2 + 2, 0, srb);
+                                   tpl, ttr, thc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, wpl[nxt], d_err, 0,
+                                   d_strag + cnt, cnt2 + 2, 0, srb, K, WW);
                 HIPCHK(hipGetLastError());
             }
             HIPCHK(hipMemcpyAsync(h_cnt, cnt2, 16, hipMemcpyDeviceToHost, st));
@@ -807,7 +818,8 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const int rows_per_lane = (two || n_hi > 19 * G8) ? 20 : 19;
         if (fp) {
             // sub-batches whose fast-path working set (checkpoints, planes, window slots, staging) fits the workspace
-            const size_t fixed = (size_t)FP_WWORDS * QA * G * 16 + H * 4 + G * 4 + fp_cap(S) * sizeof(gnx_cigar) + sizeof(FpState) + 3 * sizeof(PairPlan) + 72;
+            const int Kw = S > 1 ? std::min(FP_SPEC, S) : 1; // windows per request (at most)
+            const size_t fixed = (size_t)Kw * ((size_t)fp_spec_wwords(Kw) * QA * G * 16 + H * 4 + G * 4 + 2 * sizeof(PairPlan)) + fp_cap(S) * sizeof(gnx_cigar) + sizeof(FpState) + sizeof(PairPlan) + 72;
             // ... of about equal size (a small last sub-batch would leave most of the GPU idle for the length of a sweep wave)
             std::vector<int64_t> cb{0};
             size_t acc_b = 0, total_b = 0;

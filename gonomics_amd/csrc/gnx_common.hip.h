@@ -54,6 +54,9 @@ constexpr int FP_MAXS = 128; // row blocks of 160 rows the fast path sweeps (rea
 constexpr int FP_TILE = 1024;                                  // straggler tiles: columns (c*FP_TILE, (c+1)*FP_TILE]
 constexpr int FP_TWORDS = (FP_TILE + CKW + 15 + 15) / 16;      // direction words of a tile (plus the checkpoint interval it starts early)
 constexpr int FP_WWORDS = (FP_SPAN + CKW + 15 + 15) / 16 + 1;                                         // direction words of the widest window
+constexpr int FP_SPEC = 4;                                                                             // windows per request of a read of several row blocks (1 asked for + speculative ones)
+__host__ __device__ constexpr int fp_spec_margin(int k) { return k == 0 ? 0 : 16 + 8 * k; }            // how far a path may drift from the diagonal over k row blocks and still find its window
+__host__ __device__ constexpr int fp_spec_wwords(int K) { return K <= 1 ? FP_WWORDS : (FP_SPAN + 2 * fp_spec_margin(K - 1) + CKW + 15 + 15) / 16 + 1; }
 __host__ __device__ constexpr int fp_cap(int S) { return FP_CAP * (S < 1 ? 1 : S); }                   // staged CIGAR runs per pair of S row blocks
 
 struct KParams {
