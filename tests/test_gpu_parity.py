@@ -637,6 +637,13 @@ def test_fast_path_many_row_blocks(gpu_lib, seed, n_lo, n_hi, monkeypatch):
         common.assert_same(gpu_lib.align_batch(p7, alphas, betas), exp7, "%d row blocks, 7x7 checkerboards, maxit %s" % (S, maxit))
     monkeypatch.setenv("GNX_NO_PIPE", "1")  # one launch per row block instead of one launch whose levels follow each other
     common.assert_same(gpu_lib.align_batch(p7, alphas, betas), exp7, "%d row blocks, a launch per level" % S)
+    monkeypatch.delenv("GNX_NO_PIPE")
+    monkeypatch.delenv("GNX_FP_MAXIT")
+    monkeypatch.setenv("GNX_WALK_LANE", "1")  # what batches of more than 32 768 such reads get: one lane per pair, one window per request
+    common.assert_same(gpu_lib.align_batch(p7, alphas, betas), exp7, "%d row blocks, lanes" % S)
+    monkeypatch.delenv("GNX_WALK_LANE")
+    monkeypatch.setenv("GNX_FP_SPEC", "2")   # one speculative window instead of three
+    common.assert_same(gpu_lib.align_batch(p7, alphas, betas), exp7, "%d row blocks, two windows per request" % S)
 
 
 @pytest.mark.gpu

@@ -31,7 +31,7 @@ def main():
         kind = int(rng.integers(0, 10))
         n = int(rng.integers(1, 161))
         cnt = int(rng.integers(1, 40))
-        for k in ("GNX_FASTPATH", "GNX_FP_MAXIT", "GNX_NO_PIPE"):
+        for k in ("GNX_FASTPATH", "GNX_FP_MAXIT", "GNX_NO_PIPE", "GNX_WALK_LANE", "GNX_FP_SPEC"):
             os.environ.pop(k, None)
         if kind >= 7:  # reads of several row blocks on the (forced) fast path: mixed numbers of blocks, both orientations, forced straggler rounds
             os.environ["GNX_FASTPATH"] = "2"
@@ -39,6 +39,10 @@ def main():
                 os.environ["GNX_FP_MAXIT"] = str(int(rng.choice([0, 1, 3])))
             if rng.random() < 0.2:
                 os.environ["GNX_NO_PIPE"] = "1"
+            if rng.random() < 0.25:
+                os.environ["GNX_WALK_LANE"] = "1"
+            elif rng.random() < 0.3:
+                os.environ["GNX_FP_SPEC"] = str(int(rng.choice([1, 2, 3])))
             n_top = int(rng.choice([200, 320, 500, 800, 1300]))
             uniform = rng.random() < 0.4
             m = int(rng.integers(300, 5000))
