@@ -871,8 +871,10 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // 3200 x 10 000: +46 %; 480 / 800 x 10 000 and a single 10 kb x 10 kb pair are faster over the stored matrix).
         long double rows_ld = 0;
         for (int64_t p = 0; p < n_pairs; p++) rows_ld += (long double)h_alen[p];
-        const bool big = (cells_ld >= 2.0e6L * (long double)n_pairs && (!affine || (rows_ld >= 1600.0L * (long double)n_pairs && n_pairs >= 256))) ||
-                         dir_bytes > (long double)c.ws_limit;
+        // (Since the fast path's row blocks take the batches of pairs x blocks >= 8192, what reaches this point with the affine functions
+        // is small batches, and there the stored matrix wins -- 256 x (3200 x 10 000): 5.96 ms against 10.2 ms: affine only when the matrix does not fit.)
+        (void)rows_ld;
+        const bool big = (cells_ld >= 2.0e6L * (long double)n_pairs && !affine) || dir_bytes > (long double)c.ws_limit;
         if (use && ((any_multi && big) || (cl && cl[0] == '2'))) {
             rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
             if (rc != -1) return rc;
