@@ -43,6 +43,42 @@ def test_pipelined_sub_batches(gpu_lib, monkeypatch):
         common.assert_same(gpu_lib.align_batch(pm, alphas, betas), oracle.align_batch(mode, MX["Default"], go, ge, alphas, betas, threads=8), "mode %d" % mode)
 
 
+def test_sub_batches_with_reads_of_several_row_blocks(gpu_lib, monkeypatch):
+    """the host entry point with reads of 100 .. 700 bases (1 .. 5 row blocks of the fast path, grouped per sub-batch) against windows
+    of 800 .. 2500 bases: sub-batches, the CIGAR buffer retry, global and local mode"""
+    rng = np.random.default_rng(74)
+    L = 2500
+    chunk = rng.integers(0, 4, size=L).astype(np.uint8)
+    n_pairs = 700
+    lens = rng.choice([100, 150, 200, 250, 320, 400, 700], size=n_pairs).astype(np.int64)
+    reads = []
+    for k in range(n_pairs):
+        n = int(lens[k]); o = int(rng.integers(0, L - n - 60))
+        r = common.mutate(rng, chunk[o:o + n + 50], sub=0.02, indel=0.006, geo=0.5)[:n]
+        if len(r) < n:
+            r = np.concatenate([r, rng.integers(0, 4, size=n - len(r)).astype(np.uint8)])
+        reads.append(r)
+    a = np.concatenate(reads)
+    a_start = np.zeros(n_pairs, dtype=np.int64); a_start[1:] = np.cumsum(lens)[:-1]
+    b_len = rng.choice([800, 1500, 2500], size=n_pairs).astype(np.int64)
+    b_len = np.maximum(b_len, lens + 100)
+    b_start = np.zeros(n_pairs, dtype=np.int64)
+    monkeypatch.setenv("GNX_FASTPATH", "2")  # (the batches are small: no routing rule)
+    for mode, go, ge in ((0, -600, -150), (3, -600, -150)):
+        p = gpu_lib.make_params(mode, MX["HumanChimpTwo"], go, ge)
+        if mode == 3:  # AffineGapLocal(target = window, query = read)
+            exp = oracle.align_batch_windows(mode, MX["HumanChimpTwo"], go, ge, chunk, b_start, b_len, a, a_start, lens, threads=8)
+        else:
+            exp = oracle.align_batch_windows(mode, MX["HumanChimpTwo"], go, ge, a, a_start, lens, chunk, b_start, b_len, threads=8)
+        for sub in ("1000000", "200", "64"):
+            monkeypatch.setenv("GNX_HOST_SUB", sub)
+            if mode == 3:
+                got = gpu_lib.align_batch_windows(p, chunk, b_start, b_len, a, a_start, lens)
+            else:
+                got = gpu_lib.align_batch_windows(p, a, a_start, lens, chunk, b_start, b_len)
+            common.assert_same(got, exp, "mode %d sub %s" % (mode, sub))
+
+
 def test_resident_reference(gpu_lib, monkeypatch):
     """gnx_set_reference + gnx_align_batch_by_offset == the same windows passed as host buffers"""
     rng = np.random.default_rng(73)
