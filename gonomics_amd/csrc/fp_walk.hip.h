@@ -39,7 +39,9 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                                                      int *__restrict__ next_active, int *__restrict__ next_count,
                                                      PairPlan *__restrict__ next_wplans, int *__restrict__ err, int p_base,
                                                      int *__restrict__ strag_active, int *__restrict__ strag_count, int force_strag,
-                                                     const int2 *__restrict__ rowbuf, int spec, int wwords) {
+                                                     const int2 *__restrict__ rowbuf, int spec, int wwords,
+                                                     const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                     const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp) {
     const int a = CW ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (a >= n_active) return;
     const int lane = threadIdx.x & 63;
@@ -220,6 +222,27 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             else if (j < st.j_hi) { int p2; ht = (int)((load_word<true>(wtrace, wp, 0, i + 1 - wrow, j + 1 - st.jc_lo, p2) >> (2 * p2)) & 3u); }
             else ht = whcol[wp.hcol_off + i - wrow - 1] & 3;
             k = k_of(ht);
+        }
+    }
+    if (FIRST && !XP && !done && k == 0 && i == pl.n && j >= i && cnt == 0 && (cur_op == -1 || cur_op == op_of(1))) {
+        // The walk so far is nothing, or one run of gap steps along row n (the stored plane), and it stands in state M at (n, j): then
+        // M(n, j) is known exactly -- h(n,m) if nothing was walked, else h(n,m) - gapOpen - gapExtend * (m - j): the gap was opened from
+        // this cell.  If the plain diagonal from here up to row 0 scores exactly that, the traceback IS that diagonal: every prefix of an
+        // optimal alignment is optimal for its end cell, so M(t, c) equals the diagonal's prefix score all the way up, hence
+        // h(t-1, c-1) = M(t-1, c-1), and tripleMaxTrace gives a tie to M (quirk Q1 re-reads the same argmax).  No window needed: the
+        // ~half of the reads without an indel whose trailing gap sits on row n skip the re-fill stages altogether.  A read whose best
+        // alignment is anything else fails the equality (its optimum is higher) and asks for its window as before.
+        const int64_t score = (int64_t)(hcol_fwd[pl.hcol_off] >> 2);
+        const int64_t V = cur_op == -1 ? score : score - tp.gap_open - tp.gap_extend * (int64_t)(pl.m - j);
+        const uint8_t *ap = a_buf + a_start[pl.src], *bp = b_buf + b_start[pl.src] + (j - i);
+        int64_t P = (j == i) ? 0 : tp.gap_open + tp.gap_extend * (int64_t)(j - i); // h(0, j - n): the leading gap
+        for (int t = 0; t < i; t++) P += (int64_t)(kp.sc4[min((int)ap[t], 4) * 5 + min((int)bp[t], 4)] >> 2);
+        if (P == V) {
+            emit(op_of(0), i); last_op = 0;
+            li -= i;
+            if (li < 0) { li %= tp.ci; if (li < 0) li += tp.ci; }
+            j -= i; i = 0;
+            done = true;
         }
     }
     if (done) {

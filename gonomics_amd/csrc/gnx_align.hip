@@ -386,7 +386,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         int h_cnt[4] = {0, 0, 0, 0};
         HIPCHK(hipMemsetAsync(cnt2, 0, 16, st));
         hipLaunchKernelGGL(k_first, dim3((unsigned)(cw_first ? cnt : (cnt + 63) / 64)), blockT, 0, st, dpl, (const int *)nullptr, cnt, d_st, d_hfwd, d_rowi, d_tail,
-                           (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, wpl[0], d_err, p0, d_strag, cnt2 + 2, force(0), srb, K, WW);
+                           (const PairPlan *)nullptr, wtr, whc, tp, d_stage, d_score, d_nops, d_act[0] + p0, cnt2, wpl[0], d_err, p0, d_strag, cnt2 + 2, force(0), srb, K, WW, d_a, d_as, d_b, d_bs, kp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_cnt, cnt2, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -410,7 +410,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                 // (its stragglers go to a second list: d_strag holds this round's while they are being served)
                 hipLaunchKernelGGL(k_next, dim3((unsigned)(cw_next ? n_act : (n_act + 63) / 64)), blockT, 0, st, dpl, d_act[cur] + p0, n_act, d_st, d_hfwd, d_rowi, d_tail,
                                    wpl[cur], wtr, whc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, wpl[nxt], d_err, 0,
-                                   d_strag + cnt, cnt2 + 2, force(it + 1), srb, K, WW);
+                                   d_strag + cnt, cnt2 + 2, force(it + 1), srb, K, WW, d_a, d_as, d_b, d_bs, kp);
                 HIPCHK(hipGetLastError());
             }
             if (n_strag > 0) { // all remaining columns of the stragglers' row blocks as independent tiles, one launch
@@ -432,7 +432,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                 HIPCHK(hipEventRecord(c.ev[7], st));
                 hipLaunchKernelGGL(k_tiled, wgrid(n_strag), blockT, 0, st, dpl, d_strag, n_strag, d_st, d_hfwd, d_rowi, d_tail,
                                    tpl, ttr, thc, tp, d_stage, d_score, d_nops, d_act[nxt] + p0, cnt2 + nxt, wpl[nxt], d_err, 0,
-                                   d_strag + cnt, cnt2 + 2, 0, srb, K, WW);
+                                   d_strag + cnt, cnt2 + 2, 0, srb, K, WW, d_a, d_as, d_b, d_bs, kp);
                 HIPCHK(hipGetLastError());
             }
             HIPCHK(hipMemcpyAsync(h_cnt, cnt2, 16, hipMemcpyDeviceToHost, st));
