@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
     int64_t cur_run = st.cur_run, li = st.li;
     // FIRST: the exact value of the walk's cell in its state -- h(n,m) to begin with, minus what every step taken so far contributed
     // (the steps of a first walk are gap cells on the stored planes and diagonal steps in the corner): see the shortcut after the loop
-    int64_t val = (FIRST && !XP) ? (int64_t)(hcol_fwd[pl.hcol_off] >> 2) : 0;
+    int64_t val = FIRST ? (int64_t)(hcol_fwd[pl.hcol_off] >> 2) : 0;
     const int cap = fp_cap(pl.strips);
     gnx_cigar *stg = stage + (int64_t)p * cap;
     auto flush_run = [&]() {
@@ -165,10 +165,10 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                 if (tag == 0) { atomicOr(err, 2); done = true; break; }
                 steps = pos - pnz + 1;
                 k = k_of(tag);
-                if (FIRST && !XP) val -= tp.gap_open; // the last of these cells opened the gap
+                if (FIRST && !(XP && i == pl.n)) val -= tp.gap_open; // the last of these cells opened the gap (XP: steps along the last row are free)
             }
             emit(op_of(1), steps); j -= steps; last_op = 1;
-            if (FIRST && !XP) val -= tp.gap_extend * (int64_t)steps;
+            if (FIRST && !(XP && i == pl.n)) val -= tp.gap_extend * (int64_t)steps;
             if (CW && TILED && !on_plane && x == 0 && steps == pos + 1 && j >= lo_ok(st.jc_lo)) {
                 // a straggler's long gap on a row without a stored plane: 64 words of its tile per look (lane t takes the t-th word
                 // further left), while they are all-I and lie inside the usable part of the tile
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                     const unsigned qv = lane < lim ? wbase[wi - lane] : 0u;
                     const unsigned long long stop = __ballot(!(lane < lim && qv == IRUN));
                     const int T = stop ? __ffsll((long long)stop) - 1 : 64;
-                    if (T > 0) { emit(op_of(1), 16 * (int64_t)T); j -= 16 * T; wi -= T; if (FIRST && !XP) val -= tp.gap_extend * 16 * (int64_t)T; }
+                    if (T > 0) { emit(op_of(1), 16 * (int64_t)T); j -= 16 * T; wi -= T; if (FIRST && !(XP && i == pl.n)) val -= tp.gap_extend * 16 * (int64_t)T; }
                     more = (T == 64);
                 }
                 while (!CW && more && wi >= 0 && j >= 16) {
@@ -205,14 +205,14 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                     for (int u = 0; u < 4; u++) q[u] = (wi - u >= 0) ? wbase[wi - u] : 0u;
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        if (more && q[u] == IRUN && j >= 16) { emit(op_of(1), 16); j -= 16; wi--; if (FIRST && !XP) val -= tp.gap_extend * 16; }
+                        if (more && q[u] == IRUN && j >= 16) { emit(op_of(1), 16); j -= 16; wi--; if (FIRST && !(XP && i == pl.n)) val -= tp.gap_extend * 16; }
                         else more = false;
                     }
                 }
             }
             continue;
         }
-        if (FIRST && !XP && k == 0) val -= (int64_t)(kp.sc4[min((int)a_buf[a_start[pl.src] + i - 1], 4) * 5 + min((int)b_buf[b_start[pl.src] + j - 1], 4)] >> 2); // a diagonal step: M(i,j) = h(i-1,j-1) + s
+        if (FIRST && k == 0) val -= (int64_t)(kp.sc4[min((int)a_buf[a_start[pl.src] + i - 1], 4) * 5 + min((int)b_buf[b_start[pl.src] + j - 1], 4)] >> 2); // a diagonal step: M(i,j) = h(i-1,j-1) + s
         emit(op_of(k), 1);
         last_op = k;
         bool up_exit = false;
@@ -230,15 +230,15 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             k = k_of(ht);
         }
     }
-    if (FIRST && !XP && !done && k == 0 && i >= 1 && j >= i) {
+    if (FIRST && !done && k == 0 && i >= 1 && j >= i) {
         // The walk stands in state M at (i, j) and `val` is M(i, j) exactly.  If the plain diagonal from here up to row 0 scores exactly
         // that, the traceback IS that diagonal: every prefix of an optimal alignment is optimal for its end cell, so M(t, c) equals the
         // diagonal's prefix score all the way up, hence h(t-1, c-1) = M(t-1, c-1), and tripleMaxTrace gives a tie to M (quirk Q1 re-reads
         // the same argmax).  No window needed: the reads without an indel (three quarters of the headline batch) skip the re-fill
         // stages altogether.  A read whose best alignment is anything else fails the equality (its optimum is higher) and asks for
-        // its window as before.
+        // its window as before.  (XP, the transposed AffineGapLocal: the same with a free row 0 and free steps along the last row.)
         const uint8_t *ap = a_buf + a_start[pl.src], *bp = b_buf + b_start[pl.src] + (j - i);
-        int64_t P = (j == i) ? 0 : tp.gap_open + tp.gap_extend * (int64_t)(j - i); // h(0, j - i): the leading gap
+        int64_t P = (XP || j == i) ? 0 : tp.gap_open + tp.gap_extend * (int64_t)(j - i); // h(0, j - i): the leading gap (XP: row 0 is free)
         for (int t = 0; t < i; t++) P += (int64_t)(kp.sc4[min((int)ap[t], 4) * 5 + min((int)bp[t], 4)] >> 2);
         if (P == val) {
             emit(op_of(0), i); last_op = 0;
