@@ -15,10 +15,12 @@
 //     in HBM; small launches run the strips as pipelined workgroups.  A separate traceback kernel walks the packed matrix
 //     (one lane per pair, or one wave per pair for long pairs), emulating the reference's checkerboard quirks, two passes
 //     (count, exclusive scan, write) so CIGARs come out densely in input order.
-//   * FAST path (short read x long window, affine; the headline workload; AffineGapLocal runs it transposed): fp_sweep_kernel
-//     computes scores only -- 8 lanes x 19/20 rows per pair, rebased keys (5 VALU instructions per cell), column checkpoints
-//     every 128 columns, the I-planes of the last four rows -- and fp_walk_kernel re-fills just the <= 319 columns around the
-//     path with the general kernel (WIN) to read its direction bits.
+//   * FAST path (a read of up to 20 480 bases x a window of >= 768, affine; the headline workload; AffineGapLocal runs it
+//     transposed): fp_sweep_kernel computes scores only -- 8 lanes x 19/20 rows per pair, rebased keys (5 VALU instructions per
+//     cell), column checkpoints every 128 columns, the I-planes of the last four rows; longer reads as row blocks of 160 rows in
+//     ONE launch whose levels follow each other through a row buffer (fp_sweep_levels_kernel) -- and fp_walk_kernel finishes a
+//     read whose traceback is a plain diagonal on the spot, or re-fills just the <= 319 columns x <= 160 rows around the path
+//     with the general kernel (WIN) to read its direction bits, block by block.
 //   * No MFMA: this is an integer max-plus recurrence.  No CPU fallback: every entry point needs the GPU.
 //
 // Source layout (one translation unit):
@@ -27,6 +29,8 @@
 //   fill_const.hip.h   fill_const_kernel (+GSW)   traceback.hip.h  traceback_kernel, gsw_traceback_kernel
 //   fp_walk.hip.h      fp_walk_kernel & co        aux_kernels.hip.h score_matrix / scale_runs / scan kernels
 //   const_long.hip.h   cl_sweep_kernel / cl_walk_kernel: constant-gap pairs without a stored direction matrix (config C5)
+//   affine_long.hip.h  the same scheme for affine pairs whose matrix does not fit     seed_kernels.hip.h  the graph aligner's index / seed search
+//   gnx_host.hip.h     host-buffer entry points: pinned staging, sub-batches, resident reference, contexts per GPU, RCCL
 //   gnx_align.hip      host orchestration + C ABI (this file)
 #include "gnx_common.hip.h"
 #include "fill_affine.hip.h"
@@ -236,8 +240,8 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
                   int64_t *out_total, hipStream_t stream, bool first, bool xp, int S) {
     // rows_per_lane: 19 (every n <= 152) or 20 (n <= 160) -> fp_sweep_kernel<19 / 20>
-    // S >= 2: every read has 160 (S - 1) + 1 .. 160 S bases: swept as S row blocks, one launch each (fp_sweep_kernel<.., false, 1>, then
-    //     S - 2 times <20, false, 3>, then <20, false, 2>), windows / tiles re-filled as S strips
+    // S >= 2: every read has 160 (S - 1) + 1 .. 160 S bases: swept as S row blocks in one launch (fp_sweep_levels_kernel: the levels
+    //     follow each other through the row buffer); the walk re-fills one row block per window / tile
     // xp: AffineGapLocal, transposed -- the caller passes the query as "a" (rows) and the target as "b" (columns), and kp holds the
     //     transposed score table with the column-0 boundary of a global alignment (fp_sweep_kernel<.., true> and friends)
     Ctx &c = g_ctx;
@@ -467,7 +471,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[3]));
     HIPCHK(hipEventElapsedTime(&fa, c.ev[0], c.ev[1]));
     const double forward_ms = (double)fa;
-    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] forward sweep (fp_sweep_kernel<%d%s>): %d pairs %.3f ms\n", rows_per_lane, xp ? ", transposed" : "", np, fa);
+    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx fp] forward sweep (%d row block%s, %d slots per lane%s): %d pairs %.3f ms\n", S, S > 1 ? "s in one launch" : "", rows_per_lane, xp ? ", transposed" : "", np, fa);
     if (first) c.timing = gnx_timing{};
     c.timing.fill_ms += forward_ms + refill_ms; c.timing.traceback_ms += std::max(0.0, (double)tot - fa - refill_ms); c.timing.total_ms += tot;
     c.timing.cells += cells; c.timing.n_launches += 1; c.timing.trace_bytes += (int64_t)coff * 8 + (int64_t)roff * 4;
@@ -869,11 +873,8 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // Affine (affine_long.hip.h): a global alignment against a long window crosses every column tile, so the re-fill costs about
         // 1 / strips of a full fill at the walk kernel's low occupancy: it pays from ~10 strips on, for batches (1600 x 10 000: +21 %,
         // 3200 x 10 000: +46 %; 480 / 800 x 10 000 and a single 10 kb x 10 kb pair are faster over the stored matrix).
-        long double rows_ld = 0;
-        for (int64_t p = 0; p < n_pairs; p++) rows_ld += (long double)h_alen[p];
         // (Since the fast path's row blocks take the batches of pairs x blocks >= 8192, what reaches this point with the affine functions
         // is small batches, and there the stored matrix wins -- 256 x (3200 x 10 000): 5.96 ms against 10.2 ms: affine only when the matrix does not fit.)
-        (void)rows_ld;
         const bool big = (cells_ld >= 2.0e6L * (long double)n_pairs && !affine) || dir_bytes > (long double)c.ws_limit;
         if (use && ((any_multi && big) || (cl && cl[0] == '2'))) {
             rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
