@@ -124,6 +124,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         }
         const int2 *ck0 = nullptr; // window re-fill: left boundary = column checkpoint col_off / CKW
         if (WIN && pl.col_off > 0) ck0 = ckpt + pl.ckpt_off + (int64_t)(pl.col_off / CKW - 1) * ck_pitch + row_base;
+        static_assert(!WIN || HFORM, "the checkpoints are rebased keys");
+        const int Kck = WIN ? RB * (row_base + pl.col_off) : 0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = row0 + r + 1; // column-0 cell of row i: M = I = -inf, D = D00 + i*ecol
@@ -131,15 +133,15 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
             rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;      // I(i,1) = D(i,0) + oe, rebased with j = 1
             if (XP && r == r_last) rt[r] = D1c - RB; // I'(n,1) = h(n,0), no penalty
-            // checkpoint {I(i,j+1), h(i,j)+e} of the sweep, plain values: both lose e*(i + 1) (window column 0; the e of "h+e" is the other one)
-            if (WIN && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x - RB * (i + 1); hold[r] = v.y - (REB ? RB * (i + 1) : 0); }
+            // checkpoint {I'(i,j+1), h'(i,j)} of the sweep, rebased with the pair's (i + j): + e*(row base + col_off) makes them this launch's
+            if (WIN && ck0 && gact && i <= pl.n) { const int2 v = ck0[i - 1]; rt[r] = v.x + Kck; hold[r] = v.y + Kck; }
             acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
         }
         const int grow0 = row0 + row_base; // row of the pair above this lane's first row
         int diag0 = (grow0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + grow0 * kp.ecol4 + TD - RB * row0);
         if (WIN && ck0) {
             if (grow0 == 0) diag0 = max3i(NEG4 + 3, (XP ? 0 : kp.o4 + pl.col_off * E4) + TI, NEG4 + TD); // h(0, col_off)
-            else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y - (REB ? RB * (row0 + 1) : 0);        // (row0 = 0: the checkpoint of the row above the window)
+            else if (gact && row0 <= pl.n) diag0 = ck0[row0 - 1].y + Kck;                              // (row0 = 0: the checkpoint of the row above the window)
         }
         int dn_out = 0, h_out = 0, b_out = 0;
         int sq_dn = 0, sq_h = 0;

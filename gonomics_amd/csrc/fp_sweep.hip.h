@@ -33,8 +33,10 @@ namespace {
 //        are FAKE ROWS with profile entry -e, whose diagonal candidate R(j-1) - e = R(j) reproduces row 0 column by column
 //        (their gap candidates R(j) + o and R(j-1) + o never exceed it), so the first real row sees exactly row 0 above it.
 //    Needs gapExtend < 0 (strictly) besides gapOpen <= 0.
-// Outputs (what fp_walk_kernel and the window re-fills of fill_affine_kernel<.., WIN> consume): un-rebased, tagged column
-// checkpoints {rt = I(i,j+1), X = h(i,j)+e} of every row every CKW columns, the I-plane words of rows n..n-3
+// Outputs (what fp_walk_kernel and the window re-fills of fill_affine_kernel<.., WIN> consume): column checkpoints
+// {I'(i,j+1), h'(i,j)} of every row every CKW columns -- the rebased keys as they stand in the registers (the re-fill shifts them into its own frame).  The checkpoints
+// cost 1.1 ms of the 29.8 ms sweep of the headline batch (28.7 ms without them); un-rebasing them in the sweep, 16-byte stores and
+// branch-free stores all measure the same within 0.2 ms --, the I-plane words of rows n..n-3
 // (word = step >> 4, field = step & 15 with step = j + 7), and h(n,m).
 // ------------------------------------------------------------------------------------------------------
 constexpr int G8 = 8;
@@ -238,13 +240,15 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
             }
             if (ckflag) { // wave-uniform: a real scalar branch (the empty asm keeps the per-lane test from being hoisted out of it)
             asm volatile("" ::: "memory");
-            if ((j & (CKW - 1)) == 0 && j < m_eff && valid) { // column checkpoint, un-rebased values {I(i,j+1), h(i,j)+e} (tag bits junk)
-                int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n;
+            if ((j & (CKW - 1)) == 0 && j < m_eff && valid) { // column checkpoint {I'(i,j+1), h'(i,j)}: the keys as they are (rebased with the pair's i + j; tag bits junk)
+                int2 *ck = ckpt + pl.ckpt_off + (int64_t)(j / CKW - 1) * pl.n + (q0 - P + row_base); // [r] = row q0 + r - P + 1 + row_base of the pair
+                if (q0 >= P) { // every slot of this lane is a row (all lanes but the first ones of a padded block): plain stores
 #pragma unroll
-                for (int r = 0; r < RR; r++) {
-                    const int i = q0 + r - P + 1 + row_base; // row of the pair
-                    const int off = E4 * (i + j + 1);
-                    if (i - row_base >= 1) ck[i - 1] = make_int2(rt[r] + off, hold[r] + off);
+                    for (int r = 0; r < RR; r++) ck[r] = make_int2(rt[r], hold[r]);
+                } else { // (a branch per row: only the steps at which a padded lane stands on a checkpoint column come here)
+#pragma unroll
+                    for (int r = 0; r < RR; r++)
+                        if (q0 + r >= P) ck[r] = make_int2(rt[r], hold[r]);
                 }
             }
             }
