@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNX_LIB_PATH") or os.path.join(_HERE, "libgonomics_align_hip.so")
 
-GNX_OK, GNX_EINVAL, GNX_EBASE, GNX_EEMPTY, GNX_ERANGE, GNX_EDEVICE, GNX_ENOMEM, GNX_ECAPACITY, GNX_ETRACE = range(9)
+GNX_OK, GNX_EINVAL, GNX_EBASE, GNX_EEMPTY, GNX_ERANGE, GNX_EDEVICE, GNX_ENOMEM, GNX_ECAPACITY, GNX_ETRACE, GNX_EDIVZERO = range(10)
 GNX_AFFINE_GAP, GNX_CONST_GAP, GNX_AFFINE_GAP_HIGHMEM, GNX_AFFINE_GAP_LOCAL, GNX_CONST_GAP_HIGHMEM = range(5)
 
 EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gnx_free", "gnx_align_batch",
@@ -38,7 +38,8 @@ class GnxTiming(ctypes.Structure):
     _fields_ = [("fill_ms", ctypes.c_double), ("traceback_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
                 ("cells", ctypes.c_int64), ("n_launches", ctypes.c_int64), ("trace_bytes", ctypes.c_int64),
                 ("dominant_ms", ctypes.c_double), ("dominant_launches", ctypes.c_int64), ("fast_path", ctypes.c_int32),
-                ("_pad", ctypes.c_int32), ("host_ms", ctypes.c_double), ("stage0_ms", ctypes.c_double), ("fetch_ms", ctypes.c_double)]
+                ("_pad", ctypes.c_int32), ("host_ms", ctypes.c_double), ("stage0_ms", ctypes.c_double), ("fetch_ms", ctypes.c_double),
+                ("transport", ctypes.c_int32), ("n_contexts", ctypes.c_int32), ("gather_ms", ctypes.c_double), ("bcast_ms", ctypes.c_double)]
 
 
 class GnxError(RuntimeError):
@@ -328,7 +329,7 @@ def get_timing():
     return {"fill_ms": t.fill_ms, "traceback_ms": t.traceback_ms, "total_ms": t.total_ms, "cells": t.cells,
             "n_launches": t.n_launches, "trace_bytes": t.trace_bytes, "dominant_ms": t.dominant_ms,
             "dominant_launches": t.dominant_launches, "fast_path": t.fast_path, "host_ms": t.host_ms, "stage0_ms": t.stage0_ms,
-            "fetch_ms": t.fetch_ms}
+            "fetch_ms": t.fetch_ms, "transport": t.transport, "n_contexts": t.n_contexts, "gather_ms": t.gather_ms, "bcast_ms": t.bcast_ms}
 
 
 def _cat(seqs):

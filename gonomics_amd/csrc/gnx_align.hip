@@ -113,7 +113,9 @@ struct Ctx {
     DevBuf sd_keys, sd_locs, sd_nodes, sd_node_off, sd_word_off, sd_words, sd_tmp[8];
     int64_t sd_n = -1, sd_nodes_n = 0; int sd_seed_len = 0;
     PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
-    int64_t ref_len = -1; // >= 0: a reference is resident in `ref`
+    int64_t ref_len = -1; // >= 0: a reference of that many bases is resident in `ref`
+    size_t ref_bytes = 0; // bytes of `ref` in use
+    int64_t ref_epoch = 0; // which gnx_set_reference call filled `ref` (contexts created later are brought up to date on first use)
     hipEvent_t ev_in[2] = {nullptr, nullptr};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -1178,7 +1180,7 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     HIPCHK(hipMemcpyAsync(sflag, c.sc_err.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (sflag[0] & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
-    if (sflag[0] & 16) { set_err("scoreColumnMatch over gap-only columns: the reference panics (integer divide by zero)%s", ""); return GNX_EINVAL; }
+    if (sflag[0] & 16) { set_err("scoreColumnMatch over gap-only columns: the reference panics (integer divide by zero)%s", ""); return GNX_EDIVZERO; }
     int64_t cap = std::max<int64_t>(std::min<int64_t>(worst, std::max<int64_t>((int64_t)1 << 20, 64 * n_pairs)), 1);
     int64_t total = 0;
     for (int attempt = 0; attempt < 8; attempt++) {
@@ -1312,6 +1314,7 @@ int gnx_init_devices(int n_devices, const int *devices, int64_t workspace_bytes)
         for (ncclComm_t cm : g_rccl.comms) (void)g_rccl.CommDestroy(cm);
         g_rccl.comms.clear();
     }
+    g_rccl_broken = false;
     for (int k = 0; k < n_devices; k++) {
         Ctx &c = ctx_at(k);
         CtxScope sc(c);
@@ -1375,6 +1378,7 @@ void gnx_shutdown(void) {
     g_pool.drain();
     g_nctx = 1;
     g_shared_dev = false;
+    g_rccl_broken = false;
 }
 
 /* the calling thread's last error; if this thread has none, the most recent error of the process (a cgo caller may fetch the
@@ -1389,22 +1393,36 @@ const char *gnx_last_error(void) {
 
 void gnx_free(void *p) { if (p && !g_pool.put(p)) free(p); }
 
-int gnx_set_reference(const uint8_t *ref, int64_t len) {
-    std::lock_guard<std::mutex> api(g_api_mu);
-    g_err[0] = 0;
-    if (len < 0 || (len > 0 && !ref)) { set_err("bad argument%s", ""); return GNX_EINVAL; }
-    std::vector<void *> dst((size_t)g_nctx, nullptr);
+int64_t g_ref_epoch = 0;
+// makes `len` bases resident on every context in use: allocates, marks, and returns the per-context pointers for the broadcast
+static int reference_slots(int64_t len, std::vector<void *> &dst) {
+    g_ref_epoch++;
+    dst.assign((size_t)g_nctx, nullptr);
     for (int d = 0; d < g_nctx; d++) {
         Ctx &c = ctx_at(d);
         CtxScope sc(c);
         int rc = ensure_init();
         if (rc) return rc;
-        if ((rc = c.ref.ensure((size_t)len + 16))) return rc;
-        c.ref_len = len;
+        if ((rc = c.ref.ensure((size_t)len + 16))) { c.ref_len = -1; return rc; }
+        c.ref_len = len; c.ref_bytes = (size_t)len; c.ref_epoch = g_ref_epoch;
         dst[(size_t)d] = c.ref.p;
     }
+    // contexts beyond g_nctx (a smaller gnx_init_devices after a larger one) no longer hold the current reference
+    int n_all; { std::lock_guard<std::mutex> lk(g_ctxs_mu); n_all = (int)g_ctxs.size(); }
+    for (int d = g_nctx; d < n_all; d++) { Ctx &c = ctx_at(d); CtxScope sc(c); c.ref_len = -1; }
+    return GNX_OK;
+}
+
+int gnx_set_reference(const uint8_t *ref, int64_t len) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    g_err[0] = 0;
+    if (len < 0 || (len > 0 && !ref)) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    std::vector<void *> dst;
+    int rc = reference_slots(len, dst);
+    if (rc) return rc;
     Ctx &c0 = ctx_at(0);
     { CtxScope sc(c0); HIPCHK(hipSetDevice(c0.device)); if (len) HIPCHK(hipMemcpy(c0.ref.p, ref, (size_t)len, hipMemcpyHostToDevice)); }
+    g_bcast_ms = 0;
     return broadcast_from_ctx0(c0.ref.p, dst, (size_t)len);
 }
 
@@ -1412,16 +1430,9 @@ int gnx_set_reference_synthetic(int64_t len, uint64_t seed) {
     std::lock_guard<std::mutex> api(g_api_mu);
     g_err[0] = 0;
     if (len < 0) { set_err("bad argument%s", ""); return GNX_EINVAL; }
-    std::vector<void *> dst((size_t)g_nctx, nullptr);
-    for (int d = 0; d < g_nctx; d++) {
-        Ctx &c = ctx_at(d);
-        CtxScope sc(c);
-        int rc = ensure_init();
-        if (rc) return rc;
-        if ((rc = c.ref.ensure((size_t)len + 16))) return rc;
-        c.ref_len = len;
-        dst[(size_t)d] = c.ref.p;
-    }
+    std::vector<void *> dst;
+    int rc = reference_slots(len, dst);
+    if (rc) return rc;
     Ctx &c0 = ctx_at(0);
     {
         CtxScope sc(c0);
@@ -1431,6 +1442,7 @@ int gnx_set_reference_synthetic(int64_t len, uint64_t seed) {
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c0.own_stream));
     }
+    g_bcast_ms = 0;
     return broadcast_from_ctx0(c0.ref.p, dst, (size_t)len);
 }
 
@@ -1593,6 +1605,7 @@ int gnx_seed_index_build(const uint8_t *node_cat, const int64_t *node_off, int64
     *out_keys = nullptr; *out_locs = nullptr; *out_n = 0;
     if (n_slots == 0) return GNX_OK;
     DevBuf *t = c.sd_tmp;
+    c.sd_n = -1; // the build uploads its nodes into the buffers of the resident index: gnx_seed_find_batch needs a new gnx_seed_index_set
     if ((rc = c.sd_nodes.ensure((size_t)total + 64))) return rc;
     if ((rc = c.sd_node_off.ensure((size_t)(n_nodes + 1) * 8))) return rc;
     if ((rc = t[0].ensure((size_t)(n_nodes + 1) * 8))) return rc;   // slot_off

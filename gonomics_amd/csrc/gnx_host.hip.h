@@ -96,7 +96,17 @@ int rccl_load() {
         ncclResult_t r_ = (call);                                                                                         \
         if (r_ != ncclSuccess) { set_err("RCCL error: %s", g_rccl.GetErrorString(r_)); return GNX_EDEVICE; }              \
     } while (0)
-bool rccl_active() { return !g_rccl.comms.empty(); }
+bool g_rccl_broken = false; // a RCCL call failed in this process: every later exchange uses peer copies (transport 3)
+int g_transport = 0;        // what carried the last broadcast / gather, see gnx_timing.transport
+double g_bcast_ms = 0;      // broadcast time of the current call
+bool rccl_active() { return !g_rccl.comms.empty() && !g_rccl_broken; }
+// after a failed RCCL call: remember the text, drain whatever was enqueued, and never use the communicators again
+void rccl_give_up() {
+    g_rccl_broken = true;
+    fprintf(stderr, "[gnx] %s -- falling back to peer copies for this process\n", g_err);
+    for (int d = 0; d < g_nctx; d++) { Ctx &c = ctx_at(d); if (c.inited && hipSetDevice(c.device) == hipSuccess) (void)hipDeviceSynchronize(); }
+    (void)hipGetLastError();
+}
 
 __global__ __launch_bounds__(256) void add_offset_kernel(int64_t *__restrict__ off, int64_t n, int64_t base) {
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,9 +168,10 @@ int run_host_job(HostJob &j) {
     if ((rc = c.res_off.ensure((size_t)(n + 1) * 8))) return rc;
     if (n == 0) { HIPCHK(hipMemsetAsync(c.res_off.p, 0, 8, c.own_stream)); HIPCHK(hipStreamSynchronize(c.own_stream)); return GNX_OK; }
     int64_t sub = 131072;
-    if (const char *e = getenv("GNX_HOST_SUB")) sub = std::max<int64_t>(atoll(e), 8);
-    const int64_t K = (n + sub - 1) / sub;
-    const int64_t size = (((n + K - 1) / K) + 7) & ~(int64_t)7;
+    if (const char *e = getenv("GNX_HOST_SUB")) sub = (std::max<int64_t>(atoll(e), 8) + 7) & ~(int64_t)7;
+    const int64_t K0 = (n + sub - 1) / sub;
+    const int64_t size = (((n + K0 - 1) / K0) + 7) & ~(int64_t)7; // equal sub-batches (the fast path re-uses its plans), whole waves
+    const int64_t K = (n + size - 1) / size;                      // rounding `size` up can save a sub-batch: never index past n
     const int64_t *as = j.a_start + j.p0, *al = j.a_len + j.p0, *bs = j.b_start + j.p0, *bl = j.b_len + j.p0;
 
     // stage(k): inputs of sub-batch k -> device buffers of slot k & 1 (H2D on s_in, event ev_in[slot]).  k == 0 copies straight from
@@ -284,23 +295,59 @@ std::vector<int64_t> partition_by_cells(const int64_t *a_len, const int64_t *b_l
 
 // broadcast `bytes` from context 0's buffer src0 to dst[d] of every other context (RCCL over xGMI; plain copies when the contexts
 // share a device or RCCL is off)
+// GNX_RCCL_INJECT_FAIL=1: the next RCCL exchange reports a failure before it starts (tests of the fall-back to peer copies)
+bool rccl_injected_failure() {
+    if (!getenv("GNX_RCCL_INJECT_FAIL")) return false;
+    set_err("RCCL error: injected failure (GNX_RCCL_INJECT_FAIL)%s", "");
+    return true;
+}
+int broadcast_rccl(const void *src0, std::vector<void *> &dst, size_t bytes) {
+    const int nc = (int)dst.size();
+    if (rccl_injected_failure()) return GNX_EDEVICE;
+    RCCLCHK(g_rccl.GroupStart());
+    for (int d = 0; d < nc; d++) {
+        Ctx &c = ctx_at(d);
+        HIPCHK(hipSetDevice(c.device));
+        RCCLCHK(g_rccl.Broadcast(src0, d == 0 ? const_cast<void *>(src0) : dst[(size_t)d], bytes, ncclUint8, 0, g_rccl.comms[(size_t)d], c.own_stream));
+    }
+    RCCLCHK(g_rccl.GroupEnd());
+    for (int d = 0; d < nc; d++) { Ctx &c = ctx_at(d); HIPCHK(hipSetDevice(c.device)); HIPCHK(hipStreamSynchronize(c.own_stream)); }
+    return GNX_OK;
+}
 int broadcast_from_ctx0(const void *src0, std::vector<void *> &dst, size_t bytes) {
     const int nc = (int)dst.size();
-    if (bytes == 0) return GNX_OK;
-    if (rccl_active() && (int)g_rccl.comms.size() == nc) { // (also with one rank: the call is then a no-op that checks the plumbing)
-        RCCLCHK(g_rccl.GroupStart());
-        for (int d = 0; d < nc; d++) {
-            Ctx &c = ctx_at(d);
-            HIPCHK(hipSetDevice(c.device));
-            RCCLCHK(g_rccl.Broadcast(src0, d == 0 ? const_cast<void *>(src0) : dst[(size_t)d], bytes, ncclUint8, 0, g_rccl.comms[(size_t)d], c.own_stream));
-        }
-        RCCLCHK(g_rccl.GroupEnd());
-        for (int d = 0; d < nc; d++) { Ctx &c = ctx_at(d); HIPCHK(hipSetDevice(c.device)); HIPCHK(hipStreamSynchronize(c.own_stream)); }
-        HIPCHK(hipSetDevice(ctx_at(0).device));
-        return GNX_OK;
-    }
-    for (int d = 1; d < nc; d++) HIPCHK(hipMemcpyPeer(dst[(size_t)d], ctx_at(d).device, src0, ctx_at(0).device, bytes));
+    if (bytes == 0 || nc == 0) return GNX_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    // RCCL needs every rank of the communicator in the collective: a call that uses fewer contexts than gnx_init_devices created
+    // (a batch too small to cut) copies instead
+    bool via_rccl = rccl_active() && (int)g_rccl.comms.size() == nc; // (also with one rank: a no-op that checks the plumbing)
+    const bool tried = via_rccl;
+    if (via_rccl && broadcast_rccl(src0, dst, bytes) != GNX_OK) { rccl_give_up(); via_rccl = false; }
+    if (!via_rccl) for (int d = 1; d < nc; d++) if (dst[(size_t)d] != src0) HIPCHK(hipMemcpyPeer(dst[(size_t)d], ctx_at(d).device, src0, ctx_at(0).device, bytes));
+    HIPCHK(hipSetDevice(ctx_at(0).device));
+    if (nc > 1 || tried) g_transport = via_rccl ? 1 : (g_rccl_broken ? 3 : 2);
+    g_bcast_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return GNX_OK;
+}
+// the resident reference on contexts [0, nc): a context created after gnx_set_reference (gnx_init_devices called later)
+// gets its copy from context 0 here
+int ensure_reference(int nc) {
+    Ctx &c0 = ctx_at(0);
+    bool missing = false;
+    std::vector<void *> dst((size_t)nc, nullptr);
+    for (int d = 0; d < nc; d++) {
+        Ctx &c = ctx_at(d);
+        CtxScope sc(c);
+        int rc = ensure_init();
+        if (rc) return rc;
+        if (d > 0 && (c.ref_len != c0.ref_len || c.ref.p == nullptr || c.ref_epoch != c0.ref_epoch)) {
+            missing = true;
+            if ((rc = c.ref.ensure(c0.ref_bytes + 16))) return rc;
+            c.ref_len = c0.ref_len; c.ref_bytes = c0.ref_bytes; c.ref_epoch = c0.ref_epoch;
+        }
+        dst[(size_t)d] = c.ref.p;
+    }
+    return missing ? broadcast_from_ctx0(c0.ref.p, dst, c0.ref_bytes) : GNX_OK;
 }
 
 // The sharded host flow.  b_buf == nullptr: beta windows index the resident reference (gnx_set_reference).
@@ -315,6 +362,7 @@ int run_host_sharded(const gnx_params *prm, int64_t n_pairs,
     Ctx &c0 = ctx_at(0);
     int rc;
     { CtxScope sc(c0); if ((rc = ensure_init())) return rc; }
+    g_transport = 0; g_bcast_ms = 0;
     if (resident) {
         if (c0.ref_len < 0) { set_err("no resident reference: call gnx_set_reference first%s", ""); return GNX_EINVAL; }
         b_len_total = c0.ref_len;
@@ -333,7 +381,11 @@ int run_host_sharded(const gnx_params *prm, int64_t n_pairs,
     const bool whole_b = !resident && b_len_total > 0 && (sum_b > 1.5L * (long double)b_len_total || b_len_total <= ((int64_t)16 << 20));
     std::vector<void *> bdev((size_t)nc, nullptr);
     if (resident) {
-        for (int d = 0; d < nc; d++) bdev[(size_t)d] = ctx_at(d).ref.p;
+        if ((rc = ensure_reference(nc))) return rc;
+        for (int d = 0; d < nc; d++) {
+            bdev[(size_t)d] = ctx_at(d).ref.p;
+            if (!bdev[(size_t)d] && b_len_total > 0) { set_err("context %s%lld has no resident reference", "", (long long)d); return GNX_EINVAL; }
+        }
     } else if (whole_b) {
         for (int d = 0; d < nc; d++) {
             Ctx &c = ctx_at(d);
@@ -374,53 +426,82 @@ int run_host_sharded(const gnx_params *prm, int64_t n_pairs,
     auto fail = [&](int code) { g_pool.put(ops); g_pool.put(off); return code; };
     CtxScope sc(c0);
     if (hipSetDevice(c0.device) != hipSuccess) { set_err("hipSetDevice failed%s", ""); return fail(GNX_EDEVICE); }
+    double gather_ms = 0;
     const int64_t *d_score = (const int64_t *)c0.res_score.p, *d_off = (const int64_t *)c0.res_off.p;
     const gnx_cigar *d_ops = (const gnx_cigar *)c0.res_ops.p;
     if (nc > 1) {
         if ((rc = c0.gat_score.ensure((size_t)std::max<int64_t>(n_pairs, 1) * 8))) return fail(rc);
         if ((rc = c0.gat_off.ensure((size_t)(n_pairs + nc) * 8))) return fail(rc);
         if ((rc = c0.gat_ops.ensure((size_t)std::max<int64_t>(total, 1) * sizeof(gnx_cigar)))) return fail(rc);
-        auto gather = [&]() -> int {
-            int64_t obase = 0;
-            if (rccl_active()) {
-                RCCLCHK(g_rccl.GroupStart());
-                for (int d = 0; d < nc; d++) {
-                    HostJob &j = jobs[(size_t)d];
-                    Ctx &c = *j.c;
-                    const int64_t nd = j.p1 - j.p0;
-                    HIPCHK(hipSetDevice(c.device));
-                    if (nd > 0) {
-                        RCCLCHK(g_rccl.Send(c.res_score.p, (size_t)nd, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
-                        RCCLCHK(g_rccl.Send(c.res_off.p, (size_t)nd + 1, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
-                    }
-                    if (j.total_ops > 0) RCCLCHK(g_rccl.Send(c.res_ops.p, (size_t)j.total_ops * 2, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
-                    HIPCHK(hipSetDevice(c0.device));
-                    if (nd > 0) {
-                        RCCLCHK(g_rccl.Recv((int64_t *)c0.gat_score.p + j.p0, (size_t)nd, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
-                        RCCLCHK(g_rccl.Recv((int64_t *)c0.gat_off.p + j.p0 + d, (size_t)nd + 1, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
-                    }
-                    if (j.total_ops > 0) RCCLCHK(g_rccl.Recv((gnx_cigar *)c0.gat_ops.p + obase, (size_t)j.total_ops * 2, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
-                    obase += j.total_ops;
-                }
-                RCCLCHK(g_rccl.GroupEnd());
-                for (int d = 0; d < nc; d++) { Ctx &c = *jobs[(size_t)d].c; HIPCHK(hipSetDevice(c.device)); HIPCHK(hipStreamSynchronize(c.own_stream)); }
-                HIPCHK(hipSetDevice(c0.device));
-            } else {
-                for (int d = 0; d < nc; d++) {
-                    HostJob &j = jobs[(size_t)d];
-                    Ctx &c = *j.c;
-                    const int64_t nd = j.p1 - j.p0;
-                    if (nd > 0) {
-                        HIPCHK(hipMemcpyPeer((int64_t *)c0.gat_score.p + j.p0, c0.device, c.res_score.p, c.device, (size_t)nd * 8));
-                        HIPCHK(hipMemcpyPeer((int64_t *)c0.gat_off.p + j.p0 + d, c0.device, c.res_off.p, c.device, (size_t)(nd + 1) * 8));
-                    }
-                    if (j.total_ops > 0) HIPCHK(hipMemcpyPeer((gnx_cigar *)c0.gat_ops.p + obase, c0.device, c.res_ops.p, c.device, (size_t)j.total_ops * sizeof(gnx_cigar)));
-                    obase += j.total_ops;
-                }
+        // context 0's own share never goes through RCCL (no send-to-self): a device-to-device copy on its stream
+        auto gather_local = [&]() -> int {
+            HostJob &j = jobs[0];
+            const int64_t nd = j.p1 - j.p0;
+            HIPCHK(hipSetDevice(c0.device));
+            if (nd > 0) {
+                HIPCHK(hipMemcpyAsync((int64_t *)c0.gat_score.p + j.p0, c0.res_score.p, (size_t)nd * 8, hipMemcpyDeviceToDevice, c0.own_stream));
+                HIPCHK(hipMemcpyAsync((int64_t *)c0.gat_off.p + j.p0, c0.res_off.p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToDevice, c0.own_stream));
             }
+            if (j.total_ops > 0) HIPCHK(hipMemcpyAsync(c0.gat_ops.p, c0.res_ops.p, (size_t)j.total_ops * sizeof(gnx_cigar), hipMemcpyDeviceToDevice, c0.own_stream));
             return GNX_OK;
         };
+        auto gather_rccl = [&]() -> int {
+            int64_t obase = jobs[0].total_ops;
+            if (rccl_injected_failure()) return GNX_EDEVICE;
+            RCCLCHK(g_rccl.GroupStart());
+            for (int d = 1; d < nc; d++) {
+                HostJob &j = jobs[(size_t)d];
+                Ctx &c = *j.c;
+                const int64_t nd = j.p1 - j.p0;
+                HIPCHK(hipSetDevice(c.device));
+                if (nd > 0) {
+                    RCCLCHK(g_rccl.Send(c.res_score.p, (size_t)nd, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
+                    RCCLCHK(g_rccl.Send(c.res_off.p, (size_t)nd + 1, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
+                }
+                if (j.total_ops > 0) RCCLCHK(g_rccl.Send(c.res_ops.p, (size_t)j.total_ops * 2, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
+                HIPCHK(hipSetDevice(c0.device));
+                if (nd > 0) {
+                    RCCLCHK(g_rccl.Recv((int64_t *)c0.gat_score.p + j.p0, (size_t)nd, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
+                    RCCLCHK(g_rccl.Recv((int64_t *)c0.gat_off.p + j.p0 + d, (size_t)nd + 1, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
+                }
+                if (j.total_ops > 0) RCCLCHK(g_rccl.Recv((gnx_cigar *)c0.gat_ops.p + obase, (size_t)j.total_ops * 2, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
+                obase += j.total_ops;
+            }
+            RCCLCHK(g_rccl.GroupEnd());
+            for (int d = 0; d < nc; d++) { Ctx &c = *jobs[(size_t)d].c; HIPCHK(hipSetDevice(c.device)); HIPCHK(hipStreamSynchronize(c.own_stream)); }
+            HIPCHK(hipSetDevice(c0.device));
+            return GNX_OK;
+        };
+        auto gather_copies = [&]() -> int {
+            int64_t obase = jobs[0].total_ops;
+            for (int d = 1; d < nc; d++) {
+                HostJob &j = jobs[(size_t)d];
+                Ctx &c = *j.c;
+                const int64_t nd = j.p1 - j.p0;
+                if (nd > 0) {
+                    HIPCHK(hipMemcpyPeer((int64_t *)c0.gat_score.p + j.p0, c0.device, c.res_score.p, c.device, (size_t)nd * 8));
+                    HIPCHK(hipMemcpyPeer((int64_t *)c0.gat_off.p + j.p0 + d, c0.device, c.res_off.p, c.device, (size_t)(nd + 1) * 8));
+                }
+                if (j.total_ops > 0) HIPCHK(hipMemcpyPeer((gnx_cigar *)c0.gat_ops.p + obase, c0.device, c.res_ops.p, c.device, (size_t)j.total_ops * sizeof(gnx_cigar)));
+                obase += j.total_ops;
+            }
+            HIPCHK(hipSetDevice(c0.device));
+            return GNX_OK;
+        };
+        auto gather = [&]() -> int {
+            int r = gather_local();
+            if (r) return r;
+            // every rank of the communicator must take part in a grouped exchange: only when the call uses all contexts
+            bool via_rccl = rccl_active() && (int)g_rccl.comms.size() == nc;
+            if (via_rccl && gather_rccl() != GNX_OK) { rccl_give_up(); via_rccl = false; if ((r = gather_local())) return r; }
+            if (!via_rccl && (r = gather_copies())) return r;
+            HIPCHK(hipStreamSynchronize(c0.own_stream));
+            g_transport = via_rccl ? 1 : (g_rccl_broken ? 3 : 2);
+            return GNX_OK;
+        };
+        const auto t_gather = std::chrono::steady_clock::now();
         if ((rc = gather())) return fail(rc);
+        gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gather).count();
         d_score = (const int64_t *)c0.gat_score.p; d_ops = (const gnx_cigar *)c0.gat_ops.p;
     }
     auto fetch = [&]() -> int {
@@ -454,9 +535,10 @@ int run_host_sharded(const gnx_params *prm, int64_t n_pairs,
     }
     t.fetch_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fetch).count();
     t.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
+    t.transport = g_transport; t.n_contexts = nc; t.gather_ms = gather_ms; t.bcast_ms = g_bcast_ms;
     c0.timing = t;
-    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx host] %lld pairs on %d context(s): call %.3f ms = first upload %.3f + kernels %.3f (device, slowest context) + gather / D2H %.3f + rest\n",
-                                     (long long)n_pairs, nc, t.host_ms, t.stage0_ms, t.total_ms, t.fetch_ms);
+    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx host] %lld pairs on %d context(s): call %.3f ms = first upload %.3f + kernels %.3f (device, slowest context) + gather / D2H %.3f (gather %.3f, transport %d) + broadcast %.3f + rest\n",
+                                     (long long)n_pairs, nc, t.host_ms, t.stage0_ms, t.total_ms, t.fetch_ms, t.gather_ms, t.transport, t.bcast_ms);
     *out_ops = ops; *out_ops_off = off;
     return GNX_OK;
 }

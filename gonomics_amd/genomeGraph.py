@@ -519,10 +519,21 @@ def CatPaths(currPaths, newPaths):
     return currPaths + list(newPaths[1:])
 
 
+class GoPanic(RuntimeError):
+    """a situation in which the Go code panics (the process dies): reported, never papered over"""
+
+
 def _left_target(n, extension, refEnd, seq):
-    """getLeftTargetBases (search.go:135-140)"""
-    take = min(len(seq) + refEnd, extension) - len(seq)
-    return np.concatenate([n.Seq[refEnd - take:refEnd], seq]).astype(np.uint8)
+    """getLeftTargetBases (search.go:135-140), the expression AS WRITTEN: `refEnd-numbers.Min(len(seq)+refEnd, extension)-len(seq)` is
+    left-associative, i.e. the slice starts at refEnd - min(..) - len(seq) -- not at refEnd - (min(..) - len(seq)) as the commented-out
+    lines above it intend.  With an empty `seq` (the first node of a traversal) both agree.  With bases already collected (a
+    traversal that went into a Prev node) the reference takes extension + len(seq) bases of that node when it is long enough, and
+    panics with a negative slice bound when it is not."""
+    start = refEnd - min(len(seq) + refEnd, extension) - len(seq)
+    if start < 0 or start > refEnd:
+        raise GoPanic("runtime error: slice bounds out of range [%d:%d] (getLeftTargetBases, search.go:139: node %d, %d bases collected, extension %d)"
+                      % (start, refEnd, n.Id, len(seq), extension))
+    return np.concatenate([n.Seq[start:refEnd], seq]).astype(np.uint8)
 
 
 def _right_target(n, extension, start, seq):
@@ -654,17 +665,29 @@ def _read_to_giraf(gg, read, seeds, scoreMatrix):
     return best
 
 
-def GswBatchToGiraf(gg, reads, index, seedLen, scoreMatrix, device_seeds=True):
-    """GraphSmithWatermanToGiraf for a batch of reads: seeds from the device (or the host statement), then rounds of batched DPs."""
+def GswBatchToGiraf(gg, reads, index, seedLen, scoreMatrix, device_seeds=True, on_panic="raise"):
+    """GraphSmithWatermanToGiraf for a batch of reads: seeds from the device (or the host statement), then rounds of batched DPs.
+    on_panic: what to do with a read on which the Go code panics (getLeftTargetBases with a short Prev node, see _left_target):
+    "raise" (default: the Go process would die there) or "mark" (that read's result is the GoPanic instance, the others go on)."""
     seeds = seed_map_batch(index, gg.Nodes, reads, seedLen) if device_seeds else [seed_map_host(index, gg.Nodes, r, seedLen) for r in reads]
     gens = [_read_to_giraf(gg, r, s, scoreMatrix) for r, s in zip(reads, seeds)]
     results = [None] * len(reads)
     pending = {}
-    for k, g in enumerate(gens):
+
+    def advance(k, value, first):
         try:
-            pending[k] = next(g)
+            pending[k] = next(gens[k]) if first else gens[k].send(value)
         except StopIteration as st:
             results[k] = st.value
+            pending.pop(k, None)
+        except GoPanic as gp:
+            if on_panic != "mark":
+                raise
+            results[k] = gp
+            pending.pop(k, None)
+
+    for k in range(len(gens)):
+        advance(k, None, True)
     while pending:
         for side in ("left", "right"):
             ks = [k for k, rq in pending.items() if rq[0] == side]
@@ -672,9 +695,5 @@ def GswBatchToGiraf(gg, reads, index, seedLen, scoreMatrix, device_seeds=True):
                 continue
             outs = DynamicAlnBatch(side, [pending[k][1] for k in ks], [pending[k][2] for k in ks], scoreMatrix, -600, [pending[k][3] for k in ks])
             for k, o in zip(ks, outs):
-                try:
-                    pending[k] = gens[k].send(o)
-                except StopIteration as st:
-                    results[k] = st.value
-                    del pending[k]
+                advance(k, o, False)
     return results

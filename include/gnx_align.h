@@ -45,6 +45,7 @@ extern "C" {
 #define GNX_ENOMEM 6    /* host or device allocation failed / workspace too small for one pair */
 #define GNX_ECAPACITY 7 /* caller-provided device CIGAR buffer too small (device entry point) */
 #define GNX_ETRACE 8    /* impossible traceback value: the Go code would log.Fatalf */
+#define GNX_EDIVZERO 9  /* scoreColumnMatch over a column pair of gaps only: the Go code panics (integer divide by zero, multiAlign.go:101) */
 
 /* align.ColType, /root/reference/align/align.go:12-18 */
 #define GNX_COL_M 0
@@ -95,6 +96,12 @@ typedef struct gnx_timing {
     double host_ms;      /* entry to return of the whole call */
     double stage0_ms;    /* exposed upload of the first sub-batch (later ones run under the kernels) */
     double fetch_ms;     /* gather on device 0 + D2H of scores / offsets / CIGAR runs */
+    /* multi-context calls (gnx_init_devices): */
+    int32_t transport;   /* what carried the last broadcast / gather: 0 one context, 1 RCCL over xGMI, 2 peer copies (GNX_RCCL=0, or a
+                            device listed twice), 3 peer copies AFTER a RCCL call failed (the text is in gnx_last_error) */
+    int32_t n_contexts;  /* contexts the call was sharded over */
+    double gather_ms;    /* the gather on device 0 alone (part of fetch_ms) */
+    double bcast_ms;     /* broadcast of the shared beta buffer of this call (0 with a resident reference) */
 } gnx_timing;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */

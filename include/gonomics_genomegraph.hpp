@@ -36,6 +36,9 @@ inline void gnxCheck(int rc) {
     if (rc != GNX_OK) throw std::runtime_error(std::string("libgonomics_align_hip: ") + gnx_last_error());
 }
 
+// a situation in which the Go code panics (the process dies): reported, never papered over
+struct GoPanic : std::runtime_error { using std::runtime_error::runtime_error; };
+
 // ---- cigar.Cigar (cigar/cigar.go:15-35): SAM-style ops as bytes ------------------------------------------------------------
 struct Cigar {
     int64_t RunLength;
@@ -497,8 +500,12 @@ class Traversal {
         const int64_t have = (int64_t)seq.size() + (left_ ? pos : (int64_t)n->Seq.size() - pos);
         int64_t take = std::min(have, ext_) - (int64_t)seq.size();
         if (take < 0) take = 0;
-        if (left_) { // getLeftTargetBases (search.go:135-140)
-            f.sSeq.assign(n->Seq.begin() + (pos - take), n->Seq.begin() + pos);
+        if (left_) { // getLeftTargetBases (search.go:135-140), the expression as written: refEnd - Min(len(seq)+refEnd, extension) - len(seq)
+            // is left-associative, so with bases already collected the slice starts len(seq) further left than the commented-out
+            // intent (extension + len(seq) bases of a Prev node), and a negative start is a Go panic
+            const int64_t start = pos - std::min(have, ext_) - (int64_t)seq.size();
+            if (start < 0 || start > pos) throw GoPanic("runtime error: slice bounds out of range (getLeftTargetBases, search.go:139)");
+            f.sSeq.assign(n->Seq.begin() + start, n->Seq.begin() + pos);
             f.sSeq.insert(f.sSeq.end(), seq.begin(), seq.end());
             f.leaf = have >= ext_ || n->Prev.empty();
         } else { // getRightBases (search.go:142-147)
@@ -526,6 +533,8 @@ struct Giraf { // giraf.Giraf, the fields the function fills (giraf/giraf.go:16-
     int64_t AlnScore = 0;
     int MapQ = 255;
     const Bases *Seq = nullptr;
+    bool Panicked = false; // GswBatchToGiraf(.., markPanics = true): the Go code panics on this read (see GoPanic); the other fields are void
+    std::string PanicText;
 };
 inline void AddPath(std::vector<uint32_t> &all, uint32_t p) {
     if (all.empty() || all.back() != p) all.push_back(p);
@@ -655,14 +664,25 @@ class ReadTask {
     }
 };
 // GraphSmithWatermanToGiraf for a batch of reads: seeds from the device, then rounds of batched DPs (gapPen: gsw passes -600)
+// markPanics: a read on which the Go code panics (getLeftTargetBases with a short Prev node) is marked Panicked and the others go on;
+// default: the GoPanic propagates (the Go process would die there)
 inline std::vector<Giraf> GswBatchToGiraf(const GenomeGraph &g, std::vector<FastqBig> &reads, const SeedIndex &index, const int64_t *scores25,
-                                          int64_t gapPen = -600, int *outRounds = nullptr) {
+                                          int64_t gapPen = -600, int *outRounds = nullptr, bool markPanics = false) {
     auto seeds = seedMapBatch(index, g, reads);
     std::vector<std::unique_ptr<ReadTask>> tasks;
     std::vector<size_t> pending;
+    auto advance = [&](size_t k, const DpResult *res) -> bool {
+        try {
+            return tasks[k]->advance(res);
+        } catch (const GoPanic &gp) {
+            if (!markPanics) throw;
+            tasks[k]->best.Panicked = true; tasks[k]->best.PanicText = gp.what();
+            return false;
+        }
+    };
     for (size_t k = 0; k < reads.size(); k++) {
         tasks.push_back(std::make_unique<ReadTask>(g, reads[k], std::move(seeds[k]), scores25));
-        if (tasks.back()->advance(nullptr)) pending.push_back(k);
+        if (advance(k, nullptr)) pending.push_back(k);
     }
     int rounds = 0;
     std::vector<char> alive(reads.size(), 0);
@@ -677,7 +697,7 @@ inline std::vector<Giraf> GswBatchToGiraf(const GenomeGraph &g, std::vector<Fast
             if (ks.empty()) continue;
             auto outs = DynamicAlnBatch(side, rq, scores25, gapPen);
             for (size_t y = 0; y < ks.size(); y++)
-                if (!tasks[ks[y]]->advance(&outs[y])) { alive[ks[y]] = 0; n_alive--; }
+                if (!advance(ks[y], &outs[y])) { alive[ks[y]] = 0; n_alive--; }
         }
         rounds++;
     }

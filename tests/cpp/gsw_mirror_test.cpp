@@ -41,10 +41,11 @@ int main(int argc, char **argv) {
         SeedIndex index(g, seedLen, seedStep);
         auto t1 = std::chrono::steady_clock::now();
         int rounds = 0;
-        auto res = GswBatchToGiraf(g, reads, index, sc, -600, &rounds);
+        auto res = GswBatchToGiraf(g, reads, index, sc, -600, &rounds, /*markPanics=*/true);
         auto t2 = std::chrono::steady_clock::now();
         std::ofstream out(argv[2]);
         for (const Giraf &r : res) {
+            if (r.Panicked) { out << "panic\n"; continue; } // the Go code panics on this read (getLeftTargetBases, search.go:139)
             out << r.QStart << ' ' << r.QEnd << ' ' << (r.PosStrand ? 1 : 0) << ' ' << r.TStart << ' ' << r.TEnd << ' ' << r.AlnScore << " |";
             for (uint32_t n : r.Nodes) out << ' ' << n;
             out << " |";

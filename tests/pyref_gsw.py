@@ -248,8 +248,12 @@ def could_be_better(seed_len, best, perfect, qlen, mx, mn, lsm, lsc):
 # ---- traversals (routes as [(run, op 0/1/2)], the oracle's format) ----
 def left_trav(nodes, nid, seq, ref_end, path, extension, read, scores, route):
     n = nodes[nid]
-    take = min(len(seq) + ref_end, extension) - len(seq)
-    s_seq = [int(x) for x in n["seq"][ref_end - take:ref_end]] + list(seq)
+    # search.go:139 as Go parses it: ((refEnd - Min(len(seq)+refEnd, extension)) - len(seq)); a negative bound is a Go panic
+    lo = ref_end - min(len(seq) + ref_end, extension)
+    lo = lo - len(seq)
+    if lo < 0:
+        raise IndexError("slice bounds out of range [%d:%d]" % (lo, ref_end))
+    s_seq = [int(x) for x in n["seq"][lo:ref_end]] + list(seq)
     s_path = list(path)  # AddPath's result is dropped (search.go:176): the node is not recorded
     if len(seq) + ref_end >= extension or not n["prev"]:
         score, aln, ti, qi = oracle.gsw_extend(0, scores, -600, s_seq, read, route_in=route)
