@@ -18,7 +18,7 @@ EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gn
            "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing",
            "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch",
            "gnx_init_devices", "gnx_n_devices", "gnx_set_reference", "gnx_set_reference_synthetic", "gnx_align_batch_by_offset",
-           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch"]
+           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch", "gnx_debug_occupy"]
 
 
 class GnxCigar(ctypes.Structure):
@@ -106,6 +106,8 @@ def lib():
         L.gnx_seed_find_batch.restype = ctypes.c_int
         L.gnx_get_timing.argtypes = [ctypes.POINTER(GnxTiming)]
         L.gnx_get_timing.restype = ctypes.c_int
+        L.gnx_debug_occupy.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.gnx_debug_occupy.restype = ctypes.c_int
         _lib = L
     return _lib
 

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
     const bool piped = strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
-    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
+    const int bid = piped ? block_ticket(strip_prog + gridDim.x) : (int)blockIdx.x; // piped: the work item is the ticket, not the block index
+    const int pbase = (piped ? strip_map[bid].x : bid) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
     const int Tend = (m_max + 15 + 15) & ~15;
     int bad = 0;
 
-    const int s_lo = piped ? strip_map[blockIdx.x].y : 0, s_hi = piped ? s_lo + 1 : S_max;
+    const int s_lo = piped ? strip_map[bid].y : 0, s_hi = piped ? s_lo + 1 : S_max;
     const int64_t rb_pitch = (int64_t)pl.m + 1;
     for (int s = s_lo; s < s_hi; s++) {
         const bool gact = valid && s < pl.strips;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
                 const long long t_begin = wall_clock64();
-                while ((rb_seen = rb_progress(&strip_prog[blockIdx.x - 1])) < cmax) {
+                while ((rb_seen = rb_progress(&strip_prog[bid - 1])) < cmax) {
                     __builtin_amdgcn_s_sleep(32);
                     if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; }
                 }
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
             }
             // the progress word of the strip above is polled ONE BLOCK AHEAD (the load issued in the previous block lands while its 16
             // steps run); only a strip that has caught up with its producer falls into the blocking spin of wait_rows
-            if (piped && s > 0) { rb_seen = max(rb_seen, pf_seen); if (rb_seen < t0 + 5 * G) pf_seen = rb_progress(&strip_prog[blockIdx.x - 1]); }
+            if (piped && s > 0) { rb_seen = max(rb_seen, pf_seen); if (rb_seen < t0 + 5 * G) pf_seen = rb_progress(&strip_prog[bid - 1]); }
             wait_rows(t0 + 2 * G);
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
@@ -178,13 +179,13 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
                 const int c = t0 + l - 14;
                 if (c >= 1 && c <= m_eff) rb_store32(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_v, piped);
             }
-            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[blockIdx.x], t0 + 1, lane);
+            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[bid], t0 + 1, lane);
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
             for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (val[r] >> 2) + (kp.g4 >> 2) * (pl.n + m_eff); // plain V(n, m)
         }
-        if (piped) rb_publish(&strip_prog[blockIdx.x], 0x7fffffff, lane);
+        if (piped) rb_publish(&strip_prog[bid], 0x7fffffff, lane);
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     if (bad) atomicOr(err, 1);

@@ -11,9 +11,10 @@ namespace {
 //           one wave per 4 pairs (host decision: strip_map != nullptr), the strips of a pair run as separate workgroups,
 //           pipelined: block (group of 4 pairs, strip s) reads the bottom row of strip s-1 from the row buffer once the block
 //           before it has published it (strip_prog, every RB_PUB steps; rows and progress word are agent-scope atomics, see rb_store).  A 20 kb x 100 kb
-//           pair is up to 125 concurrent waves instead of one.  Blocks are ordered (group, strip) and every XCD dispatches
-//           its share in order, so the lowest unfinished block is always resident and never waits: no deadlock; a 5 s
-//           timeout on the spin turns any surprise into an error flag instead of a hang.  Such launches store their direction
+//           pair is up to 125 concurrent waves instead of one.  Work items are ordered (group, strip) and a workgroup takes
+//           the item of the TICKET it draws at its start (block_ticket), not of its block index: the item it waits for has a
+//           smaller number, so its workgroup is already running -- no deadlock whatever the dispatch order; the 5 s timeout on
+//           the spin is a bug trap (error flag instead of a hang), not part of the protocol.  Such launches store their direction
 //           words non-temporally (full lines that the fill never reads back).
 //   P16   = 4*score fits int16: the per-row score profile is stored as packed int16 pairs in LDS
 //   HFORM = gapOpen <= 0 (every caller): with h = max3(M,I,D) the recurrences collapse to
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
 
     const bool piped = MULTI && strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
-    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
+    const int bid = piped ? block_ticket(strip_prog + gridDim.x) : (int)blockIdx.x; // piped: the work item is the ticket, not the block index
+    const int pbase = (piped ? strip_map[bid].x : bid) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vOE4), "=v"(vE4), "=v"(vO4) : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4));
     int bad = 0;
 
-    const int s_lo = piped ? strip_map[blockIdx.x].y : 0, s_hi = piped ? s_lo + 1 : S_max;
+    const int s_lo = piped ? strip_map[bid].y : 0, s_hi = piped ? s_lo + 1 : S_max;
     const int64_t rb_pitch = (int64_t)pl.m + 1; // row-buffer entries per strip of this pair
     for (int s = s_lo; s < s_hi; s++) {
         const bool gact = valid && s < pl.strips;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
                 const long long t_begin = wall_clock64();
-                while ((rb_seen = rb_progress(&strip_prog[blockIdx.x - 1])) < cmax) {
+                while ((rb_seen = rb_progress(&strip_prog[bid - 1])) < cmax) {
                     __builtin_amdgcn_s_sleep(32);
                     if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; } // 5 s at 100 MHz
                 }
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 const int c = t0 + l - 14;
                 if (c >= 1 && c <= m_eff) rb_store(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_dn, sq_h, piped);
             }
-            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[blockIdx.x], t0 + 1, lane); // the bottom row of this strip is out up to column t0 + 1
+            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[bid], t0 + 1, lane); // the bottom row of this strip is out up to column t0 + 1
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             for (int r = 0; r < R; r++) dw |= ((acc[2 * R + r] >> (30 - 2 * missf)) & 3u) << (2 * r);
             dcol[pl.dcol_off + s * G + l] = dw;
         }
-        if (piped) rb_publish(&strip_prog[blockIdx.x], 0x7fffffff, lane);
+        if (piped) rb_publish(&strip_prog[bid], 0x7fffffff, lane);
         else if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     if (bad) atomicOr(err, 1);

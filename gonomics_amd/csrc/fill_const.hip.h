@@ -39,7 +39,8 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
     const bool piped = MULTI && strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
-    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
+    const int bid = piped ? block_ticket(strip_prog + gridDim.x) : (int)blockIdx.x; // piped: the work item is the ticket, not the block index
+    const int pbase = (piped ? strip_map[bid].x : bid) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vGL), "=v"(vGU) : "s"(kp.g4 + 2), "s"(kp.g4 + 1));
     int bad = 0;
 
-    const int s_lo = piped ? strip_map[blockIdx.x].y : 0, s_hi = piped ? s_lo + 1 : S_max;
+    const int s_lo = piped ? strip_map[bid].y : 0, s_hi = piped ? s_lo + 1 : S_max;
     const int64_t rb_pitch = (int64_t)pl.m + 1;
     for (int s = s_lo; s < s_hi; s++) {
         const bool gact = valid && s < pl.strips;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
                 const long long t_begin = wall_clock64();
-                while ((rb_seen = rb_progress(&strip_prog[blockIdx.x - 1])) < cmax) {
+                while ((rb_seen = rb_progress(&strip_prog[bid - 1])) < cmax) {
                     __builtin_amdgcn_s_sleep(32);
                     if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; }
                 }
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                 const int c = t0 + l - 14;
                 if (c >= 1 && c <= m_eff) rb_store(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_v, 0, piped);
             }
-            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[blockIdx.x], t0 + 1, lane);
+            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[bid], t0 + 1, lane);
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             for (int r = 0; r < R; r++) dw |= ((acc[r] >> (30 - 2 * missf)) & 3u) << (2 * r);
             dcol[pl.dcol_off + s * G + l] = dw;
         }
-        if (piped) rb_publish(&strip_prog[blockIdx.x], 0x7fffffff, lane);
+        if (piped) rb_publish(&strip_prog[bid], 0x7fffffff, lane);
         else if (MULTI) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     if (bad) atomicOr(err, 1);

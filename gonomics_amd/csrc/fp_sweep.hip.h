@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
 
 // reads of S >= 2 row blocks: the grid holds n_levels levels of W waves, block index = level-major, level level0 + blockIdx.x / W (0 = top).
 //   piped = 1: ONE launch for all levels (level0 = 0, n_levels = S); wave w of a level follows wave w of the level above through
-//              prog[level * W + w].  Workgroups are dispatched in index order, so a block's producer is always on the GPU before it.
+//              prog[level * W + w].  Work items are handed out by ticket (block_ticket), so an item's producer has always started before it.
 //              (800 x 10 000, 12 000 pairs: 21.2 ms against 27.8 ms for five launches of 1 500 waves; 32 768 pairs: 51.4 / 52.6 ms.
 //              Level-major order beats wave-major -- the levels of a wave group as grid neighbours, in lockstep -- 51.4 / 54.1 ms.)
 //   piped = 0: one launch per level in turn (n_levels = 1): nothing to wait for (GNX_NO_PIPE, and the fallback after a timeout).
@@ -339,7 +339,10 @@ __global__ __launch_bounds__(64) void fp_sweep_levels_kernel(const PairPlan *__r
                                                              unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err,
                                                              int2 *__restrict__ rowbuf, int S, int W, int level0, int piped, int *__restrict__ prog) {
     __shared__ int lds[32 + 8 * FP8_PST + 8 * 8 * 2]; // + the staging area of the hand-over (8 pairs x 8 columns x int2)
-    const int lv = (int)blockIdx.x / W, w = (int)blockIdx.x - lv * W, level = level0 + lv, below = S - 1 - level;
+    // piped: the (level, wave) a workgroup sweeps is its TICKET, not its block index (block_ticket): the wave it follows, ticket - W, is
+    // then running or done whatever order workgroups start in; the counter sits behind the S * W progress words
+    const int bid = piped ? block_ticket(prog + (int64_t)S * W) : (int)blockIdx.x;
+    const int lv = bid / W, w = bid - lv * W, level = level0 + lv, below = S - 1 - level;
     int *po = prog + (int64_t)level * W + w;
     const int *pi = po - W;
     if (level == 0) fp_sweep_body<RRTOP, XP, 1>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, nullptr, po);

@@ -129,8 +129,9 @@ struct Ctx {
 std::mutex g_ctxs_mu;          // guards the list itself
 std::vector<Ctx *> g_ctxs;     // [0] = the default context; never shrinks while the library is loaded
 thread_local Ctx *t_ctx = nullptr;
-// set while a call is re-run with sequential strips after a pipelined launch timed out waiting for a row buffer (the pipeline relies
-// on workgroups being dispatched in block order; if a driver / partition mode ever breaks that, the call still returns right results)
+// set while a call is re-run with sequential strips after a pipelined launch timed out waiting for a row buffer (a bug trap: work
+// items are handed out by ticket, block_ticket, so a producer has always started before its consumer; should the trap ever fire,
+// the call still returns right results)
 thread_local bool t_no_pipe = false;
 bool no_pipe() { return t_no_pipe || getenv("GNX_NO_PIPE") != nullptr; }
 Ctx &ctx_at(int k) {
@@ -222,6 +223,25 @@ int run_device(const gnx_params *prm, int64_t n_pairs, const uint8_t *d_a, const
                const int64_t *h_alen, const int64_t *h_blen, int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off,
                int64_t *out_total, hipStream_t stream, const int *d_smat, const int64_t *h_soff, int gsw, int2 *d_endpos, bool no_fast_path, bool smat16);
 
+// holds a CU's whole LDS and spins until `ticks` of the 100 MHz wall clock have passed (gnx_debug_occupy)
+__global__ __launch_bounds__(64) void occupy_kernel(long long ticks) {
+    extern __shared__ int occupy_lds[];
+    occupy_lds[threadIdx.x] = (int)ticks;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+// GNX_TICKET_DELAY=k (tests): the lower half of a piped grid sleeps k x 127 x 64 cycles before it draws its tickets (block_ticket), so
+// the work items are taken out of block-index order.  tk[0] = the counter (already zeroed), tk[1] = the switch.
+int ticket_test_switch(int *tk, hipStream_t st) {
+    const char *e = getenv("GNX_TICKET_DELAY");
+    if (!e || !*e) return GNX_OK;
+    const int v = atoi(e);
+    HIPCHK(hipMemcpyAsync(tk + 1, &v, 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return GNX_OK;
+}
+
 // exclusive scan of the run counts: off[0..n], carry[0] in / out (see scan_kernel); three launches when the array is long
 int launch_scan(const int64_t *d_nops, int n, int64_t *d_off, int64_t *d_carry, hipStream_t stream) {
     Ctx &c = g_ctx;
@@ -284,7 +304,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     if ((rc = c.dcol.ensure((size_t)np * K * G * 4))) return rc;
     if ((rc = c.fp_strag.ensure((size_t)np * 2 * 4 + 64))) return rc;   // stragglers of this round / of the next one
     if ((rc = c.rowbuf.ensure((size_t)std::max<int64_t>(rboff, 1) * 8))) return rc;   // what each row block hands to the one below it
-    if (two && (rc = c.fp_prog.ensure((size_t)S * ((np + G8 - 1) / G8) * 4 + 64))) return rc; // progress words of the levels' waves
+    if (two && (rc = c.fp_prog.ensure((size_t)S * ((np + G8 - 1) / G8) * 4 + 64))) return rc; // progress words of the levels' waves + the ticket counter
     if ((rc = c.plans.ensure((size_t)np * sizeof(PairPlan)))) return rc;
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
     if ((rc = c.misc.ensure(64))) return rc;
@@ -337,10 +357,11 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
             const int W = (int)grid8.x;
             int *prog = reinterpret_cast<int *>(c.fp_prog.p);
             if (!no_pipe()) {
-                HIPCHK(hipMemsetAsync(prog, 0, (size_t)S * W * 4, st));
+                HIPCHK(hipMemsetAsync(prog, 0, ((size_t)S * W + 2) * 4, st)); // progress words, ticket counter, test switch
+                if ((rc = ticket_test_switch(prog + (size_t)S * W, st))) return rc;
                 hipLaunchKernelGGL(klev, dim3((unsigned)(S * W)), blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, rb, S, W, 0, 1, prog);
                 HIPCHK(hipGetLastError());
-                int e = 0; // a level that waited 5 s for the one above it (cannot happen while workgroups start in index order): sweep again, level by level
+                int e = 0; // a level that waited 5 s for the one above it (a bug trap: with tickets the level above has always started): sweep again, level by level
                 HIPCHK(hipMemcpyAsync(&e, d_err, 4, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 if (!(e & 16)) return GNX_OK;
@@ -624,11 +645,12 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             }
             n_blocks = (int64_t)smap.size();
             if (n_blocks > 0x7fffffff) { set_err("too many strips in one chunk%s", ""); return GNX_ENOMEM; }
-            if ((rc = c.strip_map.ensure((size_t)std::max<int64_t>(n_blocks, 1) * 12))) return rc;
+            if ((rc = c.strip_map.ensure((size_t)std::max<int64_t>(n_blocks, 1) * 12 + 8))) return rc; // map, progress words, ticket counter + test switch
             d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
             d_sprog = reinterpret_cast<int *>(reinterpret_cast<char *>(c.strip_map.p) + (size_t)std::max<int64_t>(n_blocks, 1) * 8);
             HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)n_blocks * 8, hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)std::max<int64_t>(n_blocks, 1) * 4, stream));
+            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)std::max<int64_t>(n_blocks, 1) * 4 + 8, stream));
+            if ((rc = ticket_test_switch(d_sprog + n_blocks, stream))) return rc;
             HIPCHK(hipStreamSynchronize(stream)); // smap is a local
         }
         HIPCHK(hipEventRecord(c.ev[1], stream));
@@ -997,11 +1019,12 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             }
             n_blocks = (int64_t)smap.size();
             if (n_blocks > 0x7fffffff) { set_err("too many strips in one chunk%s", ""); return GNX_ENOMEM; }
-            if ((rc = c.strip_map.ensure((size_t)std::max<int64_t>(n_blocks, 1) * 12))) return rc;
+            if ((rc = c.strip_map.ensure((size_t)std::max<int64_t>(n_blocks, 1) * 12 + 8))) return rc; // map, progress words, ticket counter + test switch
             d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
             d_sprog = reinterpret_cast<int *>(reinterpret_cast<char *>(c.strip_map.p) + (size_t)std::max<int64_t>(n_blocks, 1) * 8);
             HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)n_blocks * 8, hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)std::max<int64_t>(n_blocks, 1) * 4, stream));
+            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)std::max<int64_t>(n_blocks, 1) * 4 + 8, stream));
+            if ((rc = ticket_test_switch(d_sprog + n_blocks, stream))) return rc;
             HIPCHK(hipStreamSynchronize(stream)); // smap is a local
         }
         const dim3 gridF((unsigned)n_blocks), blockF(64);
@@ -1403,6 +1426,7 @@ static int reference_slots(int64_t len, std::vector<void *> &dst) {
         CtxScope sc(c);
         int rc = ensure_init();
         if (rc) return rc;
+        if (len == 0) c.ref.release(); // an empty reference gives the memory back
         if ((rc = c.ref.ensure((size_t)len + 16))) { c.ref_len = -1; return rc; }
         c.ref_len = len; c.ref_bytes = (size_t)len; c.ref_epoch = g_ref_epoch;
         dst[(size_t)d] = c.ref.p;
@@ -1748,6 +1772,22 @@ int gnx_seed_find_batch(const uint8_t *read_cat, const int64_t *read_off, int64_
     for (int64_t r = 0; r <= n_reads; r++) hoff[r] = soff[(size_t)slot_off[(size_t)r]];
     *out_hits = hh; *out_hit_off = hoff;
     guard.a = nullptr; guard.b = nullptr;
+    return GNX_OK;
+}
+
+/* diagnostics: n_workgroups workgroups that each hold a whole CU's LDS and spin for `milliseconds`, on a stream of their own; returns
+ * at once.  The stress leg of the ticket protocol (tests/test_ticket.py): piped launches must finish with half the CUs taken away. */
+int gnx_debug_occupy(int n_workgroups, int milliseconds) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    CtxScope sc(ctx_at(0));
+    g_err[0] = 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (n_workgroups <= 0 || milliseconds < 0 || milliseconds > 10000) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    static bool attr_set = false;
+    if (!attr_set) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)n_workgroups), dim3(64), 160 * 1024, g_ctx.s_in, (long long)milliseconds * 100000LL);
+    HIPCHK(hipGetLastError());
     return GNX_OK;
 }
 

@@ -112,6 +112,24 @@ __device__ __forceinline__ int rb_progress(const int *prog) {
     asm volatile("" ::: "memory"); // row loads stay behind the progress load
     return v;
 }
+// ---- logical index of a workgroup in a piped launch: a TICKET drawn when the workgroup starts -----------------------------------
+// HIP promises nothing about the order in which workgroups are dispatched (MI355X_MICROARCH "Workgroup dispatch": placement-
+// independent protocols only), and a workgroup of a piped launch spins on the progress of another one.  So a workgroup does not derive
+// what it works on from blockIdx: it draws the next ticket of the launch and takes the work item of that number.  Every item a
+// workgroup waits for has a smaller number, i.e. its ticket was drawn earlier, i.e. the workgroup that holds it is already running
+// (or done): by induction the unfinished item with the smallest number never waits for something that has not started, whatever the
+// dispatch order, the partition mode or other kernels on the device do.  tk[0] = the counter (zeroed by the host before the
+// launch); tk[1] = test switch GNX_TICKET_DELAY: the workgroups of the lower half of the grid sleep before drawing, so tickets come
+// out of index order and the suite proves that nothing depends on it.  One wave per workgroup (all piped kernels).
+__device__ __forceinline__ int block_ticket(int *tk) {
+    int t = 0;
+    if (threadIdx.x == 0) {
+        const int delay = tk[1];
+        if (delay && blockIdx.x * 2 < gridDim.x) for (int i = 0; i < delay; i++) __builtin_amdgcn_s_sleep(127);
+        t = atomicAdd(tk, 1);
+    }
+    return __builtin_amdgcn_readfirstlane(t);
+}
 __device__ __forceinline__ unsigned alignbit2(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 2); }
 
 } // namespace

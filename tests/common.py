@@ -81,6 +81,31 @@ def c2_workload(seed, n_pairs, read_len=150, chunk_len=10000):
     return reads, chunk
 
 
+def c3_reads(seed, n_pairs, ref_len, ref_seed, window=10000, read_len=150):
+    """config C3: windows at uniform offsets of the synthetic reference, one 150 b read sampled inside each window
+    (1 % substitutions, one geometric(0.5)-length indel in ~26 % of the reads).  Vectorised; returns (reads [P, 150], window starts)."""
+    from gonomics_amd import _lib
+    rng = np.random.default_rng(seed)
+    starts = rng.integers(0, ref_len - window, size=n_pairs).astype(np.int64)
+    off = rng.integers(0, window - read_len - 64, size=n_pairs)
+    x = np.arange(read_len)[None, :]
+    has_indel = rng.random(n_pairs) < 0.26
+    pos = rng.integers(10, read_len - 10, size=n_pairs)
+    ln = np.minimum(rng.geometric(0.5, size=n_pairs), 32)
+    is_del = rng.random(n_pairs) < 0.5
+    shift = np.where(has_indel[:, None] & (x >= pos[:, None]), np.where(is_del, ln, -ln)[:, None], 0)
+    src = (starts + off)[:, None] + np.clip(x + shift, 0, None)
+    reads = np.empty((n_pairs, read_len), dtype=np.uint8)
+    for lo in range(0, n_pairs, 65536):
+        hi = min(n_pairs, lo + 65536)
+        reads[lo:hi] = _lib.synthetic_reference_positions(src[lo:hi].reshape(-1), ref_seed).reshape(hi - lo, read_len)
+    ins_mask = has_indel[:, None] & (~is_del)[:, None] & (x >= pos[:, None]) & (x < (pos + ln)[:, None])
+    reads = np.where(ins_mask, rng.integers(0, 4, size=reads.shape), reads)
+    sub = rng.random(reads.shape) < 0.01
+    reads = np.where(sub, rng.integers(0, 4, size=reads.shape), reads).astype(np.uint8)
+    return np.ascontiguousarray(reads), starts
+
+
 def assert_same(res_a, res_b, what=""):
     sa, oa, fa = res_a
     sb, ob, fb = res_b

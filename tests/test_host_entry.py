@@ -122,6 +122,38 @@ def test_synthetic_reference_matches_its_host_statement(gpu_lib):
         assert int(score[k]) == int(sc[w, w].sum()) and int(off[k + 1] - off[k]) == 1 and int(ops[int(off[k])]["run_length"]) == 900
 
 
+def test_contexts_created_after_the_reference(gpu_lib, monkeypatch):
+    """gnx_set_reference, THEN gnx_init_devices -- the new contexts have no copy of the reference; the first call that
+    shards over them brings them up to date from context 0 (it used to hand the workers a null pointer).  Also: a reference that
+    is replaced reaches every context, and GNX_HOST_SUB values that are not multiples of 8 do not break the sub-batch loop."""
+    L = gpu_lib.lib()
+    a, a_start, a_len, chunk, b_start, b_len = _c2_batch(81, 1000, chunk_len=2500)
+    a_off = np.concatenate([a_start, [a_start[-1] + 150]])
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+    exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, a, a_start, a_len, chunk, b_start, b_len, threads=8)
+    chunk2 = chunk[::-1].copy()
+    exp2 = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, a, a_start, a_len, chunk2, b_start, b_len, threads=8)
+    try:
+        gpu_lib.check(L.gnx_shutdown() or 0)
+        gpu_lib.check(L.gnx_init(0, 8 << 30))
+        gpu_lib.set_reference(chunk)                       # one context exists
+        monkeypatch.setenv("GNX_RCCL", "0")
+        monkeypatch.setenv("GNX_HOST_SUB", "12")           # ADVICE r2 (low): sub = 12 used to give K = 84 sub-batches of 16 > n
+        assert gpu_lib.init_devices([0, 0, 0], 4 << 30) == 3  # three contexts, two of them new
+        common.assert_same(gpu_lib.align_batch_by_offset(p, a, a_off, b_start, b_len), exp, "contexts created after the reference")
+        assert gpu_lib.get_timing()["n_contexts"] == 3
+        monkeypatch.setenv("GNX_HOST_SUB", "100")
+        gpu_lib.set_reference(chunk2)                      # replaced: every context must see the new one
+        common.assert_same(gpu_lib.align_batch_by_offset(p, a, a_off, b_start, b_len), exp2, "replaced reference")
+        assert gpu_lib.init_devices([0, 0], 4 << 30) == 2  # fewer contexts: still right
+        common.assert_same(gpu_lib.align_batch_by_offset(p, a, a_off, b_start, b_len), exp2, "fewer contexts")
+    finally:
+        monkeypatch.delenv("GNX_RCCL", raising=False)
+        monkeypatch.delenv("GNX_HOST_SUB", raising=False)
+        L.gnx_shutdown()
+        gpu_lib.check(L.gnx_init(0, 8 << 30))
+
+
 @pytest.mark.parametrize("rccl", ["0", "1"])
 def test_two_contexts_on_one_device(gpu_lib, monkeypatch, rccl):
     """the N > 1 flow of the C ABI on a 1-GPU box: contexts (0, 0) -> two worker threads, blocks of equal DP cells, the shared chunk /
@@ -148,6 +180,7 @@ def test_two_contexts_on_one_device(gpu_lib, monkeypatch, rccl):
         tm2 = gpu_lib.get_timing()
         common.assert_same(two, one, "two contexts, shared chunk")
         assert tm2["cells"] == tm1["cells"]
+        assert tm2["n_contexts"] == 2 and tm2["transport"] == 2 and tm1["transport"] == 0  # peer copies; one context: no exchange
         common.assert_same(gpu_lib.align_batch(pc, alphas, betas), expc, "two contexts, disjoint windows")
         gpu_lib.set_reference(chunk)
         a_off = np.concatenate([a_start, [a_start[-1] + 150]])
@@ -162,35 +195,24 @@ def test_two_contexts_on_one_device(gpu_lib, monkeypatch, rccl):
             assert gpu_lib.init_devices([0], 8 << 30) == 1
             gpu_lib.set_reference(chunk)  # ncclBroadcast on the 1-rank communicator
             common.assert_same(gpu_lib.align_batch_by_offset(p, a, a_off, b_start, b_len), ref_two, "1-rank RCCL")
+            one_r = gpu_lib.align_batch_windows(p, a, a_start, a_len, chunk, b_start, b_len)  # shared chunk: broadcast inside the call
+            assert gpu_lib.get_timing()["transport"] == 1
+            common.assert_same(one_r, one, "1-rank RCCL, shared chunk")
+            # a RCCL call that fails must not fail the alignment: peer copies from then on, and the timing says so
+            monkeypatch.setenv("GNX_RCCL_INJECT_FAIL", "1")
+            again = gpu_lib.align_batch_windows(p, a, a_start, a_len, chunk, b_start, b_len)
+            monkeypatch.delenv("GNX_RCCL_INJECT_FAIL")
+            assert gpu_lib.get_timing()["transport"] == 3
+            common.assert_same(again, one, "after an injected RCCL failure")
+            common.assert_same(gpu_lib.align_batch_windows(p, a, a_start, a_len, chunk, b_start, b_len), one, "RCCL stays off")
+            assert gpu_lib.get_timing()["transport"] == 0  # one context and no usable communicator: nothing is exchanged any more
     finally:
         monkeypatch.delenv("GNX_RCCL", raising=False)
         L.gnx_shutdown()
         gpu_lib.check(L.gnx_init(0, 8 << 30))
 
 
-def c3_reads(seed, n_pairs, ref_len, ref_seed, window=10000, read_len=150):
-    """config C3: windows at uniform offsets of the synthetic reference, one 150 b read sampled inside each window
-    (1 % substitutions, one geometric(0.5)-length indel in ~26 % of the reads).  Vectorised; returns (reads [P, 150], window starts)."""
-    from gonomics_amd import _lib
-    rng = np.random.default_rng(seed)
-    starts = rng.integers(0, ref_len - window, size=n_pairs).astype(np.int64)
-    off = rng.integers(0, window - read_len - 64, size=n_pairs)
-    x = np.arange(read_len)[None, :]
-    has_indel = rng.random(n_pairs) < 0.26
-    pos = rng.integers(10, read_len - 10, size=n_pairs)
-    ln = np.minimum(rng.geometric(0.5, size=n_pairs), 32)
-    is_del = rng.random(n_pairs) < 0.5
-    shift = np.where(has_indel[:, None] & (x >= pos[:, None]), np.where(is_del, ln, -ln)[:, None], 0)
-    src = (starts + off)[:, None] + np.clip(x + shift, 0, None)
-    reads = np.empty((n_pairs, read_len), dtype=np.uint8)
-    for lo in range(0, n_pairs, 65536):
-        hi = min(n_pairs, lo + 65536)
-        reads[lo:hi] = _lib.synthetic_reference_positions(src[lo:hi].reshape(-1), ref_seed).reshape(hi - lo, read_len)
-    ins_mask = has_indel[:, None] & (~is_del)[:, None] & (x >= pos[:, None]) & (x < (pos + ln)[:, None])
-    reads = np.where(ins_mask, rng.integers(0, 4, size=reads.shape), reads)
-    sub = rng.random(reads.shape) < 0.01
-    reads = np.where(sub, rng.integers(0, 4, size=reads.shape), reads).astype(np.uint8)
-    return np.ascontiguousarray(reads), starts
+c3_reads = common.c3_reads
 
 
 def rescore_affine_batch(reads, starts, ref_seed, window, score, ops, off, scores, go, ge):
