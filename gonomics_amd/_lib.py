@@ -106,8 +106,9 @@ def lib():
         L.gnx_seed_find_batch.restype = ctypes.c_int
         L.gnx_get_timing.argtypes = [ctypes.POINTER(GnxTiming)]
         L.gnx_get_timing.restype = ctypes.c_int
-        L.gnx_debug_occupy.argtypes = [ctypes.c_int, ctypes.c_int]
-        L.gnx_debug_occupy.restype = ctypes.c_int
+        if hasattr(L, "gnx_debug_occupy"):  # (absent from older builds loaded through GNX_LIB_PATH for A/B runs)
+            L.gnx_debug_occupy.argtypes = [ctypes.c_int, ctypes.c_int]
+            L.gnx_debug_occupy.restype = ctypes.c_int
         _lib = L
     return _lib
 

@@ -40,8 +40,11 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
     const bool piped = strip_map != nullptr;
-    const int bid = piped ? block_ticket(strip_prog + gridDim.x) : (int)blockIdx.x; // piped: the work item is the ticket, not the block index
-    const int pbase = (piped ? strip_map[bid].x : bid) * 4;
+    // piped: this workgroup runs strip strip_map[blockIdx].y of its group -- and first every strip above it that nobody has claimed yet
+    // (claim_items: forward progress without any assumption about dispatch order); none in the normal case
+    int n_stolen = 0;
+    if (piped) { n_stolen = claim_items(strip_prog + gridDim.x, 1, strip_map[blockIdx.x].y); if (n_stolen < 0) return; }
+    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -58,9 +61,11 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
     asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
     int bad = 0;
 
-    const int s_lo = piped ? strip_map[bid].y : 0, s_hi = piped ? s_lo + 1 : S_max;
+    const int s_own = piped ? strip_map[blockIdx.x].y : 0;
+    const int s_lo = piped ? s_own - n_stolen : 0, s_hi = piped ? s_own + 1 : S_max;
     const int64_t rb_pitch = (int64_t)pl.m + 1;
     for (int s = s_lo; s < s_hi; s++) {
+        const int bid = (int)blockIdx.x - s_own + s; // piped: block index of strip s of this group = its slot in strip_prog
         const bool gact = valid && s < pl.strips;
         const int m_eff = gact ? pl.m : 0;
         int m_min = 0x7fffffff;
@@ -104,10 +109,9 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
                 const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
                 odn = v.x; oh = v.y;
             } else { odn = 0; oh = 0; }
-            int b = 0;
-            if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
-            ob = b * (BST * 4);
+            ob = (c >= 1 && c <= m_eff) ? (int)bp[c - 1] : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
         };
+        auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
         int rb_seen = 0;
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
@@ -121,22 +125,33 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
         if (!piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qdn, qh, qb);
+        qb = base_off(qb);
 
-        auto step = [&](const int t, auto chk) {
+        // profile entries one step ahead (software pipeline over the LDS round trip, see cl_sweep_kernel)
+        int wq[LW], pb_cur;
+        auto fetch = [&](int pbv, int *w) {
+            const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+#pragma unroll
+            for (int k = 0; k < LW; k++) w[k] = pw[k];
+        };
+        pb_cur = dpp_shr1(qb, b_out);
+        qb = dpp_shl1(qb, qb);
+        fetch(pb_cur, wq);
+        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
             constexpr bool CHECK = decltype(chk)::value;
             const int up_dn = dpp_shr1(qdn, dn_out);
             const int up_h = dpp_shr1(qh, h_out);
-            const int pb = dpp_shr1(qb, b_out);
             qdn = dpp_shl1(qdn, qdn);
             qh = dpp_shl1(qh, qh);
+            if (take) qb = nqv; // (last step of a block: the base queue of the next one takes over)
+            const int pb_next = dpp_shr1(qb, pb_cur);
             qb = dpp_shl1(qb, qb);
+            int wn[LW];
+            fetch(pb_next, wn);
+            asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic
             const int j = t - l;
-            b_out = pb;
+            const int *w = wq;
             if (!CHECK || (j >= 1 && j <= m_eff)) {
-                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
-                int w[LW];
-#pragma unroll
-                for (int k = 0; k < LW; k++) w[k] = pw[k];
                 int hd = diag0, dnu = up_dn;
 #pragma unroll
                 for (int r = 0; r < R - 1; r++) {
@@ -169,6 +184,9 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
             }
             sq_dn = dpp_shl1(dn_out, sq_dn);
             sq_h = dpp_shl1(h_out, sq_h);
+#pragma unroll
+            for (int k = 0; k < LW; k++) wq[k] = wn[k];
+            pb_cur = pb_next;
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
@@ -185,12 +203,15 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
             boundary(t0 + 16 + l + 1, ndn, nh, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
-            qdn = ndn; qh = nh; qb = nb;
+            // consume the loads issued at the top of this block BEFORE the stores below are issued (exact wait, nothing newer in flight;
+            // left to their first real use -- the DPP moves of the next block -- the wait becomes a vmcnt(0) behind those stores)
+            asm volatile("" :: "v"(ndn), "v"(nh));
+            qdn = ndn; qh = nh;
             if (store_row) {
                 const int c = t0 + l - 14;
                 if (c >= 1 && c <= m_eff) rb_store(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_dn, sq_h, piped);
@@ -327,26 +348,36 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
                 const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
                 odn = v.x; oh = v.y;
             } else { odn = 0; oh = 0; }
-            int b = 0;
-            if (cc >= 1 && cc <= m_eff) { b = bp[cc - 1]; if (b >= 5) { bad = 1; b = 4; } }
-            ob = b * (BST * 4);
+            ob = (cc >= 1 && cc <= m_eff) ? (int)bp[cc - 1] : 0; // RAW base, see al_sweep_kernel
         };
+        auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
         boundary(tbeg + l + 1, qdn, qh, qb);
-        auto step = [&](const int t, auto chk) {
+        qb = base_off(qb);
+        // profile entries one step ahead (software pipeline over the LDS round trip, see cl_sweep_kernel)
+        int wq[LW], pb_cur;
+        auto fetch = [&](int pbv, int *w) {
+            const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+#pragma unroll
+            for (int k = 0; k < LW; k++) w[k] = pw[k];
+        };
+        pb_cur = dpp_shr1(qb, b_out);
+        qb = dpp_shl1(qb, qb);
+        fetch(pb_cur, wq);
+        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
             constexpr bool CHECK = decltype(chk)::value;
             const int up_dn = dpp_shr1(qdn, dn_out);
             const int up_h = dpp_shr1(qh, h_out);
-            const int pb = dpp_shr1(qb, b_out);
             qdn = dpp_shl1(qdn, qdn);
             qh = dpp_shl1(qh, qh);
+            if (take) qb = nqv; // (last step of a block: the base queue of the next one takes over)
+            const int pb_next = dpp_shr1(qb, pb_cur);
             qb = dpp_shl1(qb, qb);
+            int wn[LW];
+            fetch(pb_next, wn);
+            asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic
             const int j = t - l;
-            b_out = pb;
+            const int *w = wq;
             if (!CHECK || (j >= 1 && j <= m_eff)) {
-                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
-                int w[LW];
-#pragma unroll
-                for (int k = 0; k < LW; k++) w[k] = pw[k];
                 int hd = diag0, dnu = up_dn;
 #pragma unroll
                 for (int r = 0; r < R; r++) { // the recording h-form of fill_affine_kernel (rebased keys)
@@ -369,18 +400,21 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
                 dn_out = dnu;
                 h_out = hold[R - 1];
             }
+#pragma unroll
+            for (int k = 0; k < LW; k++) wq[k] = wn[k];
+            pb_cur = pb_next;
         };
         for (int b = 0; b < nblk_max; b++) {
             const int t0 = tbeg + 16 * b; // per pair
             boundary(t0 + 16 + l + 1, ndn, nh, nb);
             if (__all(!gact || b >= nblk || (t0 >= 16 && t0 + 16 <= m_eff))) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
-            qdn = ndn; qh = nh; qb = nb;
+            qdn = ndn; qh = nh;
             if (gact && b < nblk) {
                 const int miss = (t0 + 16 - l) - m_eff;
                 const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;

@@ -43,23 +43,39 @@ __device__ __forceinline__ int rb_load32(const int *p, bool piped) {
 
 // PairPlan fields used here: n, m, strips, rowbuf_off (ints), ckpt_off (ints: snapshots [c-1][strip][lane][SNAPW]), hcol_off (slot of
 // the final value), src (output slot).
-template <bool P16>
-__global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
-                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
-                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                                      KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
-                                                      int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
+// PIPED = the strips of a pair run as separate, pipelined workgroups (strip_map); else one wave walks the strips of its 4 pairs in turn.
+// The two forms differ in what bounds them.  Un-piped (big batches), the wave is alone with its arithmetic: the profile entries of a
+// step are read from LDS ONE STEP AHEAD (the base a lane needs at step t + 1 is the one its left neighbour has at step t, so the DPP
+// move and the reads for t + 1 go out before the arithmetic of step t), and a base loaded for the next block is turned into its LDS
+// offset only where the queue is needed -- checked on the spot it costs a full memory round trip per block (the compiler's
+// s_waitcnt vmcnt(0) sits right behind the global_load_ubyte): 320 x 10 000 x 32 768 pairs 10.2 -> 9.0 ms, 1.16e13 cells/s.
+// Piped, a wave spends two thirds of its time parked behind the hand-over of the strip above it (uncached loads, spin waits) and
+// what counts is how many waves a SIMD holds: the ten registers of the look-ahead cost the fifth wave, and every variant that made
+// the single wave stall less (look-ahead, deferred conversion, lagged publishes, loads two blocks ahead with hand-kept counts) made the
+// launch SLOWER -- 451 -> 492 -> 522 ms for 2048 pairs of config C5 (profiles/r3_experiments.md).  So the piped form keeps the
+// plain step.
+template <bool P16, bool PIPED>
+__device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairPlan *__restrict__ plans, int n_pairs,
+                                              const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                              const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                              const KParams &kp, int *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
+                                              int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
     using PC = ProfCfg<P16>;
     constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
-    __shared__ int lds[32 + 4 * PST];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.g4; // rebased diagonal move: 4*(s - 2g); every value carries tag 2
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
-    const bool piped = strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
-    const int bid = piped ? block_ticket(strip_prog + gridDim.x) : (int)blockIdx.x; // piped: the work item is the ticket, not the block index
-    const int pbase = (piped ? strip_map[bid].x : bid) * 4;
+    // (PIPED instantiation: `piped` stays a run-time value on purpose -- with the un-piped branches folded away the compiler allocates 77
+    // registers instead of 92 and schedules the block loop so that the launch takes 3.5 % longer: 242 against 234 ms, 1024 pairs of C5)
+    const bool piped = PIPED && strip_map != nullptr;
+    constexpr bool PF = !PIPED; // look-ahead form, see above
+    // piped: this workgroup runs strip strip_map[blockIdx].y of its group -- and first every strip above it that nobody has claimed yet
+    // (claim_items: forward progress without any assumption about dispatch order); none in the normal case
+    int n_stolen = 0;
+    if (piped) { n_stolen = claim_items(strip_prog + gridDim.x, 1, strip_map[blockIdx.x].y); if (n_stolen < 0) return; }
+    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -73,9 +89,11 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
     const int Tend = (m_max + 15 + 15) & ~15;
     int bad = 0;
 
-    const int s_lo = piped ? strip_map[bid].y : 0, s_hi = piped ? s_lo + 1 : S_max;
+    const int s_own = piped ? strip_map[blockIdx.x].y : 0;
+    const int s_lo = piped ? s_own - n_stolen : 0, s_hi = piped ? s_own + 1 : S_max;
     const int64_t rb_pitch = (int64_t)pl.m + 1;
     for (int s = s_lo; s < s_hi; s++) {
+        const int bid = (int)blockIdx.x - s_own + s; // piped: block index of strip s of this group = its slot in strip_prog
         const bool gact = valid && s < pl.strips;
         const int m_eff = gact ? pl.m : 0;
         int m_min = 0x7fffffff;
@@ -110,9 +128,12 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
             else if (c >= 1 && c <= m_eff) ov = rb_load32(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
             else ov = 0;
             int b = 0;
-            if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            if (c >= 1 && c <= m_eff) b = bp[c - 1];
+            if (PF) { ob = b; return; } // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
+            if (b >= 5) { bad = 1; b = 4; }
             ob = b * (BST * 4);
         };
+        auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
         int rb_seen = 0, pf_seen = 0;
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
@@ -126,20 +147,41 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
         if (!piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qv, qb);
+        if (PF) qb = base_off(qb);
 
-        auto step = [&](const int t, auto chk) {
+        int wq[LW], pb_cur = 0; // PF: the profile entries and the base of the CURRENT step (fetched during the step before)
+        auto fetch = [&](int pbv, int *w) {
+            const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+#pragma unroll
+            for (int k = 0; k < LW; k++) w[k] = pw[k];
+        };
+        if (PF) {
+            pb_cur = dpp_shr1(qb, b_out);
+            qb = dpp_shl1(qb, qb);
+            fetch(pb_cur, wq);
+        }
+        // take / nqv (PF): at the last step of a block the base queue of the next one takes over
+        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
             constexpr bool CHECK = decltype(chk)::value;
             const int up_v = dpp_shr1(qv, v_out);
-            const int pb = dpp_shr1(qb, b_out);
             qv = dpp_shl1(qv, qv);
-            qb = dpp_shl1(qb, qb);
-            const int j = t - l;
-            b_out = pb;
-            if (!CHECK || (j >= 1 && j <= m_eff)) {
-                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
-                int w[LW];
+            int w[LW], wn[LW], pb_next = 0;
+            if (PF) {
+                if (take) qb = nqv;
+                pb_next = dpp_shr1(qb, pb_cur);
+                qb = dpp_shl1(qb, qb);
+                fetch(pb_next, wn);
+                asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic (the scheduler would sink them next to their first use)
 #pragma unroll
-                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                for (int k = 0; k < LW; k++) w[k] = wq[k];
+            } else {
+                const int pb = dpp_shr1(qb, b_out);
+                qb = dpp_shl1(qb, qb);
+                b_out = pb;
+                fetch(pb, w);
+            }
+            const int j = t - l;
+            if (!CHECK || (j >= 1 && j <= m_eff)) {
                 int vd = diag0, vu = up_v;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
@@ -153,6 +195,11 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
                 v_out = vu;
             }
             sq_v = dpp_shl1(v_out, sq_v);
+            if (PF) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) wq[k] = wn[k];
+                pb_cur = pb_next;
+            }
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
@@ -169,12 +216,14 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+                for (int u = 0; u < 16; u++) { if (PF && u == 15) nb = base_off(nb); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+                for (int u = 0; u < 16; u++) { if (PF && u == 15) nb = base_off(nb); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
-            qv = nv; qb = nb;
+            if (PF) asm volatile("" :: "v"(nv)); // the row values loaded at the top of this block are consumed before the store below goes out (else: a vmcnt(0) behind it)
+            qv = nv;
+            if (!PF) qb = nb;
             if (store_row) {
                 const int c = t0 + l - 14;
                 if (c >= 1 && c <= m_eff) rb_store32(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_v, piped);
@@ -189,6 +238,25 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     if (bad) atomicOr(err, 1);
+}
+// the piped form wants as many waves per SIMD as fit (it waits); the un-piped form, compute-bound, runs best with the registers of four
+// waves per SIMD for its look-ahead (103 registers: 9.0 ms for 320 x 10 000 x 32 768; squeezed into the 96 of five waves: 9.8 ms)
+template <bool P16>
+__global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                      KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
+                                                      int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
+    __shared__ int lds[32 + 4 * ProfCfg<P16>::PST];
+    cl_sweep_body<P16, true>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, strip_map, strip_prog);
+}
+template <bool P16>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void cl_sweep_flat_kernel(
+    const PairPlan *__restrict__ plans, int n_pairs, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+    const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap,
+    int *__restrict__ hfin, int *__restrict__ err) {
+    __shared__ int lds[32 + 4 * ProfCfg<P16>::PST];
+    cl_sweep_body<P16, false>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, nullptr, nullptr);
 }
 
 // One wave per 4 pairs.  Per round every pair (16 lanes) re-fills the tile its walk is in -- strip s = (i-1)/160, steps

@@ -11,10 +11,10 @@ namespace {
 //           one wave per 4 pairs (host decision: strip_map != nullptr), the strips of a pair run as separate workgroups,
 //           pipelined: block (group of 4 pairs, strip s) reads the bottom row of strip s-1 from the row buffer once the block
 //           before it has published it (strip_prog, every RB_PUB steps; rows and progress word are agent-scope atomics, see rb_store).  A 20 kb x 100 kb
-//           pair is up to 125 concurrent waves instead of one.  Work items are ordered (group, strip) and a workgroup takes
-//           the item of the TICKET it draws at its start (block_ticket), not of its block index: the item it waits for has a
-//           smaller number, so its workgroup is already running -- no deadlock whatever the dispatch order; the 5 s timeout on
-//           the spin is a bug trap (error flag instead of a hang), not part of the protocol.  Such launches store their direction
+//           pair is up to 125 concurrent waves instead of one.  A workgroup runs the strip of its block index -- and, before
+//           it, every strip above it that nobody has claimed yet (claim_items, gnx_common.hip.h): nobody waits for work that has
+//           not been taken, whatever the dispatch order; the 5 s timeout on the spin is a bug trap (error flag instead of a
+//           hang), not part of the protocol.  Such launches store their direction
 //           words non-temporally (full lines that the fill never reads back).
 //   P16   = 4*score fits int16: the per-row score profile is stored as packed int16 pairs in LDS
 //   HFORM = gapOpen <= 0 (every caller): with h = max3(M,I,D) the recurrences collapse to
@@ -68,8 +68,11 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
 
     const bool piped = MULTI && strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
-    const int bid = piped ? block_ticket(strip_prog + gridDim.x) : (int)blockIdx.x; // piped: the work item is the ticket, not the block index
-    const int pbase = (piped ? strip_map[bid].x : bid) * 4;
+    // piped: this workgroup runs strip strip_map[blockIdx].y of its group -- and first every strip above it that nobody has claimed yet
+    // (claim_items: forward progress without any assumption about dispatch order); none in the normal case
+    int n_stolen = 0;
+    if (piped) { n_stolen = claim_items(strip_prog + gridDim.x, 1, strip_map[blockIdx.x].y); if (n_stolen < 0) return; }
+    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -90,9 +93,11 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vOE4), "=v"(vE4), "=v"(vO4) : "s"(kp.oe4), "s"(kp.e4), "s"(kp.o4));
     int bad = 0;
 
-    const int s_lo = piped ? strip_map[bid].y : 0, s_hi = piped ? s_lo + 1 : S_max;
+    const int s_own = piped ? strip_map[blockIdx.x].y : 0;
+    const int s_lo = piped ? s_own - n_stolen : 0, s_hi = piped ? s_own + 1 : S_max;
     const int64_t rb_pitch = (int64_t)pl.m + 1; // row-buffer entries per strip of this pair
     for (int s = s_lo; s < s_hi; s++) {
+        const int bid = (int)blockIdx.x - s_own + s; // piped: block index of strip s of this group = its slot in strip_prog
         const bool gact = valid && s < pl.strips;
         const int m_eff = gact ? pl.m : 0;
         int m_min = 0x7fffffff; // over the 4 pairs of the wave, this strip (wave-uniform)
@@ -165,10 +170,9 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
                 odn = v.x; oh = v.y; // rebased like everything else
             } else { odn = 0; oh = 0; }
-            int b = 0;
-            if (!SCORED && c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
-            ob = b * (BST * 4); // LDS byte offset of the base's profile plane
+            ob = (!SCORED && c >= 1 && c <= m_eff) ? (int)bp[c - 1] : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
         };
+        auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
         // wait until the block of strip s-1 (the previous block of the grid) has published the row-buffer columns <= cmax;
         // strip_prog holds the number of columns it has published so far (INT_MAX when it is done)
         int rb_seen = 0;
@@ -184,26 +188,51 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         if (MULTI && !piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qdn, qh, qb);
+        qb = base_off(qb);
 
+        // LDS profile (!SCORED): the entries of a step are read ONE STEP AHEAD -- the base a lane needs at step t + 1 is the one its left
+        // neighbour has at step t, so the DPP move and the reads for t + 1 are issued before the arithmetic of step t and land while it
+        // runs (at the top of their own step they cost the wave an LDS round trip per step; see cl_sweep_kernel).
+        int wq[LW], pb_cur = 0;
+        auto fetch = [&](int pbv, int *w) {
+            const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+#pragma unroll
+            for (int k = 0; k < LW; k++) w[k] = pw[k];
+        };
+        if (!SCORED) {
+            pb_cur = dpp_shr1(qb, b_out);
+            qb = dpp_shl1(qb, qb);
+            fetch(pb_cur, wq);
+        }
         // one anti-diagonal step; CHECK=false is the steady state (every lane of the wave has a live column)
-        auto step = [&](const int t, auto chk) {
+        // take / nqv (!SCORED): the base queue of the next 16-step block, taken over at the last step of this one
+        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
             constexpr bool CHECK = decltype(chk)::value;
             const int up_dn = dpp_shr1(qdn, dn_out);
             const int up_h = dpp_shr1(qh, h_out);
-            const int pb = dpp_shr1(qb, b_out);
             qdn = dpp_shl1(qdn, qdn);
             qh = dpp_shl1(qh, qh);
-            qb = dpp_shl1(qb, qb);
+            int wn[LW], pb_next = 0;
+            if (!SCORED) {
+                if (take) qb = nqv;
+                pb_next = dpp_shr1(qb, pb_cur);
+                qb = dpp_shl1(qb, qb);
+                fetch(pb_next, wn);
+                asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic (the scheduler would sink them next to their first use)
+            }
             const int j = t - l;
-            b_out = pb;
             if (!CHECK || (j >= 1 && j <= m_eff)) {
-                // SCORED: the lane's R rows of column j are contiguous in the score matrix (int32 entries, or int16 with P16: s_off, s_pitch and row0 are even)
-                const int *pw = !SCORED ? reinterpret_cast<const int *>(prof_lane + pb)
-                                : P16 ? reinterpret_cast<const int *>(reinterpret_cast<const short *>(smat) + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0)
-                                      : smat + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0;
                 int w[LW];
+                if (SCORED) {
+                    // the lane's R rows of column j are contiguous in the score matrix (int32 entries, or int16 with P16: s_off, s_pitch and row0 are even)
+                    const int *pw = P16 ? reinterpret_cast<const int *>(reinterpret_cast<const short *>(smat) + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0)
+                                        : smat + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0;
 #pragma unroll
-                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                    for (int k = 0; k < LW; k++) w[k] = pw[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < LW; k++) w[k] = wq[k];
+                }
                 int hd = diag0, dnu = up_dn;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
@@ -243,6 +272,11 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 h_out = hold[R - 1];
             }
             if (MULTI) { sq_dn = dpp_shl1(dn_out, sq_dn); sq_h = dpp_shl1(h_out, sq_h); }
+            if (!SCORED) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) wq[k] = wn[k];
+                pb_cur = pb_next;
+            }
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
@@ -251,15 +285,18 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             const bool steady = t0 >= 16 && t0 + 16 <= m_min;
             if (steady && SCORED) { // the per-step HBM loads of the score matrix do better with the shallow unroll (3.2 -> 2.3 ms on tools/bench_n1.py)
 #pragma unroll 2
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{}, false, 0);
             } else if (steady) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
-            qdn = ndn; qh = nh; qb = nb;
+            // consume the loads issued at the top of this block BEFORE the stores below are issued (exact wait, nothing newer in flight;
+            // left to their first real use -- the DPP moves of the next block -- the wait becomes a vmcnt(0) behind those stores)
+            asm volatile("" :: "v"(ndn), "v"(nh));
+            qdn = ndn; qh = nh;
             // flush 16 steps of direction bits: word w of this strip
             const int w = t0 >> 4;
             if (gact && w < pl.words) {

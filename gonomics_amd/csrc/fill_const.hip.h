@@ -39,8 +39,11 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     int *prof = &lds[32 + g * PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
     const bool piped = MULTI && strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
-    const int bid = piped ? block_ticket(strip_prog + gridDim.x) : (int)blockIdx.x; // piped: the work item is the ticket, not the block index
-    const int pbase = (piped ? strip_map[bid].x : bid) * 4;
+    // piped: this workgroup runs strip strip_map[blockIdx].y of its group -- and first every strip above it that nobody has claimed yet
+    // (claim_items: forward progress without any assumption about dispatch order); none in the normal case
+    int n_stolen = 0;
+    if (piped) { n_stolen = claim_items(strip_prog + gridDim.x, 1, strip_map[blockIdx.x].y); if (n_stolen < 0) return; }
+    const int pbase = (piped ? strip_map[blockIdx.x].x : (int)blockIdx.x) * 4;
     int S_max = 0, m_max = 0;
     for (int q = 0; q < 4; q++) {
         if (pbase + q < n_pairs) { S_max = max(S_max, plans[pbase + q].strips); m_max = max(m_max, plans[pbase + q].m); }
@@ -56,9 +59,11 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vGL), "=v"(vGU) : "s"(kp.g4 + 2), "s"(kp.g4 + 1));
     int bad = 0;
 
-    const int s_lo = piped ? strip_map[bid].y : 0, s_hi = piped ? s_lo + 1 : S_max;
+    const int s_own = piped ? strip_map[blockIdx.x].y : 0;
+    const int s_lo = piped ? s_own - n_stolen : 0, s_hi = piped ? s_own + 1 : S_max;
     const int64_t rb_pitch = (int64_t)pl.m + 1;
     for (int s = s_lo; s < s_hi; s++) {
+        const int bid = (int)blockIdx.x - s_own + s; // piped: block index of strip s of this group = its slot in strip_prog
         const bool gact = valid && s < pl.strips;
         const int m_eff = gact ? pl.m : 0;
         int m_min = 0x7fffffff;
@@ -96,10 +101,9 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             if (!MULTI || s == 0) ov = REB ? 2 : (GSW == 1 ? 0 : c * kp.g4); // row 0: j*gapPen (rebased: 0, tag 2)
             else if (c >= 1 && c <= m_eff) ov = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped).x;
             else ov = 0;
-            int b = 0;
-            if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
-            ob = b * (BST * 4);
+            ob = (c >= 1 && c <= m_eff) ? (int)bp[c - 1] : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
         };
+        auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
         int rb_seen = 0;
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
@@ -113,20 +117,31 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         if (MULTI && !piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qv, qb);
+        qb = base_off(qb);
 
-        auto step = [&](const int t, auto chk) {
+        // profile entries one step ahead (software pipeline over the LDS round trip, see cl_sweep_kernel)
+        int wq[LW], pb_cur;
+        auto fetch = [&](int pbv, int *w) {
+            const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+#pragma unroll
+            for (int k = 0; k < LW; k++) w[k] = pw[k];
+        };
+        pb_cur = dpp_shr1(qb, b_out);
+        qb = dpp_shl1(qb, qb);
+        fetch(pb_cur, wq);
+        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
             constexpr bool CHECK = decltype(chk)::value;
             const int up_v = dpp_shr1(qv, v_out);
-            const int pb = dpp_shr1(qb, b_out);
             qv = dpp_shl1(qv, qv);
+            if (take) qb = nqv; // (last step of a block: the base queue of the next one takes over)
+            const int pb_next = dpp_shr1(qb, pb_cur);
             qb = dpp_shl1(qb, qb);
+            int wn[LW];
+            fetch(pb_next, wn);
+            asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic
             const int j = t - l;
-            b_out = pb;
+            const int *w = wq;
             if (!CHECK || (j >= 1 && j <= m_eff)) {
-                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
-                int w[LW];
-#pragma unroll
-                for (int k = 0; k < LW; k++) w[k] = pw[k];
                 int vd = diag0, vu = up_v;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
@@ -143,6 +158,9 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                 v_out = vu;
             }
             if (MULTI) sq_v = dpp_shl1(v_out, sq_v);
+#pragma unroll
+            for (int k = 0; k < LW; k++) wq[k] = wn[k];
+            pb_cur = pb_next;
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
@@ -150,12 +168,15 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
-            qv = nv; qb = nb;
+            // consume the loads issued at the top of this block BEFORE the stores below are issued (exact wait, nothing newer in flight;
+            // left to their first real use -- the DPP moves of the next block -- the wait becomes a vmcnt(0) behind those stores)
+            asm volatile("" :: "v"(nv));
+            qv = nv;
             const int w = t0 >> 4;
             if (gact && w < pl.words) {
                 const int miss = (t0 + 16 - l) - m_eff;

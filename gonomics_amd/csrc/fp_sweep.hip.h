@@ -159,12 +159,12 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     if (TAKES && q0 == 0) diag0 = kp.o4 + TD; // the slot above is a row of the pair, column 0: h' = D' = o
     int dn_out = 0, h_out = 0, b_out = 0;
     int up_dn = cDN, up_h = cH;
-    auto base_of = [&](int c) { // LDS byte offset of the profile plane of beta[c] (column c, 1-based)
-        int b = 0;
-        if (c >= 1 && c <= m_eff) { b = bp[c - 1]; if (b >= 5) { bad = 1; b = 4; } }
-        return b * (FP8_BST * 4);
-    };
-    int qb = base_of(lp), nb = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
+    // beta[c] (column c, 1-based) is LOADED at the top of a half block and turned into the LDS byte offset of its profile plane just
+    // before the half block's last step, where the next queue is needed: a load whose value is checked on the spot makes the wave
+    // wait for the whole memory round trip (the compiler's s_waitcnt vmcnt(0) sat right behind every global_load_ubyte)
+    auto base_raw = [&](int c) { return (c >= 1 && c <= m_eff) ? (int)bp[c - 1] : 0; };
+    auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (FP8_BST * 4); };
+    int qb = base_off(base_raw(lp)), nb = 0, nraw = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
 
     const int level = pl.strips - 1 - below; // 0 = top block
     const int2 *rb_in = (TAKES && valid) ? rowbuf + pl.rowbuf_off + (int64_t)(level - 1) * (pl.m + 1) : nullptr; // [j] = what the block above hands down for column j
@@ -186,7 +186,19 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
             }
         }
     };
-    auto step = [&](const int t, auto chk, const bool ckflag) {
+    // The profile entries of a step are read from LDS ONE STEP AHEAD: the base a lane needs at step t + 1 is the one the previous lane
+    // of its pair has at step t, so the DPP moves and the 5 ds_read_b64 for t + 1 are issued before the 19-row chain of step t and land
+    // while it runs (issued at the top of their own step, every step began with an LDS round trip in s_waitcnt lgkmcnt).
+    int wq[FP8_LW], pb_cur;
+    auto fetch = [&](int pbv, int *w) {
+        const int2 *pw = reinterpret_cast<const int2 *>(prof_lane + pbv);
+#pragma unroll
+        for (int k = 0; k < FP8_LW / 2; k++) { const int2 v = pw[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+    };
+    pb_cur = dpp_prev8(qb, b_out);
+    qb = dpp_next8(qb);
+    fetch(pb_cur, wq);
+    auto step = [&](const int t, auto chk, const bool ckflag, const bool take, const int nqv) {
         constexpr bool CHECK = decltype(chk)::value; // false: every lane of the wave is inside its matrix (steady state)
         // ckflag (wave-uniform): this half block crosses a checkpoint column
         // The first lane of a pair keeps the DPP `old` value = the row-0 boundary constant.  Passing the previous step's result
@@ -196,15 +208,15 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         up_h = dpp_prev8(TAKES ? rq.y : up_h, h_out);
         if (TAKES) { rq.x = dpp_next8(rq.x); rq.y = dpp_next8(rq.y); }
         if (XP && !TAKES) { up_dn += vInc; up_h += vInc; }
-        const int pb = dpp_prev8(qb, b_out);
+        if (take) qb = nqv; // (last step of a half block: the queue of the next one takes over)
+        const int pb_next = dpp_prev8(qb, pb_cur);
         qb = dpp_next8(qb);
+        int wn[FP8_LW];
+        fetch(pb_next, wn);
+        asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic (the scheduler would sink them next to their first use)
         const int j = t - lp;
-        b_out = pb;
+        const int *w = wq;
         if (!CHECK || (j >= 1 && j <= m_eff)) {
-            const int2 *pw = reinterpret_cast<const int2 *>(prof_lane + pb);
-            int w[FP8_LW];
-#pragma unroll
-            for (int k = 0; k < FP8_LW / 2; k++) { const int2 v = pw[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
             int hd = diag0, dnu = up_dn;
 #pragma unroll
             for (int r = 0; r < RR; r++) {
@@ -253,6 +265,9 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
             }
             }
         }
+#pragma unroll
+        for (int k = 0; k < FP8_LW; k++) wq[k] = wn[k];
+        pb_cur = pb_next;
     };
 
     // half blocks of 8 steps t0 .. t0+7 (step t: lane lp is at column t - lp); a plane word is two half blocks
@@ -282,11 +297,13 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         }
     };
     auto edge_half_block = [&](int t0) { // head and tail of the sweep: some lanes are outside their matrix
-        nb = base_of(t0 + 8 + lp); // prefetch the next half block's bases
+        nraw = base_raw(t0 + 8 + lp); // prefetch the next half block's bases
         if (TAKES) { wait_cols(t0 + 15); rqn = rb_at(t0 + 8 + lp); }
 #pragma unroll 1
-        for (int u = 0; u < 8; u++) step(t0 + u, std::true_type{}, true);
-        qb = nb;
+        for (int u = 0; u < 8; u++) {
+            if (u == 7) nb = base_off(nraw);
+            step(t0 + u, std::true_type{}, true, u == 7, nb);
+        }
         if (TAKES) rq = rqn;
         flush(t0);
         hand_down(t0);
@@ -297,12 +314,14 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     if (TAKES) { wait_cols(7); rq = rb_at(lp); }
     for (; t0 < Tend && !(t0 >= 8 && t0 + 7 <= m_min); t0 += 8) edge_half_block(t0);
     for (; t0 + 7 <= m_min; t0 += 8) { // steady state: every lane of the wave is inside its matrix
-        nb = base_of(t0 + 8 + lp);
+        nraw = base_raw(t0 + 8 + lp);
         if (TAKES) { wait_cols(t0 + 15); rqn = rb_at(t0 + 8 + lp); }
         const bool ckflag = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
 #pragma unroll
-        for (int u = 0; u < 8; u++) step(t0 + u, std::false_type{}, ckflag);
-        qb = nb;
+        for (int u = 0; u < 8; u++) {
+            if (u == 7) nb = base_off(nraw);
+            step(t0 + u, std::false_type{}, ckflag, u == 7, nb);
+        }
         if (TAKES) rq = rqn;
         flush(t0);
         hand_down(t0);
@@ -326,7 +345,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
 
 // reads of S >= 2 row blocks: the grid holds n_levels levels of W waves, block index = level-major, level level0 + blockIdx.x / W (0 = top).
 //   piped = 1: ONE launch for all levels (level0 = 0, n_levels = S); wave w of a level follows wave w of the level above through
-//              prog[level * W + w].  Work items are handed out by ticket (block_ticket), so an item's producer has always started before it.
+//              prog[level * W + w].  Nobody waits for a level that has not been taken: claim_items (gnx_common.hip.h).
 //              (800 x 10 000, 12 000 pairs: 21.2 ms against 27.8 ms for five launches of 1 500 waves; 32 768 pairs: 51.4 / 52.6 ms.
 //              Level-major order beats wave-major -- the levels of a wave group as grid neighbours, in lockstep -- 51.4 / 54.1 ms.)
 //   piped = 0: one launch per level in turn (n_levels = 1): nothing to wait for (GNX_NO_PIPE, and the fallback after a timeout).
@@ -339,15 +358,21 @@ __global__ __launch_bounds__(64) void fp_sweep_levels_kernel(const PairPlan *__r
                                                              unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err,
                                                              int2 *__restrict__ rowbuf, int S, int W, int level0, int piped, int *__restrict__ prog) {
     __shared__ int lds[32 + 8 * FP8_PST + 8 * 8 * 2]; // + the staging area of the hand-over (8 pairs x 8 columns x int2)
-    // piped: the (level, wave) a workgroup sweeps is its TICKET, not its block index (block_ticket): the wave it follows, ticket - W, is
-    // then running or done whatever order workgroups start in; the counter sits behind the S * W progress words
-    const int bid = piped ? block_ticket(prog + (int64_t)S * W) : (int)blockIdx.x;
-    const int lv = bid / W, w = bid - lv * W, level = level0 + lv, below = S - 1 - level;
-    int *po = prog + (int64_t)level * W + w;
-    const int *pi = po - W;
-    if (level == 0) fp_sweep_body<RRTOP, XP, 1>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, nullptr, po);
-    else if (below == 0) fp_sweep_body<2 * FP8_LW, XP, 2>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, 0, piped != 0, pi, nullptr);
-    else fp_sweep_body<2 * FP8_LW, XP, 3>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, pi, po);
+    // piped: this workgroup sweeps level blockIdx / W of wave column blockIdx % W -- and first every level above it that nobody has
+    // claimed yet (claim_items: forward progress without any assumption about dispatch order); none in the normal case.  The claim
+    // words sit behind the S * W progress words.
+    const int lv_own = (int)blockIdx.x / W, w = (int)blockIdx.x - lv_own * W;
+    int n_stolen = 0;
+    if (piped) { n_stolen = claim_items(prog + (int64_t)S * W, W, lv_own); if (n_stolen < 0) return; }
+    for (int lv = lv_own - n_stolen; lv <= lv_own; lv++) {
+        const int level = level0 + lv, below = S - 1 - level;
+        int *po = prog + (int64_t)level * W + w;
+        const int *pi = po - W;
+        if (lv != lv_own - n_stolen) __syncthreads(); // the LDS profile of the level before is no longer read
+        if (level == 0) fp_sweep_body<RRTOP, XP, 1>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, nullptr, po);
+        else if (below == 0) fp_sweep_body<2 * FP8_LW, XP, 2>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, 0, piped != 0, pi, nullptr);
+        else fp_sweep_body<2 * FP8_LW, XP, 3>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, pi, po);
+    }
 }
 
 } // namespace

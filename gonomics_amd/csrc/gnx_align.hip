@@ -129,9 +129,8 @@ struct Ctx {
 std::mutex g_ctxs_mu;          // guards the list itself
 std::vector<Ctx *> g_ctxs;     // [0] = the default context; never shrinks while the library is loaded
 thread_local Ctx *t_ctx = nullptr;
-// set while a call is re-run with sequential strips after a pipelined launch timed out waiting for a row buffer (a bug trap: work
-// items are handed out by ticket, block_ticket, so a producer has always started before its consumer; should the trap ever fire,
-// the call still returns right results)
+// set while a call is re-run with sequential strips after a pipelined launch timed out waiting for a row buffer (a bug trap: nobody
+// waits for an item that has not been claimed, claim_items; should the trap ever fire, the call still returns right results)
 thread_local bool t_no_pipe = false;
 bool no_pipe() { return t_no_pipe || getenv("GNX_NO_PIPE") != nullptr; }
 Ctx &ctx_at(int k) {
@@ -231,13 +230,13 @@ __global__ __launch_bounds__(64) void occupy_kernel(long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
-// GNX_TICKET_DELAY=k (tests): the lower half of a piped grid sleeps k x 127 x 64 cycles before it draws its tickets (block_ticket), so
-// the work items are taken out of block-index order.  tk[0] = the counter (already zeroed), tk[1] = the switch.
-int ticket_test_switch(int *tk, hipStream_t st) {
+// GNX_TICKET_DELAY=k (tests): the lower half of a piped grid sleeps k x 127 x 64 cycles before it claims its items (claim_items), so the
+// upper half finds its predecessors unclaimed and runs them itself.  sw = the switch word behind the claim words (already zeroed).
+int claim_test_switch(int *sw, hipStream_t st) {
     const char *e = getenv("GNX_TICKET_DELAY");
     if (!e || !*e) return GNX_OK;
     const int v = atoi(e);
-    HIPCHK(hipMemcpyAsync(tk + 1, &v, 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sw, &v, 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     return GNX_OK;
 }
@@ -304,7 +303,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     if ((rc = c.dcol.ensure((size_t)np * K * G * 4))) return rc;
     if ((rc = c.fp_strag.ensure((size_t)np * 2 * 4 + 64))) return rc;   // stragglers of this round / of the next one
     if ((rc = c.rowbuf.ensure((size_t)std::max<int64_t>(rboff, 1) * 8))) return rc;   // what each row block hands to the one below it
-    if (two && (rc = c.fp_prog.ensure((size_t)S * ((np + G8 - 1) / G8) * 4 + 64))) return rc; // progress words of the levels' waves + the ticket counter
+    if (two && (rc = c.fp_prog.ensure((size_t)S * ((np + G8 - 1) / G8) * 8 + 64))) return rc; // progress words and claim words of the levels' waves, test switch
     if ((rc = c.plans.ensure((size_t)np * sizeof(PairPlan)))) return rc;
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
     if ((rc = c.misc.ensure(64))) return rc;
@@ -357,11 +356,11 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
             const int W = (int)grid8.x;
             int *prog = reinterpret_cast<int *>(c.fp_prog.p);
             if (!no_pipe()) {
-                HIPCHK(hipMemsetAsync(prog, 0, ((size_t)S * W + 2) * 4, st)); // progress words, ticket counter, test switch
-                if ((rc = ticket_test_switch(prog + (size_t)S * W, st))) return rc;
+                HIPCHK(hipMemsetAsync(prog, 0, ((size_t)S * W * 2 + 1) * 4, st)); // progress words, claim words, test switch
+                if ((rc = claim_test_switch(prog + (size_t)S * W * 2, st))) return rc;
                 hipLaunchKernelGGL(klev, dim3((unsigned)(S * W)), blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, rb, S, W, 0, 1, prog);
                 HIPCHK(hipGetLastError());
-                int e = 0; // a level that waited 5 s for the one above it (a bug trap: with tickets the level above has always started): sweep again, level by level
+                int e = 0; // a level that waited 5 s for the one above it (a bug trap: the level above is always claimed by a running workgroup): sweep again, level by level
                 HIPCHK(hipMemcpyAsync(&e, d_err, 4, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 if (!(e & 16)) return GNX_OK;
@@ -645,20 +644,22 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             }
             n_blocks = (int64_t)smap.size();
             if (n_blocks > 0x7fffffff) { set_err("too many strips in one chunk%s", ""); return GNX_ENOMEM; }
-            if ((rc = c.strip_map.ensure((size_t)std::max<int64_t>(n_blocks, 1) * 12 + 8))) return rc; // map, progress words, ticket counter + test switch
+            if ((rc = c.strip_map.ensure((size_t)std::max<int64_t>(n_blocks, 1) * 16 + 8))) return rc; // map, progress words, claim words, test switch
             d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
             d_sprog = reinterpret_cast<int *>(reinterpret_cast<char *>(c.strip_map.p) + (size_t)std::max<int64_t>(n_blocks, 1) * 8);
             HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)n_blocks * 8, hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)std::max<int64_t>(n_blocks, 1) * 4 + 8, stream));
-            if ((rc = ticket_test_switch(d_sprog + n_blocks, stream))) return rc;
+            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)std::max<int64_t>(n_blocks, 1) * 8 + 8, stream));
+            if ((rc = claim_test_switch(d_sprog + 2 * n_blocks, stream))) return rc;
             HIPCHK(hipStreamSynchronize(stream)); // smap is a local
         }
         HIPCHK(hipEventRecord(c.ev[1], stream));
         int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
         if (affine && p16) hipLaunchKernelGGL(al_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
         else if (affine) hipLaunchKernelGGL(al_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
-        else if (p16) hipLaunchKernelGGL(cl_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
-        else hipLaunchKernelGGL(cl_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        else if (p16 && piped) hipLaunchKernelGGL(cl_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        else if (p16) hipLaunchKernelGGL(cl_sweep_flat_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err);
+        else if (piped) hipLaunchKernelGGL(cl_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        else hipLaunchKernelGGL(cl_sweep_flat_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
         const dim3 gridW((unsigned)((np + 3) / 4));
@@ -1019,12 +1020,12 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             }
             n_blocks = (int64_t)smap.size();
             if (n_blocks > 0x7fffffff) { set_err("too many strips in one chunk%s", ""); return GNX_ENOMEM; }
-            if ((rc = c.strip_map.ensure((size_t)std::max<int64_t>(n_blocks, 1) * 12 + 8))) return rc; // map, progress words, ticket counter + test switch
+            if ((rc = c.strip_map.ensure((size_t)std::max<int64_t>(n_blocks, 1) * 16 + 8))) return rc; // map, progress words, claim words, test switch
             d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
             d_sprog = reinterpret_cast<int *>(reinterpret_cast<char *>(c.strip_map.p) + (size_t)std::max<int64_t>(n_blocks, 1) * 8);
             HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)n_blocks * 8, hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)std::max<int64_t>(n_blocks, 1) * 4 + 8, stream));
-            if ((rc = ticket_test_switch(d_sprog + n_blocks, stream))) return rc;
+            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)std::max<int64_t>(n_blocks, 1) * 8 + 8, stream));
+            if ((rc = claim_test_switch(d_sprog + 2 * n_blocks, stream))) return rc;
             HIPCHK(hipStreamSynchronize(stream)); // smap is a local
         }
         const dim3 gridF((unsigned)n_blocks), blockF(64);
@@ -1776,7 +1777,7 @@ int gnx_seed_find_batch(const uint8_t *read_cat, const int64_t *read_off, int64_
 }
 
 /* diagnostics: n_workgroups workgroups that each hold a whole CU's LDS and spin for `milliseconds`, on a stream of their own; returns
- * at once.  The stress leg of the ticket protocol (tests/test_ticket.py): piped launches must finish with half the CUs taken away. */
+ * at once.  The stress leg of the claim protocol (tests/test_ticket.py): piped launches must finish with half the CUs taken away. */
 int gnx_debug_occupy(int n_workgroups, int milliseconds) {
     std::lock_guard<std::mutex> api(g_api_mu);
     CtxScope sc(ctx_at(0));

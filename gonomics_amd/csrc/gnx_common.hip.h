@@ -112,23 +112,59 @@ __device__ __forceinline__ int rb_progress(const int *prog) {
     asm volatile("" ::: "memory"); // row loads stay behind the progress load
     return v;
 }
-// ---- logical index of a workgroup in a piped launch: a TICKET drawn when the workgroup starts -----------------------------------
-// HIP promises nothing about the order in which workgroups are dispatched (MI355X_MICROARCH "Workgroup dispatch": placement-
-// independent protocols only), and a workgroup of a piped launch spins on the progress of another one.  So a workgroup does not derive
-// what it works on from blockIdx: it draws the next ticket of the launch and takes the work item of that number.  Every item a
-// workgroup waits for has a smaller number, i.e. its ticket was drawn earlier, i.e. the workgroup that holds it is already running
-// (or done): by induction the unfinished item with the smallest number never waits for something that has not started, whatever the
-// dispatch order, the partition mode or other kernels on the device do.  tk[0] = the counter (zeroed by the host before the
-// launch); tk[1] = test switch GNX_TICKET_DELAY: the workgroups of the lower half of the grid sleep before drawing, so tickets come
-// out of index order and the suite proves that nothing depends on it.  One wave per workgroup (all piped kernels).
-__device__ __forceinline__ int block_ticket(int *tk) {
-    int t = 0;
+// ---- forward progress of piped launches without any assumption about dispatch order: CLAIMS ----------------------------------------
+// A workgroup of a piped launch spins on the progress of the workgroup that runs the item before its own (the strip above, the
+// level above), and HIP promises nothing about the order in which workgroups are dispatched (MI355X_MICROARCH "Workgroup dispatch":
+// placement-independent protocols only).  So nobody waits for work that has not been taken: every item has a claim word (zeroed by
+// the host).  A workgroup claims its own item -- the one of its block index, so the placement of the normal case is exactly that of
+// a launch that trusted the dispatch order -- and then, going up its chain, every predecessor item that is still unclaimed: those it
+// runs itself, first, one after the other (the kernels loop over strips / levels anyway) -- after a short grace period, see below.  A workgroup whose own item was taken by
+// a successor exits.  The predecessor of the first item a workgroup runs is therefore always claimed by a workgroup that is running
+// -- one that runs its items in chain order and, by induction, never waits for unclaimed work: the lowest unfinished item of a chain
+// is always being executed.  In the normal case (dispatch in index order) every claim of a predecessor fails and nothing changes.
+// (A first version handed out TICKETS, atomicAdd on a launch counter: as safe, but the item a workgroup got then depended on
+// the race to the counter, and the pipelined constant-gap sweep of config C5 lost 5 % -- 234 -> 247 ms for 1024 pairs, same box,
+// profiles/r3_experiments.md.)
+// cw[0 .. n_items) claim words, cw[n_items] = test switch GNX_TICKET_DELAY: the workgroups of the lower half of the grid sleep before
+// they claim, so the upper half finds its predecessors unclaimed and runs them (the suite proves results do not depend on who runs what).
+// `stride` = distance of an item from its predecessor in block indices (1: strips of a group; W: levels of a wave column), `depth` =
+// number of predecessors of this workgroup's own item.  Returns how many of them it has to run itself (0 in the normal case), -1 if
+// its own item is already taken.  One wave per workgroup (all piped kernels).
+#ifndef GNX_CLAIM_MODE
+#define GNX_CLAIM_MODE 2
+#endif
+#ifndef GNX_CLAIM_GRACE_US
+#define GNX_CLAIM_GRACE_US 20000
+#endif
+constexpr long long CLAIM_GRACE_TICKS = 100LL * GNX_CLAIM_GRACE_US; // ticks of the 100 MHz wall clock
+__device__ __forceinline__ int claim_items(int *cw, int stride, int depth) {
+    int n = 0;
+#if GNX_CLAIM_MODE == 0
+    (void)cw; (void)stride; (void)depth; return 0; // experiment: no claims (the round-2 protocol: trust the dispatch order)
+#endif
     if (threadIdx.x == 0) {
-        const int delay = tk[1];
-        if (delay && blockIdx.x * 2 < gridDim.x) for (int i = 0; i < delay; i++) __builtin_amdgcn_s_sleep(127);
-        t = atomicAdd(tk, 1);
+        const int b = (int)blockIdx.x;
+#if GNX_CLAIM_MODE == 1
+        (void)stride; (void)depth; if (atomicCAS(&cw[b], 0, 1) != 0) n = -1; // experiment: own item only
+        return __builtin_amdgcn_readfirstlane(n);
+#endif
+        const int delay = cw[gridDim.x];
+        if (delay && b * 2 < (int)gridDim.x) for (int i = 0; i < delay; i++) __builtin_amdgcn_s_sleep(127);
+        if (atomicCAS(&cw[b], 0, 1) != 0) n = -1;
+        else while (n < depth) {
+            // The predecessor's own workgroup gets a GRACE period to arrive (workgroups of one launch start within microseconds of
+            // each other, but an XCD hands out its share of the grid as ITS slots free up, so a workgroup can be resident long before its
+            // predecessor on the neighbouring XCD): taking an unclaimed item at once, or after 50 us, made whoever won the race run whole
+            // chains alone -- config C5 7 x slower.  After 20 ms the item is taken: the wait is bounded, no progress depends on dispatch.
+            int *pw = &cw[b - (n + 1) * stride];
+            const long long t_begin = wall_clock64();
+            int seen;
+            while ((seen = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - t_begin < CLAIM_GRACE_TICKS) __builtin_amdgcn_s_sleep(8);
+            if (seen != 0 || atomicCAS(pw, 0, 1) != 0) break;
+            n++;
+        }
     }
-    return __builtin_amdgcn_readfirstlane(t);
+    return __builtin_amdgcn_readfirstlane(n);
 }
 __device__ __forceinline__ unsigned alignbit2(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 2); }
 

@@ -179,7 +179,7 @@ int gnx_align_batch_device(const gnx_params *p, int64_t n_pairs,
 int gnx_get_timing(gnx_timing *out);
 /* Diagnostics (tests only; nothing in the reference corresponds to it): launch n_workgroups workgroups that each hold one CU's whole
  * LDS and spin for `milliseconds` on a stream of their own, and return at once -- the pipelined launches of the library must make
- * progress whatever else occupies the device (their work items are handed out by ticket, not by block index). */
+ * progress whatever else occupies the device (no workgroup waits for work that has not been claimed by a running one). */
 int gnx_debug_occupy(int n_workgroups, int milliseconds);
 
 /* ---- "next" row N1: chunk and multiple-alignment variants (what cmd/faChunkAlign and popgen/dunn.go run) ---- */

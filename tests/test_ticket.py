@@ -1,8 +1,9 @@
 """Forward progress of the pipelined launches must not depend on the order in which workgroups start (VERDICT r2 item 3;
-MI355X_MICROARCH "Workgroup dispatch": HIP promises nothing about dispatch order).  Every piped kernel hands out its work items by
-TICKET (csrc/gnx_common.hip.h: block_ticket).  Two stress legs, each over all five piped kernels, results against the oracle:
-  * GNX_TICKET_DELAY: the workgroups of the lower half of the grid sleep before they draw, so the items are taken far out of
-    block-index order (what a different dispatcher could do);
+MI355X_MICROARCH "Workgroup dispatch": HIP promises nothing about dispatch order).  In every piped kernel a workgroup CLAIMS its item
+and every unclaimed predecessor of it, and runs those first (csrc/gnx_common.hip.h: claim_items): nobody waits for work that has not been
+taken.  Two stress legs, each over all five piped kernels, results against the oracle:
+  * GNX_TICKET_DELAY: the workgroups of the lower half of the grid sleep before they claim, so the upper half finds its predecessors
+    unclaimed and runs whole chains itself (what a dispatcher that starts workgroups in another order would cause);
   * gnx_debug_occupy: 128 workgroups that each hold a whole CU's LDS spin on another stream while the piped launch runs, so half
     the CUs cannot take workgroups of the launch at all.
 The bug trap (5 s spin timeout -> error flag 16 -> sequential re-run) must stay silent: the legs assert that the piped launch was
@@ -56,7 +57,7 @@ def test_piped_launches_do_not_depend_on_dispatch_order(gpu_lib, monkeypatch, le
     plain = gpu_lib.align_batch(p, alphas, betas)
     common.assert_same(plain, exp, name)
     if stress in ("delay", "both"):
-        monkeypatch.setenv("GNX_TICKET_DELAY", "40")   # ~ 40 x 127 x 64 cycles = 0.15 ms before the lower half draws
+        monkeypatch.setenv("GNX_TICKET_DELAY", "40")   # ~ 40 x 127 x 64 cycles = 0.15 ms before the lower half claims
     if stress in ("occupy", "both"):
         gpu_lib.check(gpu_lib.lib().gnx_debug_occupy(128, 300))  # half the CUs gone for 0.3 s
     t0 = time.time()
