@@ -18,7 +18,7 @@ EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gn
            "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing",
            "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch",
            "gnx_init_devices", "gnx_n_devices", "gnx_set_reference", "gnx_set_reference_synthetic", "gnx_align_batch_by_offset",
-           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch", "gnx_debug_occupy"]
+           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch", "gnx_debug_occupy", "gnx_reference_info"]
 
 
 class GnxCigar(ctypes.Structure):
@@ -184,6 +184,16 @@ def init_devices(devices=None, workspace_bytes=0):
 def set_reference(ref):
     ref = _u8(ref)
     check(lib().gnx_set_reference(ref.ctypes.data, ref.shape[0]))
+
+
+def reference_info():
+    """(bases, device bytes per context, 64-base blocks on the exception list) of the resident, packed reference"""
+    L = lib()
+    a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    L.gnx_reference_info.argtypes = [ctypes.POINTER(ctypes.c_int64)] * 3
+    L.gnx_reference_info.restype = ctypes.c_int
+    check(L.gnx_reference_info(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return a.value, b.value, c.value
 
 
 def synthetic_reference_bases(start, length, seed):

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    BetaSrc bp;
+    bp.init(b_buf, kp, valid ? b_start[p] : 0, valid ? pl.m : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4, RB = kp.e4;
     int vO4;
@@ -109,9 +110,9 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
                 const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
                 odn = v.x; oh = v.y;
             } else { odn = 0; oh = 0; }
-            ob = (c >= 1 && c <= m_eff) ? (int)bp[c - 1] : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
+            ob = (c >= 1 && c <= m_eff) ? bp.raw(c - 1) : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
         };
-        auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
+        auto base_off = [&](int raw, int c) { int b = (c >= 1 && c <= m_eff) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane (c: the column the raw base was loaded for)
         int rb_seen = 0;
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
         if (!piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qdn, qh, qb);
-        qb = base_off(qb);
+        qb = base_off(qb, l + 1);
 
         // profile entries one step ahead (software pipeline over the LDS round trip, see cl_sweep_kernel)
         int wq[LW], pb_cur;
@@ -203,10 +204,10 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
             boundary(t0 + 16 + l + 1, ndn, nh, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
             // consume the loads issued at the top of this block BEFORE the stores below are issued (exact wait, nothing newer in flight;
             // left to their first real use -- the DPP moves of the next block -- the wait becomes a vmcnt(0) behind those stores)
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    BetaSrc bp;
+    bp.init(b_buf, kp, valid ? b_start[p] : 0, valid ? pl.m : 0);
     const int64_t rb_pitch = (int64_t)pl.m + 1;
     const int po = pl.src;
     const int OE4 = kp.oe4, E4 = kp.e4, RB = kp.e4;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
             hold[6] = (int)x4.x; hold[7] = (int)x4.y; hold[8] = (int)x4.z; hold[9] = (int)x4.w; diag0 = (int)x5.x; dn_out = (int)x5.y;
             h_out = hold[R - 1];
             const int jb = tbeg - l;
-            if (jb >= 1 && jb <= m_eff) { int b = bp[jb - 1]; if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
+            if (jb >= 1 && jb <= m_eff) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
         }
         int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
         auto boundary = [&](int cc, int &odn, int &oh, int &ob) {
@@ -348,11 +350,11 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
                 const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
                 odn = v.x; oh = v.y;
             } else { odn = 0; oh = 0; }
-            ob = (cc >= 1 && cc <= m_eff) ? (int)bp[cc - 1] : 0; // RAW base, see al_sweep_kernel
+            ob = (cc >= 1 && cc <= m_eff) ? bp.raw(cc - 1) : 0; // RAW base, see al_sweep_kernel
         };
-        auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
+        auto base_off = [&](int raw, int c) { int b = (c >= 1 && c <= m_eff) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane (c: the column the raw base was loaded for)
         boundary(tbeg + l + 1, qdn, qh, qb);
-        qb = base_off(qb);
+        qb = base_off(qb, tbeg + l + 1);
         // profile entries one step ahead (software pipeline over the LDS round trip, see cl_sweep_kernel)
         int wq[LW], pb_cur;
         auto fetch = [&](int pbv, int *w) {
@@ -409,10 +411,10 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
             boundary(t0 + 16 + l + 1, ndn, nh, nb);
             if (__all(!gact || b >= nblk || (t0 >= 16 && t0 + 16 <= m_eff))) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
             qdn = ndn; qh = nh;
             if (gact && b < nblk) {

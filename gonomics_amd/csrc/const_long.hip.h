@@ -85,7 +85,8 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    BetaSrc bp;
+    bp.init(b_buf, kp, valid ? b_start[p] : 0, valid ? pl.m : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     int bad = 0;
 
@@ -128,12 +129,13 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
             else if (c >= 1 && c <= m_eff) ov = rb_load32(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
             else ov = 0;
             int b = 0;
-            if (c >= 1 && c <= m_eff) b = bp[c - 1];
+            if (c >= 1 && c <= m_eff) b = bp.raw(c - 1);
             if (PF) { ob = b; return; } // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
+            if (c >= 1 && c <= m_eff) b = bp.value(b, c - 1);
             if (b >= 5) { bad = 1; b = 4; }
             ob = b * (BST * 4);
         };
-        auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
+        auto base_off = [&](int raw, int c) { int b = (c >= 1 && c <= m_eff) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
         int rb_seen = 0, pf_seen = 0;
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
@@ -147,7 +149,7 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
         if (!piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qv, qb);
-        if (PF) qb = base_off(qb);
+        if (PF) qb = base_off(qb, l + 1);
 
         int wq[LW], pb_cur = 0; // PF: the profile entries and the base of the CURRENT step (fetched during the step before)
         auto fetch = [&](int pbv, int *w) {
@@ -216,10 +218,10 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) { if (PF && u == 15) nb = base_off(nb); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (PF && u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) { if (PF && u == 15) nb = base_off(nb); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (PF && u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
             if (PF) asm volatile("" :: "v"(nv)); // the row values loaded at the top of this block are consumed before the store below goes out (else: a vmcnt(0) behind it)
             qv = nv;
@@ -283,7 +285,8 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    BetaSrc bp;
+    bp.init(b_buf, kp, valid ? b_start[p] : 0, valid ? pl.m : 0);
     const int64_t rb_pitch = (int64_t)pl.m + 1;
     const int po = pl.src;
     int bad = 0;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
             val[8] = (int)x2.x; val[9] = (int)x2.y; diag0 = (int)x2.z;
             v_out = val[R - 1];
             const int jb = tbeg - l; // the column this lane processed at step tbeg: its base goes to the next lane
-            if (jb >= 1 && jb <= m_eff) { int b = bp[jb - 1]; if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
+            if (jb >= 1 && jb <= m_eff) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
         }
         int qv, qb, nv = 0, nb = 0;
         auto boundary = [&](int cc, int &ov, int &ob) {
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
             else if (cc >= 1 && cc <= m_eff) ov = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
             else ov = 0;
             int b = 0;
-            if (cc >= 1 && cc <= m_eff) { b = bp[cc - 1]; if (b >= 5) { bad = 1; b = 4; } }
+            if (cc >= 1 && cc <= m_eff) { b = bp.at(cc - 1); if (b >= 5) { bad = 1; b = 4; } }
             ob = b * (BST * 4);
         };
         boundary(tbeg + l + 1, qv, qb);

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const int row_base = WIN ? (int)pl.s_off : 0;                          // rows of the pair above this window
     const int ck_pitch = (WIN && pl.s_pitch) ? (int)pl.s_pitch : pl.n;    // rows of the whole pair
     const uint8_t *ap = SCORED ? nullptr : a_buf + (valid ? a_start[pl.src] + row_base : 0);
-    const uint8_t *bp = SCORED ? nullptr : b_buf + (valid ? b_start[pl.src] + (WIN ? pl.col_off : 0) : 0);
+    BetaSrc bp; // (SCORED: unused)
+    bp.init(b_buf, kp, (valid && !SCORED) ? b_start[pl.src] + (WIN ? pl.col_off : 0) : 0, (valid && !SCORED) ? pl.m : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4;
     constexpr bool REB = HFORM;   // rebased keys (see above)
@@ -170,9 +171,9 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
                 odn = v.x; oh = v.y; // rebased like everything else
             } else { odn = 0; oh = 0; }
-            ob = (!SCORED && c >= 1 && c <= m_eff) ? (int)bp[c - 1] : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
+            ob = (!SCORED && c >= 1 && c <= m_eff) ? bp.raw(c - 1) : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
         };
-        auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
+        auto base_off = [&](int raw, int c) { int b = (c >= 1 && c <= m_eff) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane (c: the column the raw base was loaded for)
         // wait until the block of strip s-1 (the previous block of the grid) has published the row-buffer columns <= cmax;
         // strip_prog holds the number of columns it has published so far (INT_MAX when it is done)
         int rb_seen = 0;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         if (MULTI && !piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qdn, qh, qb);
-        qb = base_off(qb);
+        qb = base_off(qb, l + 1);
 
         // LDS profile (!SCORED): the entries of a step are read ONE STEP AHEAD -- the base a lane needs at step t + 1 is the one its left
         // neighbour has at step t, so the DPP move and the reads for t + 1 are issued before the arithmetic of step t and land while it
@@ -288,10 +289,10 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{}, false, 0);
             } else if (steady) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
             // consume the loads issued at the top of this block BEFORE the stores below are issued (exact wait, nothing newer in flight;
             // left to their first real use -- the DPP moves of the next block -- the wait becomes a vmcnt(0) behind those stores)

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[p] : 0);
+    BetaSrc bp;
+    bp.init(b_buf, kp, valid ? b_start[p] : 0, valid ? pl.m : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     int vGL, vGU;
     asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vGL), "=v"(vGU) : "s"(kp.g4 + 2), "s"(kp.g4 + 1));
@@ -101,9 +102,9 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             if (!MULTI || s == 0) ov = REB ? 2 : (GSW == 1 ? 0 : c * kp.g4); // row 0: j*gapPen (rebased: 0, tag 2)
             else if (c >= 1 && c <= m_eff) ov = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped).x;
             else ov = 0;
-            ob = (c >= 1 && c <= m_eff) ? (int)bp[c - 1] : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
+            ob = (c >= 1 && c <= m_eff) ? bp.raw(c - 1) : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
         };
-        auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane
+        auto base_off = [&](int raw, int c) { int b = (c >= 1 && c <= m_eff) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane (c: the column the raw base was loaded for)
         int rb_seen = 0;
         auto wait_rows = [&](int cmax) {
             if (piped && s > 0 && rb_seen < cmax) {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
         if (MULTI && !piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qv, qb);
-        qb = base_off(qb);
+        qb = base_off(qb, l + 1);
 
         // profile entries one step ahead (software pipeline over the LDS round trip, see cl_sweep_kernel)
         int wq[LW], pb_cur;
@@ -168,10 +169,10 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
             // consume the loads issued at the top of this block BEFORE the stores below are issued (exact wait, nothing newer in flight;
             // left to their first real use -- the DPP moves of the next block -- the wait becomes a vmcnt(0) behind those stores)

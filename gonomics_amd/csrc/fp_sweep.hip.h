@@ -114,7 +114,8 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     const int row_base = TAKES ? pl.n - BOT * (below + 1) : 0;                      // rows of the pair above this block
     const int n_loc = ROLE == 1 ? pl.n - BOT * below : (TAKES ? BOT : pl.n);        // rows in this block
     const uint8_t *ap = a_buf + (valid ? a_start[pl.src] + row_base : 0);
-    const uint8_t *bp = b_buf + (valid ? b_start[pl.src] : 0);
+    BetaSrc bp;
+    bp.init(b_buf, kp, valid ? b_start[pl.src] : 0, valid ? pl.m : 0);
     const int m_eff = valid ? pl.m : 0;
     const int P = G8 * RR - n_loc; // padding slots above row 1
     const int q0 = lp * RR;        // first slot of this lane; slot q holds row q - P + 1 of the block
@@ -162,9 +163,9 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     // beta[c] (column c, 1-based) is LOADED at the top of a half block and turned into the LDS byte offset of its profile plane just
     // before the half block's last step, where the next queue is needed: a load whose value is checked on the spot makes the wave
     // wait for the whole memory round trip (the compiler's s_waitcnt vmcnt(0) sat right behind every global_load_ubyte)
-    auto base_raw = [&](int c) { return (c >= 1 && c <= m_eff) ? (int)bp[c - 1] : 0; };
-    auto base_off = [&](int b) { if (b >= 5) { bad = 1; b = 4; } return b * (FP8_BST * 4); };
-    int qb = base_off(base_raw(lp)), nb = 0, nraw = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
+    auto base_raw = [&](int c) { return (c >= 1 && c <= m_eff) ? bp.raw(c - 1) : 0; };
+    auto base_off = [&](int raw, int c) { int b = (c >= 1 && c <= m_eff) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (FP8_BST * 4); };
+    int qb = base_off(base_raw(lp), lp), nb = 0, nraw = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
 
     const int level = pl.strips - 1 - below; // 0 = top block
     const int2 *rb_in = (TAKES && valid) ? rowbuf + pl.rowbuf_off + (int64_t)(level - 1) * (pl.m + 1) : nullptr; // [j] = what the block above hands down for column j
@@ -301,7 +302,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         if (TAKES) { wait_cols(t0 + 15); rqn = rb_at(t0 + 8 + lp); }
 #pragma unroll 1
         for (int u = 0; u < 8; u++) {
-            if (u == 7) nb = base_off(nraw);
+            if (u == 7) nb = base_off(nraw, t0 + 8 + lp);
             step(t0 + u, std::true_type{}, true, u == 7, nb);
         }
         if (TAKES) rq = rqn;
@@ -319,7 +320,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         const bool ckflag = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            if (u == 7) nb = base_off(nraw);
+            if (u == 7) nb = base_off(nraw, t0 + 8 + lp);
             step(t0 + u, std::false_type{}, ckflag, u == 7, nb);
         }
         if (TAKES) rq = rqn;

@@ -48,6 +48,8 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
     const bool writer = !CW || lane == 0;
     const int p = FIRST ? a + p_base : active[a];
     const PairPlan pl = plans[p];
+    BetaSrc wbeta; // (FIRST walks only: the diagonal shortcut reads bases)
+    wbeta.init(b_buf, kp, FIRST ? b_start[pl.src] : 0, FIRST ? pl.m : 0);
     auto k_of = [](int tag) { return XP ? (tag == 3 ? 0 : tag) : 3 - tag; }; // state of a direction tag
     auto op_of = [](int k) { return XP ? (k == 0 ? 0 : 3 - k) : k; };         // CIGAR op of a step taken in state k
     constexpr unsigned IRUN = XP ? 0x55555555u : 0xAAAAAAAAu;                // 16 fields "horizontal gap extended"
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             }
             continue;
         }
-        if (FIRST && k == 0) val -= (int64_t)(kp.sc4[min((int)a_buf[a_start[pl.src] + i - 1], 4) * 5 + min((int)b_buf[b_start[pl.src] + j - 1], 4)] >> 2); // a diagonal step: M(i,j) = h(i-1,j-1) + s
+        if (FIRST && k == 0) val -= (int64_t)(kp.sc4[min((int)a_buf[a_start[pl.src] + i - 1], 4) * 5 + min(wbeta.at(j - 1), 4)] >> 2); // a diagonal step: M(i,j) = h(i-1,j-1) + s
         emit(op_of(k), 1);
         last_op = k;
         bool up_exit = false;
@@ -237,9 +239,9 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         // the same argmax).  No window needed: the reads without an indel (three quarters of the headline batch) skip the re-fill
         // stages altogether.  A read whose best alignment is anything else fails the equality (its optimum is higher) and asks for
         // its window as before.  (XP, the transposed AffineGapLocal: the same with a free row 0 and free steps along the last row.)
-        const uint8_t *ap = a_buf + a_start[pl.src], *bp = b_buf + b_start[pl.src] + (j - i);
+        const uint8_t *ap = a_buf + a_start[pl.src];
         int64_t P = (XP || j == i) ? 0 : tp.gap_open + tp.gap_extend * (int64_t)(j - i); // h(0, j - i): the leading gap (XP: row 0 is free)
-        for (int t = 0; t < i; t++) P += (int64_t)(kp.sc4[min((int)ap[t], 4) * 5 + min((int)bp[t], 4)] >> 2);
+        for (int t = 0; t < i; t++) P += (int64_t)(kp.sc4[min((int)ap[t], 4) * 5 + min(wbeta.at((j - i) + t), 4)] >> 2);
         if (P == val) {
             emit(op_of(0), i); last_op = 0;
             li -= i;

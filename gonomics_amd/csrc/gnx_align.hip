@@ -113,9 +113,13 @@ struct Ctx {
     DevBuf sd_keys, sd_locs, sd_nodes, sd_node_off, sd_word_off, sd_words, sd_tmp[8];
     int64_t sd_n = -1, sd_nodes_n = 0; int sd_seed_len = 0;
     PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
-    int64_t ref_len = -1; // >= 0: a reference of that many bases is resident in `ref`
-    size_t ref_bytes = 0; // bytes of `ref` in use
-    int64_t ref_epoch = 0; // which gnx_set_reference call filled `ref` (contexts created later are brought up to date on first use)
+    // the resident reference, PACKED (gnx_host.hip.h: pack_reference): `ref` = 2 bits per base, ref_flag / ref_rank / ref_exc = the
+    // sparse list of bases that are not A C G T (KParams::b2 / bflag / brank / bexc)
+    DevBuf ref_flag, ref_rank, ref_exc;
+    int64_t ref_len = -1;  // >= 0: a reference of that many bases is resident
+    int64_t ref_nexc = 0;  // 64-base blocks with an exception
+    int64_t ref_epoch = 0; // which gnx_set_reference call filled it (contexts created later are brought up to date on first use)
+    bool beta_packed = false; // set by the host flow around run_device: beta windows index the packed reference of this context
     hipEvent_t ev_in[2] = {nullptr, nullptr};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     gnx_timing timing = {};
@@ -189,6 +193,7 @@ int check_params(const gnx_params *p, KParams &kp, TbParams &tp, bool &affine, b
     const int64_t lim = (int64_t)1 << 26;
     for (int x = 0; x < 25; x++) if (p->scores[x] > lim || p->scores[x] < -lim) { set_err("score out of int32 kernel range%s", ""); return GNX_ERANGE; }
     if (p->gap_open > lim || p->gap_open < -lim || (affine && (p->gap_extend > lim || p->gap_extend < -lim))) { set_err("gap penalty out of int32 kernel range%s", ""); return GNX_ERANGE; }
+    kp.b2 = nullptr; kp.bflag = nullptr; kp.brank = nullptr; kp.bexc = nullptr;
     for (int x = 0; x < 25; x++) kp.sc4[x] = (int)(4 * p->scores[x]);
     kp.o4 = (int)(4 * p->gap_open);
     kp.e4 = affine ? (int)(4 * p->gap_extend) : 0;
@@ -723,6 +728,11 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     KParams kp; TbParams tp; bool affine, local, lowmem;
     int rc = check_params(prm, kp, tp, affine, local, lowmem);
     if (rc) return rc;
+    if (c.beta_packed) { // beta windows of the packed resident reference (by_offset flow); d_b is then unused
+        if (local || gsw || d_smat) { set_err("internal: packed reference on a path that reads beta as bytes%s", ""); return GNX_EINVAL; }
+        kp.b2 = reinterpret_cast<const unsigned *>(c.ref.p); kp.bflag = reinterpret_cast<const unsigned long long *>(c.ref_flag.p);
+        kp.brank = reinterpret_cast<const unsigned *>(c.ref_rank.p); kp.bexc = reinterpret_cast<const unsigned long long *>(c.ref_exc.p);
+    }
     if (d_smat && (!affine || local || lowmem)) { set_err("scored mode needs AffineGap_highMem semantics%s", ""); return GNX_EINVAL; }
     if (gsw && (affine || lowmem || !d_endpos || prm->gap_open > 0)) { set_err("gsw extension needs ConstGap_highMem parameters with gapPen <= 0%s", ""); return GNX_EINVAL; }
     if (n_pairs < 0 || n_pairs > 0x7ffffff0) { set_err("bad n_pairs%s", ""); return GNX_EINVAL; }
@@ -1385,7 +1395,7 @@ void gnx_shutdown(void) {
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,
-                          &c.ref, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
+                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
                           &c.sd_tmp[0], &c.sd_tmp[1], &c.sd_tmp[2], &c.sd_tmp[3], &c.sd_tmp[4], &c.sd_tmp[5], &c.sd_tmp[6], &c.sd_tmp[7]};
         for (DevBuf *b : bufs) b->release();
         PinBuf *pins[] = {&c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};
@@ -1417,58 +1427,29 @@ const char *gnx_last_error(void) {
 
 void gnx_free(void *p) { if (p && !g_pool.put(p)) free(p); }
 
-int64_t g_ref_epoch = 0;
-// makes `len` bases resident on every context in use: allocates, marks, and returns the per-context pointers for the broadcast
-static int reference_slots(int64_t len, std::vector<void *> &dst) {
-    g_ref_epoch++;
-    dst.assign((size_t)g_nctx, nullptr);
-    for (int d = 0; d < g_nctx; d++) {
-        Ctx &c = ctx_at(d);
-        CtxScope sc(c);
-        int rc = ensure_init();
-        if (rc) return rc;
-        if (len == 0) c.ref.release(); // an empty reference gives the memory back
-        if ((rc = c.ref.ensure((size_t)len + 16))) { c.ref_len = -1; return rc; }
-        c.ref_len = len; c.ref_bytes = (size_t)len; c.ref_epoch = g_ref_epoch;
-        dst[(size_t)d] = c.ref.p;
-    }
-    // contexts beyond g_nctx (a smaller gnx_init_devices after a larger one) no longer hold the current reference
-    int n_all; { std::lock_guard<std::mutex> lk(g_ctxs_mu); n_all = (int)g_ctxs.size(); }
-    for (int d = g_nctx; d < n_all; d++) { Ctx &c = ctx_at(d); CtxScope sc(c); c.ref_len = -1; }
-    return GNX_OK;
-}
-
 int gnx_set_reference(const uint8_t *ref, int64_t len) {
     std::lock_guard<std::mutex> api(g_api_mu);
     g_err[0] = 0;
     if (len < 0 || (len > 0 && !ref)) { set_err("bad argument%s", ""); return GNX_EINVAL; }
-    std::vector<void *> dst;
-    int rc = reference_slots(len, dst);
-    if (rc) return rc;
-    Ctx &c0 = ctx_at(0);
-    { CtxScope sc(c0); HIPCHK(hipSetDevice(c0.device)); if (len) HIPCHK(hipMemcpy(c0.ref.p, ref, (size_t)len, hipMemcpyHostToDevice)); }
-    g_bcast_ms = 0;
-    return broadcast_from_ctx0(c0.ref.p, dst, (size_t)len);
+    return set_reference_packed(ref, len, 0);
 }
 
 int gnx_set_reference_synthetic(int64_t len, uint64_t seed) {
     std::lock_guard<std::mutex> api(g_api_mu);
     g_err[0] = 0;
     if (len < 0) { set_err("bad argument%s", ""); return GNX_EINVAL; }
-    std::vector<void *> dst;
-    int rc = reference_slots(len, dst);
-    if (rc) return rc;
-    Ctx &c0 = ctx_at(0);
-    {
-        CtxScope sc(c0);
-        HIPCHK(hipSetDevice(c0.device));
-        const int64_t words = (len + 31) / 32;
-        if (words) hipLaunchKernelGGL(synth_ref_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c0.own_stream, (uint8_t *)c0.ref.p, len, seed);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c0.own_stream));
-    }
-    g_bcast_ms = 0;
-    return broadcast_from_ctx0(c0.ref.p, dst, (size_t)len);
+    return set_reference_packed(nullptr, len, seed);
+}
+
+int gnx_reference_info(int64_t *out_bases, int64_t *out_device_bytes, int64_t *out_exception_blocks) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    Ctx &c = ctx_at(0);
+    CtxScope sc(c);
+    if (c.ref_len < 0) { set_err("no resident reference%s", ""); return GNX_EINVAL; }
+    if (out_bases) *out_bases = c.ref_len;
+    if (out_device_bytes) *out_device_bytes = (int64_t)(ref_words(c.ref_len) * 4 + ref_flagwords(c.ref_len) * 12 + (size_t)c.ref_nexc * 16);
+    if (out_exception_blocks) *out_exception_blocks = c.ref_nexc;
+    return GNX_OK;
 }
 
 int gnx_align_batch_by_offset(const gnx_params *p, int64_t n_pairs, const uint8_t *alpha_cat, const int64_t *alpha_off,

@@ -65,6 +65,49 @@ struct KParams {
     int d00_4;   // 4*D(0,0): gapOpen, or 0 with free end gaps
     int ecol4;   // 4*(column-0 extension): gapExtend, or 0 with free end gaps
     int g4;      // const gap: 4*gapPen
+    // beta = windows of the PACKED resident reference (gnx_set_reference; all null: plain dna.Base bytes in b_buf):
+    const unsigned *b2;              // 2 bits per base, 16 bases per dword (base k: bits 2*(k & 15) of word k >> 4); A C G T = 0 1 2 3
+    const unsigned long long *bflag; // one bit per 64-base block: the block holds a base that is not A C G T (N, or a byte >= 5)
+    const unsigned *brank;           // per flag word (4096 bases): number of such blocks before it
+    const unsigned long long *bexc;  // per such block, in order: {mask of N, mask of bytes >= 5}
+};
+
+// ---- beta as the kernels read it -------------------------------------------------------------------------------------------------
+// Plain: dna.Base bytes.  Packed (the resident reference, SURVEY 7 step 4 / north_star "packed dna.Base sequences"): 2 bits per base
+// plus a sparse exception list -- 4.4e9 bases in 1.1 GB instead of 4.4 GB, on the device and on the RCCL broadcast.  raw(k) is the
+// LOAD (the byte, or the dword holding base k), value(raw, k) the arithmetic that turns it into 0 .. 4 (5: a byte >= 5, which the
+// kernels flag like before): the kernels issue the load a block ahead and take the value where they need it.  A window without
+// exceptions (`dirty` false: all but ~0.02 % of the windows of a genome with its N runs) never touches the exception structures.
+struct BetaSrc {
+    const uint8_t *bytes;
+    const unsigned *w2;
+    const KParams *kp;
+    int64_t off; // absolute index of column 1 of this pair's window
+    bool dirty;
+    __device__ __forceinline__ void init(const uint8_t *b_buf, const KParams &k, int64_t start, int64_t len) {
+        bytes = b_buf; w2 = k.b2; kp = &k; off = start; dirty = false;
+        if (w2 && len > 0) { // exception blocks before block x: rank of the flag word + bits below
+            auto rank = [&](int64_t x) { const unsigned long long f = k.bflag[x >> 6]; return (int64_t)k.brank[x >> 6] + __popcll(f & ((1ull << (x & 63)) - 1ull)); };
+            dirty = rank(((start + len - 1) >> 6) + 1) > rank(start >> 6);
+        }
+    }
+    __device__ __forceinline__ int raw(int64_t k) const { return w2 ? (int)w2[(off + k) >> 4] : (int)bytes[off + k]; }
+    __device__ __forceinline__ int value(int r, int64_t k) const {
+        if (!w2) return r;
+        const int64_t x = off + k;
+        int b = (int)(((unsigned)r >> (2 * ((int)x & 15))) & 3u);
+        if (dirty) {
+            const unsigned long long f = kp->bflag[x >> 12];
+            const int bit = (int)(x >> 6) & 63;
+            if ((f >> bit) & 1ull) {
+                const int64_t e = (int64_t)kp->brank[x >> 12] + __popcll(f & ((1ull << bit) - 1ull));
+                if ((kp->bexc[2 * e] >> (x & 63)) & 1ull) b = 4;
+                if ((kp->bexc[2 * e + 1] >> (x & 63)) & 1ull) b = 5;
+            }
+        }
+        return b;
+    }
+    __device__ __forceinline__ int at(int64_t k) const { return value(raw(k), k); } // load and use on the spot
 };
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }

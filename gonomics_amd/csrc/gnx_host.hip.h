@@ -120,15 +120,144 @@ __device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-__global__ __launch_bounds__(256) void synth_ref_kernel(uint8_t *__restrict__ ref, int64_t len, uint64_t seed) {
+// out[0 .. n) = bases [pos0, pos0 + n) of the synthetic reference (pos0 a multiple of 32)
+__global__ __launch_bounds__(256) void synth_ref_kernel(uint8_t *__restrict__ out, int64_t pos0, int64_t n, uint64_t seed) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // 32 bases per thread: one 64-bit draw
     const int64_t p0 = w * 32;
-    if (p0 >= len) return;
-    const uint64_t bits = splitmix64(seed ^ (uint64_t)w);
-    for (int k = 0; k < 32 && p0 + k < len; k++) {
-        const int64_t pos = p0 + k;
-        ref[pos] = (pos % 50000000 < 1000 && pos >= 50000000) ? 4 : (uint8_t)((bits >> (2 * k)) & 3u);
+    if (p0 >= n) return;
+    const uint64_t bits = splitmix64(seed ^ (uint64_t)(pos0 / 32 + w));
+    for (int k = 0; k < 32 && p0 + k < n; k++) {
+        const int64_t pos = pos0 + p0 + k;
+        out[p0 + k] = (pos % 50000000 < 1000 && pos >= 50000000) ? 4 : (uint8_t)((bits >> (2 * k)) & 3u);
     }
+}
+
+// ---- the resident reference, packed --------------------------------------------------------------------------------------------
+// 2 bits per base (A C G T), 16 bases per dword; one flag bit per 64-base block that holds anything else (N = 4, or a byte >= 5 that
+// the Go code would panic on WHEN AN ALIGNMENT TOUCHES IT -- so it is recorded, not refused), the rank of every flag word, and per
+// flagged block the two masks.  4.4e9 bases: 1.1 GB + 13 MB + 16 B per flagged block, instead of 4.4 GB.
+size_t ref_words(int64_t len) { return (size_t)((len + 15) / 16) + 4; }
+size_t ref_flagwords(int64_t len) { return (size_t)(((len + 63) / 64 + 63) / 64) + 2; }
+constexpr int64_t REF_CHUNK = (int64_t)256 << 20; // bases packed per pass (multiple of 4096): staging 256 MB
+
+// pass 1: one thread per 64-base block of the chunk: the four 2-bit words, the block's flag bit
+__global__ __launch_bounds__(256) void pack_ref_kernel(const uint8_t *__restrict__ bytes, int64_t base0, int64_t n, unsigned *__restrict__ w2,
+                                                       unsigned long long *__restrict__ flag) {
+    const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // block index inside the chunk
+    if (blk * 64 >= n) return;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    bool exc = false;
+    for (int k = 0; k < 64; k++) {
+        const int64_t x = blk * 64 + k;
+        const int b = x < n ? bytes[x] : 0;
+        if (b >= 4) exc = true;
+        w[k >> 4] |= (unsigned)(b & 3) << (2 * (k & 15));
+    }
+    const int64_t gblk = base0 / 64 + blk;
+    unsigned *dst = w2 + gblk * 4;
+    dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
+    if (exc) atomicOr(&flag[gblk >> 6], 1ull << (gblk & 63));
+}
+// pass 2 (ranks known): the masks of the flagged blocks of the chunk
+__global__ __launch_bounds__(256) void pack_exc_kernel(const uint8_t *__restrict__ bytes, int64_t base0, int64_t n, const unsigned long long *__restrict__ flag,
+                                                       const unsigned *__restrict__ rank, unsigned long long *__restrict__ exc) {
+    const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk * 64 >= n) return;
+    const int64_t gblk = base0 / 64 + blk;
+    const unsigned long long f = flag[gblk >> 6];
+    if (!((f >> (gblk & 63)) & 1ull)) return;
+    unsigned long long nm = 0, bm = 0;
+    for (int k = 0; k < 64; k++) {
+        const int64_t x = blk * 64 + k;
+        const int b = x < n ? bytes[x] : 0;
+        if (b == 4) nm |= 1ull << k;
+        if (b >= 5) bm |= 1ull << k;
+    }
+    const int64_t e = (int64_t)rank[gblk >> 6] + __popcll(f & ((1ull << (gblk & 63)) - 1ull));
+    exc[2 * e] = nm; exc[2 * e + 1] = bm;
+}
+// windows of the packed reference back to bytes (AffineGapLocal on the resident reference: its fast path reads the long sequence as
+// the kernels' alpha, which is read as bytes; GNX_REF_UNPACK=1 forces this for every mode: the A/B of the packed reads)
+__global__ __launch_bounds__(256) void unpack_windows_kernel(KParams kp, const int64_t *__restrict__ start, const int64_t *__restrict__ out_off, int n_pairs,
+                                                             uint8_t *__restrict__ out) {
+    const int p = blockIdx.x; // one workgroup per window
+    if (p >= n_pairs) return;
+    const int64_t len = out_off[p + 1] - out_off[p];
+    BetaSrc b;
+    b.init(nullptr, kp, start[p], len);
+    for (int64_t k = threadIdx.x; k < len; k += blockDim.x) out[out_off[p] + k] = (uint8_t)b.at(k);
+}
+
+int64_t g_ref_epoch = 0;
+int ensure_reference(int nc);
+// ref != nullptr: host bytes; else the synthetic reference of SURVEY 8d (generated chunk by chunk on the device)
+int set_reference_packed(const uint8_t *ref, int64_t len, uint64_t seed) {
+    g_ref_epoch++;
+    Ctx &c0 = ctx_at(0);
+    {
+        CtxScope sc(c0);
+        int rc = ensure_init();
+        if (rc) return rc;
+        HIPCHK(hipSetDevice(c0.device));
+        hipStream_t st = c0.own_stream;
+        c0.ref_len = -1;
+        if (len == 0) { c0.ref.release(); c0.ref_flag.release(); c0.ref_rank.release(); c0.ref_exc.release(); }
+        const size_t nw = ref_words(len), nf = ref_flagwords(len);
+        if ((rc = c0.ref.ensure(nw * 4))) return rc;
+        if ((rc = c0.ref_flag.ensure(nf * 8))) return rc;
+        if ((rc = c0.ref_rank.ensure(nf * 4))) return rc;
+        HIPCHK(hipMemsetAsync(c0.ref.p, 0, nw * 4, st));
+        HIPCHK(hipMemsetAsync(c0.ref_flag.p, 0, nf * 8, st));
+        DevBuf stage;
+        const int64_t chunk = std::min<int64_t>(REF_CHUNK, std::max<int64_t>(len, 1));
+        if ((rc = stage.ensure((size_t)chunk + 64))) return rc;
+        std::vector<unsigned long long> hflag(nf, 0ull);
+        std::vector<unsigned> hrank(nf, 0u);
+        int64_t nexc = 0;
+        // exception masks: grown as needed (a genome's N runs are a few per cent of its blocks at most)
+        auto grow_exc = [&](int64_t want, int64_t keep) -> int {
+            if ((size_t)want * 16 <= c0.ref_exc.cap) return GNX_OK;
+            DevBuf nb;
+            int r = nb.ensure((size_t)std::max<int64_t>(want * 2, 1024) * 16);
+            if (r) return r;
+            if (keep > 0) { HIPCHK(hipMemcpyAsync(nb.p, c0.ref_exc.p, (size_t)keep * 16, hipMemcpyDeviceToDevice, st)); HIPCHK(hipStreamSynchronize(st)); }
+            c0.ref_exc.release(); c0.ref_exc = nb;
+            return GNX_OK;
+        };
+        if ((rc = grow_exc(1, 0))) { stage.release(); return rc; }
+        auto fail = [&](int code) { stage.release(); return code; };
+        for (int64_t b0 = 0; b0 < len; b0 += chunk) {
+            const int64_t n = std::min(chunk, len - b0);
+            if (ref) { if (hipMemcpyAsync(stage.p, ref + b0, (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) { set_err("upload of the reference failed%s", ""); return fail(GNX_EDEVICE); } }
+            else hipLaunchKernelGGL(synth_ref_kernel, dim3((unsigned)(((n + 31) / 32 + 255) / 256)), dim3(256), 0, st, (uint8_t *)stage.p, b0, n, seed);
+            const int64_t nblk = (n + 63) / 64;
+            hipLaunchKernelGGL(pack_ref_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, (const uint8_t *)stage.p, b0, n, (unsigned *)c0.ref.p, (unsigned long long *)c0.ref_flag.p);
+            // ranks of this chunk's flag words (the chunk starts on a flag-word boundary: REF_CHUNK is a multiple of 4096)
+            const size_t f0 = (size_t)(b0 / 4096), f1 = (size_t)((b0 + n + 4095) / 4096);
+            if (hipMemcpyAsync(hflag.data() + f0, (const unsigned long long *)c0.ref_flag.p + f0, (f1 - f0) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { set_err("packing the reference failed%s", ""); return fail(GNX_EDEVICE); }
+            const int64_t before = nexc;
+            for (size_t f = f0; f < f1; f++) { hrank[f] = (unsigned)nexc; nexc += __builtin_popcountll(hflag[f]); }
+            if (nexc > 0xfffffff0LL) { set_err("too many non-ACGT blocks in the reference%s", ""); return fail(GNX_ENOMEM); }
+            if (nexc > before) {
+                if ((rc = grow_exc(nexc, before))) return fail(rc);
+                if (hipMemcpyAsync((unsigned *)c0.ref_rank.p + f0, hrank.data() + f0, (f1 - f0) * 4, hipMemcpyHostToDevice, st) != hipSuccess) { set_err("packing the reference failed%s", ""); return fail(GNX_EDEVICE); }
+                hipLaunchKernelGGL(pack_exc_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, (const uint8_t *)stage.p, b0, n, (const unsigned long long *)c0.ref_flag.p,
+                                   (const unsigned *)c0.ref_rank.p, (unsigned long long *)c0.ref_exc.p);
+            }
+            if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { set_err("packing the reference failed%s", ""); return fail(GNX_EDEVICE); }
+        }
+        // the ranks of ALL flag words (also behind the last chunk: BetaSrc::init looks one block past a window's end)
+        for (size_t f = (size_t)((len + 4095) / 4096); f < nf; f++) hrank[f] = (unsigned)nexc;
+        if (hipMemcpy(c0.ref_rank.p, hrank.data(), nf * 4, hipMemcpyHostToDevice) != hipSuccess) { set_err("packing the reference failed%s", ""); return fail(GNX_EDEVICE); }
+        stage.release();
+        c0.ref_len = len; c0.ref_nexc = nexc; c0.ref_epoch = g_ref_epoch;
+    }
+    // contexts beyond the ones in use no longer hold the current reference; the others get it now
+    int n_all; { std::lock_guard<std::mutex> lk(g_ctxs_mu); n_all = (int)g_ctxs.size(); }
+    for (int d = 1; d < n_all; d++) { Ctx &c = ctx_at(d); CtxScope sc(c); c.ref_len = -1; }
+    g_bcast_ms = 0;
+    return ensure_reference(g_nctx);
 }
 
 // ---- one context's share of a batch ---------------------------------------------------------------------------------------------
@@ -139,6 +268,7 @@ struct HostJob {
     const uint8_t *a_buf = nullptr; const int64_t *a_start = nullptr, *a_len = nullptr; // host windows
     const uint8_t *b_buf = nullptr; const int64_t *b_start = nullptr, *b_len = nullptr; // host windows, or windows into b_dev
     const uint8_t *b_dev = nullptr; // != nullptr: the whole beta buffer / the resident reference is on this context's device
+    bool packed = false;            // b_dev is the PACKED resident reference (beta windows = base positions in it)
     int64_t total_ops = 0;
     int rc = GNX_OK;
     char err[512] = "";
@@ -243,11 +373,32 @@ int run_host_job(HostJob &j) {
         rc = GNX_OK;
         if (hipStreamWaitEvent(c.own_stream, c.ev_in[slot], 0) != hipSuccess) { set_err("hipStreamWaitEvent failed%s", ""); rc = GNX_EDEVICE; }
         int64_t tot = 0;
+        const uint8_t *db = j.b_dev ? j.b_dev : (const uint8_t *)c.pin_b[slot].p;
+        const int64_t *dbs = (const int64_t *)c.pin_bs[slot].p;
+        bool packed = j.packed;
+        if (packed && rc == GNX_OK && (j.prm->mode == GNX_AFFINE_GAP_LOCAL || getenv("GNX_REF_UNPACK"))) {
+            // the windows as bytes (AffineGapLocal's transposed fast path reads the long sequence as the kernels' alpha; GNX_REF_UNPACK: A/B)
+            std::vector<int64_t> uoff((size_t)cnt + 1, 0);
+            for (int64_t q = 0; q < cnt; q++) { uoff[(size_t)q + 1] = uoff[(size_t)q] + bl[b + q]; }
+            if ((rc = c.in_b.ensure((size_t)uoff[(size_t)cnt] + 64)) == GNX_OK && (rc = c.in_bl.ensure((size_t)(cnt + 1) * 8)) == GNX_OK) {
+                KParams ukp;
+                memset(&ukp, 0, sizeof(ukp));
+                ukp.b2 = (const unsigned *)c.ref.p; ukp.bflag = (const unsigned long long *)c.ref_flag.p; ukp.brank = (const unsigned *)c.ref_rank.p; ukp.bexc = (const unsigned long long *)c.ref_exc.p;
+                if (hipMemcpyAsync(c.in_bl.p, uoff.data(), (size_t)(cnt + 1) * 8, hipMemcpyHostToDevice, c.own_stream) != hipSuccess || hipStreamSynchronize(c.own_stream) != hipSuccess) { set_err("upload of the window table failed%s", ""); rc = GNX_EDEVICE; }
+                else {
+                    hipLaunchKernelGGL(unpack_windows_kernel, dim3((unsigned)cnt), dim3(256), 0, c.own_stream, ukp, dbs, (const int64_t *)c.in_bl.p, (int)cnt, (uint8_t *)c.in_b.p);
+                    if (hipGetLastError() != hipSuccess) { set_err("unpack_windows_kernel failed to launch%s", ""); rc = GNX_EDEVICE; }
+                    db = (const uint8_t *)c.in_b.p; dbs = (const int64_t *)c.in_bl.p; packed = false;
+                }
+            }
+        }
         for (int attempt = 0; rc == GNX_OK; attempt++) {
             const int64_t cap = (int64_t)(c.res_ops.cap / sizeof(gnx_cigar)) - total;
+            c.beta_packed = packed;
             rc = run_device(j.prm, cnt, (const uint8_t *)c.pin_a[slot].p, (const int64_t *)c.pin_as[slot].p,
-                            j.b_dev ? j.b_dev : (const uint8_t *)c.pin_b[slot].p, (const int64_t *)c.pin_bs[slot].p, al + b, bl + b,
+                            db, dbs, al + b, bl + b,
                             (int64_t *)c.res_score.p + done, (gnx_cigar *)c.res_ops.p + total, cap, (int64_t *)c.res_off.p + done, &tot, c.own_stream);
+            c.beta_packed = false;
             if (rc != GNX_ECAPACITY || attempt >= 8) break;
             // the reported total is exact (every sub-batch of the device flow is counted); leave room for the sub-batches to come
             const int64_t left = (n - done + cnt - 1) / cnt;
@@ -329,25 +480,31 @@ int broadcast_from_ctx0(const void *src0, std::vector<void *> &dst, size_t bytes
     g_bcast_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return GNX_OK;
 }
-// the resident reference on contexts [0, nc): a context created after gnx_set_reference (gnx_init_devices called later)
-// gets its copy from context 0 here
+// the resident reference on contexts [0, nc): a context that lacks the current one (created after gnx_set_reference -- ADVICE r2 --
+// or simply not context 0, where the packing happens) gets its copy from context 0: four arrays, RCCL over xGMI or peer copies
 int ensure_reference(int nc) {
     Ctx &c0 = ctx_at(0);
+    if (c0.ref_len < 0) return GNX_OK;
+    const size_t sz[4] = {ref_words(c0.ref_len) * 4, ref_flagwords(c0.ref_len) * 8, ref_flagwords(c0.ref_len) * 4, (size_t)std::max<int64_t>(c0.ref_nexc, 1) * 16};
     bool missing = false;
-    std::vector<void *> dst((size_t)nc, nullptr);
+    std::vector<void *> dst[4];
+    for (int k = 0; k < 4; k++) dst[k].assign((size_t)nc, nullptr);
     for (int d = 0; d < nc; d++) {
         Ctx &c = ctx_at(d);
         CtxScope sc(c);
         int rc = ensure_init();
         if (rc) return rc;
-        if (d > 0 && (c.ref_len != c0.ref_len || c.ref.p == nullptr || c.ref_epoch != c0.ref_epoch)) {
+        DevBuf *bufs[4] = {&c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc};
+        if (d > 0 && (c.ref_len != c0.ref_len || c.ref_epoch != c0.ref_epoch || c.ref.p == nullptr)) {
             missing = true;
-            if ((rc = c.ref.ensure(c0.ref_bytes + 16))) return rc;
-            c.ref_len = c0.ref_len; c.ref_bytes = c0.ref_bytes; c.ref_epoch = c0.ref_epoch;
+            for (int k = 0; k < 4; k++) if ((rc = bufs[k]->ensure(sz[k]))) { c.ref_len = -1; return rc; }
+            c.ref_len = c0.ref_len; c.ref_nexc = c0.ref_nexc; c.ref_epoch = c0.ref_epoch;
         }
-        dst[(size_t)d] = c.ref.p;
+        for (int k = 0; k < 4; k++) dst[k][(size_t)d] = bufs[k]->p;
     }
-    return missing ? broadcast_from_ctx0(c0.ref.p, dst, c0.ref_bytes) : GNX_OK;
+    if (!missing) return GNX_OK;
+    for (int k = 0; k < 4; k++) { int rc = broadcast_from_ctx0(dst[k][0], dst[k], sz[k]); if (rc) return rc; }
+    return GNX_OK;
 }
 
 // The sharded host flow.  b_buf == nullptr: beta windows index the resident reference (gnx_set_reference).
@@ -403,6 +560,7 @@ int run_host_sharded(const gnx_params *prm, int64_t n_pairs,
         j.c = &ctx_at(d); j.prm = prm; j.p0 = bounds[(size_t)d]; j.p1 = bounds[(size_t)d + 1];
         j.a_buf = a_buf; j.a_start = a_start; j.a_len = a_lens; j.b_buf = b_buf; j.b_start = b_start; j.b_len = b_lens;
         j.b_dev = (const uint8_t *)bdev[(size_t)d];
+        j.packed = resident;
     }
     auto work = [](HostJob *j) {
         CtxScope sc(*j->c);

@@ -126,10 +126,15 @@ const char *gnx_last_error(void);
 void gnx_free(void *p);
 
 /* ---- resident reference (configs C3 / C4: reads against windows of one genome) ------------------ */
-/* Upload `ref` (dna.Base bytes) once; it stays on the device(s) until the next call or gnx_shutdown.  With several contexts it is
- * uploaded to device 0 and broadcast over RCCL.  Replaces passing the same target slice to every align.* call of a loop
+/* Upload `ref` (dna.Base bytes) once; it stays on the device(s) until the next call or gnx_shutdown -- PACKED: 2 bits per base plus a
+ * sparse list of the 64-base blocks that hold anything but A C G T (N; bytes >= 5, which make GNX_EBASE only when an alignment's
+ * window touches them, like the Go code's panic): 4.4e9 bases take 1.1 GB of HBM and of RCCL broadcast instead of 4.4 GB.  It is
+ * packed on device 0 (256 MB of bases at a time) and, with several contexts, broadcast over RCCL; the sweep kernels read the packed
+ * words directly (len = 0 releases it).  Replaces passing the same target slice to every align.* call of a loop
  * (/root/reference/cmd/globalAlignmentAnchor/globalAlignmentAnchor.go:352-384 re-reads its two genomes per anchor). */
 int gnx_set_reference(const uint8_t *ref, int64_t len);
+/* What is resident: bases, bytes of device memory per context, 64-base blocks on the exception list. */
+int gnx_reference_info(int64_t *out_bases, int64_t *out_device_bytes, int64_t *out_exception_blocks);
 /* Synthetic reference of SURVEY 8d (config C3), generated on the device: base(pos) = 2 bits of splitmix64(seed ^ (pos / 32)) at
  * bit 2*(pos % 32), with an N run of 1000 bases at every multiple of 5e7 except 0.  For benchmarks and tests (3e9 bases do not
  * have to cross PCIe); nothing in the reference corresponds to it. */

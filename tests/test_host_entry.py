@@ -257,6 +257,8 @@ def test_c3_one_million_reads_against_a_resident_4gb_reference(gpu_lib):
     gpu_lib.check(L.gnx_init(0, 60 << 30))
     try:
         gpu_lib.check(L.gnx_set_reference_synthetic(ref_len, ref_seed))
+        bases, dev_bytes, nexc = gpu_lib.reference_info()
+        assert bases == ref_len and dev_bytes <= 1.2e9 and nexc >= 87 * 15  # 4.4e9 bases resident in 1.1 GB; the N runs are on the exception list
         p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, sc, -600, -150)
         a_off = np.arange(n + 1, dtype=np.int64) * 150
         score, ops, off = gpu_lib.align_batch_by_offset(p, reads.reshape(-1), a_off, starts, np.full(n, window, dtype=np.int64))
@@ -278,3 +280,78 @@ def test_c3_one_million_reads_against_a_resident_4gb_reference(gpu_lib):
     assert np.array_equal(got_cnt, np.diff(exp[2]))
     flat = np.concatenate([np.arange(off[x], off[x + 1]) for x in sel])
     assert np.array_equal(ops["run_length"][flat], exp[1]["run_length"]) and np.array_equal(ops["op"][flat], exp[1]["op"])
+
+
+def _ref_with_exceptions(seed, n):
+    """a reference with N runs, scattered N, and two stretches of bytes the Go code would panic on (lower-case-like 5 .. 9, dna.Gap 10)"""
+    rng = np.random.default_rng(seed)
+    ref = rng.integers(0, 4, size=n).astype(np.uint8)
+    ref[rng.random(n) < 0.0005] = 4
+    for s0 in (3000, 50000, 50063, 50064, 90001):
+        ref[s0:s0 + int(rng.integers(1, 700))] = 4
+    ref[120000:120040] = rng.integers(5, 11, size=40).astype(np.uint8)
+    ref[n - 3] = 7
+    return ref
+
+
+@pytest.mark.parametrize("route", ["default", "general", "snapshot"])
+def test_packed_reference_equals_bytes(gpu_lib, monkeypatch, route):
+    """The resident reference is kept 2 bits per base + an exception list and the kernels read the packed words (BetaSrc): every mode
+    and route must give what the byte windows give -- against the oracle, and against GNX_REF_UNPACK=1 (windows expanded to bytes
+    first).  Windows start at every alignment modulo 64, cross N runs, end at the last base."""
+    L = gpu_lib.lib()
+    n_ref = 200000
+    ref = _ref_with_exceptions(91, n_ref)
+    rng = np.random.default_rng(92)
+    env = {"default": {}, "general": {"GNX_FASTPATH": "0", "GNX_CLONG": "0"}, "snapshot": {"GNX_CLONG": "2", "GNX_FASTPATH": "0"}}[route]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cases = [  # (mode, oracle mode, matrix, go, ge, read lengths, window lengths)
+        (gpu_lib.GNX_AFFINE_GAP, 0, "HumanChimpTwo", -600, -150, (100, 160), (900, 2500)),
+        (gpu_lib.GNX_AFFINE_GAP, 0, "Default", -400, -30, (200, 700), (800, 1500)),       # several row blocks / strips
+        (gpu_lib.GNX_CONST_GAP, 1, "HumanChimpTwo", -430, 0, (100, 500), (300, 1200)),
+        (gpu_lib.GNX_AFFINE_GAP_HIGHMEM, 2, "Default", -400, -30, (30, 200), (30, 400)),
+        (gpu_lib.GNX_AFFINE_GAP_LOCAL, 3, "HumanChimpTwo", -600, -150, (100, 160), (900, 2500)),  # target = alpha = the read here: by_offset's beta is the window
+    ]
+    try:
+        gpu_lib.set_reference(ref)
+        bases, dev_bytes, nexc = gpu_lib.reference_info()
+        assert bases == n_ref and nexc > 10 and dev_bytes < 0.27 * n_ref + 4096
+        for mode, omode, mx, go, ge, (n_lo, n_hi), (m_lo, m_hi) in cases:
+            n_pairs = 300
+            wl = rng.integers(m_lo, m_hi + 1, size=n_pairs).astype(np.int64)
+            ws = rng.integers(0, 119000 - m_hi, size=n_pairs).astype(np.int64)   # before the stretch of bad bytes
+            ws[:64] = 40000 + np.arange(64)                                          # every alignment modulo 64; crosses the N runs at 50 000
+            ws[64] = n_ref - 3 - wl[64]                                               # ends right before the bad byte at n - 3 ...
+            ws[64] = max(ws[64], 130000)
+            reads = []
+            for k in range(n_pairs):
+                w = ref[ws[k]:ws[k] + wl[k]]
+                ln = int(rng.integers(n_lo, n_hi + 1))
+                o = int(rng.integers(0, max(1, wl[k] - ln)))
+                r = common.mutate(rng, np.minimum(w[o:o + ln], 4), sub=0.03, indel=0.01, geo=0.4, alphabet=4)
+                reads.append(r if len(r) else np.zeros(1, np.uint8))
+            a_cat = np.concatenate(reads)
+            a_off = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+            p = gpu_lib.make_params(mode, MX[mx], go, ge)
+            got = gpu_lib.align_batch_by_offset(p, a_cat, a_off, ws, wl)
+            exp = oracle.align_batch(omode, MX[mx], go, ge, reads, [ref[ws[k]:ws[k] + wl[k]] for k in range(n_pairs)], 10000, 10000, threads=8)
+            common.assert_same(got, exp, "packed reference, mode %d, %s" % (mode, route))
+            monkeypatch.setenv("GNX_REF_UNPACK", "1")
+            common.assert_same(gpu_lib.align_batch_by_offset(p, a_cat, a_off, ws, wl), exp, "windows unpacked to bytes, mode %d" % mode)
+            monkeypatch.delenv("GNX_REF_UNPACK")
+        # a window that touches a byte >= 5 makes GNX_EBASE (the Go code indexes its 5 x 5 matrix with it); the others do not care
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150)
+        rd = np.minimum(ref[119000:119150], 3)
+        a_off = np.asarray([0, 150], dtype=np.int64)
+        gpu_lib.align_batch_by_offset(p, rd, a_off, np.asarray([119000]), np.asarray([1000]))  # ends at 120 000: clean
+        for bad_start, bad_len in ((119100, 1000), (n_ref - 1000, 1000)):
+            with pytest.raises(gpu_lib.GnxError) as ei:
+                gpu_lib.align_batch_by_offset(p, rd, a_off, np.asarray([bad_start]), np.asarray([bad_len]))
+            assert ei.value.code == gpu_lib.GNX_EBASE
+    finally:
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.delenv("GNX_REF_UNPACK", raising=False)
+        L.gnx_shutdown()
+        gpu_lib.check(L.gnx_init(0, 8 << 30))
