@@ -68,6 +68,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
 
     const bool piped = MULTI && strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
+    constexpr bool PF = !SCORED && !WIN; // the look-ahead form of the step (LDS reads one step ahead, base conversion deferred), see below
     // piped: this workgroup runs strip strip_map[blockIdx].y of its group -- and first every strip above it that nobody has claimed yet
     // (claim_items: forward progress without any assumption about dispatch order); none in the normal case
     int n_stolen = 0;
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
                 odn = v.x; oh = v.y; // rebased like everything else
             } else { odn = 0; oh = 0; }
-            ob = (!SCORED && c >= 1 && c <= m_eff) ? bp.raw(c - 1) : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
+            ob = (!SCORED && c >= 1 && c <= m_eff) ? bp.raw(c - 1) : 0; // PF: the RAW base -- base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
+            if (!PF && !SCORED) { int b = (c >= 1 && c <= m_eff) ? bp.value(ob, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } ob = b * (BST * 4); }
         };
         auto base_off = [&](int raw, int c) { int b = (c >= 1 && c <= m_eff) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); }; // LDS byte offset of the base's profile plane (c: the column the raw base was loaded for)
         // wait until the block of strip s-1 (the previous block of the grid) has published the row-buffer columns <= cmax;
@@ -189,18 +191,20 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
         if (MULTI && !piped && s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wait_rows(G);
         boundary(l + 1, qdn, qh, qb);
-        qb = base_off(qb, l + 1);
+        if (PF) qb = base_off(qb, l + 1);
 
         // LDS profile (!SCORED): the entries of a step are read ONE STEP AHEAD -- the base a lane needs at step t + 1 is the one its left
         // neighbour has at step t, so the DPP move and the reads for t + 1 are issued before the arithmetic of step t and land while it
         // runs (at the top of their own step they cost the wave an LDS round trip per step; see cl_sweep_kernel).
+        // (PF = the un-windowed fill only: the window re-fills of the fast path are launches of a few ten thousand short waves whose time is
+        // set by how many of them a SIMD holds -- the look-ahead's registers cost them 0.9 ms per headline step, 31.6 -> 32.5 ms)
         int wq[LW], pb_cur = 0;
         auto fetch = [&](int pbv, int *w) {
             const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
 #pragma unroll
             for (int k = 0; k < LW; k++) w[k] = pw[k];
         };
-        if (!SCORED) {
+        if (PF) {
             pb_cur = dpp_shr1(qb, b_out);
             qb = dpp_shl1(qb, qb);
             fetch(pb_cur, wq);
@@ -213,13 +217,17 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
             const int up_h = dpp_shr1(qh, h_out);
             qdn = dpp_shl1(qdn, qdn);
             qh = dpp_shl1(qh, qh);
-            int wn[LW], pb_next = 0;
-            if (!SCORED) {
+            int wn[LW], pb_next = 0, pb = 0;
+            if (PF) {
                 if (take) qb = nqv;
                 pb_next = dpp_shr1(qb, pb_cur);
                 qb = dpp_shl1(qb, qb);
                 fetch(pb_next, wn);
                 asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic (the scheduler would sink them next to their first use)
+            } else if (!SCORED) {
+                pb = dpp_shr1(qb, b_out);
+                qb = dpp_shl1(qb, qb);
+                b_out = pb;
             }
             const int j = t - l;
             if (!CHECK || (j >= 1 && j <= m_eff)) {
@@ -230,10 +238,10 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                                         : smat + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0;
 #pragma unroll
                     for (int k = 0; k < LW; k++) w[k] = pw[k];
-                } else {
+                } else if (PF) {
 #pragma unroll
                     for (int k = 0; k < LW; k++) w[k] = wq[k];
-                }
+                } else fetch(pb, w);
                 int hd = diag0, dnu = up_dn;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 h_out = hold[R - 1];
             }
             if (MULTI) { sq_dn = dpp_shl1(dn_out, sq_dn); sq_h = dpp_shl1(h_out, sq_h); }
-            if (!SCORED) {
+            if (PF) {
 #pragma unroll
                 for (int k = 0; k < LW; k++) wq[k] = wn[k];
                 pb_cur = pb_next;
@@ -289,15 +297,16 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
                 for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{}, false, 0);
             } else if (steady) {
 #pragma unroll
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (PF && u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (PF && u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
             }
             // consume the loads issued at the top of this block BEFORE the stores below are issued (exact wait, nothing newer in flight;
             // left to their first real use -- the DPP moves of the next block -- the wait becomes a vmcnt(0) behind those stores)
-            asm volatile("" :: "v"(ndn), "v"(nh));
+            if (PF) asm volatile("" :: "v"(ndn), "v"(nh));
             qdn = ndn; qh = nh;
+            if (!PF) qb = nb;
             // flush 16 steps of direction bits: word w of this strip
             const int w = t0 >> 4;
             if (gact && w < pl.words) {

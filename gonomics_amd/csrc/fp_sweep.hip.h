@@ -78,7 +78,7 @@ __device__ __forceinline__ int dpp_next8(int src) { // every lane of the two ban
 // (fp_sweep_levels_kernel), a block following the one above it through the row buffer as that one publishes its progress
 // (prog_out / prog_in: the last step whose hand-over stores are out, INT_MAX at the end; rows and progress word are agent-scope
 // atomics like the general path's strips, see rb_store).
-template <int RR, bool XP, int ROLE>
+template <int RR, bool XP, int ROLE, bool PK>
 __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int wblk, const PairPlan *__restrict__ plans, int n_pairs,
                                               const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                               const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
@@ -114,7 +114,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     const int row_base = TAKES ? pl.n - BOT * (below + 1) : 0;                      // rows of the pair above this block
     const int n_loc = ROLE == 1 ? pl.n - BOT * below : (TAKES ? BOT : pl.n);        // rows in this block
     const uint8_t *ap = a_buf + (valid ? a_start[pl.src] + row_base : 0);
-    BetaSrc bp;
+    BetaSrcT<PK ? 1 : 0> bp; // (PK: beta = windows of the packed resident reference)
     bp.init(b_buf, kp, valid ? b_start[pl.src] : 0, valid ? pl.m : 0);
     const int m_eff = valid ? pl.m : 0;
     const int P = G8 * RR - n_loc; // padding slots above row 1
@@ -164,7 +164,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     // before the half block's last step, where the next queue is needed: a load whose value is checked on the spot makes the wave
     // wait for the whole memory round trip (the compiler's s_waitcnt vmcnt(0) sat right behind every global_load_ubyte)
     auto base_raw = [&](int c) { return (c >= 1 && c <= m_eff) ? bp.raw(c - 1) : 0; };
-    auto base_off = [&](int raw, int c) { int b = (c >= 1 && c <= m_eff) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (FP8_BST * 4); };
+    auto base_off = [&](int raw, int c) { int b = (PK && !(c >= 1 && c <= m_eff)) ? 0 : bp.value(raw, c - 1); if (b >= 5) { bad = 1; b = 4; } return b * (FP8_BST * 4); }; // (bytes: raw is 0 outside the window already)
     int qb = base_off(base_raw(lp), lp), nb = 0, nraw = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
 
     const int level = pl.strips - 1 - below; // 0 = top block
@@ -334,14 +334,14 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
 }
 
 // reads of one row block (n <= 8 * RR)
-template <int RR, bool XP = false>
+template <int RR, bool XP = false, bool PK = false>
 __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                       const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                       KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
                                                       unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err) {
     __shared__ int lds[32 + 8 * FP8_PST];
-    fp_sweep_body<RR, XP, 0>(lds, (int)blockIdx.x, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, nullptr, 0, false, nullptr, nullptr);
+    fp_sweep_body<RR, XP, 0, PK>(lds, (int)blockIdx.x, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, nullptr, 0, false, nullptr, nullptr);
 }
 
 // reads of S >= 2 row blocks: the grid holds n_levels levels of W waves, block index = level-major, level level0 + blockIdx.x / W (0 = top).
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict
 //              Level-major order beats wave-major -- the levels of a wave group as grid neighbours, in lockstep -- 51.4 / 54.1 ms.)
 //   piped = 0: one launch per level in turn (n_levels = 1): nothing to wait for (GNX_NO_PIPE, and the fallback after a timeout).
 // RRTOP = slots per lane of the top block (as few as hold the longest read's rows above the full blocks).
-template <int RRTOP, bool XP = false>
+template <int RRTOP, bool XP = false, bool PK = false>
 __global__ __launch_bounds__(64) void fp_sweep_levels_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                              const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                              const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
@@ -370,9 +370,9 @@ __global__ __launch_bounds__(64) void fp_sweep_levels_kernel(const PairPlan *__r
         int *po = prog + (int64_t)level * W + w;
         const int *pi = po - W;
         if (lv != lv_own - n_stolen) __syncthreads(); // the LDS profile of the level before is no longer read
-        if (level == 0) fp_sweep_body<RRTOP, XP, 1>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, nullptr, po);
-        else if (below == 0) fp_sweep_body<2 * FP8_LW, XP, 2>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, 0, piped != 0, pi, nullptr);
-        else fp_sweep_body<2 * FP8_LW, XP, 3>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, pi, po);
+        if (level == 0) fp_sweep_body<RRTOP, XP, 1, PK>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, nullptr, po);
+        else if (below == 0) fp_sweep_body<2 * FP8_LW, XP, 2, PK>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, 0, piped != 0, pi, nullptr);
+        else fp_sweep_body<2 * FP8_LW, XP, 3, PK>(lds, w, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, rowbuf, below, piped != 0, pi, po);
     }
 }
 

@@ -356,7 +356,9 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         if (two) { // S row blocks ("levels"): one launch, each level following the one above it through the row buffer (GNX_NO_PIPE: a launch per level)
             int2 *rb = reinterpret_cast<int2 *>(c.rowbuf.p);
             const int top_rows = (int)(top_hi + G8 - 1) / G8; // slots per lane of the top block: as few as hold the longest read's rows above the full blocks
+            const bool pk = kp.b2 != nullptr; // beta = the packed resident reference (never with xp: AffineGapLocal gets byte windows)
             auto klev = xp ? (top_rows <= 8 ? fp_sweep_levels_kernel<8, true> : (top_rows <= 12 ? fp_sweep_levels_kernel<12, true> : (top_rows <= 16 ? fp_sweep_levels_kernel<16, true> : fp_sweep_levels_kernel<20, true>)))
+                      : pk ? (top_rows <= 8 ? fp_sweep_levels_kernel<8, false, true> : (top_rows <= 12 ? fp_sweep_levels_kernel<12, false, true> : (top_rows <= 16 ? fp_sweep_levels_kernel<16, false, true> : fp_sweep_levels_kernel<20, false, true>)))
                            : (top_rows <= 8 ? fp_sweep_levels_kernel<8> : (top_rows <= 12 ? fp_sweep_levels_kernel<12> : (top_rows <= 16 ? fp_sweep_levels_kernel<16> : fp_sweep_levels_kernel<20>)));
             const int W = (int)grid8.x;
             int *prog = reinterpret_cast<int *>(c.fp_prog.p);
@@ -379,7 +381,9 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
             HIPCHK(hipGetLastError());
             return GNX_OK;
         }
-        auto k = xp ? (rows_per_lane == 19 ? fp_sweep_kernel<19, true> : fp_sweep_kernel<20, true>) : (rows_per_lane == 19 ? fp_sweep_kernel<19, false> : fp_sweep_kernel<20, false>);
+        auto k = xp ? (rows_per_lane == 19 ? fp_sweep_kernel<19, true> : fp_sweep_kernel<20, true>)
+                 : kp.b2 ? (rows_per_lane == 19 ? fp_sweep_kernel<19, false, true> : fp_sweep_kernel<20, false, true>)
+                         : (rows_per_lane == 19 ? fp_sweep_kernel<19, false> : fp_sweep_kernel<20, false>);
         hipLaunchKernelGGL(k, grid8, blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err);
         HIPCHK(hipGetLastError());
         return GNX_OK;

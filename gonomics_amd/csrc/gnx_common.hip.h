@@ -78,22 +78,26 @@ struct KParams {
 // LOAD (the byte, or the dword holding base k), value(raw, k) the arithmetic that turns it into 0 .. 4 (5: a byte >= 5, which the
 // kernels flag like before): the kernels issue the load a block ahead and take the value where they need it.  A window without
 // exceptions (`dirty` false: all but ~0.02 % of the windows of a genome with its N runs) never touches the exception structures.
-struct BetaSrc {
+// MODE 0 / 1: bytes / packed known at compile time (the headline sweep has an instantiation of each: the run-time form costs it the
+// 1.3 % the look-ahead gained, 29.3 -> 29.7 ms per 100 000 pairs); 2: decided per launch (every other kernel).
+template <int MODE>
+struct BetaSrcT {
     const uint8_t *bytes;
     const unsigned *w2;
     const KParams *kp;
     int64_t off; // absolute index of column 1 of this pair's window
     bool dirty;
+    __device__ __forceinline__ bool packed() const { return MODE == 1 || (MODE == 2 && w2 != nullptr); }
     __device__ __forceinline__ void init(const uint8_t *b_buf, const KParams &k, int64_t start, int64_t len) {
         bytes = b_buf; w2 = k.b2; kp = &k; off = start; dirty = false;
-        if (w2 && len > 0) { // exception blocks before block x: rank of the flag word + bits below
+        if (packed() && len > 0) { // exception blocks before block x: rank of the flag word + bits below
             auto rank = [&](int64_t x) { const unsigned long long f = k.bflag[x >> 6]; return (int64_t)k.brank[x >> 6] + __popcll(f & ((1ull << (x & 63)) - 1ull)); };
             dirty = rank(((start + len - 1) >> 6) + 1) > rank(start >> 6);
         }
     }
-    __device__ __forceinline__ int raw(int64_t k) const { return w2 ? (int)w2[(off + k) >> 4] : (int)bytes[off + k]; }
+    __device__ __forceinline__ int raw(int64_t k) const { return packed() ? (int)w2[(off + k) >> 4] : (int)bytes[off + k]; }
     __device__ __forceinline__ int value(int r, int64_t k) const {
-        if (!w2) return r;
+        if (!packed()) return r;
         const int64_t x = off + k;
         int b = (int)(((unsigned)r >> (2 * ((int)x & 15))) & 3u);
         if (dirty) {
@@ -109,6 +113,7 @@ struct BetaSrc {
     }
     __device__ __forceinline__ int at(int64_t k) const { return value(raw(k), k); } // load and use on the spot
 };
+using BetaSrc = BetaSrcT<2>;
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 __device__ __forceinline__ int dpp_shr1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHR1, 0xf, 0xf, false); }
