@@ -65,7 +65,7 @@ def main():
                "note": "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; separate --pmc passes of bench.py --steps 1 --warmup 0"}
     hbm_rows = []
     # (series, path, pmc dir stem, kernel regex, pairs per launch, SQ dir stem, SQ pairs)
-    cases = (("affine", "fast_path", "pmc_fast", r"^fp_sweep_kernel", 100000, "pmc_sq_fast", 32768),
+    cases = (("affine", "fast_path", "pmc_fast", r"^fp_sweep_kernel", 100000, "pmc_sq_fast", 100000),
              ("affine", "general_path", "pmc_general", r"^fill_affine_kernel", 100000, None, 0),
              ("long", "const_long", "pmc_long", r"^cl_sweep_kernel", 1024, "pmc_sq_long", 1024))
     sq_lines = []
@@ -106,6 +106,23 @@ def main():
                         entry["waves_per_simd"] = val["SQ_WAVE_CYCLES"] * 4.0 / (val["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
                     if "SQ_WAIT_INST_LDS" in val and "SQ_WAVE_CYCLES" in val:
                         entry["wait_lds_frac_of_wave_cycles"] = val["SQ_WAIT_INST_LDS"] / val["SQ_WAVE_CYCLES"]
+                    if "SQ_WAIT_ANY" in val and "SQ_WAVE_CYCLES" in val:
+                        entry["wait_any_frac_of_wave_cycles"] = val["SQ_WAIT_ANY"] / val["SQ_WAVE_CYCLES"]
+                # the 2-round launch of the same kernel (32 768 pairs), for the ramp / tail share of a small launch
+                sq2 = {}
+                for d in glob.glob(os.path.join(src, sqstem.replace("pmc_sq_", "pmc_sq32k_") + "*")):
+                    rows = [r for r in pmc_rows(d) if re.search(kre, r["kernel"])]
+                    big = max([r["grid"] for r in rows] or [0])
+                    for r in rows:
+                        if r["grid"] == big:
+                            sq2.setdefault(r["counter"], []).append(r["value"])
+                if sq2:
+                    v2 = {k: sum(v) / len(v) for k, v in sq2.items()}
+                    for k in sorted(v2):
+                        sq_lines.append("%s@32768,%s,%s,%f\n" % (series, tot["kernel"], k, v2[k]))
+                    if "SQ_ACTIVE_INST_VALU" in v2 and "GRBM_GUI_ACTIVE" in v2:
+                        entry["valu_busy_at_32768_pairs"] = v2["SQ_ACTIVE_INST_VALU"] * 4.0 / (v2["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+                        entry["waves_per_simd_at_32768_pairs"] = v2.get("SQ_WAVE_CYCLES", 0) * 4.0 / (v2["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
             traffic.setdefault(series, {})[path] = entry
     with open(os.path.join(prof, rnd + "_pmc_hbm.csv"), "w") as out:
         wr = csv.writer(out)
@@ -114,7 +131,7 @@ def main():
             wr.writerow([r["series"], r["path"], r["kernel"], r["grid"], r["counter"], r["value"]])
     if sq_lines:
         with open(os.path.join(prof, rnd + "_pmc_sq.csv"), "w") as out:
-            out.write("# rocprofv3 --pmc <SQ counters> passes (bench.py --steps 1 --warmup 0; affine: --pairs 32768, long: --pairs 1024), mean over the\n"
+            out.write("# rocprofv3 --pmc <SQ counters> passes (bench.py --steps 1 --warmup 0; affine: the 100 000-pair launch, affine@32768: --pairs 32768, long: --pairs 1024), mean over the\n"
                       "# launches of the kernel; SQ_*_CYCLES / WAIT / ACTIVE are in quad-cycles\nseries,kernel,counter,value\n")
             out.writelines(sq_lines)
     with open(os.path.join(prof, rnd + "_hbm_traffic.json"), "w") as fh:
@@ -122,7 +139,7 @@ def main():
         fh.write("\n")
     for nm, dst in (("bench.json", "_bench.json"), ("bench_long.json", "_bench_long.json"), ("all_series.jsonl", "_all_series.jsonl"), ("host_entry.jsonl", "_host_entry.jsonl"),
                     ("shapes_affine.jsonl", "_shapes_affine.jsonl"), ("shapes_const.jsonl", "_shapes_const.jsonl"), ("shapes_local.jsonl", "_shapes_local.jsonl"), ("gsw_reads.jsonl", "_gsw_reads.jsonl"), ("cabi_n1_n2.jsonl", "_cabi_n1_n2.jsonl"),
-                    ("pytest_gpu.log", "_pytest_gpu.log")):
+                    ("pytest_gpu.log", "_pytest_gpu.log"), ("bench_2ranks_shared_gpu.json", "_bench_2ranks_shared_gpu.json")):
         p = os.path.join(src, nm)
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copyfile(p, os.path.join(prof, rnd + dst))
