@@ -165,7 +165,21 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     // wait for the whole memory round trip (the compiler's s_waitcnt vmcnt(0) sat right behind every global_load_ubyte)
     auto base_raw = [&](int c) { return (c >= 1 && c <= m_eff) ? bp.raw(c - 1) : 0; };
     auto base_off = [&](int raw, int c) { int b = (PK && !(c >= 1 && c <= m_eff)) ? 0 : bp.value(raw, c - 1); if (b >= 5) { bad = 1; b = 4; } return b * (FP8_BST * 4); }; // (bytes: raw is 0 outside the window already)
-    int qb = base_off(base_raw(lp), lp), nb = 0, nraw = 0; // base queue: lane lp holds column t0 + lp of the current 8-step half block
+    // The LDS offsets of the bases travel through a RING in LDS instead of a DPP queue: lane lp converts the base of column t0 + 8 + lp once
+    // per half block and writes it to ring[column & 15]; at step t every lane reads ring[t + 2 - lp], the offset it needs two steps
+    // later (its profile entries are fetched one step ahead of their use, see below).  One ds_read_u16 per step instead of four DPP
+    // moves (queue rotation + hand-down, each twice for the mirrored pair).  16 columns are enough -- the reads of a half block reach back
+    // to column t0 - 5, its write replaces columns t0 - 8 .. t0 - 1 -- and every entry is stored twice, 16 entries apart, so that the
+    // eight reads of a half block are consecutive (immediate offsets, no wrap): 64 bytes, the unused tail of the pair's first
+    // profile plane (8 lanes x 10 dwords of 96).
+    unsigned short *ring = reinterpret_cast<unsigned short *>(prof + G8 * FP8_LW);
+    static_assert(FP8_BST - G8 * FP8_LW >= 16, "the ring lives in the padding of a profile plane");
+    {
+        const int o = base_off(base_raw(lp), lp); // columns 0 .. 7 (column 0 and everything left of it: offset 0, never used by a live cell)
+        ring[lp] = (unsigned short)o; ring[lp + 16] = (unsigned short)o;
+        ring[lp + 8] = 0; ring[lp + 24] = 0;      // columns -8 .. -1
+    }
+    int nraw = 0;
 
     const int level = pl.strips - 1 - below; // 0 = top block
     const int2 *rb_in = (TAKES && valid) ? rowbuf + pl.rowbuf_off + (int64_t)(level - 1) * (pl.m + 1) : nullptr; // [j] = what the block above hands down for column j
@@ -190,16 +204,18 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     // The profile entries of a step are read from LDS ONE STEP AHEAD: the base a lane needs at step t + 1 is the one the previous lane
     // of its pair has at step t, so the DPP moves and the 5 ds_read_b64 for t + 1 are issued before the 19-row chain of step t and land
     // while it runs (issued at the top of their own step, every step began with an LDS round trip in s_waitcnt lgkmcnt).
-    int wq[FP8_LW], pb_cur;
+    int wq[FP8_LW], pb1;
     auto fetch = [&](int pbv, int *w) {
         const int2 *pw = reinterpret_cast<const int2 *>(prof_lane + pbv);
 #pragma unroll
         for (int k = 0; k < FP8_LW / 2; k++) { const int2 v = pw[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
     };
-    pb_cur = dpp_prev8(qb, b_out);
-    qb = dpp_next8(qb);
-    fetch(pb_cur, wq);
-    auto step = [&](const int t, auto chk, const bool ckflag, const bool take, const int nqv) {
+    auto ring_at = [&](int c) { return (int)ring[c & 15]; }; // (prologue only; the steps read with an immediate offset from rp)
+    fetch(ring_at(0 - lp), wq); // step 0
+    pb1 = ring_at(1 - lp);      // step 1
+    const unsigned short *rp = ring; // ring + ((t0 + 2 - lp) & 15) of the current half block
+    // u = the step's index inside its half block (compile time in the steady loop: the ring read gets an immediate offset)
+    auto step = [&](const int t, auto chk, const bool ckflag, const int u) {
         constexpr bool CHECK = decltype(chk)::value; // false: every lane of the wave is inside its matrix (steady state)
         // ckflag (wave-uniform): this half block crosses a checkpoint column
         // The first lane of a pair keeps the DPP `old` value = the row-0 boundary constant.  Passing the previous step's result
@@ -209,11 +225,9 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         up_h = dpp_prev8(TAKES ? rq.y : up_h, h_out);
         if (TAKES) { rq.x = dpp_next8(rq.x); rq.y = dpp_next8(rq.y); }
         if (XP && !TAKES) { up_dn += vInc; up_h += vInc; }
-        if (take) qb = nqv; // (last step of a half block: the queue of the next one takes over)
-        const int pb_next = dpp_prev8(qb, pb_cur);
-        qb = dpp_next8(qb);
         int wn[FP8_LW];
-        fetch(pb_next, wn);
+        fetch(pb1, wn);                    // profile entries of step t + 1
+        const int pb2 = (int)rp[u];        // LDS offset of the base of step t + 2
         asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic (the scheduler would sink them next to their first use)
         const int j = t - lp;
         const int *w = wq;
@@ -268,7 +282,14 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         }
 #pragma unroll
         for (int k = 0; k < FP8_LW; k++) wq[k] = wn[k];
-        pb_cur = pb_next;
+        pb1 = pb2;
+    };
+    // the bases of the NEXT half block (loaded at the top of this one) go into the ring at its sixth step: two steps before lane 0 reads
+    // column t0 + 8, and after every read of the columns they replace
+    auto ring_put = [&](int t0) {
+        const int o = base_off(nraw, t0 + 8 + lp);
+        const int x = ((t0 + 8) & 15) + lp;
+        ring[x] = (unsigned short)o; ring[x + 16] = (unsigned short)o;
     };
 
     // half blocks of 8 steps t0 .. t0+7 (step t: lane lp is at column t - lp); a plane word is two half blocks
@@ -300,10 +321,11 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     auto edge_half_block = [&](int t0) { // head and tail of the sweep: some lanes are outside their matrix
         nraw = base_raw(t0 + 8 + lp); // prefetch the next half block's bases
         if (TAKES) { wait_cols(t0 + 15); rqn = rb_at(t0 + 8 + lp); }
+        rp = ring + ((t0 + 2 - lp) & 15);
 #pragma unroll 1
         for (int u = 0; u < 8; u++) {
-            if (u == 7) nb = base_off(nraw, t0 + 8 + lp);
-            step(t0 + u, std::true_type{}, true, u == 7, nb);
+            if (u == 5) ring_put(t0);
+            step(t0 + u, std::true_type{}, true, u);
         }
         if (TAKES) rq = rqn;
         flush(t0);
@@ -318,10 +340,11 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         nraw = base_raw(t0 + 8 + lp);
         if (TAKES) { wait_cols(t0 + 15); rqn = rb_at(t0 + 8 + lp); }
         const bool ckflag = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
+        rp = ring + ((t0 + 2 - lp) & 15);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            if (u == 7) nb = base_off(nraw, t0 + 8 + lp);
-            step(t0 + u, std::false_type{}, ckflag, u == 7, nb);
+            if (u == 5) ring_put(t0);
+            step(t0 + u, std::false_type{}, ckflag, u);
         }
         if (TAKES) rq = rqn;
         flush(t0);
