@@ -154,7 +154,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         hold[r] = (q >= P) ? kp.o4 + TD : ((XP || q == P - 1) ? 3 : kp.o4 + 2);
         rt[r] = (q >= P) ? kp.o4 + TD + (r == RR - 1 ? vO4L : kp.o4) : (XP ? kp.o4 : kp.o4 + 2);
     }
-    unsigned accR[FP_PLANES] = {0u, 0u, 0u, 0u}; // I-planes of rows n-d = slots RR-1-d of the last lane
+    unsigned accR[FP_PLANES] = {}; // I-planes of rows n-d = slots RR-1-d of the last lane
     unsigned tailw = 0; // argmax tags of h(n-d, m-x), d, x = 0..3, field 4x + d: lets the walk take its first diagonal steps without a window
     int diag0 = (q0 == 0) ? ((XP || P == 0) ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + TD : ((XP || q0 - 1 == P - 1) ? 3 : kp.o4 + 2));
     if (TAKES && q0 == 0) diag0 = kp.o4 + TD; // the slot above is a row of the pair, column 0: h' = D' = o

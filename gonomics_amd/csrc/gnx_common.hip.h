@@ -48,7 +48,10 @@ struct PairPlan {
 
 constexpr int CKW = 128;     // column checkpoint spacing of the fast path
 constexpr int FP_SPAN = 192; // a re-fill window (one row block of <= 160 rows) is at least this wide: the rows + typical indels
-constexpr int FP_PLANES = 4; // rows n .. n-3 keep their I-plane: a trailing gap sits on row n-d when the last d bases match the chunk end
+#ifndef GNX_FP_PLANES
+#define GNX_FP_PLANES 4
+#endif
+constexpr int FP_PLANES = GNX_FP_PLANES; // rows n .. n-3 keep their I-plane: a trailing gap sits on row n-d when the last d bases match the chunk end
 constexpr int FP_CAP = 64;   // CIGAR runs staged per pair and row block on the fast path (more -> general path)
 constexpr int FP_MAXS = 128; // row blocks of 160 rows the fast path sweeps (reads up to 20 480 bases; longer ones: snapshot path)
 constexpr int FP_TILE = 1024;                                  // straggler tiles: columns (c*FP_TILE, (c+1)*FP_TILE]

@@ -623,6 +623,7 @@ class Giraf:
         self.QName, self.QStart, self.QEnd, self.PosStrand = read.Name, 0, 0, True
         self.Path = (0, [], 0)  # (TStart, Nodes, TEnd)
         self.Cigar, self.AlnScore, self.MapQ, self.Seq = None, 0, 255, read.Seq
+        self.Flag = 0  # set by WrapPairGirafBatch only (toGiraf.go:130-140)
 
     def key(self):
         return (self.QStart, self.QEnd, self.PosStrand, self.Path[0], tuple(self.Path[1]), self.Path[2],
@@ -697,3 +698,40 @@ def GswBatchToGiraf(gg, reads, index, seedLen, scoreMatrix, device_seeds=True, o
             for k, o in zip(ks, outs):
                 advance(k, o, False)
     return results
+
+
+def getGirafFlags(ag):
+    """toGiraf.go:183-192 (uint8)"""
+    return (4 if ag.PosStrand else 0) + (2 if ag.AlnScore < 1200 else 0)
+
+
+def isProperPairAlign(fwd, rev):
+    """toGiraf.go:171-181"""
+    if abs(float(fwd.Path[0] - rev.Path[0])) < 10000:
+        if fwd.Path[0] < rev.Path[0] and fwd.PosStrand and not rev.PosStrand:
+            return True
+        if fwd.Path[0] > rev.Path[0] and not fwd.PosStrand and rev.PosStrand:
+            return True
+    return False
+
+
+def WrapPairGirafBatch(gg, pairs, index, seedLen, scoreMatrix, device_seeds=True, on_panic="raise"):
+    """WrapPairGiraf (toGiraf.go:117-128) for a batch of read pairs [(fwd FastqBig, rev FastqBig)]: both mates of every pair go through
+    ONE GswBatchToGiraf call (2 x len(pairs) reads: the same seed search and DP rounds), then setGirafFlags (toGiraf.go:130-140) as
+    written -- the forward mate gets +8 and +16 TWICE, the reverse mate no pairing flag at all, arithmetic in uint8."""
+    flat = [r for pr in pairs for r in pr]
+    res = GswBatchToGiraf(gg, flat, index, seedLen, scoreMatrix, device_seeds=device_seeds, on_panic=on_panic)
+    out = []
+    for k in range(len(pairs)):
+        fwd, rev = res[2 * k], res[2 * k + 1]
+        if isinstance(fwd, GoPanic) or isinstance(rev, GoPanic):
+            out.append((fwd, rev))
+            continue
+        fwd.Flag = getGirafFlags(fwd)
+        rev.Flag = getGirafFlags(rev)
+        fwd.Flag = (fwd.Flag + 8 + 16 + 16) & 0xff
+        if isProperPairAlign(fwd, rev):
+            fwd.Flag = (fwd.Flag + 1) & 0xff
+            rev.Flag = (rev.Flag + 1) & 0xff
+        out.append((fwd, rev))
+    return out

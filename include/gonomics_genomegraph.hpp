@@ -533,6 +533,7 @@ struct Giraf { // giraf.Giraf, the fields the function fills (giraf/giraf.go:16-
     int64_t AlnScore = 0;
     int MapQ = 255;
     const Bases *Seq = nullptr;
+    uint8_t Flag = 0;      // set by WrapPairGirafBatch only (toGiraf.go:130-140)
     bool Panicked = false; // GswBatchToGiraf(.., markPanics = true): the Go code panics on this read (see GoPanic); the other fields are void
     std::string PanicText;
 };
@@ -705,6 +706,32 @@ inline std::vector<Giraf> GswBatchToGiraf(const GenomeGraph &g, std::vector<Fast
     std::vector<Giraf> out;
     for (auto &t : tasks) out.push_back(std::move(t->best));
     return out;
+}
+
+// WrapPairGiraf (toGiraf.go:117-128) for a batch of read pairs -- reads[2k] / reads[2k+1] are the forward / reverse mate of pair k: both
+// mates of every pair go through ONE GswBatchToGiraf call, then setGirafFlags (toGiraf.go:130-140) as written: the forward mate gets
+// +8 and +16 twice, the reverse mate no pairing flag, arithmetic in uint8; getGirafFlags :183-192, isProperPairAlign :171-181.
+inline uint8_t getGirafFlags(const Giraf &ag) { return (uint8_t)((ag.PosStrand ? 4 : 0) + (ag.AlnScore < 1200 ? 2 : 0)); }
+inline bool isProperPairAlign(const Giraf &fwd, const Giraf &rev) {
+    const double d = (double)(fwd.TStart - rev.TStart);
+    if ((d < 0 ? -d : d) < 10000) {
+        if (fwd.TStart < rev.TStart && fwd.PosStrand && !rev.PosStrand) return true;
+        if (fwd.TStart > rev.TStart && !fwd.PosStrand && rev.PosStrand) return true;
+    }
+    return false;
+}
+inline std::vector<Giraf> WrapPairGirafBatch(const GenomeGraph &g, std::vector<FastqBig> &reads, const SeedIndex &index, const int64_t *scores25,
+                                             int64_t gapPen = -600, int *outRounds = nullptr, bool markPanics = false) {
+    std::vector<Giraf> res = GswBatchToGiraf(g, reads, index, scores25, gapPen, outRounds, markPanics);
+    for (size_t k = 0; k + 1 < res.size(); k += 2) {
+        Giraf &fwd = res[k], &rev = res[k + 1];
+        if (fwd.Panicked || rev.Panicked) continue;
+        fwd.Flag = getGirafFlags(fwd);
+        rev.Flag = getGirafFlags(rev);
+        fwd.Flag = (uint8_t)(fwd.Flag + 8); fwd.Flag = (uint8_t)(fwd.Flag + 16); fwd.Flag = (uint8_t)(fwd.Flag + 16);
+        if (isProperPairAlign(fwd, rev)) { fwd.Flag = (uint8_t)(fwd.Flag + 1); rev.Flag = (uint8_t)(rev.Flag + 1); }
+    }
+    return res;
 }
 
 } // namespace genomeGraph

@@ -41,7 +41,9 @@ int main(int argc, char **argv) {
         SeedIndex index(g, seedLen, seedStep);
         auto t1 = std::chrono::steady_clock::now();
         int rounds = 0;
-        auto res = GswBatchToGiraf(g, reads, index, sc, -600, &rounds, /*markPanics=*/true);
+        const bool paired = argc > 3 && std::string(argv[3]) == "pairs"; // reads 2k / 2k+1 = the mates of pair k (WrapPairGiraf)
+        auto res = paired ? WrapPairGirafBatch(g, reads, index, sc, -600, &rounds, /*markPanics=*/true)
+                          : GswBatchToGiraf(g, reads, index, sc, -600, &rounds, /*markPanics=*/true);
         auto t2 = std::chrono::steady_clock::now();
         std::ofstream out(argv[2]);
         for (const Giraf &r : res) {
@@ -51,7 +53,9 @@ int main(int argc, char **argv) {
             out << " |";
             if (!r.hasCigar) out << " none";
             for (const Cigar &c : r.Cig) out << ' ' << c.RunLength << ' ' << (int)c.Op;
-            out << " | " << (r.Seq == nullptr ? -1 : (long)r.Seq->size()) << '\n';
+            out << " | " << (r.Seq == nullptr ? -1 : (long)r.Seq->size());
+            if (paired) out << " | " << (int)r.Flag;
+            out << '\n';
         }
         out << "# " << std::chrono::duration<double, std::milli>(t1 - t0).count() << ' ' << std::chrono::duration<double, std::milli>(t2 - t1).count() << ' ' << rounds << '\n';
     } catch (const std::exception &e) {

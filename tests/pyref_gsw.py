@@ -362,3 +362,30 @@ def read_to_giraf(nodes, rd, seeds, scores):
 def giraf_key(g):
     return (g["QStart"], g["QEnd"], g["PosStrand"], g["Path"][0], tuple(g["Path"][1]), g["Path"][2],
             None if g["Cigar"] is None else tuple(g["Cigar"]), g["AlnScore"], bytes(np.asarray(g["Seq"], dtype=np.uint8)))
+
+
+def wrap_pair(nodes, rd_fwd, rd_rev, seeds_fwd, seeds_rev, scores):
+    """WrapPairGiraf + setGirafFlags (toGiraf.go:117-140), restated from the Go text: flags are uint8; Fwd gets 8, 16 and 16 again."""
+    f = read_to_giraf(nodes, rd_fwd, seeds_fwd, scores)
+    r = read_to_giraf(nodes, rd_rev, seeds_rev, scores)
+    def flags(g):
+        a = 0
+        if g["PosStrand"]:
+            a += 4
+        if g["AlnScore"] < 1200:
+            a += 2
+        return a
+    ff, rf = flags(f), flags(r)
+    ff += 8
+    ff += 16
+    ff += 16
+    proper = False
+    if abs(float(f["Path"][0] - r["Path"][0])) < 10000:
+        if f["Path"][0] < r["Path"][0] and f["PosStrand"] and not r["PosStrand"]:
+            proper = True
+        if f["Path"][0] > r["Path"][0] and (not f["PosStrand"]) and r["PosStrand"]:
+            proper = True
+    if proper:
+        ff += 1
+        rf += 1
+    return f, r, ff % 256, rf % 256

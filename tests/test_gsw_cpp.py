@@ -51,10 +51,11 @@ def read_out(path):
         if line.strip() == "panic":
             rows.append("panic")
             continue
-        head, nodes, cig, seqlen = [x.strip() for x in line.split("|")]
+        parts = [x.strip() for x in line.split("|")]
+        head, nodes, cig, seqlen = parts[:4]
         h = [int(x) for x in head.split()]
         c = None if cig == "none" else tuple((int(a), int(b)) for a, b in zip(cig.split()[0::2], cig.split()[1::2]))
-        rows.append((h[0], h[1], bool(h[2]), h[3], tuple(int(x) for x in nodes.split()), h[4], c, h[5], int(seqlen)))
+        rows.append((h[0], h[1], bool(h[2]), h[3], tuple(int(x) for x in nodes.split()), h[4], c, h[5], int(seqlen)) + ((int(parts[4]),) if len(parts) > 4 else ()))
     return rows, timing
 
 
@@ -95,3 +96,22 @@ def test_cpp_gsw_mirror_equals_python_mirror(gpu_lib, tmp_path, kind, seed_len, 
         assert rows[k] == key[:8] + (len(key[8]),), "read %d" % k
         assert key == exp, "read %d" % k
     assert (panics > 0) == (kind == "snp")  # bubbles of 1 .. 5 bases are what the reference cannot extend across; long alleles are fine
+
+
+@pytest.mark.gpu
+def test_cpp_wrap_pair_giraf_equals_python_mirror(gpu_lib, tmp_path):
+    """WrapPairGirafBatch of the C++ mirror == the Python mirror (both against the restatement in test_gsw_reads.py)"""
+    _build()
+    seqs, edges, reads = make_case(11, "wide")
+    sc = MX["HumanChimpTwo"]
+    write_case(str(tmp_path / "case.txt"), seqs, edges, reads, 16, 1, sc)
+    assert subprocess.call([BIN, str(tmp_path / "case.txt"), str(tmp_path / "out.txt"), "pairs"]) == 0
+    rows, _ = read_out(str(tmp_path / "out.txt"))
+    g = build(seqs, edges)
+    index = gg.SeedIndex(g.Nodes, 16, 1)
+    pairs = [(gg.FastqBig("a", reads[2 * k]), gg.FastqBig("b", reads[2 * k + 1])) for k in range(len(reads) // 2)]
+    py = gg.WrapPairGirafBatch(g, pairs, index, 16, sc)
+    for k, (fw, rv) in enumerate(py):
+        for r, row in ((fw, rows[2 * k]), (rv, rows[2 * k + 1])):
+            key = r.key()
+            assert row == key[:8] + (len(key[8]), r.Flag), "pair %d" % k

@@ -175,3 +175,27 @@ def test_reads_to_giraf(gpu_lib, kind):
     if panics:  # default behaviour: what the Go process does
         with pytest.raises(gg.GoPanic):
             gg.GswBatchToGiraf(g, bigs, index, seed_len, sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["linear", "wide"])
+def test_wrap_pair_giraf(gpu_lib, kind):
+    """WrapPairGiraf for a batch of read pairs (the paired reads of config C3 go through it, toGiraf.go:117-140): both mates in one batched
+    call, flags as the Go code sets them (Fwd: +8 +16 +16, Rev: nothing; uint8), against the sequential restatement"""
+    seqs, edges, reads = make_case(11, kind)
+    g = build(seqs, edges)
+    nodes = ref.make_graph(seqs, edges)
+    sc = MX["HumanChimpTwo"]
+    seed_len = 16
+    index = gg.SeedIndex(g.Nodes, seed_len, 1)
+    full = ref.index_genome(nodes, seed_len, 1)
+    pairs = [(gg.FastqBig("p%d/1" % k, reads[2 * k]), gg.FastqBig("p%d/2" % k, reads[2 * k + 1])) for k in range(len(reads) // 2)]
+    got = gg.WrapPairGirafBatch(g, pairs, index, seed_len, sc)
+    flags_seen = set()
+    for k, (fw, rv) in enumerate(got):
+        r1, r2 = ref.make_read(reads[2 * k]), ref.make_read(reads[2 * k + 1])
+        ef, er, ff, rf = ref.wrap_pair(nodes, r1, r2, ref.seed_map(full, nodes, r1, seed_len), ref.seed_map(full, nodes, r2, seed_len), sc)
+        assert fw.key() == ref.giraf_key(ef) and rv.key() == ref.giraf_key(er), "pair %d" % k
+        assert (fw.Flag, rv.Flag) == (ff, rf), "pair %d" % k
+        flags_seen.add((ff, rf))
+    assert len(flags_seen) >= 2
