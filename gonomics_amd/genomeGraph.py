@@ -425,9 +425,16 @@ def heapSortSeeds(a):
         heapify(a, size, 0)
 
 
+# census of the situations in which the parity contract has a declared deviation (tools/bench_gsw.py reports it): reads whose seed list
+# goes through Go's unstable sort.Slice, traversals that branch (where Go's shared backing arrays can alias), reads Go panics on
+STATS = {"reads_with_more_than_100_seeds": 0, "seed_lists": 0, "branching_left_traversals": 0, "branching_right_traversals": 0}
+
+
 def sort_seeds(seeds):
     """seedMapMemPool's tail (search.go:583-589); see the parity contract for > 100 seeds"""
+    STATS["seed_lists"] += 1
     if len(seeds) > 100:
+        STATS["reads_with_more_than_100_seeds"] += 1
         seeds.sort(key=lambda s: -s.TotalLength)  # Python's sort is stable: ties stay in order of discovery
     else:
         heapSortSeeds(seeds)
@@ -553,6 +560,8 @@ def _left_traversal(n, seq, refEnd, currentPath, extension, read, route):
         return aln, score, refEnd - len(sSeq) - len(seq) + tStart, qStart, sPath
     best = None
     leftScore = -(1 << 63)
+    if len(n.Prev) > 1:
+        STATS["branching_left_traversals"] += 1
     for e in n.Prev:
         route, cs, ts, qs, cpath = yield from _left_traversal(e.Dest, sSeq, len(e.Dest.Seq), sPath, extension, read, route)
         if cs > leftScore:
@@ -573,6 +582,8 @@ def _right_traversal(n, seq, start, currentPath, extension, read, route):
         return aln, score, tEnd + start, qEnd, sPath
     best = None
     rightScore = -(1 << 63)
+    if len(n.Next) > 1:
+        STATS["branching_right_traversals"] += 1
     for e in n.Next:
         route, cs, te, qe, cpath = yield from _right_traversal(e.Dest, sSeq, 0, sPath, extension, read, route)
         if cs > rightScore:

@@ -74,6 +74,53 @@ def main():
             print(json.dumps({"series": "GswBatchToGiraf through the C++ mirror: %s reads, same graph" % name, "mapped": int(sum(r[7] > 0 for r in rows)),
                               "index_ms": timing[0], "seeds_traversals_dps_ms": timing[1], "dp_rounds": int(timing[2]), "reads_per_s": len(batch) / (timing[1] / 1e3),
                               "equals_python_mirror": same}), flush=True)
+    census(rng)
+
+
+def census(rng):
+    """how often do the declared deviations of the parity contract come into play?  A variation graph in
+    the style of config C3's gsw workload: a 600 kb backbone cut at a variant every ~1 kb (70 % SNPs: two alleles of 1 base; 30 %
+    indels: alleles of 1 .. 6 bases), 3000 reads of 150 bases sampled from random haplotypes with 1 % substitutions."""
+    for k in gg.STATS:
+        gg.STATS[k] = 0
+    g = gg.GenomeGraph()
+    prev, paths = None, []
+    hap_nodes = []
+    nid = 0
+    pos = 0
+    while pos < 600000:
+        ln = int(rng.integers(600, 1400))
+        node = gg.Node(nid, rng.integers(0, 4, size=ln).astype(np.uint8)); gg.AddNode(g, node); nid += 1
+        if prev is not None:
+            for u in prev:
+                gg.AddEdge(u, node)
+        hap_nodes.append([node])
+        pos += ln
+        snp = rng.random() < 0.7
+        a1 = gg.Node(nid, rng.integers(0, 4, size=1 if snp else int(rng.integers(1, 7))).astype(np.uint8)); gg.AddNode(g, a1); nid += 1
+        a2 = gg.Node(nid, rng.integers(0, 4, size=1 if snp else int(rng.integers(1, 7))).astype(np.uint8)); gg.AddNode(g, a2); nid += 1
+        gg.AddEdge(node, a1); gg.AddEdge(node, a2)
+        hap_nodes.append([a1, a2])
+        prev = [a1, a2]
+    seed_len, step = 32, 32
+    index = gg.SeedIndex(g.Nodes, seed_len, step)
+    reads = []
+    for _ in range(3000):
+        k0 = int(rng.integers(0, len(hap_nodes) - 8))
+        hap = np.concatenate([c[int(rng.integers(0, len(c)))].Seq for c in hap_nodes[k0:k0 + 8]])
+        o = int(rng.integers(0, hap.shape[0] - 160))
+        r = hap[o:o + 150].copy()
+        r[rng.random(150) < 0.01] = rng.integers(0, 4)
+        reads.append(gg.FastqBig("r", r if rng.random() < 0.5 else (3 - r[::-1]).astype(np.uint8)))
+    t0 = time.perf_counter()
+    out = gg.GswBatchToGiraf(g, reads, index, seed_len, align.HumanChimpTwoScoreMatrix, on_panic="mark")
+    dt = time.perf_counter() - t0
+    panics = sum(isinstance(o, gg.GoPanic) for o in out)
+    print(json.dumps({"series": "census of the parity contract's declared deviations: 3000 reads of 150 bases on a 600 kb variation graph (a variant every ~1 kb)",
+                      "reads": len(reads), "nodes": len(g.Nodes), "reads_the_go_code_panics_on": int(panics),
+                      "mapped": int(sum((not isinstance(o, gg.GoPanic)) and o.AlnScore > 0 for o in out)), **gg.STATS, "host_call_s": dt,
+                      "reading": "reads_with_more_than_100_seeds: order among equal TotalLength undefined without a Go toolchain (sort.Slice); branching traversals: "
+                                 "where Go's shared backing arrays can alias an earlier sibling's route; panics: getLeftTargetBases with a short Prev node (search.go:139)"}), flush=True)
 
 
 if __name__ == "__main__":
