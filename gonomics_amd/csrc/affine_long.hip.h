@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    BetaSrc bp;
+    BetaBytes bp;
     bp.init(b_buf, kp, valid ? b_start[p] : 0, valid ? pl.m : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4, RB = kp.e4;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    BetaSrc bp;
+    BetaBytes bp;
     bp.init(b_buf, kp, valid ? b_start[p] : 0, valid ? pl.m : 0);
     const int64_t rb_pitch = (int64_t)pl.m + 1;
     const int po = pl.src;

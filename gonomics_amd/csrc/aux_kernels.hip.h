@@ -151,4 +151,17 @@ __global__ __launch_bounds__(256) void reverse_runs_kernel(const PairPlan *__res
     for (int64_t x = threadIdx.x; x < cnt; x += blockDim.x) ops[base + (cnt - 1 - x)] = scr[sb + x];
 }
 
+// windows of the packed reference back to bytes: for the kernels of the general and the snapshot paths (run_device), for
+// AffineGapLocal on the resident reference (its fast path reads the long sequence as the kernels' alpha) and, with GNX_REF_UNPACK=1,
+// for every call (the A/B of the packed reads)
+__global__ __launch_bounds__(256) void unpack_windows_kernel(KParams kp, const int64_t *__restrict__ start, const int64_t *__restrict__ out_off, int n_pairs,
+                                                             uint8_t *__restrict__ out) {
+    const int p = blockIdx.x; // one workgroup per window
+    if (p >= n_pairs) return;
+    const int64_t len = out_off[p + 1] - out_off[p];
+    BetaSrc b;
+    b.init(nullptr, kp, start[p], len);
+    for (int64_t k = threadIdx.x; k < len; k += blockDim.x) out[out_off[p] + k] = (uint8_t)b.at(k);
+}
+
 } // namespace

@@ -85,7 +85,7 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    BetaSrc bp;
+    BetaBytes bp;
     bp.init(b_buf, kp, valid ? b_start[p] : 0, valid ? pl.m : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     int bad = 0;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
-    BetaSrc bp;
+    BetaBytes bp;
     bp.init(b_buf, kp, valid ? b_start[p] : 0, valid ? pl.m : 0);
     const int64_t rb_pitch = (int64_t)pl.m + 1;
     const int po = pl.src;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     const int row_base = WIN ? (int)pl.s_off : 0;                          // rows of the pair above this window
     const int ck_pitch = (WIN && pl.s_pitch) ? (int)pl.s_pitch : pl.n;    // rows of the whole pair
     const uint8_t *ap = SCORED ? nullptr : a_buf + (valid ? a_start[pl.src] + row_base : 0);
-    BetaSrc bp; // (SCORED: unused)
+    BetaSrcT<WIN ? 2 : 0> bp; // (SCORED: unused; WIN: re-fills of the fast path, whose beta may be windows of the packed resident reference)
     bp.init(b_buf, kp, (valid && !SCORED) ? b_start[pl.src] + (WIN ? pl.col_off : 0) : 0, (valid && !SCORED) ? pl.m : 0);
     const int Tend = (m_max + 15 + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4;

@@ -115,7 +115,7 @@ struct Ctx {
     PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
     // the resident reference, PACKED (gnx_host.hip.h: pack_reference): `ref` = 2 bits per base, ref_flag / ref_rank / ref_exc = the
     // sparse list of bases that are not A C G T (KParams::b2 / bflag / brank / bexc)
-    DevBuf ref_flag, ref_rank, ref_exc;
+    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off;
     int64_t ref_len = -1;  // >= 0: a reference of that many bases is resident
     int64_t ref_nexc = 0;  // 64-base blocks with an exception
     int64_t ref_epoch = 0; // which gnx_set_reference call filled it (contexts created later are brought up to date on first use)
@@ -895,6 +895,22 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             if (fp && rc != -1) return rc;
         }
     }
+    // ---- everything below reads beta as bytes (BetaBytes): windows of the packed resident reference are unpacked first.  What gets
+    // here with a packed reference is what the fast path does not take -- windows of fewer than 768 columns, gapOpen > 0, the constant
+    // gap functions, the few pairs whose CIGAR overflowed the fast path's staging area ----
+    if (kp.b2) {
+        std::vector<int64_t> uoff((size_t)n_pairs + 1, 0);
+        for (int64_t p = 0; p < n_pairs; p++) uoff[(size_t)p + 1] = uoff[(size_t)p] + h_blen[p];
+        if ((rc = c.unpk_b.ensure((size_t)uoff[(size_t)n_pairs] + 64))) return rc;
+        if ((rc = c.unpk_off.ensure((size_t)(n_pairs + 1) * 8))) return rc;
+        HIPCHK(hipMemcpyAsync(c.unpk_off.p, uoff.data(), (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream)); // (uoff is pageable)
+        hipLaunchKernelGGL(unpack_windows_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, kp, d_bs, reinterpret_cast<const int64_t *>(c.unpk_off.p), (int)n_pairs,
+                           reinterpret_cast<uint8_t *>(c.unpk_b.p));
+        HIPCHK(hipGetLastError());
+        d_b = reinterpret_cast<const uint8_t *>(c.unpk_b.p); d_bs = reinterpret_cast<const int64_t *>(c.unpk_off.p);
+        kp.b2 = nullptr; kp.bflag = nullptr; kp.brank = nullptr; kp.bexc = nullptr;
+    }
     // ---- constant gap without a stored direction matrix (const_long.hip.h): pairs of more than one strip; GNX_CLONG=0 / 2 = never / always ----
     if (!gsw && !d_smat && !local && (!affine || (prm->gap_open <= 0 && !getenv("GNX_NO_HFORM")))) { // (GNX_CLONG also governs the affine form, affine_long.hip.h)
         const char *cl = getenv("GNX_CLONG");
@@ -1399,7 +1415,7 @@ void gnx_shutdown(void) {
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,
-                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
+                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
                           &c.sd_tmp[0], &c.sd_tmp[1], &c.sd_tmp[2], &c.sd_tmp[3], &c.sd_tmp[4], &c.sd_tmp[5], &c.sd_tmp[6], &c.sd_tmp[7]};
         for (DevBuf *b : bufs) b->release();
         PinBuf *pins[] = {&c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};

@@ -117,6 +117,10 @@ struct BetaSrcT {
     __device__ __forceinline__ int at(int64_t k) const { return value(raw(k), k); } // load and use on the spot
 };
 using BetaSrc = BetaSrcT<2>;
+// The kernels of the general and the snapshot paths read beta as bytes only: with both forms compiled into their unrolled steps the
+// register allocator gives up (fill_affine_kernel 152 -> 512 registers + scratch, one wave per SIMD; fill_const_kernel 113 -> 256);
+// run_device unpacks the windows of a packed reference before it launches them.
+using BetaBytes = BetaSrcT<0>;
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 __device__ __forceinline__ int dpp_shr1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_ROW_SHR1, 0xf, 0xf, false); }

@@ -176,18 +176,6 @@ __global__ __launch_bounds__(256) void pack_exc_kernel(const uint8_t *__restrict
     const int64_t e = (int64_t)rank[gblk >> 6] + __popcll(f & ((1ull << (gblk & 63)) - 1ull));
     exc[2 * e] = nm; exc[2 * e + 1] = bm;
 }
-// windows of the packed reference back to bytes (AffineGapLocal on the resident reference: its fast path reads the long sequence as
-// the kernels' alpha, which is read as bytes; GNX_REF_UNPACK=1 forces this for every mode: the A/B of the packed reads)
-__global__ __launch_bounds__(256) void unpack_windows_kernel(KParams kp, const int64_t *__restrict__ start, const int64_t *__restrict__ out_off, int n_pairs,
-                                                             uint8_t *__restrict__ out) {
-    const int p = blockIdx.x; // one workgroup per window
-    if (p >= n_pairs) return;
-    const int64_t len = out_off[p + 1] - out_off[p];
-    BetaSrc b;
-    b.init(nullptr, kp, start[p], len);
-    for (int64_t k = threadIdx.x; k < len; k += blockDim.x) out[out_off[p] + k] = (uint8_t)b.at(k);
-}
-
 int64_t g_ref_epoch = 0;
 int ensure_reference(int nc);
 // ref != nullptr: host bytes; else the synthetic reference of SURVEY 8d (generated chunk by chunk on the device)

@@ -1,0 +1,80 @@
+"""Register / scratch budgets of the wavefront kernels, read from the gfx950 code object inside the built library (CPU suite: no GPU
+needed).  The kernels are paced by waves per SIMD; a change that silently pushes one over its budget (round 3: a run-time choice
+between two beta encodings inside the unrolled steps took fill_affine_kernel from 152 to 512 registers plus scratch, one wave per
+SIMD, 1.8x slower) shows up here instead of in a profile several commits later."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernels(tmp_path):
+    import __graft_entry__ as g
+    g.build()
+    lib = os.path.join(ROOT, "gonomics_amd", "libgonomics_align_hip.so")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib])
+    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+    notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    out = {}
+    for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+        blk = ".agpr_count:" + blk
+        f = {k: v for k, v in re.findall(r"\.(\w+):\s+(\S+)", blk)}
+        if "name" not in f or ".kd" in f["name"]:
+            continue
+        out[f["name"]] = {k: int(f[k]) for k in ("agpr_count", "vgpr_count", "private_segment_fixed_size", "group_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count")}
+    names = sorted(out)
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout.split("\n")
+    res = {}
+    for n, d in zip(names, dem):
+        d = re.sub(r"\(.*", "", d.replace("(anonymous namespace)::", "")).replace("void ", "")
+        res[d] = out[n]
+    return res
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not os.path.exists(f"{LLVM}/llvm-readelf"):
+        pytest.skip("no llvm-readelf")
+    return _kernels(tmp_path_factory.mktemp("co"))
+
+
+def _waves_per_simd(k):
+    regs = k["vgpr_count"] + k["agpr_count"]            # unified register file of 512 per SIMD lane, granule 8
+    return min(8, 512 // max(8, (regs + 7) // 8 * 8))
+
+
+# kernel (prefix of the demangled name) -> waves per SIMD its register count must allow
+BUDGET = [
+    ("fp_sweep_kernel<19, false", 3), ("fp_sweep_kernel<20, false", 3), ("fp_sweep_kernel<19, true", 2), ("fp_sweep_levels_kernel", 2),
+    ("fill_affine_kernel<false, false", 3), ("fill_affine_kernel<true, false", 3), ("fill_affine_kernel<false, true", 2), ("fill_affine_kernel<true, true", 2),
+    ("fill_const_kernel<false, 0", 3), ("fill_const_kernel<false, 1", 3), ("fill_const_kernel<false, 2", 3), ("fill_const_kernel<true", 2),
+    ("cl_sweep_kernel<true>", 5), ("cl_sweep_flat_kernel<true>", 4), ("cl_sweep_kernel<false>", 3), ("al_sweep_kernel", 3),
+    ("fp_walk_kernel", 6), ("traceback_kernel", 4), ("gsw_traceback_kernel", 8),
+]
+# kernels that are allowed scratch (register-bound by design: their tiles live in LDS at one workgroup of 4 pairs per half CU)
+SCRATCH_OK = ("al_walk_kernel",)
+
+
+def test_every_wavefront_kernel_is_in_the_library(kernels):
+    for prefix, _ in BUDGET:
+        assert any(k.startswith(prefix) for k in kernels), prefix
+
+
+def test_register_budgets(kernels):
+    bad = []
+    for prefix, waves in BUDGET:
+        for name, k in kernels.items():
+            if name.startswith(prefix) and _waves_per_simd(k) < waves:
+                bad.append((name, k["vgpr_count"], k["agpr_count"], _waves_per_simd(k), waves))
+    assert not bad, bad
+
+
+def test_no_scratch_outside_the_declared_kernels(kernels):
+    bad = [(n, k["private_segment_fixed_size"], k["vgpr_spill_count"]) for n, k in kernels.items()
+           if (k["private_segment_fixed_size"] or k["vgpr_spill_count"]) and not n.startswith(SCRATCH_OK) and "rocprim" not in n and "hipcub" not in n]
+    assert not bad, bad
