@@ -31,13 +31,13 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
                                                       KParams kp, int2 *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
                                                       int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
     using PC = ProfCfg<P16>;
-    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
     constexpr int TI = 2, TD = 1;
-    __shared__ int lds[32 + 4 * PST];
+    __shared__ int lds[32 + PTOT];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.e4; // rebased diagonal move: 4*(s - 2e)
-    int *prof = &lds[32 + g * PST];
+    int *prof = &lds[32 + PC::pair_off(g)];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
     const bool piped = strip_map != nullptr;
     // piped: this workgroup runs strip strip_map[blockIdx].y of its group -- and first every strip above it that nobody has claimed yet
@@ -237,16 +237,16 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
                                                      const int *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                      const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err) {
     using PC = ProfCfg<P16>;
-    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
     constexpr int TI = 2, TD = 1;
-    __shared__ int lds[32 + 4 * PST + 4 * AL_DIRG + 4 * H];
+    __shared__ int lds[32 + PTOT + 4 * AL_DIRG + 4 * H];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.e4;
-    int *prof = &lds[32 + g * PST];
+    int *prof = &lds[32 + PC::pair_off(g)];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
-    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + 4 * PST + g * AL_DIRG]);
-    int *hcolT = &lds[32 + 4 * PST + 4 * AL_DIRG + g * H]; // keys h(i, m) of the strip's rows whose lanes have passed column m
+    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + PTOT + g * AL_DIRG]);
+    int *hcolT = &lds[32 + PTOT + 4 * AL_DIRG + g * H]; // keys h(i, m) of the strip's rows whose lanes have passed column m
     const int p = blockIdx.x * 4 + g;
     const bool valid = p < n_pairs;
     PairPlan pl;

@@ -69,6 +69,48 @@ __global__ __launch_bounds__(256) void score_matrix_kernel(const ScorePair *__re
     }
 }
 
+// The pairwise case (AffineGapChunk: cell (i, j) = sum over the chunk's positions of scores[alpha][beta]) for chunk sizes 1 .. 4, which is
+// what the callers use: a thread keeps the bases of its four rows in registers and walks the columns (the general kernel above
+// re-reads them, with 64-bit index arithmetic, for every cell: 6 ms for 4096 pairs of 160 x 3000 chunks, more than the fill).
+// block = 64 x 4 threads: x = groups of four rows, y = 4 columns; a block walks the columns blockIdx.x * 4 + y, + 4 * gridDim.x, ...
+template <bool S16, int CH>
+__global__ __launch_bounds__(256) void score_matrix_pairs_kernel(const ScorePair *__restrict__ sp, const uint8_t *__restrict__ bases, KParams kp, int bias4,
+                                                                 int *__restrict__ smat, int *__restrict__ err) {
+    __shared__ int sc[32];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid < 25) sc[tid] = kp.sc4[tid]; // 4 * score
+    __syncthreads();
+    const ScorePair q = sp[blockIdx.y];
+    const uint8_t *ap = bases + q.a_off, *bq = bases + q.b_off;
+    int bad = 0;
+    for (int i0 = threadIdx.x * 4; i0 < q.nc; i0 += 256) {
+        int a5[4][CH];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                int a = (i0 + r < q.nc) ? ap[(i0 + r) * CH + k] : 0; // (rows nc .. of the last group of four lie inside the pitch and are never read)
+                if (a >= 5) { bad = 1; a = 0; }
+                a5[r][k] = a * 5;
+            }
+        }
+        for (int j = blockIdx.x * 4 + threadIdx.y; j < q.mc; j += gridDim.x * 4) {
+            int out[4] = {bias4, bias4, bias4, bias4};
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                int b = bq[j * CH + k];
+                if (b >= 5) { bad = 1; b = 0; }
+#pragma unroll
+                for (int r = 0; r < 4; r++) out[r] += sc[a5[r][k] + b];
+            }
+            const int64_t at = q.s_off + (int64_t)j * q.s_pitch + i0;
+            if (S16) *reinterpret_cast<uint2 *>(reinterpret_cast<short *>(smat) + at) = make_uint2((unsigned)(out[0] & 0xffff) | ((unsigned)out[1] << 16), (unsigned)(out[2] & 0xffff) | ((unsigned)out[3] << 16));
+            else *reinterpret_cast<int4 *>(smat + at) = make_int4(out[0], out[1], out[2], out[3]);
+        }
+    }
+    if (bad) atomicOr(err, 1);
+}
+
 __global__ __launch_bounds__(256) void scale_runs_kernel(gnx_cigar *__restrict__ ops, int64_t total, int64_t factor) {
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x < total) ops[x].run_length *= factor; // expandCigarRunLength, affineGap_highMem.go:91-95

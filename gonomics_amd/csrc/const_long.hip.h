@@ -61,11 +61,11 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
                                               const KParams &kp, int *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
                                               int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
     using PC = ProfCfg<P16>;
-    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
+    constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.g4; // rebased diagonal move: 4*(s - 2g); every value carries tag 2
-    int *prof = &lds[32 + g * PST];
+    int *prof = &lds[32 + PC::pair_off(g)];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
     // (PIPED instantiation: `piped` stays a run-time value on purpose -- with the un-piped branches folded away the compiler allocates 77
     // registers instead of 92 and schedules the block loop so that the launch takes 3.5 % longer: 242 against 234 ms, 1024 pairs of C5)
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                       KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
                                                       int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
-    __shared__ int lds[32 + 4 * ProfCfg<P16>::PST];
+    __shared__ int lds[32 + ProfCfg<P16>::TOTAL];
     cl_sweep_body<P16, true>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, strip_map, strip_prog);
 }
 template <bool P16>
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const PairPlan *__restrict__ plans, int n_pairs, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
     const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap,
     int *__restrict__ hfin, int *__restrict__ err) {
-    __shared__ int lds[32 + 4 * ProfCfg<P16>::PST];
+    __shared__ int lds[32 + ProfCfg<P16>::TOTAL];
     cl_sweep_body<P16, false>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, nullptr, nullptr);
 }
 
@@ -272,14 +272,14 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
                                                      const int *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                      const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err) {
     using PC = ProfCfg<P16>;
-    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
-    __shared__ int lds[32 + 4 * PST + 4 * CL_DIRG];
+    constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
+    __shared__ int lds[32 + PTOT + 4 * CL_DIRG];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.g4 + 1; // pre-tagged diagonal candidate (tag 3), see fill_const_kernel
-    int *prof = &lds[32 + g * PST];
+    int *prof = &lds[32 + PC::pair_off(g)];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
-    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + 4 * PST + g * CL_DIRG]);
+    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + PTOT + g * CL_DIRG]);
     const int p = blockIdx.x * 4 + g;
     const bool valid = p < n_pairs;
     PairPlan pl;

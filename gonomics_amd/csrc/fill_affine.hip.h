@@ -27,15 +27,20 @@ namespace {
 //           un-rebased h-form, 15 with the literal three-candidate form kept for gapOpen > 0).  Every max compares candidates
 //           of one cell (same offset), so values and tags are the plain recurrence's; the row buffer carries V', hcol is
 //           un-rebased when stored, checkpoints of the sweep are rebased when loaded.
-// LDS (dwords): [0,32) 4*score table; then per pair g a profile  prof[b][lane][LW]  (b-stride BST, pair stride
-// PST).  BST = 0 and PST = 16 (mod 32) make the 32 lanes of a ds_read_b32 group hit 32 distinct banks whatever
+// LDS (dwords): [0,32) 4*score table; then per pair g a profile  prof[b][lane][LW]  (b-stride BST, pair offset
+// ProfCfg::pair_off(g)).  BST = 0 and the second pair's offset = 16 (mod 32) make the 32 lanes of a ds_read_b32 group hit 32 distinct banks whatever
 // bases they look up (lane stride 5 or 10 dwords is odd/2*odd -> a permutation within a pair, +16 for the
 // second pair of the group fills the complement).
 // ------------------------------------------------------------------------------------------------------
 template <bool P16> struct ProfCfg {
     static constexpr int LW = P16 ? R / 2 : R;       // dwords per lane per base
-    static constexpr int BST = P16 ? 96 : 160;       // dwords per base (>= 16*LW, multiple of 32)
-    static constexpr int PST = 5 * BST + 16;         // dwords per pair
+    // int32 entries: one pair per 160-dword plane, pair stride 5 planes + 16.  int16 entries (16 lanes x 5 dwords = 80 per plane): the
+    // two pairs of a 32-lane group interleave plane by plane -- pair 0 in [0, 80) of a 160-dword plane, pair 1 in [80, 160), 80 == 16
+    // (mod 32) -- so nothing is padding: 6 528 B per workgroup instead of 8 064, i.e. 6 instead of 7 of the 1280-byte granules LDS is
+    // handed out in on gfx950: 21 workgroups per CU instead of 18 (the piped constant-gap sweep holds 5 waves per SIMD by registers).
+    static constexpr int BST = 160;                  // dwords per base plane (P16: of a duo of pairs); multiple of 32
+    static constexpr int TOTAL = P16 ? 2 * 5 * BST : 4 * (5 * BST + 16); // dwords of the four pairs of a workgroup
+    static __device__ __forceinline__ int pair_off(int g) { return P16 ? (g >> 1) * (5 * BST) + (g & 1) * (G * (R / 2)) : g * (5 * BST + 16); }
 };
 
 template <bool LOCAL, bool MULTI, bool P16, bool HFORM, bool WIN = false, bool SCORED = false, bool XP = false>
@@ -59,12 +64,12 @@ __global__ __launch_bounds__(64) void fill_affine_kernel(const PairPlan *__restr
     static_assert(!XP || (WIN && HFORM && !LOCAL && !MULTI && !SCORED), "XP is a window re-fill variant");
     constexpr int TI = XP ? 1 : 2, TD = XP ? 2 : 1;
     using PC = ProfCfg<P16>;
-    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
-    __shared__ int lds[32 + 4 * PST];
+    constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
+    __shared__ int lds[32 + PTOT];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     if (lane < 25) lds[lane] = kp.sc4[lane] - (HFORM ? 2 * kp.e4 : 0); // rebased diagonal: s - 2e
-    int *prof = &lds[32 + g * PST];
+    int *prof = &lds[32 + PC::pair_off(g)];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
 
     const bool piped = MULTI && strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other

@@ -30,13 +30,13 @@ __global__ __launch_bounds__(64) void fill_const_kernel(const PairPlan *__restri
                                                         const int2 *__restrict__ strip_map = nullptr, int *__restrict__ strip_prog = nullptr) {
     // MULTI: one workgroup per (group of 4 pairs, strip), pipelined through the row buffer -- see fill_affine_kernel
     using PC = ProfCfg<P16>;
-    constexpr int LW = PC::LW, BST = PC::BST, PST = PC::PST;
-    __shared__ int lds[32 + 4 * PST];
+    constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
+    __shared__ int lds[32 + PTOT];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     constexpr bool REB = (GSW == 0);
     if (lane < 25) lds[lane] = REB ? kp.sc4[lane] - 2 * kp.g4 + 1 : kp.sc4[lane] + 3; // pre-tagged diagonal candidate
-    int *prof = &lds[32 + g * PST];
+    int *prof = &lds[32 + PC::pair_off(g)];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
     const bool piped = MULTI && strip_map != nullptr; // else one wave walks the strips of its 4 pairs one after the other
     // piped: this workgroup runs strip strip_map[blockIdx].y of its group -- and first every strip above it that nobody has claimed yet

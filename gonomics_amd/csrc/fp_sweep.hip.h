@@ -40,9 +40,22 @@ namespace {
 // (word = step >> 4, field = step & 15 with step = j + 7), and h(n,m).
 // ------------------------------------------------------------------------------------------------------
 constexpr int G8 = 8;
-constexpr int FP8_BST = 96;                // dwords per base plane (>= 8 lanes * 10 dwords, multiple of 32)
-constexpr int FP8_PST = 5 * FP8_BST + 16;  // dwords per pair: == 16 (mod 32), the two pairs of a 16-lane group hit disjoint banks
 constexpr int FP8_LW = 10;                 // dwords per lane per base (20 int16 entries)
+// LDS layout of the int16 profile.  A ds_read_b64 serves 16 lanes per cycle = one DPP row = a DUO of pairs; lane lp reads dwords
+// 10*lp + 2k, +1 of the plane of ITS base.  Conflict-free whatever the bases are when a plane stride is == 0 (mod 32) and the second
+// pair of the duo sits 16 banks from the first (10*lp mod 32 = {0,10,20,30,8,18,28,6}: with their +1 neighbours 16 distinct banks, the
+// other 16 are theirs + 16).  Compact form (round 3): the two pairs of a duo interleave plane by plane -- pair 0 in dwords [0, 80) of
+// a 160-dword plane, pair 1 in [80, 160), 80 == 16 (mod 32) -- so no padding is left: 3200 dwords of profile, 32 of score table, 128
+// of base rings = 13 440 B per wave, 11 waves per CU (LDS is handed out in granules of 1280 B on gfx950) where the padded form
+// (96-dword planes, pair stride 496: 16 000 B) allowed 9.
+#ifndef GNX_FP_LDS_COMPACT
+#define GNX_FP_LDS_COMPACT 1
+#endif
+constexpr int FP8_BST = GNX_FP_LDS_COMPACT ? 160 : 96;   // dwords per base plane (of a duo / of a pair)
+constexpr int FP8_PST = 5 * 96 + 16;                      // padded form: dwords per pair
+constexpr int FP8_PROF = GNX_FP_LDS_COMPACT ? 4 * 5 * FP8_BST : 8 * FP8_PST; // dwords of profile per wave
+constexpr int FP8_RINGS = GNX_FP_LDS_COMPACT ? 8 * 16 : 0;                    // compact form: 32 uint16 per pair behind the profile
+constexpr int FP8_LDS = 32 + FP8_PROF + FP8_RINGS;                             // dwords per wave (+ the hand-over staging of the levels kernel)
 
 // lanes 0-7 of a DPP row: from lane-1; lanes 8-15 (mirrored pair): from lane+1; the first lane of each pair keeps oldv
 __device__ __forceinline__ int dpp_prev8(int oldv, int src) {
@@ -55,8 +68,9 @@ __device__ __forceinline__ int dpp_next8(int src) { // every lane of the two ban
     return __builtin_amdgcn_update_dpp(v, src, DPP_ROW_SHR1, 0xf, 0xc, false);
 }
 
-// 2 waves per SIMD by choice: capping the kernel at 168 VGPRs for a third wave makes the compiler shuffle registers in the
-// unrolled loop and costs 20 % (measured: 32.2 ms vs 38.6-40.6 ms per 100 k pairs); 16 000 B of LDS allow 10 waves per CU.
+// Occupancy: 168 VGPRs = three waves per SIMD by registers (round 1 needed ~200 and lost 20 % when capped; since the base ring and the
+// look-ahead of round 3 the kernel fits on its own, and the transposed form is held to 168 by amdgpu_waves_per_eu at the price of
+// three spilled values outside the steady loop: -2.4 %), 13 440 B of LDS = 11 waves per CU (see FP8_LDS above).
 // ROLE: reads of 161 .. 320 bases are swept as TWO row blocks of 8 x 20 slots, one launch each (pl.strips == 2):
 //   1 = the TOP block: rows 1 .. n - 160, right-aligned like a short read in 8 x RR slots (RR = 8, 12, 16 or 20: the host picks the
 //       smallest that holds the longest read of the batch); instead of planes / h(n,m) it hands its bottom row down:
@@ -98,7 +112,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     constexpr int TI = XP ? 1 : 2, TD = XP ? 2 : 1; // tags of the horizontal / vertical gap state (tie order, see above)
     if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * E4;
     else if (lane < 32) lds[lane] = XP ? -E4 : -32768; // padding rows: the diagonal candidate never wins (XP: fake rows that repeat row 0)
-    int *prof = &lds[32 + g * FP8_PST];
+    int *prof = GNX_FP_LDS_COMPACT ? &lds[32 + (g >> 1) * (5 * FP8_BST) + (g & 1) * (G8 * FP8_LW)] : &lds[32 + g * FP8_PST];
     const char *prof_lane = reinterpret_cast<const char *>(prof + lp * FP8_LW);
 
     const int pbase = wblk * 8;
@@ -170,10 +184,10 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     // later (its profile entries are fetched one step ahead of their use, see below).  One ds_read_u16 per step instead of four DPP
     // moves (queue rotation + hand-down, each twice for the mirrored pair).  16 columns are enough -- the reads of a half block reach back
     // to column t0 - 5, its write replaces columns t0 - 8 .. t0 - 1 -- and every entry is stored twice, 16 entries apart, so that the
-    // eight reads of a half block are consecutive (immediate offsets, no wrap): 64 bytes, the unused tail of the pair's first
-    // profile plane (8 lanes x 10 dwords of 96).
-    unsigned short *ring = reinterpret_cast<unsigned short *>(prof + G8 * FP8_LW);
-    static_assert(FP8_BST - G8 * FP8_LW >= 16, "the ring lives in the padding of a profile plane");
+    // eight reads of a half block are consecutive (immediate offsets, no wrap): 64 bytes per pair behind the profile (padded form:
+    // the unused tail of the pair's first profile plane, 8 lanes x 10 dwords of 96).
+    unsigned short *ring = reinterpret_cast<unsigned short *>(GNX_FP_LDS_COMPACT ? lds + 32 + FP8_PROF + g * 16 : prof + G8 * FP8_LW);
+    static_assert(GNX_FP_LDS_COMPACT || FP8_BST - G8 * FP8_LW >= 16, "padded form: the ring lives in the padding of a profile plane");
     {
         const int o = base_off(base_raw(lp), lp); // columns 0 .. 7 (column 0 and everything left of it: offset 0, never used by a live cell)
         ring[lp] = (unsigned short)o; ring[lp + 16] = (unsigned short)o;
@@ -189,7 +203,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     auto rb_at = [&](int c) { return (TAKES && valid && c >= 1 && c <= m_eff) ? rb_load(&rb_in[c], piped) : make_int2(0, 0); };
     int2 rq = make_int2(0, 0), rqn = make_int2(0, 0);
     // the last lane stages its bottom row in LDS, one column per step; after a half block lane lp stores column t0 - 7 + lp (64 bytes per pair)
-    int2 *hand = reinterpret_cast<int2 *>(lds + 32 + 8 * FP8_PST) + g * 8;
+    int2 *hand = reinterpret_cast<int2 *>(lds + FP8_LDS) + g * 8;
     // piped: wait until the block above has handed down the columns <= c (it stores column c at its step c + 7)
     int rb_seen = 0;
     auto wait_cols = [&](int c) {
@@ -358,12 +372,12 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
 
 // reads of one row block (n <= 8 * RR)
 template <int RR, bool XP = false, bool PK = false>
-__global__ __launch_bounds__(64) void fp_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void fp_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                       const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                       KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
                                                       unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err) {
-    __shared__ int lds[32 + 8 * FP8_PST];
+    __shared__ int lds[FP8_LDS];
     fp_sweep_body<RR, XP, 0, PK>(lds, (int)blockIdx.x, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, hcol, ckpt, rowi, tail, err, nullptr, 0, false, nullptr, nullptr);
 }
 
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(64) void fp_sweep_levels_kernel(const PairPlan *__r
                                                              KParams kp, int *__restrict__ hcol, int2 *__restrict__ ckpt,
                                                              unsigned *__restrict__ rowi, unsigned *__restrict__ tail, int *__restrict__ err,
                                                              int2 *__restrict__ rowbuf, int S, int W, int level0, int piped, int *__restrict__ prog) {
-    __shared__ int lds[32 + 8 * FP8_PST + 8 * 8 * 2]; // + the staging area of the hand-over (8 pairs x 8 columns x int2)
+    __shared__ int lds[FP8_LDS + 8 * 8 * 2]; // + the staging area of the hand-over (8 pairs x 8 columns x int2)
     // piped: this workgroup sweeps level blockIdx / W of wave column blockIdx % W -- and first every level above it that nobody has
     // claimed yet (claim_items: forward progress without any assumption about dispatch order); none in the normal case.  The claim
     // words sit behind the S * W progress words.

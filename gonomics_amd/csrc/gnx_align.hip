@@ -1201,9 +1201,10 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     const int64_t bias4 = hform_sc ? -8 * prm2.gap_extend : 0;
     const bool s16 = 4 * chunk * smax + llabs((long long)bias4) <= 32767;
     std::vector<int64_t> hn((size_t)n_pairs), hm((size_t)n_pairs), hso((size_t)n_pairs);
-    int64_t stot = 0, worst = 0, maxcols = 1;
+    int64_t stot = 0, worst = 0, maxcols = 1, maxrows = 1;
     for (int64_t p = 0; p < n_pairs; p++) {
         ScorePair &q = sp[(size_t)p];
+        maxrows = std::max<int64_t>(maxrows, q.nc);
         const int64_t strips = std::max<int64_t>((q.nc + H - 1) / H, 1);
         q.s_pitch = strips * H; q.s_off = stot;
         stot += (int64_t)q.mc * q.s_pitch;
@@ -1225,9 +1226,20 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     for (int64_t b = 0; b < n_pairs; b += 32768) {
         const unsigned ny = (unsigned)std::min<int64_t>(32768, n_pairs - b);
         const unsigned nx = (unsigned)std::min<int64_t>((maxcols + 3) / 4, 1024);
-        auto ksm = s16 ? score_matrix_kernel<true> : score_matrix_kernel<false>;
-        hipLaunchKernelGGL(ksm, dim3(nx, ny), dim3(64, 4), 0, st, reinterpret_cast<const ScorePair *>(c.sc_pairs.p) + b,
-                           reinterpret_cast<const uint8_t *>(c.in_a.p), kp0, (int)chunk, groups ? 1 : 0, (int)bias4, reinterpret_cast<int *>(c.sc_mat.p), reinterpret_cast<int *>(c.sc_err.p));
+        const ScorePair *spd = reinterpret_cast<const ScorePair *>(c.sc_pairs.p) + b;
+        const uint8_t *bd = reinterpret_cast<const uint8_t *>(c.in_a.p);
+        int *sm = reinterpret_cast<int *>(c.sc_mat.p), *se = reinterpret_cast<int *>(c.sc_err.p);
+        if (!groups && chunk <= 4 && maxrows * chunk < ((int64_t)1 << 30) && maxcols * chunk < ((int64_t)1 << 30) && !getenv("GNX_SCORE_GENERIC")) {
+            // a block walks ~16 column quads, so that the rows' bases it keeps in registers are loaded once per 64 columns
+            const dim3 grid((unsigned)std::min<int64_t>((maxcols + 63) / 64, 1024), ny), blk(64, 4);
+#define GNX_SMP(S, C) hipLaunchKernelGGL((score_matrix_pairs_kernel<S, C>), grid, blk, 0, st, spd, bd, kp0, (int)bias4, sm, se)
+            if (s16) { if (chunk == 1) GNX_SMP(true, 1); else if (chunk == 2) GNX_SMP(true, 2); else if (chunk == 3) GNX_SMP(true, 3); else GNX_SMP(true, 4); }
+            else { if (chunk == 1) GNX_SMP(false, 1); else if (chunk == 2) GNX_SMP(false, 2); else if (chunk == 3) GNX_SMP(false, 3); else GNX_SMP(false, 4); }
+#undef GNX_SMP
+        } else {
+            auto ksm = s16 ? score_matrix_kernel<true> : score_matrix_kernel<false>;
+            hipLaunchKernelGGL(ksm, dim3(nx, ny), dim3(64, 4), 0, st, spd, bd, kp0, (int)chunk, groups ? 1 : 0, (int)bias4, sm, se);
+        }
     }
     HIPCHK(hipGetLastError());
     int sflag[4] = {0, 0, 0, 0};

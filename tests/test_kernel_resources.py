@@ -50,14 +50,17 @@ def _waves_per_simd(k):
 
 # kernel (prefix of the demangled name) -> waves per SIMD its register count must allow
 BUDGET = [
-    ("fp_sweep_kernel<19, false", 3), ("fp_sweep_kernel<20, false", 3), ("fp_sweep_kernel<19, true", 2), ("fp_sweep_levels_kernel", 2),
+    ("fp_sweep_kernel<19, false", 3), ("fp_sweep_kernel<20, false", 3), ("fp_sweep_kernel<19, true", 3), ("fp_sweep_kernel<20, true", 3), ("fp_sweep_levels_kernel", 2),
     ("fill_affine_kernel<false, false", 3), ("fill_affine_kernel<true, false", 3), ("fill_affine_kernel<false, true", 2), ("fill_affine_kernel<true, true", 2),
     ("fill_const_kernel<false, 0", 3), ("fill_const_kernel<false, 1", 3), ("fill_const_kernel<false, 2", 3), ("fill_const_kernel<true", 2),
     ("cl_sweep_kernel<true>", 5), ("cl_sweep_flat_kernel<true>", 4), ("cl_sweep_kernel<false>", 3), ("al_sweep_kernel", 3),
     ("fp_walk_kernel", 6), ("traceback_kernel", 4), ("gsw_traceback_kernel", 8),
 ]
 # kernels that are allowed scratch (register-bound by design: their tiles live in LDS at one workgroup of 4 pairs per half CU)
-SCRATCH_OK = ("al_walk_kernel",)
+SCRATCH_OK = ("al_walk_kernel", "fp_sweep_kernel<19, true", "fp_sweep_kernel<20, true")  # (the transposed sweep: three values outside the steady loop)
+# LDS per workgroup: handed out in granules of 1280 B on gfx950 (160 KB per CU) -- the budgets are granule counts
+LDS_GRANULES = [("fp_sweep_kernel", 11), ("fp_sweep_levels_kernel", 11), ("cl_sweep_kernel<true>", 6), ("cl_sweep_flat_kernel<true>", 6), ("fill_const_kernel<false, 0, true>", 6),
+                ("fill_affine_kernel<false, false, false, true, false, false, false>", 11)]
 
 
 def test_every_wavefront_kernel_is_in_the_library(kernels):
@@ -77,4 +80,13 @@ def test_register_budgets(kernels):
 def test_no_scratch_outside_the_declared_kernels(kernels):
     bad = [(n, k["private_segment_fixed_size"], k["vgpr_spill_count"]) for n, k in kernels.items()
            if (k["private_segment_fixed_size"] or k["vgpr_spill_count"]) and not n.startswith(SCRATCH_OK) and "rocprim" not in n and "hipcub" not in n]
+    assert not bad, bad
+
+
+def test_lds_budgets(kernels):
+    bad = []
+    for prefix, granules in LDS_GRANULES:
+        for name, k in kernels.items():
+            if name.startswith(prefix) and (k["group_segment_fixed_size"] + 1279) // 1280 > granules:
+                bad.append((name, k["group_segment_fixed_size"], granules))
     assert not bad, bad
