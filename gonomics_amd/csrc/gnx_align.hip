@@ -1194,6 +1194,10 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     prm2.gap_extend = prm->gap_extend * chunk;
     for (int x = 0; x < 25; x++) prm2.scores[x] = prm->scores[x] * chunk;
     hipStream_t st = c.own_stream;
+    const bool dbg = getenv("GNX_DEBUG") != nullptr;
+    auto t_now = []() { return std::chrono::steady_clock::now(); };
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    const auto t_begin = t_now();
     int64_t smax = 0; // int16 score matrix when every 4 * cell score fits (a cell is a sum of `chunk` scores, or of averages of scores)
     for (int x = 0; x < 25; x++) smax = std::max<int64_t>(smax, llabs((long long)prm->scores[x]));
     // the fill's h-form works on rebased keys: the matrix entries carry the -2e of the diagonal move (e = gapExtend * chunk)
@@ -1245,6 +1249,7 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     int sflag[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(sflag, c.sc_err.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const double t_scores = ms_since(t_begin);
     if (sflag[0] & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
     if (sflag[0] & 16) { set_err("scoreColumnMatch over gap-only columns: the reference panics (integer divide by zero)%s", ""); return GNX_EDIVZERO; }
     int64_t cap = std::max<int64_t>(std::min<int64_t>(worst, std::max<int64_t>((int64_t)1 << 20, 64 * n_pairs)), 1);
@@ -1257,6 +1262,7 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
         cap = std::max(total, cap + 1);
     }
     if (rc) return rc;
+    const double t_dp = ms_since(t_begin);
     if (chunk > 1 && total > 0) hipLaunchKernelGGL(scale_runs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (gnx_cigar *)c.out_ops.p, total, chunk);
     struct HostArr { void *p; explicit HostArr(size_t b) : p(malloc(b)) {} ~HostArr() { free(p); } void *release() { void *q = p; p = nullptr; return q; } };
     HostArr ops_h((size_t)std::max<int64_t>(total, 1) * sizeof(gnx_cigar)), off_h((size_t)(n_pairs + 1) * 8); // freed on every early return below
@@ -1268,6 +1274,8 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     if (total) HIPCHK(hipMemcpyAsync(ops, c.out_ops.p, (size_t)total * sizeof(gnx_cigar), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     *out_ops = (gnx_cigar *)ops_h.release(); *out_ops_off = (int64_t *)off_h.release();
+    if (dbg) fprintf(stderr, "[gnx] scored batch of %lld pairs: upload + score matrices %.3f ms, DP (fill %.3f + traceback %.3f on the device) until %.3f ms, results on the host at %.3f ms\n",
+                     (long long)n_pairs, t_scores, c.timing.fill_ms, c.timing.traceback_ms, t_dp, ms_since(t_begin));
     return GNX_OK;
 }
 
