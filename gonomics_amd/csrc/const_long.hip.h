@@ -261,10 +261,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     cl_sweep_body<P16, false>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, nullptr, nullptr);
 }
 
-// One wave per 4 pairs.  Per round every pair (16 lanes) re-fills the tile its walk is in -- strip s = (i-1)/160, steps
+// One wave per NP pairs (NP = 4, 2 or 1: lanes 16 * NP .. 63 idle).  The walk of a pair is one long chain of dependent steps (re-fill a
+// tile, walk it with one lane, next tile), so a launch is as fast as its slowest wave -- and a wave of four pairs re-fills, every round,
+// as many blocks as the pair that needs most, and walks until the last of the four has left its tile.  With one pair per wave a
+// workgroup needs a quarter of the LDS, so the same number of pairs is resident (8 workgroups per CU instead of 2) on all four SIMDs
+// instead of two, and nobody waits for a neighbour.  Per round every pair (16 lanes) re-fills the tile its walk is in -- strip s = (i-1)/160, steps
 // (c*CKC, j + lane(i)] of that strip's wavefront -- into LDS, then lane 0 of the pair walks inside the tile until it leaves it.
 // Runs are staged in traceback order at scr[scr_off[p] ..] (n + m + 2 entries per pair); reverse_runs_kernel puts them in place.
-template <bool P16>
+template <bool P16, int NP>
 __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
@@ -272,16 +276,20 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
                                                      const int *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                      const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err) {
     using PC = ProfCfg<P16>;
-    constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
-    __shared__ int lds[32 + PTOT + 4 * CL_DIRG];
+    static_assert(NP == 1 || NP == 2 || NP == 4, "pairs per workgroup");
+    // profile of NP pairs: the layout of ProfCfg (one or two duos), or, for a single pair, planes of its own 16 * LW dwords (a plane
+    // stride of 80 or 160 dwords keeps the 16 lanes of one pair on 16 distinct banks whatever bases they look up)
+    constexpr int LW = PC::LW, BST = NP == 1 ? G * LW : PC::BST, PTOT = NP == 1 ? 5 * BST : (NP == 2 ? PC::TOTAL / 2 : PC::TOTAL);
+    __shared__ int lds[32 + PTOT + NP * CL_DIRG];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.g4 + 1; // pre-tagged diagonal candidate (tag 3), see fill_const_kernel
-    int *prof = &lds[32 + PC::pair_off(g)];
+    const int gl = g < NP ? g : 0; // (idle lane groups compute on pair 0's addresses and store nothing)
+    int *prof = &lds[32 + (NP == 1 ? 0 : PC::pair_off(gl))];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
-    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + PTOT + g * CL_DIRG]);
-    const int p = blockIdx.x * 4 + g;
-    const bool valid = p < n_pairs;
+    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + PTOT + gl * CL_DIRG]);
+    const int p = blockIdx.x * NP + g;
+    const bool valid = g < NP && p < n_pairs;
     PairPlan pl;
     if (valid) pl = plans[p]; else { pl.n = 0; pl.m = 0; pl.words = 0; pl.strips = 0; pl.trace_off = 0; pl.hcol_off = 0; pl.rowbuf_off = 0; pl.dcol_off = 0; pl.src = 0; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0; }
     const uint8_t *ap = a_buf + (valid ? a_start[p] : 0);
@@ -336,10 +344,12 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
                 a5[r] = a * 5;
             }
             __syncthreads(); // table visible; the previous round's walk is over
+            if (NP == 4 || g < NP) {
 #pragma unroll
-            for (int b = 0; b < 5; b++) {
+                for (int b = 0; b < 5; b++) {
 #pragma unroll
-                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+                    for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+                }
             }
             __syncthreads();
         }

@@ -674,8 +674,16 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         const dim3 gridW((unsigned)((np + 3) / 4));
         if (affine && p16) hipLaunchKernelGGL(al_walk_kernel<true>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
         else if (affine) hipLaunchKernelGGL(al_walk_kernel<false>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
-        else if (p16) hipLaunchKernelGGL(cl_walk_kernel<true>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
-        else hipLaunchKernelGGL(cl_walk_kernel<false>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
+        else {
+            // pairs per walk workgroup: GNX_CL_WALK_NP = 1 / 2 / 4 (default 1, see cl_walk_kernel)
+            const char *npe = getenv("GNX_CL_WALK_NP");
+            const int wnp = (npe && (npe[0] == '2' || npe[0] == '4')) ? npe[0] - '0' : 1;
+            const dim3 gw((unsigned)((np + wnp - 1) / wnp));
+#define GNX_CLW(P, N) hipLaunchKernelGGL((cl_walk_kernel<P, N>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err)
+            if (p16) { if (wnp == 1) GNX_CLW(true, 1); else if (wnp == 2) GNX_CLW(true, 2); else GNX_CLW(true, 4); }
+            else { if (wnp == 1) GNX_CLW(false, 1); else if (wnp == 2) GNX_CLW(false, 2); else GNX_CLW(false, 4); }
+#undef GNX_CLW
+        }
         HIPCHK(hipGetLastError());
         if ((rc = launch_scan(dn, np, d_ops_off + b, d_carry, stream))) return rc;
         hipLaunchKernelGGL(reverse_runs_kernel, dim3((unsigned)np), dim3(256), 0, stream, dpl, np, d_scr, d_so, dn, d_ops_off + b, d_ops, ops_capacity, d_err);
