@@ -42,6 +42,7 @@ timeout 600 python tools/bench_host.py 100000 1000000 > $out/host_entry.jsonl 2>
 timeout 600 python tools/bench_shapes.py affine > $out/shapes_affine.jsonl 2>> $out/bench.err
 timeout 600 python tools/bench_shapes.py const > $out/shapes_const.jsonl 2>> $out/bench.err
 timeout 600 python tools/bench_shapes.py local > $out/shapes_local.jsonl 2>> $out/bench.err
+tools/lds_occupancy.bin > $out/lds_occupancy.txt 2>>$out/bench.err
 timeout 600 python tools/bench_gsw.py > $out/gsw_reads.jsonl 2>> $out/bench.err
 g++ -std=c++17 -O2 -Iinclude -o tools/bench_cabi.bin tools/bench_cabi.cpp gonomics_amd/libgonomics_align_hip.so -Wl,-rpath,$PWD/gonomics_amd -L/opt/rocm/lib -lamdhip64 2>> $out/bench.err && tools/bench_cabi.bin > $out/cabi_n1_n2.jsonl 2>> $out/bench.err
 find $out -name '*.db' -size +20M -delete
