@@ -206,4 +206,10 @@ __global__ __launch_bounds__(256) void unpack_windows_kernel(KParams kp, const i
     for (int64_t k = threadIdx.x; k < len; k += blockDim.x) out[out_off[p] + k] = (uint8_t)b.at(k);
 }
 
+// CIGAR offsets of a sub-batch (they start at 0) moved behind the runs of the sub-batches before it
+__global__ __launch_bounds__(256) void add_offset_kernel(int64_t *__restrict__ off, int64_t n, int64_t base) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n) off[x] += base;
+}
+
 } // namespace

@@ -1231,44 +1231,130 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     const size_t np = (size_t)std::max<int64_t>(n_pairs, 1);
     if ((rc = c.out_score.ensure(np * 8))) return rc;
     if ((rc = c.out_off.ensure((np + 1) * 8))) return rc;
-    if (bases_len) HIPCHK(hipMemcpyAsync(c.in_a.p, bases, (size_t)bases_len, hipMemcpyHostToDevice, st));
-    if (bases2_len) HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t *>(c.in_a.p) + bases_len, bases2, (size_t)bases2_len, hipMemcpyHostToDevice, st));
     if (n_pairs) HIPCHK(hipMemcpyAsync(c.sc_pairs.p, sp.data(), (size_t)n_pairs * sizeof(ScorePair), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(c.sc_err.p, 0, 16, st));
-    for (int64_t b = 0; b < n_pairs; b += 32768) {
-        const unsigned ny = (unsigned)std::min<int64_t>(32768, n_pairs - b);
-        const unsigned nx = (unsigned)std::min<int64_t>((maxcols + 3) / 4, 1024);
-        const ScorePair *spd = reinterpret_cast<const ScorePair *>(c.sc_pairs.p) + b;
-        const uint8_t *bd = reinterpret_cast<const uint8_t *>(c.in_a.p);
-        int *sm = reinterpret_cast<int *>(c.sc_mat.p), *se = reinterpret_cast<int *>(c.sc_err.p);
-        if (!groups && chunk <= 4 && maxrows * chunk < ((int64_t)1 << 30) && maxcols * chunk < ((int64_t)1 << 30) && !getenv("GNX_SCORE_GENERIC")) {
-            // a block walks ~16 column quads, so that the rows' bases it keeps in registers are loaded once per 64 columns
-            const dim3 grid((unsigned)std::min<int64_t>((maxcols + 63) / 64, 1024), ny), blk(64, 4);
-#define GNX_SMP(S, C) hipLaunchKernelGGL((score_matrix_pairs_kernel<S, C>), grid, blk, 0, st, spd, bd, kp0, (int)bias4, sm, se)
-            if (s16) { if (chunk == 1) GNX_SMP(true, 1); else if (chunk == 2) GNX_SMP(true, 2); else if (chunk == 3) GNX_SMP(true, 3); else GNX_SMP(true, 4); }
-            else { if (chunk == 1) GNX_SMP(false, 1); else if (chunk == 2) GNX_SMP(false, 2); else if (chunk == 3) GNX_SMP(false, 3); else GNX_SMP(false, 4); }
-#undef GNX_SMP
-        } else {
-            auto ksm = s16 ? score_matrix_kernel<true> : score_matrix_kernel<false>;
-            hipLaunchKernelGGL(ksm, dim3(nx, ny), dim3(64, 4), 0, st, spd, bd, kp0, (int)chunk, groups ? 1 : 0, (int)bias4, sm, se);
-        }
+    // ---- sub-batches: the bases of sub-batch k + 1 cross PCIe (from the caller's pageable memory: an uploader thread sits in that copy)
+    // while the score matrices and the DP of sub-batch k run.  Pairwise entry point only (alpha_cat / beta_cat are in pair order), big inputs only.
+    // A sub-batch must still fill the GPU on its own (4 pairs per wave, one wave per group of strips: 8192 pairs = 2048 waves) -- 4096
+    // pairs cut in four ran 7.9 instead of 5.1 ms: each quarter takes as long as the whole.  GNX_SCORED_SUB=k forces k sub-batches (tests).
+    int K = 1;
+    if (!groups && bases2 && n_pairs >= 2) {
+        if (bases_len + bases2_len >= ((int64_t)8 << 20)) K = (int)std::min<int64_t>(4, n_pairs / 8192);
+        if (const char *e = getenv("GNX_SCORED_SUB")) K = atoi(e);
+        K = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(K, 16), n_pairs));
     }
-    HIPCHK(hipGetLastError());
+    std::vector<int64_t> kb((size_t)K + 1, n_pairs);
+    kb[0] = 0;
+    if (K > 1) { // boundaries by bytes of bases
+        int next = 1;
+        for (int64_t p = 0; p < n_pairs && next < K; p++) {
+            const int64_t done_bytes = sp[(size_t)p].a_off + (sp[(size_t)p].b_off - bases_len); // = alpha_off[p] + beta_off[p]
+            if (done_bytes * K >= (bases_len + bases2_len) * next) kb[(size_t)next++] = p;
+        }
+        for (int k = 1; k <= K; k++) kb[(size_t)k] = std::max(kb[(size_t)k], kb[(size_t)k - 1]);
+    }
+    std::vector<hipEvent_t> evs((size_t)K, nullptr);
+    struct EvGuard { std::vector<hipEvent_t> &e; ~EvGuard() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } evg{evs};
+    for (int k = 0; k < K; k++) HIPCHK(hipEventCreateWithFlags(&evs[(size_t)k], hipEventDisableTiming));
+    std::atomic<int> uploaded{0};
+    std::atomic<int> up_rc{0};
+    auto a_begin = [&](int64_t p) { return p < n_pairs ? sp[(size_t)p].a_off : bases_len; };
+    auto b_begin = [&](int64_t p) { return p < n_pairs ? sp[(size_t)p].b_off : bases_len + bases2_len; };
+    auto upload = [&]() { // (K == 1: everything; runs on the calling thread then)
+        uint8_t *dst = reinterpret_cast<uint8_t *>(c.in_a.p);
+        for (int k = 0; k < K; k++) {
+            bool ok = true;
+            if (K == 1) {
+                if (bases_len) ok = ok && hipMemcpyAsync(dst, bases, (size_t)bases_len, hipMemcpyHostToDevice, c.s_in) == hipSuccess;
+                if (bases2_len) ok = ok && hipMemcpyAsync(dst + bases_len, bases2, (size_t)bases2_len, hipMemcpyHostToDevice, c.s_in) == hipSuccess;
+            } else {
+                const int64_t a0 = a_begin(kb[(size_t)k]), a1 = a_begin(kb[(size_t)k + 1]), b0 = b_begin(kb[(size_t)k]), b1 = b_begin(kb[(size_t)k + 1]);
+                if (a1 > a0) ok = ok && hipMemcpyAsync(dst + a0, bases + a0, (size_t)(a1 - a0), hipMemcpyHostToDevice, c.s_in) == hipSuccess;
+                if (b1 > b0) ok = ok && hipMemcpyAsync(dst + b0, bases2 + (b0 - bases_len), (size_t)(b1 - b0), hipMemcpyHostToDevice, c.s_in) == hipSuccess;
+            }
+            ok = ok && hipEventRecord(evs[(size_t)k], c.s_in) == hipSuccess;
+            if (!ok) up_rc.store(1);
+            uploaded.store(k + 1, std::memory_order_release);
+        }
+    };
+    std::thread uploader;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
+    if (K > 1) {
+        const int dev = c.device;
+        uploader = std::thread([&, dev]() { if (hipSetDevice(dev) != hipSuccess) { up_rc.store(1); uploaded.store(K, std::memory_order_release); return; } upload(); });
+    } else upload();
+    int64_t cap = std::max<int64_t>(std::min<int64_t>(worst, std::max<int64_t>((int64_t)1 << 20, 64 * n_pairs)), 1);
+    if ((rc = c.out_ops.ensure((size_t)cap * sizeof(gnx_cigar)))) return rc;
+    int64_t total = 0;
+    gnx_timing tsum = {};
+    bool redo = false; // a sub-batch did not fit the CIGAR buffer: once everything is uploaded, the whole batch runs again as one
+    const ScorePair *spd0 = reinterpret_cast<const ScorePair *>(c.sc_pairs.p);
+    const uint8_t *bd = reinterpret_cast<const uint8_t *>(c.in_a.p);
+    int *sm = reinterpret_cast<int *>(c.sc_mat.p), *se = reinterpret_cast<int *>(c.sc_err.p);
+    auto score_matrices = [&](int64_t p0, int64_t p1) {
+        for (int64_t b = p0; b < p1; b += 32768) {
+            const unsigned ny = (unsigned)std::min<int64_t>(32768, p1 - b);
+            const unsigned nx = (unsigned)std::min<int64_t>((maxcols + 3) / 4, 1024);
+            const ScorePair *spd = spd0 + b;
+            if (!groups && chunk <= 4 && maxrows * chunk < ((int64_t)1 << 30) && maxcols * chunk < ((int64_t)1 << 30) && !getenv("GNX_SCORE_GENERIC")) {
+                // a block walks ~16 column quads, so that the rows' bases it keeps in registers are loaded once per 64 columns
+                const dim3 grid((unsigned)std::min<int64_t>((maxcols + 63) / 64, 1024), ny), blk(64, 4);
+#define GNX_SMP(S, C) hipLaunchKernelGGL((score_matrix_pairs_kernel<S, C>), grid, blk, 0, st, spd, bd, kp0, (int)bias4, sm, se)
+                if (s16) { if (chunk == 1) GNX_SMP(true, 1); else if (chunk == 2) GNX_SMP(true, 2); else if (chunk == 3) GNX_SMP(true, 3); else GNX_SMP(true, 4); }
+                else { if (chunk == 1) GNX_SMP(false, 1); else if (chunk == 2) GNX_SMP(false, 2); else if (chunk == 3) GNX_SMP(false, 3); else GNX_SMP(false, 4); }
+#undef GNX_SMP
+            } else {
+                auto ksm = s16 ? score_matrix_kernel<true> : score_matrix_kernel<false>;
+                hipLaunchKernelGGL(ksm, dim3(nx, ny), dim3(64, 4), 0, st, spd, bd, kp0, (int)chunk, groups ? 1 : 0, (int)bias4, sm, se);
+            }
+        }
+    };
+    double t_scores = 0;
+    for (int k = 0; k < K; k++) {
+        while (uploaded.load(std::memory_order_acquire) <= k) std::this_thread::yield();
+        if (up_rc.load()) { set_err("upload of the bases failed%s", ""); return GNX_EDEVICE; }
+        HIPCHK(hipStreamWaitEvent(st, evs[(size_t)k], 0));
+        const int64_t p0 = kb[(size_t)k], p1 = kb[(size_t)k + 1], cnt = p1 - p0;
+        score_matrices(p0, p1);
+        HIPCHK(hipGetLastError());
+        if (K == 1) { // one batch: errors of the score kernels are reported before the DP runs (sub-batches: after it; bad bases were read as 'A')
+            int f[4] = {0, 0, 0, 0};
+            HIPCHK(hipMemcpyAsync(f, c.sc_err.p, 16, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (f[0] & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
+            if (f[0] & 16) { set_err("scoreColumnMatch over gap-only columns: the reference panics (integer divide by zero)%s", ""); return GNX_EDIVZERO; }
+        }
+        if (k == 0) t_scores = ms_since(t_begin);
+        if (redo || cnt == 0) continue;
+        int64_t tot = 0;
+        rc = run_device(&prm2, cnt, nullptr, nullptr, nullptr, nullptr, hn.data() + p0, hm.data() + p0, (int64_t *)c.out_score.p + p0, (gnx_cigar *)c.out_ops.p + total, cap - total,
+                        (int64_t *)c.out_off.p + p0, &tot, st, reinterpret_cast<const int *>(c.sc_mat.p), hso.data() + p0, 0, nullptr, false, s16);
+        if (rc == GNX_ECAPACITY) { redo = true; continue; }
+        if (rc) return rc;
+        tsum.fill_ms += c.timing.fill_ms; tsum.traceback_ms += c.timing.traceback_ms; tsum.total_ms += c.timing.total_ms; tsum.cells += c.timing.cells;
+        tsum.n_launches += c.timing.n_launches; tsum.trace_bytes += c.timing.trace_bytes; tsum.dominant_ms += c.timing.dominant_ms; tsum.dominant_launches += c.timing.dominant_launches;
+        if (total > 0) { // offsets of a sub-batch start at 0
+            hipLaunchKernelGGL(add_offset_kernel, dim3((unsigned)((cnt + 1 + 255) / 256)), dim3(256), 0, st, (int64_t *)c.out_off.p + p0, cnt + 1, total);
+            HIPCHK(hipGetLastError());
+        }
+        total += tot;
+    }
     int sflag[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(sflag, c.sc_err.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    const double t_scores = ms_since(t_begin);
     if (sflag[0] & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
     if (sflag[0] & 16) { set_err("scoreColumnMatch over gap-only columns: the reference panics (integer divide by zero)%s", ""); return GNX_EDIVZERO; }
-    int64_t cap = std::max<int64_t>(std::min<int64_t>(worst, std::max<int64_t>((int64_t)1 << 20, 64 * n_pairs)), 1);
-    int64_t total = 0;
-    for (int attempt = 0; attempt < 8; attempt++) {
-        if ((rc = c.out_ops.ensure((size_t)cap * sizeof(gnx_cigar)))) return rc;
-        rc = run_device(&prm2, n_pairs, nullptr, nullptr, nullptr, nullptr, hn.data(), hm.data(), (int64_t *)c.out_score.p, (gnx_cigar *)c.out_ops.p, cap,
-                        (int64_t *)c.out_off.p, &total, st, reinterpret_cast<const int *>(c.sc_mat.p), hso.data(), 0, nullptr, false, s16);
-        if (rc != GNX_ECAPACITY) break;
-        cap = std::max(total, cap + 1);
-    }
+    if (redo || n_pairs == 0) { // (also the empty batch: run_device writes the single offset)
+        total = 0; tsum = gnx_timing{};
+        for (int attempt = 0; attempt < 8; attempt++) {
+            if ((rc = c.out_ops.ensure((size_t)cap * sizeof(gnx_cigar)))) return rc;
+            rc = run_device(&prm2, n_pairs, nullptr, nullptr, nullptr, nullptr, hn.data(), hm.data(), (int64_t *)c.out_score.p, (gnx_cigar *)c.out_ops.p, cap,
+                            (int64_t *)c.out_off.p, &total, st, reinterpret_cast<const int *>(c.sc_mat.p), hso.data(), 0, nullptr, false, s16);
+            if (rc != GNX_ECAPACITY) break;
+            cap = std::max(total, cap + 1);
+        }
+        tsum = c.timing;
+    } else c.timing = tsum;
     if (rc) return rc;
     const double t_dp = ms_since(t_begin);
     if (chunk > 1 && total > 0) hipLaunchKernelGGL(scale_runs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (gnx_cigar *)c.out_ops.p, total, chunk);

@@ -6,7 +6,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <mutex>
 #include <vector>
 #include <algorithm>

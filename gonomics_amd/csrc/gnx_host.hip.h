@@ -108,10 +108,6 @@ void rccl_give_up() {
     (void)hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void add_offset_kernel(int64_t *__restrict__ off, int64_t n, int64_t base) {
-    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x < n) off[x] += base;
-}
 // the synthetic reference is a pure function of the position (splitmix64), 2 bits per base, an N run of
 // 1000 bases every 5e7 -- generated where it is used instead of crossing PCIe
 __device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {

@@ -72,6 +72,39 @@ def test_chunk_fuzz_vs_oracle(gpu_lib):
         assert got == exp, ("int32 matrix", k)
 
 
+def test_chunk_batch_in_sub_batches(gpu_lib, monkeypatch):
+    """Big inputs cross PCIe in sub-batches while the DP of the sub-batch before runs (run_host_scored; by itself only from 16 384
+    pairs and 8 MB on, GNX_SCORED_SUB forces it): same results as the one-batch flow, a sample against the oracle; ragged lengths,
+    empty pairs, a bad base in the last sub-batch -> GNX_EBASE."""
+    rng = np.random.default_rng(21)
+    chunk, pairs = 3, 700
+    alphas, betas = [], []
+    for k in range(pairs):
+        nb = int(rng.integers(300, 900)) if k % 97 else 0
+        b = rng.integers(0, 4, size=nb * chunk).astype(np.uint8)
+        na = int(rng.integers(0, 200)) if nb else int(rng.integers(0, 3))
+        s0 = int(rng.integers(0, max(nb - na, 1))) * chunk
+        a = common.mutate(rng, b[s0:s0 + na * chunk], sub=0.05, indel=0.02, geo=0.4, alphabet=4) if na and nb else rng.integers(0, 4, size=na * chunk).astype(np.uint8)
+        a = a[:(len(a) // chunk) * chunk]
+        alphas.append(a); betas.append(b)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_HIGHMEM, align.HumanChimpTwoScoreMatrix, -600, -150)
+    monkeypatch.setenv("GNX_SCORED_SUB", "1")
+    sc1, ops1, off1 = gpu_lib.affine_gap_chunk_batch(p, chunk, alphas, betas)
+    for sub in ("4", "7"):
+        monkeypatch.setenv("GNX_SCORED_SUB", sub)
+        sc, ops, off = gpu_lib.affine_gap_chunk_batch(p, chunk, alphas, betas)
+        assert np.array_equal(sc, sc1) and np.array_equal(off, off1), sub
+        assert np.array_equal(ops["run_length"][:off[-1]], ops1["run_length"][:off1[-1]]) and np.array_equal(ops["op"][:off[-1]], ops1["op"][:off1[-1]]), sub
+    for k in list(range(0, pairs, 131)) + [96, 97, 98, pairs - 1]:
+        exp = oracle.affine_gap_chunk(MX["HumanChimpTwo"], -600, -150, chunk, alphas[k], betas[k])
+        got = (int(sc[k]), [(int(r), int(o)) for r, o in zip(ops["run_length"][off[k]:off[k + 1]], ops["op"][off[k]:off[k + 1]])])
+        assert got == exp, k
+    betas[pairs - 2] = betas[pairs - 2].copy(); betas[pairs - 2][5] = 7
+    with pytest.raises((gpu_lib.GnxError, IndexError)):
+        gpu_lib.affine_gap_chunk_batch(p, chunk, alphas, betas)
+    monkeypatch.delenv("GNX_SCORED_SUB")
+
+
 def test_groups_fuzz_vs_oracle(gpu_lib):
     rng = np.random.default_rng(9)
     for chunk in (1, 2):

@@ -38,8 +38,8 @@ int main() {
                         side ? "RightDynamicAln" : "LeftDynamicAln", (long long)n, best, tm.total_ms, n / (best * 1e-3));
         }
     }
-    {   // N1: 4096 pairs of 160 x 3000 chunks of 3
-        const int64_t n = 4096, chunk = 3, na = 160 * chunk, nb = 3000 * chunk;
+    for (const int64_t n : {(int64_t)4096, (int64_t)32768}) {   // N1: pairs of 160 x 3000 chunks of 3 (32 768 pairs: the bases cross PCIe in sub-batches under the DP)
+        const int64_t chunk = 3, na = 160 * chunk, nb = 3000 * chunk;
         std::vector<uint8_t> a((size_t)(n * na)), b((size_t)(n * nb));
         for (auto &x : b) x = (uint8_t)(rng() & 3);
         for (int64_t p = 0; p < n; p++) for (int64_t k = 0; k < na; k++) a[(size_t)(p * na + k)] = b[(size_t)(p * nb + 300 * chunk + k)];
