@@ -54,6 +54,9 @@ __device__ __forceinline__ int rb_load32(const int *p, bool piped) {
 // the single wave stall less (look-ahead, deferred conversion, lagged publishes, loads two blocks ahead with hand-kept counts) made the
 // launch SLOWER -- 451 -> 492 -> 522 ms for 2048 pairs of config C5 (profiles/r3_experiments.md).  So the piped form keeps the
 // plain step.
+#ifndef GNX_CL_PRIO
+#define GNX_CL_PRIO 1
+#endif
 template <bool P16, bool PIPED>
 __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairPlan *__restrict__ plans, int n_pairs,
                                               const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
@@ -214,6 +217,15 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
             // the progress word of the strip above is polled ONE BLOCK AHEAD (the load issued in the previous block lands while its 16
             // steps run); only a strip that has caught up with its producer falls into the blocking spin of wait_rows
             if (piped && s > 0) { rb_seen = max(rb_seen, pf_seen); if (rb_seen < t0 + 5 * G) pf_seen = rb_progress(&strip_prog[bid - 1]); }
+#if GNX_CL_PRIO
+            // Issue priority by slack (round 3): a strip that has columns in hand -- or the top strip -- is what the strips below it wait
+            // for; one that runs right behind its producer will stop at the next block anyway.  Raising the former over the latter in the
+            // SIMD's arbitration: 2048 pairs of C5 400 -> 382 ms (levels 2 / 0, 3 / 0 and 3 / 1 / 0 measure the same).
+            if (piped) {
+                const int slack = s == 0 ? (1 << 30) : __builtin_amdgcn_readfirstlane(rb_seen) - t0;
+                if (slack >= 5 * G) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             wait_rows(t0 + 2 * G);
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
@@ -230,7 +242,7 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
                 const int c = t0 + l - 14;
                 if (c >= 1 && c <= m_eff) rb_store32(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_v, piped);
             }
-            if (piped && ((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[bid], t0 + 1, lane);
+            if (piped && ((t0 + 16) & (kp.rb_pub - 1)) == 0) rb_publish(&strip_prog[bid], t0 + 1, lane);
         }
         if (gact && m_eff >= 1) {
 #pragma unroll

@@ -39,6 +39,12 @@ namespace {
 // branch-free stores all measure the same within 0.2 ms --, the I-plane words of rows n..n-3
 // (word = step >> 4, field = step & 15 with step = j + 7), and h(n,m).
 // ------------------------------------------------------------------------------------------------------
+#ifndef GNX_FP_PUB
+#define GNX_FP_PUB 32
+#endif
+#ifndef GNX_FP_PRIO
+#define GNX_FP_PRIO 0
+#endif
 constexpr int G8 = 8;
 constexpr int FP8_LW = 10;                 // dwords per lane per base (20 int16 entries)
 // LDS layout of the int16 profile.  A ds_read_b64 serves 16 lanes per cycle = one DPP row = a DUO of pairs; lane lp reads dwords
@@ -329,7 +335,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
             const int2 v = hand[lp];
             if (valid && c >= 1 && c <= m_eff) rb_store(&rb_out[c], v.x, v.y, piped);
             __syncthreads();
-            if (piped && ((t0 + 8) & 31) == 0) rb_publish(prog_out, t0 + 7, lane); // every 32 steps: columns <= t0 are out
+            if (piped && ((t0 + 8) & (GNX_FP_PUB - 1)) == 0) rb_publish(prog_out, t0 + 7, lane); // every GNX_FP_PUB steps: columns <= t0 are out
         }
     };
     auto edge_half_block = [&](int t0) { // head and tail of the sweep: some lanes are outside their matrix
@@ -352,6 +358,12 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     for (; t0 < Tend && !(t0 >= 8 && t0 + 7 <= m_min); t0 += 8) edge_half_block(t0);
     for (; t0 + 7 <= m_min; t0 += 8) { // steady state: every lane of the wave is inside its matrix
         nraw = base_raw(t0 + 8 + lp);
+#if GNX_FP_PRIO
+        if (piped) { // issue priority by slack, as in cl_sweep_body: blocks with columns in hand (and the top block) before blocks that run right behind their producer
+            const int slack = TAKES ? __builtin_amdgcn_readfirstlane(rb_seen) - t0 : (1 << 30);
+            if (slack >= 48) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         if (TAKES) { wait_cols(t0 + 15); rqn = rb_at(t0 + 8 + lp); }
         const bool ckflag = (t0 & (CKW - 1)) == 0; // steps t0 + lp are the lanes' checkpoint columns
         rp = ring + ((t0 + 2 - lp) & 15);

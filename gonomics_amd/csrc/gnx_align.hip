@@ -112,6 +112,7 @@ struct Ctx {
     // resident seed index of the graph aligner (gnx_seed_index_set)
     DevBuf sd_keys, sd_locs, sd_nodes, sd_node_off, sd_word_off, sd_words, sd_tmp[8];
     int64_t sd_n = -1, sd_nodes_n = 0; int sd_seed_len = 0;
+    PinBuf h_plans; // host-side plans of the general path
     PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
     // the resident reference, PACKED (gnx_host.hip.h: pack_reference): `ref` = 2 bits per base, ref_flag / ref_rank / ref_exc = the
     // sparse list of bases that are not A C G T (KParams::b2 / bflag / brank / bexc)
@@ -201,6 +202,7 @@ int check_params(const gnx_params *p, KParams &kp, TbParams &tp, bool &affine, b
     kp.d00_4 = local ? 0 : kp.o4;
     kp.ecol4 = local ? 0 : kp.e4;
     kp.g4 = kp.o4;
+    kp.rb_pub = RB_PUB;
     tp.ci = lowmem ? p->checkersize_i : ((int64_t)1 << 62);
     tp.cj = lowmem ? p->checkersize_j : ((int64_t)1 << 62);
     tp.d00 = local ? 0 : p->gap_open;
@@ -662,12 +664,20 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             HIPCHK(hipStreamSynchronize(stream)); // smap is a local
         }
         HIPCHK(hipEventRecord(c.ev[1], stream));
+        // How often a piped strip publishes its bottom row.  A strip cannot start before the one above it has published its first columns,
+        // so a launch ramps up over (strips per pair) x (publish interval + look-ahead) columns: with the GPU full of waves (C5: 64 000
+        // workgroups on 5 120 wave slots) a publish every block instead of every fourth hides its cost (the wait for the stores'
+        // acknowledgement) behind the other waves and shortens the ramp -- 2048 pairs 437 -> 400 ms; a launch that does not fill the GPU
+        // pays for every publish with its own latency (64 pairs of C5: 17.4 -> 19.2 ms) and keeps the coarse interval.
+        KParams kps = kp;
+        kps.rb_pub = n_blocks >= 10240 ? 16 : RB_PUB;
+        if (const char *e = getenv("GNX_CL_PUB")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) kps.rb_pub = v; }
         int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
         if (affine && p16) hipLaunchKernelGGL(al_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
         else if (affine) hipLaunchKernelGGL(al_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
-        else if (p16 && piped) hipLaunchKernelGGL(cl_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        else if (p16 && piped) hipLaunchKernelGGL(cl_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
         else if (p16) hipLaunchKernelGGL(cl_sweep_flat_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err);
-        else if (piped) hipLaunchKernelGGL(cl_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        else if (piped) hipLaunchKernelGGL(cl_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
         else hipLaunchKernelGGL(cl_sweep_flat_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
@@ -784,11 +794,15 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // (AffineGapLocal: of its query, the rows of the transposed problem); 0 = not for the fast path.  The walk re-fills ~256 columns per row block whatever the window
         // length, so the path pays from ~768 columns on (a third of the cells again at half the sweep's rate).
         const bool forced = fpenv && fpenv[0] == '2'; // no shape rules (tests)
+        // Round 3: for big batches the path pays at ANY window length -- its plans are built on the device, the general path's on the host
+        // (~35 ns per pair: 400 000 pairs of 150 x 216 take 23.8 ms on the general path, 6.9 ms here; 50 x 128: 18.8 / 4.5 ms); small
+        // batches of short windows stay on the general path (4 000 pairs of 150 x 256: 0.41 / 0.47 ms).
+        const int64_t min_cols = n_pairs >= 8192 ? 32 : 768;
         auto key_of = [&](int64_t n, int64_t m) -> int {
             if (n < 1 || m < 1 || m > 0x3fffffff || (n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) return 0;
             const int64_t Sp = (n + H - 1) / H;
             if (Sp > FP_MAXS) return 0;
-            if (!forced && m < 768) return 0;
+            if (!forced && m < min_cols) return 0;
             return (int)Sp;
         };
         int64_t n_hi = 0, cntk[FP_MAXS + 1] = {0};
@@ -951,7 +965,11 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     bool hform = affine && prm->gap_open <= 0;
     if (getenv("GNX_NO_HFORM")) hform = false;
     const int Q = affine ? QA : QC;
-    std::vector<PairPlan> plans((size_t)n_pairs);
+    // the plans are built in pinned host memory kept by the context: a fresh std::vector of 96 B per pair costs a page fault per 42 pairs
+    // and an upload from pageable memory -- 400 000 pairs of 150 x 216: 16 of the call's 24 ms (round 3)
+    if ((rc = c.h_plans.ensure((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(PairPlan)))) return rc;
+    struct PlanSpan { PairPlan *p; PairPlan &operator[](size_t i) const { return p[i]; } PairPlan *data() const { return p; } };
+    const PlanSpan plans{reinterpret_cast<PairPlan *>(c.h_plans.p)};
     std::vector<int64_t> chunk_begin;
     int64_t cells = 0;
     {
@@ -1532,7 +1550,7 @@ void gnx_shutdown(void) {
                           &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
                           &c.sd_tmp[0], &c.sd_tmp[1], &c.sd_tmp[2], &c.sd_tmp[3], &c.sd_tmp[4], &c.sd_tmp[5], &c.sd_tmp[6], &c.sd_tmp[7]};
         for (DevBuf *b : bufs) b->release();
-        PinBuf *pins[] = {&c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};
+        PinBuf *pins[] = {&c.h_plans, &c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};
         for (PinBuf *b : pins) b->release();
         c.fpc_ptr = nullptr; c.ref_len = -1; c.sd_n = -1;
         for (int i = 0; i < 8; i++) if (c.ev[i]) { (void)hipEventDestroy(c.ev[i]); c.ev[i] = nullptr; }
