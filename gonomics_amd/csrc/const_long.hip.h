@@ -26,11 +26,13 @@ namespace {
 // bits fill_const_kernel would have stored; the walk itself (run merging, Step 4 with quirk Q2) is traceback_kernel<false>'s.
 // Memory per 20 kb x 100 kb pair: row buffer 50 MB + snapshots 19 MB + run staging 2 MB instead of 500 MB.
 // ------------------------------------------------------------------------------------------------------
-constexpr int CKC = 448;                          // snapshot spacing in wavefront steps (multiple of 16): the 4 tiles of a walk wave + its
-                                                  // int16 profile are 80 000 B of LDS, two workgroups per CU
-constexpr int CL_WORDS = CKC / 16;                // direction words per lane row and tile
+// Snapshot spacing in wavefront steps (multiple of 16), chosen per call (KParams::ckc; the walk kernel is compiled for both).  A small tile
+// means less to re-fill before the walk can look at its cell (on average half a tile) but more tiles per path, each with the fixed cost
+// of a round (profile, snapshot, boundary): while the walk is a latency chain -- fewer workgroups than the GPU holds two per SIMD -- 224
+// wins (ConstGap 250 .. 3200 x 10 000: walk stage -8 .. -27 %; 1024 pairs of C5: 41.4 -> 38.1 ms); with 2048 pairs of C5 resident the
+// walk is bound by its instruction count and 448 wins (42 against 50 ms).
+constexpr int CKC = 448, CKC_SMALL = 224;
 constexpr int SNAPW = 12;                         // dwords per lane per snapshot: val[R], diag0, pad
-constexpr int CL_DIRG = CL_WORDS * R * G + 16;    // LDS dwords of one pair's tile (+16: neighbouring pairs start in different banks)
 
 __device__ __forceinline__ void rb_store32(int *p, int v, bool piped) {
     if (piped && !GNX_RB_FENCE) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -208,8 +210,8 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
-            if (t0 > 0 && t0 % CKC == 0 && gact && t0 <= m_eff + 15) { // snapshot: the state the wave resumes from at step t0
-                uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / CKC - 1) * pl.strips + s) * G + l) * SNAPW);
+            if (t0 > 0 && t0 % kp.ckc == 0 && gact && t0 <= m_eff + 15) { // snapshot: the state the wave resumes from at step t0
+                uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / kp.ckc - 1) * pl.strips + s) * G + l) * SNAPW);
                 dst[0] = make_uint4((unsigned)val[0], (unsigned)val[1], (unsigned)val[2], (unsigned)val[3]);
                 dst[1] = make_uint4((unsigned)val[4], (unsigned)val[5], (unsigned)val[6], (unsigned)val[7]);
                 dst[2] = make_uint4((unsigned)val[8], (unsigned)val[9], (unsigned)diag0, 0u);
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // instead of two, and nobody waits for a neighbour.  Per round every pair (16 lanes) re-fills the tile its walk is in -- strip s = (i-1)/160, steps
 // (c*CKC, j + lane(i)] of that strip's wavefront -- into LDS, then lane 0 of the pair walks inside the tile until it leaves it.
 // Runs are staged in traceback order at scr[scr_off[p] ..] (n + m + 2 entries per pair); reverse_runs_kernel puts them in place.
-template <bool P16, int NP>
+template <bool P16, int NP, int CK>
 __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
@@ -292,14 +294,16 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
     // profile of NP pairs: the layout of ProfCfg (one or two duos), or, for a single pair, planes of its own 16 * LW dwords (a plane
     // stride of 80 or 160 dwords keeps the 16 lanes of one pair on 16 distinct banks whatever bases they look up)
     constexpr int LW = PC::LW, BST = NP == 1 ? G * LW : PC::BST, PTOT = NP == 1 ? 5 * BST : (NP == 2 ? PC::TOTAL / 2 : PC::TOTAL);
-    __shared__ int lds[32 + PTOT + NP * CL_DIRG];
+    static_assert(CK % 16 == 0 && CK <= CKC, "snapshot spacing");
+    constexpr int DIRG = (CK / 16) * R * G + 16; // LDS dwords of one pair's tile (+16: neighbouring pairs start in different banks)
+    __shared__ int lds[32 + PTOT + NP * DIRG];
     const int lane = threadIdx.x;
     const int g = lane >> 4, l = lane & 15;
     if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * kp.g4 + 1; // pre-tagged diagonal candidate (tag 3), see fill_const_kernel
     const int gl = g < NP ? g : 0; // (idle lane groups compute on pair 0's addresses and store nothing)
     int *prof = &lds[32 + (NP == 1 ? 0 : PC::pair_off(gl))];
     const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
-    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + PTOT + gl * CL_DIRG]);
+    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + PTOT + gl * DIRG]);
     const int p = blockIdx.x * NP + g;
     const bool valid = g < NP && p < n_pairs;
     PairPlan pl;
@@ -336,8 +340,8 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
         const int s = gact ? (ci - 1) / H : 0;
         const int lw = gact ? (ci - 1 - s * H) / R : 0;
         const int tend = gact ? cj + lw : 0;   // step of the cell the walk is at
-        const int c = gact ? (tend - 1) / CKC : 0;
-        const int tbeg = c * CKC;
+        const int c = gact ? (tend - 1) / CK : 0;
+        const int tbeg = c * CK;
         const int nblk = gact ? (tend - tbeg + 15) >> 4 : 0;
         int nblk_max = nblk;
         nblk_max = max(nblk_max, __shfl_xor(nblk_max, 16, 64));

@@ -103,6 +103,7 @@ struct Ctx {
     int index = 0;
     int device = -1;
     int64_t ws_limit = 0;
+    int n_cu = 256; // compute units of the device
     hipStream_t own_stream = nullptr, s_in = nullptr;
     DevBuf trace, hcol, rowbuf, dcol, plans, nops, misc;
     DevBuf strip_map, tb_scr, tb_scr_off, scan_tmp, fp_tail, fp_rowi, fp_ckpt, fp_states, fp_stage, fp_wplans[2], fp_active[2], fp_thcol, fp_ttrace, fp_redo, fp_strag, mx_idx, mx_tab, mx_score, mx_off, mx_ops, fp_prog;
@@ -161,6 +162,7 @@ int init_ctx(Ctx &c, int device, int64_t workspace_bytes) {
     HIPCHK(hipStreamCreateWithFlags(&c.s_in, hipStreamNonBlocking));
     for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c.ev_in[i], hipEventDisableTiming));
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c.n_cu = v; }
     if (workspace_bytes > 0) c.ws_limit = workspace_bytes;
     if (c.ws_limit <= 0) {
         size_t fr = 0, tot = 0;
@@ -203,6 +205,7 @@ int check_params(const gnx_params *p, KParams &kp, TbParams &tp, bool &affine, b
     kp.ecol4 = local ? 0 : kp.e4;
     kp.g4 = kp.o4;
     kp.rb_pub = RB_PUB;
+    kp.ckc = CKC_SMALL;
     tp.ci = lowmem ? p->checkersize_i : ((int64_t)1 << 62);
     tp.cj = lowmem ? p->checkersize_j : ((int64_t)1 << 62);
     tp.d00 = local ? 0 : p->gap_open;
@@ -569,6 +572,14 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
                      int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream) {
     Ctx &c = g_ctx;
     int rc;
+    // snapshot spacing of the constant-gap form (const_long.hip.h): the wide tiles only when the walk will have the GPU full of long chains
+    int64_t ckc = CKC_SMALL;
+    {
+        int64_t strips_sum = 0;
+        for (int64_t p = 0; p < n_pairs; p++) strips_sum += (h_alen[p] + H - 1) / H;
+        if (n_pairs > 1536 && strips_sum >= 64 * n_pairs) ckc = CKC;
+        if (const char *e = getenv("GNX_CL_CKC")) { const int v = atoi(e); if (v == CKC || v == CKC_SMALL) ckc = v; }
+    }
     std::vector<PairPlan> plans((size_t)n_pairs);
     std::vector<int64_t> so((size_t)n_pairs + 1, 0); // staging offsets (runs), chunk-relative; so[chunk end] is unused
     std::vector<int64_t> chunk_begin{0};
@@ -576,7 +587,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     {
         int64_t rb = 0, sn = 0, sc = 0;
         const int64_t budget = c.ws_limit - c.ws_limit / 16;
-        const int64_t rbw = affine ? 8 : 4, ck = affine ? CKA : CKC, snw = affine ? AL_SNAPW : SNAPW; // row-buffer entry bytes, snapshot spacing / dwords
+        const int64_t rbw = affine ? 8 : 4, ck = affine ? CKA : ckc, snw = affine ? AL_SNAPW : SNAPW; // row-buffer entry bytes, snapshot spacing / dwords
         auto bytes_of = [&](int64_t rb2, int64_t sn2, int64_t sc2) { return rbw * rb2 + 4 * sn2 + (int64_t)sizeof(gnx_cigar) * sc2; };
         for (int64_t p = 0; p < n_pairs; p++) {
             const int64_t n = h_alen[p], m = h_blen[p];
@@ -670,15 +681,16 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         // acknowledgement) behind the other waves and shortens the ramp -- 2048 pairs 437 -> 400 ms; a launch that does not fill the GPU
         // pays for every publish with its own latency (64 pairs of C5: 17.4 -> 19.2 ms) and keeps the coarse interval.
         KParams kps = kp;
+        kps.ckc = (int)ckc;
         kps.rb_pub = n_blocks >= 10240 ? 16 : RB_PUB;
         if (const char *e = getenv("GNX_CL_PUB")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) kps.rb_pub = v; }
         int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
         if (affine && p16) hipLaunchKernelGGL(al_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
         else if (affine) hipLaunchKernelGGL(al_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
         else if (p16 && piped) hipLaunchKernelGGL(cl_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
-        else if (p16) hipLaunchKernelGGL(cl_sweep_flat_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err);
+        else if (p16) hipLaunchKernelGGL(cl_sweep_flat_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err);
         else if (piped) hipLaunchKernelGGL(cl_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
-        else hipLaunchKernelGGL(cl_sweep_flat_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb, dsn, dhf, d_err);
+        else hipLaunchKernelGGL(cl_sweep_flat_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
         const dim3 gridW((unsigned)((np + 3) / 4));
@@ -689,10 +701,29 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             const char *npe = getenv("GNX_CL_WALK_NP");
             const int wnp = (npe && (npe[0] == '2' || npe[0] == '4')) ? npe[0] - '0' : 1;
             const dim3 gw((unsigned)((np + wnp - 1) / wnp));
-#define GNX_CLW(P, N) hipLaunchKernelGGL((cl_walk_kernel<P, N>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err)
-            if (p16) { if (wnp == 1) GNX_CLW(true, 1); else if (wnp == 2) GNX_CLW(true, 2); else GNX_CLW(true, 4); }
-            else { if (wnp == 1) GNX_CLW(false, 1); else if (wnp == 2) GNX_CLW(false, 2); else GNX_CLW(false, 4); }
-#undef GNX_CLW
+            // A launch of fewer workgroups than the GPU holds is placed greedily: 1024 one-pair workgroups at 8 per CU land on half of the
+            // CUs.  The walk is a latency chain per pair, so the workgroups are spread instead -- by asking for as much (unused) dynamic
+            // LDS as makes exactly ceil(workgroups / CUs) of them fit a CU (LDS is handed out in granules of 1280 B).
+            auto launch_walk = [&](auto kern) {
+                size_t pad = 0;
+                hipFuncAttributes fa;
+                if (!getenv("GNX_NO_SPREAD") && hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess) {
+                    const size_t stat = fa.sharedSizeBytes, per_cu = ((size_t)gw.x + (size_t)c.n_cu - 1) / (size_t)c.n_cu;
+                    const size_t want = std::min<size_t>(((size_t)160 * 1024 / std::max<size_t>(per_cu, 1)) / 1280 * 1280, (size_t)64 * 1024);
+                    if (want >= (stat + 1279) / 1280 * 1280 + 1280) pad = want - stat;
+                }
+                hipLaunchKernelGGL(kern, gw, dim3(64), pad, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
+            };
+            const bool wide = ckc == CKC;
+            if (p16) {
+                if (wnp == 1) { if (wide) launch_walk(cl_walk_kernel<true, 1, CKC>); else launch_walk(cl_walk_kernel<true, 1, CKC_SMALL>); }
+                else if (wnp == 2) { if (wide) launch_walk(cl_walk_kernel<true, 2, CKC>); else launch_walk(cl_walk_kernel<true, 2, CKC_SMALL>); }
+                else { if (wide) launch_walk(cl_walk_kernel<true, 4, CKC>); else launch_walk(cl_walk_kernel<true, 4, CKC_SMALL>); }
+            } else {
+                if (wnp == 1) { if (wide) launch_walk(cl_walk_kernel<false, 1, CKC>); else launch_walk(cl_walk_kernel<false, 1, CKC_SMALL>); }
+                else if (wnp == 2) { if (wide) launch_walk(cl_walk_kernel<false, 2, CKC>); else launch_walk(cl_walk_kernel<false, 2, CKC_SMALL>); }
+                else { if (wide) launch_walk(cl_walk_kernel<false, 4, CKC>); else launch_walk(cl_walk_kernel<false, 4, CKC_SMALL>); }
+            }
         }
         HIPCHK(hipGetLastError());
         if ((rc = launch_scan(dn, np, d_ops_off + b, d_carry, stream))) return rc;
@@ -706,7 +737,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         fill_ms += f1; tb_ms += f2;
         for (int64_t p = b; p < e; p++) {
             const PairPlan &pl = plans[(size_t)p];
-            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + 15) / (affine ? CKA : CKC)) * pl.strips * G * (affine ? AL_SNAPW : SNAPW);
+            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + 15) / (affine ? CKA : ckc)) * pl.strips * G * (affine ? AL_SNAPW : SNAPW);
         }
     }
     HIPCHK(hipEventRecord(c.ev[2], stream));

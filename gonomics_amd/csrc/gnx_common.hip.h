@@ -71,6 +71,7 @@ struct KParams {
     int d00_4;   // 4*D(0,0): gapOpen, or 0 with free end gaps
     int ecol4;   // 4*(column-0 extension): gapExtend, or 0 with free end gaps
     int g4;      // const gap: 4*gapPen
+    int ckc;     // cl_sweep_kernel: snapshot spacing in steps (CKC or CKC_SMALL, set per call)
     int rb_pub;  // cl_sweep_kernel: piped strips publish their bottom row every rb_pub steps (power of two, multiple of 16; set per launch)
     // beta = windows of the PACKED resident reference (gnx_set_reference; all null: plain dna.Base bytes in b_buf):
     const unsigned *b2;              // 2 bits per base, 16 bases per dword (base k: bits 2*(k & 15) of word k >> 4); A C G T = 0 1 2 3

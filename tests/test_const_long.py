@@ -51,11 +51,15 @@ def test_const_long_fuzz(gpu_lib, monkeypatch, mode, cs):
             common.assert_same(got, exp, "seed %d %s" % (seed, name))
 
 
+@pytest.mark.parametrize("ckc", ["", "224", "448"])
 @pytest.mark.parametrize("nopipe", [False, True])
-def test_const_long_strips_and_chunks(gpu_lib, monkeypatch, nopipe):
-    """pipelined strips vs one wave per group of 4, and a workspace small enough to split the batch into several launches"""
+def test_const_long_strips_and_chunks(gpu_lib, monkeypatch, nopipe, ckc):
+    """pipelined strips vs one wave per group of 4, both snapshot spacings (the sweep and the walk must agree on it: GNX_CL_CKC),
+    and a workspace small enough to split the batch into several launches"""
     if nopipe:
         monkeypatch.setenv("GNX_NO_PIPE", "1")
+    if ckc:
+        monkeypatch.setenv("GNX_CL_CKC", ckc)
     alphas, betas = _ragged(21, 23, 2500, 6000)
     exp = oracle.align_batch(1, MX["HumanChimpTwo"], -430, 0, alphas, betas, 1000, 1000, threads=8)
     p = gpu_lib.make_params(gpu_lib.GNX_CONST_GAP, MX["HumanChimpTwo"], -430, 0, 1000, 1000)
