@@ -682,7 +682,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         // pays for every publish with its own latency (64 pairs of C5: 17.4 -> 19.2 ms) and keeps the coarse interval.
         KParams kps = kp;
         kps.ckc = (int)ckc;
-        kps.rb_pub = n_blocks >= 10240 ? 16 : RB_PUB;
+        kps.rb_pub = n_blocks >= (int64_t)40 * c.n_cu ? 16 : RB_PUB; // (twice the wave slots of the piped sweep: 20 per CU)
         if (const char *e = getenv("GNX_CL_PUB")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) kps.rb_pub = v; }
         int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
         if (affine && p16) hipLaunchKernelGGL(al_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
@@ -701,18 +701,9 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             const char *npe = getenv("GNX_CL_WALK_NP");
             const int wnp = (npe && (npe[0] == '2' || npe[0] == '4')) ? npe[0] - '0' : 1;
             const dim3 gw((unsigned)((np + wnp - 1) / wnp));
-            // A launch of fewer workgroups than the GPU holds is placed greedily: 1024 one-pair workgroups at 8 per CU land on half of the
-            // CUs.  The walk is a latency chain per pair, so the workgroups are spread instead -- by asking for as much (unused) dynamic
-            // LDS as makes exactly ceil(workgroups / CUs) of them fit a CU (LDS is handed out in granules of 1280 B).
+            // (padding the workgroups' LDS so that a launch smaller than the GPU spreads over all CUs changes nothing: the dispatcher already does)
             auto launch_walk = [&](auto kern) {
-                size_t pad = 0;
-                hipFuncAttributes fa;
-                if (!getenv("GNX_NO_SPREAD") && hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess) {
-                    const size_t stat = fa.sharedSizeBytes, per_cu = ((size_t)gw.x + (size_t)c.n_cu - 1) / (size_t)c.n_cu;
-                    const size_t want = std::min<size_t>(((size_t)160 * 1024 / std::max<size_t>(per_cu, 1)) / 1280 * 1280, (size_t)64 * 1024);
-                    if (want >= (stat + 1279) / 1280 * 1280 + 1280) pad = want - stat;
-                }
-                hipLaunchKernelGGL(kern, gw, dim3(64), pad, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
+                hipLaunchKernelGGL(kern, gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
             };
             const bool wide = ckc == CKC;
             if (p16) {
