@@ -592,6 +592,47 @@ def test_fast_path_mixed_read_lengths(gpu_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["global", "lowmem", "local"])
+def test_fast_path_big_batch_short_windows(gpu_lib, mode):
+    """batches of >= 8192 pairs take the fast path at ANY window length (run_device: min_cols 32; the general path's host-built plans
+    cost more than its kernels there): 9000 pairs with windows of 32 .. 400 columns and reads of 1 .. 200 bases (one and two row
+    blocks, reads longer than their window, windows with N), natural routing, against the oracle; windows below 32 columns in the
+    same batch go the general way and come back in input order"""
+    rng = np.random.default_rng(123)
+    n_pairs, L = 9000, 3000
+    ref = rng.integers(0, 4, size=L, dtype=np.uint8)
+    ref[rng.integers(0, L, size=12)] = 4
+    lens = rng.integers(1, 201, size=n_pairs).astype(np.int64)
+    b_len = rng.choice([32, 33, 47, 64, 100, 150, 216, 256, 400], size=n_pairs).astype(np.int64)
+    b_len[::500] = rng.integers(1, 32, size=len(b_len[::500]))
+    b_start = rng.integers(0, L - b_len + 1).astype(np.int64)
+    a_start = np.zeros(n_pairs, dtype=np.int64)
+    a_start[1:] = np.cumsum(lens)[:-1]
+    reads = np.empty(int(lens.sum()), dtype=np.uint8)
+    for k in range(n_pairs):
+        n, m = int(lens[k]), int(b_len[k])
+        src = ref[b_start[k]:b_start[k] + m]
+        s0 = int(rng.integers(0, max(m - n, 0) + 1))
+        seg = src[s0:s0 + n].copy()
+        if len(seg) < n:
+            seg = np.concatenate([seg, rng.integers(0, 4, size=n - len(seg), dtype=np.uint8)])
+        flip = rng.random(n) < 0.06
+        seg[flip] = rng.integers(0, 4, size=int(flip.sum()), dtype=np.uint8)
+        reads[a_start[k]:a_start[k] + n] = seg
+    if mode == "local":  # AffineGapLocal(target = window, query = read): the transposed fast path
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_LOCAL, MX["HumanChimpTwo"], -600, -150)
+        got = gpu_lib.align_batch_windows(p, ref, b_start, b_len, reads, a_start, lens)
+        exp = oracle.align_batch_windows(gpu_lib.GNX_AFFINE_GAP_LOCAL, MX["HumanChimpTwo"], -600, -150, ref, b_start, b_len, reads, a_start, lens, threads=8)
+    else:
+        ck = (7, 7) if mode == "lowmem" else (10000, 10000)
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150, *ck)
+        got = gpu_lib.align_batch_windows(p, reads, a_start, lens, ref, b_start, b_len)
+        exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads, a_start, lens, ref, b_start, b_len, *ck, threads=8)
+    assert gpu_lib.get_timing()["fast_path"] == 1
+    common.assert_same(got, exp, "big batch of short windows, " + mode)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed,n_lo,n_hi", [(61, 321, 480), (62, 481, 640), (63, 1441, 1600), (64, 700, 800), (65, 3041, 3200)])
 def test_fast_path_many_row_blocks(gpu_lib, seed, n_lo, n_hi, monkeypatch):
     """reads of 321 .. 3200 bases on the fast path: a top block, middle blocks (fp_sweep_kernel<20, false, 3>: take the row above from the
