@@ -138,6 +138,7 @@ thread_local Ctx *t_ctx = nullptr;
 // set while a call is re-run with sequential strips after a pipelined launch timed out waiting for a row buffer (a bug trap: nobody
 // waits for an item that has not been claimed, claim_items; should the trap ever fire, the call still returns right results)
 thread_local bool t_no_pipe = false;
+thread_local int64_t t_min_cols = 0; // != 0: the fast path takes windows of at least this many columns (set by a mixed batch for its groups, see run_device)
 bool no_pipe() { return t_no_pipe || getenv("GNX_NO_PIPE") != nullptr; }
 Ctx &ctx_at(int k) {
     std::lock_guard<std::mutex> lk(g_ctxs_mu);
@@ -819,7 +820,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // Round 3: for big batches the path pays at ANY window length -- its plans are built on the device, the general path's on the host
         // (~35 ns per pair: 400 000 pairs of 150 x 216 take 23.8 ms on the general path, 6.9 ms here; 50 x 128: 18.8 / 4.5 ms); small
         // batches of short windows stay on the general path (4 000 pairs of 150 x 256: 0.41 / 0.47 ms).
-        const int64_t min_cols = n_pairs >= 8192 ? 32 : 768;
+        const int64_t min_cols = t_min_cols ? t_min_cols : (n_pairs >= 8192 ? 32 : 768); // (t_min_cols: the rule of the whole batch, for the groups of a mixed one)
         auto key_of = [&](int64_t n, int64_t m) -> int {
             if (n < 1 || m < 1 || m > 0x3fffffff || (n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) return 0;
             const int64_t Sp = (n + H - 1) / H;
@@ -868,8 +869,11 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
                 HIPCHK(hipGetLastError());
                 obase[k] = std::min(tot_all, ops_capacity);
                 int64_t tg = 0;
+                const int64_t outer_min_cols = t_min_cols;
+                t_min_cols = min_cols;
                 rc = run_device(prm, ng, d_a, gas, d_b, gbs, hal[k].data(), hbl[k].data(), gsc, reinterpret_cast<gnx_cigar *>(c.mx_ops.p) + obase[k], ops_capacity - obase[k], goff, &tg, stream,
                                 nullptr, nullptr, 0, nullptr, k == 0, false);
+                t_min_cols = outer_min_cols;
                 if (rc == GNX_ECAPACITY) capfail = true;
                 else if (rc) return rc;
                 tot_all += tg;
@@ -981,6 +985,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         }
     }
     // ---- plan ----
+    const auto t_plan0 = std::chrono::steady_clock::now();
     bool p16 = true; // 4*score fits a signed 16-bit profile entry
     for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * (affine ? prm->gap_extend : 0)); if (v > 32767 || v < -32768) p16 = false; }
     if (!getenv("GNX_FORCE_P16")) p16 = false; // int32 profile: plain 2-cycle VGPR add instead of a 4-cycle SDWA add
@@ -1062,6 +1067,8 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
     HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
     HIPCHK(hipMemcpyAsync(c.plans.p, plans.data(), (size_t)n_pairs * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
+    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx] general path: %lld pairs, plans built and queued in %.3f ms on the host\n", (long long)n_pairs,
+                                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count());
 
     // ---- launches ----
     double fill_ms = 0, tb_ms = 0;
