@@ -963,11 +963,12 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     if (!gsw && !d_smat && !local && (!affine || (prm->gap_open <= 0 && !getenv("GNX_NO_HFORM")))) { // (GNX_CLONG also governs the affine form, affine_long.hip.h)
         const char *cl = getenv("GNX_CLONG");
         bool use = !(cl && cl[0] == '0'), any_multi = false;
-        long double cells_ld = 0, dir_bytes = 0;
+        long double cells_ld = 0, dir_bytes = 0, rows_ld = 0, cols_ld = 0;
         for (int64_t p = 0; use && p < n_pairs; p++) {
             if (h_alen[p] < 1 || h_blen[p] < 1) use = false;
             if (h_alen[p] > H) any_multi = true;
             cells_ld += (long double)h_alen[p] * h_blen[p];
+            rows_ld += (long double)h_alen[p]; cols_ld += (long double)h_blen[p];
             dir_bytes += (long double)((h_alen[p] + H - 1) / H) * ((h_blen[p] + 30) / 16) * (affine ? QA : QC) * G * 16;
         }
         // It pays when the pairs are big: the sweep saves ~1.3e-13 s per cell against the recording fill, the fused re-fill + walk
@@ -979,7 +980,11 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // (Since the fast path's row blocks take the batches of pairs x blocks >= 8192, what reaches this point with the affine functions
         // is small batches, and there the stored matrix wins -- 256 x (3200 x 10 000): 5.96 ms against 10.2 ms: affine only when the matrix does not fit.)
         const bool big = (cells_ld >= 2.0e6L * (long double)n_pairs && !affine) || dir_bytes > (long double)c.ws_limit;
-        if (use && ((any_multi && big) || (cl && cl[0] == '2'))) {
+        // Round 3 (one pair per walk workgroup, tiles of 224 steps): short reads against LONG windows gain as well -- the sweep saves
+        // ~8.5e-14 s per cell, the walk costs ~7e-8 s per pair plus ~1e-11 s per column: ConstGap 150 x 10 000 18.6 -> 16.1 ms per 65 536
+        // pairs (1000 pairs: 1.81 -> 1.25 ms), but 150 x 2000, 500 x 600 and 1000 x 1200 lose 1.4 .. 2.6 x and stay on the stored matrix.
+        const bool long_windows = !affine && cells_ld >= 1.4e6L * (long double)n_pairs && cols_ld >= 48.0L * rows_ld;
+        if (use && ((any_multi && big) || long_windows || (cl && cl[0] == '2'))) {
             rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
             if (rc != -1) return rc;
         }

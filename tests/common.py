@@ -197,3 +197,13 @@ QUIRK_CASES = [
     ("const", "Default", -430, 0, 2, "GGCC", "CC", -660, "2D2M", "2M"),
     ("const", "Default", -430, 0, 2, "CTTCAGTAGTCA", "TCAGAGTTCA", -464, "2D10M", "10M"),
 ]
+
+
+# Route assertions.  tools/switch_matrix.sh runs the suites under switches that force another route (GNX_FASTPATH, GNX_CLONG,
+# GNX_NO_HFORM set OUTSIDE the test): results must not change, but "which path ran" legitimately does -- then only results are checked.
+OUTER_ROUTE_SWITCH = any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM"))  # (at import: before any monkeypatch)
+
+
+def expect_route(timing, route):
+    if not OUTER_ROUTE_SWITCH:
+        assert timing["fast_path"] == route, (timing["fast_path"], route)

@@ -46,7 +46,7 @@ def test_const_long_fuzz(gpu_lib, monkeypatch, mode, cs):
         for name, g in (("Default", -430), ("HumanChimpTwo", -430), ("HoxD55", -100)):
             p = gpu_lib.make_params(mode, MX[name], g, 0, cs, cs)
             got = gpu_lib.align_batch(p, alphas, betas)
-            assert gpu_lib.get_timing()["fast_path"] == 2
+            common.expect_route(gpu_lib.get_timing(), 2)
             exp = oracle.align_batch(mode, MX[name], g, 0, alphas, betas, cs, cs, threads=8)
             common.assert_same(got, exp, "seed %d %s" % (seed, name))
 
@@ -56,6 +56,8 @@ def test_const_long_fuzz(gpu_lib, monkeypatch, mode, cs):
 def test_const_long_strips_and_chunks(gpu_lib, monkeypatch, nopipe, ckc):
     """pipelined strips vs one wave per group of 4, both snapshot spacings (the sweep and the walk must agree on it: GNX_CL_CKC),
     and a workspace small enough to split the batch into several launches"""
+    if os.environ.get("GNX_CLONG") == "0":
+        pytest.skip("the snapshot path is switched off from outside: nothing to compare here")
     if nopipe:
         monkeypatch.setenv("GNX_NO_PIPE", "1")
     if ckc:
@@ -64,7 +66,7 @@ def test_const_long_strips_and_chunks(gpu_lib, monkeypatch, nopipe, ckc):
     exp = oracle.align_batch(1, MX["HumanChimpTwo"], -430, 0, alphas, betas, 1000, 1000, threads=8)
     p = gpu_lib.make_params(gpu_lib.GNX_CONST_GAP, MX["HumanChimpTwo"], -430, 0, 1000, 1000)
     got = gpu_lib.align_batch(p, alphas, betas)
-    assert gpu_lib.get_timing()["fast_path"] == 2
+    common.expect_route(gpu_lib.get_timing(), 2)
     common.assert_same(got, exp)
     gpu_lib.check(gpu_lib.lib().gnx_init(0, 1 << 20))
     try:
@@ -142,7 +144,8 @@ def test_c5_full_size(gpu_lib):
         got_hi = gpu_lib.align_batch(ph, reads[2:3], wins[2:3])
     finally:
         gpu_lib.check(gpu_lib.lib().gnx_init(0, 8 << 30))
-    assert tm["fast_path"] == 2 and tm["n_launches"] == 1  # 259 pairs in ONE launch (a stored direction matrix would need 130 GB)
+    common.expect_route(tm, 2)
+    assert common.OUTER_ROUTE_SWITCH or tm["n_launches"] == 1  # 259 pairs in ONE launch (a stored direction matrix would need 130 GB)
     k = int(exp[2][-1])
     assert np.array_equal(score[:3], exp[0]) and np.array_equal(off[:4], exp[2])
     assert np.array_equal(ops["run_length"][:k], exp[1]["run_length"]) and np.array_equal(ops["op"][:k], exp[1]["op"])
@@ -176,7 +179,7 @@ def test_affine_long_fuzz(gpu_lib, monkeypatch, mode, cs):
         for name, go, ge in (("Default", -400, -30), ("HumanChimpTwo", -600, -150), ("HoxD55", 0, -40)):
             p = gpu_lib.make_params(mode, MX[name], go, ge, cs, cs)
             got = gpu_lib.align_batch(p, alphas, betas)
-            assert gpu_lib.get_timing()["fast_path"] == 2
+            common.expect_route(gpu_lib.get_timing(), 2)
             exp = oracle.align_batch(mode, MX[name], go, ge, alphas, betas, cs, cs, threads=8)
             common.assert_same(got, exp, "seed %d %s" % (seed, name))
 
@@ -197,19 +200,21 @@ def test_affine_long_big_pairs(gpu_lib, monkeypatch):
     exp1 = oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, [a], [b])
     monkeypatch.setenv("GNX_CLONG", "2")
     got = gpu_lib.align_batch(p, alphas, betas)
-    assert gpu_lib.get_timing()["fast_path"] == 2
+    common.expect_route(gpu_lib.get_timing(), 2)
     common.assert_same(got, exp)
     got = gpu_lib.align_batch(p, [a], [b])
-    assert gpu_lib.get_timing()["fast_path"] == 2
+    common.expect_route(gpu_lib.get_timing(), 2)
     common.assert_same(got, exp1)
     monkeypatch.delenv("GNX_CLONG")
     got = gpu_lib.align_batch(p, [a], [b])
-    assert gpu_lib.get_timing()["fast_path"] == 0  # one pair: the stored matrix (73 MB) and the wave-cooperative walk
+    common.expect_route(gpu_lib.get_timing(), 0)  # one pair: the stored matrix (73 MB) and the wave-cooperative walk
     common.assert_same(got, exp1)
+    if "GNX_NO_HFORM" in os.environ or os.environ.get("GNX_CLONG") == "0":
+        return  # (the snapshot path is switched off from outside: a 32 MB workspace is then, rightly, GNX_ENOMEM)
     gpu_lib.check(gpu_lib.lib().gnx_init(0, 32 << 20))
     try:
         got = gpu_lib.align_batch(p, [a], [b])
-        assert gpu_lib.get_timing()["fast_path"] == 2  # ... unless it does not fit the workspace
+        common.expect_route(gpu_lib.get_timing(), 2)  # ... unless it does not fit the workspace
     finally:
         gpu_lib.check(gpu_lib.lib().gnx_init(0, 8 << 30))
     common.assert_same(got, exp1)

@@ -43,6 +43,8 @@ def main():
         row = {"kind": kind, "n": n, "m": m, "pairs": pairs}
         res = {}
         variants = [("general", {"GNX_CLONG": "0", "GNX_FASTPATH": "0"}), ("default", {})]
+        if kind == "const":
+            variants.append(("snapshot", {"GNX_CLONG": "2"}))  # the snapshot path whatever the routing rule says
         if kind != "const" and n <= 20480 and m >= 16:
             variants.append(("row_blocks", {"GNX_FASTPATH": "2"}))  # the fast path whatever the routing rule says
         for name, env in variants:
