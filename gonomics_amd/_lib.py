@@ -18,7 +18,7 @@ EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gn
            "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing",
            "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch",
            "gnx_init_devices", "gnx_n_devices", "gnx_set_reference", "gnx_set_reference_synthetic", "gnx_align_batch_by_offset",
-           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch", "gnx_debug_occupy", "gnx_reference_info"]
+           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch", "gnx_debug_occupy", "gnx_debug_counter", "gnx_reference_info"]
 
 
 class GnxCigar(ctypes.Structure):
@@ -109,8 +109,17 @@ def lib():
         if hasattr(L, "gnx_debug_occupy"):  # (absent from older builds loaded through GNX_LIB_PATH for A/B runs)
             L.gnx_debug_occupy.argtypes = [ctypes.c_int, ctypes.c_int]
             L.gnx_debug_occupy.restype = ctypes.c_int
+        if hasattr(L, "gnx_debug_counter"):
+            L.gnx_debug_counter.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+            L.gnx_debug_counter.restype = ctypes.c_int
         _lib = L
     return _lib
+
+
+def debug_counter(which=0, reset=True):
+    v = ctypes.c_int64()
+    check(lib().gnx_debug_counter(which, 1 if reset else 0, ctypes.byref(v)))
+    return int(v.value)
 
 
 def check(rc):
@@ -168,6 +177,46 @@ def align_batch_windows(params, a_buf, a_start, a_len, b_buf, b_start, b_len):
                                     scores.ctypes.data, ctypes.byref(ops_p), ctypes.byref(off_p)))
     ops, off = _take(ops_p, off_p, n)
     return scores[:n], ops, off
+
+
+class RawResult:
+    """Results of a host-buffer call as the C ABI hands them over: `scores` is the caller's array, `ops` / `off` are VIEWS of the
+    pinned arrays the library returned (no copy -- what a cgo shim wraps with unsafe.Slice); free() gives them back (gnx_free)."""
+
+    def __init__(self, scores, ops_p, off_p, n):
+        self.scores, self._ops_p, self._off_p, self.n = scores, ops_p, off_p, n
+        self.off = np.ctypeslib.as_array(ctypes.cast(off_p, ctypes.POINTER(ctypes.c_int64)), shape=(n + 1,))
+        total = int(self.off[-1])
+        if total:
+            buf = (ctypes.c_char * (total * 16)).from_address(ops_p.value)
+            self.ops = np.frombuffer(buf, dtype=CIGAR_DTYPE, count=total)
+        else:
+            self.ops = np.zeros(0, dtype=CIGAR_DTYPE)
+
+    def copy(self):
+        return self.scores[:self.n].copy(), self.ops.copy(), self.off.copy()
+
+    def free(self):
+        if self._ops_p is not None:
+            L = lib()
+            self.ops = self.off = None
+            L.gnx_free(self._ops_p)
+            L.gnx_free(self._off_p)
+            self._ops_p = self._off_p = None
+
+
+def align_batch_windows_raw(params, a_buf, a_start, a_len, b_buf, b_start, b_len, scores=None):
+    """gnx_align_batch_windows without the binding's extra copy of the results (arguments must already be contiguous uint8 / int64
+    arrays).  Returns a RawResult; call .free() when done."""
+    L = lib()
+    n = int(a_start.shape[0])
+    if scores is None:
+        scores = np.zeros(max(n, 1), dtype=np.int64)
+    ops_p, off_p = ctypes.c_void_p(), ctypes.c_void_p()
+    check(L.gnx_align_batch_windows(ctypes.byref(params), n, a_buf.ctypes.data, a_buf.shape[0], a_start.ctypes.data, a_len.ctypes.data,
+                                    b_buf.ctypes.data, b_buf.shape[0], b_start.ctypes.data, b_len.ctypes.data,
+                                    scores.ctypes.data, ctypes.byref(ops_p), ctypes.byref(off_p)))
+    return RawResult(scores, ops_p, off_p, n)
 
 
 def init_devices(devices=None, workspace_bytes=0):

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict
     cl_sweep_body<P16, true>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, strip_map, strip_prog);
 }
 template <bool P16>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void cl_sweep_flat_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P16 ? 4 : 3, P16 ? 4 : 3))) void cl_sweep_flat_kernel( // (the int32 profile form needs 3 waves' worth of registers; GNX_CL_P16=0 only)
     const PairPlan *__restrict__ plans, int n_pairs, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
     const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap,
     int *__restrict__ hfin, int *__restrict__ err) {

@@ -244,9 +244,9 @@ __global__ __launch_bounds__(64) void occupy_kernel(long long ticks) {
 // GNX_TICKET_DELAY=k (tests): the lower half of a piped grid sleeps k x 127 x 64 cycles before it claims its items (claim_items), so the
 // upper half finds its predecessors unclaimed and runs them itself.  sw = the switch word behind the claim words (already zeroed).
 int claim_test_switch(int *sw, hipStream_t st) {
-    const char *e = getenv("GNX_TICKET_DELAY");
+    const char *e = getenv("GNX_TICKET_DELAY"), *g = getenv("GNX_CLAIM_GRACE_US"); // (grace: only together with a delay, see claim_items)
     if (!e || !*e) return GNX_OK;
-    const int v = atoi(e);
+    const int v = (std::min(std::max(atoi(e), 0), 0xffff)) | ((g && *g) ? (std::min(std::max(atoi(g), 1), 0x7fff) << 16) : 0);
     HIPCHK(hipMemcpyAsync(sw, &v, 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     return GNX_OK;
@@ -369,7 +369,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
             const int W = (int)grid8.x;
             int *prog = reinterpret_cast<int *>(c.fp_prog.p);
             if (!no_pipe()) {
-                HIPCHK(hipMemsetAsync(prog, 0, ((size_t)S * W * 2 + 1) * 4, st)); // progress words, claim words, test switch
+                HIPCHK(hipMemsetAsync(prog, 0, ((size_t)S * W * 2 + 2) * 4, st)); // progress words, claim words, test switch
                 if ((rc = claim_test_switch(prog + (size_t)S * W * 2, st))) return rc;
                 hipLaunchKernelGGL(klev, dim3((unsigned)(S * W)), blockF, 0, st, dpl + p0, cnt, d_a, d_as, d_b, d_bs, kp, d_hfwd, d_ckpt, d_rowi, d_tail, d_err, rb, S, W, 0, 1, prog);
                 HIPCHK(hipGetLastError());
@@ -1530,11 +1530,8 @@ int gnx_init_devices(int n_devices, const int *devices, int64_t workspace_bytes)
         if (devs[(size_t)k] < 0 || devs[(size_t)k] >= cnt) { set_err("device index out of range%s", ""); return GNX_EINVAL; }
         for (int q = 0; q < k; q++) if (devs[(size_t)q] == devs[(size_t)k]) distinct = false;
     }
-    if (!g_rccl.comms.empty()) { // a previous set of devices: drop its communicators
-        for (ncclComm_t cm : g_rccl.comms) (void)g_rccl.CommDestroy(cm);
-        g_rccl.comms.clear();
-    }
-    g_rccl_broken = false;
+    if (!g_rccl.comms.empty()) rccl_drop_comms(); // a previous set of devices: drop its communicators
+    // (g_rccl_broken stays: after a RCCL failure the process uses peer copies until gnx_shutdown)
     for (int k = 0; k < n_devices; k++) {
         Ctx &c = ctx_at(k);
         CtxScope sc(c);
@@ -1551,7 +1548,7 @@ int gnx_init_devices(int n_devices, const int *devices, int64_t workspace_bytes)
     // RCCL communicators, one per context (all in this process).  GNX_RCCL=0: plain peer copies; GNX_RCCL=1: also for one device
     // (a 1-rank communicator: every RCCL call of the flow still runs, which is what a 1-GPU box can check of the plumbing)
     const char *re = getenv("GNX_RCCL");
-    const bool want = distinct && !(re && re[0] == '0') && (n_devices > 1 || (re && re[0] == '1'));
+    const bool want = !g_rccl_broken && distinct && !(re && re[0] == '0') && (n_devices > 1 || (re && re[0] == '1'));
     if (want) {
         int rc = rccl_load();
         if (rc) return rc;
@@ -1567,8 +1564,7 @@ int gnx_n_devices(void) { std::lock_guard<std::mutex> api(g_api_mu); return g_nc
 
 void gnx_shutdown(void) {
     std::lock_guard<std::mutex> api(g_api_mu);
-    for (ncclComm_t cm : g_rccl.comms) (void)g_rccl.CommDestroy(cm);
-    g_rccl.comms.clear();
+    rccl_drop_comms();
     int n;
     { std::lock_guard<std::mutex> lk(g_ctxs_mu); n = (int)g_ctxs.size(); }
     for (int k = 0; k < n; k++) {
@@ -1830,9 +1826,9 @@ int gnx_seed_index_build(const uint8_t *node_cat, const int64_t *node_off, int64
     HIPCHK(hipGetLastError());
     size_t tmp_bytes = 0;
     if (n_kmers > 0x7ffffff0) { set_err("too many k-mers for one sort%s", ""); return GNX_EINVAL; }
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ck, sk, cl, sl, (int)n_kmers, 0, 2 * seed_len, st));
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ck, sk, cl, sl, (size_t)n_kmers, 0u, (unsigned)(2 * seed_len), st));
     if ((rc = t[1].ensure(tmp_bytes + 16))) return rc; // (the per-slot keys are compacted by now)
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(t[1].p, tmp_bytes, ck, sk, cl, sl, (int)n_kmers, 0, 2 * seed_len, st)); // stable: insertion order within a key
+    HIPCHK(rocprim::radix_sort_pairs(t[1].p, tmp_bytes, ck, sk, cl, sl, (size_t)n_kmers, 0u, (unsigned)(2 * seed_len), st)); // stable LSD radix sort: insertion order within a key
     uint64_t *hk = (uint64_t *)malloc((size_t)n_kmers * 8), *hl = (uint64_t *)malloc((size_t)n_kmers * 8);
     if (!hk || !hl) { free(hk); free(hl); set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
     if (hipMemcpyAsync(hk, sk, (size_t)n_kmers * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(hl, sl, (size_t)n_kmers * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -1943,19 +1939,39 @@ int gnx_seed_find_batch(const uint8_t *read_cat, const int64_t *read_off, int64_
     return GNX_OK;
 }
 
-/* diagnostics: n_workgroups workgroups that each hold a whole CU's LDS and spin for `milliseconds`, on a stream of their own; returns
+/* diagnostics (refused unless the process runs with GNX_DEBUG_ENTRY=1: a production caller cannot park the GPU by accident):
+ * n_workgroups workgroups that each hold a whole CU's LDS and spin for `milliseconds`, on a stream of their own; returns
  * at once.  The stress leg of the claim protocol (tests/test_ticket.py): piped launches must finish with half the CUs taken away. */
 int gnx_debug_occupy(int n_workgroups, int milliseconds) {
     std::lock_guard<std::mutex> api(g_api_mu);
     CtxScope sc(ctx_at(0));
     g_err[0] = 0;
+    if (!getenv("GNX_DEBUG_ENTRY")) { set_err("gnx_debug_occupy is a test hook: set GNX_DEBUG_ENTRY=1%s", ""); return GNX_EINVAL; }
     int rc = ensure_init();
     if (rc) return rc;
     if (n_workgroups <= 0 || milliseconds < 0 || milliseconds > 10000) { set_err("bad argument%s", ""); return GNX_EINVAL; }
-    static bool attr_set = false;
-    if (!attr_set) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    // (function attributes are per device: set on every call -- a process may have gone through gnx_shutdown and another device)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)n_workgroups), dim3(64), 160 * 1024, g_ctx.s_in, (long long)milliseconds * 100000LL);
     HIPCHK(hipGetLastError());
+    return GNX_OK;
+}
+
+/* diagnostics: counters kept on context 0's device.  which = 0: items of piped launches that were run by a workgroup other than
+ * their own since the last reset (claim_items: the abnormal path the tests force); reset != 0 zeroes it after reading. */
+int gnx_debug_counter(int which, int reset, int64_t *out) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    CtxScope sc(ctx_at(0));
+    g_err[0] = 0;
+    if (which != 0 || !out) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(g_ctx.device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_dev_claims_stolen), sizeof(v)));
+    if (reset) { const unsigned long long z = 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dev_claims_stolen), &z, sizeof(z))); }
+    *out = (int64_t)v;
     return GNX_OK;
 }
 

@@ -197,6 +197,10 @@ __device__ __forceinline__ int rb_progress(const int *prog) {
 #define GNX_CLAIM_GRACE_US 20000
 #endif
 constexpr long long CLAIM_GRACE_TICKS = 100LL * GNX_CLAIM_GRACE_US; // ticks of the 100 MHz wall clock
+__device__ unsigned long long g_dev_claims_stolen; // items run by a workgroup other than their own (gnx_debug_counter(0): the tests prove the abnormal paths ran)
+// The test switch word cw[n_items]: bits 0-15 = GNX_TICKET_DELAY (sleep units of the lower half of the grid), bits 16-31 =
+// GNX_CLAIM_GRACE_US (a grace period in microseconds for this launch instead of the compiled-in 20 ms: a delay longer than the grace
+// period makes the upper half really TAKE its predecessors' items; with the default grace the delayed workgroups still arrive in time).
 __device__ __forceinline__ int claim_items(int *cw, int stride, int depth) {
     int n = 0;
 #if GNX_CLAIM_MODE == 0
@@ -208,7 +212,9 @@ __device__ __forceinline__ int claim_items(int *cw, int stride, int depth) {
         (void)stride; (void)depth; if (atomicCAS(&cw[b], 0, 1) != 0) n = -1; // experiment: own item only
         return __builtin_amdgcn_readfirstlane(n);
 #endif
-        const int delay = cw[gridDim.x];
+        const int sw = cw[gridDim.x];
+        const int delay = sw & 0xffff;
+        const long long grace = (sw >> 16) ? 100LL * ((sw >> 16) & 0xffff) : CLAIM_GRACE_TICKS;
         if (delay && b * 2 < (int)gridDim.x) for (int i = 0; i < delay; i++) __builtin_amdgcn_s_sleep(127);
         if (atomicCAS(&cw[b], 0, 1) != 0) n = -1;
         else while (n < depth) {
@@ -219,10 +225,11 @@ __device__ __forceinline__ int claim_items(int *cw, int stride, int depth) {
             int *pw = &cw[b - (n + 1) * stride];
             const long long t_begin = wall_clock64();
             int seen;
-            while ((seen = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - t_begin < CLAIM_GRACE_TICKS) __builtin_amdgcn_s_sleep(8);
+            while ((seen = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - t_begin < grace) __builtin_amdgcn_s_sleep(8);
             if (seen != 0 || atomicCAS(pw, 0, 1) != 0) break;
             n++;
         }
+        if (n > 0) atomicAdd(&g_dev_claims_stolen, (unsigned long long)n);
     }
     return __builtin_amdgcn_readfirstlane(n);
 }

@@ -65,6 +65,7 @@ struct RcclApi {
     void *h = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr; // optional: used instead of CommDestroy after a failure
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
@@ -88,6 +89,7 @@ int rccl_load() {
     GNX_SYM(Send, "ncclSend"); GNX_SYM(Recv, "ncclRecv"); GNX_SYM(GroupStart, "ncclGroupStart"); GNX_SYM(GroupEnd, "ncclGroupEnd");
     GNX_SYM(GetErrorString, "ncclGetErrorString");
 #undef GNX_SYM
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
     g_rccl.h = h;
     return GNX_OK;
 }
@@ -100,12 +102,24 @@ bool g_rccl_broken = false; // a RCCL call failed in this process: every later e
 int g_transport = 0;        // what carried the last broadcast / gather, see gnx_timing.transport
 double g_bcast_ms = 0;      // broadcast time of the current call
 bool rccl_active() { return !g_rccl.comms.empty() && !g_rccl_broken; }
-// after a failed RCCL call: remember the text, drain whatever was enqueued, and never use the communicators again
+// drop the communicators (after a failure: abort, a destroy may wait for the peers of a collective that never completed)
+void rccl_drop_comms() {
+    for (ncclComm_t cm : g_rccl.comms) {
+        if (!cm) continue;
+        if (g_rccl_broken && g_rccl.CommAbort) (void)g_rccl.CommAbort(cm);
+        else (void)g_rccl.CommDestroy(cm);
+    }
+    g_rccl.comms.clear();
+}
+// after a failed RCCL call (the caller has already closed any open group): remember the text, drain whatever was enqueued, abort
+// the communicators, and keep RCCL off until gnx_shutdown -- every later exchange of the process uses peer copies (transport 3)
 void rccl_give_up() {
     g_rccl_broken = true;
-    fprintf(stderr, "[gnx] %s -- falling back to peer copies for this process\n", g_err);
+    fprintf(stderr, "[gnx] %s -- falling back to peer copies until gnx_shutdown\n", g_err);
     for (int d = 0; d < g_nctx; d++) { Ctx &c = ctx_at(d); if (c.inited && hipSetDevice(c.device) == hipSuccess) (void)hipDeviceSynchronize(); }
     (void)hipGetLastError();
+    rccl_drop_comms();
+    if (ctx_at(0).inited) (void)hipSetDevice(ctx_at(0).device);
 }
 
 // the synthetic reference is a pure function of the position (splitmix64), 2 bits per base, an N run of
@@ -185,7 +199,22 @@ int set_reference_packed(const uint8_t *ref, int64_t len, uint64_t seed) {
         HIPCHK(hipSetDevice(c0.device));
         hipStream_t st = c0.own_stream;
         c0.ref_len = -1;
-        if (len == 0) { c0.ref.release(); c0.ref_flag.release(); c0.ref_rank.release(); c0.ref_exc.release(); }
+        if (len == 0) { // release: every context gives the reference (and the unpacked-window scratch) back; nothing is re-allocated
+            int n_all0; { std::lock_guard<std::mutex> lk(g_ctxs_mu); n_all0 = (int)g_ctxs.size(); }
+            for (int d = 0; d < n_all0; d++) {
+                Ctx &c = ctx_at(d);
+                if (!c.inited) continue;
+                std::unique_lock<std::mutex> lkd;
+                if (d > 0) lkd = std::unique_lock<std::mutex>(c.mu); // (context 0 is held by this call's scope)
+                HIPCHK(hipSetDevice(c.device));
+                HIPCHK(hipDeviceSynchronize());
+                c.ref.release(); c.ref_flag.release(); c.ref_rank.release(); c.ref_exc.release(); c.unpk_b.release(); c.unpk_off.release();
+                c.ref_len = -1;
+            }
+            HIPCHK(hipSetDevice(c0.device));
+            g_bcast_ms = 0;
+            return GNX_OK;
+        }
         const size_t nw = ref_words(len), nf = ref_flagwords(len);
         if ((rc = c0.ref.ensure(nw * 4))) return rc;
         if ((rc = c0.ref_flag.ensure(nf * 8))) return rc;
@@ -430,23 +459,42 @@ std::vector<int64_t> partition_by_cells(const int64_t *a_len, const int64_t *b_l
 
 // broadcast `bytes` from context 0's buffer src0 to dst[d] of every other context (RCCL over xGMI; plain copies when the contexts
 // share a device or RCCL is off)
-// GNX_RCCL_INJECT_FAIL=1: the next RCCL exchange reports a failure before it starts (tests of the fall-back to peer copies)
-bool rccl_injected_failure() {
-    if (!getenv("GNX_RCCL_INJECT_FAIL")) return false;
-    set_err("RCCL error: injected failure (GNX_RCCL_INJECT_FAIL)%s", "");
+// GNX_RCCL_INJECT_FAIL=1: the next RCCL exchange reports a failure before it starts; =2: INSIDE its group, after the first operation
+// has been enqueued (tests of the fall-back to peer copies; `where` = 1 before ncclGroupStart, 2 inside the group)
+bool rccl_injected_failure(int where) {
+    const char *e = getenv("GNX_RCCL_INJECT_FAIL");
+    if (!e || atoi(e) != where) return false;
+    set_err("RCCL error: injected failure (GNX_RCCL_INJECT_FAIL=%s)", e);
     return true;
+}
+// A grouped exchange: `body` enqueues the operations between ncclGroupStart and ncclGroupEnd.  Whatever fails inside the group, the
+// group is CLOSED again before the error is reported (an open group would swallow the next ncclCommInitAll of this thread) and the
+// current device is context 0's; the caller then gives RCCL up and repeats the exchange with peer copies.
+template <class Body>
+int rccl_grouped(Body body) {
+    if (rccl_injected_failure(1)) return GNX_EDEVICE;
+    RCCLCHK(g_rccl.GroupStart());
+    const int rc = body();
+    const ncclResult_t re = g_rccl.GroupEnd(); // also on the error path; its own result only matters when the body was fine
+    (void)hipSetDevice(ctx_at(0).device);
+    if (rc) return rc;
+    if (re != ncclSuccess) { set_err("RCCL error: %s", g_rccl.GetErrorString(re)); return GNX_EDEVICE; }
+    return GNX_OK;
 }
 int broadcast_rccl(const void *src0, std::vector<void *> &dst, size_t bytes) {
     const int nc = (int)dst.size();
-    if (rccl_injected_failure()) return GNX_EDEVICE;
-    RCCLCHK(g_rccl.GroupStart());
-    for (int d = 0; d < nc; d++) {
-        Ctx &c = ctx_at(d);
-        HIPCHK(hipSetDevice(c.device));
-        RCCLCHK(g_rccl.Broadcast(src0, d == 0 ? const_cast<void *>(src0) : dst[(size_t)d], bytes, ncclUint8, 0, g_rccl.comms[(size_t)d], c.own_stream));
-    }
-    RCCLCHK(g_rccl.GroupEnd());
+    int rc = rccl_grouped([&]() -> int {
+        for (int d = 0; d < nc; d++) {
+            Ctx &c = ctx_at(d);
+            HIPCHK(hipSetDevice(c.device));
+            RCCLCHK(g_rccl.Broadcast(src0, d == 0 ? const_cast<void *>(src0) : dst[(size_t)d], bytes, ncclUint8, 0, g_rccl.comms[(size_t)d], c.own_stream));
+            if (d == 0 && rccl_injected_failure(2)) return GNX_EDEVICE;
+        }
+        return GNX_OK;
+    });
+    if (rc) return rc;
     for (int d = 0; d < nc; d++) { Ctx &c = ctx_at(d); HIPCHK(hipSetDevice(c.device)); HIPCHK(hipStreamSynchronize(c.own_stream)); }
+    HIPCHK(hipSetDevice(ctx_at(0).device));
     return GNX_OK;
 }
 int broadcast_from_ctx0(const void *src0, std::vector<void *> &dst, size_t bytes) {
@@ -589,27 +637,29 @@ int run_host_sharded(const gnx_params *prm, int64_t n_pairs,
         };
         auto gather_rccl = [&]() -> int {
             int64_t obase = jobs[0].total_ops;
-            if (rccl_injected_failure()) return GNX_EDEVICE;
-            RCCLCHK(g_rccl.GroupStart());
-            for (int d = 1; d < nc; d++) {
-                HostJob &j = jobs[(size_t)d];
-                Ctx &c = *j.c;
-                const int64_t nd = j.p1 - j.p0;
-                HIPCHK(hipSetDevice(c.device));
-                if (nd > 0) {
-                    RCCLCHK(g_rccl.Send(c.res_score.p, (size_t)nd, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
-                    RCCLCHK(g_rccl.Send(c.res_off.p, (size_t)nd + 1, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
+            const int grc = rccl_grouped([&]() -> int {
+                for (int d = 1; d < nc; d++) {
+                    HostJob &j = jobs[(size_t)d];
+                    Ctx &c = *j.c;
+                    const int64_t nd = j.p1 - j.p0;
+                    HIPCHK(hipSetDevice(c.device));
+                    if (nd > 0) {
+                        RCCLCHK(g_rccl.Send(c.res_score.p, (size_t)nd, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
+                        RCCLCHK(g_rccl.Send(c.res_off.p, (size_t)nd + 1, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
+                    }
+                    if (d == 1 && rccl_injected_failure(2)) return GNX_EDEVICE; // (a send is enqueued, its receive is not)
+                    if (j.total_ops > 0) RCCLCHK(g_rccl.Send(c.res_ops.p, (size_t)j.total_ops * 2, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
+                    HIPCHK(hipSetDevice(c0.device));
+                    if (nd > 0) {
+                        RCCLCHK(g_rccl.Recv((int64_t *)c0.gat_score.p + j.p0, (size_t)nd, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
+                        RCCLCHK(g_rccl.Recv((int64_t *)c0.gat_off.p + j.p0 + d, (size_t)nd + 1, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
+                    }
+                    if (j.total_ops > 0) RCCLCHK(g_rccl.Recv((gnx_cigar *)c0.gat_ops.p + obase, (size_t)j.total_ops * 2, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
+                    obase += j.total_ops;
                 }
-                if (j.total_ops > 0) RCCLCHK(g_rccl.Send(c.res_ops.p, (size_t)j.total_ops * 2, ncclInt64, 0, g_rccl.comms[(size_t)d], c.own_stream));
-                HIPCHK(hipSetDevice(c0.device));
-                if (nd > 0) {
-                    RCCLCHK(g_rccl.Recv((int64_t *)c0.gat_score.p + j.p0, (size_t)nd, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
-                    RCCLCHK(g_rccl.Recv((int64_t *)c0.gat_off.p + j.p0 + d, (size_t)nd + 1, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
-                }
-                if (j.total_ops > 0) RCCLCHK(g_rccl.Recv((gnx_cigar *)c0.gat_ops.p + obase, (size_t)j.total_ops * 2, ncclInt64, d, g_rccl.comms[0], c0.own_stream));
-                obase += j.total_ops;
-            }
-            RCCLCHK(g_rccl.GroupEnd());
+                return GNX_OK;
+            });
+            if (grc) return grc;
             for (int d = 0; d < nc; d++) { Ctx &c = *jobs[(size_t)d].c; HIPCHK(hipSetDevice(c.device)); HIPCHK(hipStreamSynchronize(c.own_stream)); }
             HIPCHK(hipSetDevice(c0.device));
             return GNX_OK;

@@ -1,7 +1,7 @@
 // seed_kernels.hip.h -- "next" row N4: the k-mer index of the graph aligner and its seed search (hash lookup + exact-match extension)
 // Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).  See DESIGN.md section 5.3.
 #pragma once
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #include "gnx_common.hip.h"
 
 namespace {
@@ -9,7 +9,7 @@ namespace {
 // genomeGraph.IndexGenomeIntoMap (/root/reference/genomeGraph/index.go:21-43) for the k-mers that lie inside one node: a Go map from
 // the 2-bit code of `seedLen` bases to the list of (node << 32 | pos) it was seen at, positions 0, seedStep, 2 seedStep, ...; k-mers
 // with an N are skipped.  Here: one thread per position emits (key, location) or nothing, an exclusive scan compacts, a STABLE
-// radix sort by key (hipcub) makes the map: equal keys keep the insertion order of the reference (by node, by position).  The
+// radix sort by key (rocprim::radix_sort_pairs) makes the map: equal keys keep the insertion order of the reference (by node, by position).  The
 // k-mers that run across node borders (index.go:34-38, a recursion over Next edges) are few and stay on the host.
 //
 // seedMapMemPool (search.go:549-590) + dnaTwoBit.CountLeftMatches / CountRightMatches (dna/dnaTwoBit/perfectAlign.go): for every

@@ -185,7 +185,11 @@ int gnx_get_timing(gnx_timing *out);
 /* Diagnostics (tests only; nothing in the reference corresponds to it): launch n_workgroups workgroups that each hold one CU's whole
  * LDS and spin for `milliseconds` on a stream of their own, and return at once -- the pipelined launches of the library must make
  * progress whatever else occupies the device (no workgroup waits for work that has not been claimed by a running one). */
-int gnx_debug_occupy(int n_workgroups, int milliseconds);
+int gnx_debug_occupy(int n_workgroups, int milliseconds); /* refused with GNX_EINVAL unless the process runs with GNX_DEBUG_ENTRY=1 */
+/* Diagnostics: which = 0: number of items of pipelined launches (strips, row-block levels) that were run by a workgroup other
+ * than their own since the last reset -- the abnormal path of the claim protocol, which tests/test_ticket.py forces and then
+ * proves to have run.  reset != 0 zeroes the counter after reading. */
+int gnx_debug_counter(int which, int reset, int64_t *out);
 
 /* ---- "next" row N1: chunk and multiple-alignment variants (what cmd/faChunkAlign and popgen/dunn.go run) ---- */
 /* align.AffineGapChunk (/root/reference/align/affineGap_highMem.go:227-268): the affine DP over chunks of chunk_size

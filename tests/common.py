@@ -106,6 +106,61 @@ def c3_reads(seed, n_pairs, ref_len, ref_seed, window=10000, read_len=150):
     return np.ascontiguousarray(reads), starts
 
 
+def synthetic_reference_positions_torch(pos, seed):
+    """gonomics_amd._lib.synthetic_reference_positions on a torch int64 tensor (any device): splitmix64 in wrapping int64 arithmetic,
+    logical shifts spelled as arithmetic shift + mask.  Used to generate the 10 M reads of config C3 in seconds instead of minutes."""
+    import torch
+
+    def s64(v):
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    w = pos >> 5
+    x = (w ^ s64(seed)) + s64(0x9E3779B97F4A7C15)
+    x = (x ^ lsr(x, 30)) * s64(0xBF58476D1CE4E5B9)
+    x = (x ^ lsr(x, 27)) * s64(0x94D049BB133111EB)
+    x = x ^ lsr(x, 31)
+    b = ((x >> (2 * (pos & 31))) & 3).to(torch.uint8)
+    b[(pos % 50000000 < 1000) & (pos >= 50000000)] = 4
+    return b
+
+
+def c3_reads_torch(seed, n_pairs, ref_len, ref_seed, window=10000, read_len=150, device="cpu"):
+    """c3_reads with the per-base work on a torch device (same distributions, its own random stream).  Returns numpy (reads, starts)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    dev = torch.device(device)
+
+    def randint(lo, hi, shape):
+        return torch.randint(lo, hi, shape, generator=g, device=dev, dtype=torch.int64)
+
+    starts = randint(0, ref_len - window, (n_pairs,))
+    off = randint(0, window - read_len - 64, (n_pairs,))
+    has_indel = torch.rand(n_pairs, generator=g, device=dev) < 0.26
+    pos = randint(10, read_len - 10, (n_pairs,))
+    u = torch.rand(n_pairs, generator=g, device=dev).clamp_min(1e-12)
+    ln = torch.clamp(torch.floor(torch.log2(1.0 / u)).to(torch.int64) + 1, max=32)  # geometric(0.5), capped
+    is_del = torch.rand(n_pairs, generator=g, device=dev) < 0.5
+    reads = torch.empty((n_pairs, read_len), dtype=torch.uint8, device=dev)
+    x = torch.arange(read_len, device=dev)[None, :]
+    for lo in range(0, n_pairs, 1 << 18):
+        hi = min(n_pairs, lo + (1 << 18))
+        sl = slice(lo, hi)
+        shift = torch.where(has_indel[sl, None] & (x >= pos[sl, None]), torch.where(is_del[sl], ln[sl], -ln[sl])[:, None], torch.zeros((), dtype=torch.int64, device=dev))
+        src = (starts[sl] + off[sl])[:, None] + torch.clamp(x + shift, min=0)
+        r = synthetic_reference_positions_torch(src.reshape(-1), ref_seed).reshape(hi - lo, read_len)
+        ins_mask = has_indel[sl, None] & (~is_del[sl])[:, None] & (x >= pos[sl, None]) & (x < (pos[sl] + ln[sl])[:, None])
+        rnd = torch.randint(0, 4, r.shape, generator=g, device=dev, dtype=torch.uint8)
+        r = torch.where(ins_mask, rnd, r)
+        sub = torch.rand(r.shape, generator=g, device=dev) < 0.01
+        rnd2 = torch.randint(0, 4, r.shape, generator=g, device=dev, dtype=torch.uint8)
+        reads[sl] = torch.where(sub, rnd2, r)
+    return np.ascontiguousarray(reads.cpu().numpy()), starts.cpu().numpy().astype(np.int64)
+
+
 def assert_same(res_a, res_b, what=""):
     sa, oa, fa = res_a
     sb, ob, fb = res_b

@@ -57,3 +57,19 @@ def test_host_helpers():
     p = _lib.make_params(_lib.GNX_AFFINE_GAP, align.HumanChimpTwoScoreMatrix, -600, -150)
     assert p.scores[1 * 5 + 0] == -330 and p.checkersize_i == 10000
     assert np.dtype(_lib.CIGAR_DTYPE).fields["op"][1] == 8
+
+
+def test_torch_restatement_of_the_synthetic_reference():
+    """tests/common.py:synthetic_reference_positions_torch (used to generate the 10 M reads of config C3 on the device) equals the
+    binding's numpy restatement of gnx_set_reference_synthetic, N runs and 64-bit seeds included"""
+    import torch
+    import common
+    from gonomics_amd import _lib
+    pos = np.concatenate([np.arange(0, 5000), np.arange(49999000, 50002000),
+                          np.random.default_rng(1).integers(0, 4400000000, 20000)]).astype(np.int64)
+    for seed in (3, 33, 0xFFFFFFFFFFFFFFF1):
+        a = _lib.synthetic_reference_positions(pos, seed)
+        b = common.synthetic_reference_positions_torch(torch.from_numpy(pos), seed).numpy()
+        assert np.array_equal(a, b), seed
+    reads, starts = common.c3_reads_torch(5, 2000, 3000000000, 3)
+    assert reads.shape == (2000, 150) and reads.max() <= 4 and starts.min() >= 0

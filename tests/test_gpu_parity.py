@@ -777,11 +777,12 @@ def test_stress_regression_q1_at_block_top(gpu_lib, monkeypatch):
     """a batch tools/stress.py found (round 2): 64 x 64 checkerboards, reads of 1 .. 5 row blocks against 568-base windows, tiles for
     everyone.  A vertical step out of a row block's first row in the first column of a window / tile, on a checkerboard edge (quirk Q1),
     needs the argmax tag of a cell of the block above: it is the key that block handed down (fp_walk_kernel, `i == wrow`)."""
-    d = np.load(os.path.join(common.DATA, "stress_r2_q1_block_top.npz"), allow_pickle=True)
+    d = np.load(os.path.join(common.DATA, "stress_r2_q1_block_top.npz"))  # plain arrays (concatenated sequences + offsets): no pickle
     mode, go, ge, cs = int(d["mode"]), int(d["go"]), int(d["ge"]), int(d["cs"])
     mx = d["mx"]
-    alphas = [np.asarray(a, dtype=np.uint8) for a in d["alphas"]]
-    betas = [np.asarray(b, dtype=np.uint8) for b in d["betas"]]
+    ao, bo = d["alpha_off"], d["beta_off"]
+    alphas = [np.asarray(d["alpha_cat"][ao[k]:ao[k + 1]], dtype=np.uint8) for k in range(ao.shape[0] - 1)]
+    betas = [np.asarray(d["beta_cat"][bo[k]:bo[k + 1]], dtype=np.uint8) for k in range(bo.shape[0] - 1)]
     exp = oracle.align_batch(mode, mx, go, ge, alphas, betas, cs, cs, threads=8)
     p = gpu_lib.make_params(mode, mx, go, ge, cs, cs)
     monkeypatch.setenv("GNX_FASTPATH", "2")

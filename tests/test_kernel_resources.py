@@ -53,7 +53,7 @@ BUDGET = [
     ("fp_sweep_kernel<19, false", 3), ("fp_sweep_kernel<20, false", 3), ("fp_sweep_kernel<19, true", 3), ("fp_sweep_kernel<20, true", 3), ("fp_sweep_levels_kernel", 2),
     ("fill_affine_kernel<false, false", 3), ("fill_affine_kernel<true, false", 3), ("fill_affine_kernel<false, true", 2), ("fill_affine_kernel<true, true", 2),
     ("fill_const_kernel<false, 0", 3), ("fill_const_kernel<false, 1", 3), ("fill_const_kernel<false, 2", 3), ("fill_const_kernel<true", 2),
-    ("cl_sweep_kernel<true>", 5), ("cl_sweep_flat_kernel<true>", 4), ("cl_sweep_kernel<false>", 3), ("al_sweep_kernel", 3),
+    ("cl_sweep_kernel<true>", 5), ("cl_sweep_flat_kernel<true>", 4), ("cl_sweep_flat_kernel<false>", 3), ("cl_sweep_kernel<false>", 3), ("al_sweep_kernel", 3),
     ("fp_walk_kernel", 6), ("traceback_kernel", 4), ("gsw_traceback_kernel", 8),
 ]
 # kernels that are allowed scratch (register-bound by design: their tiles live in LDS at one workgroup of 4 pairs per half CU)

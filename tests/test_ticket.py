@@ -6,8 +6,13 @@ taken.  Two stress legs, each over all five piped kernels, results against the o
     unclaimed and runs whole chains itself (what a dispatcher that starts workgroups in another order would cause);
   * gnx_debug_occupy: 128 workgroups that each hold a whole CU's LDS spin on another stream while the piped launch runs, so half
     the CUs cannot take workgroups of the launch at all.
+  * steal: the delay alone never makes anybody TAKE an item -- the default grace period (20 ms) outlasts it.  This leg
+    sets GNX_CLAIM_GRACE_US=50 for the launch together with a delay of ~2 ms, so the upper half of the grid really claims and runs its
+    predecessors' items (the s_lo .. s_own loops of the strip kernels, the level loop of fp_sweep_levels_kernel), and asserts through
+    gnx_debug_counter(0) that at least one item was run by a workgroup other than its own.
 The bug trap (5 s spin timeout -> error flag 16 -> sequential re-run) must stay silent: the legs assert that the piped launch was
 the one that produced the result by checking that the call took far less than the timeout."""
+import os
 import time
 
 import numpy as np
@@ -46,7 +51,7 @@ LEGS = [
 
 
 @pytest.mark.parametrize("leg", LEGS, ids=[x[0].split()[0] for x in LEGS])
-@pytest.mark.parametrize("stress", ["delay", "occupy", "both"])
+@pytest.mark.parametrize("stress", ["delay", "occupy", "both", "steal"])
 def test_piped_launches_do_not_depend_on_dispatch_order(gpu_lib, monkeypatch, leg, stress):
     name, env, mode, mx, (go, ge), spec = leg
     alphas, betas = _pairs(*spec)
@@ -54,8 +59,13 @@ def test_piped_launches_do_not_depend_on_dispatch_order(gpu_lib, monkeypatch, le
     p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP if mode == 0 else gpu_lib.GNX_CONST_GAP, MX[mx], go, ge)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    monkeypatch.setenv("GNX_DEBUG_ENTRY", "1")
     plain = gpu_lib.align_batch(p, alphas, betas)
     common.assert_same(plain, exp, name)
+    gpu_lib.debug_counter(0, reset=True)
+    if stress == "steal":
+        monkeypatch.setenv("GNX_TICKET_DELAY", "600")     # ~ 600 x 127 x 64 cycles = 2 ms before the lower half claims ...
+        monkeypatch.setenv("GNX_CLAIM_GRACE_US", "50")    # ... and a successor takes an unclaimed predecessor after 50 us
     if stress in ("delay", "both"):
         monkeypatch.setenv("GNX_TICKET_DELAY", "40")   # ~ 40 x 127 x 64 cycles = 0.15 ms before the lower half claims
     if stress in ("occupy", "both"):
@@ -65,4 +75,7 @@ def test_piped_launches_do_not_depend_on_dispatch_order(gpu_lib, monkeypatch, le
     dt = time.time() - t0
     common.assert_same(got, exp, name + " / " + stress)
     assert dt < 3.0, "%s: %.1f s -- the spin timeout fired, the pipeline did not make progress on its own" % (name, dt)
+    stolen = gpu_lib.debug_counter(0, reset=True)
+    if stress == "steal" and not common.OUTER_ROUTE_SWITCH and "GNX_NO_PIPE" not in os.environ:
+        assert stolen > 0, "%s: nobody ran a predecessor's item -- the n_stolen > 0 paths were not exercised" % name
     time.sleep(0.35)  # let the occupying workgroups end before the next test
