@@ -45,6 +45,22 @@ namespace {
 #ifndef GNX_FP_PRIO
 #define GNX_FP_PRIO 0
 #endif
+// GNX_FP_EVENTS (round 4): reads of ONE row block (ROLE 0, not the transposed form) keep no I-planes in the steady part of the sweep.
+// The four plane rows then run the untagged 5-instruction cell like every other row, and each of them tracks only the LAST step at
+// which its horizontal gap could have been opened:  event  <=>  h'(i,j) + o >= I'(i,j)  (values; all keys are multiples of 4 there).
+// After the last event every cell of the row is a plain extension, so the walk can take a trailing gap in one stride down to the event
+// cell and decide there (fp_walk_kernel: the diagonal shortcut proves "opened from M", else a window is re-filled as for any other cell).
+// The tagged arithmetic (4 x (or, and_or, and_or, alignbit) = 16 of 121 instructions per step, executed by all 64 lanes for the sake of
+// the last lane of each pair) is left to the TAIL of the sweep: the half blocks in which some lane of the wave has run out of columns
+// (t0 + 7 > m_min), which hold the last columns of every pair -- corner tags, h(n, m) and the plane fields of the last ~8-22 columns.
+// GNX_FP_EVBR: the event update sits behind a wave-uniform branch (taken only when a LAST lane of a pair has an event: a few per cent
+// of the steps), so the steady step pays one v_cmp per plane row and nothing else.
+#ifndef GNX_FP_EVENTS
+#define GNX_FP_EVENTS 0
+#endif
+#ifndef GNX_FP_EVBR
+#define GNX_FP_EVBR 1
+#endif
 constexpr int G8 = 8;
 constexpr int FP8_LW = 10;                 // dwords per lane per base (20 int16 entries)
 // LDS layout of the int16 profile.  A ds_read_b64 serves 16 lanes per cycle = one DPP row = a DUO of pairs; lane lp reads dwords
@@ -60,7 +76,16 @@ constexpr int FP8_LW = 10;                 // dwords per lane per base (20 int16
 constexpr int FP8_BST = GNX_FP_LDS_COMPACT ? 160 : 96;   // dwords per base plane (of a duo / of a pair)
 constexpr int FP8_PST = 5 * 96 + 16;                      // padded form: dwords per pair
 constexpr int FP8_PROF = GNX_FP_LDS_COMPACT ? 4 * 5 * FP8_BST : 8 * FP8_PST; // dwords of profile per wave
-constexpr int FP8_RINGS = GNX_FP_LDS_COMPACT ? 8 * 16 : 0;                    // compact form: 32 uint16 per pair behind the profile
+#ifndef GNX_FP_RING_SKEW
+#define GNX_FP_RING_SKEW 1
+#endif
+// compact form: 32 uint16 = 16 dwords per pair behind the profile.  A ds_read_u16 serves 32 lanes = 4 pairs per cycle and every pair reads
+// the same 4-5 dword window of its ring, so the four rings of a half-wave must start in different banks (mod 32): with a plain stride
+// of 16 dwords pairs g and g + 2 sat exactly 32 dwords apart -- a 2-way conflict on every read (SQ_LDS_BANK_CONFLICT 3.1e8 per
+// 100 000 pairs in round 3).  Skewed: the third and fourth pair of a half-wave start 8 dwords later -> bases 0, 16, 40, 56
+// = 0, 16, 8, 24 (mod 32); a half-wave's four rings take 72 dwords.
+constexpr int FP8_RINGS = GNX_FP_LDS_COMPACT ? (GNX_FP_RING_SKEW ? 2 * 72 : 8 * 16) : 0;
+__device__ __forceinline__ constexpr int fp8_ring_base(int g) { return GNX_FP_RING_SKEW ? (g >> 2) * 72 + (g & 3) * 16 + ((g >> 1) & 1) * 8 : g * 16; }
 constexpr int FP8_LDS = 32 + FP8_PROF + FP8_RINGS;                             // dwords per wave (+ the hand-over staging of the levels kernel)
 
 // lanes 0-7 of a DPP row: from lane-1; lanes 8-15 (mirrored pair): from lane+1; the first lane of each pair keeps oldv
@@ -116,6 +141,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     const int lp = (lane & 8) ? 15 - (lane & 15) : (lane & 7); // position of the lane inside its pair
     const int E4 = kp.e4;
     constexpr int TI = XP ? 1 : 2, TD = XP ? 2 : 1; // tags of the horizontal / vertical gap state (tie order, see above)
+    constexpr bool EV = (GNX_FP_EVENTS != 0) && ROLE == 0 && !XP; // plane rows untagged + last-event tracking until the tail (see GNX_FP_EVENTS)
     if (lane < 25) lds[lane] = kp.sc4[lane] - 2 * E4;
     else if (lane < 32) lds[lane] = XP ? -E4 : -32768; // padding rows: the diagonal candidate never wins (XP: fake rows that repeat row 0)
     int *prof = GNX_FP_LDS_COMPACT ? &lds[32 + (g >> 1) * (5 * FP8_BST) + (g & 1) * (G8 * FP8_LW)] : &lds[32 + g * FP8_PST];
@@ -140,11 +166,14 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     const int P = G8 * RR - n_loc; // padding slots above row 1
     const int q0 = lp * RR;        // first slot of this lane; slot q holds row q - P + 1 of the block
     int bad = 0;
+    // EV: every key starts WITHOUT its tag (tg = 0) unless the very first half block is already a tail block (a wave with a window of < 7
+    // columns): the event test compares values, and a tag left in the low bits would decide a tie
+    const int tg = (!EV || m_min < 7) ? 1 : 0;
     int vO4, cH, cDN; // constants pinned in VGPRs (2-cycle adds, DPP `old` operands)
     // XP: the first lane's boundary is row 0 = R(j) = -e*j: h'(0,t) = R(t), D'(1,t) = R(t) + o at step t, advanced by vInc after
     // every DPP move (the values below are those of "step -1")
     asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(vO4), "=v"(cH), "=v"(cDN)
-                 : "s"(kp.o4), "s"(XP ? E4 + TI : kp.o4 + 2), "s"(XP ? kp.o4 + E4 + TI : 2 * kp.o4 + 2));
+                 : "s"(kp.o4), "s"(XP ? E4 + TI : kp.o4 + 2 * tg), "s"(XP ? kp.o4 + E4 + TI : 2 * kp.o4 + 2 * tg));
     const int vInc = (XP && !TAKES && lp == 0) ? -E4 : 0;           // (row 0 is above the top block only)
     const int vO4L = (XP && BOTTOM && lp == G8 - 1) ? -E4 : kp.o4;  // horizontal open of the last slot: the step of the pair's last row is free (XP)
 
@@ -171,12 +200,16 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         const int q = q0 + r;
         // column 0: real row i: h'(i,0) = D'(i,0) = o (tag D), I'(i,1) = 2o (from D); padding: h' = I' = o; the slot above row 1 is h(0,0) = 0 (tag 3)
         // XP: padding = fake rows, h' = R(0) = 0 and an I' that never wins; the last row's I'(n,1) = h(n,0) at no cost
-        hold[r] = (q >= P) ? kp.o4 + TD : ((XP || q == P - 1) ? 3 : kp.o4 + 2);
-        rt[r] = (q >= P) ? kp.o4 + TD + (r == RR - 1 ? vO4L : kp.o4) : (XP ? kp.o4 : kp.o4 + 2);
+        hold[r] = (q >= P) ? kp.o4 + TD * tg : ((XP || q == P - 1) ? 3 * tg : kp.o4 + 2 * tg);
+        rt[r] = (q >= P) ? kp.o4 + TD * tg + (r == RR - 1 ? vO4L : kp.o4) : (XP ? kp.o4 : kp.o4 + 2 * tg);
     }
+    int ev[FP_PLANES]; // EV: the last step at which row n - d could have opened its horizontal gap (-1: none)
+#pragma unroll
+    for (int d = 0; d < FP_PLANES; d++) ev[d] = -1;
+    int tstart = EV ? -1 : 0; // first step of the tagged tail
     unsigned accR[FP_PLANES] = {}; // I-planes of rows n-d = slots RR-1-d of the last lane
     unsigned tailw = 0; // argmax tags of h(n-d, m-x), d, x = 0..3, field 4x + d: lets the walk take its first diagonal steps without a window
-    int diag0 = (q0 == 0) ? ((XP || P == 0) ? 3 : kp.o4 + 2) : ((q0 - 1 >= P) ? kp.o4 + TD : ((XP || q0 - 1 == P - 1) ? 3 : kp.o4 + 2));
+    int diag0 = (q0 == 0) ? ((XP || P == 0) ? 3 * tg : kp.o4 + 2 * tg) : ((q0 - 1 >= P) ? kp.o4 + TD * tg : ((XP || q0 - 1 == P - 1) ? 3 * tg : kp.o4 + 2 * tg));
     if (TAKES && q0 == 0) diag0 = kp.o4 + TD; // the slot above is a row of the pair, column 0: h' = D' = o
     int dn_out = 0, h_out = 0, b_out = 0;
     int up_dn = cDN, up_h = cH;
@@ -192,7 +225,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     // to column t0 - 5, its write replaces columns t0 - 8 .. t0 - 1 -- and every entry is stored twice, 16 entries apart, so that the
     // eight reads of a half block are consecutive (immediate offsets, no wrap): 64 bytes per pair behind the profile (padded form:
     // the unused tail of the pair's first profile plane, 8 lanes x 10 dwords of 96).
-    unsigned short *ring = reinterpret_cast<unsigned short *>(GNX_FP_LDS_COMPACT ? lds + 32 + FP8_PROF + g * 16 : prof + G8 * FP8_LW);
+    unsigned short *ring = reinterpret_cast<unsigned short *>(GNX_FP_LDS_COMPACT ? lds + 32 + FP8_PROF + fp8_ring_base(g) : prof + G8 * FP8_LW);
     static_assert(GNX_FP_LDS_COMPACT || FP8_BST - G8 * FP8_LW >= 16, "padded form: the ring lives in the padding of a profile plane");
     {
         const int o = base_off(base_raw(lp), lp); // columns 0 .. 7 (column 0 and everything left of it: offset 0, never used by a live cell)
@@ -235,8 +268,9 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
     pb1 = ring_at(1 - lp);      // step 1
     const unsigned short *rp = ring; // ring + ((t0 + 2 - lp) & 15) of the current half block
     // u = the step's index inside its half block (compile time in the steady loop: the ring read gets an immediate offset)
-    auto step = [&](const int t, auto chk, const bool ckflag, const int u) {
+    auto step = [&](const int t, auto chk, auto tgd, const bool ckflag, const int u) {
         constexpr bool CHECK = decltype(chk)::value; // false: every lane of the wave is inside its matrix (steady state)
+        constexpr bool TGD = decltype(tgd)::value;   // the plane rows run the tagged arithmetic and record their I-planes (always, unless EV)
         // ckflag (wave-uniform): this half block crosses a checkpoint column
         // The first lane of a pair keeps the DPP `old` value = the row-0 boundary constant.  Passing the previous step's result
         // as `old` (its first lane already holds that constant) lets the move happen in place, without a copy of the constant.
@@ -256,12 +290,17 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
 #pragma unroll
             for (int r = 0; r < RR; r++) {
                 const int S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff);
-                if (BOTTOM && r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
+                if (BOTTOM && TGD && r >= RR - FP_PLANES) accR[RR - 1 - r] = alignbit2((unsigned)rt[r], accR[RR - 1 - r]);
                 int hnew, dnn;
-                if (BOTTOM ? r < RR - FP_PLANES : r < RR - 1) { // tag bits are junk < 4 here; they never change the value of a max
+                if (BOTTOM ? (r < RR - FP_PLANES || !TGD) : r < RR - 1) { // tag bits are junk < 4 here (EV: zero); they never change the value of a max
                     const int M = hd + S4;
                     hnew = max3i(M, rt[r], dnu);
                     const int ho = hnew + vO4;
+                    if (EV && BOTTOM && r >= RR - FP_PLANES) { // a plane row of the untagged part: remember the step if the gap could have been opened here
+                        const bool evc = ho >= rt[r];
+                        if (GNX_FP_EVBR) { if (__builtin_amdgcn_ballot_w64(evc) & 0x0180018001800180ull) ev[RR - 1 - r] = evc ? t : ev[RR - 1 - r]; } // (the pairs' last lanes: 7, 8, 23, 24, ...)
+                        else ev[RR - 1 - r] = evc ? t : ev[RR - 1 - r];
+                    }
                     rt[r] = max(ho, rt[r]);
                     dnn = max(ho, dnu);
                 } else {
@@ -281,7 +320,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
             dn_out = dnu;
             h_out = hold[RR - 1];
             if (HANDS) { if (lp == G8 - 1) hand[t & 7] = make_int2(dn_out, h_out); } // hand the bottom row down (staged, see hand_down)
-            if (BOTTOM && CHECK && j + 3 >= m_eff) { // the last four columns (always in a CHECK half block)
+            if (BOTTOM && CHECK && TGD && j + 3 >= m_eff) { // the last four columns (always in a CHECK half block, and in the tagged tail)
 #pragma unroll
                 for (int d = 0; d < FP_PLANES; d++) tailw |= (unsigned)(hold[RR - 1 - d] & 3) << (8 * (m_eff - j) + 2 * d);
             }
@@ -342,13 +381,23 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
         nraw = base_raw(t0 + 8 + lp); // prefetch the next half block's bases
         if (TAKES) { wait_cols(t0 + 15); rqn = rb_at(t0 + 8 + lp); }
         rp = ring + ((t0 + 2 - lp) & 15);
+        const bool tail_blk = !EV || t0 + 7 > m_min; // EV: head blocks run untagged like the steady part; the tail is tagged
+        if (tail_blk) {
+            if (tstart < 0) tstart = t0;
 #pragma unroll 1
-        for (int u = 0; u < 8; u++) {
-            if (u == 5) ring_put(t0);
-            step(t0 + u, std::true_type{}, true, u);
+            for (int u = 0; u < 8; u++) {
+                if (u == 5) ring_put(t0);
+                step(t0 + u, std::true_type{}, std::true_type{}, true, u);
+            }
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < 8; u++) {
+                if (u == 5) ring_put(t0);
+                step(t0 + u, std::true_type{}, std::bool_constant<!EV>{}, true, u);
+            }
         }
         if (TAKES) rq = rqn;
-        flush(t0);
+        if (tail_blk) flush(t0);
         hand_down(t0);
     };
     // Three phases, so that the steady loop is ONE loop over half blocks whose state stays in the same registers (separate
@@ -370,15 +419,22 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             if (u == 5) ring_put(t0);
-            step(t0 + u, std::false_type{}, ckflag, u);
+            step(t0 + u, std::false_type{}, std::bool_constant<!EV>{}, ckflag, u);
         }
         if (TAKES) rq = rqn;
-        flush(t0);
+        if (!EV) flush(t0);
         hand_down(t0);
     }
     for (; t0 < Tend; t0 += 8) edge_half_block(t0);
     if (HANDS && piped) rb_publish(prog_out, 0x7fffffff, lane);
-    if (BOTTOM && lp == G8 - 1 && valid && m_eff >= 1) { hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); tail[pl.hcol_off] = tailw; } // h(n, m)
+    if (BOTTOM && lp == G8 - 1 && valid && m_eff >= 1) {
+        hcol[pl.hcol_off] = hold[RR - 1] + E4 * (pl.n + m_eff); // h(n, m)
+        unsigned *tw = tail + pl.hcol_off * FP_TAILW;
+        tw[0] = tailw;
+#pragma unroll
+        for (int d = 0; d < FP_PLANES; d++) tw[1 + d] = (unsigned)ev[d];
+        tw[5] = (unsigned)tstart; tw[6] = EV ? 1u : 0u;
+    }
     if (bad) atomicOr(err, 1);
 }
 

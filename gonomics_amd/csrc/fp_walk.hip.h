@@ -98,15 +98,50 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
     // not usable: the walk uses a window / tile from its second column on (all of it when it starts at column 0).
     auto lo_ok = [](int jc_lo) { return jc_lo + (jc_lo > 0 ? 2 : 1); };
     // argmax tag of h(ii, jj) kept by the sweep for the 4 x 4 cells at the bottom right corner
-    const unsigned tailw = tail[pl.hcol_off];
+    const unsigned *trec = tail + (int64_t)pl.hcol_off * FP_TAILW;
+    const unsigned tailw = trec[0];
+    // Sweeps with GNX_FP_EVENTS keep plane fields only for their tagged tail: steps > tst, i.e. the columns >= jplane of the plane rows.
+    // Left of that a plane row has ONE number: the last step at which its gap could have been opened (trec[1 + d]); every cell right of
+    // that step's column + 1 is a plain extension.
+    const bool evm = trec[6] != 0;
+    const int tst = (int)trec[5];
+    const int jplane = evm ? (tst > 0 ? tst - (G8 - 2) : 1) : 1;
+    bool diag_ok = false; // the plain diagonal from the walk's cell has already been scored and found to be the path (event cell, below)
+    // score of the plain diagonal from (ii, jj) in state M up to row 0 plus the leading gap h(0, jj - ii) (FIRST walks: wbeta is bound)
+    auto diag_score = [&](int ii, int jj) {
+        const uint8_t *ap = a_buf + a_start[pl.src];
+        int64_t P = (XP || jj == ii) ? 0 : tp.gap_open + tp.gap_extend * (int64_t)(jj - ii); // (XP: row 0 is free)
+        for (int t = 0; t < ii; t++) P += (int64_t)(kp.sc4[min((int)ap[t], 4) * 5 + min(wbeta.at((jj - ii) + t), 4)] >> 2);
+        return P;
+    };
     auto tail_ok = [&](int ii, int jj) { return ii >= 1 && jj >= 1 && pl.n - ii < FP_PLANES && pl.m - jj < 4; };
     auto tail_tag = [&](int ii, int jj) { return (tailw >> (8 * (pl.m - jj) + 2 * (pl.n - ii))) & 3u; };
     while (true) {
         if (i == 0 || j == 0) { done = true; break; }
         unsigned w;
         int pos;
-        const bool on_plane = (k == 1) && (pl.n - i) < FP_PLANES;
+        const bool on_plane = (k == 1) && (pl.n - i) < FP_PLANES && j >= jplane;
         const bool in_win = !on_plane && j >= lo_ok(st.jc_lo) && j <= st.j_hi && i > wrow && i <= wrow + wp.n;
+        if (evm && !TILED && !on_plane && !in_win && k == 1 && (pl.n - i) < FP_PLANES) {
+            // a plane row of an event sweep, left of the stored fields
+            const int te = (int)trec[1 + (pl.n - i)];
+            if (te < 0) { // the gap was never re-opened: plain extensions back to column 1, whose gap came out of column 0
+                emit(op_of(1), j); last_op = 1; j = 0; k = 2;
+                continue; // (j == 0 ends the walk: Step 4)
+            }
+            const int jc = te - (G8 - 1); // the column of that step: the direction of cell (i, jc + 1) is the first unknown one
+            if (j <= jc) break;           // left of the last event nothing is known: a window
+            const int steps = j - (jc + 1);
+            if (steps > 0) { emit(op_of(1), steps); j -= steps; last_op = 1; last_win = false; if (FIRST) val -= tp.gap_extend * (int64_t)steps; }
+            if (FIRST && jc >= i) {
+                // Was the gap opened from M there?  Then M(i, jc) = I(i, jc + 1) - gapOpen - gapExtend.  If the plain diagonal from (i, jc)
+                // scores exactly that, M(i, jc) >= it; and M(i, jc) + oe <= I(i, jc + 1) bounds it from above: equal, tripleMaxTrace gives
+                // the tie to M, and the path is that diagonal (the argument of the shortcut below).  Otherwise: the window decides.
+                const int64_t vM = val - tp.gap_open - tp.gap_extend;
+                if (diag_score(i, jc) == vM) { emit(op_of(1), 1); last_op = 1; j = jc; k = 0; val = vM; diag_ok = true; }
+            }
+            break;
+        }
         if (on_plane || in_win || (k == 0 && tail_ok(i - 1, j - 1))) last_win = in_win; // was the last step taken inside the window? (then the walk leaves it by walking through it)
         if (CW && in_win && k == 0 && !no_look) {
             // a diagonal run inside the window, 64 cells per look: lane t looks at the cell (i - t, j - t); the run goes on while the cells
@@ -155,6 +190,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         if (k == 1) {
             int avail = min(pos + 1, j);
             if (!on_plane) avail = min(avail, j - lo_ok(st.jc_lo) + 1); // do not run past the window's usable left edge
+            else if (evm) avail = min(avail, j - jplane + 1);            // ... or past the first stored field of an event sweep
             unsigned x = w ^ IRUN;
             if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
             const int lowcut = pos + 1 - avail;
@@ -193,21 +229,21 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                 const unsigned *wbase = rowi + pl.rowi_off + (int64_t)(pl.n - i) * pl.words;
                 int wi = ((j + steps + G8 - 1) >> 4) - 1;
                 bool more = true;
-                while (CW && more && wi >= 0 && j >= 16) { // 64 words per look
-                    const int lim = min(min(wi + 1, j >> 4), 64);
+                while (CW && more && wi >= 0 && j >= 16 && (!evm || j - 15 >= jplane)) { // 64 words per look
+                    const int lim = min(min(wi + 1, evm ? (j - jplane + 1) >> 4 : j >> 4), 64);
                     const unsigned qv = lane < lim ? wbase[wi - lane] : 0u;
                     const unsigned long long stop = __ballot(!(lane < lim && qv == IRUN));
                     const int T = stop ? __ffsll((long long)stop) - 1 : 64;
                     if (T > 0) { emit(op_of(1), 16 * (int64_t)T); j -= 16 * T; wi -= T; if (FIRST && !(XP && i == pl.n)) val -= tp.gap_extend * 16 * (int64_t)T; }
                     more = (T == 64);
                 }
-                while (!CW && more && wi >= 0 && j >= 16) {
+                while (!CW && more && wi >= 0 && j >= 16 && (!evm || j - 15 >= jplane)) {
                     unsigned q[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) q[u] = (wi - u >= 0) ? wbase[wi - u] : 0u;
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        if (more && q[u] == IRUN && j >= 16) { emit(op_of(1), 16); j -= 16; wi--; if (FIRST && !(XP && i == pl.n)) val -= tp.gap_extend * 16; }
+                        if (more && q[u] == IRUN && j >= 16 && (!evm || j - 15 >= jplane)) { emit(op_of(1), 16); j -= 16; wi--; if (FIRST && !(XP && i == pl.n)) val -= tp.gap_extend * 16; }
                         else more = false;
                     }
                 }
@@ -239,9 +275,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
         // the same argmax).  No window needed: the reads without an indel (three quarters of the headline batch) skip the re-fill
         // stages altogether.  A read whose best alignment is anything else fails the equality (its optimum is higher) and asks for
         // its window as before.  (XP, the transposed AffineGapLocal: the same with a free row 0 and free steps along the last row.)
-        const uint8_t *ap = a_buf + a_start[pl.src];
-        int64_t P = (XP || j == i) ? 0 : tp.gap_open + tp.gap_extend * (int64_t)(j - i); // h(0, j - i): the leading gap (XP: row 0 is free)
-        for (int t = 0; t < i; t++) P += (int64_t)(kp.sc4[min((int)ap[t], 4) * 5 + min(wbeta.at((j - i) + t), 4)] >> 2);
+        const int64_t P = diag_ok ? val : diag_score(i, j); // (h(0, j - i), the leading gap, + the i diagonal steps)
         if (P == val) {
             emit(op_of(0), i); last_op = 0;
             li -= i;

@@ -40,6 +40,7 @@
 #include "fp_walk.hip.h"
 #include "aux_kernels.hip.h"
 #include "const_long.hip.h"
+#include "const_long_wg.hip.h"
 #include "affine_long.hip.h"
 #include "seed_kernels.hip.h"
 
@@ -319,7 +320,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
     if ((rc = c.misc.ensure(64))) return rc;
     if ((rc = c.fp_rowi.ensure((size_t)std::max<int64_t>(roff, 1) * 4))) return rc;
-    if ((rc = c.fp_tail.ensure((size_t)np * 4))) return rc;
+    if ((rc = c.fp_tail.ensure((size_t)np * 4 * FP_TAILW))) return rc;
     if ((rc = c.fp_ckpt.ensure((size_t)std::max<int64_t>(coff, 1) * 8))) return rc;
     if ((rc = c.fp_states.ensure((size_t)np * sizeof(FpState)))) return rc;
     if ((rc = c.fp_stage.ensure((size_t)np * CAP * sizeof(gnx_cigar)))) return rc;
@@ -656,14 +657,18 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         for (int64_t q2 = b; q2 < e; q2++) { if (plans[(size_t)q2].strips > 1) multi = true; m_maxc = std::max<int64_t>(m_maxc, plans[(size_t)q2].m); }
         int64_t n_blocks = (np + 3) / 4;
         const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB && !no_pipe();
+        // constant gap, int16 profile: several strips per workgroup, rows handed over through LDS (cl_sweep_wg_kernel; GNX_CL_WG=0: one strip per workgroup)
+        constexpr int CLW_NW = 4;
+        const bool wg = piped && !affine && p16 && !(getenv("GNX_CL_WG") && atoi(getenv("GNX_CL_WG")) == 0);
+        const int per_item = wg ? CLW_NW : 1;
         const int2 *d_smap = nullptr;
         int *d_sprog = nullptr;
         if (piped) {
-            std::vector<int2> smap;
+            std::vector<int2> smap; // (group, item): an item = one strip, or CLW_NW consecutive strips
             for (int gq = 0; gq < (np + 3) / 4; gq++) {
                 int smax = 0;
                 for (int q3 = 0; q3 < 4 && gq * 4 + q3 < np; q3++) smax = std::max(smax, (int)plans[(size_t)(b + gq * 4 + q3)].strips);
-                for (int st2 = 0; st2 < smax; st2++) smap.push_back(make_int2(gq, st2));
+                for (int st2 = 0; st2 < (smax + per_item - 1) / per_item; st2++) smap.push_back(make_int2(gq, st2));
             }
             n_blocks = (int64_t)smap.size();
             if (n_blocks > 0x7fffffff) { set_err("too many strips in one chunk%s", ""); return GNX_ENOMEM; }
@@ -683,11 +688,12 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         // pays for every publish with its own latency (64 pairs of C5: 17.4 -> 19.2 ms) and keeps the coarse interval.
         KParams kps = kp;
         kps.ckc = (int)ckc;
-        kps.rb_pub = n_blocks >= (int64_t)40 * c.n_cu ? 16 : RB_PUB; // (twice the wave slots of the piped sweep: 20 per CU)
+        kps.rb_pub = n_blocks * per_item >= (int64_t)40 * c.n_cu ? 16 : RB_PUB; // (twice the wave slots of the piped sweep: 20 per CU)
         if (const char *e = getenv("GNX_CL_PUB")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) kps.rb_pub = v; }
         int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
         if (affine && p16) hipLaunchKernelGGL(al_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
         else if (affine) hipLaunchKernelGGL(al_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
+        else if (wg) hipLaunchKernelGGL(cl_sweep_wg_kernel<CLW_NW>, dim3((unsigned)n_blocks), dim3(64 * CLW_NW), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
         else if (p16 && piped) hipLaunchKernelGGL(cl_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
         else if (p16) hipLaunchKernelGGL(cl_sweep_flat_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err);
         else if (piped) hipLaunchKernelGGL(cl_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);

@@ -55,6 +55,7 @@ constexpr int FP_SPAN = 192; // a re-fill window (one row block of <= 160 rows) 
 #define GNX_FP_PLANES 4
 #endif
 constexpr int FP_PLANES = GNX_FP_PLANES; // rows n .. n-3 keep their I-plane: a trailing gap sits on row n-d when the last d bases match the chunk end
+constexpr int FP_TAILW = 8; // dwords per pair of the sweep's small outputs: [0] corner tags, [1 + d] last event step of row n - d, [5] first tagged step, [6] events in use (fp_sweep.hip.h: GNX_FP_EVENTS)
 constexpr int FP_CAP = 64;   // CIGAR runs staged per pair and row block on the fast path (more -> general path)
 constexpr int FP_MAXS = 128; // row blocks of 160 rows the fast path sweeps (reads up to 20 480 bases; longer ones: snapshot path)
 constexpr int FP_TILE = 1024;                                  // straggler tiles: columns (c*FP_TILE, (c+1)*FP_TILE]
@@ -215,7 +216,10 @@ __device__ __forceinline__ int claim_items(int *cw, int stride, int depth) {
         const int sw = cw[gridDim.x];
         const int delay = sw & 0xffff;
         const long long grace = (sw >> 16) ? 100LL * ((sw >> 16) & 0xffff) : CLAIM_GRACE_TICKS;
-        if (delay && b * 2 < (int)gridDim.x) for (int i = 0; i < delay; i++) __builtin_amdgcn_s_sleep(127);
+        // who sleeps: the lower half of the grid; with a grace override (the steal leg) every other item of a chain instead, so that
+        // every awake workgroup has a sleeping direct predecessor whatever the grid looks like
+        const bool sleeper = (sw >> 16) ? (((b / stride) & 1) == 0) : (b * 2 < (int)gridDim.x);
+        if (delay && sleeper) for (int i = 0; i < delay; i++) __builtin_amdgcn_s_sleep(127);
         if (atomicCAS(&cw[b], 0, 1) != 0) n = -1;
         else while (n < depth) {
             // The predecessor's own workgroup gets a GRACE period to arrive (workgroups of one launch start within microseconds of

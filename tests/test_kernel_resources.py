@@ -53,13 +53,16 @@ BUDGET = [
     ("fp_sweep_kernel<19, false", 3), ("fp_sweep_kernel<20, false", 3), ("fp_sweep_kernel<19, true", 3), ("fp_sweep_kernel<20, true", 3), ("fp_sweep_levels_kernel", 2),
     ("fill_affine_kernel<false, false", 3), ("fill_affine_kernel<true, false", 3), ("fill_affine_kernel<false, true", 2), ("fill_affine_kernel<true, true", 2),
     ("fill_const_kernel<false, 0", 3), ("fill_const_kernel<false, 1", 3), ("fill_const_kernel<false, 2", 3), ("fill_const_kernel<true", 2),
-    ("cl_sweep_kernel<true>", 5), ("cl_sweep_flat_kernel<true>", 4), ("cl_sweep_flat_kernel<false>", 3), ("cl_sweep_kernel<false>", 3), ("al_sweep_kernel", 3),
+    ("cl_sweep_kernel<true>", 5), ("cl_sweep_wg_kernel<4>", 5), ("cl_sweep_flat_kernel<true>", 4), ("cl_sweep_flat_kernel<false>", 3), ("cl_sweep_kernel<false>", 3), ("al_sweep_kernel", 3),
     ("fp_walk_kernel", 6), ("traceback_kernel", 4), ("gsw_traceback_kernel", 8),
 ]
 # kernels that are allowed scratch (register-bound by design: their tiles live in LDS at one workgroup of 4 pairs per half CU)
-SCRATCH_OK = ("al_walk_kernel", "fp_sweep_kernel<19, true", "fp_sweep_kernel<20, true")  # (the transposed sweep: three values outside the steady loop)
+SCRATCH_OK = ("al_walk_kernel",)
+# a few values parked in scratch OUTSIDE the steady loops (the ISA listing shows the spills in the prologue / epilogue of the headline sweep -- it sits
+# exactly at the 168 registers of three waves per SIMD -- and one reload per 16-step block of address pairs in the multi-strip constant-gap sweep)
+SCRATCH_SMALL = {"fp_sweep_kernel<": 32, "cl_sweep_wg_kernel<": 32}
 # LDS per workgroup: handed out in granules of 1280 B on gfx950 (160 KB per CU) -- the budgets are granule counts
-LDS_GRANULES = [("fp_sweep_kernel", 11), ("fp_sweep_levels_kernel", 11), ("cl_sweep_kernel<true>", 6), ("cl_sweep_flat_kernel<true>", 6), ("fill_const_kernel<false, 0, true>", 6),
+LDS_GRANULES = [("fp_sweep_kernel", 11), ("fp_sweep_levels_kernel", 11), ("cl_sweep_kernel<true>", 6), ("cl_sweep_wg_kernel<4>", 25), ("cl_sweep_flat_kernel<true>", 6), ("fill_const_kernel<false, 0, true>", 6),
                 ("fill_affine_kernel<false, false, false, true, false, false, false>", 11)]
 
 
@@ -79,7 +82,8 @@ def test_register_budgets(kernels):
 
 def test_no_scratch_outside_the_declared_kernels(kernels):
     bad = [(n, k["private_segment_fixed_size"], k["vgpr_spill_count"]) for n, k in kernels.items()
-           if (k["private_segment_fixed_size"] or k["vgpr_spill_count"]) and not n.startswith(SCRATCH_OK) and "rocprim" not in n and "hipcub" not in n]
+           if (k["private_segment_fixed_size"] or k["vgpr_spill_count"]) and not n.startswith(SCRATCH_OK) and "rocprim" not in n and "hipcub" not in n
+           and not any(n.startswith(pre) and k["private_segment_fixed_size"] <= lim for pre, lim in SCRATCH_SMALL.items())]
     assert not bad, bad
 
 
