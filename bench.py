@@ -647,7 +647,7 @@ def main():
         path = {0: "general_path", 1: "fast_path", 2: "const_long"}[fast_path]
         kernel = {0: "fill_affine_kernel (full direction matrix)" if S["bits"] == 6 else "fill_const_kernel (full direction matrix)",
                   1: "fp_sweep_kernel<%d, %s> (fast-path forward sweep)" % (19 if READ_LEN <= 152 else 20, "true" if swap else "false"),
-                  2: "cl_sweep_kernel (score-only constant-gap sweep with wavefront snapshots)"}[fast_path]
+                  2: "cl_sweep_wg_kernel<4> (score-only constant-gap sweep with wavefront snapshots, four strips per workgroup handing rows over through LDS)"}[fast_path]
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), valid
         # only for the kernel sources they were taken from
         traffic, traffic_note, pmc = None, None, None

@@ -56,10 +56,10 @@ namespace {
 // GNX_FP_EVBR: the event update sits behind a wave-uniform branch (taken only when a LAST lane of a pair has an event: a few per cent
 // of the steps), so the steady step pays one v_cmp per plane row and nothing else.
 #ifndef GNX_FP_EVENTS
-#define GNX_FP_EVENTS 0
+#define GNX_FP_EVENTS 1
 #endif
 #ifndef GNX_FP_EVBR
-#define GNX_FP_EVBR 1
+#define GNX_FP_EVBR 0
 #endif
 constexpr int G8 = 8;
 constexpr int FP8_LW = 10;                 // dwords per lane per base (20 int16 entries)
@@ -298,7 +298,7 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
                     const int ho = hnew + vO4;
                     if (EV && BOTTOM && r >= RR - FP_PLANES) { // a plane row of the untagged part: remember the step if the gap could have been opened here
                         const bool evc = ho >= rt[r];
-                        if (GNX_FP_EVBR) { if (__builtin_amdgcn_ballot_w64(evc) & 0x0180018001800180ull) ev[RR - 1 - r] = evc ? t : ev[RR - 1 - r]; } // (the pairs' last lanes: 7, 8, 23, 24, ...)
+                        if (GNX_FP_EVBR) { if (__builtin_amdgcn_ballot_w64(evc) & 0x0180018001800180ull) { asm volatile(""); ev[RR - 1 - r] = evc ? t : ev[RR - 1 - r]; } } // (the pairs' last lanes: 7, 8, 23, 24, ...; the empty asm keeps the branch a branch: if-converted, the update costs two v_cndmask per row and step)
                         else ev[RR - 1 - r] = evc ? t : ev[RR - 1 - r];
                     }
                     rt[r] = max(ho, rt[r]);

@@ -1691,15 +1691,104 @@ int gnx_gsw_extend_batch(int side, const int64_t *scores, int64_t gap_pen, int64
                             out_score, out_ops, out_ops_off, side == GNX_GSW_LEFT ? 1 : 2, out_end_i, out_end_j);
 }
 
-int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const uint8_t *beta, int64_t m,
-                   int64_t *out_score, gnx_cigar **out_ops, int64_t *out_n_ops) {
-    if (!out_n_ops) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+/* align.AffineGap / ConstGap / ... for ONE pair (the body of every Go-signature function of the shim).
+ *
+ * Concurrency (the reference's house pattern is a pool of goroutines that each call align.* in a loop,
+ * genomeGraph/routines.go:12-65): calls from many threads are COMBINED.  Every caller queues its request and then takes the API lock;
+ * whoever holds the lock aligns, as ONE batch, every queued request that has the same parameters as its own (the others were queued
+ * while the previous batch was on the device), and hands each its result.  A caller that finds its request done when it gets the lock
+ * just returns.  One thread alone pays nothing (a batch of one goes straight through); 16 threads get batches of ~15 pairs and the
+ * device's batch throughput instead of 16 serial launches.  A failure inside a combined batch (a bad base in one pair) is re-run pair
+ * by pair, so that every caller sees the return code and message of its own pair only. */
+namespace {
+struct PairReq {
+    const gnx_params *p; const uint8_t *a; int64_t n; const uint8_t *b; int64_t m;
+    int64_t score = 0; gnx_cigar *ops = nullptr; int64_t n_ops = 0;
+    int rc = GNX_OK; char err[512] = ""; bool done = false;
+};
+std::mutex g_pq_mu;
+std::vector<PairReq *> g_pq;
+std::atomic<int64_t> g_pq_batches{0}, g_pq_pairs{0}; // combined batches run / pairs in them (gnx_debug_counter(1 / 2))
+
+int run_pair_alone(PairReq &r) {
     const int64_t zero = 0;
     int64_t *off = nullptr;
-    int rc = gnx_align_batch_windows(p, 1, alpha, n, &zero, &n, beta, m, &zero, &m, out_score, out_ops, &off);
-    if (rc) return rc;
-    *out_n_ops = off[1];
-    gnx_free(off);
+    static const uint8_t none = 0;
+    g_err[0] = 0;
+    int rc = run_host_sharded(r.p, 1, r.a ? r.a : &none, r.n, &zero, &r.n, r.b ? r.b : &none, r.m, &zero, &r.m, &r.score, &r.ops, &off);
+    if (rc == GNX_OK) { r.n_ops = off[1]; gnx_free(off); }
+    else memcpy(r.err, g_err, sizeof(r.err));
+    return rc;
+}
+// aligns the requests of `batch` (equal parameters) -- as ONE device batch when there are several; the caller holds the API lock
+void run_pair_batch(const gnx_params *p, std::vector<PairReq *> &batch) {
+    if (batch.size() == 1) batch[0]->rc = run_pair_alone(*batch[0]);
+    else if (batch.size() > 1) {
+        const int64_t nb = (int64_t)batch.size();
+        std::vector<int64_t> as((size_t)nb), al((size_t)nb), bs((size_t)nb), bl((size_t)nb), sc((size_t)nb);
+        int64_t ta = 0, tb = 0;
+        for (int64_t k = 0; k < nb; k++) { as[(size_t)k] = ta; al[(size_t)k] = batch[(size_t)k]->n; ta += batch[(size_t)k]->n; bs[(size_t)k] = tb; bl[(size_t)k] = batch[(size_t)k]->m; tb += batch[(size_t)k]->m; }
+        std::vector<uint8_t> ca((size_t)ta + 1), cb((size_t)tb + 1);
+        for (int64_t k = 0; k < nb; k++) {
+            if (batch[(size_t)k]->n) memcpy(ca.data() + as[(size_t)k], batch[(size_t)k]->a, (size_t)batch[(size_t)k]->n);
+            if (batch[(size_t)k]->m) memcpy(cb.data() + bs[(size_t)k], batch[(size_t)k]->b, (size_t)batch[(size_t)k]->m);
+        }
+        gnx_cigar *ops = nullptr;
+        int64_t *off = nullptr;
+        g_err[0] = 0;
+        int rc = run_host_sharded(p, nb, ca.data(), ta, as.data(), al.data(), cb.data(), tb, bs.data(), bl.data(), sc.data(), &ops, &off);
+        if (rc == GNX_OK) {
+            for (int64_t k = 0; k < nb && rc == GNX_OK; k++) {
+                PairReq &r = *batch[(size_t)k];
+                r.score = sc[(size_t)k]; r.n_ops = off[k + 1] - off[k];
+                r.ops = (gnx_cigar *)malloc((size_t)std::max<int64_t>(r.n_ops, 1) * sizeof(gnx_cigar)); // (gnx_free: not from the pinned pool -> free())
+                if (!r.ops) { rc = GNX_ENOMEM; break; }
+                memcpy(r.ops, ops + off[k], (size_t)r.n_ops * sizeof(gnx_cigar));
+                r.rc = GNX_OK;
+            }
+            gnx_free(ops); gnx_free(off);
+            g_pq_batches++; g_pq_pairs += nb;
+        }
+        if (rc != GNX_OK) { // one pair's error must not become its neighbours': every request on its own
+            for (PairReq *r : batch) { if (r->ops) { free(r->ops); r->ops = nullptr; } r->rc = run_pair_alone(*r); }
+        }
+    }
+}
+std::condition_variable g_pq_cv;
+bool g_pq_leader = false; // a combined batch is being aligned (guarded by g_pq_mu)
+} // namespace
+
+int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const uint8_t *beta, int64_t m,
+                   int64_t *out_score, gnx_cigar **out_ops, int64_t *out_n_ops) {
+    if (!p || !out_score || !out_ops || !out_n_ops || n < 0 || m < 0) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    PairReq self;
+    self.p = p; self.a = alpha; self.n = n; self.b = beta; self.m = m;
+    std::unique_lock<std::mutex> lk(g_pq_mu);
+    g_pq.push_back(&self);
+    while (!self.done) {
+        if (g_pq_leader) { g_pq_cv.wait(lk); continue; } // a batch is on the device: this request rides in the next one
+        // become the combiner: everything queued with this request's parameters is one batch (requests with other parameters stay
+        // queued; one of their owners combines them next)
+        g_pq_leader = true;
+        std::vector<PairReq *> batch;
+        for (size_t k = 0; k < g_pq.size();) {
+            if (g_pq[k] == &self || memcmp(g_pq[k]->p, p, sizeof(gnx_params)) == 0) { batch.push_back(g_pq[k]); g_pq.erase(g_pq.begin() + (long)k); }
+            else k++;
+        }
+        lk.unlock();
+        {
+            std::lock_guard<std::mutex> api(g_api_mu);
+            run_pair_batch(p, batch);
+        }
+        lk.lock();
+        for (PairReq *r : batch) r->done = true;
+        g_pq_leader = false;
+        g_pq_cv.notify_all();
+    }
+    lk.unlock();
+    // (self.done is set: either by this thread's batch or by the batch of the thread that held the lock before)
+    if (self.rc != GNX_OK) { memcpy(g_err, self.err, sizeof(g_err)); publish_err(); return self.rc; }
+    *out_score = self.score; *out_ops = self.ops; *out_n_ops = self.n_ops;
     return GNX_OK;
 }
 
@@ -1969,7 +2058,12 @@ int gnx_debug_counter(int which, int reset, int64_t *out) {
     std::lock_guard<std::mutex> api(g_api_mu);
     CtxScope sc(ctx_at(0));
     g_err[0] = 0;
-    if (which != 0 || !out) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    if (which < 0 || which > 2 || !out) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    if (which > 0) { // combined gnx_align_pair batches run / pairs served by them
+        *out = which == 1 ? g_pq_batches.load() : g_pq_pairs.load();
+        if (reset) { if (which == 1) g_pq_batches = 0; else g_pq_pairs = 0; }
+        return GNX_OK;
+    }
     int rc = ensure_init();
     if (rc) return rc;
     HIPCHK(hipSetDevice(g_ctx.device));

@@ -165,7 +165,10 @@ int gnx_align_batch_windows(const gnx_params *p, int64_t n_pairs,
                             const uint8_t *beta_buf, int64_t beta_buf_len, const int64_t *beta_start, const int64_t *beta_len,
                             int64_t *out_score, gnx_cigar **out_ops, int64_t **out_ops_off);
 
-/* One pair == batch of 1: the body of the Go-signature functions. */
+/* One pair == batch of 1: the body of the Go-signature functions.  Safe and EFFICIENT from many threads at once (a pool of
+ * goroutines calling align.* is the reference's house pattern, /root/reference/genomeGraph/routines.go:12-65): concurrent calls with
+ * equal parameters are combined into one device batch by whichever caller holds the library's lock; each caller still gets the
+ * result, return code and error text of its own pair. */
 int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const uint8_t *beta, int64_t m,
                    int64_t *out_score, gnx_cigar **out_ops, int64_t *out_n_ops);
 
@@ -188,7 +191,8 @@ int gnx_get_timing(gnx_timing *out);
 int gnx_debug_occupy(int n_workgroups, int milliseconds); /* refused with GNX_EINVAL unless the process runs with GNX_DEBUG_ENTRY=1 */
 /* Diagnostics: which = 0: number of items of pipelined launches (strips, row-block levels) that were run by a workgroup other
  * than their own since the last reset -- the abnormal path of the claim protocol, which tests/test_ticket.py forces and then
- * proves to have run.  reset != 0 zeroes the counter after reading. */
+ * proves to have run.  which = 1 / 2: combined batches run for concurrent gnx_align_pair calls / pairs served by them.
+ * reset != 0 zeroes the counter after reading. */
 int gnx_debug_counter(int which, int reset, int64_t *out);
 
 /* ---- "next" row N1: chunk and multiple-alignment variants (what cmd/faChunkAlign and popgen/dunn.go run) ---- */

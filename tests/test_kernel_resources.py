@@ -54,13 +54,13 @@ BUDGET = [
     ("fill_affine_kernel<false, false", 3), ("fill_affine_kernel<true, false", 3), ("fill_affine_kernel<false, true", 2), ("fill_affine_kernel<true, true", 2),
     ("fill_const_kernel<false, 0", 3), ("fill_const_kernel<false, 1", 3), ("fill_const_kernel<false, 2", 3), ("fill_const_kernel<true", 2),
     ("cl_sweep_kernel<true>", 5), ("cl_sweep_wg_kernel<4>", 5), ("cl_sweep_flat_kernel<true>", 4), ("cl_sweep_flat_kernel<false>", 3), ("cl_sweep_kernel<false>", 3), ("al_sweep_kernel", 3),
-    ("fp_walk_kernel", 6), ("traceback_kernel", 4), ("gsw_traceback_kernel", 8),
+    ("fp_walk_kernel", 5), ("traceback_kernel", 4), ("gsw_traceback_kernel", 8),
 ]
 # kernels that are allowed scratch (register-bound by design: their tiles live in LDS at one workgroup of 4 pairs per half CU)
 SCRATCH_OK = ("al_walk_kernel",)
 # a few values parked in scratch OUTSIDE the steady loops (the ISA listing shows the spills in the prologue / epilogue of the headline sweep -- it sits
 # exactly at the 168 registers of three waves per SIMD -- and one reload per 16-step block of address pairs in the multi-strip constant-gap sweep)
-SCRATCH_SMALL = {"fp_sweep_kernel<": 32, "cl_sweep_wg_kernel<": 32}
+SCRATCH_SMALL = {"fp_sweep_kernel<": 256, "cl_sweep_wg_kernel<": 32}
 # LDS per workgroup: handed out in granules of 1280 B on gfx950 (160 KB per CU) -- the budgets are granule counts
 LDS_GRANULES = [("fp_sweep_kernel", 11), ("fp_sweep_levels_kernel", 11), ("cl_sweep_kernel<true>", 6), ("cl_sweep_wg_kernel<4>", 25), ("cl_sweep_flat_kernel<true>", 6), ("fill_const_kernel<false, 0, true>", 6),
                 ("fill_affine_kernel<false, false, false, true, false, false, false>", 11)]

@@ -67,7 +67,7 @@ def main():
     # (series, path, pmc dir stem, kernel regex, pairs per launch, SQ dir stem, SQ pairs)
     cases = (("affine", "fast_path", "pmc_fast", r"^fp_sweep_kernel", 100000, "pmc_sq_fast", 100000),
              ("affine", "general_path", "pmc_general", r"^fill_affine_kernel", 100000, None, 0),
-             ("long", "const_long", "pmc_long", r"^cl_sweep_kernel", 1024, "pmc_sq_long", 1024))
+             ("long", "const_long", "pmc_long", r"^cl_sweep_(wg_)?kernel", 1024, "pmc_sq_long", 1024))
     sq_lines = []
     for series, path, stem, kre, pairs, sqstem, sqpairs in cases:
         tot = {}
@@ -139,7 +139,7 @@ def main():
         fh.write("\n")
     for nm, dst in (("bench.json", "_bench.json"), ("bench_long.json", "_bench_long.json"), ("all_series.jsonl", "_all_series.jsonl"), ("host_entry.jsonl", "_host_entry.jsonl"),
                     ("shapes_affine.jsonl", "_shapes_affine.jsonl"), ("shapes_const.jsonl", "_shapes_const.jsonl"), ("shapes_local.jsonl", "_shapes_local.jsonl"), ("gsw_reads.jsonl", "_gsw_reads.jsonl"), ("cabi_n1_n2.jsonl", "_cabi_n1_n2.jsonl"),
-                    ("pytest_gpu.log", "_pytest_gpu.log"), ("bench_2ranks_shared_gpu.json", "_bench_2ranks_shared_gpu.json"), ("lds_occupancy.txt", "_lds_occupancy.txt"), ("stress.log", "_stress.log"), ("switch_matrix.log", "_switch_matrix.log")):
+                    ("pytest_gpu.log", "_pytest_gpu.log"), ("bench_2ranks_shared_gpu.json", "_bench_2ranks_shared_gpu.json"), ("lds_occupancy.txt", "_lds_occupancy.txt"), ("stress.log", "_stress.log"), ("switch_matrix.log", "_switch_matrix.log"), ("concurrent_pairs.json", "_concurrent_pairs.json"), ("pmc_c5_wg_ab.txt", "_pmc_c5_wg_ab.txt"), ("wg_occupancy.txt", "_wg_occupancy.txt")):
         p = os.path.join(src, nm)
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copyfile(p, os.path.join(prof, rnd + dst))

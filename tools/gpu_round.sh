@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-end GPU sequence: parity suite, smoke, bench lines, rocprofv3 kernel stats + HBM / SQ PMC passes (separate runs, as the
 # MI355X guide prescribes).  Usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tag]; then, in the build container,
-# python tools/collect_profiles.py gpurun_out/<tag> r3
-tag=${1:-r3}
+# python tools/collect_profiles.py gpurun_out/<tag> r4
+tag=${1:-r4}
 repo=$PWD
 out=$repo/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
@@ -45,5 +45,11 @@ timeout 600 python tools/bench_shapes.py local > $out/shapes_local.jsonl 2>> $ou
 tools/lds_occupancy.bin > $out/lds_occupancy.txt 2>>$out/bench.err
 timeout 600 python tools/bench_gsw.py > $out/gsw_reads.jsonl 2>> $out/bench.err
 g++ -std=c++17 -O2 -Iinclude -o tools/bench_cabi.bin tools/bench_cabi.cpp gonomics_amd/libgonomics_align_hip.so -Wl,-rpath,$PWD/gonomics_amd -L/opt/rocm/lib -lamdhip64 2>> $out/bench.err && tools/bench_cabi.bin > $out/cabi_n1_n2.jsonl 2>> $out/bench.err
+# round 4: concurrency at the boundary, the C5 sweep's counters with one strip / four strips per workgroup, workgroup occupancy census, stress
+g++ -std=c++17 -O2 -pthread -Iinclude -o tests/cpp/concurrent_pairs_test.bin tests/cpp/concurrent_pairs_test.cpp gonomics_amd/libgonomics_align_hip.so -Wl,-rpath,$PWD/gonomics_amd -L/opt/rocm/lib -lamdhip64 2>> $out/bench.err && tests/cpp/concurrent_pairs_test.bin 16 1000 8 > $out/concurrent_pairs.json 2>> $out/bench.err
+bash tools/pmc_env_ab.sh gpurun_out/$tag/c5_ab "--no-cpu --no-host --no-extras --series long --pairs 1024 --steps 1 --warmup 0 --verify 0" "cl_sweep" "wg4:GNX_CL_WG=1" "one_strip:GNX_CL_WG=0" > /dev/null 2>> $out/bench.err; cp gpurun_out/$tag/c5_ab/pmc_ab.txt $out/pmc_c5_wg_ab.txt
+tools/wg_occupancy.bin > $out/wg_occupancy.txt 2>> $out/bench.err
+timeout 700 python tools/stress.py ${GNX_STRESS_S:-420} 77 > $out/stress.log 2>&1
+[ -n "$GNX_SWITCH_MATRIX" ] && bash tools/switch_matrix.sh > $out/switch_matrix.log 2>&1
 find $out -name '*.db' -size +20M -delete
 tail -3 $out/pytest_gpu.log; tail -1 $out/smoke.log; cat $out/bench.json | cut -c1-400; cat $out/bench_long.json | cut -c1-400
