@@ -41,6 +41,7 @@
 #include "aux_kernels.hip.h"
 #include "const_long.hip.h"
 #include "const_long_wg.hip.h"
+#include "const_long_walk.hip.h"
 #include "affine_long.hip.h"
 #include "seed_kernels.hip.h"
 
@@ -713,7 +714,24 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
                 hipLaunchKernelGGL(kern, gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
             };
             const bool wide = ckc == CKC;
-            if (p16) {
+            // speculative re-fills of the next tiles by the wave's other lane groups (cl_walk_spec_kernel): GNX_CL_WALK_SPEC = 0 / 3 / 4 tiles per round
+            // Three tiles per round while every pair of the launch is resident at once (33.6 KB of LDS: four workgroups per CU) and the walk is a
+            // latency chain: 1024 pairs of C5 37.9 -> 28.6 ms.  With more pairs than that the plain walk's eight workgroups per CU win
+            // (2048 pairs, 448-step tiles: 42 ms plain, 111 ms speculative), and four tiles per round (three workgroups per CU) never pay.
+            int spec = (np <= 4 * c.n_cu && !wide) ? 3 : 0;
+            if (const char *se = getenv("GNX_CL_WALK_SPEC")) { const int v = atoi(se); spec = (v == 3 || v == 4) ? v : 0; }
+            if (npe) spec = 0; // (an explicit GNX_CL_WALK_NP asks for the plain walk)
+            const dim3 gs((unsigned)np);
+            auto launch_spec = [&](auto kern) {
+                hipLaunchKernelGGL(kern, gs, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
+            };
+            if (spec && p16) {
+                if (spec == 3) { if (wide) launch_spec(cl_walk_spec_kernel<true, CKC, 3>); else launch_spec(cl_walk_spec_kernel<true, CKC_SMALL, 3>); }
+                else { if (wide) launch_spec(cl_walk_spec_kernel<true, CKC, 4>); else launch_spec(cl_walk_spec_kernel<true, CKC_SMALL, 4>); }
+            } else if (spec) {
+                if (spec == 3) { if (wide) launch_spec(cl_walk_spec_kernel<false, CKC, 3>); else launch_spec(cl_walk_spec_kernel<false, CKC_SMALL, 3>); }
+                else { if (wide) launch_spec(cl_walk_spec_kernel<false, CKC, 4>); else launch_spec(cl_walk_spec_kernel<false, CKC_SMALL, 4>); }
+            } else if (p16) {
                 if (wnp == 1) { if (wide) launch_walk(cl_walk_kernel<true, 1, CKC>); else launch_walk(cl_walk_kernel<true, 1, CKC_SMALL>); }
                 else if (wnp == 2) { if (wide) launch_walk(cl_walk_kernel<true, 2, CKC>); else launch_walk(cl_walk_kernel<true, 2, CKC_SMALL>); }
                 else { if (wide) launch_walk(cl_walk_kernel<true, 4, CKC>); else launch_walk(cl_walk_kernel<true, 4, CKC_SMALL>); }
@@ -1755,7 +1773,8 @@ void run_pair_batch(const gnx_params *p, std::vector<PairReq *> &batch) {
     }
 }
 std::condition_variable g_pq_cv;
-bool g_pq_leader = false; // a combined batch is being aligned (guarded by g_pq_mu)
+bool g_pq_leader = false; // a combined batch is being collected / aligned (guarded by g_pq_mu)
+size_t g_pq_prev_batch = 0; // pairs in the batch before (guarded by g_pq_mu)
 } // namespace
 
 int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const uint8_t *beta, int64_t m,
@@ -1765,11 +1784,24 @@ int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const u
     self.p = p; self.a = alpha; self.n = n; self.b = beta; self.m = m;
     std::unique_lock<std::mutex> lk(g_pq_mu);
     g_pq.push_back(&self);
+    if (g_pq_leader) g_pq_cv.notify_all(); // (a combiner may be collecting: it counts arrivals)
     while (!self.done) {
         if (g_pq_leader) { g_pq_cv.wait(lk); continue; } // a batch is on the device: this request rides in the next one
         // become the combiner: everything queued with this request's parameters is one batch (requests with other parameters stay
         // queued; one of their owners combines them next)
         g_pq_leader = true;
+        if (g_pq.size() > 1 || g_pq_prev_batch > 1) {
+            // Other threads are calling too: the callers of the batch that has just been handed out are on their way back with their next
+            // pair.  Collect until nobody has arrived for ~25 us (at most 200 us): without this a pool of 16 threads settles into two groups of 8
+            // that take turns (measured: 8 pairs per batch, 6.5 x the serial rate); one thread alone never waits.
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+            size_t seen = g_pq.size();
+            while (std::chrono::steady_clock::now() < t_end) {
+                g_pq_cv.wait_for(lk, std::chrono::microseconds(25));
+                if (g_pq.size() == seen) break;
+                seen = g_pq.size();
+            }
+        }
         std::vector<PairReq *> batch;
         for (size_t k = 0; k < g_pq.size();) {
             if (g_pq[k] == &self || memcmp(g_pq[k]->p, p, sizeof(gnx_params)) == 0) { batch.push_back(g_pq[k]); g_pq.erase(g_pq.begin() + (long)k); }
@@ -1782,6 +1814,7 @@ int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const u
         }
         lk.lock();
         for (PairReq *r : batch) r->done = true;
+        g_pq_prev_batch = batch.size();
         g_pq_leader = false;
         g_pq_cv.notify_all();
     }

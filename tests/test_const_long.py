@@ -51,6 +51,32 @@ def test_const_long_fuzz(gpu_lib, monkeypatch, mode, cs):
             common.assert_same(got, exp, "seed %d %s" % (seed, name))
 
 
+@pytest.mark.parametrize("spec", ["0", "3", "4"])
+@pytest.mark.parametrize("cs", [7, 10000])
+def test_const_long_walk_speculation(gpu_lib, monkeypatch, spec, cs):
+    """the walk with 0 / 3 / 4 tiles re-filled per round (cl_walk_kernel / cl_walk_spec_kernel: the wave's other lane groups re-fill the tiles
+    a diagonal path enters next): near-diagonal ONT-like pairs (every guess right), ragged random pairs (most guesses wrong), both
+    snapshot spacings, small checkerboards (quirk Q2) -- a wrong guess may cost a round, never a bit"""
+    if os.environ.get("GNX_CLONG") == "0":
+        pytest.skip("the snapshot path is switched off from outside")
+    monkeypatch.setenv("GNX_CLONG", "2")
+    monkeypatch.setenv("GNX_CL_WALK_SPEC", spec)
+    rng = np.random.default_rng(77)
+    alphas, betas = _ragged(31, 20, 1900, 5000)
+    for _ in range(6):  # reads of 1500 .. 4000 bases inside windows of 6 .. 9 kb, 10 % errors
+        m = int(rng.integers(6000, 9000)); n = int(rng.integers(1500, 4000))
+        win = rng.integers(0, 4, size=m).astype(np.uint8)
+        off = int(rng.integers(0, m - n - n // 8))
+        alphas.append(common.mutate(rng, win[off:off + n + n // 8], sub=0.04, indel=0.06, geo=0.6)[:n]); betas.append(win)
+    exp = oracle.align_batch(1, MX["HumanChimpTwo"], -430, 0, alphas, betas, cs, cs, threads=8)
+    p = gpu_lib.make_params(gpu_lib.GNX_CONST_GAP, MX["HumanChimpTwo"], -430, 0, cs, cs)
+    for ckc in ("224", "448"):
+        monkeypatch.setenv("GNX_CL_CKC", ckc)
+        got = gpu_lib.align_batch(p, alphas, betas)
+        common.expect_route(gpu_lib.get_timing(), 2)
+        common.assert_same(got, exp, "spec %s ckc %s" % (spec, ckc))
+
+
 @pytest.mark.parametrize("ckc", ["", "224", "448"])
 @pytest.mark.parametrize("nopipe", [False, True])
 def test_const_long_strips_and_chunks(gpu_lib, monkeypatch, nopipe, ckc):
