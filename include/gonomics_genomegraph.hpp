@@ -386,6 +386,11 @@ inline std::vector<Cigar> mergeRoute(const std::vector<Cigar> &routeIn, const gn
     }
     return route;
 }
+// What runs a batch of extension DPs: the library (gnx_gsw_extend_batch).  A function pointer so that a benchmark can put the CPU
+// restatement behind the same read path for a baseline beside it (tests/cpp/gsw_cpu_backend.cpp; nothing in the product sets it).
+using GswExtendFn = int (*)(int, const int64_t *, int64_t, int64_t, const uint8_t *, const int64_t *, const uint8_t *, const int64_t *,
+                            int64_t *, int64_t *, int64_t *, gnx_cigar **, int64_t **);
+inline GswExtendFn &gswExtendBackend() { static GswExtendFn f = gnx_gsw_extend_batch; return f; }
 // LeftDynamicAln / RightDynamicAln (search.go:234-321) for a batch of requests of one side
 inline std::vector<DpResult> DynamicAlnBatch(int side, const std::vector<const DpRequest *> &reqs, const int64_t *scores25, int64_t gapPen) {
     const size_t n = reqs.size();
@@ -402,7 +407,7 @@ inline std::vector<DpResult> DynamicAlnBatch(int side, const std::vector<const D
     std::vector<int64_t> sc(n ? n : 1), ei(n ? n : 1), ej(n ? n : 1);
     gnx_cigar *ops = nullptr;
     int64_t *off = nullptr;
-    gnxCheck(gnx_gsw_extend_batch(side, scores25, gapPen, (int64_t)n, acat.data(), aoff.data(), bcat.data(), boff.data(), sc.data(), ei.data(), ej.data(), &ops, &off));
+    gnxCheck(gswExtendBackend()(side, scores25, gapPen, (int64_t)n, acat.data(), aoff.data(), bcat.data(), boff.data(), sc.data(), ei.data(), ej.data(), &ops, &off));
     std::vector<DpResult> out(n);
     for (size_t p = 0; p < n; p++) {
         out[p].score = sc[p]; out[p].i = ei[p]; out[p].j = ej[p];

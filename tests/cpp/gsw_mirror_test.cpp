@@ -19,8 +19,14 @@ static Bases read_bases(std::istream &in) {
     return b;
 }
 
+extern "C" int cpu_gsw_extend_batch(int, const int64_t *, int64_t, int64_t, const uint8_t *, const int64_t *, const uint8_t *, const int64_t *,
+                                    int64_t *, int64_t *, int64_t *, gnx_cigar **, int64_t **); // tests/cpp/gsw_cpu_backend.cpp (CPU oracle on all host threads)
+extern int cpu_gsw_threads;
+
 int main(int argc, char **argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s case.txt out.txt\n", argv[0]); return 64; }
+    if (argc < 3) { fprintf(stderr, "usage: %s case.txt out.txt [pairs|reads] [cpu [threads]]\n", argv[0]); return 64; }
+    // "cpu": the extension DPs of the same read path on the CPU oracle instead of the device (a baseline beside the GPU number)
+    if (argc > 4 && std::string(argv[4]) == "cpu") { gswExtendBackend() = cpu_gsw_extend_batch; if (argc > 5) cpu_gsw_threads = atoi(argv[5]); }
     if (gnx_init(0, 0) != GNX_OK) { fprintf(stderr, "%s\n", gnx_last_error()); return 2; } // no HIP device: no CPU fallback
     std::ifstream in(argv[1]);
     GenomeGraph g;

@@ -23,8 +23,11 @@ def _build():
     if not os.path.exists(LIB):
         import __graft_entry__
         __graft_entry__.build()
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", BIN, SRC, LIB,
-                           "-Wl,-rpath," + os.path.join(ROOT, "gonomics_amd"), "-L/opt/rocm/lib", "-lamdhip64"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], stdout=subprocess.DEVNULL)
+    # (the CPU backend + the oracle are linked for the "cpu" baseline mode of this TEST binary only)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", BIN, SRC,
+                           os.path.join(ROOT, "tests", "cpp", "gsw_cpu_backend.cpp"), LIB, os.path.join(ROOT, "oracle", "liboracle.so"),
+                           "-Wl,-rpath," + os.path.join(ROOT, "gonomics_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-L/opt/rocm/lib", "-lamdhip64"])
 
 
 def write_case(path, seqs, edges, reads, seed_len, seed_step, sc):
@@ -77,6 +80,9 @@ def test_cpp_gsw_mirror_equals_python_mirror(gpu_lib, tmp_path, kind, seed_len, 
     assert subprocess.call([BIN, str(tmp_path / "case.txt"), str(tmp_path / "out.txt")]) == 0
     rows, timing = read_out(str(tmp_path / "out.txt"))
     assert len(rows) == len(reads) and timing is not None
+    # the benchmark's CPU-baseline mode (extension DPs on the CPU oracle, all host threads) walks the same read path to the same results
+    assert subprocess.call([BIN, str(tmp_path / "case.txt"), str(tmp_path / "out_cpu.txt"), "reads", "cpu"]) == 0
+    assert read_out(str(tmp_path / "out_cpu.txt"))[0] == rows
     g = build(seqs, edges)
     index = gg.SeedIndex(g.Nodes, seed_len, step)
     bigs = [gg.FastqBig("r%d" % k, rd) for k, rd in enumerate(reads)]

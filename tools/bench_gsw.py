@@ -74,6 +74,14 @@ def main():
             print(json.dumps({"series": "GswBatchToGiraf through the C++ mirror: %s reads, same graph" % name, "mapped": int(sum(r[7] > 0 for r in rows)),
                               "index_ms": timing[0], "seeds_traversals_dps_ms": timing[1], "dp_rounds": int(timing[2]), "reads_per_s": len(batch) / (timing[1] / 1e3),
                               "equals_python_mirror": same}), flush=True)
+            # CPU baseline beside it: the SAME read path (device seeds, the C++ mirror's loop) with the extension DPs on the
+            # CPU oracle (or_gsw_extend, literal restatement of search.go:234-321) on every host thread -- the reference's -t worker pool
+            subprocess.check_call([tc.BIN, os.path.join(td, "case.txt"), os.path.join(td, "out_cpu.txt"), "reads", "cpu"])
+            rows_c, timing_c = tc.read_out(os.path.join(td, "out_cpu.txt"))
+            print(json.dumps({"series": "cpu_baseline: the same read path, extension DPs on the CPU oracle (all host threads): %s reads" % name,
+                              "host_threads": os.cpu_count(), "seeds_traversals_dps_ms": timing_c[1], "reads_per_s": len(batch) / (timing_c[1] / 1e3),
+                              "equals_gpu_results": rows_c == rows, "gpu_vs_cpu": timing_c[1] / timing[1],
+                              "kind": "port (oracle/gnx_oracle.c); seeds and index stay on the device in both runs"}), flush=True)
     census(rng)
 
 
