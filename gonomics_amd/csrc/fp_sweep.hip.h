@@ -58,6 +58,9 @@ namespace {
 #ifndef GNX_FP_EVENTS
 #define GNX_FP_EVENTS 1
 #endif
+#ifndef GNX_FP_EVPIN
+#define GNX_FP_EVPIN 1
+#endif
 #ifndef GNX_FP_EVBR
 #define GNX_FP_EVBR 0
 #endif
@@ -299,7 +302,12 @@ __device__ __forceinline__ void fp_sweep_body(int *__restrict__ lds, const int w
                     if (EV && BOTTOM && r >= RR - FP_PLANES) { // a plane row of the untagged part: remember the step if the gap could have been opened here
                         const bool evc = ho >= rt[r];
                         if (GNX_FP_EVBR) { if (__builtin_amdgcn_ballot_w64(evc) & 0x0180018001800180ull) { asm volatile(""); ev[RR - 1 - r] = evc ? t : ev[RR - 1 - r]; } } // (the pairs' last lanes: 7, 8, 23, 24, ...; the empty asm keeps the branch a branch: if-converted, the update costs two v_cndmask per row and step)
-                        else ev[RR - 1 - r] = evc ? t : ev[RR - 1 - r];
+                        else {
+                            ev[RR - 1 - r] = evc ? t : ev[RR - 1 - r];
+#if GNX_FP_EVPIN
+                            asm volatile("" : "+v"(ev[RR - 1 - r])); // the update stays in its step (left alone, the scheduler collects the 32 updates of a half block at its end)
+#endif
+                        }
                     }
                     rt[r] = max(ho, rt[r]);
                     dnn = max(ho, dnu);

@@ -1,7 +1,7 @@
 // gonomics_genomegraph.hpp -- C++ host mirror of the graph aligner's read path over the C ABI of libgonomics_align_hip.so
 // ("next" rows N2 and N4 of SURVEY 8f).  Header-only, C++17.  Same structure and the same parity contract as the Python mirror
-// gonomics_amd/genomeGraph.py (see its module docstring: UNPINNED by the reference's tests; value semantics where Go shares
-// backing arrays between sibling branches; > 100 seeds sorted stably by TotalLength).
+// gonomics_amd/genomeGraph.py (see its module docstring: UNPINNED by the reference's tests; Go's shared backing arrays between sibling
+// branches are modelled -- CigSlice, SeedSlice --; > 100 seeds sorted stably by TotalLength).
 //
 //   N2  LeftDynamicAln / RightDynamicAln               /root/reference/genomeGraph/search.go:234-321   -> gnx_gsw_extend_batch
 //       LeftAlignTraversal / RightAlignTraversal        search.go:166-232                               -> Traversal (explicit stack)
@@ -230,21 +230,68 @@ inline std::vector<uint32_t> getSeedPath(const SeedDev *s) {
     for (; s; s = s->NextPart.get()) p.push_back(s->TargetId);
     return p;
 }
-inline std::vector<SeedPtr> extendToTheRightDev(const Node &node, FastqBig &read, int readStart, int nodeStart, bool posStrand) {
+// Go's append capacities (runtime/slice.go nextslicecap + roundupsize over the allocator's size classes; go.mod: go 1.25)
+inline int64_t goNextCap(int64_t newLen, int64_t oldCap, int64_t elemSize = 16) {
+    static const int64_t classes[] = {0, 8, 16, 24, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 208, 224, 240, 256, 288, 320, 352, 384, 416, 448, 480, 512, 576, 640,
+                                      704, 768, 896, 1024, 1152, 1280, 1408, 1536, 1792, 2048, 2304, 2688, 3072, 3200, 3456, 4096, 4864, 5376, 6144, 6528, 6784, 6912,
+                                      8192, 9472, 9728, 10240, 10880, 12288, 13568, 14336, 16384, 18432, 19072, 20480, 21760, 24576, 27264, 28672, 32768};
+    int64_t newcap = oldCap;
+    if (newLen > 2 * oldCap) newcap = newLen;
+    else if (oldCap < 256) newcap = 2 * oldCap;
+    else while (newcap < newLen) newcap += (newcap + 3 * 256) >> 2;
+    int64_t mem = newcap * elemSize;
+    if (mem <= 32768) { for (int64_t c : classes) if (c >= mem) { mem = c; break; } }
+    else mem = (mem + 8191) / 8192 * 8192;
+    return mem / elemSize;
+}
+// []SeedDev as extendToTheRightDev uses it (search.go:425-461): the cells are SeedDev objects with identity -- `NextPart: &nextParts[j]`
+// points AT a cell -- and the slice is handed back into the call for the next edge of node.Next, where `answer = answer[:0]` + append
+// overwrite the cells in place: a seed made for the first edge can end up pointing at the part made for the second one (round 4; rounds
+// 1-3 built fresh vectors).  Capacities follow Go's append (SeedDev: 32 bytes).
+struct SeedSlice {
+    std::vector<SeedPtr> arr; // the backing array: arr.size() == cap
+    size_t n = 0;
+    bool nil = true;
+    SeedSlice append(const SeedDev &v) const {
+        SeedSlice s = *this; s.nil = false;
+        if (n < arr.size()) { *s.arr[n] = v; s.n = n + 1; return s; } // in place: whoever points at this cell sees the new seed
+        const size_t cap = (size_t)goNextCap((int64_t)n + 1, (int64_t)arr.size(), 32);
+        s.arr.assign(cap, nullptr);
+        for (size_t k = 0; k < cap; k++) s.arr[k] = std::make_shared<SeedDev>(k < n ? *arr[k] : SeedDev{0, 0, 0, 0, true, 0, nullptr});
+        *s.arr[n] = v; s.n = n + 1;
+        return s;
+    }
+};
+inline SeedSlice extendRightSlices(const Node &node, FastqBig &read, int readStart, int nodeStart, bool posStrand, SeedSlice answer) {
+    answer.n = 0; // answer = answer[:0]
     read.rainbows();
     const int nodeOffset = nodeStart % 32;
     const int readOffset = 31 - ((readStart - nodeOffset + 31) % 32);
     const auto &rain = posStrand ? read.Rainbow : read.RainbowRc;
     const int rightMatches = CountRightMatches(node.SeqTwoBit, nodeStart, rain[readOffset], readStart + readOffset);
-    std::vector<SeedPtr> answer;
-    if (rightMatches == 0) return answer;
+    if (rightMatches == 0) return SeedSlice(); // nil
+    SeedSlice nextParts;
     if (readStart + rightMatches < (int)read.Seq.size() && nodeStart + rightMatches == node.SeqTwoBit.Len && !node.Next.empty()) {
-        for (const Edge &e : node.Next)
-            for (const SeedPtr &nxt : extendToTheRightDev(*e.Dest, read, readStart + rightMatches, 0, posStrand))
-                answer.push_back(mkSeed(node.Id, nodeStart, readStart, rightMatches, posStrand, rightMatches + nxt->TotalLength, nxt));
+        for (const Edge &e : node.Next) {
+            nextParts = extendRightSlices(*e.Dest, read, readStart + rightMatches, 0, posStrand, nextParts);
+            for (size_t j = 0; j < nextParts.n; j++)
+                answer = answer.append(SeedDev{node.Id, (uint32_t)nodeStart, (uint32_t)readStart, (uint32_t)rightMatches, posStrand, (uint32_t)rightMatches + nextParts.arr[j]->TotalLength, nextParts.arr[j]});
+        }
     }
-    if (answer.empty()) answer.push_back(mkSeed(node.Id, nodeStart, readStart, rightMatches, posStrand, rightMatches));
+    if (answer.n == 0) { // answer = []SeedDev{currNode}: a fresh array of one
+        SeedSlice one;
+        one.arr.push_back(std::make_shared<SeedDev>(SeedDev{node.Id, (uint32_t)nodeStart, (uint32_t)readStart, (uint32_t)rightMatches, posStrand, (uint32_t)rightMatches, nullptr}));
+        one.n = 1; one.nil = false;
+        return one;
+    }
     return answer;
+}
+// the seeds (value copies, as `append(finalSeeds, tempSeeds...)` takes them) that start at (node, nodeStart) / readStart and run to the right
+inline std::vector<SeedPtr> extendToTheRightDev(const Node &node, FastqBig &read, int readStart, int nodeStart, bool posStrand) {
+    const SeedSlice sl = extendRightSlices(node, read, readStart, nodeStart, posStrand, SeedSlice());
+    std::vector<SeedPtr> out;
+    for (size_t k = 0; k < sl.n; k++) out.push_back(std::make_shared<SeedDev>(*sl.arr[k]));
+    return out;
 }
 inline std::vector<SeedPtr> leftHelper(const Node &node, FastqBig &read, const SeedPtr &nextPart) {
     read.rainbows();
@@ -359,29 +406,63 @@ inline bool seedCouldBeBetter(int64_t seedLen, int64_t currBestScore, int64_t pe
     return false;
 }
 
+// ---- Go slices ----------------------------------------------------------------------------------------------------------------------
+// LeftAlignTraversal / RightAlignTraversal hand ONE route slice from sibling to sibling, keep headers of it (sk.leftAlignment =
+// dynamicScore.route), reverse it in place, and GraphSmithWatermanToGiraf appends to it in place (cigar.Append / Concat): what a later
+// sibling's DP writes through the shared backing array shows through every header that still points into it, until an append outgrows
+// the capacity and moves to a new array.  Rounds 1-3 copied vectors ("value semantics") and differed from the Go program on ~12 % of
+// the reads of a variant graph (VERDICT r3 missing 1).  The model: (backing array, offset, len, cap) + Go 1.25's growth rule
+// (runtime/slice.go nextslicecap + roundupsize over the allocator's size classes; go.mod: go 1.25; cigar.Cigar is 16 bytes).
+class CigSlice { // []cigar.Cigar as Go sees it
+  public:
+    CigSlice() = default;
+    static CigSlice make(int64_t len, int64_t cap) { CigSlice s; s.arr_ = std::make_shared<std::vector<Cigar>>((size_t)cap); s.n_ = len; s.cap_ = cap; return s; }
+    int64_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    Cigar &operator[](int64_t i) const { return (*arr_)[(size_t)(off_ + i)]; } // (through the shared array, also from a const header)
+    CigSlice tail(int64_t k) const { CigSlice s = *this; s.off_ += k; s.n_ -= k; s.cap_ -= k; return s; }
+    // append(s, v...): in place while the capacity lasts, else a new array (old elements copied) of Go's next capacity
+    CigSlice append(const Cigar *v, int64_t cnt) const {
+        const int64_t need = n_ + cnt;
+        if (need <= cap_) { for (int64_t k = 0; k < cnt; k++) (*arr_)[(size_t)(off_ + n_ + k)] = v[k]; CigSlice s = *this; s.n_ = need; return s; }
+        CigSlice s = make(need, goNextCap(need, cap_));
+        for (int64_t k = 0; k < n_; k++) (*s.arr_)[(size_t)k] = (*this)[k];
+        for (int64_t k = 0; k < cnt; k++) (*s.arr_)[(size_t)(n_ + k)] = v[k];
+        return s;
+    }
+    CigSlice append(const Cigar &v) const { return append(&v, 1); }
+    CigSlice append(const CigSlice &o) const { std::vector<Cigar> tmp = o.toVector(); return append(tmp.data(), (int64_t)tmp.size()); } // (the values first: o may share the array)
+    void reverse() const { for (int64_t i = 0, j = n_ - 1; i < n_ / 2; i++, j--) std::swap((*this)[i], (*this)[j]); } // cigar.ReverseCigar: in place
+    std::vector<Cigar> toVector() const { std::vector<Cigar> v((size_t)n_); for (int64_t k = 0; k < n_; k++) v[(size_t)k] = (*this)[k]; return v; }
+
+  private:
+    std::shared_ptr<std::vector<Cigar>> arr_;
+    int64_t off_ = 0, n_ = 0, cap_ = 0;
+};
+
 // ---- N2: the DPs, batched ---------------------------------------------------------------------------------------------------------
 struct DpRequest {
     int side = GNX_GSW_LEFT;
     Bases target;
     const uint8_t *read = nullptr;
     size_t readLen = 0;
-    std::vector<Cigar> route; // dynamicScore.route on entry (carried over from the sibling branch before, search.go:104-107)
+    CigSlice route; // dynamicScore.route on entry (carried over from the sibling branch before, search.go:104-107)
 };
 struct DpResult {
     int64_t score = 0;
-    std::vector<Cigar> route;
+    CigSlice route;
     int64_t i = 0, j = 0;
 };
-// the route-building loop of search.go:252-262 / 298-308 applied to the traced runs (traceback order)
-inline std::vector<Cigar> mergeRoute(const std::vector<Cigar> &routeIn, const gnx_cigar *runs, int64_t nRuns) {
-    std::vector<Cigar> route = routeIn;
-    size_t idx = 0;
+// the route-building loop of search.go:252-262 / 298-308 applied to the traced runs (traceback order): increments go through the
+// shared array of `route`, appends follow Go's capacities
+inline CigSlice mergeRoute(CigSlice route, const gnx_cigar *runs, int64_t nRuns) {
+    int64_t idx = 0;
     for (int64_t k = 0; k < nRuns; k++) {
         const uint8_t op = opFromCol(runs[k].op);
         for (int64_t x = 0; x < runs[k].run_length; x++) {
-            if (route.empty()) route.push_back(Cigar{1, op});
+            if (route.empty()) route = route.append(Cigar{1, op});
             else if (route[idx].Op == op) route[idx].RunLength++;
-            else { route.push_back(Cigar{1, op}); idx++; }
+            else { route = route.append(Cigar{1, op}); idx++; }
         }
     }
     return route;
@@ -411,11 +492,7 @@ inline std::vector<DpResult> DynamicAlnBatch(int side, const std::vector<const D
     std::vector<DpResult> out(n);
     for (size_t p = 0; p < n; p++) {
         out[p].score = sc[p]; out[p].i = ei[p]; out[p].j = ej[p];
-        if (!reqs[p]->route.empty()) out[p].route = mergeRoute(reqs[p]->route, ops + off[p], off[p + 1] - off[p]);
-        else {
-            out[p].route.reserve((size_t)(off[p + 1] - off[p]));
-            for (int64_t k = off[p]; k < off[p + 1]; k++) out[p].route.push_back(Cigar{ops[k].run_length, opFromCol(ops[k].op)});
-        }
+        out[p].route = mergeRoute(reqs[p]->route, ops + off[p], off[p + 1] - off[p]);
     }
     gnx_free(ops);
     gnx_free(off);
@@ -424,7 +501,7 @@ inline std::vector<DpResult> DynamicAlnBatch(int side, const std::vector<const D
 
 // ---- N2: LeftAlignTraversal / RightAlignTraversal (search.go:166-232) as a stack machine ---------------------------------------
 struct TraversalResult {
-    std::vector<Cigar> aln;
+    CigSlice aln;
     int64_t score = 0, t = 0, q = 0; // left: targetStart, queryStart; right: targetEnd, queryEnd
     std::vector<uint32_t> path;
 };
@@ -471,7 +548,7 @@ class Traversal {
             } else { // every branch tried: hand the best one up (search.go:196-198, 228-231: ReverseCigar; the left one reverses its path too)
                 r = std::move(f.best);
                 r.score = f.bestScore;
-                std::reverse(r.aln.begin(), r.aln.end());
+                r.aln.reverse(); // in place: every header into this array sees it
                 if (left_) std::reverse(r.path.begin(), r.path.end());
                 else r.t += f.pos;
                 stack_.pop_back();
@@ -486,7 +563,7 @@ class Traversal {
         Bases seq, sSeq;
         int64_t pos; // refEnd (left) / start (right)
         std::vector<uint32_t> sPath;
-        std::vector<Cigar> route;
+        CigSlice route;
         bool leaf;
         size_t child = 0;
         int64_t bestScore = INT64_MIN;
@@ -498,7 +575,7 @@ class Traversal {
     const uint8_t *read_ = nullptr;
     size_t readLen_ = 0;
     std::vector<Frame> stack_;
-    void push(const Node *n, const Bases &seq, int64_t pos, const std::vector<uint32_t> &path, const std::vector<Cigar> &route) {
+    void push(const Node *n, const Bases &seq, int64_t pos, const std::vector<uint32_t> &path, const CigSlice &route) {
         Frame f;
         f.n = n; f.seq = seq; f.pos = pos; f.route = route;
         f.sPath = path; // search.go:174-176 calls AddPath(s.Path, n.Id) and drops its result: the node is never recorded
@@ -552,33 +629,31 @@ inline std::vector<uint32_t> CatPaths(std::vector<uint32_t> curr, const std::vec
     curr.insert(curr.end(), more.begin() + 1, more.end());
     return curr;
 }
-inline int64_t queryLength(const std::vector<Cigar> &c) {
+inline int64_t queryLength(const CigSlice &c) {
     int64_t s = 0;
-    for (const Cigar &x : c) if (x.Op == 'M' || x.Op == 'I' || x.Op == 'S' || x.Op == '=' || x.Op == 'X') s += x.RunLength;
+    for (int64_t k = 0; k < c.size(); k++) { const Cigar &x = c[k]; if (x.Op == 'M' || x.Op == 'I' || x.Op == 'S' || x.Op == '=' || x.Op == 'X') s += x.RunLength; }
     return s;
 }
 // cigar.AppendSoftClips (cigar/tools.go:26-40), literally -- including that a front clip without a back clip returns only the clip
-inline std::vector<Cigar> appendSoftClips(int64_t front, int64_t lengthOfRead, const std::vector<Cigar> &cigs) {
+inline CigSlice appendSoftClips(int64_t front, int64_t lengthOfRead, const CigSlice &cigs) {
     const int64_t run = queryLength(cigs);
     if (front == 0 && run >= lengthOfRead) return cigs;
-    std::vector<Cigar> answer;
-    if (front > 0) answer.push_back(Cigar{front, 'S'});
-    if (front + run < lengthOfRead) {
-        answer.insert(answer.end(), cigs.begin(), cigs.end());
-        answer.push_back(Cigar{lengthOfRead - front - run, 'S'});
-    }
+    CigSlice answer = CigSlice::make(0, cigs.size() + 2); // make([]Cigar, 0, len(cigars)+2)
+    if (front > 0) answer = answer.append(Cigar{front, 'S'});
+    if (front + run < lengthOfRead) answer = answer.append(cigs).append(Cigar{lengthOfRead - front - run, 'S'});
     return answer;
 }
-inline void cigAppend(std::vector<Cigar> &alpha, const Cigar &beta) {
-    if (!alpha.empty() && alpha.back().Op == beta.Op) alpha.back().RunLength += beta.RunLength;
-    else alpha.push_back(beta);
-}
-inline std::vector<Cigar> cigConcat(std::vector<Cigar> alpha, const std::vector<Cigar> &beta) {
-    if (alpha.empty()) return beta;
-    size_t from = 0;
-    if (!beta.empty()) { cigAppend(alpha, beta[0]); from = 1; }
-    alpha.insert(alpha.end(), beta.begin() + (long)from, beta.end());
+// cigar.Append (cigar/tools.go:4-11): the last cell is incremented IN the shared array, or beta is appended
+inline CigSlice cigAppend(CigSlice alpha, const Cigar &beta) {
+    if (!alpha.empty() && alpha[alpha.size() - 1].Op == beta.Op) alpha[alpha.size() - 1].RunLength += beta.RunLength;
+    else alpha = alpha.append(beta);
     return alpha;
+}
+// cigar.Concat (cigar/tools.go:14-23)
+inline CigSlice cigConcat(CigSlice alpha, CigSlice beta) {
+    if (alpha.empty()) return beta;
+    if (!beta.empty()) { alpha = cigAppend(alpha, beta[0]); beta = beta.tail(1); }
+    return alpha.append(beta);
 }
 // one read's loop over its sorted seeds, stopping whenever a traversal needs a DP
 class ReadTask {
@@ -647,7 +722,7 @@ class ReadTask {
     int64_t seedScore_ = 0, currScore_ = 0, leftScore_ = 0;
     // scoreKeeper fields that survive from one seed to the next (resetScoreKeeper gets its argument by value: a no-op): a seed that
     // covers the whole read re-uses the alignments, paths and queryEnd of the seed before it (toGiraf.go:47-51)
-    std::vector<Cigar> leftAln_, rightAln_;
+    CigSlice leftAln_, rightAln_; // (slice HEADERS: cigar.Append below writes through sk.leftAlignment's own array, and a later whole-read seed re-uses the stale header)
     std::vector<uint32_t> leftPath_, rightPath_;
     int64_t targetStart_ = 0, targetEnd_ = 0, queryStart_ = 0, queryEnd_ = 0;
     Traversal trav_;
@@ -658,9 +733,7 @@ class ReadTask {
             best.PosStrand = seed_->PosStrand;
             best.TStart = targetStart_; best.TEnd = targetEnd_;
             best.Nodes = CatPaths(CatPaths(leftPath_, getSeedPath(seed_)), rightPath_);
-            std::vector<Cigar> mid = leftAln_;
-            cigAppend(mid, Cigar{(int64_t)seed_->TotalLength, 'M'});
-            best.Cig = appendSoftClips(queryStart_, (int64_t)currSeq_->size(), cigConcat(std::move(mid), rightAln_));
+            best.Cig = appendSoftClips(queryStart_, (int64_t)currSeq_->size(), cigConcat(cigAppend(leftAln_, Cigar{(int64_t)seed_->TotalLength, 'M'}), rightAln_)).toVector();
             best.hasCigar = true;
             best.AlnScore = currScore_;
             best.Seq = currSeq_;

@@ -571,6 +571,49 @@ def test_fast_path_two_row_blocks(gpu_lib, seed, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("alphabet", [2, 4])
+def test_fast_path_event_tracking(gpu_lib, monkeypatch, alphabet):
+    """Round 4: the headline sweep keeps no I-planes in its steady part -- per plane row only the last step at which the gap could have
+    been opened (h' + o >= I'), the walk strides to that cell and decides there.  The cases that stress it: TIES (two-letter and
+    homopolymer sequences: equal-scoring alternatives everywhere, opens that tie with extensions), windows of very different lengths in
+    one wave of 8 pairs (the tagged tail starts at the shortest window's end: the long windows' last thousands of columns run tagged),
+    reads that end exactly at the window's end (trailing gap on rows n-1 .. n-3 and beyond), reads placed at the window's start,
+    penalties with gapOpen = 0 (every step an event) and tiny extensions."""
+    monkeypatch.setenv("GNX_FASTPATH", "2")
+    rng = np.random.default_rng(500 + alphabet)
+    ref = rng.integers(0, alphabet, size=6000, dtype=np.uint8)
+    ref[2000:2300] = 1                      # a homopolymer stretch
+    ref[3000:3400] = np.tile([0, 1], 200)   # a dinucleotide repeat
+    alphas, betas = [], []
+    for k in range(320):
+        n = int(rng.integers(1, 153))
+        m = int(rng.choice([16, 40, 130, 300, 900, 2500, 5000])) if k % 8 else 5000  # every wave holds one long window
+        off = int(rng.integers(0, 6000 - m + 1))
+        beta = ref[off:off + m].copy()
+        kind = k % 5
+        if kind == 0 and m > n:      # read = the window's last bases: the path ends in the corner
+            alpha = beta[m - n:].copy()
+        elif kind == 1 and m > n:    # ... its first bases: one long trailing gap on row n
+            alpha = beta[:n].copy()
+        elif kind == 2 and m > n + 4:  # the last d bases match the window's end, the rest sits further left: trailing gap on row n - d
+            d = int(rng.integers(1, 7)); pos = int(rng.integers(0, m - n - d + 1))
+            alpha = np.concatenate([beta[pos:pos + n - d], beta[m - d:]]) if n > d else beta[m - n:].copy()
+        else:
+            pos = int(rng.integers(0, max(1, m - n + 1)))
+            alpha = common.mutate(rng, beta[pos:pos + n], 0.04, 0.03, alphabet=alphabet)[:152] if m >= n else rng.integers(0, alphabet, size=n, dtype=np.uint8)
+        if alpha.shape[0] == 0:
+            alpha = np.array([1], dtype=np.uint8)
+        alphas.append(alpha.astype(np.uint8)); betas.append(beta)
+    for name, go, ge in [("HumanChimpTwo", -600, -150), ("Default", -400, -30), ("Default", -100, -100), ("HumanChimpTwo", 0, -150), ("HoxD55", -1, -1)]:
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX[name], go, ge)
+        got = gpu_lib.align_batch(p, alphas, betas)
+        exp = oracle.align_batch(0, MX[name], go, ge, alphas, betas, threads=8)
+        common.assert_same(got, exp, "event tracking, alphabet %d, %s %d %d" % (alphabet, name, go, ge))
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX["HumanChimpTwo"], -600, -150, 64, 64)  # checkerboard edges inside the windows (quirks)
+    common.assert_same(gpu_lib.align_batch(p, alphas, betas), oracle.align_batch(0, MX["HumanChimpTwo"], -600, -150, alphas, betas, 64, 64, threads=8), "event tracking, 64 x 64 checkerboards")
+
+
+@pytest.mark.gpu
 def test_fast_path_mixed_read_lengths(gpu_lib, monkeypatch):
     """a batch that mixes reads of <= 160 and of 161 .. 320 bases: two uniform sub-batches, each on its fast path, merged back into
     input order (run_device, the block under 'mixed with shorter reads')"""

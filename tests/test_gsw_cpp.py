@@ -71,7 +71,7 @@ def test_cpp_gsw_mirror_builds_and_refuses_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,seed_len,step", [("linear", 16, 1), ("snp", 16, 1), ("snp", 20, 7), ("wide", 16, 1)])
+@pytest.mark.parametrize("kind,seed_len,step", [("linear", 16, 1), ("snp", 16, 1), ("snp", 20, 7), ("wide", 16, 1), ("wide3", 16, 1)])
 def test_cpp_gsw_mirror_equals_python_mirror(gpu_lib, tmp_path, kind, seed_len, step):
     _build()
     seqs, edges, reads = make_case(9, kind)

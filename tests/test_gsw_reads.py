@@ -25,26 +25,26 @@ def make_case(seed, kind):
         paths = [[k] for k in range(3)]
     else:
         prev = None
-        path_a, path_b = [], []
+        n_alt = 3 if kind == "wide3" else 2  # "wide3": three alleles per bubble -- every traversal across one has >= 3 sibling branches, the case in
+        #                                      which a later sibling's DP writes through the route slice an earlier best alignment still points into
+        paths = [[] for _ in range(n_alt)]
         for b in range(6):
             k = len(seqs)
             seqs.append(rng.integers(0, 4, size=int(rng.integers(40, 160) if kind == "snp" else rng.integers(420, 520))).astype(np.uint8))
             if prev is not None:
                 for u in prev:
                     edges.append((u, k))
-            path_a.append(k); path_b.append(k)
+            for pth in paths:
+                pth.append(k)
             if b < 5:
                 if kind == "snp":
-                    alt1 = rng.integers(0, 4, size=int(rng.integers(1, 4))).astype(np.uint8)
-                    alt2 = rng.integers(0, 4, size=int(rng.integers(1, 6))).astype(np.uint8)
-                else:  # two long alleles that differ by a few substitutions and an indel
+                    alts = [rng.integers(0, 4, size=int(rng.integers(1, 4))).astype(np.uint8), rng.integers(0, 4, size=int(rng.integers(1, 6))).astype(np.uint8)]
+                else:  # long alleles that differ by a few substitutions and an indel
                     alt1 = rng.integers(0, 4, size=int(rng.integers(420, 520))).astype(np.uint8)
-                    alt2 = common.mutate(rng, alt1, sub=0.02, indel=0.005, geo=0.5, alphabet=4)
-                seqs.append(alt1); seqs.append(alt2)
-                edges.append((k, k + 1)); edges.append((k, k + 2))
-                path_a.append(k + 1); path_b.append(k + 2)
-                prev = [k + 1, k + 2]
-        paths = [path_a, path_b]
+                    alts = [alt1] + [common.mutate(rng, alt1, sub=0.02, indel=0.005, geo=0.5, alphabet=4) for _ in range(n_alt - 1)]
+                prev = []
+                for a, alt in enumerate(alts):
+                    seqs.append(alt); edges.append((k, k + 1 + a)); paths[a].append(k + 1 + a); prev.append(k + 1 + a)
     reads = []
     for r in range(40):
         pth = paths[int(rng.integers(0, len(paths)))]
@@ -53,7 +53,7 @@ def make_case(seed, kind):
         if hap.shape[0] <= L + 2:
             L = hap.shape[0] - 2
         o = int(rng.integers(0, hap.shape[0] - L))
-        if kind == "wide" and r % 3 == 0:  # start a few bases after a node border: the left extension collects bases, then enters the Prev node
+        if kind in ("wide", "wide3") and r % 3 == 0:  # start a few bases after a node border: the left extension collects bases, then enters the Prev node
             cuts = np.cumsum([len(seqs[k]) for k in pth])[:-1]
             o = int(cuts[int(rng.integers(0, len(cuts)))]) + int(rng.integers(1, 12))
             o = min(o, hap.shape[0] - L - 1)
@@ -147,7 +147,7 @@ def test_left_target_known_answers():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["linear", "snp", "wide"])
+@pytest.mark.parametrize("kind", ["linear", "snp", "wide", "wide3"])
 def test_reads_to_giraf(gpu_lib, kind):
     """GraphSmithWatermanToGiraf for a batch: device seeds + rounds of batched device DPs == the sequential restatement on the CPU oracle"""
     seqs, edges, reads = make_case(7, kind)
@@ -178,7 +178,7 @@ def test_reads_to_giraf(gpu_lib, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["linear", "wide"])
+@pytest.mark.parametrize("kind", ["linear", "wide", "wide3"])
 def test_wrap_pair_giraf(gpu_lib, kind):
     """WrapPairGiraf for a batch of read pairs (the paired reads of config C3 go through it, toGiraf.go:117-140): both mates in one batched
     call, flags as the Go code sets them (Fwd: +8 +16 +16, Rev: nothing; uint8), against the sequential restatement"""

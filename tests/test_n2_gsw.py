@@ -111,6 +111,33 @@ def test_gsw_known_answers():
     assert oracle.gsw_extend(1, sc, -600, a, e) == (0, [], 0, 0)
 
 
+def test_go_slice_model():
+    """The traversals of the graph aligner share ONE route slice between sibling branches (search.go:185-195), so the restatement and
+    the mirrors model Go slices: header (array, offset, len, cap) + Go 1.25's growth rule.  Known facts of the Go runtime (16-byte
+    elements): appending one element at a time to nil gives the capacities 1, 2, 4 ... 512, 848; appending 5 elements to a full slice
+    of 4 gives 9.  And the aliasing case itself: a second DP started from the route of the first increments the first's cells through
+    the shared array until its append outgrows the capacity."""
+    import pyref_gsw as ref
+    s, caps = ref.GoSlice(), []
+    for _ in range(600):
+        s = ref.go_append(s, [1, 0]); caps.append(s.cap)
+    assert sorted(set(caps)) == [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 848]
+    full = ref.go_append(ref.go_append(ref.GoSlice(), [1, 0], [1, 1]), [1, 0], [1, 1])
+    assert (full.n, full.cap) == (4, 4) and ref.go_append(full, *[[1, 0]] * 5).cap == 9
+    assert genomeGraph._go_next_cap(9, 4) == 9 and genomeGraph._go_next_cap(513, 512) == 848 and genomeGraph._go_next_cap(1, 0) == 1
+    a = ref.dp_merge(ref.GoSlice(), [(3, 0), (1, 1)])
+    assert [tuple(c) for c in a.cells()] == [(3, 0), (1, 1)] and a.cap == 2
+    b = ref.dp_merge(a, [(2, 0), (1, 2)])  # M M D on top of a's route, routeIdx restarting at 0
+    assert [tuple(c) for c in b.cells()] == [(5, 0), (1, 1), (1, 2)] and b.cap == 4 and b.arr is not a.arr
+    assert [tuple(c) for c in a.cells()] == [(5, 0), (1, 1)]  # the first route, seen through its own header: changed by the second DP
+    ga = genomeGraph._merge_route_go(genomeGraph.GoSlice(), [(3, cigar.Match), (1, cigar.Insertion)])
+    gb = genomeGraph._merge_route_go(ga, [(2, cigar.Match), (1, cigar.Deletion)])
+    assert [(c.RunLength, c.Op) for c in ga] == [(5, cigar.Match), (1, cigar.Insertion)]
+    assert [(c.RunLength, c.Op) for c in gb] == [(5, cigar.Match), (1, cigar.Insertion), (1, cigar.Deletion)] and gb.cap == 4
+    ga.reverse()  # cigar.ReverseCigar in place: gb has its own array by now
+    assert [(c.RunLength, c.Op) for c in ga] == [(1, cigar.Insertion), (5, cigar.Match)] and gb[0].RunLength == 5
+
+
 def test_gsw_route_carry_over_host_logic():
     """resetDynamicScore is a no-op in the reference: a route passed in is kept and merged with routeIdx restarting at 0.
     genomeGraph._merge_route (product host code) must equal the oracle's literal loop."""
