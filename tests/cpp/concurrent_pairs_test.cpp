@@ -14,12 +14,14 @@
 static uint64_t sm64(uint64_t &x) { x += 0x9E3779B97F4A7C15ull; uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 
 struct Res { int64_t score; std::vector<gnx_cigar> ops; int rc; };
+static gnx_params prm_a;
 
 int main(int argc, char **argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 16, N = argc > 2 ? atoi(argv[2]) : 1000;
     const double want = argc > 3 ? atof(argv[3]) : 8.0;
+    const bool mixed = argc > 4; // a fourth argument: every fourth thread calls with other parameters (ConstGap)
     if (gnx_init(0, 0) != GNX_OK) { fprintf(stderr, "%s\n", gnx_last_error()); return 2; }
-    gnx_params prm;
+    gnx_params &prm = prm_a;
     memset(&prm, 0, sizeof(prm));
     prm.mode = GNX_AFFINE_GAP;
     const int64_t hc2[25] = {90, -330, -236, -356, -208, -330, 100, -318, -236, -196, -236, -318, 100, -330, -196, -356, -236, -330, 90, -208, -208, -196, -196, -208, -202};
@@ -38,9 +40,14 @@ int main(int argc, char **argv) {
         for (auto &x : A[(size_t)q]) if (sm64(seed) % 50 == 0) x = (uint8_t)(sm64(seed) & 3);
         if (q % 997 == 5) A[(size_t)q][3] = 9; // a base the Go code would panic on: GNX_EBASE for THIS pair only
     }
+    // every fourth thread's pairs go through align.ConstGap instead: requests with different parameters wait in the same queue and
+    // must never be combined into one batch
+    gnx_params prm_c = prm;
+    prm_c.mode = GNX_CONST_GAP; prm_c.gap_open = -430; prm_c.gap_extend = 0;
     auto call = [&](int q, Res &r) {
         int64_t sc = 0, nops = 0;
         gnx_cigar *ops = nullptr;
+        const gnx_params &prm = (mixed && (q / N) % 4 == 3) ? prm_c : ::prm_a;
         r.rc = gnx_align_pair(&prm, A[(size_t)q].data(), (int64_t)A[(size_t)q].size(), B[(size_t)q].data(), (int64_t)B[(size_t)q].size(), &sc, &ops, &nops);
         if (r.rc == GNX_OK) { r.score = sc; r.ops.assign(ops, ops + nops); gnx_free(ops); }
     };

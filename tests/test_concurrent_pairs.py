@@ -35,3 +35,8 @@ def test_sixteen_threads_of_single_pair_calls():
     assert d["mismatches"] == 0 and d["calls_with_GNX_EBASE"] > 0
     assert d["combined_batches"] > 0 and d["speedup"] >= 8.0, d
     assert r.returncode == 0
+    # every fourth thread with other parameters (align.ConstGap): requests of different parameters share the queue, never a batch
+    r = subprocess.run([BIN, "16", "300", "2", "mixed"], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["mismatches"] == 0 and d["combined_batches"] > 0 and r.returncode == 0, d
