@@ -456,6 +456,24 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                                    d_strag + cnt, cnt2 + 2, force(it + 1), srb, K, WW, d_a, d_as, d_b, d_bs, kp);
                 HIPCHK(hipGetLastError());
             }
+            if (n_strag > 0 && getenv("GNX_DEBUG") && atoi(getenv("GNX_DEBUG")) >= 2) { // census: where the stragglers stand (row distance from n, state, column)
+                std::vector<int> hs((size_t)n_strag);
+                HIPCHK(hipStreamSynchronize(st));
+                HIPCHK(hipMemcpy(hs.data(), d_strag, (size_t)n_strag * 4, hipMemcpyDeviceToHost));
+                std::vector<PairPlan> hp((size_t)cnt);
+                HIPCHK(hipMemcpy(hp.data(), dpl, (size_t)cnt * sizeof(PairPlan), hipMemcpyDeviceToHost));
+                int hist_d[8] = {0}, hist_k[3] = {0}, far = 0;
+                for (int x = 0; x < n_strag; x++) {
+                    FpState fs;
+                    HIPCHK(hipMemcpy(&fs, d_st + hs[(size_t)x], sizeof(fs), hipMemcpyDeviceToHost));
+                    const int dd = hp[(size_t)hs[(size_t)x]].n - fs.i;
+                    hist_d[dd < 7 ? dd : 7]++; hist_k[fs.k < 3 ? fs.k : 2]++;
+                    if (fs.j > 600) far++;
+                    if (x < 12) fprintf(stderr, "[gnx fp]   straggler pair %d: i %d (n - i = %d) j %d state %d last_op %d runs so far %d\n", hs[(size_t)x], fs.i, dd, fs.j, fs.k, fs.last_op, fs.cnt);
+                }
+                fprintf(stderr, "[gnx fp] straggler census: n - i = 0..6, >= 7: %d %d %d %d %d %d %d %d; state M / I / D: %d %d %d; with more than 600 columns left: %d of %d\n",
+                        hist_d[0], hist_d[1], hist_d[2], hist_d[3], hist_d[4], hist_d[5], hist_d[6], hist_d[7], hist_k[0], hist_k[1], hist_k[2], far, n_strag);
+            }
             if (n_strag > 0) { // all remaining columns of the stragglers' row blocks as independent tiles, one launch
                 const int64_t n_tiles = (int64_t)n_strag * tiles_per;
                 const size_t tb = (size_t)n_tiles * FP_TWORDS * QA * G * 16;
@@ -468,7 +486,8 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                 int *thc = reinterpret_cast<int *>(c.fp_thcol.p);
                 unsigned *tdc = reinterpret_cast<unsigned *>(thc + n_tiles * H);
                 uint4 *ttr = reinterpret_cast<uint4 *>(c.fp_ttrace.p);
-                hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, dpl, d_strag, n_strag, tiles_per, d_st, tpl);
+                hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, dpl, d_strag, n_strag, tiles_per, d_st, tpl,
+                                   (const int2 *)d_ckpt, (getenv("GNX_FP_STRAG_TRIM") && atoi(getenv("GNX_FP_STRAG_TRIM")) == 0) ? 0 : 1);
                 HIPCHK(hipEventRecord(c.ev[6], st));
                 hipLaunchKernelGGL(k_win, dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, st, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
                                    ttr, thc, srb, tdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);
