@@ -172,7 +172,6 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             const int c = (j - 1) / FP_TILE;
             if (st.j_hi > 0 && !(i > wrow && i <= wrow + wp.n)) break; // left the tiles' row block through its top: the next block needs a window
             wp = wplans[(int64_t)a * tiles_per + c];
-            if (wp.strips == 0) { st.j_hi = 0; st.jc_lo = 0; break; } // this tile was not re-filled (fp_straggler_plans_kernel: trimmed): ask for a window
             wrow = (int)wp.s_off;
             st.jc_lo = wp.col_off; st.j_hi = st.jc_lo + wp.m; // tile c starts one checkpoint before column c*FP_TILE
             if (j > st.j_hi || j < lo_ok(st.jc_lo) || !(i > wrow && i <= wrow + wp.n)) { atomicOr(err, 2); done = true; break; }
@@ -344,15 +343,8 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
 // stragglers (the path keeps needing windows, e.g. a long gap on a row without a stored plane): every remaining
 // column of such a pair is re-filled as independent FP_TILE-column tiles from the column checkpoints -- one launch,
 // a tile deep instead of a matrix deep -- and fp_walk_kernel<false, true> finishes the walk through them.
-// GNX_FP_STRAG_TRIM (round 4): a straggler in state I stands in a long horizontal gap whose rebased value V = I'(i, .) is constant back to
-// the column where the gap was opened; the column checkpoints hold I'(i, 128 c + 1) of every row, and I' never decreases from left to
-// right.  So the gap was opened right of the last checkpoint whose I' is smaller than V, and only the tiles from ~ one window left of that
-// checkpoint up to the walk's column are re-filled (the census of the headline batch: 1 646 of 1 658 stragglers are such gaps, 1 612 of
-// them with more than 600 columns left -- reads whose last bases found a better place further right at the price of one more gap open).
-// A walk that runs out of tiles asks for a window like any other walk.
 __global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan *__restrict__ plans, const int *__restrict__ active, int n_active,
-                                                                  int tiles_per, const FpState *__restrict__ states, PairPlan *__restrict__ out,
-                                                                  const int2 *__restrict__ ckpt, int trim) {
+                                                                  int tiles_per, const FpState *__restrict__ states, PairPlan *__restrict__ out) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n_active * tiles_per) return;
     const int a = x / tiles_per, c = x - a * tiles_per;
@@ -360,20 +352,10 @@ __global__ __launch_bounds__(256) void fp_straggler_plans_kernel(const PairPlan 
     const PairPlan pl = plans[p];
     const int j_cur = states[p].j, i_cur = states[p].i;
     const int b = (pl.n - i_cur) / H, rb = max(0, pl.n - H * (b + 1)), rows = pl.n - H * b - rb; // the row block of the walk's current row
-    int j_need = 0; // columns <= j_need are not re-filled
-    if (trim && states[p].k == 1 && i_cur >= 1) {
-        int ck = (j_cur - 1) / CKW; // checkpoint ck sits at column CKW * ck; its entry holds I'(i, CKW * ck + 1)
-        if (ck >= 1) {
-            const int2 *col = ckpt + pl.ckpt_off + (i_cur - 1);
-            const int V = col[(int64_t)(ck - 1) * pl.n].x & ~3;
-            while (ck >= 1 && (col[(int64_t)(ck - 1) * pl.n].x & ~3) >= V) ck--;
-            j_need = max(0, ck * CKW - (FP_SPAN + CKW + 16)); // the rest of the alignment left of the gap's opening: a window's worth
-        }
-    }
     PairPlan q = pl;
     const int lo = c * FP_TILE, lo2 = max(0, lo - CKW); // start one checkpoint early: the first re-filled column has no usable tags
     q.n = rows;
-    q.m = (j_cur > lo && lo + FP_TILE > j_need) ? min(FP_TILE, j_cur - lo) + (lo - lo2) : 0;
+    q.m = (j_cur > lo) ? min(FP_TILE, j_cur - lo) + (lo - lo2) : 0;
     q.words = (q.m + 15 + 15) / 16; q.strips = q.m > 0 ? 1 : 0;
     q.trace_off = (int64_t)x * FP_TWORDS * QA * G; q.hcol_off = (int64_t)x * H;
     q.rowbuf_off = pl.rowbuf_off + (int64_t)(pl.strips - 2 - b) * (pl.m + 1);

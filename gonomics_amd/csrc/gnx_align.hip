@@ -486,8 +486,7 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
                 int *thc = reinterpret_cast<int *>(c.fp_thcol.p);
                 unsigned *tdc = reinterpret_cast<unsigned *>(thc + n_tiles * H);
                 uint4 *ttr = reinterpret_cast<uint4 *>(c.fp_ttrace.p);
-                hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, dpl, d_strag, n_strag, tiles_per, d_st, tpl,
-                                   (const int2 *)d_ckpt, (getenv("GNX_FP_STRAG_TRIM") && atoi(getenv("GNX_FP_STRAG_TRIM")) == 0) ? 0 : 1);
+                hipLaunchKernelGGL(fp_straggler_plans_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, dpl, d_strag, n_strag, tiles_per, d_st, tpl);
                 HIPCHK(hipEventRecord(c.ev[6], st));
                 hipLaunchKernelGGL(k_win, dim3((unsigned)((n_tiles + 3) / 4)), blockF, 0, st, tpl, (int)n_tiles, d_a, d_as, d_b, d_bs, kp,
                                    ttr, thc, srb, tdc, d_ckpt, d_err, (const int *)nullptr, (const int2 *)nullptr, (int *)nullptr);

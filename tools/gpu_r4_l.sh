@@ -8,4 +8,4 @@ done
 for t in 0 1; do
   GNX_FP_STRAG_TRIM=$t python bench.py --no-cpu --no-host --no-extras --steps 20 --warmup 3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('trim $t', d['ms_per_step'], d.get('value_device_resident'), d['ok'] if 'ok' in d else '')" | tee -a $out/ab.log
 done
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_fast_path.py -m gpu -x -q 2>&1 | tail -3 | tee -a $out/ab.log
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3 | tee -a $out/ab.log
