@@ -2046,7 +2046,7 @@ int gnx_seed_find_batch(const uint8_t *read_cat, const int64_t *read_off, int64_
     if ((rc = t[2].ensure((size_t)(n_reads + 1) * 8))) return rc;                // read_off
     if ((rc = t[3].ensure((size_t)(n_reads + 1) * 8))) return rc;                // slot_off
     if ((rc = t[4].ensure((size_t)n_reads * 64 * RW * 8))) return rc;            // rainbows
-    if ((rc = t[5].ensure((size_t)(n_slots + 1) * 8))) return rc;                // counts
+    if ((rc = t[5].ensure((size_t)(std::max(n_slots, n_reads) + 1) * 8))) return rc; // counts, then the hit offsets per read
     if ((rc = t[6].ensure((size_t)(n_slots + 1) * 8))) return rc;                // offsets
     if ((rc = c.misc.ensure(64))) return rc;
     HIPCHK(hipMemcpyAsync(t[0].p, read_cat, (size_t)total, hipMemcpyHostToDevice, st));
@@ -2072,14 +2072,15 @@ int gnx_seed_find_batch(const uint8_t *read_cat, const int64_t *read_off, int64_
     if (n_hits) hipLaunchKernelGGL(seed_find_kernel<true>, dim3(gb), dim3(128), 0, st, sx, (const int64_t *)t[3].p, (int)n_reads, n_slots, (int64_t *)nullptr, (const int64_t *)t[6].p, (SeedHit *)t[7].p);
     HIPCHK(hipGetLastError());
     gnx_seed_hit *hh = (gnx_seed_hit *)malloc((size_t)std::max<int64_t>(n_hits, 1) * sizeof(gnx_seed_hit));
-    std::vector<int64_t> soff((size_t)n_slots + 1);
     guard.b = hh;
     if (!hh) { set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
     static_assert(sizeof(gnx_seed_hit) == sizeof(SeedHit), "hit layout");
     if (n_hits) HIPCHK(hipMemcpyAsync(hh, t[7].p, (size_t)n_hits * sizeof(SeedHit), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(soff.data(), t[6].p, (size_t)(n_slots + 1) * 8, hipMemcpyDeviceToHost, st));
+    // the offsets of the reads' first slots are all the caller wants of the slot offsets (8 bytes per read position would be 38 MB for 20 000 reads)
+    hipLaunchKernelGGL(seed_read_off_kernel, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, (const int64_t *)t[6].p, (const int64_t *)t[3].p, n_reads + 1, (int64_t *)t[5].p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hoff, t[5].p, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (int64_t r = 0; r <= n_reads; r++) hoff[r] = soff[(size_t)slot_off[(size_t)r]];
     *out_hits = hh; *out_hit_off = hoff;
     guard.a = nullptr; guard.b = nullptr;
     return GNX_OK;

@@ -84,6 +84,11 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t *__restri
     const uint8_t *s = (st ? rc : cat) + read_off[r];
     words[x] = pack_word(s, len, (int64_t)w * 32, o);
 }
+// out[r] = slot_offsets[first_slot[r]] for r in [0, n): where the hits of read r start (gnx_seed_find_batch)
+__global__ __launch_bounds__(256) void seed_read_off_kernel(const int64_t *__restrict__ slot_offsets, const int64_t *__restrict__ first_slot, int64_t n, int64_t *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = slot_offsets[first_slot[r]];
+}
 __global__ __launch_bounds__(256) void revcomp_kernel(const uint8_t *__restrict__ cat, const int64_t *__restrict__ read_off, int n_reads, int64_t total, uint8_t *__restrict__ rc) {
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= total) return;

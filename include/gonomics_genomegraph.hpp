@@ -14,14 +14,28 @@
 // The reference's recursion (a traversal calls the DP at its leaves and hands the route from one sibling branch to the next) is
 // turned inside out here: a traversal is a stack machine that stops whenever it needs a DP, so that the DPs of a whole batch of
 // reads go to the device together, one gnx_gsw_extend_batch call per side and round.
+//
+// Worker pool (round 4): the per-read host work between the device calls -- seed continuation across node borders and the seed sort,
+// the traversal machines, merging the DP routes -- runs on `threads` host threads, the reads dealt out in chunks (the reference's
+// own parallelism: `-t` worker goroutines taking reads off a channel, genomeGraph/routines.go:12-65, cmd/gsw).  Reads are independent
+// (every slice a read's branches share belongs to that read), results are in input order and equal the one-thread run's; a GoPanic
+// that propagates is the one of the first read (input order) that panics.  threads = 0: GNX_GSW_THREADS, else min(hardware threads, 16).
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <exception>
+#include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -31,6 +45,95 @@ namespace gonomics {
 namespace genomeGraph {
 
 using Bases = std::vector<uint8_t>; // dna.Base: A C G T N = 0 .. 4
+
+inline int gswThreads(int asked) {
+    if (asked > 0) return asked;
+    if (const char *e = getenv("GNX_GSW_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hw, 16u));
+}
+// the workers: parked on a condition variable between regions, started on first use, joined at exit
+class GswPool {
+  public:
+    static GswPool &get() { static GswPool p; return p; }
+    // job(w) on the caller (w = 0) and on threads - 1 workers (w = 1 ..); returns when all of them are back
+    void run(int threads, const std::function<void(int)> &job) {
+        std::lock_guard<std::mutex> one(run_mu_); // one region at a time (concurrent callers take turns)
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            while ((int)th_.size() < threads - 1) { const int id = (int)th_.size(); th_.emplace_back([this, id]() { loop(id); }); }
+            job_ = &job; want_ = threads - 1; pending_ = std::min((int)th_.size(), threads - 1); gen_++;
+        }
+        cv_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&]() { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    ~GswPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+
+  private:
+    std::vector<std::thread> th_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *job_ = nullptr;
+    uint64_t gen_ = 0;
+    int want_ = 0, pending_ = 0;
+    bool stop_ = false;
+    void loop(int id) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&]() { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
+            if (id >= want_) continue; // (more workers than this region asked for)
+            const std::function<void(int)> *job = job_;
+            lk.unlock();
+            (*job)(id + 1);
+            lk.lock();
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+};
+// f(k) for k in [0, n) on `threads` threads; the exception of the lowest k is rethrown.  blocks = false: chunks handed out by a counter;
+// blocks = true: worker w takes the w-th of `threads` equal blocks -- the regions that run over ALL reads use it, so that a read's
+// seeds, task and result are allocated and freed by the same thread (malloc arenas: freeing another thread's blocks contends)
+template <class F> inline void parallelFor(size_t n, int threads, F &&f, bool blocks = false) {
+    if (threads <= 1 || n < 32) { for (size_t k = 0; k < n; k++) f(k); return; }
+    const size_t chunk = std::max<size_t>(4, n / ((size_t)threads * 16));
+    std::atomic<size_t> next{0};
+    std::mutex mu;
+    std::exception_ptr err;
+    size_t err_at = n;
+    auto one = [&](size_t k) {
+        try { f(k); }
+        catch (...) { std::lock_guard<std::mutex> lk(mu); if (k < err_at) { err_at = k; err = std::current_exception(); } }
+    };
+    const std::function<void(int)> work = [&](int w) {
+        if (blocks) {
+            for (size_t k = n * (size_t)w / (size_t)threads; k < n * ((size_t)w + 1) / (size_t)threads; k++) one(k);
+            return;
+        }
+        for (;;) {
+            const size_t k0 = next.fetch_add(chunk);
+            if (k0 >= n) return;
+            for (size_t k = k0; k < std::min(n, k0 + chunk); k++) one(k);
+        }
+    };
+    GswPool::get().run(threads, work);
+    if (err) std::rethrow_exception(err);
+}
+// wall clock of the stages of one GswBatchToGiraf call (ms), filled when the caller passes one
+struct GswTimings {
+    double seed_device = 0, seed_host = 0, tasks = 0, dp_pack = 0, dp_device = 0, dp_merge = 0, advance = 0, finish = 0;
+    int threads = 0;
+};
+inline double gswNow() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 inline void gnxCheck(int rc) {
     if (rc != GNX_OK) throw std::runtime_error(std::string("libgonomics_align_hip: ") + gnx_last_error());
@@ -162,9 +265,13 @@ inline void packNodes(const GenomeGraph &g, Bases &cat, std::vector<int64_t> &of
 }
 // IndexGenomeIntoMap (index.go:21-59) as two arrays sorted by key, equal keys in the reference's insertion order: the k-mers inside
 // nodes from the device, the few that run across node borders from the host recursion over Next edges (indexGenomeIntoMapHelper).
+inline std::mutex &gswSeedMu() { static std::mutex m; return m; }          // the library holds ONE resident index: set + find under this lock
+inline uint64_t &gswResidentGen() { static uint64_t g = 0; return g; }     // bumped by every gnx_seed_index_set of this header
 struct SeedIndex {
     int seedLen = 0, seedStep = 0;
     std::vector<uint64_t> keys, locs;
+    mutable uint64_t residentGen = 0;              // == gswResidentGen() while this index (with residentGraph's nodes) is the one on the device
+    mutable const void *residentGraph = nullptr;
     SeedIndex(const GenomeGraph &g, int seed_len, int seed_step) : seedLen(seed_len), seedStep(seed_step) {
         if (seed_len < 2 || seed_len > 32) throw std::runtime_error("Error: seed length needs to be greater than 1 and less than 33.");
         Bases cat;
@@ -317,10 +424,10 @@ inline std::vector<SeedPtr> leftHelper(const Node &node, FastqBig &read, const S
     return answer;
 }
 inline std::vector<SeedPtr> extendToTheLeftDev(const Node &node, FastqBig &read, const SeedPtr &currPart) {
-    read.rainbows();
-    const auto &rain = currPart->PosStrand ? read.Rainbow : read.RainbowRc;
     std::vector<SeedPtr> answer;
-    if (currPart->QueryStart > 0 && currPart->TargetStart == 0) {
+    if (currPart->QueryStart > 0 && currPart->TargetStart == 0 && !node.Prev.empty()) {
+        read.rainbows(); // (only a seed that starts at its node's first base with read to spare needs the shifted copies: most reads never do)
+        const auto &rain = currPart->PosStrand ? read.Rainbow : read.RainbowRc;
         for (const Edge &e : node.Prev) {
             const int readBase = GetBase(rain[0], (int)currPart->QueryStart - 1);
             if (readBase == GetBase(e.Dest->SeqTwoBit, e.Dest->SeqTwoBit.Len - 1)) {
@@ -358,25 +465,36 @@ inline void sortSeeds(std::vector<SeedPtr> &seeds) { // seedMapMemPool's tail (s
 }
 // seedMapMemPool for a batch of reads: hash lookups and in-node exact-match extensions on the device, continuation into
 // neighbouring nodes here
-inline std::vector<std::vector<SeedPtr>> seedMapBatch(const SeedIndex &index, const GenomeGraph &g, std::vector<FastqBig> &reads) {
-    Bases ncat, rcat;
-    std::vector<int64_t> noff, roff(1, 0);
-    packNodes(g, ncat, noff);
-    for (const auto &r : reads) { rcat.insert(rcat.end(), r.Seq.begin(), r.Seq.end()); roff.push_back((int64_t)rcat.size()); }
-    rcat.push_back(0);
-    gnxCheck(gnx_seed_index_set(index.keys.data(), index.locs.data(), (int64_t)index.keys.size(), ncat.data(), noff.data(), (int64_t)g.Nodes.size(), index.seedLen));
+inline std::vector<std::vector<SeedPtr>> seedMapBatch(const SeedIndex &index, const GenomeGraph &g, std::vector<FastqBig> &reads, int threads = 1, GswTimings *tm = nullptr) {
+    const double t0 = gswNow();
+    Bases rcat;
+    std::vector<int64_t> roff(reads.size() + 1, 0);
+    for (size_t r = 0; r < reads.size(); r++) roff[r + 1] = roff[r] + (int64_t)reads[r].Seq.size();
+    rcat.resize((size_t)roff.back() + 1, 0);
+    parallelFor(reads.size(), threads, [&](size_t r) { if (!reads[r].Seq.empty()) memcpy(rcat.data() + roff[r], reads[r].Seq.data(), reads[r].Seq.size()); });
     gnx_seed_hit *hits = nullptr;
     int64_t *hoff = nullptr;
-    gnxCheck(gnx_seed_find_batch(rcat.data(), roff.data(), (int64_t)reads.size(), &hits, &hoff));
+    {
+        std::lock_guard<std::mutex> lk(gswSeedMu());
+        if (index.residentGen == 0 || index.residentGen != gswResidentGen() || index.residentGraph != (const void *)&g) { // (a later batch against the same index: it is still there)
+            Bases ncat;
+            std::vector<int64_t> noff;
+            packNodes(g, ncat, noff);
+            gnxCheck(gnx_seed_index_set(index.keys.data(), index.locs.data(), (int64_t)index.keys.size(), ncat.data(), noff.data(), (int64_t)g.Nodes.size(), index.seedLen));
+            index.residentGen = ++gswResidentGen(); index.residentGraph = (const void *)&g;
+        }
+        gnxCheck(gnx_seed_find_batch(rcat.data(), roff.data(), (int64_t)reads.size(), &hits, &hoff));
+    }
     std::vector<std::vector<SeedPtr>> out(reads.size());
-    for (size_t r = 0; r < reads.size(); r++) {
+    const double t1 = gswNow();
+    parallelFor(reads.size(), threads, [&](size_t r) {
         FastqBig &read = reads[r];
         std::vector<SeedPtr> fin;
         for (int64_t h = hoff[r]; h < hoff[r + 1]; h++) {
             const gnx_seed_hit &x = hits[h];
             const Node &node = *g.Nodes[(size_t)x.node];
             const bool pos = x.strand == 0;
-            if (x.right == 0) continue;
+            if (x.right == 0) continue; // (inner loop)
             std::vector<SeedPtr> temp;
             if (x.q_start + x.right < (int)read.Seq.size() && x.node_start + x.right == node.SeqTwoBit.Len && !node.Next.empty())
                 temp = extendToTheRightDev(node, read, x.q_start, x.node_start, pos); // crosses into the next node(s)
@@ -390,9 +508,10 @@ inline std::vector<std::vector<SeedPtr>> seedMapBatch(const SeedIndex &index, co
         }
         sortSeeds(fin);
         out[r] = std::move(fin);
-    }
+    }, /*blocks=*/true);
     gnx_free(hits);
     gnx_free(hoff);
+    if (tm) { tm->seed_device += t1 - t0; tm->seed_host += gswNow() - t1; }
     return out;
 }
 inline bool seedCouldBeBetter(int64_t seedLen, int64_t currBestScore, int64_t perfectScore, int64_t queryLen, int64_t maxMatch, int64_t minMatch,
@@ -473,29 +592,30 @@ using GswExtendFn = int (*)(int, const int64_t *, int64_t, int64_t, const uint8_
                             int64_t *, int64_t *, int64_t *, gnx_cigar **, int64_t **);
 inline GswExtendFn &gswExtendBackend() { static GswExtendFn f = gnx_gsw_extend_batch; return f; }
 // LeftDynamicAln / RightDynamicAln (search.go:234-321) for a batch of requests of one side
-inline std::vector<DpResult> DynamicAlnBatch(int side, const std::vector<const DpRequest *> &reqs, const int64_t *scores25, int64_t gapPen) {
+inline std::vector<DpResult> DynamicAlnBatch(int side, const std::vector<const DpRequest *> &reqs, const int64_t *scores25, int64_t gapPen, int threads = 1, GswTimings *tm = nullptr) {
     const size_t n = reqs.size();
-    Bases acat, bcat;
-    std::vector<int64_t> aoff(1, 0), boff(1, 0);
-    for (const DpRequest *r : reqs) {
-        acat.insert(acat.end(), r->target.begin(), r->target.end());
-        aoff.push_back((int64_t)acat.size());
-        bcat.insert(bcat.end(), r->read, r->read + r->readLen);
-        boff.push_back((int64_t)bcat.size());
-    }
-    acat.push_back(0);
-    bcat.push_back(0);
+    const double t0 = gswNow();
+    std::vector<int64_t> aoff(n + 1, 0), boff(n + 1, 0);
+    for (size_t p = 0; p < n; p++) { aoff[p + 1] = aoff[p] + (int64_t)reqs[p]->target.size(); boff[p + 1] = boff[p] + (int64_t)reqs[p]->readLen; }
+    Bases acat((size_t)aoff[n] + 1, 0), bcat((size_t)boff[n] + 1, 0);
+    parallelFor(n, threads, [&](size_t p) {
+        if (!reqs[p]->target.empty()) memcpy(acat.data() + aoff[p], reqs[p]->target.data(), reqs[p]->target.size());
+        if (reqs[p]->readLen) memcpy(bcat.data() + boff[p], reqs[p]->read, reqs[p]->readLen);
+    });
     std::vector<int64_t> sc(n ? n : 1), ei(n ? n : 1), ej(n ? n : 1);
     gnx_cigar *ops = nullptr;
     int64_t *off = nullptr;
+    const double t1 = gswNow();
     gnxCheck(gswExtendBackend()(side, scores25, gapPen, (int64_t)n, acat.data(), aoff.data(), bcat.data(), boff.data(), sc.data(), ei.data(), ej.data(), &ops, &off));
+    const double t2 = gswNow();
     std::vector<DpResult> out(n);
-    for (size_t p = 0; p < n; p++) {
+    parallelFor(n, threads, [&](size_t p) {
         out[p].score = sc[p]; out[p].i = ei[p]; out[p].j = ej[p];
         out[p].route = mergeRoute(reqs[p]->route, ops + off[p], off[p + 1] - off[p]);
-    }
+    });
     gnx_free(ops);
     gnx_free(off);
+    if (tm) { tm->dp_pack += t1 - t0; tm->dp_device += t2 - t1; tm->dp_merge += gswNow() - t2; }
     return out;
 }
 
@@ -746,10 +866,13 @@ class ReadTask {
 // markPanics: a read on which the Go code panics (getLeftTargetBases with a short Prev node) is marked Panicked and the others go on;
 // default: the GoPanic propagates (the Go process would die there)
 inline std::vector<Giraf> GswBatchToGiraf(const GenomeGraph &g, std::vector<FastqBig> &reads, const SeedIndex &index, const int64_t *scores25,
-                                          int64_t gapPen = -600, int *outRounds = nullptr, bool markPanics = false) {
-    auto seeds = seedMapBatch(index, g, reads);
-    std::vector<std::unique_ptr<ReadTask>> tasks;
-    std::vector<size_t> pending;
+                                          int64_t gapPen = -600, int *outRounds = nullptr, bool markPanics = false, int threads = 0, GswTimings *tm = nullptr) {
+    const int T = gswThreads(threads);
+    if (tm) tm->threads = T;
+    auto seeds = seedMapBatch(index, g, reads, T, tm);
+    const size_t n = reads.size();
+    std::vector<std::unique_ptr<ReadTask>> tasks(n);
+    std::vector<char> alive(n, 0); // (one byte per read: the workers write the bytes of their own reads only)
     auto advance = [&](size_t k, const DpResult *res) -> bool {
         try {
             return tasks[k]->advance(res);
@@ -759,30 +882,36 @@ inline std::vector<Giraf> GswBatchToGiraf(const GenomeGraph &g, std::vector<Fast
             return false;
         }
     };
-    for (size_t k = 0; k < reads.size(); k++) {
-        tasks.push_back(std::make_unique<ReadTask>(g, reads[k], std::move(seeds[k]), scores25));
-        if (advance(k, nullptr)) pending.push_back(k);
-    }
+    double t0 = gswNow();
+    parallelFor(n, T, [&](size_t k) {
+        tasks[k] = std::make_unique<ReadTask>(g, reads[k], std::move(seeds[k]), scores25);
+        alive[k] = advance(k, nullptr) ? 1 : 0;
+    }, /*blocks=*/true);
+    if (tm) tm->tasks += gswNow() - t0;
     int rounds = 0;
-    std::vector<char> alive(reads.size(), 0);
-    for (size_t k : pending) alive[k] = 1;
-    size_t n_alive = pending.size();
+    size_t n_alive = 0;
+    for (size_t k = 0; k < n; k++) n_alive += alive[k];
     while (n_alive > 0) { // a round: the pending left DPs of all reads in one call, then the right ones (incl. those the left answers led to)
         for (int side = GNX_GSW_LEFT; side <= GNX_GSW_RIGHT; side++) {
             std::vector<size_t> ks;
             std::vector<const DpRequest *> rq;
-            for (size_t k = 0; k < tasks.size(); k++)
+            for (size_t k = 0; k < n; k++)
                 if (alive[k] && tasks[k]->req->side == side) { ks.push_back(k); rq.push_back(tasks[k]->req); }
             if (ks.empty()) continue;
-            auto outs = DynamicAlnBatch(side, rq, scores25, gapPen);
-            for (size_t y = 0; y < ks.size(); y++)
-                if (!advance(ks[y], &outs[y])) { alive[ks[y]] = 0; n_alive--; }
+            auto outs = DynamicAlnBatch(side, rq, scores25, gapPen, T, tm);
+            t0 = gswNow();
+            parallelFor(ks.size(), T, [&](size_t y) { if (!advance(ks[y], &outs[y])) alive[ks[y]] = 0; });
+            if (tm) tm->advance += gswNow() - t0;
         }
+        n_alive = 0;
+        for (size_t k = 0; k < n; k++) n_alive += alive[k];
         rounds++;
     }
     if (outRounds) *outRounds = rounds;
-    std::vector<Giraf> out;
-    for (auto &t : tasks) out.push_back(std::move(t->best));
+    t0 = gswNow();
+    std::vector<Giraf> out(n);
+    parallelFor(n, T, [&](size_t k) { out[k] = std::move(tasks[k]->best); tasks[k].reset(); }, /*blocks=*/true); // (the workers free what they allocated: seeds, stacks, slices)
+    if (tm) tm->finish += gswNow() - t0;
     return out;
 }
 
@@ -799,8 +928,8 @@ inline bool isProperPairAlign(const Giraf &fwd, const Giraf &rev) {
     return false;
 }
 inline std::vector<Giraf> WrapPairGirafBatch(const GenomeGraph &g, std::vector<FastqBig> &reads, const SeedIndex &index, const int64_t *scores25,
-                                             int64_t gapPen = -600, int *outRounds = nullptr, bool markPanics = false) {
-    std::vector<Giraf> res = GswBatchToGiraf(g, reads, index, scores25, gapPen, outRounds, markPanics);
+                                             int64_t gapPen = -600, int *outRounds = nullptr, bool markPanics = false, int threads = 0, GswTimings *tm = nullptr) {
+    std::vector<Giraf> res = GswBatchToGiraf(g, reads, index, scores25, gapPen, outRounds, markPanics, threads, tm);
     for (size_t k = 0; k + 1 < res.size(); k += 2) {
         Giraf &fwd = res[k], &rev = res[k + 1];
         if (fwd.Panicked || rev.Panicked) continue;

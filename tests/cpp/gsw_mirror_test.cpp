@@ -1,7 +1,8 @@
 // The C++ mirror of the graph aligner's read path (include/gonomics_genomegraph.hpp) on a case written by tests/test_gsw_cpp.py:
 //   input  (text): n_nodes, then per node "len b b b ..."; n_edges, then "u v"; n_reads, then per read "len b b ..."; seedLen seedStep; 25 scores
 //   output (text): one line per read: QStart QEnd PosStrand TStart TEnd AlnScore | nodes... | cigar (len op)... | n_seeds
-// and a last line "# index_ms seeds_and_dp_ms rounds" (wall clock of the two stages through the C ABI).
+// and a last line "# index_ms seeds_and_dp_ms rounds threads seed_device seed_host tasks dp_pack dp_device dp_merge advance finish" (wall clock of
+// the stages through the C ABI, ms; GNX_GSW_THREADS = the mirror's worker threads).
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -48,9 +49,25 @@ int main(int argc, char **argv) {
         auto t1 = std::chrono::steady_clock::now();
         int rounds = 0;
         const bool paired = argc > 3 && std::string(argv[3]) == "pairs"; // reads 2k / 2k+1 = the mates of pair k (WrapPairGiraf)
-        auto res = paired ? WrapPairGirafBatch(g, reads, index, sc, -600, &rounds, /*markPanics=*/true)
-                          : GswBatchToGiraf(g, reads, index, sc, -600, &rounds, /*markPanics=*/true);
+        GswTimings tm;
+        auto res = paired ? WrapPairGirafBatch(g, reads, index, sc, -600, &rounds, /*markPanics=*/true, 0, &tm)
+                          : GswBatchToGiraf(g, reads, index, sc, -600, &rounds, /*markPanics=*/true, 0, &tm);
         auto t2 = std::chrono::steady_clock::now();
+        // GNX_GSW_REPEAT=k (benchmarks): the same batch k more times against the index that is now resident, fresh read objects each time;
+        // the fastest call is the one reported (the first call pays the index upload, the workers' start and first-touch allocations)
+        for (int rep = 0; rep < (getenv("GNX_GSW_REPEAT") ? atoi(getenv("GNX_GSW_REPEAT")) : 0); rep++) {
+            std::vector<FastqBig> again;
+            for (const FastqBig &r : reads) again.emplace_back(r.Name, r.Seq);
+            GswTimings tm2;
+            auto a0 = std::chrono::steady_clock::now();
+            auto res2 = paired ? WrapPairGirafBatch(g, again, index, sc, -600, &rounds, true, 0, &tm2) : GswBatchToGiraf(g, again, index, sc, -600, &rounds, true, 0, &tm2);
+            auto a1 = std::chrono::steady_clock::now();
+            if (res2.size() != res.size()) { fprintf(stderr, "error: repeat call returned %zu results\n", res2.size()); return 1; }
+            for (size_t k = 0; k < res.size(); k++)
+                if (res2[k].Panicked != res[k].Panicked || res2[k].AlnScore != res[k].AlnScore || res2[k].Nodes != res[k].Nodes || res2[k].TStart != res[k].TStart ||
+                    res2[k].Cig.size() != res[k].Cig.size()) { fprintf(stderr, "error: repeat call differs at read %zu\n", k); return 1; }
+            if (a1 - a0 < t2 - t1) { t2 = t1 + (a1 - a0); tm = tm2; }
+        }
         std::ofstream out(argv[2]);
         for (const Giraf &r : res) {
             if (r.Panicked) { out << "panic\n"; continue; } // the Go code panics on this read (getLeftTargetBases, search.go:139)
@@ -63,7 +80,8 @@ int main(int argc, char **argv) {
             if (paired) out << " | " << (int)r.Flag;
             out << '\n';
         }
-        out << "# " << std::chrono::duration<double, std::milli>(t1 - t0).count() << ' ' << std::chrono::duration<double, std::milli>(t2 - t1).count() << ' ' << rounds << '\n';
+        out << "# " << std::chrono::duration<double, std::milli>(t1 - t0).count() << ' ' << std::chrono::duration<double, std::milli>(t2 - t1).count() << ' ' << rounds
+            << ' ' << tm.threads << ' ' << tm.seed_device << ' ' << tm.seed_host << ' ' << tm.tasks << ' ' << tm.dp_pack << ' ' << tm.dp_device << ' ' << tm.dp_merge << ' ' << tm.advance << ' ' << tm.finish << '\n';
     } catch (const std::exception &e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

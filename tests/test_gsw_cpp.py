@@ -105,6 +105,29 @@ def test_cpp_gsw_mirror_equals_python_mirror(gpu_lib, tmp_path, kind, seed_len, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["snp", "wide3"])
+def test_cpp_gsw_worker_pool_equals_one_thread(gpu_lib, tmp_path, kind):
+    """the mirror's worker pool (per-read host work on GNX_GSW_THREADS threads, genomeGraph/routines.go:12-65) returns what one thread
+    returns, read for read, panics included"""
+    _build()
+    seqs, edges, reads = [], [], []
+    for seed in (21, 22, 23, 24, 25):  # five cases side by side in one graph: 200 reads
+        s2, e2, r2 = make_case(seed, kind)
+        edges += [(u + len(seqs), v + len(seqs)) for u, v in e2]
+        seqs += s2
+        reads += r2
+    write_case(str(tmp_path / "case.txt"), seqs, edges, reads, 16, 1, MX["HumanChimpTwo"])
+    outs = {}
+    for threads in ("1", "3", "16"):
+        env = dict(os.environ, GNX_GSW_THREADS=threads)
+        assert subprocess.call([BIN, str(tmp_path / "case.txt"), str(tmp_path / ("out%s.txt" % threads))], env=env) == 0
+        outs[threads], timing = read_out(str(tmp_path / ("out%s.txt" % threads)))
+        assert int(timing[3]) == int(threads)
+    assert len(outs["1"]) == len(reads) and outs["1"] == outs["3"] == outs["16"]
+    assert any(r != "panic" and r[7] > 0 for r in outs["1"])
+
+
+@pytest.mark.gpu
 def test_cpp_wrap_pair_giraf_equals_python_mirror(gpu_lib, tmp_path):
     """WrapPairGirafBatch of the C++ mirror == the Python mirror (both against the restatement in test_gsw_reads.py)"""
     _build()
