@@ -18,7 +18,7 @@ EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gn
            "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing",
            "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch",
            "gnx_init_devices", "gnx_n_devices", "gnx_set_reference", "gnx_set_reference_synthetic", "gnx_align_batch_by_offset",
-           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch", "gnx_debug_occupy", "gnx_debug_counter", "gnx_reference_info"]
+           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch", "gnx_gsw_graph_create", "gnx_gsw_graph_free", "gnx_gsw_map_reads", "gnx_debug_occupy", "gnx_debug_counter", "gnx_reference_info"]
 
 
 class GnxCigar(ctypes.Structure):
@@ -104,6 +104,13 @@ def lib():
         L.gnx_seed_index_set.restype = ctypes.c_int
         L.gnx_seed_find_batch.argtypes = [c_p, c_p, i64, ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
         L.gnx_seed_find_batch.restype = ctypes.c_int
+        if hasattr(L, "gnx_gsw_map_reads"):
+            L.gnx_gsw_graph_create.argtypes = [c_p, c_p, i64, c_p, c_p, i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_p)]
+            L.gnx_gsw_graph_create.restype = ctypes.c_int
+            L.gnx_gsw_graph_free.argtypes = [c_p]
+            L.gnx_gsw_graph_free.restype = None
+            L.gnx_gsw_map_reads.argtypes = [c_p, c_p, c_p, i64, ctypes.c_int, c_p, i64, ctypes.c_int, ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p)]
+            L.gnx_gsw_map_reads.restype = ctypes.c_int
         L.gnx_get_timing.argtypes = [ctypes.POINTER(GnxTiming)]
         L.gnx_get_timing.restype = ctypes.c_int
         if hasattr(L, "gnx_debug_occupy"):  # (absent from older builds loaded through GNX_LIB_PATH for A/B runs)
@@ -416,6 +423,64 @@ def seed_index_build(node_seqs, seed_len, seed_step):
     L.gnx_free(kp)
     L.gnx_free(lp)
     return keys, locs
+
+
+GIRAF_DTYPE = np.dtype([("q_start", np.int64), ("q_end", np.int64), ("t_start", np.int64), ("t_end", np.int64), ("aln_score", np.int64),
+                        ("node_off", np.int64), ("n_nodes", np.int64), ("cigar_off", np.int64), ("n_cigar", np.int64),
+                        ("pos_strand", np.int32), ("flag", np.int32), ("map_q", np.int32), ("has_cigar", np.int32), ("seq_is_rc", np.int32), ("panicked", np.int32)])
+
+
+class GswGraph:
+    """gnx_gsw_graph: nodes, edges and the seed index of a genome graph behind the C ABI (resident on the device between batches)"""
+
+    def __init__(self, node_seqs, edges, seed_len, seed_step):
+        L = lib()
+        cat, off = _cat(node_seqs)
+        ef = np.ascontiguousarray([u for u, _ in edges], dtype=np.int32)
+        et = np.ascontiguousarray([v for _, v in edges], dtype=np.int32)
+        h = ctypes.c_void_p()
+        check(L.gnx_gsw_graph_create(cat.ctypes.data, off.ctypes.data, len(node_seqs), ef.ctypes.data if len(edges) else None, et.ctypes.data if len(edges) else None,
+                                     len(edges), int(seed_len), int(seed_step), ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().gnx_gsw_graph_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def map_reads(self, read_seqs, scores, gap_pen=-600, paired=False, threads=0):
+        """-> (girafs: structured array GIRAF_DTYPE, node ids uint32, cigars CIGAR_DTYPE with op = ord('M' / 'I' / 'D' / 'S'))"""
+        L = lib()
+        if isinstance(read_seqs, tuple):  # (bases uint8 concatenated, offsets int64[n + 1]): as the C ABI takes them
+            rcat, roff = np.ascontiguousarray(read_seqs[0], dtype=np.uint8), np.ascontiguousarray(read_seqs[1], dtype=np.int64)
+            if rcat.shape[0] == 0:
+                rcat = np.zeros(1, np.uint8)
+            n = roff.shape[0] - 1
+        else:
+            rcat, roff = _cat(read_seqs)
+            n = len(read_seqs)
+        sc = np.ascontiguousarray(scores, dtype=np.int64).reshape(25)
+        gp, np_, cp = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        check(L.gnx_gsw_map_reads(self._h, rcat.ctypes.data, roff.ctypes.data, n, 1 if paired else 0, sc.ctypes.data, int(gap_pen), int(threads),
+                                  ctypes.byref(gp), ctypes.byref(np_), ctypes.byref(cp)))
+        _seed_set[0] = None  # (the device's resident index is this graph's now)
+
+        def take(ptr, dtype, count):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (ctypes.c_char * (count * dtype.itemsize)).from_address(ptr.value)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+        gir = take(gp, GIRAF_DTYPE, n)
+        nn = int((gir["node_off"][-1] + gir["n_nodes"][-1])) if n else 0
+        nc = int((gir["cigar_off"][-1] + gir["n_cigar"][-1])) if n else 0
+        nodes = take(np_, np.dtype(np.uint32), nn)
+        cig = take(cp, CIGAR_DTYPE, nc)
+        for ptr in (gp, np_, cp):
+            if ptr.value:
+                L.gnx_free(ptr)
+        return gir, nodes, cig
 
 
 SEED_HIT_DTYPE = np.dtype([("read_start", np.int32), ("strand", np.int32), ("node", np.int32), ("node_start", np.int32), ("q_start", np.int32), ("right", np.int32)])

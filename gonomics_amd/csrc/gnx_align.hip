@@ -1983,8 +1983,10 @@ int gnx_seed_index_build(const uint8_t *node_cat, const int64_t *node_off, int64
     return GNX_OK;
 }
 
+static std::atomic<uint64_t> g_seed_sets{0}; // calls of gnx_seed_index_set so far (gsw_reads.hip.h: is a graph handle's index still the resident one?)
 int gnx_seed_index_set(const uint64_t *keys, const uint64_t *locs, int64_t n_index, const uint8_t *node_cat, const int64_t *node_off, int64_t n_nodes, int seed_len) {
     std::lock_guard<std::mutex> api(g_api_mu);
+    g_seed_sets++;
     CtxScope sc(ctx_at(0));
     g_err[0] = 0;
     if (n_index < 0 || (n_index > 0 && (!keys || !locs)) || !node_off || n_nodes < 0 || n_nodes > 0x7ffffff0 || seed_len < 2 || seed_len > 32) { set_err("bad argument%s", ""); return GNX_EINVAL; }
@@ -2135,3 +2137,5 @@ int gnx_get_timing(gnx_timing *out) {
 }
 
 } // extern "C"
+
+#include "gsw_reads.hip.h"

@@ -838,6 +838,65 @@ def GswBatchToGiraf(gg, reads, index, seedLen, scoreMatrix, device_seeds=True, o
     return results
 
 
+def _edge_list(gg):
+    """(u, v) pairs in an order of AddEdge calls that rebuilds every node's Next AND Prev list as they are (traversals try a node's
+    edges in list order, so the order is part of the graph)"""
+    ids = {id(n): k for k, n in enumerate(gg.Nodes)}
+    by_next = [(ids[id(u)], ids[id(e.Dest)]) for u in gg.Nodes for e in u.Next]
+    by_prev = [(ids[id(e.Dest)], ids[id(v)]) for v in gg.Nodes for e in v.Prev]
+    for edges in (by_next, by_prev):
+        nxt = [[] for _ in gg.Nodes]
+        prv = [[] for _ in gg.Nodes]
+        for u, v in edges:
+            nxt[u].append(v)
+            prv[v].append(u)
+        if all(nxt[k] == [ids[id(e.Dest)] for e in n.Next] and prv[k] == [ids[id(e.Dest)] for e in n.Prev] for k, n in enumerate(gg.Nodes)):
+            return edges
+    raise ValueError("the graph's edge lists do not come from one sequence of AddEdge calls in node order: pass edges= explicitly")
+
+
+class NativeGraph:
+    """the graph behind gnx_gsw_graph_create (nodes, edges, seed index kept by the library, the index resident on the device): the whole
+    read path of a batch in one C-ABI call -- the per-read driver is the library's compiled one (include/gonomics_genomegraph.hpp on a
+    pool of host threads) instead of this module's generators.  Same results as GswBatchToGiraf / WrapPairGirafBatch."""
+
+    def __init__(self, gg, seedLen, seedStep, edges=None):
+        self.gg = gg
+        self.handle = _lib.GswGraph([n.Seq for n in gg.Nodes], _edge_list(gg) if edges is None else edges, seedLen, seedStep)
+
+    def _girafs(self, reads, scoreMatrix, paired, threads, on_panic):
+        gir, nodes, cig = self.handle.map_reads([r.Seq for r in reads], scoreMatrix, -600, paired=paired, threads=threads)
+        out = []
+        for k, r in enumerate(reads):
+            x = gir[k]
+            if x["panicked"]:
+                gp = GoPanic("runtime error: slice bounds out of range (getLeftTargetBases, search.go:139)")
+                if on_panic != "mark":
+                    raise gp
+                out.append(gp)
+                continue
+            g = Giraf(r)
+            g.QStart, g.QEnd, g.PosStrand, g.AlnScore, g.MapQ, g.Flag = int(x["q_start"]), int(x["q_end"]), bool(x["pos_strand"]), int(x["aln_score"]), int(x["map_q"]), int(x["flag"])
+            g.Path = (int(x["t_start"]), [int(v) for v in nodes[int(x["node_off"]):int(x["node_off"] + x["n_nodes"])]], int(x["t_end"]))
+            if x["has_cigar"]:
+                c = cig[int(x["cigar_off"]):int(x["cigar_off"] + x["n_cigar"])]
+                g.Cigar = [cigar.Cigar(int(a), int(b)) for a, b in zip(c["run_length"], c["op"])]
+            g.Seq = r.SeqRc if x["seq_is_rc"] else r.Seq
+            out.append(g)
+        return out
+
+    def GswBatchToGiraf(self, reads, scoreMatrix, threads=0, on_panic="raise"):
+        return self._girafs(reads, scoreMatrix, False, threads, on_panic)
+
+    def WrapPairGirafBatch(self, pairs, scoreMatrix, threads=0, on_panic="raise"):
+        flat = self._girafs([r for pr in pairs for r in pr], scoreMatrix, True, threads, on_panic)
+        return [(flat[2 * k], flat[2 * k + 1]) for k in range(len(pairs))]
+
+    def map_reads_raw(self, read_seqs, scoreMatrix, paired=False, threads=0):
+        """the arrays as the C ABI returns them (no per-read Python objects): (GIRAF_DTYPE records, node ids, cigars)"""
+        return self.handle.map_reads(read_seqs, scoreMatrix, -600, paired=paired, threads=threads)
+
+
 def getGirafFlags(ag):
     """toGiraf.go:183-192 (uint8)"""
     return (4 if ag.PosStrand else 0) + (2 if ag.AlnScore < 1200 else 0)

@@ -231,6 +231,31 @@ int gnx_gsw_extend_batch(int side, const int64_t *scores, int64_t gap_pen, int64
                          const uint8_t *alpha_cat, const int64_t *alpha_off, const uint8_t *beta_cat, const int64_t *beta_off,
                          int64_t *out_score, int64_t *out_end_i, int64_t *out_end_j, gnx_cigar **out_ops, int64_t **out_ops_off);
 
+/* The graph aligner's read path, one call per batch of reads: genomeGraph.GraphSmithWatermanToGiraf (/root/reference/genomeGraph/toGiraf.go:17-72)
+ * for every read -- seeds (seedMapMemPool, search.go:549-590), seedCouldBeBetter pruning (index.go:102-121), Left / RightAlignTraversal
+ * (search.go:166-232) with their DPs -- and, with paired != 0, WrapPairGiraf's flags (toGiraf.go:117-140; reads 2k / 2k+1 = the mates of pair k).
+ * What the reference spreads over `-t` worker goroutines (genomeGraph/routines.go:12-65, cmd/gsw) runs here as: seed search and extension
+ * DPs of the whole batch on the device, the per-read bookkeeping between them on `threads` host threads (0 = GNX_GSW_THREADS, else
+ * min(hardware threads, 16)).  The graph handle keeps the nodes, the edges and the seed index (IndexGenomeIntoMap, index.go:21-59; resident on
+ * the device between calls).  Results in input order: out_girafs[r] with its node ids at out_nodes[node_off ..) and its cigar
+ * (cigar.Cigar{RunLength, Op}: op = the ASCII byte 'M' 'I' 'D' 'S', as cigar.Cigar.Op holds it) at out_cigars[cigar_off ..); a read on
+ * which the Go code panics (getLeftTargetBases with a short Prev node, search.go:139) has panicked = 1 and nothing else.  The three
+ * arrays are malloc'd: gnx_free().  Not pinned by the reference's tests (parity contract: DESIGN.md section 6). */
+typedef struct gnx_gsw_graph gnx_gsw_graph;
+typedef struct gnx_giraf {
+    int64_t q_start, q_end, t_start, t_end, aln_score; /* giraf.Giraf: QStart, QEnd, Path.TStart, Path.TEnd, AlnScore */
+    int64_t node_off, n_nodes;                         /* Path.Nodes */
+    int64_t cigar_off, n_cigar;                        /* Cigar (has_cigar = 0: nil) */
+    int32_t pos_strand, flag, map_q, has_cigar;
+    int32_t seq_is_rc;                                 /* Seq is the read's reverse complement (1) or the read (0) */
+    int32_t panicked;
+} gnx_giraf;
+int gnx_gsw_graph_create(const uint8_t *node_cat, const int64_t *node_off, int64_t n_nodes, const int32_t *edge_from, const int32_t *edge_to,
+                         int64_t n_edges, int seed_len, int seed_step, gnx_gsw_graph **out);
+void gnx_gsw_graph_free(gnx_gsw_graph *g);
+int gnx_gsw_map_reads(gnx_gsw_graph *g, const uint8_t *read_cat, const int64_t *read_off, int64_t n_reads, int paired, const int64_t *scores,
+                      int64_t gap_pen, int threads, gnx_giraf **out_girafs, uint32_t **out_nodes, gnx_cigar **out_cigars);
+
 /* ---- "next" row N4: the seed index and the seed search of the graph aligner (what cmd/gsw does before its DPs) ----------------- */
 /* genomeGraph.IndexGenomeIntoMap (/root/reference/genomeGraph/index.go:21-43) for the k-mers inside nodes: node k is
  * node_cat[node_off[k] .. node_off[k+1]) (dna.Base bytes, N allowed); positions 0, seed_step, ... of every node; k-mers with an N

@@ -199,3 +199,50 @@ def test_wrap_pair_giraf(gpu_lib, kind):
         assert (fw.Flag, rv.Flag) == (ff, rf), "pair %d" % k
         flags_seen.add((ff, rf))
     assert len(flags_seen) >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["linear", "snp", "wide", "wide3"])
+def test_native_read_path_equals_python_mirror(gpu_lib, kind):
+    """gnx_gsw_graph_create / gnx_gsw_map_reads (the whole read path of a batch in one C-ABI call: the compiled per-read driver on a pool
+    of host threads around the device's seed search and DP rounds) == the Python mirror, read for read and pair for pair; and a batch
+    against the graph again after another index took the device's place."""
+    seqs, edges, reads = make_case(13, kind)
+    g = build(seqs, edges)
+    sc = MX["HumanChimpTwo"]
+    index = gg.SeedIndex(g.Nodes, 16, 1)
+    bigs = [gg.FastqBig("r%d" % k, rd) for k, rd in enumerate(reads)]
+    py = gg.GswBatchToGiraf(g, bigs, index, 16, sc, on_panic="mark")
+    ng = gg.NativeGraph(g, 16, 1)
+    assert gg._edge_list(g) == [tuple(e) for e in edges]
+    for threads in (1, 5):
+        nat = ng.GswBatchToGiraf(bigs, sc, threads=threads, on_panic="mark")
+        assert len(nat) == len(py)
+        for k, (a, b) in enumerate(zip(nat, py)):
+            if isinstance(b, gg.GoPanic):
+                assert isinstance(a, gg.GoPanic), "read %d" % k
+            else:
+                assert a.key() == b.key() and a.Flag == b.Flag and a.MapQ == b.MapQ, "read %d (%d threads)" % (k, threads)
+    assert any(isinstance(b, gg.GoPanic) for b in py) == (kind == "snp")
+    # the Python mirror's seed search made ITS index resident in between (gnx_seed_index_set): the handle notices and uploads its own again
+    pairs = [(bigs[2 * k], bigs[2 * k + 1]) for k in range(len(bigs) // 2)]
+    pyp = gg.WrapPairGirafBatch(g, pairs, index, 16, sc, on_panic="mark")
+    natp = ng.WrapPairGirafBatch(pairs, sc, on_panic="mark")
+    for k, (pa, pb) in enumerate(zip(natp, pyp)):
+        for a, b in zip(pa, pb):
+            if isinstance(b, gg.GoPanic):
+                assert isinstance(a, gg.GoPanic), "pair %d" % k
+            else:
+                assert a.key() == b.key() and a.Flag == b.Flag, "pair %d" % k
+    gir, nodes, cig = ng.map_reads_raw([b.Seq for b in bigs], sc)
+    assert gir.shape[0] == len(bigs) and int(gir["n_nodes"].sum()) == nodes.shape[0] and int(gir["n_cigar"].sum()) == cig.shape[0]
+    ng.handle.close()
+
+
+def test_native_graph_bad_arguments():
+    """argument checks of the graph entry points that need no device (a bad edge, a base >= 5) -- and no CPU fallback behind them"""
+    from gonomics_amd import _lib
+    with pytest.raises(_lib.GnxError):
+        _lib.GswGraph([np.zeros(40, np.uint8)], [(0, 3)], 16, 1)
+    with pytest.raises(_lib.GnxError):
+        _lib.GswGraph([np.full(40, 7, np.uint8)], [], 16, 1)
