@@ -1,0 +1,154 @@
+// routines_hip.go -- the graph aligner's worker routine (cmd/gsw) as batches behind libgonomics_align_hip.so.
+//
+// Recipe (shim/manifest.json, package genomeGraph, step2 -- optional, on top of step1): add this file.  Nothing of the package is
+// replaced: RoutineFqToGirafHip is a worker with the contract of RoutineFqToGiraf (genomeGraph/routines.go:12-25: reads off a
+// channel, one giraf.Giraf per read onto a channel, wg.Done() at the end) that a cmd/gsw built with `-tags hip` starts ONCE instead
+// of `-t` copies of RoutineFqToGiraf: it cuts the stream into batches and hands each to gnx_gsw_map_reads, where the seed search and
+// the extension DPs of the whole batch run on the device and the per-read bookkeeping of GraphSmithWatermanToGiraf
+// (toGiraf.go:17-72) on a pool of host threads inside the library.  Girafs leave in input order.
+// A read on which GraphSmithWatermanToGiraf panics (getLeftTargetBases with a short Prev node, search.go:139) panics here too.
+// NOT COMPILED in the image this repository is built in (no Go toolchain).
+//go:build hip
+
+package genomeGraph
+
+/*
+#cgo LDFLAGS: -lgonomics_align_hip
+#include <stdlib.h>
+#include "gnx_align.h"
+*/
+import "C"
+
+import (
+	"log"
+	"sync"
+	"unsafe"
+
+	"github.com/vertgenlab/gonomics/cigar"
+	"github.com/vertgenlab/gonomics/dna"
+	"github.com/vertgenlab/gonomics/fastq"
+	"github.com/vertgenlab/gonomics/giraf"
+)
+
+// HipGraph is a genome graph and its seed index (IndexGenomeIntoMap, index.go:21-59) kept by the library, the index resident on the device.
+type HipGraph struct {
+	h *C.gnx_gsw_graph
+}
+
+// NewHipGraph hands the nodes and the edges of gg to the library.  Edges go over in the order of the nodes' Next lists; the library
+// rebuilds Next and Prev with AddEdge (genomeGraph.go:118-121), so a graph whose Prev lists were filled in another order than its
+// Next lists (none of the reference's readers does that) would have its left traversals try their branches in another order.
+func NewHipGraph(gg *GenomeGraph, seedLen int, stepSize int) *HipGraph {
+	off := make([]C.int64_t, len(gg.Nodes)+1)
+	var cat []dna.Base
+	var from, to []C.int32_t
+	for i := range gg.Nodes {
+		cat = append(cat, gg.Nodes[i].Seq...)
+		off[i+1] = C.int64_t(len(cat))
+		for _, e := range gg.Nodes[i].Next {
+			from, to = append(from, C.int32_t(gg.Nodes[i].Id)), append(to, C.int32_t(e.Dest.Id))
+		}
+	}
+	var fp, tp *C.int32_t
+	if len(from) > 0 {
+		fp, tp = &from[0], &to[0]
+	}
+	var h *C.gnx_gsw_graph
+	if rc := C.gnx_gsw_graph_create(gswBasePtr(cat), &off[0], C.int64_t(len(gg.Nodes)), fp, tp, C.int64_t(len(from)), C.int(seedLen), C.int(stepSize), &h); rc != C.GNX_OK {
+		log.Panicf("genomeGraph (hip): %s", C.GoString(C.gnx_last_error()))
+	}
+	return &HipGraph{h: h}
+}
+
+// Close releases the graph and its index.
+func (g *HipGraph) Close() {
+	C.gnx_gsw_graph_free(g.h)
+	g.h = nil
+}
+
+// GswBatchToGiraf is GraphSmithWatermanToGiraf (toGiraf.go:17-72) for every read of a batch.  threads = 0: the library's default.
+func (g *HipGraph) GswBatchToGiraf(reads []fastq.FastqBig, scoreMatrix [][]int64, threads int) []giraf.Giraf {
+	n := len(reads)
+	if n == 0 {
+		return nil
+	}
+	var flat [25]C.int64_t
+	for a := 0; a < 5; a++ {
+		for b := 0; b < 5; b++ {
+			flat[a*5+b] = C.int64_t(scoreMatrix[a][b])
+		}
+	}
+	off := make([]C.int64_t, n+1)
+	var cat []dna.Base
+	for i := 0; i < n; i++ {
+		cat = append(cat, reads[i].Seq...)
+		off[i+1] = C.int64_t(len(cat))
+	}
+	var gir *C.gnx_giraf
+	var nodes *C.uint32_t
+	var cig *C.gnx_cigar
+	rc := C.gnx_gsw_map_reads(g.h, gswBasePtr(cat), &off[0], C.int64_t(n), 0, &flat[0], -600, C.int(threads), &gir, &nodes, &cig)
+	switch rc {
+	case C.GNX_OK:
+	case C.GNX_EBASE:
+		panic("runtime error: index out of range (dna.Base used as score-matrix index)")
+	default:
+		log.Panicf("genomeGraph (hip): %s", C.GoString(C.gnx_last_error()))
+	}
+	defer C.gnx_free(unsafe.Pointer(gir))
+	defer C.gnx_free(unsafe.Pointer(nodes))
+	defer C.gnx_free(unsafe.Pointer(cig))
+	recs := unsafe.Slice(gir, n)
+	last := recs[n-1]
+	allNodes := unsafe.Slice(nodes, int(last.node_off+last.n_nodes)+1)
+	allCig := unsafe.Slice(cig, int(last.cigar_off+last.n_cigar)+1)
+	out := make([]giraf.Giraf, n)
+	for i := 0; i < n; i++ {
+		r := recs[i]
+		if r.panicked != 0 {
+			panic("runtime error: slice bounds out of range (getLeftTargetBases, search.go:139)")
+		}
+		path := giraf.Path{TStart: int(r.t_start), Nodes: make([]uint32, int(r.n_nodes)), TEnd: int(r.t_end)}
+		for k := range path.Nodes {
+			path.Nodes[k] = uint32(allNodes[int(r.node_off)+k])
+		}
+		var cg []cigar.Cigar
+		if r.has_cigar != 0 {
+			cg = make([]cigar.Cigar, int(r.n_cigar))
+			for k := range cg {
+				c := allCig[int(r.cigar_off)+k]
+				cg[k] = cigar.Cigar{RunLength: int(c.run_length), Op: byte(c.op)}
+			}
+		}
+		seq := reads[i].Seq
+		if r.seq_is_rc != 0 {
+			seq = reads[i].SeqRc
+		}
+		out[i] = giraf.Giraf{QName: reads[i].Name, QStart: int(r.q_start), QEnd: int(r.q_end), Flag: uint8(r.flag), PosStrand: r.pos_strand != 0, Path: path,
+			Cigar: cg, AlnScore: int(r.aln_score), MapQ: uint8(r.map_q), Seq: seq, Qual: reads[i].Qual,
+			Notes: []giraf.Note{{Tag: []byte{'X', 'O'}, Type: 'Z', Value: "~"}}} // toGiraf.go:18-30
+		if !out[i].PosStrand {
+			fastq.ReverseQualUint8Record(out[i].Qual) // toGiraf.go:68-70 (in place, on the read's own slice, as there)
+		}
+	}
+	return out
+}
+
+// RoutineFqToGirafHip: the contract of RoutineFqToGiraf (routines.go:12-25), one worker for the whole stream, batchSize reads per device call.
+func RoutineFqToGirafHip(g *HipGraph, scoreMatrix [][]int64, batchSize int, threads int, inputChan <-chan fastq.FastqBig, outputChan chan<- giraf.Giraf, wg *sync.WaitGroup) {
+	batch := make([]fastq.FastqBig, 0, batchSize)
+	flush := func() {
+		for _, r := range g.GswBatchToGiraf(batch, scoreMatrix, threads) {
+			outputChan <- r
+		}
+		batch = batch[:0]
+	}
+	for read := range inputChan {
+		batch = append(batch, read)
+		if len(batch) == batchSize {
+			flush()
+		}
+	}
+	flush()
+	wg.Done()
+}

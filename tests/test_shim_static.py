@@ -321,10 +321,13 @@ def header_model():
         end = match_close(code, m.end() - 1, "{", "}")
         fields = set()
         for decl in code[m.end():end].split(";"):
-            mm = re.search(r"(\w+)\s*(?:\[[^\]]*\])?\s*$", decl.strip())
-            if mm:
-                fields.add(mm.group(1))
+            for part in decl.split(","):  # `int64_t a, b, c`
+                mm = re.search(r"(\w+)\s*(?:\[[^\]]*\])?\s*$", part.strip())
+                if mm:
+                    fields.add(mm.group(1))
         structs[m.group(1)] = fields
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s+(\w+)\s*;", code):  # opaque handles
+        structs.setdefault(m.group(2), set())
     return protos, consts, structs
 
 
@@ -385,7 +388,8 @@ def test_shim_binds_only_what_the_header_declares():
                 assert nm in structs, "%s uses type C.%s, not declared in gnx_align.h" % (f.name, nm)
     # what SURVEY 8b lists for the boundary is bound by the shim
     for need in ("gnx_align_pair", "gnx_align_batch", "gnx_align_batch_by_offset", "gnx_set_reference", "gnx_init_devices", "gnx_free",
-                 "gnx_last_error", "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch", "gnx_get_timing"):
+                 "gnx_last_error", "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch", "gnx_get_timing",
+                 "gnx_gsw_graph_create", "gnx_gsw_map_reads", "gnx_gsw_graph_free"):
         assert need in bound, need
     # struct fields the shim touches exist
     for f in shim_files():
