@@ -375,6 +375,49 @@ def extra_c5(_lib, L, scores, chunk_h, dev, torch, n_pairs=1024, n=20000, m=1000
             "roofline": _roofline_of(tm, n, m, 2, n_pairs, int(off[-1]))}
 
 
+def extra_gsw(_lib, L, scores, chunk_h, dev, torch, n_reads=20000, n_check=48):
+    """"next" row N2, the graph aligner's read path (cmd/gsw): GraphSmithWatermanToGiraf for a batch of reads as ONE C-ABI call
+    (gnx_gsw_graph_create / gnx_gsw_map_reads: seed search and extension DPs on the device, the per-read driver on the library's pool of
+    host threads).  4 x 200 kb graph, seedLen 32 / step 32, 150-base reads with 2 % substitutions and 1 % indels, both strands.  Not the
+    headline metric; a sample is compared with the sequential restatement tests/pyref_gsw.py (CPU oracle DPs) after the timing."""
+    import common
+    import pyref_gsw as ref
+    from gonomics_amd import genomeGraph as gg
+    rng = np.random.default_rng(9)
+    seed_len, step = 32, 32
+    seqs = [rng.integers(0, 4, size=200000).astype(np.uint8) for _ in range(4)]
+    reads = []
+    for _ in range(n_reads):
+        k = int(rng.integers(0, 4)); o = int(rng.integers(0, 200000 - 170))
+        r = common.mutate(rng, seqs[k][o:o + 170], 0.02, 0.01)[:150]
+        reads.append(r if rng.random() < 0.5 else (3 - r[::-1]).astype(np.uint8))
+    cat = (np.concatenate(reads), np.concatenate([[0], np.cumsum([len(x) for x in reads])]).astype(np.int64))
+    t0 = time.perf_counter()
+    h = _lib.GswGraph(seqs, [], seed_len, step)
+    t_graph = time.perf_counter() - t0
+    best = None
+    for _ in range(4):  # (the first call uploads the index and starts the workers)
+        t0 = time.perf_counter()
+        gir, nodes, cig = h.map_reads(cat, scores, -600)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    h.close()
+    rnodes = ref.make_graph(seqs, [])
+    full = ref.index_genome(rnodes, seed_len, step)
+    okk = True
+    pick = np.linspace(0, n_reads - 1, n_check).astype(np.int64)
+    for x in pick:
+        r2 = ref.make_read(reads[int(x)])
+        exp = ref.giraf_key(ref.read_to_giraf(rnodes, r2, ref.seed_map(full, rnodes, r2, seed_len), scores))
+        g = gir[int(x)]
+        got_c = None if not g["has_cigar"] else tuple((int(a), int(b)) for a, b in zip(cig["run_length"][int(g["cigar_off"]):int(g["cigar_off"] + g["n_cigar"])], cig["op"][int(g["cigar_off"]):int(g["cigar_off"] + g["n_cigar"])]))
+        got = (int(g["q_start"]), int(g["q_end"]), bool(g["pos_strand"]), int(g["t_start"]), tuple(int(v) for v in nodes[int(g["node_off"]):int(g["node_off"] + g["n_nodes"])]), int(g["t_end"]), got_c, int(g["aln_score"]))
+        okk = okk and got == tuple(exp[:8])
+    return {"entry": "gnx_gsw_map_reads (one call per batch of reads)", "reads": n_reads, "value": n_reads / best, "unit": "reads/s (fastest of 4 calls)", "ms_per_call": best * 1e3,
+            "mapped": int((gir["aln_score"] > 0).sum()), "graph_and_index_s": t_graph, "bit_exact_sample": bool(okk), "reads_checked": int(n_check),
+            "checked_against": "tests/pyref_gsw.py (sequential restatement of toGiraf.go:17-72 with the oracle's DPs)"}
+
+
 def one_process_flow(_lib, L, world, params, reads_h, chunk_h, n_pairs, same, steps):
     """SURVEY 8e, second form: ONE host process, one context per GPU behind the C ABI (what a Go program gets).  Rank 0 runs it on
     all `world` GPUs after the other ranks have released theirs: `world` x n_pairs reads against the shared chunk (broadcast over
@@ -720,7 +763,7 @@ def main():
             d_ops = None  # the extra legs need the memory (C3: 10 M reads of results on the device; C5: 70 GB of snapshots)
             torch.cuda.empty_cache()
             failed = []
-            for name, fn in (("north_star_1M", extra_north_star), ("c3", extra_c3), ("c3_10M", extra_c3_10m), ("c5", extra_c5)):
+            for name, fn in (("north_star_1M", extra_north_star), ("c3", extra_c3), ("c3_10M", extra_c3_10m), ("c5", extra_c5), ("gsw_reads", extra_gsw)):
                 t1 = time.perf_counter()
                 try:
                     out[name] = fn(_lib, L, scores, chunk_h, dev, torch)
