@@ -877,6 +877,17 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         if (distinct == 1 && S == 0) fp = false;
         // 8 pairs per wave and row block: a small batch of long reads leaves the GPU half empty (the general path runs 4 pairs per wave and strip)
         if (distinct == 1 && S >= 3 && n_pairs * S < 8192 && !forced) fp = false;
+        // Round 4: a small batch of one-block reads is a handful of waves whose time is ONE wave's 10 000 dependent steps on either path; the
+        // general path then has its directions, the fast path still owes its walk / re-fill rounds (150 x 10 000: 1 pair 3.3 / 5.2 ms,
+        // 128 pairs 2.6 / 3.4 ms, 2 048 pairs 2.7 / 3.4 ms, 8 192 pairs 6.5 / 3.7 ms; 150 x 3 000 x 1 024: 0.9 / 1.7 ms -- what a loop of
+        // single align.AffineGap calls sees).  While the stored directions (0.75 B per cell) stay small.
+        // GNX_FP_SMALL=1: no such rule (the test suites: their small batches are there to exercise the fast path)
+        const char *fps = getenv("GNX_FP_SMALL");
+        if (fp && !xp && distinct == 1 && S == 1 && n_pairs < 3072 && !forced && !(fps && fps[0] == '1')) {
+            int64_t cells = 0;
+            for (int64_t p = 0; p < n_pairs; p++) cells += h_rows[p] * h_cols[p];
+            if (cells < ((int64_t)1 << 32)) fp = false;
+        }
         if (fp && distinct > 1 && n_pairs < 256 && !forced) fp = false;
         if (fp && distinct > 1) {
             // Mixed batch: one uniform sub-batch per number of row blocks, each on its fast path (those not for it: general path),

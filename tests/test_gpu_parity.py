@@ -835,3 +835,28 @@ def test_stress_regression_q1_at_block_top(gpu_lib, monkeypatch):
         else:
             monkeypatch.setenv("GNX_FP_MAXIT", maxit)
         common.assert_same(gpu_lib.align_batch(p, alphas, betas), exp, "stress batch, maxit %s" % maxit)
+
+
+@pytest.mark.gpu
+def test_small_batch_routing(gpu_lib, monkeypatch):
+    """Round 4: a batch of fewer than 3072 one-block reads goes to the general path (its time is one wave's chain of steps either way, and
+    the general path has its directions when the sweep ends); GNX_FP_SMALL=1 (what the suites run with) and big batches keep the fast path.
+    Same bits on both."""
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, align.HumanChimpTwoScoreMatrix, -600, -150)
+    reads, chunk = common.c2_workload(31, 96, read_len=150, chunk_len=2500)
+    n = reads.shape[0]
+    a_start, a_len = np.arange(n, dtype=np.int64) * 150, np.full(n, 150, dtype=np.int64)
+    b_start, b_len = np.zeros(n, dtype=np.int64), np.full(n, chunk.shape[0], dtype=np.int64)
+    exp = oracle.align_batch_windows(0, MX["HumanChimpTwo"], -600, -150, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len, threads=8)
+    for small, route in (("1", 1), ("0", 0)):
+        monkeypatch.setenv("GNX_FP_SMALL", small)
+        got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len)
+        if not any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM")):
+            assert gpu_lib.get_timing()["fast_path"] == route
+        common.assert_same(got, exp, "GNX_FP_SMALL=%s" % small)
+    # one pair per call (a loop of align.AffineGap calls): general path by default
+    monkeypatch.delenv("GNX_FP_SMALL")
+    got = gpu_lib.align_batch_windows(p, reads[0], a_start[:1], a_len[:1], chunk, b_start[:1], b_len[:1])
+    if not any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM")):
+        assert gpu_lib.get_timing()["fast_path"] == 0
+    common.assert_same(got, (exp[0][:1], exp[1][:int(exp[2][1])], exp[2][:2]), "one pair")
