@@ -48,6 +48,7 @@ g++ -std=c++17 -O2 -Iinclude -o tools/bench_cabi.bin tools/bench_cabi.cpp gonomi
 # round 4: concurrency at the boundary, the C5 sweep's counters with one strip / four strips per workgroup, workgroup occupancy census, stress
 g++ -std=c++17 -O2 -pthread -Iinclude -o tests/cpp/concurrent_pairs_test.bin tests/cpp/concurrent_pairs_test.cpp gonomics_amd/libgonomics_align_hip.so -Wl,-rpath,$PWD/gonomics_amd -L/opt/rocm/lib -lamdhip64 2>> $out/bench.err && tests/cpp/concurrent_pairs_test.bin 16 1000 8 > $out/concurrent_pairs.json 2>> $out/bench.err
 bash tools/pmc_env_ab.sh gpurun_out/$tag/c5_ab "--no-cpu --no-host --no-extras --series long --pairs 1024 --steps 1 --warmup 0 --verify 0" "cl_sweep" "wg4:GNX_CL_WG=1" "one_strip:GNX_CL_WG=0" > /dev/null 2>> $out/bench.err; cp gpurun_out/$tag/c5_ab/pmc_ab.txt $out/pmc_c5_wg_ab.txt
+timeout 300 python tools/pair_latency.py 300 > $out/pair_latency.jsonl 2>> $out/bench.err
 tools/wg_occupancy.bin > $out/wg_occupancy.txt 2>> $out/bench.err
 timeout 700 python tools/stress.py ${GNX_STRESS_S:-420} 77 > $out/stress.log 2>&1
 [ -n "$GNX_SWITCH_MATRIX" ] && bash tools/switch_matrix.sh > $out/switch_matrix.log 2>&1
