@@ -1801,7 +1801,8 @@ void run_pair_batch(const gnx_params *p, std::vector<PairReq *> &batch) {
         }
     }
 }
-std::condition_variable g_pq_cv;
+std::condition_variable g_pq_cv;        // "a batch is done": followers wait here
+std::condition_variable g_pq_cv_arrive; // "a request was queued": only the collecting combiner waits here (no herd of followers woken per arrival)
 bool g_pq_leader = false; // a combined batch is being collected / aligned (guarded by g_pq_mu)
 size_t g_pq_prev_batch = 0; // pairs in the batch before (guarded by g_pq_mu)
 } // namespace
@@ -1813,7 +1814,7 @@ int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const u
     self.p = p; self.a = alpha; self.n = n; self.b = beta; self.m = m;
     std::unique_lock<std::mutex> lk(g_pq_mu);
     g_pq.push_back(&self);
-    if (g_pq_leader) g_pq_cv.notify_all(); // (a combiner may be collecting: it counts arrivals)
+    if (g_pq_leader) g_pq_cv_arrive.notify_one(); // (a combiner may be collecting: it counts arrivals)
     while (!self.done) {
         if (g_pq_leader) { g_pq_cv.wait(lk); continue; } // a batch is on the device: this request rides in the next one
         // become the combiner: everything queued with this request's parameters is one batch (requests with other parameters stay
@@ -1823,10 +1824,11 @@ int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const u
             // Other threads are calling too: the callers of the batch that has just been handed out are on their way back with their next
             // pair.  Collect until nobody has arrived for ~25 us (at most 200 us): without this a pool of 16 threads settles into two groups of 8
             // that take turns (measured: 8 pairs per batch, 6.5 x the serial rate); one thread alone never waits.
+            // ... and no longer than it takes the callers of the batch before to be back: their number is the best guess of how many threads are calling
             const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
             size_t seen = g_pq.size();
-            while (std::chrono::steady_clock::now() < t_end) {
-                g_pq_cv.wait_for(lk, std::chrono::microseconds(25));
+            while (seen < g_pq_prev_batch && std::chrono::steady_clock::now() < t_end) {
+                g_pq_cv_arrive.wait_for(lk, std::chrono::microseconds(25));
                 if (g_pq.size() == seen) break;
                 seen = g_pq.size();
             }
