@@ -47,8 +47,8 @@ namespace genomeGraph {
 using Bases = std::vector<uint8_t>; // dna.Base: A C G T N = 0 .. 4
 
 inline int gswThreads(int asked) {
-    if (asked > 0) return asked;
-    if (const char *e = getenv("GNX_GSW_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+    if (asked > 0) return std::min(asked, 256);
+    if (const char *e = getenv("GNX_GSW_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 256); }
     const unsigned hw = std::thread::hardware_concurrency();
     return (int)std::max(1u, std::min(hw, 16u));
 }
