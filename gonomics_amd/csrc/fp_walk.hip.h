@@ -42,14 +42,19 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
                                                      const int2 *__restrict__ rowbuf, int spec, int wwords,
                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp) {
+    // 4 x score table for the diagonal shortcuts (an index held in a VGPR: from LDS rather than from the kernel arguments)
+    __shared__ int wsc[32];
+    if (threadIdx.x < 25) wsc[threadIdx.x] = kp.sc4[threadIdx.x];
+    __syncthreads();
     const int a = CW ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (a >= n_active) return;
     const int lane = threadIdx.x & 63;
     const bool writer = !CW || lane == 0;
     const int p = FIRST ? a + p_base : active[a];
     const PairPlan pl = plans[p];
-    BetaSrc wbeta; // (FIRST walks only: the diagonal shortcut reads bases)
-    wbeta.init(b_buf, kp, FIRST ? b_start[pl.src] : 0, FIRST ? pl.m : 0);
+    BetaSrc wbeta; // (the diagonal shortcuts read bases: FIRST walks, and window walks of reads with whole row blocks between two handed-down rows)
+    const bool wb = FIRST || (!TILED && !XP && pl.strips >= 2);
+    wbeta.init(b_buf, kp, wb ? b_start[pl.src] : 0, wb ? pl.m : 0);
     auto k_of = [](int tag) { return XP ? (tag == 3 ? 0 : tag) : 3 - tag; }; // state of a direction tag
     auto op_of = [](int k) { return XP ? (k == 0 ? 0 : 3 - k) : k; };         // CIGAR op of a step taken in state k
     constexpr unsigned IRUN = XP ? 0x55555555u : 0xAAAAAAAAu;                // 16 fields "horizontal gap extended"
@@ -111,11 +116,57 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
     auto diag_score = [&](int ii, int jj) {
         const uint8_t *ap = a_buf + a_start[pl.src];
         int64_t P = (XP || jj == ii) ? 0 : tp.gap_open + tp.gap_extend * (int64_t)(jj - ii); // (XP: row 0 is free)
-        for (int t = 0; t < ii; t++) P += (int64_t)(kp.sc4[min((int)ap[t], 4) * 5 + min(wbeta.at((jj - ii) + t), 4)] >> 2);
+        int acc = 0; // (4 x the scores: int32 holds 20 480 of them)
+#pragma unroll 8
+        for (int t = 0; t < ii; t++) acc += wsc[min((int)ap[t], 4) * 5 + min(wbeta.at((jj - ii) + t), 4)];
+        P += (int64_t)(acc >> 2);
         return P;
     };
     auto tail_ok = [&](int ii, int jj) { return ii >= 1 && jj >= 1 && pl.n - ii < FP_PLANES && pl.m - jj < 4; };
     auto tail_tag = [&](int ii, int jj) { return (tailw >> (8 * (pl.m - jj) + 2 * (pl.n - ii))) & 3u; };
+    // Round 4, reads of several row blocks: the walk stands, in state M, on the BOTTOM row i of row block bq = (n - i) / 160 >= 1.  The sweep
+    // handed that row down (to block bq - 1), so h(i, j) is in the row buffer; and the row above the block as well (handed down by block
+    // bq + 1) -- or, for the top block, the row above is row 0, whose h(0, c) is the leading gap.  h(c) >= M(c) = h(c - diagonal) + s(c) in
+    // every cell, so h(i, j) - h(i - L, j - L) >= the sum of the L substitution scores along the diagonal, with equality only if h = M in
+    // every one of its cells -- tripleMaxTrace gives such ties to M (quirk Q1 re-reads the same argmax), so the path IS that diagonal: L
+    // M steps, arriving in the state the handed-down row's argmax tag names (top block: at row 0, where the walk ends).  No window for a
+    // block without an indel.  (The keys are rebased with e (i + j): 4 V = key + 4 e (i + j).)  Returns true when the walk moved.
+    auto block_diag = [&]() -> bool {
+        if (TILED || XP || k != 0 || pl.strips < 2 || i >= pl.n || i < 1 || (pl.n - i) % H != 0) return false;
+        const int bq = (pl.n - i) / H;
+        if (bq > pl.strips - 1) return false;
+        const int hA = rowbuf[pl.rowbuf_off + (int64_t)(pl.strips - 1 - bq) * (pl.m + 1) + j].y; // row i: handed down by block bq
+        if ((hA & 3) != 3) return false;
+        const uint8_t *ap = a_buf + a_start[pl.src];
+        const bool top = bq == pl.strips - 1;
+        const int L = top ? i : H;
+        if (top ? j < L : j <= L) return false;
+        int far4; // 4 h(i - L, j - L) (32 bits hold every key: the DP range check of the entry points)
+        int hB = 0;
+        if (top) far4 = (j == L) ? 0 : kp.o4 + (j - L) * kp.e4;
+        else {
+            hB = rowbuf[pl.rowbuf_off + (int64_t)(pl.strips - 2 - bq) * (pl.m + 1) + (j - L)].y; // row i - 160: handed down by block bq + 1
+            if ((hB & 3) == 0) return false;
+            far4 = (hB & ~3) + kp.e4 * (i - L + j - L);
+        }
+        int sum = 0;
+        if (CW) { // every lane runs the same walk: lane l sums the cells l, l + 64, ..., then the wave adds up
+            for (int t = lane; t < L; t += 64) sum += wsc[min((int)ap[i - 1 - t], 4) * 5 + min(wbeta.at(j - 1 - t), 4)];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        } else {
+#pragma unroll 2
+            for (int t = 0; t < L; t++) sum += wsc[min((int)ap[i - 1 - t], 4) * 5 + min(wbeta.at(j - 1 - t), 4)];
+        }
+        if ((hA & ~3) + kp.e4 * (i + j) - far4 != sum) return false;
+        emit(op_of(0), L); last_op = 0;
+        i -= L; j -= L;
+        li -= L;
+        if (li < 0) { li %= tp.ci; if (li < 0) li += tp.ci; }
+        if (!top) k = k_of(hB & 3);
+        last_win = false;
+        return true;
+    };
     while (true) {
         if (i == 0 || j == 0) { done = true; break; }
         unsigned w;
@@ -142,6 +193,7 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             }
             break;
         }
+        if (!FIRST && !in_win && !on_plane && block_diag()) continue; // (a whole row block, or the rest of the read, without a window)
         if (on_plane || in_win || (k == 0 && tail_ok(i - 1, j - 1))) last_win = in_win; // was the last step taken inside the window? (then the walk leaves it by walking through it)
         if (CW && in_win && k == 0 && !no_look) {
             // a diagonal run inside the window, 64 cells per look: lane t looks at the cell (i - t, j - t); the run goes on while the cells
@@ -282,6 +334,29 @@ __global__ __launch_bounds__(64) void fp_walk_kernel(const PairPlan *__restrict_
             if (li < 0) { li %= tp.ci; if (li < 0) li += tp.ci; }
             j -= i; i = 0;
             done = true;
+        }
+    }
+    if (FIRST && !XP && !done && k == 0 && pl.strips >= 2 && i > pl.n - H && i <= pl.n) {
+        // ... and the first walk of a read of several row blocks: `val` is M(i, j) exactly and the row above the bottom block was handed
+        // down: the same test takes the walk to the top of the bottom block, and block_diag on from there
+        const int L = i - (pl.n - H);
+        if (j > L) {
+            const int hB = rowbuf[pl.rowbuf_off + (int64_t)(pl.strips - 2) * (pl.m + 1) + (j - L)].y;
+            if ((hB & 3) != 0) {
+                const uint8_t *ap = a_buf + a_start[pl.src];
+                int sum = 0;
+#pragma unroll 8
+                for (int t = 0; t < L; t++) sum += wsc[min((int)ap[i - 1 - t], 4) * 5 + min(wbeta.at(j - 1 - t), 4)];
+                if (4 * val - ((int64_t)(hB & ~3) + (int64_t)kp.e4 * (i - L + j - L)) == (int64_t)sum) {
+                    emit(op_of(0), L); last_op = 0;
+                    i -= L; j -= L;
+                    li -= L;
+                    if (li < 0) { li %= tp.ci; if (li < 0) li += tp.ci; }
+                    k = k_of(hB & 3);
+                    while (i > 0 && j > 0 && block_diag()) {}
+                    if (i == 0 || j == 0) done = true;
+                }
+            }
         }
     }
     if (done) {

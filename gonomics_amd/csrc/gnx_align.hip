@@ -419,7 +419,9 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
         auto k_first = cw_first ? (xp ? fp_walk_kernel<true, false, true, true> : fp_walk_kernel<true, false, false, true>) : (xp ? fp_walk_kernel<true, false, true> : fp_walk_kernel<true, false, false>);
         // reads of several row blocks: the window walk with one wave per pair as well -- a long read's walk is thousands of dependent
         // loads for a lane on its own, and its diagonal runs are taken 64 cells per look (GNX_WALK_LANE=1: lanes)
-        const bool cw_next = cw && wide_walk;
+        // (round 4: whatever the batch size -- with the block shortcut a window walk is mostly sums along diagonals, which a wave takes 64
+        // cells at a time from coalesced loads; the speculative windows stay with the batches of <= 32 768 reads.  GNX_WALK_WIDE=0: as before)
+        const bool cw_next = cw && (wide_walk || (S > 1 && !(getenv("GNX_WALK_WIDE") && atoi(getenv("GNX_WALK_WIDE")) == 0)));
         auto k_next = cw_next ? (xp ? fp_walk_kernel<false, false, true, true> : fp_walk_kernel<false, false, false, true>) : (xp ? fp_walk_kernel<false, false, true> : fp_walk_kernel<false, false, false>);
         auto k_tiled = cw ? (xp ? fp_walk_kernel<false, true, true, true> : fp_walk_kernel<false, true, false, true>) : (xp ? fp_walk_kernel<false, true, true> : fp_walk_kernel<false, true, false>);
         auto wgrid = [&](int n) { return dim3((unsigned)(cw ? n : (n + 63) / 64)); };

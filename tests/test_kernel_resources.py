@@ -55,6 +55,9 @@ BUDGET = [
     ("fill_const_kernel<false, 0", 3), ("fill_const_kernel<false, 1", 3), ("fill_const_kernel<false, 2", 3), ("fill_const_kernel<true", 2),
     ("cl_sweep_kernel<true>", 5), ("cl_sweep_wg_kernel<4>", 5), ("cl_sweep_flat_kernel<true>", 4), ("cl_sweep_flat_kernel<false>", 3), ("cl_sweep_kernel<false>", 3), ("al_sweep_kernel", 3),
     ("fp_walk_kernel", 5), ("traceback_kernel", 4), ("gsw_traceback_kernel", 8),
+    # the window walk with one LANE per pair (batches of more than 32 768 reads of several row blocks): 98 registers since it carries the block
+    # shortcut of round 4 (score table in LDS, two row-buffer keys, the diagonal's sum) -- a launch of <= 2 waves per SIMD, whatever its registers allow
+    ("fp_walk_kernel<false, false, false, false>", 4),
 ]
 # kernels that are allowed scratch (register-bound by design: their tiles live in LDS at one workgroup of 4 pairs per half CU)
 SCRATCH_OK = ("al_walk_kernel",)
@@ -73,10 +76,10 @@ def test_every_wavefront_kernel_is_in_the_library(kernels):
 
 def test_register_budgets(kernels):
     bad = []
-    for prefix, waves in BUDGET:
-        for name, k in kernels.items():
-            if name.startswith(prefix) and _waves_per_simd(k) < waves:
-                bad.append((name, k["vgpr_count"], k["agpr_count"], _waves_per_simd(k), waves))
+    for name, k in kernels.items():
+        match = [(len(prefix), waves) for prefix, waves in BUDGET if name.startswith(prefix)]
+        if match and _waves_per_simd(k) < max(match)[1]:  # (the longest prefix decides)
+            bad.append((name, k["vgpr_count"], k["agpr_count"], _waves_per_simd(k), max(match)[1]))
     assert not bad, bad
 
 
