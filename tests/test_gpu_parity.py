@@ -860,3 +860,50 @@ def test_small_batch_routing(gpu_lib, monkeypatch):
     if not any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM")):
         assert gpu_lib.get_timing()["fast_path"] == 0
     common.assert_same(got, (exp[0][:1], exp[1][:int(exp[2][1])], exp[2][:2]), "one pair")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [330, 1000, 1120])
+def test_row_block_shortcut(gpu_lib, n, monkeypatch):
+    """Round 4 (fp_walk.hip.h: block_diag): reads of several row blocks whose alignment crosses whole blocks on a plain diagonal -- no indel,
+    one indel in the bottom / a middle / the top block, two indels, an indel right on a block boundary, N bases, a read that starts at
+    column 0 of its window -- take those blocks without a window.  Against the oracle with the default and with small / odd checkerboards
+    (quirk Q1 at and inside the skipped blocks), other penalties, lanes instead of waves, forced tile rounds."""
+    monkeypatch.setenv("GNX_FASTPATH", "2")
+    rng = np.random.default_rng(1000 + n)
+    L = n + 400
+    ref = rng.integers(0, 4, size=L, dtype=np.uint8)
+    S = (n + 159) // 160
+    top_rows = n - 160 * (S - 1)
+    alphas, betas = [], []
+    cuts = [None, 5, 80, 159, 160, 161, 160 + 77, n - top_rows - 1, n - top_rows, n - top_rows + 1, n - 3, (40, n - 200), (200, 360)]
+    for k in range(104):
+        off = 0 if k % 13 == 12 else int(rng.integers(1, 300))
+        src = ref[off:off + n + 40].copy()
+        cut = cuts[k % len(cuts)]
+        rows = []  # positions counted from the read's END (row n - x), so that the indel lands in the block the case names
+        for x in ([] if cut is None else (cut if isinstance(cut, tuple) else (cut,))):
+            rows.append(max(2, min(n - 2, n - int(x))))
+        alpha = src[:n + 20].copy()
+        for r in sorted(rows, reverse=True):
+            ln = int(rng.integers(1, 5))
+            if k % 2:
+                alpha = np.concatenate([alpha[:r], alpha[r + ln:]])          # deletion from the read
+            else:
+                alpha = np.concatenate([alpha[:r], rng.integers(0, 4, size=ln, dtype=np.uint8), alpha[r:]])
+        alpha = alpha[:n].copy()
+        sub = rng.random(n) < (0.0 if k % 5 == 0 else 0.01)
+        alpha[sub] = rng.integers(0, 4, size=int(sub.sum()))
+        if k % 17 == 3:
+            alpha[int(rng.integers(0, n))] = 4
+        alphas.append(alpha); betas.append(ref.copy())
+    for name, go, ge, ci, cj in [("HumanChimpTwo", -600, -150, 10000, 10000), ("HumanChimpTwo", -600, -150, 7, 7), ("HumanChimpTwo", -600, -150, 160, 161),
+                                 ("HumanChimpTwo", -600, -150, 53, 1000), ("Default", -400, -30, 10000, 10000), ("HumanChimpTwo", 0, -150, 31, 37)]:
+        exp = oracle.align_batch(0, MX[name], go, ge, alphas, betas, ci=ci, cj=cj, threads=8)
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP, MX[name], go, ge, ci, cj)
+        common.assert_same(gpu_lib.align_batch(p, alphas, betas), exp, "%d rows %s %d %d checker %d x %d" % (n, name, go, ge, ci, cj))
+        if ci == 7:
+            for sw, val in (("GNX_WALK_LANE", "1"), ("GNX_FP_MAXIT", "0"), ("GNX_FP_SPEC", "1"), ("GNX_NO_PIPE", "1")):
+                monkeypatch.setenv(sw, val)
+                common.assert_same(gpu_lib.align_batch(p, alphas, betas), exp, "%d rows, %s=%s" % (n, sw, val))
+                monkeypatch.delenv(sw)
