@@ -1,6 +1,3 @@
 #!/bin/bash
 out=gpurun_out/r4v; mkdir -p $out
-timeout 900 python bench.py > $out/bench.json 2> $out/bench.err
-python -c "
-import json; d=json.loads(open('$out/bench.json').read().strip().splitlines()[-1]); r=d['roofline']; print('value',d['value'],'frac',r['frac'],'traffic',r.get('traffic'),r.get('traffic_note'))"
-bash tools/gpu_r4_u.sh
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "row_block_shortcut or small_batch_routing" > $out/newtests.log 2>&1; grep -E "passed|failed|^E " $out/newtests.log | head -8
