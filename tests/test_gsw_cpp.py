@@ -144,3 +144,12 @@ def test_cpp_wrap_pair_giraf_equals_python_mirror(gpu_lib, tmp_path):
         for r, row in ((fw, rows[2 * k]), (rv, rows[2 * k + 1])):
             key = r.key()
             assert row == key[:8] + (len(key[8]), r.Flag), "pair %d" % k
+
+
+def test_worker_pool_on_the_cpu(tmp_path):
+    """GswPool / parallelFor of the C++ mirror (host code only, no device): every index once in both partitions, the lowest failing index's
+    exception, concurrent callers, the worker cap, Go's append capacities"""
+    exe = str(tmp_path / "pool_test.bin")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "cpp", "pool_test.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "pool ok" in r.stdout, r.stdout + r.stderr
