@@ -839,20 +839,53 @@ def GswBatchToGiraf(gg, reads, index, seedLen, scoreMatrix, device_seeds=True, o
 
 
 def _edge_list(gg):
-    """(u, v) pairs in an order of AddEdge calls that rebuilds every node's Next AND Prev list as they are (traversals try a node's
-    edges in list order, so the order is part of the graph)"""
+    """(u, v) pairs in AN order of AddEdge calls that rebuilds every node's Next AND Prev list as they are (traversals try a node's edges
+    in list order, so the order is part of the graph): a topological order of the edges under "before its successor in u's Next list" and
+    "before its successor in v's Prev list".  Lists that no sequence of AddEdge calls produces are refused."""
     ids = {id(n): k for k, n in enumerate(gg.Nodes)}
-    by_next = [(ids[id(u)], ids[id(e.Dest)]) for u in gg.Nodes for e in u.Next]
-    by_prev = [(ids[id(e.Dest)], ids[id(v)]) for v in gg.Nodes for e in v.Prev]
-    for edges in (by_next, by_prev):
-        nxt = [[] for _ in gg.Nodes]
-        prv = [[] for _ in gg.Nodes]
-        for u, v in edges:
-            nxt[u].append(v)
-            prv[v].append(u)
-        if all(nxt[k] == [ids[id(e.Dest)] for e in n.Next] and prv[k] == [ids[id(e.Dest)] for e in n.Prev] for k, n in enumerate(gg.Nodes)):
-            return edges
-    raise ValueError("the graph's edge lists do not come from one sequence of AddEdge calls in node order: pass edges= explicitly")
+    edges = []            # (u, v, occurrence) in Next-list order of the nodes
+    slot = {}
+    for u in gg.Nodes:
+        seen = {}
+        for e in u.Next:
+            key = (ids[id(u)], ids[id(e.Dest)])
+            seen[key] = seen.get(key, 0) + 1
+            slot[key + (seen[key],)] = len(edges)
+            edges.append(key + (seen[key],))
+    succ = [[] for _ in edges]
+    indeg = [0] * len(edges)
+    for x in range(1, len(edges)):  # Next-list order inside one node
+        if edges[x][0] == edges[x - 1][0]:
+            succ[x - 1].append(x); indeg[x] += 1
+    n_prev = 0
+    for v in gg.Nodes:
+        seen, last = {}, None
+        for e in v.Prev:
+            key = (ids[id(e.Dest)], ids[id(v)])
+            seen[key] = seen.get(key, 0) + 1
+            x = slot.get(key + (seen[key],))
+            if x is None:
+                raise ValueError("a Prev edge %d -> %d has no Next edge" % key)
+            if last is not None:
+                succ[last].append(x); indeg[x] += 1
+            last = x
+            n_prev += 1
+    if n_prev != len(edges):
+        raise ValueError("the graph's Next and Prev lists hold different edges")
+    import heapq
+    ready = [x for x in range(len(edges)) if indeg[x] == 0]
+    heapq.heapify(ready)
+    out = []
+    while ready:
+        x = heapq.heappop(ready)  # (the smallest ready edge: graphs built node by node come back in their original order)
+        out.append(edges[x][:2])
+        for y in succ[x]:
+            indeg[y] -= 1
+            if indeg[y] == 0:
+                heapq.heappush(ready, y)
+    if len(out) != len(edges):
+        raise ValueError("the graph's Next and Prev lists do not come from one sequence of AddEdge calls: pass edges= explicitly")
+    return out
 
 
 class NativeGraph:

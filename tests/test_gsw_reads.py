@@ -246,3 +246,32 @@ def test_native_graph_bad_arguments():
         _lib.GswGraph([np.zeros(40, np.uint8)], [(0, 3)], 16, 1)
     with pytest.raises(_lib.GnxError):
         _lib.GswGraph([np.full(40, 7, np.uint8)], [], 16, 1)
+
+
+def test_edge_list_of_a_graph():
+    """NativeGraph hands the edges over in an order of AddEdge calls that rebuilds every node's Next AND Prev list (traversals try a node's
+    edges in list order); a graph whose lists fit neither order is refused, not reordered."""
+    seqs, edges, _ = make_case(3, "wide3")
+    g = build(seqs, edges)
+    assert gg._edge_list(g) == [tuple(e) for e in edges]
+    # edges added in an order that is neither "by source" nor "by target": still one sequence of AddEdge calls
+    g2 = gg.GenomeGraph()
+    for k in range(4):
+        gg.AddNode(g2, gg.Node(k, np.zeros(40, np.uint8)))
+    for u, v in ((1, 3), (0, 3), (1, 2), (0, 2)):
+        gg.AddEdge(g2.Nodes[u], g2.Nodes[v])
+    got = gg._edge_list(g2)
+    nxt, prv = {k: [] for k in range(4)}, {k: [] for k in range(4)}
+    for u, v in got:
+        nxt[u].append(v); prv[v].append(u)
+    assert nxt[0] == [3, 2] and nxt[1] == [3, 2] and prv[3] == [1, 0] and prv[2] == [1, 0]
+    # lists that no sequence of AddEdge calls produces: 0 -> 3 before 0 -> 2 (Next of 0), 0 -> 2 ... 1 -> 2 ... and a cycle through the Prev lists
+    g3 = gg.GenomeGraph()
+    for k in range(4):
+        gg.AddNode(g3, gg.Node(k, np.zeros(40, np.uint8)))
+    for u, v in ((0, 2), (1, 2), (1, 3), (0, 3)):
+        gg.AddEdge(g3.Nodes[u], g3.Nodes[v])
+    assert gg._edge_list(g3) == [(0, 2), (1, 2), (1, 3), (0, 3)]
+    g3.Nodes[0].Next.reverse()   # now 0 -> 3 before 0 -> 2, but 0 -> 2 before 1 -> 2 before 1 -> 3 before 0 -> 3: a cycle
+    with pytest.raises(ValueError):
+        gg._edge_list(g3)
