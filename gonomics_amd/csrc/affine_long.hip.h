@@ -24,12 +24,14 @@ constexpr int AL_WORDS = CKA / 16 + 1;            // direction words per plane r
 constexpr int AL_SNAPW = 24;                      // dwords per lane per snapshot
 constexpr int AL_DIRG = AL_WORDS * 3 * R * G + 16; // LDS dwords of one pair's tile
 
-template <bool P16>
+// REBASE (const_long.hip.h): the strip's keys relative to a base it moves along every CKA steps; pl.rowi_off / pl.s_pitch = its slice of `bases`
+template <bool P16, bool REBASE = false>
 __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                       const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                                      KParams kp, int2 *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
-                                                      int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
+                                                      KParams kp, int2 *__restrict__ rowbuf, int *__restrict__ snap, int64_t *__restrict__ hfin,
+                                                      int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog,
+                                                      long long *__restrict__ bases) {
     using PC = ProfCfg<P16>;
     constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
     constexpr int TI = 2, TD = 1;
@@ -101,14 +103,22 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
         int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
         int dn_out = 0, h_out = 0, b_out = 0, sq_dn = 0, sq_h = 0;
         int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
+        // REBASE: my base; the bases of the strip above for the two CKA-step blocks the columns being loaded were written in, as differences
+        // to mine (dlo: block qp, dhi: block qp + 1 = columns c with c + 14 >= edge); row 0's I key relative to my base
+        long long Bown = 0;
+        int dlo = 0, dhi = 0, qp = 0, edge = CKA, r0i = kp.o4 + TI;
+        bool dhi_ok = false;
+        long long *my_bases = REBASE ? bases + pl.rowi_off + (int64_t)s * pl.s_pitch : nullptr;
+        auto bprod = [&](int q) -> long long { return (q == 0 || s == 0) ? 0LL : rbase_load(my_bases - pl.s_pitch + q, piped); };
         auto boundary = [&](int c, int &odn, int &oh, int &ob) {
             if (s == 0) {
-                const int M3 = NEG4 + 3, I2 = kp.o4 + c * E4 + TI - RB * c, D1 = NEG4 + TD; // row 0: I(0,c) = gapOpen + c*gapExtend
+                const int M3 = NEG4 + 3, I2 = REBASE ? r0i : kp.o4 + c * E4 + TI - RB * c, D1 = NEG4 + TD; // row 0: I(0,c) = gapOpen + c*gapExtend
                 oh = max3i(M3, I2, D1);
                 odn = max3i(M3 + OE4, I2 + OE4, D1 + E4) - RB;
             } else if (c >= 1 && c <= m_eff) {
                 const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
                 odn = v.x; oh = v.y;
+                if (REBASE) { const int dd = (c + 14 >= edge) ? dhi : dlo; odn += dd; oh += dd; }
             } else { odn = 0; oh = 0; }
             ob = (c >= 1 && c <= m_eff) ? bp.raw(c - 1) : 0; // RAW base: base_off() turns it into the LDS offset where the queue is needed (no wait on the load here)
         };
@@ -191,6 +201,17 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
+            if (REBASE && t0 > 0 && t0 % CKA == 0) { // move the base: everything this strip holds, relative to h of its first row's current cell
+                const int rep = __shfl(hold[0], lane & 48, 64);
+                const bool rb_on = gact && t0 <= m_eff + 15; // (a pair whose last lane has passed column m is done, and has no base slots beyond)
+                const int d = rb_on ? (rep & ~3) : 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) { rt[r] -= d; hold[r] -= d; }
+                diag0 -= d; dn_out -= d; h_out -= d; qdn -= d; qh -= d;
+                Bown += d; dlo -= d; dhi -= d;
+                r0i = rbase_const((long long)kp.o4 + TI, Bown);
+                if (rb_on && l == 0) rbase_store(my_bases + t0 / CKA, Bown, piped);
+            }
             if (t0 > 0 && t0 % CKA == 0 && gact && t0 <= m_eff + 15) { // snapshot: the state the wave resumes from at step t0
                 uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / CKA - 1) * pl.strips + s) * G + l) * AL_SNAPW);
                 dst[0] = make_uint4((unsigned)rt[0], (unsigned)rt[1], (unsigned)rt[2], (unsigned)rt[3]);
@@ -201,6 +222,10 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
                 dst[5] = make_uint4((unsigned)diag0, (unsigned)dn_out, 0u, 0u);
             }
             wait_rows(t0 + 2 * G);
+            if (REBASE && s > 0 && gact) { // the columns loaded now are t0 + 17 .. t0 + 32: written by the strip above in its blocks (c + 14) / CKA
+                while (t0 + 31 >= edge) { qp++; edge += CKA; dlo = dhi_ok ? dhi : rbase_delta(bprod(qp), Bown); dhi_ok = false; }
+                if (!dhi_ok && t0 + 46 >= edge) { dhi = rbase_delta(bprod(qp + 1), Bown); dhi_ok = true; }
+            }
             boundary(t0 + 16 + l + 1, ndn, nh, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
 #pragma unroll
@@ -221,7 +246,7 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (hold[r] + RB * (pl.n + m_eff)) >> 2; // plain score h(n, m)
+            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (Bown + (int64_t)hold[r] + (int64_t)RB * ((int64_t)pl.n + m_eff)) >> 2; // plain score h(n, m)
         }
         if (piped) rb_publish(&strip_prog[bid], 0x7fffffff, lane);
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -229,13 +254,14 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
     if (bad) atomicOr(err, 1);
 }
 
-template <bool P16>
+template <bool P16, bool REBASE = false>
 __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                      KParams kp, TbParams tp, const int2 *__restrict__ rowbuf, const int *__restrict__ snap,
-                                                     const int *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
-                                                     const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err) {
+                                                     const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                     const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
+                                                     const long long *__restrict__ bases) {
     using PC = ProfCfg<P16>;
     constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
     constexpr int TI = 2, TD = 1;
@@ -341,14 +367,19 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
             if (jb >= 1 && jb <= m_eff) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
         }
         int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
+        // REBASE: the snapshot's keys are relative to the strip's base of block c; the row above, block by block, to the bases of the strip above
+        long long Bt = 0;
+        if (REBASE && gact && c > 0) Bt = bases[pl.rowi_off + (int64_t)s * pl.s_pitch + c];
+        const int r0i = REBASE ? rbase_const((long long)kp.o4 + TI, Bt) : 0;
         auto boundary = [&](int cc, int &odn, int &oh, int &ob) {
             if (s == 0) {
-                const int M3 = NEG4 + 3, I2 = kp.o4 + cc * E4 + TI - RB * cc, D1 = NEG4 + TD;
+                const int M3 = NEG4 + 3, I2 = REBASE ? r0i : kp.o4 + cc * E4 + TI - RB * cc, D1 = NEG4 + TD;
                 oh = max3i(M3, I2, D1);
                 odn = max3i(M3 + OE4, I2 + OE4, D1 + E4) - RB;
             } else if (cc >= 1 && cc <= m_eff) {
                 const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
                 odn = v.x; oh = v.y;
+                if (REBASE) { const int q = (cc + 14) / CKA; const int dd = rbase_delta(q > 0 ? bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + q] : 0LL, Bt); odn += dd; oh += dd; }
             } else { odn = 0; oh = 0; }
             ob = (cc >= 1 && cc <= m_eff) ? bp.raw(cc - 1) : 0; // RAW base, see al_sweep_kernel
         };
@@ -494,7 +525,7 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
         else if (up_exit && !left_exit) emit(1, wj);
         flush_run();
         nops[po] = cnt;
-        score_out[po] = (int64_t)hfin[pl.hcol_off];
+        score_out[po] = hfin[pl.hcol_off];
     }
     if (bad) atomicOr(err, 1);
 }

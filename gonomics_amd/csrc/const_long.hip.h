@@ -43,6 +43,42 @@ __device__ __forceinline__ int rb_load32(const int *p, bool piped) {
     return *p;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// REBASE: alignments of ANY length on int32 keys (round 5; align/align.go:8 -- the reference is int64 end to end, and its low-memory
+// checkerboard, affineGap.go:59-68 / constGap.go:13-68, exists for sequences far beyond the int32 range of 4*score).
+// The statically rebased values V' = V - g*(i+j) still grow along the diagonal, by up to (s_max - 2g) per step: min(n, m) bases long
+// they leave int32.  But every max of the recurrence compares candidates of ONE cell, and the cells a wave holds at any moment -- 160
+// rows x 16 columns of an anti-diagonal band -- differ by a bounded amount (neighbouring cells of a global alignment by at most one
+// substitution score + two gaps).  So a strip keeps its keys relative to a BASE of its own that it moves along: every K steps (K = the
+// snapshot spacing, the rebase comes right before the snapshot) it subtracts d = the key of its first row's current cell (a multiple
+// of 4: tags stay) from everything it holds and adds d to its base, an int64 it also leaves in memory: bases[strip][t0 / K].
+//   * the bottom row a strip hands down carries, per 16-column block, the base that was in force when the block was written (block of
+//     column c: (c + 14) / K); the strip below converts what it loads with the difference of the two bases -- an int32, the rows are neighbours;
+//   * a snapshot is relative to bases[strip][its index]; the walk's re-fill converts the boundary row the same way and never rebases
+//     inside its <= K steps; directions depend on differences inside a cell only, so the tile's bits are the plain recurrence's;
+//   * the score leaves as base + key, in int64.
+// The REBASE instantiations are chosen by the host for pairs beyond the static range (and by GNX_REBASE=1, for the tests: then every
+// pair of the snapshot path with more than K columns rebases); everybody else runs the code without it, instruction for instruction.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rbase_store(long long *p, long long v, bool piped) {
+    if (piped) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ long long rbase_load(const long long *p, bool piped) {
+    if (piped) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+// a key that is a constant of the recurrence (row 0) relative to a base: far below everything the strip holds once the base has moved
+// -- kept above the sentinel so that it can neither wrap nor win
+__device__ __forceinline__ int rbase_const(long long key, long long base) {
+    const long long v = key - base;
+    return (int)(v < (long long)(NEG4 + 8) ? (long long)(NEG4 + 8) + (key & 3) : v);
+}
+__device__ __forceinline__ int rbase_delta(long long theirs, long long mine) {
+    const long long v = theirs - mine;
+    return (int)(v > (1LL << 30) ? (1LL << 30) : (v < -(1LL << 30) ? -(1LL << 30) : v));
+}
+
 // PairPlan fields used here: n, m, strips, rowbuf_off (ints), ckpt_off (ints: snapshots [c-1][strip][lane][SNAPW]), hcol_off (slot of
 // the final value), src (output slot).
 // PIPED = the strips of a pair run as separate, pipelined workgroups (strip_map); else one wave walks the strips of its 4 pairs in turn.
@@ -59,12 +95,14 @@ __device__ __forceinline__ int rb_load32(const int *p, bool piped) {
 #ifndef GNX_CL_PRIO
 #define GNX_CL_PRIO 1
 #endif
-template <bool P16, bool PIPED>
+template <bool P16, bool PIPED, bool REBASE = false>
 __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairPlan *__restrict__ plans, int n_pairs,
                                               const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                               const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                              const KParams &kp, int *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
-                                              int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
+                                              const KParams &kp, int *__restrict__ rowbuf, int *__restrict__ snap, int64_t *__restrict__ hfin,
+                                              int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog,
+                                              long long *__restrict__ bases = nullptr) {
+    // REBASE: pl.rowi_off = the pair's slice of `bases` (int64 per strip and K-step block), pl.s_pitch = blocks per strip
     using PC = ProfCfg<P16>;
     constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
     const int lane = threadIdx.x;
@@ -129,9 +167,19 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
         int diag0 = 2;
         int v_out = 0, b_out = 0, sq_v = 0;
         int qv, qb, nv = 0, nb = 0;
+        // REBASE: this strip's base; the strip above's bases of the two K-step blocks the columns being loaded were written in, as
+        // differences to mine (dlo: block qp, dhi: block qp + 1 = columns c with c + 14 >= edge); row 0's key relative to my base
+        long long Bown = 0;
+        int dlo = 0, dhi = 0, qp = 0, edge = kp.ckc, r0v = 2;
+        bool dhi_ok = false;
+        long long *my_bases = REBASE ? bases + pl.rowi_off + (int64_t)s * pl.s_pitch : nullptr;
+        auto bprod = [&](int q) -> long long { return (q == 0 || s == 0) ? 0LL : rbase_load(my_bases - pl.s_pitch + q, piped); };
         auto boundary = [&](int c, int &ov, int &ob) {
-            if (s == 0) ov = 2; // row 0, rebased
-            else if (c >= 1 && c <= m_eff) ov = rb_load32(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
+            if (s == 0) ov = REBASE ? r0v : 2; // row 0, rebased
+            else if (c >= 1 && c <= m_eff) {
+                ov = rb_load32(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], piped);
+                if (REBASE) ov += (c + 14 >= edge) ? dhi : dlo;
+            }
             else ov = 0;
             int b = 0;
             if (c >= 1 && c <= m_eff) b = bp.raw(c - 1);
@@ -210,6 +258,17 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
+            if (REBASE && t0 > 0 && t0 % kp.ckc == 0) { // move the base (see REBASE above): everything this strip holds, relative to the key of its first row's current cell
+                const int rep = __shfl(val[0], lane & 48, 64);
+                const bool rb_on = gact && t0 <= m_eff + 15; // (a wave runs on for its longest pair: a pair whose last lane has passed column m is done, and has no base slots beyond)
+                const int d = rb_on ? (rep & ~3) : 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) val[r] -= d;
+                diag0 -= d; v_out -= d; qv -= d;
+                Bown += d; dlo -= d; dhi -= d;
+                r0v = rbase_const(2, Bown);
+                if (rb_on && l == 0) rbase_store(my_bases + t0 / kp.ckc, Bown, piped);
+            }
             if (t0 > 0 && t0 % kp.ckc == 0 && gact && t0 <= m_eff + 15) { // snapshot: the state the wave resumes from at step t0
                 uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / kp.ckc - 1) * pl.strips + s) * G + l) * SNAPW);
                 dst[0] = make_uint4((unsigned)val[0], (unsigned)val[1], (unsigned)val[2], (unsigned)val[3]);
@@ -229,6 +288,10 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
             }
 #endif
             wait_rows(t0 + 2 * G);
+            if (REBASE && s > 0 && gact) { // the columns loaded now are t0 + 17 .. t0 + 32: written by the strip above in its blocks (c + 14) / K
+                while (t0 + 31 >= edge) { qp++; edge += kp.ckc; dlo = dhi_ok ? dhi : rbase_delta(bprod(qp), Bown); dhi_ok = false; }
+                if (!dhi_ok && t0 + 46 >= edge) { dhi = rbase_delta(bprod(qp + 1), Bown); dhi_ok = true; }
+            }
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= 16 && t0 + 16 <= m_min) {
 #pragma unroll
@@ -248,7 +311,7 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
         }
         if (gact && m_eff >= 1) {
 #pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (val[r] >> 2) + (kp.g4 >> 2) * (pl.n + m_eff); // plain V(n, m)
+            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (Bown >> 2) + (int64_t)(val[r] >> 2) + (int64_t)(kp.g4 >> 2) * ((int64_t)pl.n + m_eff); // plain V(n, m)
         }
         if (piped) rb_publish(&strip_prog[bid], 0x7fffffff, lane);
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -257,22 +320,23 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
 }
 // the piped form wants as many waves per SIMD as fit (it waits); the un-piped form, compute-bound, runs best with the registers of four
 // waves per SIMD for its look-ahead (103 registers: 9.0 ms for 320 x 10 000 x 32 768; squeezed into the 96 of five waves: 9.8 ms)
-template <bool P16>
+template <bool P16, bool REBASE = false>
 __global__ __launch_bounds__(64) void cl_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                       const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                                      KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
-                                                      int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog) {
+                                                      KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap, int64_t *__restrict__ hfin,
+                                                      int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog,
+                                                      long long *__restrict__ bases) {
     __shared__ int lds[32 + ProfCfg<P16>::TOTAL];
-    cl_sweep_body<P16, true>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, strip_map, strip_prog);
+    cl_sweep_body<P16, true, REBASE>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, strip_map, strip_prog, bases);
 }
-template <bool P16>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P16 ? 4 : 3, P16 ? 4 : 3))) void cl_sweep_flat_kernel( // (the int32 profile form needs 3 waves' worth of registers; GNX_CL_P16=0 only)
+template <bool P16, bool REBASE = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((P16 && !REBASE) ? 4 : 3, (P16 && !REBASE) ? 4 : 3))) void cl_sweep_flat_kernel( // (the int32 profile form needs 3 waves' worth of registers; GNX_CL_P16=0 only)
     const PairPlan *__restrict__ plans, int n_pairs, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
     const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap,
-    int *__restrict__ hfin, int *__restrict__ err) {
+    int64_t *__restrict__ hfin, int *__restrict__ err, long long *__restrict__ bases) {
     __shared__ int lds[32 + ProfCfg<P16>::TOTAL];
-    cl_sweep_body<P16, false>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, nullptr, nullptr);
+    cl_sweep_body<P16, false, REBASE>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, nullptr, nullptr, bases);
 }
 
 // One wave per NP pairs (NP = 4, 2 or 1: lanes 16 * NP .. 63 idle).  The walk of a pair is one long chain of dependent steps (re-fill a
@@ -282,13 +346,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P16 ? 4 : 3,
 // instead of two, and nobody waits for a neighbour.  Per round every pair (16 lanes) re-fills the tile its walk is in -- strip s = (i-1)/160, steps
 // (c*CKC, j + lane(i)] of that strip's wavefront -- into LDS, then lane 0 of the pair walks inside the tile until it leaves it.
 // Runs are staged in traceback order at scr[scr_off[p] ..] (n + m + 2 entries per pair); reverse_runs_kernel puts them in place.
-template <bool P16, int NP, int CK>
+template <bool P16, int NP, int CK, bool REBASE = false>
 __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                      const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                      const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                      KParams kp, TbParams tp, const int *__restrict__ rowbuf, const int *__restrict__ snap,
-                                                     const int *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
-                                                     const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err) {
+                                                     const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                     const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
+                                                     const long long *__restrict__ bases) {
     using PC = ProfCfg<P16>;
     static_assert(NP == 1 || NP == 2 || NP == 4, "pairs per workgroup");
     // profile of NP pairs: the layout of ProfCfg (one or two duos), or, for a single pair, planes of its own 16 * LW dwords (a plane
@@ -384,9 +449,16 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
             if (jb >= 1 && jb <= m_eff) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
         }
         int qv, qb, nv = 0, nb = 0;
+        // REBASE: the snapshot's keys are relative to the strip's base of block c; the row above, block by block, to the bases of the strip above
+        long long Bt = 0;
+        if (REBASE && gact && c > 0) Bt = bases[pl.rowi_off + (int64_t)s * pl.s_pitch + c];
+        const int r0v = REBASE ? rbase_const(2, Bt) : 2;
         auto boundary = [&](int cc, int &ov, int &ob) {
-            if (s == 0) ov = 2;
-            else if (cc >= 1 && cc <= m_eff) ov = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
+            if (s == 0) ov = r0v;
+            else if (cc >= 1 && cc <= m_eff) {
+                ov = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
+                if (REBASE) { const int q = (cc + 14) / CK; ov += rbase_delta(q > 0 ? bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + q] : 0LL, Bt); }
+            }
             else ov = 0;
             int b = 0;
             if (cc >= 1 && cc <= m_eff) { b = bp.at(cc - 1); if (b >= 5) { bad = 1; b = 4; } }
@@ -486,7 +558,7 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
         else if (up_exit && !left_exit) emit(1, wj);
         flush_run();
         nops[po] = cnt;
-        score_out[po] = (int64_t)hfin[pl.hcol_off];
+        score_out[po] = hfin[pl.hcol_off];
     }
     if (bad) atomicOr(err, 1);
 }

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void cl_walk_spec_kernel(const PairPlan *__rest
                                                           const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                           const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                           KParams kp, TbParams tp, const int *__restrict__ rowbuf, const int *__restrict__ snap,
-                                                          const int *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                          const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                           const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err) {
     using PC = ProfCfg<P16>;
     static_assert(NS >= 2 && NS <= 4, "tiles per round");
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void cl_walk_spec_kernel(const PairPlan *__rest
         else if (up_exit && !left_exit) emit(1, wj);
         flush_run();
         nops[po] = cnt;
-        score_out[po] = (int64_t)hfin[pl.hcol_off];
+        score_out[po] = hfin[pl.hcol_off];
     }
     if (bad) atomicOr(err, 1);
 }

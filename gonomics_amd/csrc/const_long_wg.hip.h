@@ -62,7 +62,7 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5, 5))) void cl_sweep_wg_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                               const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                               const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                                              KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap, int *__restrict__ hfin,
+                                                              KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap, int64_t *__restrict__ hfin,
                                                               int *__restrict__ err, const int2 *__restrict__ item_map, int *__restrict__ item_prog) {
     using PC = ProfCfg<true>;
     using LY = ClwLds<NW>;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5, 5)))
         if (has_cons && lane == 0) __hip_atomic_store(prod_out, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (gact && m_eff >= 1) {
 #pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (val[r] >> 2) + (kp.g4 >> 2) * (pl.n + m_eff); // plain V(n, m)
+            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (int64_t)((val[r] >> 2) + (kp.g4 >> 2) * (pl.n + m_eff)); // plain V(n, m) (this kernel only runs pairs inside the static int32 range)
         }
         if (to_mem) rb_publish(&item_prog[bid], 0x7fffffff, lane);
     }

@@ -119,7 +119,7 @@ struct Ctx {
     PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
     // the resident reference, PACKED (gnx_host.hip.h: pack_reference): `ref` = 2 bits per base, ref_flag / ref_rank / ref_exc = the
     // sparse list of bases that are not A C G T (KParams::b2 / bflag / brank / bexc)
-    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off;
+    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off, cl_bases;
     int64_t ref_len = -1;  // >= 0: a reference of that many bases is resident
     int64_t ref_nexc = 0;  // 64-base blocks with an exception
     int64_t ref_epoch = 0; // which gnx_set_reference call filled it (contexts created later are brought up to date on first use)
@@ -589,10 +589,11 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
 // Pairs without a stored direction matrix (const_long.hip.h; affine: affine_long.hip.h): score-only sweep that keeps the strips' bottom
 // rows and a snapshot of the wavefront every CKC / CKA steps, then one fused re-fill + walk kernel.  Every n, m >= 1 (validated by the caller).
 // Returns GNX_OK, an error, or -1 when the batch should take the general path (a single pair exceeds the workspace).
+// rebase: the REBASE instantiations (const_long.hip.h): keys relative to a base every strip moves along -- pairs of any length
 int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &tp, bool affine, int64_t n_pairs,
                      const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                      const int64_t *h_alen, const int64_t *h_blen,
-                     int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream) {
+                     int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool rebase) {
     Ctx &c = g_ctx;
     int rc;
     // snapshot spacing of the constant-gap form (const_long.hip.h): the wide tiles only when the walk will have the GPU full of long chains
@@ -606,35 +607,52 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     std::vector<PairPlan> plans((size_t)n_pairs);
     std::vector<int64_t> so((size_t)n_pairs + 1, 0); // staging offsets (runs), chunk-relative; so[chunk end] is unused
     std::vector<int64_t> chunk_begin{0};
-    int64_t cells = 0, max_rb = 1, max_sn = 1, max_sc = 1;
+    int64_t cells = 0, max_rb = 1, max_sn = 1, max_sc = 1, max_bs = 1;
     {
-        int64_t rb = 0, sn = 0, sc = 0;
-        const int64_t budget = c.ws_limit - c.ws_limit / 16;
+        int64_t rb = 0, sn = 0, sc = 0, bs = 0;
+        int64_t budget = c.ws_limit - c.ws_limit / 16;
         const int64_t rbw = affine ? 8 : 4, ck = affine ? CKA : ckc, snw = affine ? AL_SNAPW : SNAPW; // row-buffer entry bytes, snapshot spacing / dwords
-        auto bytes_of = [&](int64_t rb2, int64_t sn2, int64_t sc2) { return rbw * rb2 + 4 * sn2 + (int64_t)sizeof(gnx_cigar) * sc2; };
+        auto bytes_of = [&](int64_t rb2, int64_t sn2, int64_t sc2, int64_t bs2) { return rbw * rb2 + 4 * sn2 + (int64_t)sizeof(gnx_cigar) * sc2 + 8 * bs2; };
+        auto nq_of = [&](int64_t m) { return rebase ? (((m + 30) & ~(int64_t)15) / ck + 2) : 0; }; // K-step blocks of a strip (REBASE: one int64 base each)
+        // One pair that needs more than the workspace limit (a 1 Mb x 1 Mb pair: 50 GB of bottom rows + 43 GB of snapshots) is given what
+        // the device has free, plus what these buffers already hold: the limit is there to leave room for other contexts' batches, and such a
+        // pair cannot run any other way (the stored matrix would be 750 GB).
+        int64_t one_max = 0;
+        for (int64_t p = 0; p < n_pairs; p++) {
+            const int64_t n = h_alen[p], m = h_blen[p], strips = (n + H - 1) / H;
+            one_max = std::max(one_max, bytes_of((strips - 1) * (m + 1), (m + 15) / ck * strips * G * snw, n + m + 2, strips * nq_of(m)));
+        }
+        if (one_max > budget) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
+            const int64_t avail = (int64_t)fr + (int64_t)(c.rowbuf.cap + c.fp_ckpt.cap + c.tb_scr.cap + c.cl_bases.cap);
+            if (one_max + (one_max >> 3) + ((int64_t)1 << 28) > avail) return -1;
+            budget = one_max;
+            // (the buffers grow to exactly what is asked for: DevBuf::ensure falls back to the plain size when size + 1/8 does not fit)
+        }
         for (int64_t p = 0; p < n_pairs; p++) {
             const int64_t n = h_alen[p], m = h_blen[p];
             const int64_t strips = (n + H - 1) / H, ncp = (m + 15) / ck;
-            const int64_t prb = (strips - 1) * (m + 1), psn = ncp * strips * G * snw, psc = n + m + 2;
-            if (bytes_of(prb, psn, psc) > budget) return -1;
-            if (bytes_of(rb + prb, sn + psn, sc + psc) > budget) { // new chunk, 4-aligned so that waves stay whole
+            const int64_t prb = (strips - 1) * (m + 1), psn = ncp * strips * G * snw, psc = n + m + 2, pbs = strips * nq_of(m);
+            if (bytes_of(prb, psn, psc, pbs) > budget) return -1;
+            if (bytes_of(rb + prb, sn + psn, sc + psc, bs + pbs) > budget) { // new chunk, 4-aligned so that waves stay whole
                 int64_t cb = p & ~(int64_t)3;
                 if (cb <= chunk_begin.back()) cb = p;
-                rb = sn = sc = 0;
+                rb = sn = sc = bs = 0;
                 for (int64_t q2 = cb; q2 < p; q2++) {
                     PairPlan &pq = plans[(size_t)q2];
-                    pq.rowbuf_off = rb; pq.ckpt_off = sn; so[(size_t)q2] = sc; pq.hcol_off = q2 - cb; pq.src = (int32_t)(q2 - cb);
-                    rb += (int64_t)(pq.strips - 1) * (pq.m + 1); sn += (int64_t)((pq.m + 15) / ck) * pq.strips * G * snw; sc += (int64_t)pq.n + pq.m + 2;
+                    pq.rowbuf_off = rb; pq.ckpt_off = sn; so[(size_t)q2] = sc; pq.hcol_off = q2 - cb; pq.src = (int32_t)(q2 - cb); pq.rowi_off = bs;
+                    rb += (int64_t)(pq.strips - 1) * (pq.m + 1); sn += (int64_t)((pq.m + 15) / ck) * pq.strips * G * snw; sc += (int64_t)pq.n + pq.m + 2; bs += (int64_t)pq.strips * pq.s_pitch;
                 }
                 chunk_begin.push_back(cb);
             }
             PairPlan &pl = plans[(size_t)p];
             pl.n = (int32_t)n; pl.m = (int32_t)m; pl.words = 0; pl.strips = (int32_t)strips;
-            pl.trace_off = 0; pl.dcol_off = 0; pl.col_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0;
+            pl.trace_off = 0; pl.dcol_off = 0; pl.col_off = 0; pl.rowi_off = bs; pl.s_off = 0; pl.s_pitch = nq_of(m);
             pl.rowbuf_off = rb; pl.ckpt_off = sn; so[(size_t)p] = sc;
             pl.hcol_off = p - chunk_begin.back(); pl.src = (int32_t)(p - chunk_begin.back());
-            rb += prb; sn += psn; sc += psc;
-            max_rb = std::max(max_rb, rb); max_sn = std::max(max_sn, sn); max_sc = std::max(max_sc, sc);
+            rb += prb; sn += psn; sc += psc; bs += pbs;
+            max_rb = std::max(max_rb, rb); max_sn = std::max(max_sn, sn); max_sc = std::max(max_sc, sc); max_bs = std::max(max_bs, bs);
             cells += n * m;
         }
         chunk_begin.push_back(n_pairs);
@@ -645,7 +663,8 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     if ((rc = c.fp_ckpt.ensure((size_t)max_sn * 4))) return rc;
     if ((rc = c.tb_scr.ensure((size_t)max_sc * sizeof(gnx_cigar)))) return rc;
     if ((rc = c.tb_scr_off.ensure(((size_t)n_pairs + 1) * 8))) return rc;
-    if ((rc = c.hcol.ensure((size_t)max_np * 4))) return rc;
+    if ((rc = c.hcol.ensure((size_t)max_np * 8))) return rc;
+    if (rebase && (rc = c.cl_bases.ensure((size_t)max_bs * 8))) return rc;
     c.fpc_ptr = nullptr;
     if ((rc = c.plans.ensure((size_t)n_pairs * sizeof(PairPlan)))) return rc;
     if ((rc = c.nops.ensure((size_t)n_pairs * 8))) return rc;
@@ -669,7 +688,9 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         const int np = (int)(e - b);
         if (np <= 0) continue;
         const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p) + b;
-        int *drb = reinterpret_cast<int *>(c.rowbuf.p), *dsn = reinterpret_cast<int *>(c.fp_ckpt.p), *dhf = reinterpret_cast<int *>(c.hcol.p);
+        int *drb = reinterpret_cast<int *>(c.rowbuf.p), *dsn = reinterpret_cast<int *>(c.fp_ckpt.p);
+        int64_t *dhf = reinterpret_cast<int64_t *>(c.hcol.p);
+        long long *dbs = rebase ? reinterpret_cast<long long *>(c.cl_bases.p) : nullptr;
         int64_t *dn = reinterpret_cast<int64_t *>(c.nops.p) + b;
         const int64_t *d_so = reinterpret_cast<const int64_t *>(c.tb_scr_off.p) + b;
         gnx_cigar *d_scr = reinterpret_cast<gnx_cigar *>(c.tb_scr.p);
@@ -680,7 +701,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB && !no_pipe();
         // constant gap, int16 profile: several strips per workgroup, rows handed over through LDS (cl_sweep_wg_kernel; GNX_CL_WG=0: one strip per workgroup)
         constexpr int CLW_NW = 4;
-        const bool wg = piped && !affine && p16 && !(getenv("GNX_CL_WG") && atoi(getenv("GNX_CL_WG")) == 0);
+        const bool wg = piped && !affine && p16 && !rebase && !(getenv("GNX_CL_WG") && atoi(getenv("GNX_CL_WG")) == 0);
         const int per_item = wg ? CLW_NW : 1;
         const int2 *d_smap = nullptr;
         int *d_sprog = nullptr;
@@ -712,26 +733,38 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         kps.rb_pub = n_blocks * per_item >= (int64_t)40 * c.n_cu ? 16 : RB_PUB; // (twice the wave slots of the piped sweep: 20 per CU)
         if (const char *e = getenv("GNX_CL_PUB")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) kps.rb_pub = v; }
         int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
-        if (affine && p16) hipLaunchKernelGGL(al_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
-        else if (affine) hipLaunchKernelGGL(al_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog);
-        else if (wg) hipLaunchKernelGGL(cl_sweep_wg_kernel<CLW_NW>, dim3((unsigned)n_blocks), dim3(64 * CLW_NW), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
-        else if (p16 && piped) hipLaunchKernelGGL(cl_sweep_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
-        else if (p16) hipLaunchKernelGGL(cl_sweep_flat_kernel<true>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err);
-        else if (piped) hipLaunchKernelGGL(cl_sweep_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
-        else hipLaunchKernelGGL(cl_sweep_flat_kernel<false>, dim3((unsigned)n_blocks), dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err);
+        const dim3 gridS((unsigned)n_blocks);
+#define GNX_AL_SWEEP(P_, RBS_) hipLaunchKernelGGL((al_sweep_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs)
+#define GNX_CL_SWEEP(P_, RBS_) hipLaunchKernelGGL((cl_sweep_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs)
+#define GNX_CL_FLAT(P_, RBS_) hipLaunchKernelGGL((cl_sweep_flat_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, dbs)
+        if (rebase) HIPCHK(hipMemsetAsync(dbs, 0, (size_t)max_bs * 8, stream));
+        if (affine) { if (rebase) { if (p16) GNX_AL_SWEEP(true, true); else GNX_AL_SWEEP(false, true); } else { if (p16) GNX_AL_SWEEP(true, false); else GNX_AL_SWEEP(false, false); } }
+        else if (wg) hipLaunchKernelGGL(cl_sweep_wg_kernel<CLW_NW>, gridS, dim3(64 * CLW_NW), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        else if (piped) { if (rebase) { if (p16) GNX_CL_SWEEP(true, true); else GNX_CL_SWEEP(false, true); } else { if (p16) GNX_CL_SWEEP(true, false); else GNX_CL_SWEEP(false, false); } }
+        else { if (rebase) { if (p16) GNX_CL_FLAT(true, true); else GNX_CL_FLAT(false, true); } else { if (p16) GNX_CL_FLAT(true, false); else GNX_CL_FLAT(false, false); } }
+#undef GNX_AL_SWEEP
+#undef GNX_CL_SWEEP
+#undef GNX_CL_FLAT
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
         const dim3 gridW((unsigned)((np + 3) / 4));
-        if (affine && p16) hipLaunchKernelGGL(al_walk_kernel<true>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
-        else if (affine) hipLaunchKernelGGL(al_walk_kernel<false>, gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
-        else {
+#define GNX_AL_WALK(P_, RBS_) hipLaunchKernelGGL((al_walk_kernel<P_, RBS_>), gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs)
+        if (affine) { if (rebase) { if (p16) GNX_AL_WALK(true, true); else GNX_AL_WALK(false, true); } else { if (p16) GNX_AL_WALK(true, false); else GNX_AL_WALK(false, false); } }
+#undef GNX_AL_WALK
+        else if (rebase) { // (one pair per workgroup, plain walk)
+            const dim3 gw((unsigned)np);
+#define GNX_CL_WALKR(P_, CK_) hipLaunchKernelGGL((cl_walk_kernel<P_, 1, CK_, true>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs)
+            if (ckc == CKC) { if (p16) GNX_CL_WALKR(true, CKC); else GNX_CL_WALKR(false, CKC); }
+            else { if (p16) GNX_CL_WALKR(true, CKC_SMALL); else GNX_CL_WALKR(false, CKC_SMALL); }
+#undef GNX_CL_WALKR
+        } else {
             // pairs per walk workgroup: GNX_CL_WALK_NP = 1 / 2 / 4 (default 1, see cl_walk_kernel)
             const char *npe = getenv("GNX_CL_WALK_NP");
             const int wnp = (npe && (npe[0] == '2' || npe[0] == '4')) ? npe[0] - '0' : 1;
             const dim3 gw((unsigned)((np + wnp - 1) / wnp));
             // (padding the workgroups' LDS so that a launch smaller than the GPU spreads over all CUs changes nothing: the dispatcher already does)
             auto launch_walk = [&](auto kern) {
-                hipLaunchKernelGGL(kern, gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
+                hipLaunchKernelGGL(kern, gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, (const long long *)nullptr);
             };
             const bool wide = ckc == CKC;
             // speculative re-fills of the next tiles by the wave's other lane groups (cl_walk_spec_kernel): GNX_CL_WALK_SPEC = 0 / 3 / 4 tiles per round
@@ -794,7 +827,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         if (t_no_pipe) { set_err("a strip waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
         if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx] a pipelined strip timed out: the call runs again with sequential strips\n");
         t_no_pipe = true;
-        rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+        rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, rebase);
         t_no_pipe = false;
         return rc;
     }
@@ -834,6 +867,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         return GNX_OK;
     }
     const int64_t maxpen = max_abs_pen(prm, affine);
+    int64_t first_oor = -1; // first pair beyond the static key range
     // ---- validation, the same for every path below ----
     for (int64_t p = 0; p < n_pairs; p++) {
         const int64_t n = h_alen[p], m = h_blen[p];
@@ -844,12 +878,14 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             set_err("non-square checkerboards with n > checkersize_i are undefined in the reference (pair %s%lld)", "", (long long)p); return GNX_EINVAL;
         }
         if (lowmem && (n < 1 || m < 1)) { set_err("empty sequence at pair %s%lld: the reference never terminates on it", "", (long long)p); return GNX_EEMPTY; }
-        if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27)) { set_err("pair %s%lld exceeds the int32 DP range", "", (long long)p); return GNX_ERANGE; }
+        // beyond the STATIC int32 range of the kernels' keys (4 * score, absolute): such pairs take the snapshot path with moving bases
+        // (REBASE, const_long.hip.h), which has no length limit -- see the clong block below; the reference is int64 throughout (align/align.go:8)
+        if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27) && first_oor < 0) first_oor = p;
     }
     // ---- fast path: every alpha fits one strip, long beta, global affine with gapOpen <= 0 ----
     {
         const char *fpenv = getenv("GNX_FASTPATH");
-        bool fp = affine && !d_smat && !no_fast_path && prm->gap_open <= 0 && !(fpenv && fpenv[0] == '0');
+        bool fp = affine && !d_smat && !no_fast_path && prm->gap_open <= 0 && !(fpenv && fpenv[0] == '0') && first_oor < 0;
         // AffineGapLocal(target, query): the same sweep on the transposed problem (rows = query), see fp_sweep_kernel<.., XP>
         const bool xp = local;
         if (xp && (prm->gap_extend >= 0 || prm->gap_extend <= -8000)) fp = false;
@@ -1015,9 +1051,17 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         kp.b2 = nullptr; kp.bflag = nullptr; kp.brank = nullptr; kp.bexc = nullptr;
     }
     // ---- constant gap without a stored direction matrix (const_long.hip.h): pairs of more than one strip; GNX_CLONG=0 / 2 = never / always ----
-    if (!gsw && !d_smat && !local && (!affine || (prm->gap_open <= 0 && !getenv("GNX_NO_HFORM")))) { // (GNX_CLONG also governs the affine form, affine_long.hip.h)
+    const bool oor = first_oor >= 0;
+    if (!gsw && !d_smat && !local && (!affine || (prm->gap_open <= 0 && (oor || !getenv("GNX_NO_HFORM"))))) { // (GNX_CLONG also governs the affine form, affine_long.hip.h)
         const char *cl = getenv("GNX_CLONG");
-        bool use = !(cl && cl[0] == '0'), any_multi = false;
+        bool use = oor || !(cl && cl[0] == '0'), any_multi = false;
+        // moving bases: what a strip holds at one time -- 160 rows x 16 columns of an anti-diagonal band, the row above, the snapshot -- must fit
+        // int32 around the strip's base: neighbouring cells differ by at most one substitution score + two gap opens + two extensions
+        const int64_t step4 = 4 * (max_abs_pen(prm, false) + 2 * llabs((long long)prm->gap_open) + (affine ? 2 * llabs((long long)prm->gap_extend) : 0));
+        const bool spread_ok = (int64_t)(H + G + 64) * step4 < ((int64_t)1 << 28);
+        const char *rbe = getenv("GNX_REBASE");
+        const bool rebase = spread_ok && (oor || (rbe && rbe[0] == '1')); // GNX_REBASE=1 (tests): every pair of this path on moving bases
+        if (oor && !spread_ok) use = false;
         long double cells_ld = 0, dir_bytes = 0, rows_ld = 0, cols_ld = 0;
         for (int64_t p = 0; use && p < n_pairs; p++) {
             if (h_alen[p] < 1 || h_blen[p] < 1) use = false;
@@ -1039,10 +1083,15 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // ~8.5e-14 s per cell, the walk costs ~7e-8 s per pair plus ~1e-11 s per column: ConstGap 150 x 10 000 18.6 -> 16.1 ms per 65 536
         // pairs (1000 pairs: 1.81 -> 1.25 ms), but 150 x 2000, 500 x 600 and 1000 x 1200 lose 1.4 .. 2.6 x and stay on the stored matrix.
         const bool long_windows = !affine && cells_ld >= 1.4e6L * (long double)n_pairs && cols_ld >= 48.0L * rows_ld;
-        if (use && ((any_multi && big) || long_windows || (cl && cl[0] == '2'))) {
-            rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+        if (use && (oor || (any_multi && big) || long_windows || (cl && cl[0] == '2'))) {
+            rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, rebase);
             if (rc != -1) return rc;
+            if (oor) { set_err("pair %s%lld needs more snapshot workspace than the device has free", "", (long long)first_oor); return GNX_ENOMEM; }
         }
+    }
+    if (oor) { // what is left has absolute int32 keys: AffineGapLocal, gapOpen > 0, the chunk / graph variants, scores too big for moving bases
+        set_err("pair %s%lld exceeds the int32 DP range of this mode (global AffineGap / ConstGap with gapOpen <= 0 have no length limit)", "", (long long)first_oor);
+        return GNX_ERANGE;
     }
     // ---- plan ----
     const auto t_plan0 = std::chrono::steady_clock::now();
@@ -1632,7 +1681,7 @@ void gnx_shutdown(void) {
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,
-                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
+                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.cl_bases, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
                           &c.sd_tmp[0], &c.sd_tmp[1], &c.sd_tmp[2], &c.sd_tmp[3], &c.sd_tmp[4], &c.sd_tmp[5], &c.sd_tmp[6], &c.sd_tmp[7]};
         for (DevBuf *b : bufs) b->release();
         PinBuf *pins[] = {&c.h_plans, &c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};

@@ -53,7 +53,10 @@ BUDGET = [
     ("fp_sweep_kernel<19, false", 3), ("fp_sweep_kernel<20, false", 3), ("fp_sweep_kernel<19, true", 3), ("fp_sweep_kernel<20, true", 3), ("fp_sweep_levels_kernel", 2),
     ("fill_affine_kernel<false, false", 3), ("fill_affine_kernel<true, false", 3), ("fill_affine_kernel<false, true", 2), ("fill_affine_kernel<true, true", 2),
     ("fill_const_kernel<false, 0", 3), ("fill_const_kernel<false, 1", 3), ("fill_const_kernel<false, 2", 3), ("fill_const_kernel<true", 2),
-    ("cl_sweep_kernel<true>", 5), ("cl_sweep_wg_kernel<4>", 5), ("cl_sweep_flat_kernel<true>", 4), ("cl_sweep_flat_kernel<false>", 3), ("cl_sweep_kernel<false>", 3), ("al_sweep_kernel", 3),
+    ("cl_sweep_kernel<true, false>", 5), ("cl_sweep_wg_kernel<4>", 5), ("cl_sweep_flat_kernel<true, false>", 4), ("cl_sweep_flat_kernel<false, false>", 3), ("cl_sweep_kernel<false, false>", 3),
+    ("al_sweep_kernel<true, false>", 3), ("al_sweep_kernel<false, false>", 3),
+    # the REBASE instantiations (pairs beyond the static int32 range, round 5) carry an int64 base and two deltas: one wave per SIMD less is their price
+    ("cl_sweep_kernel<true, true>", 4), ("cl_sweep_flat_kernel<true, true>", 3), ("cl_sweep_kernel<false, true>", 3), ("cl_sweep_flat_kernel<false, true>", 3), ("al_sweep_kernel<true, true>", 3), ("al_sweep_kernel<false, true>", 2),
     ("fp_walk_kernel", 5), ("traceback_kernel", 4), ("gsw_traceback_kernel", 8),
     # the window walk with one LANE per pair (batches of more than 32 768 reads of several row blocks): 98 registers since it carries the block
     # shortcut of round 4 (score table in LDS, two row-buffer keys, the diagonal's sum) -- a launch of <= 2 waves per SIMD, whatever its registers allow
@@ -65,7 +68,7 @@ SCRATCH_OK = ("al_walk_kernel",)
 # exactly at the 168 registers of three waves per SIMD -- and one reload per 16-step block of address pairs in the multi-strip constant-gap sweep)
 SCRATCH_SMALL = {"fp_sweep_kernel<": 256, "cl_sweep_wg_kernel<": 32}
 # LDS per workgroup: handed out in granules of 1280 B on gfx950 (160 KB per CU) -- the budgets are granule counts
-LDS_GRANULES = [("fp_sweep_kernel", 11), ("fp_sweep_levels_kernel", 11), ("cl_sweep_kernel<true>", 6), ("cl_sweep_wg_kernel<4>", 25), ("cl_sweep_flat_kernel<true>", 6), ("fill_const_kernel<false, 0, true>", 6),
+LDS_GRANULES = [("fp_sweep_kernel", 11), ("fp_sweep_levels_kernel", 11), ("cl_sweep_kernel<true,", 6), ("cl_sweep_wg_kernel<4>", 25), ("cl_sweep_flat_kernel<true,", 6), ("fill_const_kernel<false, 0, true>", 6),
                 ("fill_affine_kernel<false, false, false, true, false, false, false>", 11)]
 
 

@@ -1,0 +1,164 @@
+"""Alignments beyond the static int32 range of the kernels' keys.  The reference is int64 end to end
+(align/align.go:8; align/affineGap.go:151-207, align/constGap.go:129-176) and its low-memory checkerboard exists for sequences far
+longer than 4 * score fits int32 for; here such pairs run on int32 keys relative to a base every strip moves along (REBASE,
+csrc/const_long.hip.h).  Checked: the REBASE kernels against the oracle on every shape of the snapshot suites (forced with GNX_REBASE=1),
+pairs that really leave the static range (scores x 40 at 10 kb x 10 kb: keys up to 2.6e9) against the oracle, pairs the old bound
+refused (n + m >= 178 955) against the oracle, and 1 Mb x 1 Mb / 300 kb x 2 Mb pairs through what the CIGAR must satisfy: it consumes
+both sequences and re-scores, in int64, to the score returned."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+import oracle
+from test_const_long import _ragged, rescore_const
+
+pytestmark = pytest.mark.gpu
+MX = common.matrices()
+
+
+def rescore_affine(a, b, ops, scores, go, ge):
+    """(rows consumed, columns consumed, score) of a run-length CIGAR under the affine model (a gap run of length L costs go + L * ge)"""
+    sc = np.asarray(scores, dtype=np.int64)
+    run = ops["run_length"].astype(np.int64)
+    op = ops["op"]
+    di = np.where(op != 1, run, 0)
+    dj = np.where(op != 2, run, 0)
+    i0 = np.concatenate([[0], np.cumsum(di)[:-1]])
+    j0 = np.concatenate([[0], np.cumsum(dj)[:-1]])
+    gaps = op != 0
+    total = int(go) * int(gaps.sum()) + int(ge) * int(run[gaps].sum())
+    mm = op == 0
+    if mm.any():
+        ln = run[mm]
+        idx = np.repeat(np.arange(ln.shape[0]), ln)
+        k = np.arange(ln.sum()) - np.repeat(np.cumsum(ln) - ln, ln)
+        total += int(sc[a[i0[mm][idx] + k], b[j0[mm][idx] + k]].sum())
+    return int(di.sum()), int(dj.sum()), total
+
+
+def _related(rng, n, m_extra=0, sub=0.03, indel=0.01):
+    a = rng.integers(0, 4, size=n).astype(np.uint8)
+    b = common.mutate(rng, a, sub=sub, indel=indel, geo=0.4)
+    if m_extra:
+        b = np.concatenate([b, rng.integers(0, 4, size=m_extra).astype(np.uint8)])
+    return a, b
+
+
+@pytest.mark.parametrize("cs", [3, 16, 10000])
+@pytest.mark.parametrize("mode", [0, 1, 2, 4])  # AffineGap, ConstGap, AffineGap_highMem, ConstGap_highMem
+def test_rebase_forced(gpu_lib, monkeypatch, mode, cs):
+    """GNX_CLONG=2 + GNX_REBASE=1: every pair through the snapshot path on moving bases (a rebase every 128 / 224 / 448 steps), ragged
+    batches of one to several strips, small checkerboards (quirks Q1 / Q2) -- bit-exact against the oracle"""
+    monkeypatch.setenv("GNX_CLONG", "2")
+    monkeypatch.setenv("GNX_REBASE", "1")
+    affine = mode in (0, 2)
+    for seed, nmax, mmax, count in ((21, 60, 400, 64), (22, 700, 1500, 40), (23, 400, 2600, 24)):
+        alphas, betas = _ragged(seed + 100 * cs, count, nmax, mmax)
+        for name, go, ge in (("HumanChimpTwo", -600, -150), ("Default", -400, -30), ("HoxD55", 0, -70)) if affine else (("HumanChimpTwo", -430, 0), ("HoxD55", -100, 0)):
+            p = gpu_lib.make_params(mode, MX[name], go, ge, cs, cs)
+            for ckc in ("224", "448") if not affine else ("",):
+                if ckc:
+                    monkeypatch.setenv("GNX_CL_CKC", ckc)
+                got = gpu_lib.align_batch(p, alphas, betas)
+                common.expect_route(gpu_lib.get_timing(), 2)
+                exp = oracle.align_batch(mode, MX[name], go, ge, alphas, betas, cs, cs, threads=8)
+                common.assert_same(got, exp, "seed %d %s ckc %s" % (seed, name, ckc))
+
+
+@pytest.mark.parametrize("piped", ["1", "0"])
+def test_rebase_forced_long_strips(gpu_lib, monkeypatch, piped):
+    """the same with pairs of many strips and many blocks (piped: the strips of a pair as separate workgroups, bases handed over through memory)"""
+    monkeypatch.setenv("GNX_CLONG", "2")
+    monkeypatch.setenv("GNX_REBASE", "1")
+    if piped == "0":
+        monkeypatch.setenv("GNX_NO_PIPE", "1")
+    rng = np.random.default_rng(5)
+    alphas, betas = [], []
+    for n, extra in ((3000, 0), (2500, 1500), (1700, 4000), (5000, 100)):
+        a, b = _related(rng, n, extra, sub=0.05, indel=0.03)
+        alphas.append(a); betas.append(b)
+    alphas.append(rng.integers(0, 4, size=2000).astype(np.uint8)); betas.append(rng.integers(0, 4, size=3000).astype(np.uint8))  # unrelated
+    for mode, name, go, ge in ((0, "HumanChimpTwo", -600, -150), (1, "HumanChimpTwo", -430, 0)):
+        for cs in (1000, 10000):
+            p = gpu_lib.make_params(mode, MX[name], go, ge, cs, cs)
+            got = gpu_lib.align_batch(p, alphas, betas)
+            exp = oracle.align_batch(mode, MX[name], go, ge, alphas, betas, cs, cs, threads=8)
+            common.assert_same(got, exp, "mode %d cs %d" % (mode, cs))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_keys_beyond_int32(gpu_lib, mode):
+    """pairs that REALLY leave the static range, no switch: scores x 40 at 10 kb x 10 kb -- 4 * score reaches 2.6e9 along the diagonal
+    (the old bound refused them with GNX_ERANGE); the int32 profile does not fit int16 either.  Against the oracle (int64)."""
+    rng = np.random.default_rng(8 + mode)
+    sc = [[40 * int(v) for v in row] for row in MX["HumanChimpTwo"]]
+    alphas, betas = [], []
+    for n in (10000, 9000, 2000):
+        a, b = _related(rng, n, 0)
+        alphas.append(a); betas.append(b)
+    go, ge = (-600 * 40, -150 * 40) if mode == 0 else (-430 * 40, 0)
+    p = gpu_lib.make_params(mode, sc, go, ge, 10000, 10000)
+    got = gpu_lib.align_batch(p, alphas, betas)
+    assert gpu_lib.get_timing()["fast_path"] == 2
+    exp = oracle.align_batch(mode, sc, go, ge, alphas, betas, 10000, 10000, threads=3)
+    common.assert_same(got, exp)
+    # what the kernels hold is 4 * (score - gapExtend * (i + j)) (ConstGap: - gapPen * (i + j)): at (n, m) beyond the 2^29 the absolute keys end at
+    assert 4 * (int(got[0][0]) - (ge if mode == 0 else go) * (alphas[0].shape[0] + betas[0].shape[0])) > (1 << 29)
+
+
+def test_range_boundary(gpu_lib):
+    """the largest pairs the static bound admits and the smallest it does not, both exact: AffineGap(HumanChimpTwo,
+    -600, -150) admits n + m + 2 < 2^27 / 600 = 223 696 (the bound is on (n + m + 2) * the largest penalty)"""
+    rng = np.random.default_rng(99)
+    sc, go, ge = MX["HumanChimpTwo"], -600, -150
+    lim = (1 << 27) // 600  # (n + m + 2) * 600 < 2^27
+    for total, route in ((lim - 3, None), (lim + 40, 2)):
+        n = 300
+        m = total - n
+        win = rng.integers(0, 4, size=m).astype(np.uint8)
+        off = int(rng.integers(0, m - 400))
+        a = common.mutate(rng, win[off:off + 340], sub=0.02, indel=0.01, geo=0.5)[:n]
+        p = gpu_lib.make_params(0, sc, go, ge, 10000, 10000)
+        got = gpu_lib.align_batch(p, [a], [win])
+        if route is not None:
+            assert gpu_lib.get_timing()["fast_path"] == route
+        exp = oracle.align_batch(0, sc, go, ge, [a], [win], 10000, 10000, threads=1)
+        common.assert_same(got, exp, "n + m = %d" % total)
+
+
+def test_range_error_where_it_remains(gpu_lib):
+    """AffineGapLocal keeps absolute keys: beyond the static range it still says so (and what to use instead)"""
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 4, size=200).astype(np.uint8)
+    b = rng.integers(0, 4, size=230000).astype(np.uint8)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_LOCAL, MX["HumanChimpTwo"], -600, -150)
+    with pytest.raises(gpu_lib.GnxError) as ei:
+        gpu_lib.align_batch(p, [b], [a])
+    assert ei.value.code == gpu_lib.GNX_ERANGE
+
+
+@pytest.mark.parametrize("what", ["affine_1Mb_x_1Mb", "const_300kb_x_2Mb"])
+def test_megabase_pairs(gpu_lib, what):
+    """one 1 Mb x 1 Mb AffineGap pair (1e12 cells) and one 300 kb x 2 Mb ConstGap pair (6e11 cells), the callers' parameters and
+    10 000 x 10 000 checkerboards (cmd/cigarToBed/cigarToBed.go:86; .MISSING_LARGE_BLOBS:1-3 lists a 5 Mb fixture the reference ships):
+    the CIGAR consumes both sequences and re-scores in int64 to the returned score; rows written to profiles/ by tools/long_pairs.py"""
+    rng = np.random.default_rng(1234)
+    sc = MX["HumanChimpTwo"]
+    gpu_lib.check(gpu_lib.lib().gnx_init(0, 0))
+    if what.startswith("affine"):
+        a, b = _related(rng, 1000000, 0, sub=0.02, indel=0.002)
+        p = gpu_lib.make_params(0, sc, -600, -150, 10000, 10000)
+        score, ops, off = gpu_lib.align_batch(p, [a], [b])
+        ni, nj, total = rescore_affine(a, b, ops, sc, -600, -150)
+    else:
+        win = rng.integers(0, 4, size=2000000).astype(np.uint8)
+        a = common.mutate(rng, win[700000:700000 + 300000 + 3000], sub=0.03, indel=0.004, geo=0.5)[:300000]
+        b = win
+        p = gpu_lib.make_params(1, sc, -430, 0, 10000, 10000)
+        score, ops, off = gpu_lib.align_batch(p, [a], [b])
+        ni, nj, total = rescore_const(a, b, ops, sc, -430)
+    assert gpu_lib.get_timing()["fast_path"] == 2
+    assert (ni, nj) == (a.shape[0], b.shape[0])
+    assert total == int(score[0])
