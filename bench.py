@@ -418,7 +418,7 @@ def extra_gsw(_lib, L, scores, chunk_h, dev, torch, n_reads=20000, n_check=48):
             "checked_against": "tests/pyref_gsw.py (sequential restatement of toGiraf.go:17-72 with the oracle's DPs)"}
 
 
-def one_process_flow(_lib, L, world, params, reads_h, chunk_h, n_pairs, same, steps):
+def one_process_flow(_lib, L, world, params, reads_h, chunk_h, n_pairs, same, steps, share_gpu=False):
     """SURVEY 8e, second form: ONE host process, one context per GPU behind the C ABI (what a Go program gets).  Rank 0 runs it on
     all `world` GPUs after the other ranks have released theirs: `world` x n_pairs reads against the shared chunk (broadcast over
     RCCL inside the call), then the same reads against the chunk as resident reference; compared with the one-GPU result."""
@@ -432,7 +432,9 @@ def one_process_flow(_lib, L, world, params, reads_h, chunk_h, n_pairs, same, st
     ref_res = _lib.align_batch_windows(params, reads.reshape(-1), h_as, h_al, chunk_h, h_bs, h_bl)  # one context, one GPU
     one_ms = _lib.get_timing()["host_ms"]
     L.gnx_shutdown()
-    nd = _lib.init_devices(list(range(world)), 0)
+    if share_gpu:  # flow check on a 1-GPU box: `world` contexts on device 0, the exchange by peer copies (RCCL wants distinct devices)
+        os.environ["GNX_RCCL"] = "0"
+    nd = _lib.init_devices([0] * world if share_gpu else list(range(world)), 0)
     out = {"contexts": nd, "pairs": n}
     calls = []
     got = None
@@ -471,6 +473,7 @@ def main():
     ap.add_argument("--verify", type=int, default=-1, help="pairs checked bit-exactly against the oracle after timing (default 32; 2 for --series long)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU (with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 (flow check of the N>1 path on a 1-GPU box)")
+    ap.add_argument("--one-process", action="store_true", help="run the one_process leg even with --share-gpu / --no-extras (contexts on cuda:0, peer copies)")
     ap.add_argument("--series", default="affine", choices=sorted(SERIES),
                     help="affine = the headline AffineGap(read, chunk); const = ConstGap(read, chunk, -430); "
                          "local = AffineGapLocal(target=chunk, query=read) (SURVEY 8d second series); long = config C5")
@@ -597,6 +600,7 @@ def main():
             fill_ms.append(tm["fill_ms"]); tb_ms.append(tm["traceback_ms"]); launches += tm["n_launches"]; host_ms.append(tm["host_ms"])
             dom_ms += tm["dominant_ms"]; dom_launches += tm["dominant_launches"]; fast_path = tm["fast_path"]
         torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0  # this rank's own K steps, before it waits for the others
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
@@ -630,15 +634,22 @@ def main():
             fill_ms.append(tm["fill_ms"]); tb_ms.append(tm["traceback_ms"]); launches += tm["n_launches"]
             dom_ms += tm["dominant_ms"]; dom_launches += tm["dominant_launches"]; fast_path = tm["fast_path"]
         torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
         dt_dev = dt
         step_total_ops = total_ops.value
+    rank_ms = [dt_own / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank's own time per step (before the closing barrier): a straggler rank shows in the first SCALE line
+        mine = torch.tensor([dt_own / args.steps * 1e3], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(x.item()) for x in every]
 
     def fetch(k):
         if got_main is not None and k <= n_pairs:  # the results of the last timed (host-entry) step
@@ -663,6 +674,7 @@ def main():
 
     # ---- after the timed region: verification + the other legs (rank 0) ----
     ok = True
+    gathered_pairs = n_pairs
     if n_verify > 0:
         import oracle
         k = min(n_verify, n_pairs)
@@ -676,7 +688,8 @@ def main():
         n_ops_local = int(d_off[n_pairs].item())
         gathered = shard.gather_results(d_score, d_ops[: n_ops_local * 16], d_off, dst=0)
         if rank == 0:
-            ok = ok and gathered[0].numel() == n_pairs * world and int(gathered[2][-1].item()) * 16 == gathered[1].numel()
+            gathered_pairs = int(gathered[0].numel())
+            ok = ok and gathered_pairs == n_pairs * world and int(gathered[2][-1].item()) * 16 == gathered[1].numel()
     if rank == 0:
         cells_per_step = n_pairs * READ_LEN * CHUNK_LEN * world
         value = cells_per_step * args.steps / dt
@@ -718,6 +731,9 @@ def main():
                        "pairs_per_gpu": n_pairs, "read_len": READ_LEN, "chunk_len": CHUNK_LEN, "parallelism": "pairs sharded x%d" % world,
                        "plan_cache": "the timed steps re-submit one batch, so the fast path's per-pair plans are reused on the device (see cold_plan)"},
             "pairs_per_s": n_pairs * world * args.steps / dt,
+            "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms,
+                                     "note": "each rank's own K steps / K, before the closing barrier (ms_per_step is the max-over-ranks clock around both barriers)"},
+            "gathered_pairs": gathered_pairs,
             "value_definition": ("SURVEY 8d: sum n*m over pairs / wall time of K calls of the host-buffer entry point (H2D of reads, windows and offset tables + plans + "
                                  "kernels + D2H of scores / offsets / CIGAR runs into pinned host arrays); the chunk upload is part of every call")
                                 if host_timed else "inputs and outputs resident in HBM (gnx_align_batch_device)",
@@ -785,7 +801,7 @@ def main():
             out["cpu_baseline"] = cb
         out["bit_exact_sample"] = ok
     # ---- N > 1: the one-process flow of the C ABI (gnx_init_devices) on the same GPUs, after every rank has given its memory back ----
-    if world > 1 and not args.no_extras and not args.share_gpu and S["shared"]:
+    if world > 1 and S["shared"] and ((not args.no_extras and not args.share_gpu) or args.one_process):
         d_ops = d_score = d_off = d_reads = d_chunk = d_as = d_al = d_bs = d_bl = None  # (referenced by the closures above: release, do not del)
         L.gnx_shutdown()
         torch.cuda.empty_cache()
@@ -793,7 +809,7 @@ def main():
         if rank == 0:
             t1 = time.perf_counter()
             try:
-                out["one_process"] = one_process_flow(_lib, L, world, params, reads_h, chunk_h, n_pairs, same, args.steps)
+                out["one_process"] = one_process_flow(_lib, L, world, params, reads_h, chunk_h, n_pairs, same, args.steps, args.share_gpu)
                 ok = ok and out["one_process"].get("bit_exact_sample", True)
             except Exception as e:
                 out["one_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -803,7 +819,7 @@ def main():
             w = out["one_process"].get("windows", {})
             out["one_process"]["rccl_ok"] = bool(w.get("transport") == "rccl" and w.get("rccl_ranks") == world and out["one_process"].get("contexts") == world)
             out["one_process_rccl_ok"] = out["one_process"]["rccl_ok"]  # (reported, loudly; it does not change the exit code: the headline leg stands on its own)
-            if not out["one_process"]["rccl_ok"]:
+            if not out["one_process"]["rccl_ok"] and not args.share_gpu:
                 sys.stderr.write("bench.py: the one-process leg did NOT run over RCCL with %d ranks: %r\n" % (world, w.get("transport")))
             out["bit_exact_sample"] = ok
             L.gnx_shutdown()

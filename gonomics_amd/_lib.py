@@ -11,14 +11,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNX_LIB_PATH") or os.path.join(_HERE, "libgonomics_align_hip.so")
 
-GNX_OK, GNX_EINVAL, GNX_EBASE, GNX_EEMPTY, GNX_ERANGE, GNX_EDEVICE, GNX_ENOMEM, GNX_ECAPACITY, GNX_ETRACE, GNX_EDIVZERO = range(10)
+GNX_OK, GNX_EINVAL, GNX_EBASE, GNX_EEMPTY, GNX_ERANGE, GNX_EDEVICE, GNX_ENOMEM, GNX_ECAPACITY, GNX_ETRACE, GNX_EDIVZERO, GNX_ESTALE = range(11)
 GNX_AFFINE_GAP, GNX_CONST_GAP, GNX_AFFINE_GAP_HIGHMEM, GNX_AFFINE_GAP_LOCAL, GNX_CONST_GAP_HIGHMEM = range(5)
 
 EXPORTS = ["gnx_device_count", "gnx_init", "gnx_shutdown", "gnx_last_error", "gnx_free", "gnx_align_batch",
            "gnx_align_batch_windows", "gnx_align_pair", "gnx_align_batch_device", "gnx_get_timing",
            "gnx_affine_gap_chunk_batch", "gnx_multiple_affine_gap_batch", "gnx_gsw_extend_batch",
            "gnx_init_devices", "gnx_n_devices", "gnx_set_reference", "gnx_set_reference_synthetic", "gnx_align_batch_by_offset",
-           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch", "gnx_gsw_graph_create", "gnx_gsw_graph_free", "gnx_gsw_map_reads", "gnx_debug_occupy", "gnx_debug_counter", "gnx_reference_info"]
+           "gnx_seed_index_build", "gnx_seed_index_set", "gnx_seed_find_batch", "gnx_seed_index_set_gen", "gnx_seed_find_batch_gen", "gnx_gsw_graph_create", "gnx_gsw_graph_free", "gnx_gsw_map_reads", "gnx_debug_occupy", "gnx_debug_counter", "gnx_reference_info"]
 
 
 class GnxCigar(ctypes.Structure):

@@ -1864,7 +1864,7 @@ int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const u
     PairReq self;
     self.p = p; self.a = alpha; self.n = n; self.b = beta; self.m = m;
     std::unique_lock<std::mutex> lk(g_pq_mu);
-    g_pq.push_back(&self);
+    try { g_pq.push_back(&self); } catch (...) { set_err("host allocation failed%s", ""); return GNX_ENOMEM; }
     if (g_pq_leader) g_pq_cv_arrive.notify_one(); // (a combiner may be collecting: it counts arrivals)
     while (!self.done) {
         if (g_pq_leader) { g_pq_cv.wait(lk); continue; } // a batch is on the device: this request rides in the next one
@@ -1884,17 +1884,38 @@ int gnx_align_pair(const gnx_params *p, const uint8_t *alpha, int64_t n, const u
                 seen = g_pq.size();
             }
         }
+        //  the combiner's section must not leave by an exception: the requests it took point at other callers' stack frames,
+        // and they wait for `done`.  Whatever is thrown (std::bad_alloc of the batch vectors), every request taken so far -- at the least
+        // this caller's own -- is answered with GNX_ENOMEM, the leader flag is given back and everybody is woken.
         std::vector<PairReq *> batch;
-        for (size_t k = 0; k < g_pq.size();) {
-            if (g_pq[k] == &self || memcmp(g_pq[k]->p, p, sizeof(gnx_params)) == 0) { batch.push_back(g_pq[k]); g_pq.erase(g_pq.begin() + (long)k); }
-            else k++;
-        }
+        auto same_params = [](const gnx_params *x, const gnx_params *y) { // (field by field: _reserved and padding do not keep requests apart)
+            return x->mode == y->mode && x->gap_open == y->gap_open && x->gap_extend == y->gap_extend && x->checkersize_i == y->checkersize_i &&
+                   x->checkersize_j == y->checkersize_j && memcmp(x->scores, y->scores, sizeof(x->scores)) == 0;
+        };
+        bool failed = false;
+        try {
+            batch.reserve(g_pq.size());
+            for (size_t k = 0; k < g_pq.size();) {
+                if (g_pq[k] == &self || same_params(g_pq[k]->p, p)) { batch.push_back(g_pq[k]); g_pq.erase(g_pq.begin() + (long)k); }
+                else k++;
+            }
+        } catch (...) { failed = true; }
         lk.unlock();
-        {
-            std::lock_guard<std::mutex> api(g_api_mu);
-            run_pair_batch(p, batch);
+        if (!failed) {
+            try {
+                std::lock_guard<std::mutex> api(g_api_mu);
+                run_pair_batch(p, batch);
+            } catch (...) { failed = true; }
         }
         lk.lock();
+        if (failed) {
+            bool mine = false;
+            for (PairReq *r : batch) { if (r == &self) mine = true; if (r->ops) { free(r->ops); r->ops = nullptr; } r->rc = GNX_ENOMEM; snprintf(r->err, sizeof(r->err), "host allocation failed while combining concurrent gnx_align_pair calls"); }
+            if (!mine) { // (the reserve itself failed: this request is still queued)
+                for (size_t k = 0; k < g_pq.size(); k++) if (g_pq[k] == &self) { g_pq.erase(g_pq.begin() + (long)k); break; }
+                self.rc = GNX_ENOMEM; snprintf(self.err, sizeof(self.err), "host allocation failed while combining concurrent gnx_align_pair calls"); self.done = true;
+            }
+        }
         for (PairReq *r : batch) r->done = true;
         g_pq_prev_batch = batch.size();
         g_pq_leader = false;
@@ -2047,10 +2068,25 @@ int gnx_seed_index_build(const uint8_t *node_cat, const int64_t *node_off, int64
     return GNX_OK;
 }
 
-static std::atomic<uint64_t> g_seed_sets{0}; // calls of gnx_seed_index_set so far (gsw_reads.hip.h: is a graph handle's index still the resident one?)
+// The device holds ONE resident seed index.  Every gnx_seed_index_set gives it a new GENERATION (under the API lock); a caller that must
+// be sure it searches ITS index -- the read path of a graph handle, while other threads use other handles or the raw entry points --
+// sets with gnx_seed_index_set_gen and searches with gnx_seed_find_batch_gen(generation): a search against a replaced index is refused
+// with GNX_ESTALE, inside the same lock that runs the search (the check used to sit outside it), and the caller uploads again.
+static uint64_t g_seed_gen = 0;      // generation of the resident index (0: none); guarded by g_api_mu
+static int seed_index_set_locked(const uint64_t *keys, const uint64_t *locs, int64_t n_index, const uint8_t *node_cat, const int64_t *node_off, int64_t n_nodes, int seed_len);
 int gnx_seed_index_set(const uint64_t *keys, const uint64_t *locs, int64_t n_index, const uint8_t *node_cat, const int64_t *node_off, int64_t n_nodes, int seed_len) {
     std::lock_guard<std::mutex> api(g_api_mu);
-    g_seed_sets++;
+    return seed_index_set_locked(keys, locs, n_index, node_cat, node_off, n_nodes, seed_len);
+}
+int gnx_seed_index_set_gen(const uint64_t *keys, const uint64_t *locs, int64_t n_index, const uint8_t *node_cat, const int64_t *node_off, int64_t n_nodes, int seed_len, uint64_t *out_generation) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    if (!out_generation) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    const int rc = seed_index_set_locked(keys, locs, n_index, node_cat, node_off, n_nodes, seed_len);
+    *out_generation = rc ? 0 : g_seed_gen;
+    return rc;
+}
+static int seed_index_set_locked(const uint64_t *keys, const uint64_t *locs, int64_t n_index, const uint8_t *node_cat, const int64_t *node_off, int64_t n_nodes, int seed_len) {
+    g_seed_gen++; // (also when the call fails half way: whatever was resident is not any more)
     CtxScope sc(ctx_at(0));
     g_err[0] = 0;
     if (n_index < 0 || (n_index > 0 && (!keys || !locs)) || !node_off || n_nodes < 0 || n_nodes > 0x7ffffff0 || seed_len < 2 || seed_len > 32) { set_err("bad argument%s", ""); return GNX_EINVAL; }
@@ -2079,8 +2115,17 @@ int gnx_seed_index_set(const uint64_t *keys, const uint64_t *locs, int64_t n_ind
     return GNX_OK;
 }
 
+static int seed_find_locked(const uint8_t *read_cat, const int64_t *read_off, int64_t n_reads, gnx_seed_hit **out_hits, int64_t **out_hit_off);
 int gnx_seed_find_batch(const uint8_t *read_cat, const int64_t *read_off, int64_t n_reads, gnx_seed_hit **out_hits, int64_t **out_hit_off) {
     std::lock_guard<std::mutex> api(g_api_mu);
+    return seed_find_locked(read_cat, read_off, n_reads, out_hits, out_hit_off);
+}
+int gnx_seed_find_batch_gen(uint64_t generation, const uint8_t *read_cat, const int64_t *read_off, int64_t n_reads, gnx_seed_hit **out_hits, int64_t **out_hit_off) {
+    std::lock_guard<std::mutex> api(g_api_mu);
+    if (generation == 0 || generation != g_seed_gen) { set_err("the resident seed index has been replaced since generation %s%lld was set", "", (long long)generation); return GNX_ESTALE; }
+    return seed_find_locked(read_cat, read_off, n_reads, out_hits, out_hit_off);
+}
+static int seed_find_locked(const uint8_t *read_cat, const int64_t *read_off, int64_t n_reads, gnx_seed_hit **out_hits, int64_t **out_hit_off) {
     CtxScope sc(ctx_at(0));
     g_err[0] = 0;
     if (!read_off || n_reads < 0 || n_reads > 0x3ffffff0 || !out_hits || !out_hit_off) { set_err("bad argument%s", ""); return GNX_EINVAL; }

@@ -11,8 +11,7 @@
 struct gnx_gsw_graph {
     gonomics::genomeGraph::GenomeGraph g;
     std::unique_ptr<gonomics::genomeGraph::SeedIndex> index;
-    std::mutex mu; // one batch at a time per graph (the index' resident bookkeeping)
-    uint64_t sets_seen = 0; // g_seed_sets after this graph's last batch: any other gnx_seed_index_set since then replaced the resident index
+    std::mutex mu; // one batch at a time per graph
 };
 
 extern "C" {
@@ -37,6 +36,12 @@ int gnx_gsw_graph_create(const uint8_t *node_cat, const int64_t *node_off, int64
         h->index = std::make_unique<SeedIndex>(h->g, seed_len, seed_step); // (gnx_seed_index_build on the device + the k-mers across node borders)
         *out = h.release();
         return GNX_OK;
+    } catch (const gonomics::genomeGraph::GnxFailure &e) { // a library call inside the driver failed: its own code (device, memory, ...)
+        if (!g_err[0]) set_err("%s", e.what());
+        return e.rc;
+    } catch (const std::bad_alloc &) {
+        set_err("host allocation failed%s", "");
+        return GNX_ENOMEM;
     } catch (const std::exception &e) {
         if (!g_err[0]) set_err("%s", e.what());
         return GNX_EINVAL;
@@ -62,14 +67,17 @@ int gnx_gsw_map_reads(gnx_gsw_graph *h, const uint8_t *read_cat, const int64_t *
         std::atomic<int64_t> bad{-1};
         parallelFor((size_t)n_reads, T, [&](size_t r) { // (blocks: a read's buffers belong to the worker that will drive it)
             const int64_t lo = read_off[r], hi = read_off[r + 1];
-            for (int64_t x = lo; x < hi; x++) if (read_cat[x] > 4) { bad = (int64_t)r; return; }
+            for (int64_t x = lo; x < hi; x++) if (read_cat[x] > 4) { // the LOWEST failing read is the one reported, whichever worker finds its own first
+                int64_t cur = bad.load();
+                while ((cur < 0 || (int64_t)r < cur) && !bad.compare_exchange_weak(cur, (int64_t)r)) {}
+                return;
+            }
             reads[r] = FastqBig(std::string(), Bases(read_cat + lo, read_cat + hi));
         }, /*blocks=*/true);
         if (bad >= 0) { set_err("a base >= 5 was found in read %s%lld", "", (long long)bad.load()); return GNX_EBASE; }
-        if (g_seed_sets.load() != h->sets_seen) h->index->residentGen = 0; // somebody else's index is on the device: upload again
+        // (whose index is on the device is checked by the search itself, inside the library's lock: gnx_seed_find_batch_gen)
         std::vector<Giraf> res = paired ? WrapPairGirafBatch(h->g, reads, *h->index, scores, gap_pen, nullptr, /*markPanics=*/true, threads)
                                         : GswBatchToGiraf(h->g, reads, *h->index, scores, gap_pen, nullptr, /*markPanics=*/true, threads);
-        h->sets_seen = g_seed_sets.load();
         int64_t nn = 0, nc = 0;
         for (const Giraf &g : res) if (!g.Panicked) { nn += (int64_t)g.Nodes.size(); nc += (int64_t)g.Cig.size(); }
         gnx_giraf *og = (gnx_giraf *)calloc((size_t)std::max<int64_t>(n_reads, 1), sizeof(gnx_giraf));
@@ -98,6 +106,12 @@ int gnx_gsw_map_reads(gnx_gsw_graph *h, const uint8_t *read_cat, const int64_t *
         }, /*blocks=*/true);
         *out_girafs = og; *out_nodes = on; *out_cigars = oc;
         return GNX_OK;
+    } catch (const gonomics::genomeGraph::GnxFailure &e) { // a library call inside the driver failed: its own code (device, memory, ...)
+        if (!g_err[0]) set_err("%s", e.what());
+        return e.rc;
+    } catch (const std::bad_alloc &) {
+        set_err("host allocation failed%s", "");
+        return GNX_ENOMEM;
     } catch (const std::exception &e) {
         if (!g_err[0]) set_err("%s", e.what());
         return GNX_EINVAL;

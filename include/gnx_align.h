@@ -40,12 +40,13 @@ extern "C" {
 #define GNX_EINVAL 1    /* bad argument (null pointer, negative size, unknown mode) */
 #define GNX_EBASE 2     /* a base >= 5: the Go code would panic */
 #define GNX_EEMPTY 3    /* empty sequence in a low-memory mode: the Go code would never terminate */
-#define GNX_ERANGE 4    /* lengths x penalties exceed the int32 DP range of the kernels */
+#define GNX_ERANGE 4    /* lengths x penalties exceed the int32 range of a mode that keeps absolute keys (AffineGapLocal, gapOpen > 0, chunk / graph variants; global AffineGap / ConstGap have no length limit) */
 #define GNX_EDEVICE 5   /* no HIP device / HIP runtime error */
 #define GNX_ENOMEM 6    /* host or device allocation failed / workspace too small for one pair */
 #define GNX_ECAPACITY 7 /* caller-provided device CIGAR buffer too small (device entry point) */
 #define GNX_ETRACE 8    /* impossible traceback value: the Go code would log.Fatalf */
 #define GNX_EDIVZERO 9  /* scoreColumnMatch over a column pair of gaps only: the Go code panics (integer divide by zero, multiAlign.go:101) */
+#define GNX_ESTALE 10   /* gnx_seed_find_batch_gen: the resident seed index is not the generation named (set it again) */
 
 /* align.ColType, /root/reference/align/align.go:12-18 */
 #define GNX_COL_M 0
@@ -280,6 +281,13 @@ typedef struct gnx_seed_hit {
     int32_t right;            /* its length */
 } gnx_seed_hit;
 int gnx_seed_find_batch(const uint8_t *read_cat, const int64_t *read_off, int64_t n_reads, gnx_seed_hit **out_hits, int64_t **out_hit_off);
+/* The device holds ONE resident index; gnx_seed_index_set + gnx_seed_find_batch are two calls, so another thread's set can land between
+ * them.  Callers that share the process with other users of the index (gnx_gsw_map_reads does) use this pair instead: the set returns
+ * the GENERATION it installed, the search names it and is refused with GNX_ESTALE -- inside the lock that runs the search -- when the
+ * resident index is no longer that one; the caller then sets again.  (The plain pair above stays for single-threaded callers.) */
+int gnx_seed_index_set_gen(const uint64_t *keys, const uint64_t *locs, int64_t n_index, const uint8_t *node_cat, const int64_t *node_off,
+                           int64_t n_nodes, int seed_len, uint64_t *out_generation);
+int gnx_seed_find_batch_gen(uint64_t generation, const uint8_t *read_cat, const int64_t *read_off, int64_t n_reads, gnx_seed_hit **out_hits, int64_t **out_hit_off);
 
 #ifdef __cplusplus
 }

@@ -135,8 +135,13 @@ struct GswTimings {
 };
 inline double gswNow() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// a failed library call, with its return code (so that a device failure or an allocation failure does not come out as a caller error)
+struct GnxFailure : std::runtime_error {
+    int rc;
+    GnxFailure(int r, const std::string &what) : std::runtime_error(what), rc(r) {}
+};
 inline void gnxCheck(int rc) {
-    if (rc != GNX_OK) throw std::runtime_error(std::string("libgonomics_align_hip: ") + gnx_last_error());
+    if (rc != GNX_OK) throw GnxFailure(rc, std::string("libgonomics_align_hip: ") + gnx_last_error());
 }
 
 // a situation in which the Go code panics (the process dies): reported, never papered over
@@ -265,12 +270,13 @@ inline void packNodes(const GenomeGraph &g, Bases &cat, std::vector<int64_t> &of
 }
 // IndexGenomeIntoMap (index.go:21-59) as two arrays sorted by key, equal keys in the reference's insertion order: the k-mers inside
 // nodes from the device, the few that run across node borders from the host recursion over Next edges (indexGenomeIntoMapHelper).
-inline std::mutex &gswSeedMu() { static std::mutex m; return m; }          // the library holds ONE resident index: set + find under this lock
-inline uint64_t &gswResidentGen() { static uint64_t g = 0; return g; }     // bumped by every gnx_seed_index_set of this header
 struct SeedIndex {
     int seedLen = 0, seedStep = 0;
     std::vector<uint64_t> keys, locs;
-    mutable uint64_t residentGen = 0;              // == gswResidentGen() while this index (with residentGraph's nodes) is the one on the device
+    // the library holds ONE resident index; every set gives it a new generation, and a search names the generation it expects
+    // (gnx_seed_index_set_gen / gnx_seed_find_batch_gen: checked inside the library's lock, whoever else sets an index in between)
+    mutable std::mutex residentMu;
+    mutable uint64_t residentGen = 0;              // the library's generation of this index' last upload (0: never uploaded)
     mutable const void *residentGraph = nullptr;
     SeedIndex(const GenomeGraph &g, int seed_len, int seed_step) : seedLen(seed_len), seedStep(seed_step) {
         if (seed_len < 2 || seed_len > 32) throw std::runtime_error("Error: seed length needs to be greater than 1 and less than 33.");
@@ -475,16 +481,24 @@ inline std::vector<std::vector<SeedPtr>> seedMapBatch(const SeedIndex &index, co
     gnx_seed_hit *hits = nullptr;
     int64_t *hoff = nullptr;
     {
-        std::lock_guard<std::mutex> lk(gswSeedMu());
-        if (index.residentGen == 0 || index.residentGen != gswResidentGen() || index.residentGraph != (const void *)&g) { // (a later batch against the same index: it is still there)
-            Bases ncat;
-            std::vector<int64_t> noff;
-            packNodes(g, ncat, noff);
-            gnxCheck(gnx_seed_index_set(index.keys.data(), index.locs.data(), (int64_t)index.keys.size(), ncat.data(), noff.data(), (int64_t)g.Nodes.size(), index.seedLen));
-            index.residentGen = ++gswResidentGen(); index.residentGraph = (const void *)&g;
+        std::lock_guard<std::mutex> lk(index.residentMu);
+        for (int attempt = 0;; attempt++) {
+            if (index.residentGen == 0 || index.residentGraph != (const void *)&g) { // (a later batch against the same index: it is still there -- the search will say if not)
+                Bases ncat;
+                std::vector<int64_t> noff;
+                packNodes(g, ncat, noff);
+                uint64_t gen = 0;
+                gnxCheck(gnx_seed_index_set_gen(index.keys.data(), index.locs.data(), (int64_t)index.keys.size(), ncat.data(), noff.data(), (int64_t)g.Nodes.size(), index.seedLen, &gen));
+                index.residentGen = gen; index.residentGraph = (const void *)&g;
+            }
+            const int rc = gnx_seed_find_batch_gen(index.residentGen, rcat.data(), roff.data(), (int64_t)reads.size(), &hits, &hoff);
+            if (rc == GNX_ESTALE && attempt < 8) { index.residentGen = 0; continue; } // somebody else's index is on the device now: upload again
+            gnxCheck(rc);
+            break;
         }
-        gnxCheck(gnx_seed_find_batch(rcat.data(), roff.data(), (int64_t)reads.size(), &hits, &hoff));
     }
+    for (int64_t h = 0, hn = hoff[reads.size()]; h < hn; h++) // (the hits index g.Nodes below)
+        if (hits[h].node < 0 || (size_t)hits[h].node >= g.Nodes.size()) { gnx_free(hits); gnx_free(hoff); throw std::runtime_error("seed hit outside the graph: the resident index is not this graph's"); }
     std::vector<std::vector<SeedPtr>> out(reads.size());
     const double t1 = gswNow();
     parallelFor(reads.size(), threads, [&](size_t r) {
@@ -586,11 +600,16 @@ inline CigSlice mergeRoute(CigSlice route, const gnx_cigar *runs, int64_t nRuns)
     }
     return route;
 }
-// What runs a batch of extension DPs: the library (gnx_gsw_extend_batch).  A function pointer so that a benchmark can put the CPU
-// restatement behind the same read path for a baseline beside it (tests/cpp/gsw_cpu_backend.cpp; nothing in the product sets it).
+// What runs a batch of extension DPs: the library (gnx_gsw_extend_batch), and nothing else in a product build.  Only a translation unit
+// compiled with -DGNX_TEST_BACKEND (tests/cpp/gsw_mirror_test.cpp: the CPU restatement behind the same read path, for the baseline
+// beside it) gets a settable function pointer; without the macro there is no seam to set.
 using GswExtendFn = int (*)(int, const int64_t *, int64_t, int64_t, const uint8_t *, const int64_t *, const uint8_t *, const int64_t *,
                             int64_t *, int64_t *, int64_t *, gnx_cigar **, int64_t **);
+#ifdef GNX_TEST_BACKEND
 inline GswExtendFn &gswExtendBackend() { static GswExtendFn f = gnx_gsw_extend_batch; return f; }
+#else
+inline GswExtendFn gswExtendBackend() { return gnx_gsw_extend_batch; }
+#endif
 // LeftDynamicAln / RightDynamicAln (search.go:234-321) for a batch of requests of one side
 inline std::vector<DpResult> DynamicAlnBatch(int side, const std::vector<const DpRequest *> &reqs, const int64_t *scores25, int64_t gapPen, int threads = 1, GswTimings *tm = nullptr) {
     const size_t n = reqs.size();

@@ -301,7 +301,7 @@ def test_fast_path_chunking_and_fallback(gpu_lib):
         tm = gpu_lib.get_timing()
         if os.environ.get("GNX_FASTPATH", "1") != "0" and "GNX_FP_MAXIT" not in os.environ:  # (MAXIT=0 needs more tile workspace than 12 MB)
             common.expect_route(tm, 1)
-            assert common.OUTER_ROUTE_SWITCH or tm["dominant_launches"] > 1
+            assert common.route_switched() or tm["dominant_launches"] > 1
     finally:
         gpu_lib.check(gpu_lib.lib().gnx_init(0, 8 << 30))
     common.assert_same(got, exp, "fast path, chunked")

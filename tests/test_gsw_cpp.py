@@ -25,7 +25,7 @@ def _build():
         __graft_entry__.build()
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], stdout=subprocess.DEVNULL)
     # (the CPU backend + the oracle are linked for the "cpu" baseline mode of this TEST binary only)
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", BIN, SRC,
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-DGNX_TEST_BACKEND", "-I" + os.path.join(ROOT, "include"), "-o", BIN, SRC,
                            os.path.join(ROOT, "tests", "cpp", "gsw_cpu_backend.cpp"), LIB, os.path.join(ROOT, "oracle", "liboracle.so"),
                            "-Wl,-rpath," + os.path.join(ROOT, "gonomics_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-L/opt/rocm/lib", "-lamdhip64"])
 
