@@ -30,6 +30,7 @@
 //   fp_walk.hip.h      fp_walk_kernel & co        aux_kernels.hip.h score_matrix / scale_runs / scan kernels
 //   const_long.hip.h   cl_sweep_kernel / cl_walk_kernel: constant-gap pairs without a stored direction matrix (config C5)
 //   affine_long.hip.h  the same scheme for affine pairs whose matrix does not fit     seed_kernels.hip.h  the graph aligner's index / seed search
+//   lat_fill.hip.h     lat_fill_kernel: one pair per wave (64 lanes x 2 rows), launches of few long pairs
 //   gnx_host.hip.h     host-buffer entry points: pinned staging, sub-batches, resident reference, contexts per GPU, RCCL
 //   gnx_align.hip      host orchestration + C ABI (this file)
 #include "gnx_common.hip.h"
@@ -43,6 +44,7 @@
 #include "const_long_wg.hip.h"
 #include "const_long_walk.hip.h"
 #include "affine_long.hip.h"
+#include "lat_fill.hip.h"
 #include "seed_kernels.hip.h"
 
 namespace {
@@ -140,6 +142,7 @@ thread_local Ctx *t_ctx = nullptr;
 // set while a call is re-run with sequential strips after a pipelined launch timed out waiting for a row buffer (a bug trap: nobody
 // waits for an item that has not been claimed, claim_items; should the trap ever fire, the call still returns right results)
 thread_local bool t_no_pipe = false;
+thread_local bool t_no_lat = false; // set while a call is re-run without the latency geometry (its bug trap fired)
 thread_local int64_t t_min_cols = 0; // != 0: the fast path takes windows of at least this many columns (set by a mixed batch for its groups, see run_device)
 bool no_pipe() { return t_no_pipe || getenv("GNX_NO_PIPE") != nullptr; }
 Ctx &ctx_at(int k) {
@@ -836,6 +839,105 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     return GNX_OK;
 }
 
+// The latency geometry (lat_fill.hip.h): one pair per wave, 64 lanes x 2 rows, the strips of a pair as piped workgroups; one wave per pair
+// walks the stored matrix.  For launches of few pairs (the single align.AffineGap / ConstGap call and small loops of them).
+// Returns GNX_OK, an error, or -1 when the batch should take the general path (empty sequences, workspace).
+int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp, bool affine, bool local, int64_t n_pairs,
+                   const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
+                   const int64_t *h_alen, const int64_t *h_blen,
+                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream) {
+    Ctx &c = g_ctx;
+    int rc;
+    const int np = (int)n_pairs;
+    const int Q = affine ? LQA : LQC;
+    if ((rc = c.h_plans.ensure((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(PairPlan)))) return rc;
+    PairPlan *plans = reinterpret_cast<PairPlan *>(c.h_plans.p);
+    std::vector<int2> smap;
+    std::vector<int64_t> so((size_t)np + 1, 0);
+    int64_t toff = 0, hoff = 0, roff = 0, doff = 0, cells = 0;
+    for (int64_t p = 0; p < n_pairs; p++) {
+        const int64_t n = h_alen[p], m = h_blen[p];
+        if (n < 1 || m < 1) return -1;
+        PairPlan &pl = plans[(size_t)p];
+        pl.n = (int32_t)n; pl.m = (int32_t)m;
+        pl.strips = (int32_t)((n + LH - 1) / LH);
+        pl.words = (int32_t)((m + (LG - 1) + 15) / 16);
+        pl.trace_off = toff; pl.hcol_off = hoff; pl.rowbuf_off = roff; pl.dcol_off = doff;
+        pl.src = (int32_t)p; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0;
+        toff += (int64_t)pl.strips * pl.words * Q * LG; hoff += n; roff += (int64_t)(pl.strips - 1) * (m + 1); doff += (int64_t)pl.strips * LG;
+        so[(size_t)p + 1] = so[(size_t)p] + n + m + 2;
+        cells += n * m;
+        for (int st = 0; st < pl.strips; st++) smap.push_back(make_int2((int)p, st));
+    }
+    const int64_t n_blocks = (int64_t)smap.size();
+    const size_t need = (size_t)toff * 16 + (size_t)hoff * 4 + (size_t)roff * 8 + (size_t)doff * 4 + (size_t)so[(size_t)np] * sizeof(gnx_cigar);
+    if ((int64_t)need > c.ws_limit - c.ws_limit / 8 || n_blocks > 0x3fffffff) return -1;
+    if ((rc = c.trace.ensure((size_t)std::max<int64_t>(toff, 1) * 16))) return rc;
+    if ((rc = c.hcol.ensure((size_t)std::max<int64_t>(hoff, 1) * 4))) return rc;
+    if ((rc = c.rowbuf.ensure((size_t)std::max<int64_t>(roff, 1) * 8))) return rc;
+    if ((rc = c.dcol.ensure((size_t)std::max<int64_t>(doff, 1) * 4))) return rc;
+    if ((rc = c.tb_scr.ensure((size_t)so[(size_t)np] * sizeof(gnx_cigar)))) return rc;
+    if ((rc = c.tb_scr_off.ensure(((size_t)np + 1) * 8))) return rc;
+    if ((rc = c.strip_map.ensure((size_t)n_blocks * 12 + 8))) return rc; // map, claim words, test switch
+    c.fpc_ptr = nullptr;
+    if ((rc = c.plans.ensure((size_t)np * sizeof(PairPlan)))) return rc;
+    if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
+    if ((rc = c.misc.ensure(64))) return rc;
+    int *d_err = reinterpret_cast<int *>(c.misc.p);
+    int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
+    const int2 *d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
+    int *d_claims = reinterpret_cast<int *>(reinterpret_cast<char *>(c.strip_map.p) + (size_t)n_blocks * 8);
+    HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
+    HIPCHK(hipMemcpyAsync(c.plans.p, plans, (size_t)np * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)n_blocks * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(c.tb_scr_off.p, so.data(), ((size_t)np + 1) * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemsetAsync(d_claims, 0, (size_t)n_blocks * 4 + 4, stream));
+    if (roff > 0) HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.rowbuf.p), LAT_SENT, (size_t)roff * 2, stream)); // "not written yet"
+    if ((rc = claim_test_switch(d_claims + n_blocks, stream))) return rc;
+    HIPCHK(hipStreamSynchronize(stream)); // smap / so are locals
+    const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
+    uint4 *dtrace = reinterpret_cast<uint4 *>(c.trace.p);
+    int *dh = reinterpret_cast<int *>(c.hcol.p);
+    int2 *drb = reinterpret_cast<int2 *>(c.rowbuf.p);
+    unsigned *ddc = reinterpret_cast<unsigned *>(c.dcol.p);
+    int64_t *dn = reinterpret_cast<int64_t *>(c.nops.p);
+    gnx_cigar *d_scr = reinterpret_cast<gnx_cigar *>(c.tb_scr.p);
+    const int64_t *d_so = reinterpret_cast<const int64_t *>(c.tb_scr_off.p);
+    HIPCHK(hipEventRecord(c.ev[0], stream));
+    const dim3 gridF((unsigned)n_blocks), gridP((unsigned)np), blk(64);
+#define GNX_LAT(A_, L_) hipLaunchKernelGGL((lat_fill_kernel<A_, L_>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_claims)
+    if (affine) { if (local) GNX_LAT(true, true); else GNX_LAT(true, false); }
+    else GNX_LAT(false, false);
+#undef GNX_LAT
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c.ev[1], stream));
+    if (affine) hipLaunchKernelGGL((traceback_kernel<true, false, true, true, LG, LR>), gridP, blk, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score, dn, d_so, d_scr, (int64_t)0, d_err);
+    else hipLaunchKernelGGL((traceback_kernel<false, false, true, true, LG, LR>), gridP, blk, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score, dn, d_so, d_scr, (int64_t)0, d_err);
+    HIPCHK(hipGetLastError());
+    if ((rc = launch_scan(dn, np, d_ops_off, d_carry, stream))) return rc;
+    hipLaunchKernelGGL(reverse_runs_kernel, gridP, dim3(256), 0, stream, dpl, np, d_scr, d_so, dn, d_ops_off, d_ops, ops_capacity, d_err);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c.ev[2], stream));
+    int h_misc[16];
+    HIPCHK(hipMemcpyAsync(h_misc, c.misc.p, 64, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    float f1 = 0, f2 = 0;
+    HIPCHK(hipEventElapsedTime(&f1, c.ev[0], c.ev[1]));
+    HIPCHK(hipEventElapsedTime(&f2, c.ev[1], c.ev[2]));
+    c.timing.fill_ms = f1; c.timing.traceback_ms = f2; c.timing.total_ms = f1 + f2;
+    c.timing.cells = cells; c.timing.n_launches = 1; c.timing.trace_bytes = toff * 16;
+    c.timing.dominant_ms = f1; c.timing.dominant_launches = 1; c.timing.fast_path = 3;
+    int64_t total;
+    memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
+    if (out_total) *out_total = total;
+    const int ef = h_misc[0];
+    if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
+    if (ef & 16) { if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx] a strip of the latency geometry timed out: the call runs again on the general path\n"); return -2; }
+    if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
+    if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
+    return GNX_OK;
+}
+
 // The device flow shared by all entry points.  All pointers are device pointers except h_*.
 int run_device(const gnx_params *prm, int64_t n_pairs,
                const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
@@ -881,6 +983,30 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // beyond the STATIC int32 range of the kernels' keys (4 * score, absolute): such pairs take the snapshot path with moving bases
         // (REBASE, const_long.hip.h), which has no length limit -- see the clong block below; the reference is int64 throughout (align/align.go:8)
         if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27) && first_oor < 0) first_oor = p;
+    }
+    // ---- latency geometry: few pairs (lat_fill.hip.h).  A lone wave is paced by its own instruction stream, so a launch that cannot fill
+    // the device runs one pair per wave on 64 lanes x 2 rows instead of four pairs per wave on 16 x 10: at most LAT_MAX 128-row strips in
+    // all (~2 waves per SIMD).  GNX_LAT=0 / 2: never / whenever the mode allows; the switches that force another route for the tests
+    // (GNX_FASTPATH=0 / 2, GNX_CLONG=2, GNX_FP_SMALL=1, GNX_NO_HFORM) switch the automatic choice off.
+    if (!gsw && !d_smat && first_oor < 0 && !c.beta_packed && !t_no_lat && (!affine || prm->gap_open <= 0)) {
+        const char *le = getenv("GNX_LAT");
+        const char *fpe = getenv("GNX_FASTPATH"), *cle = getenv("GNX_CLONG"), *fse = getenv("GNX_FP_SMALL");
+        const bool forced = le && le[0] == '2';
+        bool use = !(le && le[0] == '0');
+        if (!forced && ((fpe && (fpe[0] == '2' || fpe[0] == '0')) || (cle && cle[0] == '2') || (fse && fse[0] == '1') || getenv("GNX_NO_HFORM") || no_fast_path)) use = false;
+        int64_t strips = 0;
+        for (int64_t p = 0; use && p < n_pairs; p++) { if (h_alen[p] < 1 || h_blen[p] < 1) use = false; strips += (h_alen[p] + LH - 1) / LH; }
+        const int64_t lat_max = getenv("GNX_LAT_MAX") ? atoll(getenv("GNX_LAT_MAX")) : (int64_t)8 * c.n_cu;
+        if (use && (forced || strips <= lat_max)) {
+            rc = run_device_lat(prm, kp, tp, affine, local, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+            if (rc == -2) { // the bug trap of its hand-over fired: once more without it
+                t_no_lat = true;
+                rc = run_device(prm, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, d_smat, h_soff, gsw, d_endpos, no_fast_path, smat16);
+                t_no_lat = false;
+                return rc;
+            }
+            if (rc != -1) return rc;
+        }
     }
     // ---- fast path: every alpha fits one strip, long beta, global affine with gapOpen <= 0 ----
     {

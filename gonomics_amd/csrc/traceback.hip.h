@@ -16,17 +16,19 @@ struct TbParams {
 
 // direction word of cell (i,j) (1-based) for plane k (affine: 0/1/2 = M/I/D; const: 0) and the field position
 // of the cell inside it -- see the flush layout in the fill kernels.  Fields of lower columns sit at lower positions.
-template <bool AFFINE>
+// LN x RW = lanes x rows per lane of the fill that wrote the matrix: 16 x 10 (fill_affine_kernel / fill_const_kernel) or 64 x 2 (lat_fill_kernel)
+template <bool AFFINE, int LN = G, int RW = R>
 __device__ __forceinline__ unsigned load_word(const uint4 *trace, const PairPlan &pl, int k, int i, int j, int &pos) {
+    constexpr int HS = LN * RW;
     const int i0 = i - 1;
-    const int s = i0 / H, rem = i0 - s * H;
-    const int l = rem / R, r = rem - l * R;
+    const int s = i0 / HS, rem = i0 - s * HS;
+    const int l = rem / RW, r = rem - l * RW;
     const int t1 = j + l - 1;
     const int w = t1 >> 4;
     pos = t1 & 15;
-    const int d = AFFINE ? k * R + r : r;
-    const int Q = AFFINE ? QA : QC;
-    const unsigned *base = reinterpret_cast<const unsigned *>(trace + pl.trace_off + ((int64_t)(s * pl.words + w) * Q + (d >> 2)) * G + l);
+    const int d = AFFINE ? k * RW + r : r;
+    constexpr int Q = ((AFFINE ? 3 : 1) * RW + 3) / 4;
+    const unsigned *base = reinterpret_cast<const unsigned *>(trace + pl.trace_off + ((int64_t)(s * pl.words + w) * Q + (d >> 2)) * LN + l);
     return base[d & 3];
 }
 
@@ -37,7 +39,7 @@ __device__ __forceinline__ unsigned load_word(const uint4 *trace, const PairPlan
 // SCR (with COOP, WRITE = false): single pass -- the runs are also written, in traceback order, to a scratch area of n + m + 2
 // entries per pair (`ops` = scratch, `ops_off[p]` = the pair's scratch offset); reverse_runs_kernel puts them in place after the
 // scan.  A latency-bound walk is not worth doing twice.
-template <bool AFFINE, bool WRITE, bool COOP = false, bool SCR = false>
+template <bool AFFINE, bool WRITE, bool COOP = false, bool SCR = false, int LN = G, int RW = R>
 __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restrict__ plans, int n_pairs, const uint4 *__restrict__ trace,
                                                        const int *__restrict__ hcol, const unsigned *__restrict__ dcol, TbParams tp,
                                                        int64_t *__restrict__ score_out,
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
     while (i > 0 && j > 0) {
         if (j == pl.m && (!AFFINE || k == 2)) {
             // Vertical run in the last column: the packed per-lane word holds the fields of R consecutive rows.
-            const int i0 = i - 1, sl = i0 / R, r = i0 - sl * R; // sl = strip*16 + lane
+            const int i0 = i - 1, sl = i0 / RW, r = i0 - sl * RW; // sl = strip * lanes + lane
             const unsigned w = dcol[pl.dcol_off + sl];
             int tag = (int)((w >> (2 * r)) & 3u);
             if (tag == 0) { atomicOr(err, 2); break; }
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
             const int lim = min(min(i, j), 64);
             int f = 0, p2 = 0;
             unsigned wv = 0;
-            if (lane < lim) { wv = load_word<AFFINE>(trace, pl, 0, i - lane, j - lane, p2); f = (int)((wv >> (2 * p2)) & 3u); }
+            if (lane < lim) { wv = load_word<AFFINE, LN, RW>(trace, pl, 0, i - lane, j - lane, p2); f = (int)((wv >> (2 * p2)) & 3u); }
             const unsigned long long stop = __ballot(!(lane < lim && f == 3));
             const int T = stop ? __ffsll((long long)stop) - 1 : 64;
             // the cell the run stops at -- lane T's -- is the next one the walk needs: keep its word, skip the next look
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
         int pos;
         unsigned w;
         if (COOP && have_w0) { w = w0; pos = pos0; have_w0 = false; } // the diagonal look already fetched this cell's plane-0 word
-        else w = load_word<AFFINE>(trace, pl, AFFINE ? k : 0, i, j, pos);
+        else w = load_word<AFFINE, LN, RW>(trace, pl, AFFINE ? k : 0, i, j, pos);
         int tag = (int)((w >> (2 * pos)) & 3u);
         const int op = AFFINE ? k : 3 - tag;
         if (tag == 0) { atomicOr(err, 2); break; } // impossible direction: the Go code would log.Fatalf
@@ -188,14 +190,15 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
                 // the run reached the low end of its word and goes on: lane t looks at the t-th word further left (16 columns each),
                 // whole words of "came from I" are taken at once -- the 40 kb leading / trailing gaps of a read inside a long
                 // window are ~40 looks instead of 2 500 dependent loads
-                const int i0 = i - 1, s2 = i0 / H, rem = i0 - s2 * H, l2 = rem / R, r2 = rem - l2 * R;
+                constexpr int HS = LN * RW, QQ = ((AFFINE ? 3 : 1) * RW + 3) / 4;
+                const int i0 = i - 1, s2 = i0 / HS, rem = i0 - s2 * HS, l2 = rem / RW, r2 = rem - l2 * RW;
                 const int t1 = j + l2 - 1;
                 if ((t1 & 15) == 15) {
-                    const int d = AFFINE ? R + r2 : r2;
+                    const int d = AFFINE ? RW + r2 : r2;
                     const int wq = (t1 >> 4) - lane;
                     const bool ok = wq >= 0 && wq * 16 >= l2; // every field of the word is a column >= 1
                     unsigned wv = 0;
-                    if (ok) wv = reinterpret_cast<const unsigned *>(trace + pl.trace_off + ((int64_t)(s2 * pl.words + wq) * (AFFINE ? QA : QC) + (d >> 2)) * G + l2)[d & 3];
+                    if (ok) wv = reinterpret_cast<const unsigned *>(trace + pl.trace_off + ((int64_t)(s2 * pl.words + wq) * QQ + (d >> 2)) * LN + l2)[d & 3];
                     const unsigned long long stop = __ballot(!(ok && wv == 0xAAAAAAAAu));
                     const int T = stop ? __ffsll((long long)stop) - 1 : 64;
                     if (T > 0) { emit(1, 16 * (int64_t)T); j -= 16 * T; }
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairPlan *__restric
             if (up_exit && i > 0 && j > 0) {
                 // quirk Q1 (affineGap.go:305): entering a tile from below restarts in the argmax state of the entry cell
                 int ht;
-                if (j < pl.m) { int p2; ht = (int)((load_word<true>(trace, pl, 0, i + 1, j + 1, p2) >> (2 * p2)) & 3u); }
+                if (j < pl.m) { int p2; ht = (int)((load_word<true, LN, RW>(trace, pl, 0, i + 1, j + 1, p2) >> (2 * p2)) & 3u); }
                 else ht = hcol[pl.hcol_off + i - 1] & 3;
                 k = 3 - ht;
             }

@@ -272,4 +272,6 @@ def route_switched():
 def expect_route(timing, route):
     if OUTER_ROUTE_SWITCH or (route == 1 and shipped_small_batch_rule()):
         return
+    if route == 0 and timing["fast_path"] == 3:  # the stored-matrix family: small launches run it in the latency geometry (lat_fill_kernel)
+        return
     assert timing["fast_path"] == route, (timing["fast_path"], route)
