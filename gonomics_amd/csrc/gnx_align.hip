@@ -850,14 +850,21 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
     int rc;
     const int np = (int)n_pairs;
     const int Q = affine ? LQA : LQC;
-    if ((rc = c.h_plans.ensure((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(PairPlan)))) return rc;
-    PairPlan *plans = reinterpret_cast<PairPlan *>(c.h_plans.p);
-    std::vector<int2> smap;
-    std::vector<int64_t> so((size_t)np + 1, 0);
-    int64_t toff = 0, hoff = 0, roff = 0, doff = 0, cells = 0;
+    int64_t n_blocks = 0;
+    for (int64_t p = 0; p < n_pairs; p++) { if (h_alen[p] < 1 || h_blen[p] < 1) return -1; n_blocks += (h_alen[p] + LH - 1) / LH; }
+    if (n_blocks > 0x3fffffff) return -1;
+    // plans, staging offsets and the strip map are built in ONE pinned host block and go up in one copy (a single pair per call is the
+    // common case here: every separate copy or synchronisation is ~10 us of a ~200 us call); the claim words follow them on the device
+    const size_t o_so = (size_t)np * sizeof(PairPlan), o_map = o_so + ((size_t)np + 1) * 8, o_claims = o_map + (size_t)n_blocks * 8, meta_b = o_claims + (size_t)n_blocks * 4 + 8;
+    if ((rc = c.h_plans.ensure(o_claims))) return rc;
+    char *hm = reinterpret_cast<char *>(c.h_plans.p);
+    PairPlan *plans = reinterpret_cast<PairPlan *>(hm);
+    int64_t *so = reinterpret_cast<int64_t *>(hm + o_so);
+    int2 *smap = reinterpret_cast<int2 *>(hm + o_map);
+    int64_t toff = 0, hoff = 0, roff = 0, doff = 0, cells = 0, nb = 0;
+    so[0] = 0;
     for (int64_t p = 0; p < n_pairs; p++) {
         const int64_t n = h_alen[p], m = h_blen[p];
-        if (n < 1 || m < 1) return -1;
         PairPlan &pl = plans[(size_t)p];
         pl.n = (int32_t)n; pl.m = (int32_t)m;
         pl.strips = (int32_t)((n + LH - 1) / LH);
@@ -867,34 +874,30 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
         toff += (int64_t)pl.strips * pl.words * Q * LG; hoff += n; roff += (int64_t)(pl.strips - 1) * (m + 1); doff += (int64_t)pl.strips * LG;
         so[(size_t)p + 1] = so[(size_t)p] + n + m + 2;
         cells += n * m;
-        for (int st = 0; st < pl.strips; st++) smap.push_back(make_int2((int)p, st));
+        for (int st = 0; st < pl.strips; st++) smap[(size_t)nb++] = make_int2((int)p, st);
     }
-    const int64_t n_blocks = (int64_t)smap.size();
-    const size_t need = (size_t)toff * 16 + (size_t)hoff * 4 + (size_t)roff * 8 + (size_t)doff * 4 + (size_t)so[(size_t)np] * sizeof(gnx_cigar);
-    if ((int64_t)need > c.ws_limit - c.ws_limit / 8 || n_blocks > 0x3fffffff) return -1;
+    const int64_t n_scr = so[(size_t)np];
+    const size_t need = (size_t)toff * 16 + (size_t)hoff * 4 + (size_t)roff * 8 + (size_t)doff * 4 + (size_t)n_scr * sizeof(gnx_cigar);
+    if ((int64_t)need > c.ws_limit - c.ws_limit / 8) return -1;
     if ((rc = c.trace.ensure((size_t)std::max<int64_t>(toff, 1) * 16))) return rc;
     if ((rc = c.hcol.ensure((size_t)std::max<int64_t>(hoff, 1) * 4))) return rc;
     if ((rc = c.rowbuf.ensure((size_t)std::max<int64_t>(roff, 1) * 8))) return rc;
     if ((rc = c.dcol.ensure((size_t)std::max<int64_t>(doff, 1) * 4))) return rc;
-    if ((rc = c.tb_scr.ensure((size_t)so[(size_t)np] * sizeof(gnx_cigar)))) return rc;
-    if ((rc = c.tb_scr_off.ensure(((size_t)np + 1) * 8))) return rc;
-    if ((rc = c.strip_map.ensure((size_t)n_blocks * 12 + 8))) return rc; // map, claim words, test switch
+    if ((rc = c.tb_scr.ensure((size_t)n_scr * sizeof(gnx_cigar)))) return rc;
     c.fpc_ptr = nullptr;
-    if ((rc = c.plans.ensure((size_t)np * sizeof(PairPlan)))) return rc;
+    if ((rc = c.plans.ensure(meta_b))) return rc;
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
     if ((rc = c.misc.ensure(64))) return rc;
+    char *dm = reinterpret_cast<char *>(c.plans.p);
     int *d_err = reinterpret_cast<int *>(c.misc.p);
     int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
-    const int2 *d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
-    int *d_claims = reinterpret_cast<int *>(reinterpret_cast<char *>(c.strip_map.p) + (size_t)n_blocks * 8);
+    const int2 *d_smap = reinterpret_cast<const int2 *>(dm + o_map);
+    int *d_claims = reinterpret_cast<int *>(dm + o_claims);
     HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
-    HIPCHK(hipMemcpyAsync(c.plans.p, plans, (size_t)np * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)n_blocks * 8, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(c.tb_scr_off.p, so.data(), ((size_t)np + 1) * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(dm, hm, o_claims, hipMemcpyHostToDevice, stream)); // (pinned: no synchronisation needed; every call ends with one)
     HIPCHK(hipMemsetAsync(d_claims, 0, (size_t)n_blocks * 4 + 4, stream));
     if (roff > 0) HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.rowbuf.p), LAT_SENT, (size_t)roff * 2, stream)); // "not written yet"
     if ((rc = claim_test_switch(d_claims + n_blocks, stream))) return rc;
-    HIPCHK(hipStreamSynchronize(stream)); // smap / so are locals
     const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
     uint4 *dtrace = reinterpret_cast<uint4 *>(c.trace.p);
     int *dh = reinterpret_cast<int *>(c.hcol.p);
@@ -902,7 +905,7 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
     unsigned *ddc = reinterpret_cast<unsigned *>(c.dcol.p);
     int64_t *dn = reinterpret_cast<int64_t *>(c.nops.p);
     gnx_cigar *d_scr = reinterpret_cast<gnx_cigar *>(c.tb_scr.p);
-    const int64_t *d_so = reinterpret_cast<const int64_t *>(c.tb_scr_off.p);
+    const int64_t *d_so = reinterpret_cast<const int64_t *>(dm + o_so);
     HIPCHK(hipEventRecord(c.ev[0], stream));
     const dim3 gridF((unsigned)n_blocks), gridP((unsigned)np), blk(64);
 #define GNX_LAT(A_, L_) hipLaunchKernelGGL((lat_fill_kernel<A_, L_>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_claims)

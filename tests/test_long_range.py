@@ -139,26 +139,46 @@ def test_range_error_where_it_remains(gpu_lib):
     assert ei.value.code == gpu_lib.GNX_ERANGE
 
 
-@pytest.mark.parametrize("what", ["affine_1Mb_x_1Mb", "const_300kb_x_2Mb"])
-def test_megabase_pairs(gpu_lib, what):
+def _long_pairs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("long_pairs", os.path.join(common.HERE, "..", "tools", "long_pairs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("case", ["const_150k", "affine_340k"])
+def test_long_pairs_equal_the_oracle(gpu_lib, case):
+    """the callers' own parameters at lengths where the keys leave int32 (ConstGap 150 000 x 180 009: 4 (score - g (n + m)) = 5.7e8;
+    AffineGap 340 000 x 339 906: 5.3e8): score, number of runs and sha256 of the CIGAR equal what the CPU oracle produced in 185 s / 895 s
+    of one core (tests/golden/long_pairs.json, written by `python tools/long_pairs.py oracle`; the pairs are seeded, tools/long_pairs.py gen)"""
+    import json
+    lp = _long_pairs()
+    with open(lp.FIXTURE) as fh:
+        fx = json.load(fh)[case]
+    affine, a, b = lp.gen(case)
+    assert (a.shape[0], b.shape[0]) == (fx["n"], fx["m"])
+    sc, go, ge = lp.params(affine)
+    p = gpu_lib.make_params(0 if affine else 1, sc, go, ge, 10000, 10000)
+    gpu_lib.check(gpu_lib.lib().gnx_init(0, 0))
+    score, ops, off = gpu_lib.align_batch(p, [a], [b])
+    assert gpu_lib.get_timing()["fast_path"] == 2
+    assert lp.digest(score[0], ops) == {k: fx[k] for k in ("score", "runs", "sha256")}
+
+
+@pytest.mark.parametrize("case", ["affine_1M", "const_300k_2M"])
+def test_megabase_pairs(gpu_lib, case):
     """one 1 Mb x 1 Mb AffineGap pair (1e12 cells) and one 300 kb x 2 Mb ConstGap pair (6e11 cells), the callers' parameters and
     10 000 x 10 000 checkerboards (cmd/cigarToBed/cigarToBed.go:86; .MISSING_LARGE_BLOBS:1-3 lists a 5 Mb fixture the reference ships):
-    the CIGAR consumes both sequences and re-scores in int64 to the returned score; rows written to profiles/ by tools/long_pairs.py"""
-    rng = np.random.default_rng(1234)
-    sc = MX["HumanChimpTwo"]
+    no oracle finishes these -- the CIGAR consumes both sequences and re-scores in int64 to the returned score (timings: tools/long_pairs.py gpu
+    -> profiles/r5_long_pairs.jsonl)"""
+    lp = _long_pairs()
+    affine, a, b = lp.gen(case)
+    sc, go, ge = lp.params(affine)
     gpu_lib.check(gpu_lib.lib().gnx_init(0, 0))
-    if what.startswith("affine"):
-        a, b = _related(rng, 1000000, 0, sub=0.02, indel=0.002)
-        p = gpu_lib.make_params(0, sc, -600, -150, 10000, 10000)
-        score, ops, off = gpu_lib.align_batch(p, [a], [b])
-        ni, nj, total = rescore_affine(a, b, ops, sc, -600, -150)
-    else:
-        win = rng.integers(0, 4, size=2000000).astype(np.uint8)
-        a = common.mutate(rng, win[700000:700000 + 300000 + 3000], sub=0.03, indel=0.004, geo=0.5)[:300000]
-        b = win
-        p = gpu_lib.make_params(1, sc, -430, 0, 10000, 10000)
-        score, ops, off = gpu_lib.align_batch(p, [a], [b])
-        ni, nj, total = rescore_const(a, b, ops, sc, -430)
+    p = gpu_lib.make_params(0 if affine else 1, sc, go, ge, 10000, 10000)
+    score, ops, off = gpu_lib.align_batch(p, [a], [b])
+    ni, nj, total = rescore_affine(a, b, ops, sc, go, ge) if affine else rescore_const(a, b, ops, sc, go)
     assert gpu_lib.get_timing()["fast_path"] == 2
     assert (ni, nj) == (a.shape[0], b.shape[0])
     assert total == int(score[0])
