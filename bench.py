@@ -418,6 +418,20 @@ def extra_gsw(_lib, L, scores, chunk_h, dev, torch, n_reads=20000, n_check=48):
             "checked_against": "tests/pyref_gsw.py (sequential restatement of toGiraf.go:17-72 with the oracle's DPs)"}
 
 
+def extra_n1(_lib, L, scores, chunk_h, dev, torch):
+    """N1 on the workload cmd/faChunkAlign really runs: a whole align.AllSeqAffineChunk -- 8 sequences x 30 kb, chunk 3,
+    gapOpen -300, gapExtend -40, multi-fasta in / multi-fasta out through gonomics_amd.cmds.faChunkAlign -- with the fill kernel's roofline
+    (6 bits per chunk cell) and the CPU oracle on first-round pairs beside it (tools/bench_n1_cmd.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_n1_cmd
+    cold = bench_n1_cmd.run(8, 30000, 3, cpu_pairs=0)          # first use: 11 GB of score matrices and direction words are allocated
+    out = bench_n1_cmd.run(8, 30000, 3, cpu_pairs=min(4, os.cpu_count() or 1))
+    out["command_s_first_use"] = cold["command_s"]
+    pr = out.pop("per_round")
+    out["per_round_ms"] = [{"pairs": r["pairs"], "call": round(r["call_s"] * 1e3, 2), "fill": round(r["fill_ms"], 2), "traceback": round(r["traceback_ms"], 2), "path": r["path"]} for r in pr]
+    return out
+
+
 def one_process_flow(_lib, L, world, params, reads_h, chunk_h, n_pairs, same, steps, share_gpu=False):
     """SURVEY 8e, second form: ONE host process, one context per GPU behind the C ABI (what a Go program gets).  Rank 0 runs it on
     all `world` GPUs after the other ranks have released theirs: `world` x n_pairs reads against the shared chunk (broadcast over
@@ -780,7 +794,7 @@ def main():
             d_ops = None  # the extra legs need the memory (C3: 10 M reads of results on the device; C5: 70 GB of snapshots)
             torch.cuda.empty_cache()
             failed = []
-            for name, fn in (("north_star_1M", extra_north_star), ("c3", extra_c3), ("c3_10M", extra_c3_10m), ("c5", extra_c5), ("gsw_reads", extra_gsw)):
+            for name, fn in (("north_star_1M", extra_north_star), ("c3", extra_c3), ("c3_10M", extra_c3_10m), ("c5", extra_c5), ("n1", extra_n1), ("gsw_reads", extra_gsw)):
                 t1 = time.perf_counter()
                 try:
                     out[name] = fn(_lib, L, scores, chunk_h, dev, torch)

@@ -12,7 +12,7 @@ namespace {
 //     scoreColumnMatch = (sum over sequence pairs, lower case folded, gap columns skipped) / count, Go integer division
 // ------------------------------------------------------------------------------------------------------
 struct GroupDesc { int64_t off; int32_t nseq; int32_t len; };
-struct ScorePair { int64_t a_off, b_off; int32_t a_nseq, b_nseq, a_len, b_len; int32_t nc, mc; int64_t s_off, s_pitch; };
+struct ScorePair { int64_t a_off, b_off; int32_t a_nseq, b_nseq, a_len, b_len; int32_t nc, mc; int64_t s_off, s_pitch; int64_t pa_off, pb_off; }; // pa_off / pb_off: column profiles of the two groups (score_profiles_kernel), in entries
 
 // S16: every 4*score fits int16 (host check: 4 * chunk * max|score| <= 32767) -- the matrix is stored as int16, which halves the
 // HBM traffic of the SCORED fill (it reads one entry per cell and is bandwidth-bound with 4-byte entries)
@@ -109,6 +109,99 @@ __global__ __launch_bounds__(256) void score_matrix_pairs_kernel(const ScorePair
         }
     }
     if (bad) atomicOr(err, 1);
+}
+
+// ---- groups, round 5: column profiles instead of a loop over all sequence pairs per cell ---------------------------------------------
+// scoreColumnMatch(u, v) = (sum over members x of A and y of B, gaps skipped, lower case folded, of scores[a_x(u)][b_y(v)]) / count
+//                        = (sum_a cntA[u][a] * wB[v][a]) / (nA(u) * nB(v)),   wB[v][a] = sum_b scores[a][b] * cntB[v][b]
+// with cnt = how many members show base a in the column and n = how many show a base at all: five multiply-adds and one truncating
+// division per column pair whatever the group sizes (and no division at all while both groups are single sequences: the first round of
+// AllSeqAffineChunk).  The old kernel above walked every member pair of every cell with 64-bit arithmetic: 25 ms for the 28 pairs of 10 000 x
+// 10 000 chunk cells of a cmd/faChunkAlign round, three times the DP itself.
+struct ColProfA { short cnt[5]; short n; short bad; short pad; };          // 16 B per column of group A
+struct ColProfB { int w[5]; int n; int bad; int pad; };                     // 32 B per column of group B
+__global__ __launch_bounds__(256) void score_profiles_kernel(const ScorePair *__restrict__ sp, const uint8_t *__restrict__ bases, KParams kp,
+                                                            ColProfA *__restrict__ pa, ColProfB *__restrict__ pb) {
+    __shared__ int sc[25];
+    if (threadIdx.x < 25) sc[threadIdx.x] = kp.sc4[threadIdx.x] / 4;
+    __syncthreads();
+    const ScorePair q = sp[blockIdx.y];
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < (int64_t)q.a_len + q.b_len; x += (int64_t)gridDim.x * blockDim.x) {
+        const bool isb = x >= q.a_len;
+        const int col = (int)(isb ? x - q.a_len : x), nseq = isb ? q.b_nseq : q.a_nseq, len = isb ? q.b_len : q.a_len;
+        const uint8_t *src = bases + (isb ? q.b_off : q.a_off) + col;
+        int cnt[5] = {0, 0, 0, 0, 0}, bad = 0;
+        for (int m = 0; m < nseq; m++) {
+            int a = src[(int64_t)m * len];
+            if (a >= 5 && a <= 9) a -= 5; // lower case -> upper case (multiAlign.go:87-94)
+            if (a == 10) continue;        // dna.Gap
+            if (a > 10) { bad = 1; continue; }
+#pragma unroll
+            for (int z = 0; z < 5; z++) cnt[z] += (a == z);
+        }
+        const int n = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4];
+        if (!isb) {
+            ColProfA o;
+#pragma unroll
+            for (int z = 0; z < 5; z++) o.cnt[z] = (short)cnt[z];
+            o.n = (short)n; o.bad = (short)bad; o.pad = 0;
+            pa[q.pa_off + col] = o;
+        } else {
+            ColProfB o;
+#pragma unroll
+            for (int a = 0; a < 5; a++) { int w = 0; for (int b = 0; b < 5; b++) w += sc[a * 5 + b] * cnt[b]; o.w[a] = w; }
+            o.n = n; o.bad = bad; o.pad = 0;
+            pb[q.pb_off + col] = o;
+        }
+    }
+}
+// block = 64 x 4 threads: x = groups of four chunk rows (their column profiles stay in registers), y = 4 chunk columns; see score_matrix_pairs_kernel
+template <bool S16, int CH>
+__global__ __launch_bounds__(256) void score_matrix_groups_kernel(const ScorePair *__restrict__ sp, KParams kp, int bias4, const ColProfA *__restrict__ pa,
+                                                                  const ColProfB *__restrict__ pb, int *__restrict__ smat, int *__restrict__ err) {
+    const ScorePair q = sp[blockIdx.y];
+    const bool single = q.a_nseq == 1 && q.b_nseq == 1; // every count is 0 or 1: no division
+    int flags = 0;
+    for (int i0 = threadIdx.x * 4; i0 < q.nc; i0 += 256) {
+        short ca[4][CH][5];
+        int na[4][CH];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                ColProfA o;
+                if (i0 + r < q.nc) o = pa[q.pa_off + (int64_t)(i0 + r) * CH + k];
+                else { for (int z = 0; z < 5; z++) o.cnt[z] = 0; o.n = 1; o.bad = 0; } // (rows nc .. of the last group of four lie inside the pitch and are never read)
+#pragma unroll
+                for (int z = 0; z < 5; z++) ca[r][k][z] = o.cnt[z];
+                na[r][k] = o.n;
+                flags |= o.bad ? 1 : 0;
+            }
+        }
+        for (int j = blockIdx.x * 4 + threadIdx.y; j < q.mc; j += gridDim.x * 4) {
+            int out[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const ColProfB o = pb[q.pb_off + (int64_t)j * CH + k];
+                flags |= o.bad ? 1 : 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int sum = 0;
+#pragma unroll
+                    for (int z = 0; z < 5; z++) sum += (int)ca[r][k][z] * o.w[z];
+                    const int count = na[r][k] * o.n;
+                    if (count == 0) { if (i0 + r < q.nc) flags |= 16; continue; } // Go: integer divide by zero (multiAlign.go:101)
+                    out[r] += single ? sum : sum / count;                     // Go's truncating division
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[r] = 4 * out[r] + bias4;
+            const int64_t at = q.s_off + (int64_t)j * q.s_pitch + i0;
+            if (S16) *reinterpret_cast<uint2 *>(reinterpret_cast<short *>(smat) + at) = make_uint2((unsigned)(out[0] & 0xffff) | ((unsigned)out[1] << 16), (unsigned)(out[2] & 0xffff) | ((unsigned)out[3] << 16));
+            else *reinterpret_cast<int4 *>(smat + at) = make_int4(out[0], out[1], out[2], out[3]);
+        }
+    }
+    if (flags) atomicOr(err, flags);
 }
 
 __global__ __launch_bounds__(256) void scale_runs_kernel(gnx_cigar *__restrict__ ops, int64_t total, int64_t factor) {

@@ -121,7 +121,7 @@ struct Ctx {
     PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
     // the resident reference, PACKED (gnx_host.hip.h: pack_reference): `ref` = 2 bits per base, ref_flag / ref_rank / ref_exc = the
     // sparse list of bases that are not A C G T (KParams::b2 / bflag / brank / bexc)
-    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off, cl_bases;
+    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off, cl_bases, sc_prof_a, sc_prof_b;
     int64_t ref_len = -1;  // >= 0: a reference of that many bases is resident
     int64_t ref_nexc = 0;  // 64-base blocks with an exception
     int64_t ref_epoch = 0; // which gnx_set_reference call filled it (contexts created later are brought up to date on first use)
@@ -845,7 +845,9 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
 int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp, bool affine, bool local, int64_t n_pairs,
                    const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                    const int64_t *h_alen, const int64_t *h_blen,
-                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream) {
+                   int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream,
+                   const int *d_smat = nullptr, const int64_t *h_soff = nullptr, bool smat16 = false) {
+    // d_smat / h_soff: explicit score matrices (the chunk / multiple-alignment variants): lat_fill_kernel<.., SCORED>
     Ctx &c = g_ctx;
     int rc;
     const int np = (int)n_pairs;
@@ -871,6 +873,7 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
         pl.words = (int32_t)((m + (LG - 1) + 15) / 16);
         pl.trace_off = toff; pl.hcol_off = hoff; pl.rowbuf_off = roff; pl.dcol_off = doff;
         pl.src = (int32_t)p; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0;
+        if (h_soff) { pl.s_off = h_soff[p]; pl.s_pitch = (int64_t)((n + H - 1) / H) * H; } // (the matrices are laid out for the general path's 160-row strips)
         toff += (int64_t)pl.strips * pl.words * Q * LG; hoff += n; roff += (int64_t)(pl.strips - 1) * (m + 1); doff += (int64_t)pl.strips * LG;
         so[(size_t)p + 1] = so[(size_t)p] + n + m + 2;
         cells += n * m;
@@ -909,7 +912,11 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
     HIPCHK(hipEventRecord(c.ev[0], stream));
     const dim3 gridF((unsigned)n_blocks), gridP((unsigned)np), blk(64);
 #define GNX_LAT(A_, L_) hipLaunchKernelGGL((lat_fill_kernel<A_, L_>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_claims)
-    if (affine) { if (local) GNX_LAT(true, true); else GNX_LAT(true, false); }
+    if (d_smat) {
+        if (smat16) hipLaunchKernelGGL((lat_fill_kernel<true, false, true, true>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_claims, d_smat);
+        else hipLaunchKernelGGL((lat_fill_kernel<true, false, true, false>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_claims, d_smat);
+    }
+    else if (affine) { if (local) GNX_LAT(true, true); else GNX_LAT(true, false); }
     else GNX_LAT(false, false);
 #undef GNX_LAT
     HIPCHK(hipGetLastError());
@@ -989,9 +996,9 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     }
     // ---- latency geometry: few pairs (lat_fill.hip.h).  A lone wave is paced by its own instruction stream, so a launch that cannot fill
     // the device runs one pair per wave on 64 lanes x 2 rows instead of four pairs per wave on 16 x 10: at most LAT_MAX 128-row strips in
-    // all (~2 waves per SIMD).  GNX_LAT=0 / 2: never / whenever the mode allows; the switches that force another route for the tests
+    // all (~3.5 waves per SIMD: profiles/r5_lat_crossover.jsonl).  GNX_LAT=0 / 2: never / whenever the mode allows; the switches that force another route for the tests
     // (GNX_FASTPATH=0 / 2, GNX_CLONG=2, GNX_FP_SMALL=1, GNX_NO_HFORM) switch the automatic choice off.
-    if (!gsw && !d_smat && first_oor < 0 && !c.beta_packed && !t_no_lat && (!affine || prm->gap_open <= 0)) {
+    if (!gsw && first_oor < 0 && !c.beta_packed && !t_no_lat && (!affine || prm->gap_open <= 0) && !(d_smat && getenv("GNX_NO_HFORM"))) {
         const char *le = getenv("GNX_LAT");
         const char *fpe = getenv("GNX_FASTPATH"), *cle = getenv("GNX_CLONG"), *fse = getenv("GNX_FP_SMALL");
         const bool forced = le && le[0] == '2';
@@ -999,9 +1006,9 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         if (!forced && ((fpe && (fpe[0] == '2' || fpe[0] == '0')) || (cle && cle[0] == '2') || (fse && fse[0] == '1') || getenv("GNX_NO_HFORM") || no_fast_path)) use = false;
         int64_t strips = 0;
         for (int64_t p = 0; use && p < n_pairs; p++) { if (h_alen[p] < 1 || h_blen[p] < 1) use = false; strips += (h_alen[p] + LH - 1) / LH; }
-        const int64_t lat_max = getenv("GNX_LAT_MAX") ? atoll(getenv("GNX_LAT_MAX")) : (int64_t)8 * c.n_cu;
+        const int64_t lat_max = getenv("GNX_LAT_MAX") ? atoll(getenv("GNX_LAT_MAX")) : (int64_t)14 * c.n_cu; // (measured crossovers, tools/lat_crossover.py: 150 x 10 000 ~3 600 strips, 10 kb x 10 kb ~4 000, 1 kb x 1 kb and 3 kb x 3 kb beyond 8 000)
         if (use && (forced || strips <= lat_max)) {
-            rc = run_device_lat(prm, kp, tp, affine, local, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+            rc = run_device_lat(prm, kp, tp, affine, local, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, d_smat, h_soff, smat16);
             if (rc == -2) { // the bug trap of its hand-over fired: once more without it
                 t_no_lat = true;
                 rc = run_device(prm, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, d_smat, h_soff, gsw, d_endpos, no_fast_path, smat16);
@@ -1398,7 +1405,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // few, long pairs: one wave per pair, diagonal runs 64 cells at a time (traceback_kernel<.., COOP>)
         int64_t lmax = 0;
         for (int64_t q2 = b; q2 < e; q2++) lmax = std::max<int64_t>(lmax, std::max<int64_t>(plans[(size_t)q2].n, plans[(size_t)q2].m));
-        const bool coop = !gsw && np <= 2048 && lmax >= 1024;
+        const bool coop = !gsw && np <= 4096 && lmax >= 256; // (round 5: 1 024 pairs of 1 kb x 1 kb -- one lane per pair 1.3 ms, one wave per pair 0.2 ms)
         const dim3 gridC((unsigned)np);
         // ... in a single pass when the staging area (n + m + 2 runs per pair) is small next to the workspace
         bool scr = false;
@@ -1498,12 +1505,14 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     const int64_t bias4 = hform_sc ? -8 * prm2.gap_extend : 0;
     const bool s16 = 4 * chunk * smax + llabs((long long)bias4) <= 32767;
     std::vector<int64_t> hn((size_t)n_pairs), hm((size_t)n_pairs), hso((size_t)n_pairs);
-    int64_t stot = 0, worst = 0, maxcols = 1, maxrows = 1;
+    int64_t stot = 0, worst = 0, maxcols = 1, maxrows = 1, prof_a = 0, prof_b = 0, max_nseq = 1;
     for (int64_t p = 0; p < n_pairs; p++) {
         ScorePair &q = sp[(size_t)p];
         maxrows = std::max<int64_t>(maxrows, q.nc);
         const int64_t strips = std::max<int64_t>((q.nc + H - 1) / H, 1);
         q.s_pitch = strips * H; q.s_off = stot;
+        q.pa_off = prof_a; q.pb_off = prof_b; prof_a += q.a_len; prof_b += q.b_len; // (groups: column profiles, score_profiles_kernel)
+        max_nseq = std::max<int64_t>(max_nseq, std::max(q.a_nseq, q.b_nseq));
         stot += (int64_t)q.mc * q.s_pitch;
         hn[(size_t)p] = q.nc; hm[(size_t)p] = q.mc; hso[(size_t)p] = q.s_off;
         worst += q.nc + q.mc + 1;
@@ -1511,7 +1520,7 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     }
     if ((rc = c.in_a.ensure((size_t)(bases_len + bases2_len) + 16))) return rc;
     if ((rc = c.sc_pairs.ensure((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(ScorePair)))) return rc;
-    if ((rc = c.sc_mat.ensure((size_t)std::max<int64_t>(stot, 1) * 4))) return rc;
+    if ((rc = c.sc_mat.ensure((size_t)std::max<int64_t>(stot, 1) * 4 + 4096))) return rc; // (+ slack: the latency geometry's last strip reads up to 127 padding rows past a column)
     if ((rc = c.sc_err.ensure(16))) return rc;
     const size_t np = (size_t)std::max<int64_t>(n_pairs, 1);
     if ((rc = c.out_score.ensure(np * 8))) return rc;
@@ -1576,11 +1585,30 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     const ScorePair *spd0 = reinterpret_cast<const ScorePair *>(c.sc_pairs.p);
     const uint8_t *bd = reinterpret_cast<const uint8_t *>(c.in_a.p);
     int *sm = reinterpret_cast<int *>(c.sc_mat.p), *se = reinterpret_cast<int *>(c.sc_err.p);
+    // groups with chunk <= 4: column profiles (score_profiles_kernel + score_matrix_groups_kernel)
+    // (int32 sums: members(A) x members(B) x max|score| must fit; int16 counts)
+    const bool use_prof = groups && chunk <= 4 && max_nseq < 30000 && max_nseq * max_nseq * std::max<int64_t>(smax, 1) < ((int64_t)1 << 31) && !getenv("GNX_SCORE_GENERIC");
+    if (use_prof) {
+        if ((rc = c.sc_prof_a.ensure((size_t)std::max<int64_t>(prof_a, 1) * sizeof(ColProfA)))) return rc;
+        if ((rc = c.sc_prof_b.ensure((size_t)std::max<int64_t>(prof_b, 1) * sizeof(ColProfB)))) return rc;
+    }
     auto score_matrices = [&](int64_t p0, int64_t p1) {
         for (int64_t b = p0; b < p1; b += 32768) {
             const unsigned ny = (unsigned)std::min<int64_t>(32768, p1 - b);
             const unsigned nx = (unsigned)std::min<int64_t>((maxcols + 3) / 4, 1024);
             const ScorePair *spd = spd0 + b;
+            if (use_prof) {
+                const ColProfA *dpa = reinterpret_cast<const ColProfA *>(c.sc_prof_a.p);
+                const ColProfB *dpb = reinterpret_cast<const ColProfB *>(c.sc_prof_b.p);
+                hipLaunchKernelGGL(score_profiles_kernel, dim3((unsigned)std::min<int64_t>((maxrows + maxcols) * chunk / 256 + 1, 512), ny), dim3(256), 0, st, spd, bd, kp0,
+                                   reinterpret_cast<ColProfA *>(c.sc_prof_a.p), reinterpret_cast<ColProfB *>(c.sc_prof_b.p));
+                const dim3 grid((unsigned)std::min<int64_t>((maxcols + 63) / 64, 1024), ny), blk(64, 4);
+#define GNX_SMG(S, C) hipLaunchKernelGGL((score_matrix_groups_kernel<S, C>), grid, blk, 0, st, spd, kp0, (int)bias4, dpa, dpb, sm, se)
+                if (s16) { if (chunk == 1) GNX_SMG(true, 1); else if (chunk == 2) GNX_SMG(true, 2); else if (chunk == 3) GNX_SMG(true, 3); else GNX_SMG(true, 4); }
+                else { if (chunk == 1) GNX_SMG(false, 1); else if (chunk == 2) GNX_SMG(false, 2); else if (chunk == 3) GNX_SMG(false, 3); else GNX_SMG(false, 4); }
+#undef GNX_SMG
+                continue;
+            }
             if (!groups && chunk <= 4 && maxrows * chunk < ((int64_t)1 << 30) && maxcols * chunk < ((int64_t)1 << 30) && !getenv("GNX_SCORE_GENERIC")) {
                 // a block walks ~16 column quads, so that the rows' bases it keeps in registers are loaded once per 64 columns
                 const dim3 grid((unsigned)std::min<int64_t>((maxcols + 63) / 64, 1024), ny), blk(64, 4);
@@ -1618,6 +1646,7 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
         if (rc) return rc;
         tsum.fill_ms += c.timing.fill_ms; tsum.traceback_ms += c.timing.traceback_ms; tsum.total_ms += c.timing.total_ms; tsum.cells += c.timing.cells;
         tsum.n_launches += c.timing.n_launches; tsum.trace_bytes += c.timing.trace_bytes; tsum.dominant_ms += c.timing.dominant_ms; tsum.dominant_launches += c.timing.dominant_launches;
+        tsum.fast_path = std::max(tsum.fast_path, c.timing.fast_path);
         if (total > 0) { // offsets of a sub-batch start at 0
             hipLaunchKernelGGL(add_offset_kernel, dim3((unsigned)((cnt + 1 + 255) / 256)), dim3(256), 0, st, (int64_t *)c.out_off.p + p0, cnt + 1, total);
             HIPCHK(hipGetLastError());
@@ -1810,7 +1839,7 @@ void gnx_shutdown(void) {
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,
-                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.cl_bases, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
+                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.cl_bases, &c.sc_prof_a, &c.sc_prof_b, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
                           &c.sd_tmp[0], &c.sd_tmp[1], &c.sd_tmp[2], &c.sd_tmp[3], &c.sd_tmp[4], &c.sd_tmp[5], &c.sd_tmp[6], &c.sd_tmp[7]};
         for (DevBuf *b : bufs) b->release();
         PinBuf *pins[] = {&c.h_plans, &c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};

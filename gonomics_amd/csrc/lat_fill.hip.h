@@ -34,14 +34,20 @@ constexpr int LAT_SENT = (int)0x80000000; // "not written yet" in the row buffer
 #define DPP_WAVE_SHR1 0x138
 __device__ __forceinline__ int wave_shr1(int oldv, int src) { return __builtin_amdgcn_update_dpp(oldv, src, DPP_WAVE_SHR1, 0xf, 0xf, false); }
 
-template <bool AFFINE, bool LOCAL>
+// SCORED (chunk / multiple-alignment variants, "next" row N1): the substitution score of a cell comes from the pair's explicit matrix in
+// HBM (column-major, S[s_off + (j-1) s_pitch + (i-1)], int32 or -- S16 -- int16 entries carrying the -2e of the rebased diagonal move)
+// instead of the LDS profile; sequences are not read.  A lone wave cannot hide a memory round trip behind other waves, so the two entries
+// of a step are loaded SIXTEEN steps ahead into a register ring: the slot of step u is re-loaded right after step u has used it.
+template <bool AFFINE, bool LOCAL, bool SCORED = false, bool S16 = false>
 __global__ __launch_bounds__(64) void lat_fill_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                       const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                       KParams kp, uint4 *__restrict__ trace, int *__restrict__ hcol,
                                                       int2 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int *__restrict__ err,
-                                                      const int2 *__restrict__ strip_map, int *__restrict__ claims) {
+                                                      const int2 *__restrict__ strip_map, int *__restrict__ claims, const int *__restrict__ smat = nullptr) {
     static_assert(AFFINE || !LOCAL, "free end gaps are an affine mode");
+    static_assert(!SCORED || (AFFINE && !LOCAL), "the scored variants have AffineGap_highMem semantics");
+    static_assert(!S16 || SCORED, "S16 is a layout of the score matrix");
     constexpr int TI = 2, TD = 1;
     constexpr int BST = LG * LR; // dwords per base plane of the profile
     constexpr int NACC = AFFINE ? 3 * LR : LR;
@@ -57,9 +63,9 @@ __global__ __launch_bounds__(64) void lat_fill_kernel(const PairPlan *__restrict
     if (n_stolen < 0) return;
     const int p = strip_map[blockIdx.x].x;
     const PairPlan pl = plans[p];
-    const uint8_t *ap = a_buf + a_start[pl.src];
+    const uint8_t *ap = SCORED ? nullptr : a_buf + a_start[pl.src];
     BetaBytes bp;
-    bp.init(b_buf, kp, b_start[pl.src], pl.m);
+    bp.init(b_buf, kp, SCORED ? 0 : b_start[pl.src], SCORED ? 0 : pl.m);
     const int m = pl.m;
     const int Tend = (m + (LG - 1) + 15) & ~15;
     const int E4 = kp.e4, OE4 = kp.oe4, RB = AFFINE ? kp.e4 : kp.g4;
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(64) void lat_fill_kernel(const PairPlan *__restrict
     for (int s = s_own - n_stolen; s <= s_own; s++) {
         const bool store_row = s + 1 < pl.strips;
         const int row0 = s * LH + l * LR; // 0-based index of this lane's first row == 1-based index of the row above it
-        {
+        if (!SCORED) {
             int a5[LR];
 #pragma unroll
             for (int r = 0; r < LR; r++) {
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(64) void lat_fill_kernel(const PairPlan *__restrict
             if (l < 16 && c >= 1 && c <= m) {
                 if (s == 0) row0_boundary(c, odn, oh);
                 else { const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], true); odn = v.x; oh = v.y; }
-                ob = bp.raw(c - 1);
+                if (!SCORED) ob = bp.raw(c - 1);
             }
         };
         auto settle = [&](int c, int &odn, int &oh) { // ... until the strip above has written them
@@ -138,7 +144,26 @@ __global__ __launch_bounds__(64) void lat_fill_kernel(const PairPlan *__restrict
                 }
             }
         };
-        auto base_off = [&](int raw, int c) { int b = (l < 16 && c >= 1 && c <= m) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
+        auto base_off = [&](int raw, int c) { if (SCORED) return 0; int b = (l < 16 && c >= 1 && c <= m) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
+        // SCORED: the ring of score entries, slot u = the step at position u of a block; the two rows of a lane are adjacent in a column of the matrix
+        int ring[16][LR];
+        // (no branch around the load: a lane outside its columns loads the entry of the nearest one it has and never uses it -- behind a
+        // branch the compiler cannot count the loads in flight and waits for ALL of them, i.e. a memory round trip per step)
+        auto ring_load = [&](int t, int u) { // entries of step t (column t - l) into slot u
+            const int j = min(max(t - l, 1), m);
+            if (S16) {
+                const int v = *reinterpret_cast<const int *>(reinterpret_cast<const short *>(smat) + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0);
+                ring[u][0] = (int)(short)(v & 0xffff); ring[u][1] = v >> 16;
+            } else {
+                const int2 v = *reinterpret_cast<const int2 *>(smat + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0);
+                ring[u][0] = v.x; ring[u][1] = v.y;
+            }
+        };
+        static_assert(LR == 2, "the ring loads two adjacent rows as one 8-byte (S16: 4-byte) entry");
+        if (SCORED) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) ring_load(u + 1, u);
+        }
         issue(l + 1, qdn, qh, qb);
         settle(l + 1, qdn, qh);
         qb = base_off(qb, l + 1);
@@ -149,23 +174,53 @@ __global__ __launch_bounds__(64) void lat_fill_kernel(const PairPlan *__restrict
 #pragma unroll
             for (int k = 0; k < LR; k++) w[k] = pw[k];
         };
-        pb_cur = wave_shr1(qb, b_out);
-        qb = dpp_shl1(qb, qb);
-        fetch(pb_cur, wq);
-        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
+        pb_cur = 0;
+        if (!SCORED) {
+            pb_cur = wave_shr1(qb, b_out);
+            qb = dpp_shl1(qb, qb);
+            fetch(pb_cur, wq);
+        }
+        auto step = [&](const int t, auto chk, const bool take, const int nqv, const int u = 0) {
             constexpr bool CHECK = decltype(chk)::value;
             const int up_dn = wave_shr1(qdn, dn_out);
             const int up_h = AFFINE ? wave_shr1(qh, h_out) : 0;
             qdn = dpp_shl1(qdn, qdn);
             if (AFFINE) qh = dpp_shl1(qh, qh);
-            if (take) qb = nqv; // (last step of a block: the base queue of the next one takes over)
-            const int pb_next = wave_shr1(qb, pb_cur);
-            qb = dpp_shl1(qb, qb);
-            int wn[LR];
-            fetch(pb_next, wn);
-            asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic
+            int wn[LR], pb_next = 0;
+            if (!SCORED) {
+                if (take) qb = nqv; // (last step of a block: the base queue of the next one takes over)
+                pb_next = wave_shr1(qb, pb_cur);
+                qb = dpp_shl1(qb, qb);
+                fetch(pb_next, wn);
+                asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic
+            } else {
+#pragma unroll
+                for (int k = 0; k < LR; k++) wq[k] = ring[u][k];
+            }
             const int j = t - l;
-            if (!CHECK || (j >= 1 && j <= m)) {
+            if (SCORED) { // straight-line: in the ramps (CHECK) a lane outside its columns computes and keeps its old state by selects
+                const bool act = !CHECK || (j >= 1 && j <= m);
+                int hd = diag0, dnu = up_dn;
+#pragma unroll
+                for (int r = 0; r < LR; r++) {
+                    const int S4 = wq[r];
+                    const unsigned a0 = alignbit2((unsigned)hd, acc[r]), a1 = alignbit2((unsigned)rt[r], acc[LR + r]), a2 = alignbit2((unsigned)dnu, acc[2 * LR + r]);
+                    const int M3 = (hd | 3) + S4;
+                    const int I2 = (rt[r] & ~3) | TI;
+                    const int D1 = (dnu & ~3) | TD;
+                    const int hnew = max3i(M3, I2, D1);
+                    const int ho = hnew + vO4;
+                    const int rtn = max(ho, I2), dnn = max(ho, D1);
+                    hd = hold[r];
+                    acc[r] = act ? a0 : acc[r]; acc[LR + r] = act ? a1 : acc[LR + r]; acc[2 * LR + r] = act ? a2 : acc[2 * LR + r];
+                    rt[r] = act ? rtn : rt[r];
+                    hold[r] = act ? hnew : hold[r];
+                    dnu = dnn;
+                }
+                diag0 = act ? up_h : diag0;
+                dn_out = act ? dnu : dn_out;
+                h_out = act ? hold[LR - 1] : h_out;
+            } else if (!CHECK || (j >= 1 && j <= m)) {
                 if (AFFINE) {
                     int hd = diag0, dnu = up_dn;
 #pragma unroll
@@ -205,14 +260,24 @@ __global__ __launch_bounds__(64) void lat_fill_kernel(const PairPlan *__restrict
             }
             sq_dn = dpp_shl1(dn_out, sq_dn); // (row 3 of the wave: lane 63 inserts, lanes 48 .. 63 hold the last 16 columns of the bottom row)
             if (AFFINE) sq_h = dpp_shl1(h_out, sq_h);
+            if (!SCORED) {
 #pragma unroll
-            for (int k = 0; k < LR; k++) wq[k] = wn[k];
-            pb_cur = pb_next;
+                for (int k = 0; k < LR; k++) wq[k] = wn[k];
+                pb_cur = pb_next;
+            } else ring_load(t + 16, u); // this slot's next use is sixteen steps away
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
             issue(t0 + 16 + l + 1, ndn, nh, nb);
-            if (t0 >= LG && t0 + 16 <= m) {
+            if (SCORED) { // (the ring is indexed by the position in the block, so the block is unrolled in the ramps too)
+                if (t0 >= LG && t0 + 16 <= m) {
+#pragma unroll
+                    for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{}, false, 0, u);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{}, false, 0, u);
+                }
+            } else if (t0 >= LG && t0 + 16 <= m) {
 #pragma unroll
                 for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
             } else {

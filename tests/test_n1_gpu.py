@@ -16,6 +16,15 @@ MX = common.matrices()
 D = os.path.join(common.DATA, "align")
 
 
+@pytest.fixture(autouse=True, params=["lat", "general"])
+def geometry(request, monkeypatch):
+    """every test twice: small batches take the latency geometry by the library's routing (lat_fill_kernel<.., SCORED>: the score matrix through
+    a register ring), GNX_LAT=0 keeps them on fill_affine_kernel<.., SCORED> -- unless a switch from outside has chosen already"""
+    if "GNX_LAT" not in os.environ and request.param == "general":
+        monkeypatch.setenv("GNX_LAT", "0")
+    return request.param
+
+
 def _route(r):
     return [(c.RunLength, c.Op) for c in r]
 
