@@ -45,6 +45,7 @@
 #include "const_long_walk.hip.h"
 #include "affine_long.hip.h"
 #include "lat_fill.hip.h"
+#include "lat_wide.hip.h"
 #include "seed_kernels.hip.h"
 
 namespace {
@@ -775,13 +776,16 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             // latency chain: 1024 pairs of C5 37.9 -> 28.6 ms.  With more pairs than that the plain walk's eight workgroups per CU win
             // (2048 pairs, 448-step tiles: 42 ms plain, 111 ms speculative), and four tiles per round (three workgroups per CU) never pay.
             int spec = (np <= 4 * c.n_cu && !wide) ? 3 : 0;
-            if (const char *se = getenv("GNX_CL_WALK_SPEC")) { const int v = atoi(se); spec = (v == 3 || v == 4) ? v : 0; }
+            if (const char *se = getenv("GNX_CL_WALK_SPEC")) { const int v = atoi(se); spec = (v == 2 || v == 3 || v == 4) ? v : 0; }
             if (npe) spec = 0; // (an explicit GNX_CL_WALK_NP asks for the plain walk)
             const dim3 gs((unsigned)np);
             auto launch_spec = [&](auto kern) {
                 hipLaunchKernelGGL(kern, gs, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err);
             };
-            if (spec && p16) {
+            if (spec == 2) { // two tiles per round: 24.6 / 42.5 KB of LDS, six / three workgroups per CU
+                if (p16) { if (wide) launch_spec(cl_walk_spec_kernel<true, CKC, 2>); else launch_spec(cl_walk_spec_kernel<true, CKC_SMALL, 2>); }
+                else { if (wide) launch_spec(cl_walk_spec_kernel<false, CKC, 2>); else launch_spec(cl_walk_spec_kernel<false, CKC_SMALL, 2>); }
+            } else if (spec && p16) {
                 if (spec == 3) { if (wide) launch_spec(cl_walk_spec_kernel<true, CKC, 3>); else launch_spec(cl_walk_spec_kernel<true, CKC_SMALL, 3>); }
                 else { if (wide) launch_spec(cl_walk_spec_kernel<true, CKC, 4>); else launch_spec(cl_walk_spec_kernel<true, CKC_SMALL, 4>); }
             } else if (spec) {
@@ -846,8 +850,9 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
                    const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                    const int64_t *h_alen, const int64_t *h_blen,
                    int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream,
-                   const int *d_smat = nullptr, const int64_t *h_soff = nullptr, bool smat16 = false) {
+                   const int *d_smat = nullptr, const int64_t *h_soff = nullptr, bool smat16 = false, bool wide = false) {
     // d_smat / h_soff: explicit score matrices (the chunk / multiple-alignment variants): lat_fill_kernel<.., SCORED>
+    // wide: int64 keys, literal recurrences (lat_wide.hip.h): pairs no int32 kernel can hold
     Ctx &c = g_ctx;
     int rc;
     const int np = (int)n_pairs;
@@ -864,6 +869,7 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
     int64_t *so = reinterpret_cast<int64_t *>(hm + o_so);
     int2 *smap = reinterpret_cast<int2 *>(hm + o_map);
     int64_t toff = 0, hoff = 0, roff = 0, doff = 0, cells = 0, nb = 0;
+    const int64_t rbw = (wide && affine) ? 2 : 1; // row-buffer entries per column (8 bytes each: int2 {dn, h}, or int64 keys)
     so[0] = 0;
     for (int64_t p = 0; p < n_pairs; p++) {
         const int64_t n = h_alen[p], m = h_blen[p];
@@ -874,7 +880,7 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
         pl.trace_off = toff; pl.hcol_off = hoff; pl.rowbuf_off = roff; pl.dcol_off = doff;
         pl.src = (int32_t)p; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0;
         if (h_soff) { pl.s_off = h_soff[p]; pl.s_pitch = (int64_t)((n + H - 1) / H) * H; } // (the matrices are laid out for the general path's 160-row strips)
-        toff += (int64_t)pl.strips * pl.words * Q * LG; hoff += n; roff += (int64_t)(pl.strips - 1) * (m + 1); doff += (int64_t)pl.strips * LG;
+        toff += (int64_t)pl.strips * pl.words * Q * LG; hoff += n; roff += (int64_t)(pl.strips - 1) * (m + 1) * rbw; doff += (int64_t)pl.strips * LG;
         so[(size_t)p + 1] = so[(size_t)p] + n + m + 2;
         cells += n * m;
         for (int st = 0; st < pl.strips; st++) smap[(size_t)nb++] = make_int2((int)p, st);
@@ -891,6 +897,7 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
     if ((rc = c.plans.ensure(meta_b))) return rc;
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
     if ((rc = c.misc.ensure(64))) return rc;
+    if (wide && (rc = c.mx_score.ensure((size_t)np * 8))) return rc; // (the int64 scores of the wide kernel)
     char *dm = reinterpret_cast<char *>(c.plans.p);
     int *d_err = reinterpret_cast<int *>(c.misc.p);
     int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
@@ -912,7 +919,17 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
     HIPCHK(hipEventRecord(c.ev[0], stream));
     const dim3 gridF((unsigned)n_blocks), gridP((unsigned)np), blk(64);
 #define GNX_LAT(A_, L_) hipLaunchKernelGGL((lat_fill_kernel<A_, L_>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_claims)
-    if (d_smat) {
+    if (wide) {
+        int64_t *d_s64 = reinterpret_cast<int64_t *>(c.mx_score.p);
+        k64 *drw = reinterpret_cast<k64 *>(c.rowbuf.p);
+        const long long o4w = 4 * (long long)prm->gap_open, e4w = affine ? 4 * (long long)prm->gap_extend : 0;
+        const long long d00w = local ? 0 : o4w, ecolw = local ? 0 : e4w;
+#define GNX_WIDE(A_, L_) hipLaunchKernelGGL((lat_wide_kernel<A_, L_>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, o4w, e4w, d00w, ecolw, dtrace, dh, d_s64, drw, ddc, d_err, d_smap, d_claims)
+        if (affine) { if (local) GNX_WIDE(true, true); else GNX_WIDE(true, false); }
+        else GNX_WIDE(false, false);
+#undef GNX_WIDE
+    }
+    else if (d_smat) {
         if (smat16) hipLaunchKernelGGL((lat_fill_kernel<true, false, true, true>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_claims, d_smat);
         else hipLaunchKernelGGL((lat_fill_kernel<true, false, true, false>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, dtrace, dh, drb, ddc, d_err, d_smap, d_claims, d_smat);
     }
@@ -924,6 +941,7 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
     if (affine) hipLaunchKernelGGL((traceback_kernel<true, false, true, true, LG, LR>), gridP, blk, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score, dn, d_so, d_scr, (int64_t)0, d_err);
     else hipLaunchKernelGGL((traceback_kernel<false, false, true, true, LG, LR>), gridP, blk, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score, dn, d_so, d_scr, (int64_t)0, d_err);
     HIPCHK(hipGetLastError());
+    if (wide) hipLaunchKernelGGL(wide_scores_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const int64_t *>(c.mx_score.p), d_score, np);
     if ((rc = launch_scan(dn, np, d_ops_off, d_carry, stream))) return rc;
     hipLaunchKernelGGL(reverse_runs_kernel, gridP, dim3(256), 0, stream, dpl, np, d_scr, d_so, dn, d_ops_off, d_ops, ops_capacity, d_err);
     HIPCHK(hipGetLastError());
@@ -936,7 +954,7 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
     HIPCHK(hipEventElapsedTime(&f2, c.ev[1], c.ev[2]));
     c.timing.fill_ms = f1; c.timing.traceback_ms = f2; c.timing.total_ms = f1 + f2;
     c.timing.cells = cells; c.timing.n_launches = 1; c.timing.trace_bytes = toff * 16;
-    c.timing.dominant_ms = f1; c.timing.dominant_launches = 1; c.timing.fast_path = 3;
+    c.timing.dominant_ms = f1; c.timing.dominant_launches = 1; c.timing.fast_path = wide ? 4 : 3;
     int64_t total;
     memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
     if (out_total) *out_total = total;
@@ -993,6 +1011,14 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // beyond the STATIC int32 range of the kernels' keys (4 * score, absolute): such pairs take the snapshot path with moving bases
         // (REBASE, const_long.hip.h), which has no length limit -- see the clong block below; the reference is int64 throughout (align/align.go:8)
         if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27) && first_oor < 0) first_oor = p;
+    }
+    // ---- GNX_WIDE=2 (tests): everything through the int64 kernel (lat_wide.hip.h) ----
+    if (!gsw && !d_smat && !c.beta_packed) {
+        const char *we = getenv("GNX_WIDE");
+        if (we && we[0] == '2') {
+            rc = run_device_lat(prm, kp, tp, affine, local, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, nullptr, nullptr, false, true);
+            if (rc >= 0) return rc; // (-1: an empty sequence / the workspace -> the ordinary routes; -2: its bug trap)
+        }
     }
     // ---- latency geometry: few pairs (lat_fill.hip.h).  A lone wave is paced by its own instruction stream, so a launch that cannot fill
     // the device runs one pair per wave on 64 lanes x 2 rows instead of four pairs per wave on 16 x 10: at most LAT_MAX 128-row strips in
@@ -1225,8 +1251,17 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
             if (oor) { set_err("pair %s%lld needs more snapshot workspace than the device has free", "", (long long)first_oor); return GNX_ENOMEM; }
         }
     }
-    if (oor) { // what is left has absolute int32 keys: AffineGapLocal, gapOpen > 0, the chunk / graph variants, scores too big for moving bases
-        set_err("pair %s%lld exceeds the int32 DP range of this mode (global AffineGap / ConstGap with gapOpen <= 0 have no length limit)", "", (long long)first_oor);
+    if (oor) {
+        // what is left has absolute int32 keys -- AffineGapLocal, gapOpen > 0, scores too big for moving bases: the int64 kernel (lat_wide.hip.h),
+        // limited by the workspace its stored direction matrix needs (1 B per cell), not by a range.  The chunk / graph variants keep int32.
+        if (!gsw && !d_smat && (n_pairs == 0 || (long double)(h_alen[first_oor] + h_blen[first_oor] + 2) * (long double)std::max<int64_t>(maxpen, 1) < 1.0e17L)) {
+            rc = run_device_lat(prm, kp, tp, affine, local, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, nullptr, nullptr, false, true);
+            if (rc >= 0) return rc;
+            if (rc == -2) { set_err("a strip of the int64 kernel waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
+            set_err("pair %s%lld is beyond the int32 range of its mode and its direction matrix does not fit the workspace (or a sequence is empty)", "", (long long)first_oor);
+            return GNX_ENOMEM;
+        }
+        set_err("pair %s%lld exceeds the int32 DP range of this variant (chunk / graph-extension DPs)", "", (long long)first_oor);
         return GNX_ERANGE;
     }
     // ---- plan ----
