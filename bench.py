@@ -370,7 +370,7 @@ def extra_c5(_lib, L, scores, chunk_h, dev, torch, n_pairs=1024, n=20000, m=1000
     okk = _sample_check(_lib, scores, 1, -430, 0, (sc, ops, off), pick, lambda x: reads[x], lambda x: wins[x])
     cells = n_pairs * n * m
     return {"entry": "gnx_align_batch_device (GNX_CONST_GAP)", "pairs": n_pairs, "value": cells / dt, "unit": "DP cells/s", "ms_per_step": dt * 1e3,
-            "path": {0: "general_path", 1: "fast_path", 2: "const_long", 3: "latency_geometry"}[tm["fast_path"]], "bit_exact_sample": okk, "bit_exact_pairs_checked": int(pick.shape[0]),
+            "path": {0: "general_path", 1: "fast_path", 2: "const_long", 3: "latency_geometry", 4: "int64_fallback"}[tm["fast_path"]], "bit_exact_sample": okk, "bit_exact_pairs_checked": int(pick.shape[0]),
             "kernel_ms": {"sweep": tm["dominant_ms"], "walk_and_rest": tm["traceback_ms"]},
             "roofline": _roofline_of(tm, n, m, 2, n_pairs, int(off[-1]))}
 
@@ -714,11 +714,11 @@ def main():
         abytes_step = algorithmic_bytes(READ_LEN, CHUNK_LEN, S["bits"], n_pairs, step_total_ops)
         achieved = abytes / (fill_avg_ms * 1e-3) / 1e9
         achieved_step = abytes_step * world / (ms_per_step * 1e-3) / 1e9 / world  # per GPU
-        path = {0: "general_path", 1: "fast_path", 2: "const_long", 3: "latency_geometry"}[fast_path]
+        path = {0: "general_path", 1: "fast_path", 2: "const_long", 3: "latency_geometry", 4: "int64_fallback"}[fast_path]
         kernel = {0: "fill_affine_kernel (full direction matrix)" if S["bits"] == 6 else "fill_const_kernel (full direction matrix)",
                   1: "fp_sweep_kernel<%d, %s> (fast-path forward sweep)" % (19 if READ_LEN <= 152 else 20, "true" if swap else "false"),
                   2: "cl_sweep_wg_kernel<4> (score-only constant-gap sweep with wavefront snapshots, four strips per workgroup handing rows over through LDS)",
-                  3: "lat_fill_kernel (one pair per wave, 64 lanes x 2 rows, full direction matrix)"}[fast_path]
+                  3: "lat_fill_kernel (one pair per wave, 64 lanes x 2 rows, full direction matrix)", 4: "lat_wide_kernel (int64 keys)"}[fast_path]
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), valid
         # only for the kernel sources they were taken from
         traffic, traffic_note, pmc = None, None, None
@@ -773,6 +773,18 @@ def main():
             out["roofline_valu"] = {"bound": "valu", "achieved": lane_ops / 1e12, "peak": 78.6, "unit": "T lane-ops/s", "frac": lane_ops / 78.6e12,
                                     "valu_insts_per_pair": vi, "valu_busy": pmc.get("valu_busy"),
                                     "source": "SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE (rocprofv3 --pmc, %s)" % os.path.basename(TRAFFIC_FILE)}
+        if fast_path == 1 and args.series == "affine":
+            # The BINDING ceiling of the headline sweep is VALU issue, not HBM: the floor of the recurrence is five
+            # instructions per cell (add, max3, add, max, max), and tools/valu_ubench4.hip measured how fast a SIMD issues exactly that mix with
+            # two or more waves resident: 1.813 ns per wave-instruction slot (profiles/r3_valu_ubench4.txt, "CELL int32 with add_sdwa").  A
+            # read of n bases takes ceil(n / 8) rows in each of 8 lanes; 8 pairs share a wave; 4 SIMDs per CU.
+            rr = 19 if READ_LEN <= 152 else 20
+            slots_per_pair = CHUNK_LEN * rr * 5 / 8.0                      # wave-instruction slots of the floor
+            n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+            floor_ms = pairs_per_launch * slots_per_pair * 1.813e-9 / n_simd * 1e3
+            rv = out.setdefault("roofline_valu", {"bound": "valu"})
+            rv.update({"floor_ms": floor_ms, "frac_of_floor": floor_ms / fill_avg_ms, "floor_model": "5 instructions per cell x 1.813 ns per wave-instruction slot and SIMD "
+                       "(measured issue rate of add_sdwa, max3, add, max, max at >= 2 waves per SIMD, profiles/r3_valu_ubench4.txt) / (4 SIMDs x %d CUs)" % (n_simd // 4)})
         if not args.no_host and world == 1:
             # cold plans: a call of another shape first, so that the next full call builds and uploads its plans afresh
             step(max(n_pairs - 64, 1))

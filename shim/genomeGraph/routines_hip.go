@@ -36,17 +36,30 @@ type HipGraph struct {
 }
 
 // NewHipGraph hands the nodes and the edges of gg to the library.  Edges go over in the order of the nodes' Next lists; the library
-// rebuilds Next and Prev with AddEdge (genomeGraph.go:118-121), so a graph whose Prev lists were filled in another order than its
-// Next lists (none of the reference's readers does that) would have its left traversals try their branches in another order.
+// rebuilds Next and Prev with AddEdge (genomeGraph.go:118-121).  The left traversals try their branches in the order of the Prev lists,
+// so a graph whose Prev lists were NOT filled in that same edge order (none of the reference's readers builds one) is refused here
+// instead of being aligned with another branch order (ADVICE r4).
 func NewHipGraph(gg *GenomeGraph, seedLen int, stepSize int) *HipGraph {
 	off := make([]C.int64_t, len(gg.Nodes)+1)
 	var cat []dna.Base
 	var from, to []C.int32_t
+	prevSim := make([][]uint32, len(gg.Nodes)) // the Prev lists AddEdge will build on the other side
 	for i := range gg.Nodes {
 		cat = append(cat, gg.Nodes[i].Seq...)
 		off[i+1] = C.int64_t(len(cat))
 		for _, e := range gg.Nodes[i].Next {
 			from, to = append(from, C.int32_t(gg.Nodes[i].Id)), append(to, C.int32_t(e.Dest.Id))
+			prevSim[e.Dest.Id] = append(prevSim[e.Dest.Id], gg.Nodes[i].Id)
+		}
+	}
+	for i := range gg.Nodes {
+		if len(prevSim[i]) != len(gg.Nodes[i].Prev) {
+			log.Panicf("genomeGraph (hip): node %d has %d Prev edges but %d Next edges point at it", i, len(gg.Nodes[i].Prev), len(prevSim[i]))
+		}
+		for k, e := range gg.Nodes[i].Prev {
+			if e.Dest.Id != prevSim[i][k] {
+				log.Panicf("genomeGraph (hip): the Prev list of node %d is not in the order of the Next lists (edge %d): the library cannot rebuild it", i, k)
+			}
 		}
 	}
 	var fp, tp *C.int32_t
@@ -66,11 +79,23 @@ func (g *HipGraph) Close() {
 	g.h = nil
 }
 
+const gswPanicText = "runtime error: slice bounds out of range (getLeftTargetBases, search.go:139)"
+
 // GswBatchToGiraf is GraphSmithWatermanToGiraf (toGiraf.go:17-72) for every read of a batch.  threads = 0: the library's default.
+// Panics like the reference on the first read it would have panicked on.
 func (g *HipGraph) GswBatchToGiraf(reads []fastq.FastqBig, scoreMatrix [][]int64, threads int) []giraf.Giraf {
+	out, bad := g.gswBatch(reads, scoreMatrix, threads)
+	if bad >= 0 {
+		panic(gswPanicText)
+	}
+	return out
+}
+
+// gswBatch: the girafs of the reads before the first one GraphSmithWatermanToGiraf panics on, and that read's index (-1: none)
+func (g *HipGraph) gswBatch(reads []fastq.FastqBig, scoreMatrix [][]int64, threads int) ([]giraf.Giraf, int) {
 	n := len(reads)
 	if n == 0 {
-		return nil
+		return nil, -1
 	}
 	var flat [25]C.int64_t
 	for a := 0; a < 5; a++ {
@@ -100,15 +125,24 @@ func (g *HipGraph) GswBatchToGiraf(reads []fastq.FastqBig, scoreMatrix [][]int64
 	defer C.gnx_free(unsafe.Pointer(cig))
 	recs := unsafe.Slice(gir, n)
 	last := recs[n-1]
-	allNodes := unsafe.Slice(nodes, int(last.node_off+last.n_nodes)+1)
-	allCig := unsafe.Slice(cig, int(last.cigar_off+last.n_cigar)+1)
-	out := make([]giraf.Giraf, n)
+	atLeastOne := func(k int) int { // (the library allocates max(count, 1) elements)
+		if k < 1 {
+			return 1
+		}
+		return k
+	}
+	allNodes := unsafe.Slice(nodes, atLeastOne(int(last.node_off+last.n_nodes)))
+	allCig := unsafe.Slice(cig, atLeastOne(int(last.cigar_off+last.n_cigar)))
+	out := make([]giraf.Giraf, 0, n)
 	for i := 0; i < n; i++ {
 		r := recs[i]
-		if r.panicked != 0 {
-			panic("runtime error: slice bounds out of range (getLeftTargetBases, search.go:139)")
+		if r.panicked != 0 { // RoutineFqToGiraf would already have sent the girafs of the reads before this one (routines.go:17-21)
+			return out, i
 		}
-		path := giraf.Path{TStart: int(r.t_start), Nodes: make([]uint32, int(r.n_nodes)), TEnd: int(r.t_end)}
+		path := giraf.Path{TStart: int(r.t_start), TEnd: int(r.t_end)} // Nodes stays nil for a read without a hit (toGiraf.go:22)
+		if r.n_nodes > 0 {
+			path.Nodes = make([]uint32, int(r.n_nodes))
+		}
 		for k := range path.Nodes {
 			path.Nodes[k] = uint32(allNodes[int(r.node_off)+k])
 		}
@@ -124,22 +158,26 @@ func (g *HipGraph) GswBatchToGiraf(reads []fastq.FastqBig, scoreMatrix [][]int64
 		if r.seq_is_rc != 0 {
 			seq = reads[i].SeqRc
 		}
-		out[i] = giraf.Giraf{QName: reads[i].Name, QStart: int(r.q_start), QEnd: int(r.q_end), Flag: uint8(r.flag), PosStrand: r.pos_strand != 0, Path: path,
+		out = append(out, giraf.Giraf{QName: reads[i].Name, QStart: int(r.q_start), QEnd: int(r.q_end), Flag: uint8(r.flag), PosStrand: r.pos_strand != 0, Path: path,
 			Cigar: cg, AlnScore: int(r.aln_score), MapQ: uint8(r.map_q), Seq: seq, Qual: reads[i].Qual,
-			Notes: []giraf.Note{{Tag: []byte{'X', 'O'}, Type: 'Z', Value: "~"}}} // toGiraf.go:18-30
+			Notes: []giraf.Note{{Tag: []byte{'X', 'O'}, Type: 'Z', Value: "~"}}}) // toGiraf.go:18-30
 		if !out[i].PosStrand {
 			fastq.ReverseQualUint8Record(out[i].Qual) // toGiraf.go:68-70 (in place, on the read's own slice, as there)
 		}
 	}
-	return out
+	return out, -1
 }
 
 // RoutineFqToGirafHip: the contract of RoutineFqToGiraf (routines.go:12-25), one worker for the whole stream, batchSize reads per device call.
 func RoutineFqToGirafHip(g *HipGraph, scoreMatrix [][]int64, batchSize int, threads int, inputChan <-chan fastq.FastqBig, outputChan chan<- giraf.Giraf, wg *sync.WaitGroup) {
 	batch := make([]fastq.FastqBig, 0, batchSize)
 	flush := func() {
-		for _, r := range g.GswBatchToGiraf(batch, scoreMatrix, threads) {
+		out, bad := g.gswBatch(batch, scoreMatrix, threads)
+		for _, r := range out {
 			outputChan <- r
+		}
+		if bad >= 0 { // the reads before it have left, as with RoutineFqToGiraf; then the panic of that read
+			panic(gswPanicText)
 		}
 		batch = batch[:0]
 	}

@@ -1,7 +1,7 @@
 """Forward progress of the pipelined launches must not depend on the order in which workgroups start (VERDICT r2 item 3;
 MI355X_MICROARCH "Workgroup dispatch": HIP promises nothing about dispatch order).  In every piped kernel a workgroup CLAIMS its item
 and every unclaimed predecessor of it, and runs those first (csrc/gnx_common.hip.h: claim_items): nobody waits for work that has not been
-taken.  Two stress legs, each over all five piped kernels, results against the oracle:
+taken.  Two stress legs, each over all piped kernels, results against the oracle:
   * GNX_TICKET_DELAY: the workgroups of the lower half of the grid sleep before they claim, so the upper half finds its predecessors
     unclaimed and runs whole chains itself (what a dispatcher that starts workgroups in another order would cause);
   * gnx_debug_occupy: 128 workgroups that each hold a whole CU's LDS spin on another stream while the piped launch runs, so half
@@ -42,16 +42,20 @@ def _pairs(seed, n_pairs, n_lo, n_hi, m_lo, m_hi):
 
 # (name, environment that routes the batch to the kernel, mode, matrix, penalties, pairs)
 LEGS = [
-    ("fill_affine_kernel<MULTI> piped strips", {"GNX_FASTPATH": "0"}, 0, "HumanChimpTwo", (-600, -150), (101, 6, 900, 1400, 2200, 2600)),
-    ("fill_const_kernel<MULTI> piped strips", {"GNX_CLONG": "0"}, 1, "Default", (-430, 0), (102, 6, 900, 1400, 2200, 2600)),
+    ("fill_affine_kernel<MULTI> piped strips", {"GNX_FASTPATH": "0", "GNX_LAT": "0"}, 0, "HumanChimpTwo", (-600, -150), (101, 6, 900, 1400, 2200, 2600)),
+    ("fill_const_kernel<MULTI> piped strips", {"GNX_CLONG": "0", "GNX_LAT": "0"}, 1, "Default", (-430, 0), (102, 6, 900, 1400, 2200, 2600)),
     ("cl_sweep_wg_kernel piped items of 5 strips", {"GNX_CLONG": "2"}, 1, "HumanChimpTwo", (-430, 0), (103, 6, 1700, 2500, 2200, 2600)),
     ("cl_sweep_kernel piped strips", {"GNX_CLONG": "2", "GNX_CL_WG": "0"}, 1, "HumanChimpTwo", (-430, 0), (103, 6, 900, 1400, 2200, 2600)),
     ("al_sweep_kernel piped strips", {"GNX_CLONG": "2", "GNX_FASTPATH": "0"}, 0, "HumanChimpTwo", (-600, -150), (104, 6, 900, 1400, 2200, 2600)),
     ("fp_sweep_levels_kernel (row blocks)", {"GNX_FASTPATH": "2"}, 0, "HumanChimpTwo", (-600, -150), (105, 96, 500, 800, 1500, 1800)),
+    # round 5: the latency geometry's strips (one wave per strip, rows handed over through sentinel-marked memory) and its int64 form
+    ("lat_fill_kernel<affine> piped strips", {"GNX_LAT": "2"}, 0, "HumanChimpTwo", (-600, -150), (106, 6, 900, 1400, 2200, 2600)),
+    ("lat_fill_kernel<const> piped strips", {"GNX_LAT": "2"}, 1, "Default", (-430, 0), (107, 6, 900, 1400, 2200, 2600)),
+    ("lat_wide_kernel piped strips", {"GNX_WIDE": "2"}, 0, "HumanChimpTwo", (-600, -150), (108, 6, 900, 1400, 2200, 2600)),
 ]
 
 
-@pytest.mark.parametrize("leg", LEGS, ids=[x[0].split()[0] for x in LEGS])
+@pytest.mark.parametrize("leg", LEGS, ids=[x[0].split()[0].replace("<", "_").replace(">", "") for x in LEGS])
 @pytest.mark.parametrize("stress", ["delay", "occupy", "both", "steal"])
 def test_piped_launches_do_not_depend_on_dispatch_order(gpu_lib, monkeypatch, leg, stress):
     name, env, mode, mx, (go, ge), spec = leg
