@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
         int dlo = 0, dhi = 0, qp = 0, edge = CKA, r0i = kp.o4 + TI;
         bool dhi_ok = false;
         long long *my_bases = REBASE ? bases + pl.rowi_off + (int64_t)s * pl.s_pitch : nullptr;
-        auto bprod = [&](int q) -> long long { return (q == 0 || s == 0) ? 0LL : rbase_load(my_bases - pl.s_pitch + q, piped); };
+        auto bprod = [&](int q) -> long long { return s == 0 ? 0LL : rbase_load(my_bases - pl.s_pitch + q, piped); /* (block 0 too: 0 inside a pair, the frame shift of a row panel's stand-in strip, run_device_mega) */ };
         auto boundary = [&](int c, int &odn, int &oh, int &ob) {
             if (s == 0) {
                 const int M3 = NEG4 + 3, I2 = REBASE ? r0i : kp.o4 + c * E4 + TI - RB * c, D1 = NEG4 + TD; // row 0: I(0,c) = gapOpen + c*gapExtend
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
                                                      KParams kp, TbParams tp, const int2 *__restrict__ rowbuf, const int *__restrict__ snap,
                                                      const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                      const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
-                                                     const long long *__restrict__ bases) {
+                                                     const long long *__restrict__ bases, MegaState *__restrict__ mst = nullptr) {
     using PC = ProfCfg<P16>;
     constexpr int LW = PC::LW, BST = PC::BST, PTOT = PC::TOTAL;
     constexpr int TI = 2, TD = 1;
@@ -305,11 +305,23 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
         if (op == cur_op) cur_run += run;
         else { flush_run(); cur_op = op; cur_run = run; }
     };
+    // row panels (MegaState, const_long.hip.h): resume what the walk carried out of the panel below; stop where it leaves this one upwards
+    int virt = 0;
+    int64_t row_off = 0;
+    bool pexit = false;
+    if (REBASE && mst) {
+        virt = mst->virt; row_off = mst->row_off;
+        if (valid) {
+            if (mst->resume) { wi = mst->wi; wj = mst->wj; wk = mst->wk; pend = mst->pend; li = mst->li; cnt = mst->cnt; cur_run = mst->cur_run; cur_op = mst->cur_op; last_op = mst->last_op; }
+            else li = (pl.n > 0) ? ((int64_t)pl.n + row_off - 1) % tp.ci : 0;
+        }
+    }
 
     while (true) {
         const int src0 = lane & 48;
         const int ci = __shfl(wi, src0, 64), cj = __shfl(wj, src0, 64), cdone = __shfl(wdone, src0, 64);
         if (__all(cdone)) break;
+        if (REBASE && virt > 0 && __any(!cdone && ci <= virt)) { pexit = true; break; }
         const bool gact = !cdone;
         const int s = gact ? (ci - 1) / H : 0;
         const int lw = gact ? (ci - 1 - s * H) / R : 0;
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
             } else if (cc >= 1 && cc <= m_eff) {
                 const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
                 odn = v.x; oh = v.y;
-                if (REBASE) { const int q = (cc + 14) / CKA; const int dd = rbase_delta(q > 0 ? bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + q] : 0LL, Bt); odn += dd; oh += dd; }
+                if (REBASE) { const int q = (cc + 14) / CKA; const int dd = rbase_delta(bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + q], Bt); odn += dd; oh += dd; }
             } else { odn = 0; oh = 0; }
             ob = (cc >= 1 && cc <= m_eff) ? bp.raw(cc - 1) : 0; // RAW base, see al_sweep_kernel
         };
@@ -517,11 +529,16 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
             wi = i; wj = j; wk = k;
         }
     }
-    if (l == 0 && valid) {
+    if (l == 0 && valid && REBASE && mst) {
+        mst->wi = wi; mst->wj = wj; mst->wk = wk; mst->pend = pend; mst->li = li; mst->cnt = cnt; mst->cur_run = cur_run; mst->cur_op = cur_op; mst->last_op = last_op;
+        mst->done = pexit ? 0 : 1;
+    }
+    if (l == 0 && valid && !pexit) {
         // Step 4 (affineGap.go:135-139) -- quirk Q2 when the corner is not the origin
-        const bool up_exit = (last_op != 1) && ((int64_t)wi % tp.ci == 0);
+        const int64_t gi = (int64_t)wi + (wi > 0 ? row_off : 0); // (row of the pair; a panel with a stand-in strip ends here only through column 0)
+        const bool up_exit = (last_op != 1) && (gi % tp.ci == 0);
         const bool left_exit = (last_op != 2) && ((int64_t)wj % tp.cj == 0);
-        if (!up_exit && left_exit) emit(2, wi);
+        if (!up_exit && left_exit) emit(2, gi);
         else if (up_exit && !left_exit) emit(1, wj);
         flush_run();
         nops[po] = cnt;

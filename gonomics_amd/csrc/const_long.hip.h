@@ -173,7 +173,7 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
         int dlo = 0, dhi = 0, qp = 0, edge = kp.ckc, r0v = 2;
         bool dhi_ok = false;
         long long *my_bases = REBASE ? bases + pl.rowi_off + (int64_t)s * pl.s_pitch : nullptr;
-        auto bprod = [&](int q) -> long long { return (q == 0 || s == 0) ? 0LL : rbase_load(my_bases - pl.s_pitch + q, piped); };
+        auto bprod = [&](int q) -> long long { return s == 0 ? 0LL : rbase_load(my_bases - pl.s_pitch + q, piped); /* (block 0 too: 0 inside a pair, the frame shift of a row panel's stand-in strip, run_device_mega) */ };
         auto boundary = [&](int c, int &ov, int &ob) {
             if (s == 0) ov = REBASE ? r0v : 2; // row 0, rebased
             else if (c >= 1 && c <= m_eff) {
@@ -339,6 +339,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((P16 && !REB
     cl_sweep_body<P16, false, REBASE>(lds, plans, n_pairs, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, hfin, err, nullptr, nullptr, bases);
 }
 
+// Row PANELS (run_device_mega): a pair whose bottom rows + snapshots exceed the workspace (5 Mb x 5 Mb: 1.9 TB) is swept panel by panel --
+// a panel = as many 160-row strips as fit, its top boundary = the bottom row of the panel above, kept with its bases -- and walked back panel
+// by panel: the walk of a REBASE kernel given a MegaState stops where it steps from the panel's first real strip into the row above it
+// (`virt` = 160: the panel's strip 0 is a stand-in whose bottom row the host has put into the row buffer) and resumes in the panel above
+// with everything it carries.  Rows are panel-local; row_off turns them into the pair's (checkerboard bookkeeping of quirks Q1 / Q2).
+struct MegaState {
+    int32_t resume, done, wi, wj, wk, pend, cur_op, last_op;
+    int64_t li, cnt, cur_run, row_off;
+    int32_t virt, pad;
+};
+
+__global__ __launch_bounds__(64) void add_i64_kernel(long long *__restrict__ b, int64_t n, long long delta) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n) b[x] += delta;
+}
+
 // One wave per NP pairs (NP = 4, 2 or 1: lanes 16 * NP .. 63 idle).  The walk of a pair is one long chain of dependent steps (re-fill a
 // tile, walk it with one lane, next tile), so a launch is as fast as its slowest wave -- and a wave of four pairs re-fills, every round,
 // as many blocks as the pair that needs most, and walks until the last of the four has left its tile.  With one pair per wave a
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
                                                      KParams kp, TbParams tp, const int *__restrict__ rowbuf, const int *__restrict__ snap,
                                                      const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                      const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
-                                                     const long long *__restrict__ bases) {
+                                                     const long long *__restrict__ bases, MegaState *__restrict__ mst = nullptr) {
     using PC = ProfCfg<P16>;
     static_assert(NP == 1 || NP == 2 || NP == 4, "pairs per workgroup");
     // profile of NP pairs: the layout of ProfCfg (one or two duos), or, for a single pair, planes of its own 16 * LW dwords (a plane
@@ -396,11 +412,19 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
         if (op == cur_op) cur_run += run;
         else { flush_run(); cur_op = op; cur_run = run; }
     };
+    int virt = 0;
+    int64_t row_off = 0;
+    bool pexit = false; // the walk has left this panel upwards: it goes on in the panel above
+    if (REBASE && mst) {
+        virt = mst->virt; row_off = mst->row_off;
+        if (mst->resume && valid) { wi = mst->wi; wj = mst->wj; cnt = mst->cnt; cur_run = mst->cur_run; cur_op = mst->cur_op; last_op = mst->last_op; }
+    }
 
     while (true) {
         const int src0 = lane & 48;
         const int ci = __shfl(wi, src0, 64), cj = __shfl(wj, src0, 64), cdone = __shfl(wdone, src0, 64);
         if (__all(cdone)) break;
+        if (REBASE && virt > 0 && __any(!cdone && ci <= virt)) { pexit = true; break; }
         const bool gact = !cdone;
         const int s = gact ? (ci - 1) / H : 0;
         const int lw = gact ? (ci - 1 - s * H) / R : 0;
@@ -457,7 +481,7 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
             if (s == 0) ov = r0v;
             else if (cc >= 1 && cc <= m_eff) {
                 ov = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
-                if (REBASE) { const int q = (cc + 14) / CK; ov += rbase_delta(q > 0 ? bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + q] : 0LL, Bt); }
+                if (REBASE) { const int q = (cc + 14) / CK; ov += rbase_delta(bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + q], Bt); }
             }
             else ov = 0;
             int b = 0;
@@ -549,12 +573,16 @@ __global__ __launch_bounds__(64) void cl_walk_kernel(const PairPlan *__restrict_
             wi = i; wj = j;
         }
     }
-    if (l == 0 && valid) {
+    if (l == 0 && valid && REBASE && mst) {
+        mst->wi = wi; mst->wj = wj; mst->cnt = cnt; mst->cur_run = cur_run; mst->cur_op = cur_op; mst->last_op = last_op; mst->done = pexit ? 0 : 1;
+    }
+    if (l == 0 && valid && !pexit) {
         // Step 4 (constGap.go:59-63): the leading gap is appended only if the walk left through exactly one edge of its last
         // checkerboard; a corner exit appends nothing, even when it is not the origin (quirk Q2)
-        const bool up_exit = (last_op != 1) && ((int64_t)wi % tp.ci == 0);
+        const int64_t gi = (int64_t)wi + (wi > 0 ? row_off : 0); // (row of the pair; a panel with a stand-in strip ends here only through column 0)
+        const bool up_exit = (last_op != 1) && (gi % tp.ci == 0);
         const bool left_exit = (last_op != 2) && ((int64_t)wj % tp.cj == 0);
-        if (!up_exit && left_exit) emit(2, wi);
+        if (!up_exit && left_exit) emit(2, gi);
         else if (up_exit && !left_exit) emit(1, wj);
         flush_run();
         nops[po] = cnt;

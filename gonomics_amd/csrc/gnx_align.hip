@@ -122,7 +122,7 @@ struct Ctx {
     PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
     // the resident reference, PACKED (gnx_host.hip.h: pack_reference): `ref` = 2 bits per base, ref_flag / ref_rank / ref_exc = the
     // sparse list of bases that are not A C G T (KParams::b2 / bflag / brank / bexc)
-    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off, cl_bases, sc_prof_a, sc_prof_b;
+    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off, cl_bases, sc_prof_a, sc_prof_b, mega_rows, mega_state;
     int64_t ref_len = -1;  // >= 0: a reference of that many bases is resident
     int64_t ref_nexc = 0;  // 64-base blocks with an exception
     int64_t ref_epoch = 0; // which gnx_set_reference call filled it (contexts created later are brought up to date on first use)
@@ -590,6 +590,10 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
     return GNX_OK;
 }
 
+int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp, bool affine, int64_t n_pairs,
+                    const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs, const int64_t *h_alen, const int64_t *h_blen,
+                    int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream);
+
 // Pairs without a stored direction matrix (const_long.hip.h; affine: affine_long.hip.h): score-only sweep that keeps the strips' bottom
 // rows and a snapshot of the wavefront every CKC / CKA steps, then one fused re-fill + walk kernel.  Every n, m >= 1 (validated by the caller).
 // Returns GNX_OK, an error, or -1 when the batch should take the general path (a single pair exceeds the workspace).
@@ -752,12 +756,12 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.ev[2], stream));
         const dim3 gridW((unsigned)((np + 3) / 4));
-#define GNX_AL_WALK(P_, RBS_) hipLaunchKernelGGL((al_walk_kernel<P_, RBS_>), gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs)
+#define GNX_AL_WALK(P_, RBS_) hipLaunchKernelGGL((al_walk_kernel<P_, RBS_>), gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr)
         if (affine) { if (rebase) { if (p16) GNX_AL_WALK(true, true); else GNX_AL_WALK(false, true); } else { if (p16) GNX_AL_WALK(true, false); else GNX_AL_WALK(false, false); } }
 #undef GNX_AL_WALK
         else if (rebase) { // (one pair per workgroup, plain walk)
             const dim3 gw((unsigned)np);
-#define GNX_CL_WALKR(P_, CK_) hipLaunchKernelGGL((cl_walk_kernel<P_, 1, CK_, true>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs)
+#define GNX_CL_WALKR(P_, CK_) hipLaunchKernelGGL((cl_walk_kernel<P_, 1, CK_, true>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr)
             if (ckc == CKC) { if (p16) GNX_CL_WALKR(true, CKC); else GNX_CL_WALKR(false, CKC); }
             else { if (p16) GNX_CL_WALKR(true, CKC_SMALL); else GNX_CL_WALKR(false, CKC_SMALL); }
 #undef GNX_CL_WALKR
@@ -768,7 +772,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             const dim3 gw((unsigned)((np + wnp - 1) / wnp));
             // (padding the workgroups' LDS so that a launch smaller than the GPU spreads over all CUs changes nothing: the dispatcher already does)
             auto launch_walk = [&](auto kern) {
-                hipLaunchKernelGGL(kern, gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, (const long long *)nullptr);
+                hipLaunchKernelGGL(kern, gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, (const long long *)nullptr, (MegaState *)nullptr);
             };
             const bool wide = ckc == CKC;
             // speculative re-fills of the next tiles by the wave's other lane groups (cl_walk_spec_kernel): GNX_CL_WALK_SPEC = 0 / 3 / 4 tiles per round
@@ -838,6 +842,205 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         t_no_pipe = false;
         return rc;
     }
+    if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
+    if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
+    return GNX_OK;
+}
+
+// Pairs whose snapshot working set (bottom rows of all strips + snapshots: 20 B per column and strip for AffineGap) exceeds the workspace:
+// ROW PANELS.  Forward, panel by panel: the REBASE sweep of const_long / affine_long on as many strips as fit, the panel's top boundary = the
+// bottom row of the panel above (kept with the bases it is relative to: 8 B per column and panel).  The kernels need no change for that: a
+// panel below the first gets a stand-in strip 0 whose bottom row and bases the host copies into the row buffer, whose workgroup finds its
+// item claimed and its progress word at "done".  Backward, from the last panel: (re-)sweep the panel up to the column the walk has reached,
+// walk until it leaves the panel upwards (MegaState), continue in the panel above.  Cost: the forward sweep + about half of it again.
+// One pair at a time (such pairs fill the device on their own).  5 Mb x 5 Mb: 79 panels of 400 strips, 40 GB.
+int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp, bool affine, int64_t n_pairs,
+                    const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
+                    const int64_t *h_alen, const int64_t *h_blen,
+                    int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream) {
+    Ctx &c = g_ctx;
+    int rc;
+    const int np = (int)n_pairs;
+    const int64_t ck = affine ? CKA : CKC_SMALL, snw = affine ? AL_SNAPW : SNAPW, rbw = affine ? 8 : 4;
+    bool p16 = true;
+    for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * (affine ? prm->gap_extend : prm->gap_open)) + 1; if (v > 32767 || v < -32768) p16 = false; }
+    std::vector<int64_t> so((size_t)np + 1, 0), h_start((size_t)np * 2);
+    int64_t m_hi = 1;
+    for (int64_t p = 0; p < n_pairs; p++) {
+        if (h_alen[p] < 1 || h_blen[p] < 1) return -1;
+        so[(size_t)p + 1] = so[(size_t)p] + h_alen[p] + h_blen[p] + 2;
+        m_hi = std::max(m_hi, h_blen[p]);
+    }
+    const int64_t nq_hi = ((m_hi + 30) & ~(int64_t)15) / ck + 2;
+    const int64_t per_strip_hi = (m_hi + 1) * rbw + ((m_hi + 15) / ck) * G * snw * 4 + nq_hi * 8;
+    const int64_t scr_b = so[(size_t)np] * (int64_t)sizeof(gnx_cigar);
+    int64_t S = (c.ws_limit - c.ws_limit / 8 - scr_b) / per_strip_hi - 3; // strips per panel
+    if (const char *e = getenv("GNX_MEGA_STRIPS")) S = atoll(e); // (tests: panels of a few strips)
+    if (S < 2) { set_err("a single strip of pair %s%lld does not fit the workspace", "", 0); return GNX_ENOMEM; }
+    if ((rc = c.tb_scr.ensure((size_t)scr_b))) return rc;
+    if ((rc = c.tb_scr_off.ensure(((size_t)np + 1) * 8))) return rc;
+    if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
+    if ((rc = c.misc.ensure(64))) return rc;
+    if ((rc = c.hcol.ensure(64))) return rc;
+    if ((rc = c.mega_state.ensure(256))) return rc;
+    c.fpc_ptr = nullptr;
+    if ((rc = c.plans.ensure(sizeof(PairPlan)))) return rc;
+    int *d_err = reinterpret_cast<int *>(c.misc.p);
+    int64_t *d_carry = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.misc.p) + 16);
+    int64_t *dn = reinterpret_cast<int64_t *>(c.nops.p);
+    int64_t *dhf = reinterpret_cast<int64_t *>(c.hcol.p);
+    gnx_cigar *d_scr = reinterpret_cast<gnx_cigar *>(c.tb_scr.p);
+    const int64_t *d_so = reinterpret_cast<const int64_t *>(c.tb_scr_off.p);
+    MegaState *d_st = reinterpret_cast<MegaState *>(c.mega_state.p);
+    int64_t *d_starts = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(c.mega_state.p) + 128); // {alpha start, beta start} of the panel
+    HIPCHK(hipMemsetAsync(c.misc.p, 0, 64, stream));
+    HIPCHK(hipMemcpyAsync(c.tb_scr_off.p, so.data(), ((size_t)np + 1) * 8, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h_start.data(), d_as, (size_t)np * 8, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_start.data() + np, d_bs, (size_t)np * 8, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    double fill_ms = 0, tb_ms = 0;
+    int64_t cells = 0, launches = 0, ws_bytes = 0;
+    for (int64_t p = 0; p < n_pairs; p++) {
+        const int64_t n = h_alen[p], m = h_blen[p];
+        const int64_t total_strips = (n + H - 1) / H, n_panels = (total_strips + S - 1) / S;
+        const int64_t nq = ((m + 30) & ~(int64_t)15) / ck + 2; // K-step blocks of a strip: the pitch of the bases, the same in every panel
+        const int64_t top_b = (m + 1) * rbw + nq * 8;           // one saved boundary: the row + its bases
+        if ((rc = c.mega_rows.ensure((size_t)(n_panels * top_b)))) return rc;
+        char *tops = reinterpret_cast<char *>(c.mega_rows.p);
+        cells += n * m;
+        // (re-)sweep of panel k over columns 1 .. mcols
+        PairPlan pl;
+        int64_t cur_strips_local = 0; // strips of the current panel incl. the stand-in
+        auto sweep_panel = [&](int64_t k, int64_t mcols, bool final_score) -> int {
+            const int64_t r0 = k * S * H, rows = std::min(n, (k + 1) * S * H) - r0, virt = k > 0 ? H : 0;
+            const int64_t real = (rows + H - 1) / H, local = real + (k > 0 ? 1 : 0), planned = local + (k + 1 < n_panels ? 1 : 0); // (+1: the last real strip hands its row down)
+            cur_strips_local = local;
+            pl.n = (int32_t)(rows + virt); pl.m = (int32_t)mcols; pl.words = 0; pl.strips = (int32_t)planned;
+            pl.trace_off = 0; pl.dcol_off = 0; pl.col_off = 0; pl.s_off = 0; pl.rowbuf_off = 0; pl.ckpt_off = 0;
+            pl.hcol_off = final_score ? 0 : 1; pl.src = 0; pl.rowi_off = 0; pl.s_pitch = nq;
+            const int64_t rb_e = (planned - 1) * (mcols + 1), sn_e = ((mcols + 15) / ck) * planned * G * snw, bs_e = planned * nq;
+            int r2;
+            if ((r2 = c.rowbuf.ensure((size_t)std::max<int64_t>(rb_e, 1) * rbw))) return r2;
+            if ((r2 = c.fp_ckpt.ensure((size_t)std::max<int64_t>(sn_e, 1) * 4))) return r2;
+            if ((r2 = c.cl_bases.ensure((size_t)bs_e * 8))) return r2;
+            if ((r2 = c.strip_map.ensure((size_t)local * 16 + 8))) return r2;
+            ws_bytes = std::max(ws_bytes, rb_e * rbw + sn_e * 4 + bs_e * 8);
+            std::vector<int2> smap((size_t)local);
+            for (int64_t st = 0; st < local; st++) smap[(size_t)st] = make_int2(0, (int)st);
+            int *d_sprog = reinterpret_cast<int *>(reinterpret_cast<char *>(c.strip_map.p) + (size_t)local * 8);
+            const int64_t starts[2] = {h_start[(size_t)p] + r0 - virt, h_start[(size_t)(np + p)]};
+            HIPCHK(hipMemcpyAsync(c.plans.p, &pl, sizeof(PairPlan), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)local * 8, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_starts, starts, 16, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)local * 8 + 8, stream));
+            HIPCHK(hipMemsetAsync(c.cl_bases.p, 0, (size_t)bs_e * 8, stream));
+            if (k > 0) { // the stand-in strip 0: done and claimed; its bottom row and bases = what the panel above handed down
+                const int pre[1] = {0x7fffffff}, one[1] = {1};
+                HIPCHK(hipMemcpyAsync(d_sprog, pre, 4, hipMemcpyHostToDevice, stream));
+                HIPCHK(hipMemcpyAsync(d_sprog + local, one, 4, hipMemcpyHostToDevice, stream));
+                HIPCHK(hipMemcpyAsync(c.rowbuf.p, tops + k * top_b, (size_t)(mcols + 1) * rbw, hipMemcpyDeviceToDevice, stream));
+                HIPCHK(hipMemcpyAsync(c.cl_bases.p, tops + k * top_b + (m + 1) * rbw, (size_t)nq * 8, hipMemcpyDeviceToDevice, stream));
+                // (no conversion: the keys are V' = V - e (i + j) with the PAIR's row i in every panel -- the recurrences never look at i, and
+                // column 0 of a global alignment is the same constant in every row; only the final un-rebasing used the panel's row count, below)
+            }
+            HIPCHK(hipStreamSynchronize(stream)); // (pl, smap, starts are locals)
+            const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
+            const int2 *d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
+            long long *dbs = reinterpret_cast<long long *>(c.cl_bases.p);
+            int *dsn = reinterpret_cast<int *>(c.fp_ckpt.p);
+            KParams kps = kp;
+            kps.ckc = (int)ck; kps.rb_pub = RB_PUB;
+            const dim3 gridS((unsigned)local);
+            HIPCHK(hipEventRecord(c.ev[1], stream));
+            if (affine) {
+                int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
+                if (p16) hipLaunchKernelGGL((al_sweep_kernel<true, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                else hipLaunchKernelGGL((al_sweep_kernel<false, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            } else {
+                int *drb = reinterpret_cast<int *>(c.rowbuf.p);
+                if (p16) hipLaunchKernelGGL((cl_sweep_kernel<true, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                else hipLaunchKernelGGL((cl_sweep_kernel<false, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c.ev[2], stream));
+            launches++;
+            if (k + 1 < n_panels && mcols == m) { // hand the last real strip's bottom row and bases down (forward pass only)
+                HIPCHK(hipMemcpyAsync(tops + (k + 1) * top_b, reinterpret_cast<char *>(c.rowbuf.p) + (size_t)((local - 1) * (m + 1)) * rbw, (size_t)(m + 1) * rbw, hipMemcpyDeviceToDevice, stream));
+                HIPCHK(hipMemcpyAsync(tops + (k + 1) * top_b + (m + 1) * rbw, reinterpret_cast<char *>(c.cl_bases.p) + (size_t)((local - 1) * nq) * 8, (size_t)nq * 8, hipMemcpyDeviceToDevice, stream));
+            }
+            HIPCHK(hipEventSynchronize(c.ev[2]));
+            float f = 0;
+            HIPCHK(hipEventElapsedTime(&f, c.ev[1], c.ev[2]));
+            fill_ms += f;
+            return GNX_OK;
+        };
+        for (int64_t k = 0; k < n_panels; k++) if ((rc = sweep_panel(k, m, k + 1 == n_panels))) return rc; // forward; the last panel's working set stays
+        // backward
+        MegaState st;
+        memset(&st, 0, sizeof(st));
+        int64_t jcur = m;
+        for (int64_t k = n_panels - 1; k >= 0; k--) {
+            if (k + 1 < n_panels && (rc = sweep_panel(k, jcur, false))) return rc;
+            const int64_t r0 = k * S * H, virt = k > 0 ? H : 0;
+            st.virt = (int32_t)virt; st.row_off = r0 - virt;
+            if (st.resume) { st.wi = pl.n; st.wj = (int32_t)jcur; }
+            HIPCHK(hipMemcpyAsync(d_st, &st, sizeof(st), hipMemcpyHostToDevice, stream));
+            const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
+            const long long *dbs = reinterpret_cast<const long long *>(c.cl_bases.p);
+            const int *dsn = reinterpret_cast<const int *>(c.fp_ckpt.p);
+            HIPCHK(hipEventRecord(c.ev[1], stream));
+            if (affine) {
+                const int2 *drb2 = reinterpret_cast<const int2 *>(c.rowbuf.p);
+                if (p16) hipLaunchKernelGGL((al_walk_kernel<true, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_score + p, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                else hipLaunchKernelGGL((al_walk_kernel<false, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_score + p, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+            } else {
+                const int *drb = reinterpret_cast<const int *>(c.rowbuf.p);
+                if (p16) hipLaunchKernelGGL((cl_walk_kernel<true, 1, CKC_SMALL, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_score + p, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                else hipLaunchKernelGGL((cl_walk_kernel<false, 1, CKC_SMALL, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_score + p, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c.ev[2], stream));
+            HIPCHK(hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            float f = 0;
+            HIPCHK(hipEventElapsedTime(&f, c.ev[1], c.ev[2]));
+            tb_ms += f;
+            if (st.done) break;
+            if (k == 0) { set_err("internal: the walk left the first panel upwards%s", ""); return GNX_ETRACE; }
+            st.resume = 1;
+            jcur = st.wj;
+        }
+        HIPCHK(hipMemcpyAsync(d_score + p, dhf, 8, hipMemcpyDeviceToDevice, stream)); // h(n, m) of the last panel's forward sweep ...
+        { // ... un-rebased by the kernel with the panel's row count: the rows above the panel are still owed
+            const int64_t r0l = (n_panels - 1) * S * H, n_local = (n - r0l) + (n_panels > 1 ? H : 0);
+            const long long owed = (long long)(affine ? prm->gap_extend : prm->gap_open) * (n - n_local);
+            if (owed) hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<long long *>(d_score + p), (int64_t)1, owed);
+        }
+    }
+    if ((rc = launch_scan(dn, np, d_ops_off, d_carry, stream))) return rc;
+    {
+        // reverse_runs_kernel reads plans[p].src: one plan per pair whose src is the pair's index
+        std::vector<PairPlan> pls((size_t)np);
+        memset(pls.data(), 0, (size_t)np * sizeof(PairPlan));
+        for (int p = 0; p < np; p++) pls[(size_t)p].src = p;
+        if ((rc = c.plans.ensure((size_t)np * sizeof(PairPlan)))) return rc;
+        HIPCHK(hipMemcpyAsync(c.plans.p, pls.data(), (size_t)np * sizeof(PairPlan), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(reverse_runs_kernel, dim3((unsigned)np), dim3(256), 0, stream, reinterpret_cast<const PairPlan *>(c.plans.p), np, d_scr, d_so, dn, d_ops_off, d_ops, ops_capacity, d_err);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream)); // (pls is a local)
+    }
+    int h_misc[16];
+    HIPCHK(hipMemcpyAsync(h_misc, c.misc.p, 64, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    c.timing.fill_ms = fill_ms; c.timing.traceback_ms = tb_ms; c.timing.total_ms = fill_ms + tb_ms;
+    c.timing.cells = cells; c.timing.n_launches = launches; c.timing.trace_bytes = ws_bytes;
+    c.timing.dominant_ms = fill_ms; c.timing.dominant_launches = launches; c.timing.fast_path = 5;
+    int64_t total;
+    memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
+    if (out_total) *out_total = total;
+    const int ef = h_misc[0];
+    if (ef & 1) { set_err("a base >= 5 was found: the reference would panic (index out of range)%s", ""); return GNX_EBASE; }
+    if (ef & 16) { set_err("a strip waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
     if (ef & 2) { set_err("unexpected traceback%s", ""); return GNX_ETRACE; }
     if (ef & 4) { set_err("CIGAR buffer too small: need %s%lld elements", "", (long long)total); return GNX_ECAPACITY; }
     return GNX_OK;
@@ -1245,9 +1448,15 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // ~8.5e-14 s per cell, the walk costs ~7e-8 s per pair plus ~1e-11 s per column: ConstGap 150 x 10 000 18.6 -> 16.1 ms per 65 536
         // pairs (1000 pairs: 1.81 -> 1.25 ms), but 150 x 2000, 500 x 600 and 1000 x 1200 lose 1.4 .. 2.6 x and stay on the stored matrix.
         const bool long_windows = !affine && cells_ld >= 1.4e6L * (long double)n_pairs && cols_ld >= 48.0L * rows_ld;
-        if (use && (oor || (any_multi && big) || long_windows || (cl && cl[0] == '2'))) {
-            rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, rebase);
+        const bool mega_forced = getenv("GNX_MEGA_STRIPS") != nullptr; // (tests: row panels of a few strips)
+        if (use && (oor || (any_multi && big) || long_windows || (cl && cl[0] == '2') || mega_forced)) {
+            rc = (mega_forced && spread_ok) ? -1 : run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, rebase);
             if (rc != -1) return rc;
+            // one pair's bottom rows + snapshots do not fit what the device has: row panels (run_device_mega; always on moving bases)
+            if (spread_ok) {
+                rc = run_device_mega(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+                if (rc != -1) return rc;
+            }
             if (oor) { set_err("pair %s%lld needs more snapshot workspace than the device has free", "", (long long)first_oor); return GNX_ENOMEM; }
         }
     }
@@ -1874,7 +2083,7 @@ void gnx_shutdown(void) {
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,
-                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.cl_bases, &c.sc_prof_a, &c.sc_prof_b, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
+                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.cl_bases, &c.sc_prof_a, &c.sc_prof_b, &c.mega_rows, &c.mega_state, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
                           &c.sd_tmp[0], &c.sd_tmp[1], &c.sd_tmp[2], &c.sd_tmp[3], &c.sd_tmp[4], &c.sd_tmp[5], &c.sd_tmp[6], &c.sd_tmp[7]};
         for (DevBuf *b : bufs) b->release();
         PinBuf *pins[] = {&c.h_plans, &c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};

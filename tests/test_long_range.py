@@ -174,6 +174,31 @@ def test_beyond_int32_in_every_mode(gpu_lib):
     common.assert_same(got, oracle.align_batch(0, MX["HumanChimpTwo"], 50, -150, [a], [win], 10000, 10000, threads=1), "gapOpen > 0")
 
 
+@pytest.mark.parametrize("strips", ["2", "3", "7"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 4])
+def test_row_panels_forced(gpu_lib, monkeypatch, mode, strips):
+    """GNX_MEGA_STRIPS=k: the row-panel path (run_device_mega: forward sweep panel by panel, the bottom row of a panel handed to the next one with
+    its bases; backward re-sweep of a panel up to the column the walk has reached, the walk resumed from what it carried out of the panel below)
+    with panels of k strips -- pairs of 1 .. 14 panels, checkerboards small and large (quirks Q1 / Q2 across panel borders), against the oracle"""
+    monkeypatch.setenv("GNX_MEGA_STRIPS", strips)
+    affine = mode in (0, 2)
+    rng = np.random.default_rng(40 + mode)
+    alphas, betas = [], []
+    for n, extra, sub, indel in ((2100, 0, 0.05, 0.03), (1500, 900, 0.05, 0.03), (700, 2500, 0.08, 0.05), (3300, 40, 0.02, 0.004), (150, 1200, 0.05, 0.02), (330, 700, 0.2, 0.1)):
+        a, b = _related(rng, n, extra, sub=sub, indel=indel)
+        alphas.append(a); betas.append(b)
+    alphas.append(rng.integers(0, 4, size=1000).astype(np.uint8)); betas.append(rng.integers(0, 4, size=800).astype(np.uint8))  # unrelated
+    w = rng.integers(0, 4, size=3000).astype(np.uint8)
+    alphas.append(common.mutate(rng, w[1200:2300], sub=0.04, indel=0.03, geo=0.5)); betas.append(w)  # a read inside a window: long leading / trailing gaps
+    for cs in ((10000, 1000, 7) if mode in (0, 1) else (10000,)):
+        for name, go, ge in ((("HumanChimpTwo", -600, -150), ("HoxD55", 0, -70)) if affine else (("HumanChimpTwo", -430, 0),)):
+            p = gpu_lib.make_params(mode, MX[name], go, ge, cs, cs)
+            got = gpu_lib.align_batch(p, alphas, betas)
+            assert gpu_lib.get_timing()["fast_path"] == 5
+            exp = oracle.align_batch(mode, MX[name], go, ge, alphas, betas, cs, cs, threads=8)
+            common.assert_same(got, exp, "mode %d cs %d %s" % (mode, cs, name))
+
+
 def _long_pairs():
     import importlib.util
     spec = importlib.util.spec_from_file_location("long_pairs", os.path.join(common.HERE, "..", "tools", "long_pairs.py"))

@@ -28,7 +28,10 @@ CASES = {
     "const_150k": (False, 150000, 30000, 502),
     "affine_1M": (True, 1000000, 0, 1234),
     "const_300k_2M": (False, 300000, 0, 1235),
+    "affine_2M": (True, 2000000, 0, 1236),      # 4e12 cells: bottom rows + snapshots of all strips would be 500 GB -> row panels (run_device_mega)
+    "affine_5M": (True, 5000000, 0, 1237),      # 2.5e13 cells: the size of the cmd/cigarToBed fixture the reference ships (.MISSING_LARGE_BLOBS:1-3)
 }
+DEFAULT_GPU_CASES = ("const_150k", "affine_340k", "affine_1M", "const_300k_2M", "affine_2M")
 ORACLE_CASES = ("affine_340k", "const_150k")
 
 
@@ -86,7 +89,7 @@ def run_gpu(names):
         sc, go, ge = params(affine)
         p = _lib.make_params(_lib.GNX_AFFINE_GAP if affine else _lib.GNX_CONST_GAP, sc, go, ge, 10000, 10000)
         best = None
-        for rep in range(3):
+        for rep in range(3 if a.shape[0] * b.shape[0] < 2e12 else 1):
             t0 = time.perf_counter()
             score, ops, off = _lib.align_batch(p, [a], [b])
             wall = time.perf_counter() - t0
@@ -98,7 +101,7 @@ def run_gpu(names):
         row = {"case": name, "fn": "AffineGap(HumanChimpTwo,-600,-150)" if affine else "ConstGap(HumanChimpTwo,-430)", "n": int(a.shape[0]), "m": int(b.shape[0]),
                "cells": int(a.shape[0]) * int(b.shape[0]), "call_s": round(wall, 4), "sweep_ms": round(tm["fill_ms"], 2), "walk_ms": round(tm["traceback_ms"], 2),
                "cells_per_s_call": float("%.4g" % (a.shape[0] * b.shape[0] / wall)), "cells_per_s_kernels": float("%.4g" % (a.shape[0] * b.shape[0] / (tm["total_ms"] * 1e-3))),
-               "workspace_bytes": int(tm["trace_bytes"]), "route": int(tm["fast_path"]), "score": int(score[0]), "runs": int(ops.shape[0]),
+               "workspace_bytes": int(tm["trace_bytes"]), "route": {2: "snapshot path", 5: "row panels"}.get(int(tm["fast_path"]), int(tm["fast_path"])), "launches": int(tm["n_launches"]), "score": int(score[0]), "runs": int(ops.shape[0]),
                "consumes_n_m": (ni, nj) == (a.shape[0], b.shape[0]), "rescored_equals_score": total == int(score[0])}
         if name in fx:
             row["equals_oracle"] = digest(score[0], ops) == {k: fx[name][k] for k in ("score", "runs", "sha256")}
@@ -111,4 +114,4 @@ if __name__ == "__main__":
     if mode == "oracle":
         run_oracle(names or ORACLE_CASES)
     else:
-        run_gpu(names or list(CASES))
+        run_gpu(names or list(DEFAULT_GPU_CASES))
