@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void al_sweep_kernel(const PairPlan *__restrict
                 r0i = rbase_const((long long)kp.o4 + TI, Bown);
                 if (rb_on && l == 0) rbase_store(my_bases + t0 / CKA, Bown, piped);
             }
-            if (t0 > 0 && t0 % CKA == 0 && gact && t0 <= m_eff + 15) { // snapshot: the state the wave resumes from at step t0
+            if (t0 > 0 && t0 % CKA == 0 && gact && t0 <= m_eff + 15 && (!REBASE || snap != nullptr)) { // snapshot: the state the wave resumes from at step t0 (REBASE, no buffer: a forward pass of row panels, which keeps none)
                 uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / CKA - 1) * pl.strips + s) * G + l) * AL_SNAPW);
                 dst[0] = make_uint4((unsigned)rt[0], (unsigned)rt[1], (unsigned)rt[2], (unsigned)rt[3]);
                 dst[1] = make_uint4((unsigned)rt[4], (unsigned)rt[5], (unsigned)rt[6], (unsigned)rt[7]);

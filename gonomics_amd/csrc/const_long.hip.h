@@ -269,7 +269,7 @@ __device__ __forceinline__ void cl_sweep_body(int *__restrict__ lds, const PairP
                 r0v = rbase_const(2, Bown);
                 if (rb_on && l == 0) rbase_store(my_bases + t0 / kp.ckc, Bown, piped);
             }
-            if (t0 > 0 && t0 % kp.ckc == 0 && gact && t0 <= m_eff + 15) { // snapshot: the state the wave resumes from at step t0
+            if (t0 > 0 && t0 % kp.ckc == 0 && gact && t0 <= m_eff + 15 && (!REBASE || snap != nullptr)) { // snapshot: the state the wave resumes from at step t0 (REBASE, no buffer: a forward pass of row panels, which keeps none)
                 uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / kp.ckc - 1) * pl.strips + s) * G + l) * SNAPW);
                 dst[0] = make_uint4((unsigned)val[0], (unsigned)val[1], (unsigned)val[2], (unsigned)val[3]);
                 dst[1] = make_uint4((unsigned)val[4], (unsigned)val[5], (unsigned)val[6], (unsigned)val[7]);

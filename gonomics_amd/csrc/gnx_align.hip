@@ -872,11 +872,24 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
         m_hi = std::max(m_hi, h_blen[p]);
     }
     const int64_t nq_hi = ((m_hi + 30) & ~(int64_t)15) / ck + 2;
-    const int64_t per_strip_hi = (m_hi + 1) * rbw + ((m_hi + 15) / ck) * G * snw * 4 + nq_hi * 8;
+    const int64_t strip_fwd_hi = (m_hi + 1) * rbw + nq_hi * 8;                                   // forward pass: bottom row + bases
+    const int64_t strip_bwd_hi = strip_fwd_hi + ((m_hi + 15) / ck) * G * snw * 4;                 // backward pass: + snapshots
     const int64_t scr_b = so[(size_t)np] * (int64_t)sizeof(gnx_cigar);
-    int64_t S = (c.ws_limit - c.ws_limit / 8 - scr_b) / per_strip_hi - 3; // strips per panel
-    if (const char *e = getenv("GNX_MEGA_STRIPS")) S = atoll(e); // (tests: panels of a few strips)
-    if (S < 2) { set_err("a single strip of pair %s%lld does not fit the workspace", "", 0); return GNX_ENOMEM; }
+    // such a pair cannot run any other way: it is given what the device has free (plus what these buffers hold already), not the workspace
+    // limit that leaves room for other contexts' batches -- strips in flight are what keeps the device busy (400 strips: a quarter of it)
+    int64_t budget = c.ws_limit - c.ws_limit / 8;
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            const int64_t avail = (int64_t)fr + (int64_t)(c.rowbuf.cap + c.fp_ckpt.cap + c.tb_scr.cap + c.cl_bases.cap + c.mega_rows.cap);
+            budget = std::max(budget, avail / 2); // (the forward pass's row buffer stays allocated under the backward pass's snapshots: 0.5 + 0.3 of what is there)
+        }
+    }
+    budget -= scr_b;
+    int64_t Sb = budget / strip_bwd_hi - 3, Sf = budget / strip_fwd_hi - 3; // strips per backward / forward panel
+    if (const char *e = getenv("GNX_MEGA_STRIPS")) { Sb = atoll(e); Sf = 2 * Sb; } // (tests: panels of a few strips, forward panels of two backward ones)
+    if (Sb < 2) { set_err("a single strip of pair %s%lld does not fit the workspace", "", 0); return GNX_ENOMEM; }
+    Sf = std::max(Sb, Sf / Sb * Sb); // a forward panel = a whole number of backward panels: their top rows are what it saves
     if ((rc = c.tb_scr.ensure((size_t)scr_b))) return rc;
     if ((rc = c.tb_scr_off.ensure(((size_t)np + 1) * 8))) return rc;
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
@@ -902,26 +915,25 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
     int64_t cells = 0, launches = 0, ws_bytes = 0;
     for (int64_t p = 0; p < n_pairs; p++) {
         const int64_t n = h_alen[p], m = h_blen[p];
-        const int64_t total_strips = (n + H - 1) / H, n_panels = (total_strips + S - 1) / S;
+        const int64_t total_strips = (n + H - 1) / H, n_bwd = (total_strips + Sb - 1) / Sb;
         const int64_t nq = ((m + 30) & ~(int64_t)15) / ck + 2; // K-step blocks of a strip: the pitch of the bases, the same in every panel
         const int64_t top_b = (m + 1) * rbw + nq * 8;           // one saved boundary: the row + its bases
-        if ((rc = c.mega_rows.ensure((size_t)(n_panels * top_b)))) return rc;
-        char *tops = reinterpret_cast<char *>(c.mega_rows.p);
+        if ((rc = c.mega_rows.ensure((size_t)(n_bwd * top_b)))) return rc;
+        char *tops = reinterpret_cast<char *>(c.mega_rows.p); // tops[b]: the row above backward panel b (b >= 1)
         cells += n * m;
-        // (re-)sweep of panel k over columns 1 .. mcols
         PairPlan pl;
-        int64_t cur_strips_local = 0; // strips of the current panel incl. the stand-in
-        auto sweep_panel = [&](int64_t k, int64_t mcols, bool final_score) -> int {
-            const int64_t r0 = k * S * H, rows = std::min(n, (k + 1) * S * H) - r0, virt = k > 0 ? H : 0;
-            const int64_t real = (rows + H - 1) / H, local = real + (k > 0 ? 1 : 0), planned = local + (k + 1 < n_panels ? 1 : 0); // (+1: the last real strip hands its row down)
-            cur_strips_local = local;
+        // sweep of the strips [s0, s0 + cnt) of the pair over columns 1 .. mcols; forward: no snapshots, the bottom rows of every Sb-th strip saved
+        auto sweep_rows = [&](int64_t s0, int64_t cnt, int64_t mcols, bool forward) -> int {
+            const int64_t r0 = s0 * H, rows = std::min(n, (s0 + cnt) * H) - r0, virt = s0 > 0 ? H : 0;
+            const bool last = s0 + cnt >= total_strips;
+            const int64_t local = cnt + (s0 > 0 ? 1 : 0), planned = local + (last ? 0 : 1); // (+1: the last real strip hands its row down)
             pl.n = (int32_t)(rows + virt); pl.m = (int32_t)mcols; pl.words = 0; pl.strips = (int32_t)planned;
             pl.trace_off = 0; pl.dcol_off = 0; pl.col_off = 0; pl.s_off = 0; pl.rowbuf_off = 0; pl.ckpt_off = 0;
-            pl.hcol_off = final_score ? 0 : 1; pl.src = 0; pl.rowi_off = 0; pl.s_pitch = nq;
-            const int64_t rb_e = (planned - 1) * (mcols + 1), sn_e = ((mcols + 15) / ck) * planned * G * snw, bs_e = planned * nq;
+            pl.hcol_off = (forward && last) ? 0 : 1; pl.src = 0; pl.rowi_off = 0; pl.s_pitch = nq;
+            const int64_t rb_e = (planned - 1) * (mcols + 1), sn_e = forward ? 0 : ((mcols + 15) / ck) * planned * G * snw, bs_e = planned * nq;
             int r2;
             if ((r2 = c.rowbuf.ensure((size_t)std::max<int64_t>(rb_e, 1) * rbw))) return r2;
-            if ((r2 = c.fp_ckpt.ensure((size_t)std::max<int64_t>(sn_e, 1) * 4))) return r2;
+            if (!forward && (r2 = c.fp_ckpt.ensure((size_t)std::max<int64_t>(sn_e, 1) * 4))) return r2;
             if ((r2 = c.cl_bases.ensure((size_t)bs_e * 8))) return r2;
             if ((r2 = c.strip_map.ensure((size_t)local * 16 + 8))) return r2;
             ws_bytes = std::max(ws_bytes, rb_e * rbw + sn_e * 4 + bs_e * 8);
@@ -934,20 +946,21 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             HIPCHK(hipMemcpyAsync(d_starts, starts, 16, hipMemcpyHostToDevice, stream));
             HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)local * 8 + 8, stream));
             HIPCHK(hipMemsetAsync(c.cl_bases.p, 0, (size_t)bs_e * 8, stream));
-            if (k > 0) { // the stand-in strip 0: done and claimed; its bottom row and bases = what the panel above handed down
-                const int pre[1] = {0x7fffffff}, one[1] = {1};
-                HIPCHK(hipMemcpyAsync(d_sprog, pre, 4, hipMemcpyHostToDevice, stream));
-                HIPCHK(hipMemcpyAsync(d_sprog + local, one, 4, hipMemcpyHostToDevice, stream));
-                HIPCHK(hipMemcpyAsync(c.rowbuf.p, tops + k * top_b, (size_t)(mcols + 1) * rbw, hipMemcpyDeviceToDevice, stream));
-                HIPCHK(hipMemcpyAsync(c.cl_bases.p, tops + k * top_b + (m + 1) * rbw, (size_t)nq * 8, hipMemcpyDeviceToDevice, stream));
+            if (s0 > 0) { // the stand-in strip 0: done and claimed; its bottom row and bases = what the strip above handed down
                 // (no conversion: the keys are V' = V - e (i + j) with the PAIR's row i in every panel -- the recurrences never look at i, and
                 // column 0 of a global alignment is the same constant in every row; only the final un-rebasing used the panel's row count, below)
+                const int pre[1] = {0x7fffffff}, one[1] = {1};
+                const char *top = tops + (s0 / Sb) * top_b;
+                HIPCHK(hipMemcpyAsync(d_sprog, pre, 4, hipMemcpyHostToDevice, stream));
+                HIPCHK(hipMemcpyAsync(d_sprog + local, one, 4, hipMemcpyHostToDevice, stream));
+                HIPCHK(hipMemcpyAsync(c.rowbuf.p, top, (size_t)(mcols + 1) * rbw, hipMemcpyDeviceToDevice, stream));
+                HIPCHK(hipMemcpyAsync(c.cl_bases.p, top + (m + 1) * rbw, (size_t)nq * 8, hipMemcpyDeviceToDevice, stream));
             }
             HIPCHK(hipStreamSynchronize(stream)); // (pl, smap, starts are locals)
             const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
             const int2 *d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
             long long *dbs = reinterpret_cast<long long *>(c.cl_bases.p);
-            int *dsn = reinterpret_cast<int *>(c.fp_ckpt.p);
+            int *dsn = forward ? nullptr : reinterpret_cast<int *>(c.fp_ckpt.p); // (null: the sweep keeps no snapshots)
             KParams kps = kp;
             kps.ckc = (int)ck; kps.rb_pub = RB_PUB;
             const dim3 gridS((unsigned)local);
@@ -964,9 +977,13 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c.ev[2], stream));
             launches++;
-            if (k + 1 < n_panels && mcols == m) { // hand the last real strip's bottom row and bases down (forward pass only)
-                HIPCHK(hipMemcpyAsync(tops + (k + 1) * top_b, reinterpret_cast<char *>(c.rowbuf.p) + (size_t)((local - 1) * (m + 1)) * rbw, (size_t)(m + 1) * rbw, hipMemcpyDeviceToDevice, stream));
-                HIPCHK(hipMemcpyAsync(tops + (k + 1) * top_b + (m + 1) * rbw, reinterpret_cast<char *>(c.cl_bases.p) + (size_t)((local - 1) * nq) * 8, (size_t)nq * 8, hipMemcpyDeviceToDevice, stream));
+            if (forward) { // the bottom rows (and bases) of the strips that end a backward panel: the top boundaries of the panels below them
+                for (int64_t e = s0 + Sb; e <= s0 + cnt && e < total_strips; e += Sb) {
+                    const int64_t sl = (e - 1 - s0) + (s0 > 0 ? 1 : 0); // that strip's slot in this launch
+                    char *top = tops + (e / Sb) * top_b;
+                    HIPCHK(hipMemcpyAsync(top, reinterpret_cast<char *>(c.rowbuf.p) + (size_t)(sl * (m + 1)) * rbw, (size_t)(m + 1) * rbw, hipMemcpyDeviceToDevice, stream));
+                    HIPCHK(hipMemcpyAsync(top + (m + 1) * rbw, reinterpret_cast<char *>(c.cl_bases.p) + (size_t)(sl * nq) * 8, (size_t)nq * 8, hipMemcpyDeviceToDevice, stream));
+                }
             }
             HIPCHK(hipEventSynchronize(c.ev[2]));
             float f = 0;
@@ -974,29 +991,37 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             fill_ms += f;
             return GNX_OK;
         };
-        for (int64_t k = 0; k < n_panels; k++) if ((rc = sweep_panel(k, m, k + 1 == n_panels))) return rc; // forward; the last panel's working set stays
+        for (int64_t s0 = 0; s0 < total_strips; s0 += Sf) if ((rc = sweep_rows(s0, std::min(Sf, total_strips - s0), m, true))) return rc; // forward
+        int64_t n_local_last = 0;
+        { const int64_t s0l = ((total_strips - 1) / Sf) * Sf; n_local_last = (n - s0l * H) + (s0l > 0 ? H : 0); } // rows of the launch that wrote h(n, m)
+        HIPCHK(hipMemcpyAsync(d_score + p, dhf, 8, hipMemcpyDeviceToDevice, stream)); // h(n, m) of the last forward launch ...
+        { // ... un-rebased by the kernel with that launch's row count: the rows above it are still owed
+            const long long owed = (long long)(affine ? prm->gap_extend : prm->gap_open) * (n - n_local_last);
+            if (owed) hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<long long *>(d_score + p), (int64_t)1, owed);
+        }
         // backward
         MegaState st;
         memset(&st, 0, sizeof(st));
         int64_t jcur = m;
-        for (int64_t k = n_panels - 1; k >= 0; k--) {
-            if (k + 1 < n_panels && (rc = sweep_panel(k, jcur, false))) return rc;
-            const int64_t r0 = k * S * H, virt = k > 0 ? H : 0;
+        for (int64_t k = n_bwd - 1; k >= 0; k--) {
+            if ((rc = sweep_rows(k * Sb, std::min(Sb, total_strips - k * Sb), jcur, false))) return rc;
+            const int64_t r0 = k * Sb * H, virt = k > 0 ? H : 0;
             st.virt = (int32_t)virt; st.row_off = r0 - virt;
             if (st.resume) { st.wi = pl.n; st.wj = (int32_t)jcur; }
             HIPCHK(hipMemcpyAsync(d_st, &st, sizeof(st), hipMemcpyHostToDevice, stream));
             const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
             const long long *dbs = reinterpret_cast<const long long *>(c.cl_bases.p);
             const int *dsn = reinterpret_cast<const int *>(c.fp_ckpt.p);
+            int64_t *d_tmp_score = dhf + 2; // (the walk writes hfin[pl.hcol_off] here when it ends: not the pair's score, see above)
             HIPCHK(hipEventRecord(c.ev[1], stream));
             if (affine) {
                 const int2 *drb2 = reinterpret_cast<const int2 *>(c.rowbuf.p);
-                if (p16) hipLaunchKernelGGL((al_walk_kernel<true, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_score + p, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
-                else hipLaunchKernelGGL((al_walk_kernel<false, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_score + p, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                if (p16) hipLaunchKernelGGL((al_walk_kernel<true, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                else hipLaunchKernelGGL((al_walk_kernel<false, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
             } else {
                 const int *drb = reinterpret_cast<const int *>(c.rowbuf.p);
-                if (p16) hipLaunchKernelGGL((cl_walk_kernel<true, 1, CKC_SMALL, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_score + p, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
-                else hipLaunchKernelGGL((cl_walk_kernel<false, 1, CKC_SMALL, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_score + p, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                if (p16) hipLaunchKernelGGL((cl_walk_kernel<true, 1, CKC_SMALL, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                else hipLaunchKernelGGL((cl_walk_kernel<false, 1, CKC_SMALL, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c.ev[2], stream));
@@ -1009,12 +1034,6 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             if (k == 0) { set_err("internal: the walk left the first panel upwards%s", ""); return GNX_ETRACE; }
             st.resume = 1;
             jcur = st.wj;
-        }
-        HIPCHK(hipMemcpyAsync(d_score + p, dhf, 8, hipMemcpyDeviceToDevice, stream)); // h(n, m) of the last panel's forward sweep ...
-        { // ... un-rebased by the kernel with the panel's row count: the rows above the panel are still owed
-            const int64_t r0l = (n_panels - 1) * S * H, n_local = (n - r0l) + (n_panels > 1 ? H : 0);
-            const long long owed = (long long)(affine ? prm->gap_extend : prm->gap_open) * (n - n_local);
-            if (owed) hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<long long *>(d_score + p), (int64_t)1, owed);
         }
     }
     if ((rc = launch_scan(dn, np, d_ops_off, d_carry, stream))) return rc;
