@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-end GPU sequence: parity suite, smoke, bench lines, rocprofv3 kernel stats + HBM / SQ PMC passes (separate runs, as the
 # MI355X guide prescribes).  Usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tag]; then, in the build container,
-# python tools/collect_profiles.py gpurun_out/<tag> r4
-tag=${1:-r4}
+# python tools/collect_profiles.py gpurun_out/<tag> r5
+tag=${1:-r5}
 repo=$PWD
 out=$repo/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
@@ -49,6 +49,15 @@ g++ -std=c++17 -O2 -Iinclude -o tools/bench_cabi.bin tools/bench_cabi.cpp gonomi
 g++ -std=c++17 -O2 -pthread -Iinclude -o tests/cpp/concurrent_pairs_test.bin tests/cpp/concurrent_pairs_test.cpp gonomics_amd/libgonomics_align_hip.so -Wl,-rpath,$PWD/gonomics_amd -L/opt/rocm/lib -lamdhip64 2>> $out/bench.err && tests/cpp/concurrent_pairs_test.bin 16 1000 8 > $out/concurrent_pairs.json 2>> $out/bench.err
 bash tools/pmc_env_ab.sh gpurun_out/$tag/c5_ab "--no-cpu --no-host --no-extras --series long --pairs 1024 --steps 1 --warmup 0 --verify 0" "cl_sweep" "wg4:GNX_CL_WG=1" "one_strip:GNX_CL_WG=0" > /dev/null 2>> $out/bench.err; cp gpurun_out/$tag/c5_ab/pmc_ab.txt $out/pmc_c5_wg_ab.txt
 timeout 300 python tools/pair_latency.py 300 > $out/pair_latency.jsonl 2>> $out/bench.err
+# round 5: pairs beyond the static int32 range (snapshot path on moving bases; the 2 Mb / 5 Mb row-panel runs are in profiles/r5_long_pairs.jsonl),
+# the latency geometry against the general path, the whole cmd/faChunkAlign command, the graph aligner at genome scale
+timeout 600 python tools/long_pairs.py gpu const_150k affine_340k affine_1M const_300k_2M > $out/long_pairs.jsonl 2>> $out/bench.err
+timeout 600 python tools/lat_crossover.py affine > $out/lat_crossover.jsonl 2>> $out/bench.err
+timeout 600 python tools/lat_crossover.py const >> $out/lat_crossover.jsonl 2>> $out/bench.err
+timeout 600 python tools/bench_n1_cmd.py 8 30000 3 > $out/n1_cmd.json 2>> $out/bench.err
+timeout 900 python tools/bench_gsw_genome.py 100000000 300000 2>> $out/bench.err | grep "^{" > $out/gsw_genome.jsonl
+timeout 1500 python tools/bench_gsw_genome.py 3000000000 200000 2>> $out/bench.err | grep "^{" >> $out/gsw_genome.jsonl
+timeout 600 python tools/gsw_threads.py 2>> $out/bench.err | grep "^{" > $out/gsw_threads.jsonl
 tools/wg_occupancy.bin > $out/wg_occupancy.txt 2>> $out/bench.err
 timeout 700 python tools/stress.py ${GNX_STRESS_S:-420} 77 > $out/stress.log 2>&1
 [ -n "$GNX_SWITCH_MATRIX" ] && bash tools/switch_matrix.sh > $out/switch_matrix.log 2>&1
