@@ -139,7 +139,8 @@ def main():
         fh.write("\n")
     for nm, dst in (("bench.json", "_bench.json"), ("bench_long.json", "_bench_long.json"), ("all_series.jsonl", "_all_series.jsonl"), ("host_entry.jsonl", "_host_entry.jsonl"),
                     ("shapes_affine.jsonl", "_shapes_affine.jsonl"), ("shapes_const.jsonl", "_shapes_const.jsonl"), ("shapes_local.jsonl", "_shapes_local.jsonl"), ("gsw_reads.jsonl", "_gsw_reads.jsonl"), ("cabi_n1_n2.jsonl", "_cabi_n1_n2.jsonl"),
-                    ("pytest_gpu.log", "_pytest_gpu.log"), ("bench_2ranks_shared_gpu.json", "_bench_2ranks_shared_gpu.json"), ("lds_occupancy.txt", "_lds_occupancy.txt"), ("stress.log", "_stress.log"), ("switch_matrix.log", "_switch_matrix.log"), ("concurrent_pairs.json", "_concurrent_pairs.json"), ("pmc_c5_wg_ab.txt", "_pmc_c5_wg_ab.txt"), ("wg_occupancy.txt", "_wg_occupancy.txt"), ("pair_latency.jsonl", "_pair_latency.jsonl")):
+                    ("pytest_gpu.log", "_pytest_gpu.log"), ("bench_2ranks_shared_gpu.json", "_bench_2ranks_shared_gpu.json"), ("lds_occupancy.txt", "_lds_occupancy.txt"), ("stress.log", "_stress.log"), ("switch_matrix.log", "_switch_matrix.log"), ("concurrent_pairs.json", "_concurrent_pairs.json"), ("pmc_c5_wg_ab.txt", "_pmc_c5_wg_ab.txt"), ("wg_occupancy.txt", "_wg_occupancy.txt"), ("pair_latency.jsonl", "_pair_latency.jsonl"), ("n1_cmd.json", "_n1_cmd.json"), ("gsw_threads.jsonl", "_gsw_threads.jsonl"),
+                    ("lat_crossover.jsonl", "_lat_crossover.jsonl"), ("gsw_genome.jsonl", "_gsw_genome.jsonl")):
         p = os.path.join(src, nm)
         if os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copyfile(p, os.path.join(prof, rnd + dst))
