@@ -256,7 +256,7 @@ QUIRK_CASES = [
 
 # Route assertions.  tools/switch_matrix.sh runs the suites under switches that force another route (GNX_FASTPATH, GNX_CLONG,
 # GNX_NO_HFORM set OUTSIDE the test): results must not change, but "which path ran" legitimately does -- then only results are checked.
-OUTER_ROUTE_SWITCH = any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM", "GNX_LAT", "GNX_WIDE")) or os.environ.get("GNX_FP_SMALL") == "0"  # (at import: before any monkeypatch)
+OUTER_ROUTE_SWITCH = any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM", "GNX_LAT", "GNX_WIDE", "GNX_MEGA_STRIPS")) or os.environ.get("GNX_FP_SMALL") == "0"  # (at import: before any monkeypatch)
 
 
 def shipped_small_batch_rule():

@@ -851,18 +851,18 @@ def test_small_batch_routing(gpu_lib, monkeypatch):
     for small, route in (("1", 1), ("0", 3)):  # 3: the stored-matrix path in its latency geometry (96 reads = 192 strips of 128 rows: a small launch)
         monkeypatch.setenv("GNX_FP_SMALL", small)
         got = gpu_lib.align_batch_windows(p, reads.reshape(-1), a_start, a_len, chunk, b_start, b_len)
-        if not any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM", "GNX_LAT")):
+        if not common.OUTER_ROUTE_SWITCH:
             assert gpu_lib.get_timing()["fast_path"] == route
         common.assert_same(got, exp, "GNX_FP_SMALL=%s" % small)
     # one pair per call (a loop of align.AffineGap calls): the latency geometry by default, the general path's 16 x 10 mapping with GNX_LAT=0
     monkeypatch.delenv("GNX_FP_SMALL")
     got = gpu_lib.align_batch_windows(p, reads[0], a_start[:1], a_len[:1], chunk, b_start[:1], b_len[:1])
-    if not any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM", "GNX_LAT")):
+    if not common.OUTER_ROUTE_SWITCH:
         assert gpu_lib.get_timing()["fast_path"] == 3
     common.assert_same(got, (exp[0][:1], exp[1][:int(exp[2][1])], exp[2][:2]), "one pair")
     monkeypatch.setenv("GNX_LAT", "0")
     got = gpu_lib.align_batch_windows(p, reads[0], a_start[:1], a_len[:1], chunk, b_start[:1], b_len[:1])
-    if not any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM")):
+    if not common.OUTER_ROUTE_SWITCH:
         assert gpu_lib.get_timing()["fast_path"] == 0
     common.assert_same(got, (exp[0][:1], exp[1][:int(exp[2][1])], exp[2][:2]), "one pair")
 
