@@ -370,7 +370,7 @@ def extra_c5(_lib, L, scores, chunk_h, dev, torch, n_pairs=1024, n=20000, m=1000
     okk = _sample_check(_lib, scores, 1, -430, 0, (sc, ops, off), pick, lambda x: reads[x], lambda x: wins[x])
     cells = n_pairs * n * m
     return {"entry": "gnx_align_batch_device (GNX_CONST_GAP)", "pairs": n_pairs, "value": cells / dt, "unit": "DP cells/s", "ms_per_step": dt * 1e3,
-            "path": {0: "general_path", 1: "fast_path", 2: "const_long", 3: "latency_geometry", 4: "int64_fallback"}[tm["fast_path"]], "bit_exact_sample": okk, "bit_exact_pairs_checked": int(pick.shape[0]),
+            "path": {0: "general_path", 1: "fast_path", 2: "const_long", 3: "latency_geometry", 4: "int64_fallback", 5: "row_panels", 6: "const_long_w64"}[tm["fast_path"]], "bit_exact_sample": okk, "bit_exact_pairs_checked": int(pick.shape[0]),
             "kernel_ms": {"sweep": tm["dominant_ms"], "walk_and_rest": tm["traceback_ms"]},
             "roofline": _roofline_of(tm, n, m, 2, n_pairs, int(off[-1]))}
 
@@ -714,7 +714,7 @@ def main():
         abytes_step = algorithmic_bytes(READ_LEN, CHUNK_LEN, S["bits"], n_pairs, step_total_ops)
         achieved = abytes / (fill_avg_ms * 1e-3) / 1e9
         achieved_step = abytes_step * world / (ms_per_step * 1e-3) / 1e9 / world  # per GPU
-        path = {0: "general_path", 1: "fast_path", 2: "const_long", 3: "latency_geometry", 4: "int64_fallback"}[fast_path]
+        path = {0: "general_path", 1: "fast_path", 2: "const_long", 3: "latency_geometry", 4: "int64_fallback", 5: "row_panels", 6: "const_long_w64"}[fast_path]
         kernel = {0: "fill_affine_kernel (full direction matrix)" if S["bits"] == 6 else "fill_const_kernel (full direction matrix)",
                   1: "fp_sweep_kernel<%d, %s> (fast-path forward sweep)" % (19 if READ_LEN <= 152 else 20, "true" if swap else "false"),
                   2: "cl_sweep_wg_kernel<4> (score-only constant-gap sweep with wavefront snapshots, four strips per workgroup handing rows over through LDS)",

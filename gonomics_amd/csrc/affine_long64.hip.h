@@ -1,0 +1,514 @@
+// affine_long64.hip.h -- the snapshot path of affine_long.hip.h with the WHOLE WAVE on one pair: 64 lanes x 10 rows, strips of 640 rows
+// Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).  See DESIGN.md section 4.13.
+#pragma once
+#include "affine_long.hip.h"
+#include "lat_fill.hip.h" // wave_shr1
+
+namespace {
+// ------------------------------------------------------------------------------------------------------
+// al_sweep_kernel / al_walk_kernel map a pair to 16 lanes x 10 rows, four pairs per wave: right for batches, but ONE long pair -- the
+// cmd/cigarToBed case, 1 Mb x 1 Mb and beyond -- leaves 48 of 64 lanes idle in every wave of its pipeline (sweep 1.09 s per 1e12 cells).
+// Here the wavefront is the whole wave: lane l owns rows 10 l + 1 .. 10 l + 10 of a 640-row strip, the lane-to-lane moves are wave_shr:1
+// DPP moves (lat_fill.hip.h), everything else is affine_long's scheme on moving bases (REBASE, const_long.hip.h):
+//   al64_sweep_kernel  score only (add, max3, add, max, max per cell; a lane's last row keeps its tags), strips piped through the row buffer
+//                      with progress words and claims, the bottom row {dn, h} of every strip (8 B per column and 640 rows), a snapshot of
+//                      the wavefront every CK64 = 128 steps (24 dwords per lane), bases[strip][block].  A column of the bottom row is written
+//                      by lane 63 at step c + 63: its block is (c + 62) / CK64.
+//   al64_walk_kernel   one wave per pair: re-fill the tile (strip, <= CK64 + 4 steps) with the recording recurrence into three 2-bit planes
+//                      in LDS (69 KB: one workgroup per CU may declare up to 160 KB), walk inside it (quirks Q1 / Q2, run merging, MegaState for row panels: affine_long's code with 64 lanes).
+// Always on moving bases (the pairs that come here are long).  Chosen by the host for launches of few pairs (GNX_W64=0 / 2: never / always).
+// ------------------------------------------------------------------------------------------------------
+constexpr int G64 = 64;                              // lanes per pair
+constexpr int H64 = G64 * R;                         // rows per strip
+constexpr int CK64 = CKA;                            // snapshot spacing in wavefront steps (the same as affine_long's: 0.075 B of snapshots per cell)
+constexpr int AL64_WORDS = CK64 / 16 + 1;            // direction words per plane row of a tile
+constexpr int AL64_DIRG = AL64_WORDS * 3 * R * G64;  // LDS dwords of the tile
+constexpr int XB64 = G64 - 2;                        // a bottom-row column c is stored in the 16-step block of step c + 63: block index (c + XB64) / CK64
+
+template <bool P16>
+__global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                        const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                        const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                        KParams kp, int2 *__restrict__ rowbuf, int *__restrict__ snap, int64_t *__restrict__ hfin,
+                                                        int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog,
+                                                        long long *__restrict__ bases) {
+    constexpr int LW = P16 ? R / 2 : R;       // profile dwords per lane and base
+    constexpr int BST = G64 * LW;             // dwords per base plane (a multiple of 32)
+    constexpr int TI = 2, TD = 1;
+    __shared__ int lds[32 + 5 * BST];
+    const int l = threadIdx.x;
+    if (l < 25) lds[l] = kp.sc4[l] - 2 * kp.e4; // rebased diagonal move: 4*(s - 2e)
+    int *prof = &lds[32];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    const int s_own = strip_map[blockIdx.x].y;
+    const int n_stolen = claim_items(strip_prog + gridDim.x, 1, s_own);
+    if (n_stolen < 0) return;
+    const int p = strip_map[blockIdx.x].x;
+    const PairPlan pl = plans[p];
+    const uint8_t *ap = a_buf + a_start[p];
+    BetaBytes bp;
+    bp.init(b_buf, kp, b_start[p], pl.m);
+    const int m = pl.m;
+    const int Tend = (m + (G64 - 1) + 15) & ~15;
+    const int OE4 = kp.oe4, E4 = kp.e4, RB = kp.e4;
+    int vO4;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
+    int bad = 0;
+    const int64_t rb_pitch = (int64_t)m + 1;
+    for (int s = s_own - n_stolen; s <= s_own; s++) {
+        const int bid = (int)blockIdx.x - s_own + s; // block index of strip s of this pair = its slot in strip_prog
+        const bool store_row = s + 1 < pl.strips;
+        const int row0 = s * H64 + l * R;
+        int rt[R], hold[R];
+        {
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) { // column 0: M = I = -inf, D = D00 + i*ecol, rebased (a global alignment: the same constant in every row)
+            const int i = row0 + r + 1;
+            const int D1c = kp.d00_4 + i * kp.ecol4 + TD - RB * i;
+            hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
+            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;
+        }
+        int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
+        int dn_out = 0, h_out = 0, b_out = 0, sq_dn = 0, sq_h = 0;
+        int qdn = 0, qh = 0, qb = 0, ndn = 0, nh = 0, nb = 0;
+        // moving bases (REBASE, const_long.hip.h): mine; the strip above's for the two blocks the columns being loaded were written in
+        long long Bown = 0;
+        int dlo = 0, dhi = 0, qp = 0, edge = CK64, r0i = kp.o4 + TI;
+        bool dhi_ok = false;
+        long long *my_bases = bases + pl.rowi_off + (int64_t)s * pl.s_pitch;
+        auto bprod = [&](int q) -> long long { return s == 0 ? 0LL : rbase_load(my_bases - pl.s_pitch + q, true); };
+        auto boundary = [&](int c, int &odn, int &oh, int &ob) { // lanes 0 .. 15: column c of the row above the strip, the base of column c
+            odn = 0; oh = 0; ob = 0;
+            if (l < 16 && c >= 1 && c <= m) {
+                if (s == 0) {
+                    const int M3 = NEG4 + 3, I2 = r0i, D1 = NEG4 + TD; // row 0: I(0,c) = gapOpen + c*gapExtend, rebased, relative to my base
+                    oh = max3i(M3, I2, D1);
+                    odn = max3i(M3 + OE4, I2 + OE4, D1 + E4) - RB;
+                } else {
+                    const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], true);
+                    const int dd = (c + XB64 >= edge) ? dhi : dlo;
+                    odn = v.x + dd; oh = v.y + dd;
+                }
+                ob = bp.raw(c - 1);
+            }
+        };
+        auto base_off = [&](int raw, int c) { int b = (l < 16 && c >= 1 && c <= m) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
+        int rb_seen = 0;
+        auto wait_rows = [&](int cmax) { // until the strip above has published the columns <= cmax
+            if (s > 0 && rb_seen < cmax) {
+                const long long t_begin = wall_clock64();
+                while ((rb_seen = rb_progress(&strip_prog[bid - 1])) < cmax) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; }
+                }
+            }
+        };
+        wait_rows(min(16, m));
+        boundary(l + 1, qdn, qh, qb);
+        qb = base_off(qb, l + 1);
+        int wq[LW], pb_cur;
+        auto fetch = [&](int pbv, int *w) {
+            const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+#pragma unroll
+            for (int k = 0; k < LW; k++) w[k] = pw[k];
+        };
+        pb_cur = wave_shr1(qb, b_out);
+        qb = dpp_shl1(qb, qb);
+        fetch(pb_cur, wq);
+        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_dn = wave_shr1(qdn, dn_out);
+            const int up_h = wave_shr1(qh, h_out);
+            qdn = dpp_shl1(qdn, qdn);
+            qh = dpp_shl1(qh, qh);
+            if (take) qb = nqv;
+            const int pb_next = wave_shr1(qb, pb_cur);
+            qb = dpp_shl1(qb, qb);
+            int wn[LW];
+            fetch(pb_next, wn);
+            asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic
+            const int j = t - l;
+            const int *w = wq;
+            if (!CHECK || (j >= 1 && j <= m)) {
+                int hd = diag0, dnu = up_dn;
+#pragma unroll
+                for (int r = 0; r < R - 1; r++) {
+                    const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                    const int hnew = max3i(hd + S4, rt[r], dnu);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, rt[r]);
+                    const int dnn = max(ho, dnu);
+                    hd = hold[r];
+                    hold[r] = hnew;
+                    dnu = dnn;
+                }
+                { // the lane's last row with argmax tags: the row buffer's entries carry them (affine_long.hip.h)
+                    constexpr int r = R - 1;
+                    int S4;
+                    if constexpr (P16) S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff); else S4 = w[r];
+                    const int M3 = (hd | 3) + S4;
+                    const int I2 = (rt[r] & ~3) | TI;
+                    const int D1 = (dnu & ~3) | TD;
+                    const int hnew = max3i(M3, I2, D1);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, I2);
+                    dnu = max(ho, D1);
+                    hold[r] = hnew;
+                }
+                diag0 = up_h;
+                dn_out = dnu;
+                h_out = hold[R - 1];
+            }
+            sq_dn = dpp_shl1(dn_out, sq_dn); // (row 3 of the wave: lane 63 inserts, lanes 48 .. 63 hold the last 16 columns of the bottom row)
+            sq_h = dpp_shl1(h_out, sq_h);
+#pragma unroll
+            for (int k = 0; k < LW; k++) wq[k] = wn[k];
+            pb_cur = pb_next;
+        };
+
+        for (int t0 = 0; t0 < Tend; t0 += 16) {
+            if (t0 > 0 && t0 % CK64 == 0) { // move the base, then the snapshot
+                const int rep = __builtin_amdgcn_readfirstlane(hold[0]);
+                const bool rb_on = t0 <= m + (G64 - 1); // (while some lane still has columns)
+                const int d = rb_on ? (rep & ~3) : 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) { rt[r] -= d; hold[r] -= d; }
+                diag0 -= d; dn_out -= d; h_out -= d; qdn -= d; qh -= d;
+                Bown += d; dlo -= d; dhi -= d;
+                r0i = rbase_const((long long)kp.o4 + TI, Bown);
+                if (rb_on && l == 0) rbase_store(my_bases + t0 / CK64, Bown, true);
+                if (rb_on && snap != nullptr) { // snapshot: the state the wave resumes from at step t0
+                    uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / CK64 - 1) * pl.strips + s) * G64 + l) * AL_SNAPW);
+                    dst[0] = make_uint4((unsigned)rt[0], (unsigned)rt[1], (unsigned)rt[2], (unsigned)rt[3]);
+                    dst[1] = make_uint4((unsigned)rt[4], (unsigned)rt[5], (unsigned)rt[6], (unsigned)rt[7]);
+                    dst[2] = make_uint4((unsigned)rt[8], (unsigned)rt[9], (unsigned)hold[0], (unsigned)hold[1]);
+                    dst[3] = make_uint4((unsigned)hold[2], (unsigned)hold[3], (unsigned)hold[4], (unsigned)hold[5]);
+                    dst[4] = make_uint4((unsigned)hold[6], (unsigned)hold[7], (unsigned)hold[8], (unsigned)hold[9]);
+                    dst[5] = make_uint4((unsigned)diag0, (unsigned)dn_out, 0u, 0u);
+                }
+            }
+            wait_rows(min(t0 + 2 * 16, m));
+            if (s > 0) { // the columns loaded now are t0 + 17 .. t0 + 32: written by the strip above in its blocks (c + XB64) / CK64
+                while (t0 + 17 + XB64 >= edge) { qp++; edge += CK64; dlo = dhi_ok ? dhi : rbase_delta(bprod(qp), Bown); dhi_ok = false; }
+                if (!dhi_ok && t0 + 32 + XB64 >= edge) { dhi = rbase_delta(bprod(qp + 1), Bown); dhi_ok = true; }
+            }
+            boundary(t0 + 16 + l + 1, ndn, nh, nb);
+            if (t0 >= G64 && t0 + 16 <= m) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+            }
+            asm volatile("" :: "v"(ndn), "v"(nh));
+            qdn = ndn; qh = nh;
+            if (store_row) {
+                const int x = l - (G64 - 16), c = t0 + x + 1 - (G64 - 1); // lanes 48 .. 63: slot x holds what lane 63 handed down at step t0 + 1 + x
+                if (x >= 0 && c >= 1 && c <= m) rb_store(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_dn, sq_h, true);
+            }
+            if (((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[bid], t0 + 1 - (G64 - 16), l); // the bottom row is out up to column t0 + 1 - 48
+        }
+        if (m >= 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (Bown + (int64_t)hold[r] + (int64_t)RB * ((int64_t)pl.n + m)) >> 2; // plain score h(n, m)
+        }
+        rb_publish(&strip_prog[bid], 0x7fffffff, l);
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+template <bool P16>
+__global__ __launch_bounds__(64) void al64_walk_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                       const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                       KParams kp, TbParams tp, const int2 *__restrict__ rowbuf, const int *__restrict__ snap,
+                                                       const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                       const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
+                                                       const long long *__restrict__ bases, MegaState *__restrict__ mst) {
+    constexpr int LW = P16 ? R / 2 : R;
+    constexpr int BST = G64 * LW;
+    constexpr int TI = 2, TD = 1;
+    __shared__ int lds[32 + 5 * BST + AL64_DIRG + H64];
+    const int l = threadIdx.x;
+    if (l < 25) lds[l] = kp.sc4[l] - 2 * kp.e4;
+    int *prof = &lds[32];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    unsigned *dirg = reinterpret_cast<unsigned *>(&lds[32 + 5 * BST]);
+    int *hcolT = &lds[32 + 5 * BST + AL64_DIRG]; // keys h(i, m) of the strip's rows whose lanes have passed column m
+    const int p = blockIdx.x;
+    const PairPlan pl = plans[p];
+    const uint8_t *ap = a_buf + a_start[p];
+    BetaBytes bp;
+    bp.init(b_buf, kp, b_start[p], pl.m);
+    const int m = pl.m;
+    const int64_t rb_pitch = (int64_t)m + 1;
+    const int po = pl.src;
+    const int OE4 = kp.oe4, E4 = kp.e4, RB = kp.e4;
+    int vO4;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
+    int bad = 0;
+    // walker state (lane 0), as in al_walk_kernel
+    int wi = pl.n, wj = m, wk = 0, wdone = 0, pend = 1;
+    int64_t li = (pl.n > 0) ? (int64_t)(pl.n - 1) % tp.ci : 0;
+    int64_t cnt = 0, cur_run = 0;
+    int cur_op = -1, last_op = -1;
+    const int64_t sbase = scr_off[p];
+    auto flush_run = [&]() {
+        if (cur_op >= 0) {
+            gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op;
+            for (int z = 0; z < 7; z++) c._pad[z] = 0;
+            scr[sbase + cnt] = c;
+            cnt++;
+        }
+    };
+    auto emit = [&](int op, int64_t run) {
+        if (op == cur_op) cur_run += run;
+        else { flush_run(); cur_op = op; cur_run = run; }
+    };
+    // row panels (MegaState, const_long.hip.h)
+    int virt = 0;
+    int64_t row_off = 0;
+    bool pexit = false;
+    if (mst) {
+        virt = mst->virt; row_off = mst->row_off;
+        if (mst->resume) { wi = mst->wi; wj = mst->wj; wk = mst->wk; pend = mst->pend; li = mst->li; cnt = mst->cnt; cur_run = mst->cur_run; cur_op = mst->cur_op; last_op = mst->last_op; }
+        else li = (pl.n > 0) ? ((int64_t)pl.n + row_off - 1) % tp.ci : 0;
+    }
+
+    while (true) {
+        const int ci = __builtin_amdgcn_readfirstlane(wi), cj = __builtin_amdgcn_readfirstlane(wj);
+        if (__builtin_amdgcn_readfirstlane(wdone)) break;
+        if (virt > 0 && ci <= virt) { pexit = true; break; }
+        const int s = (ci - 1) / H64;
+        const int lw = (ci - 1 - s * H64) / R;
+        const int te = cj + lw;               // step of the cell the walk is at
+        const int c = (te >= 3) ? (te - 3) / CK64 : 0; // (the first two steps after a snapshot carry no usable plane fields, see al_walk_kernel)
+        const int tbeg = c * CK64;
+        const int tmin = c > 0 ? 2 : 0;
+        const int tend = te + 1;              // one step further: quirk Q1
+        const int nblk = (tend - tbeg + 15) >> 4;
+        const int row0 = s * H64 + l * R;
+        int rt[R], hold[R];
+        unsigned acc[3 * R];
+        {
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+            __syncthreads(); // table visible; the previous round's walk is over
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = row0 + r + 1;
+            const int D1c = kp.d00_4 + i * kp.ecol4 + TD - RB * i;
+            hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
+            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;
+            acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
+        }
+        int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
+        int dn_out = 0, h_out = 0, b_out = 0;
+        if (c > 0) { // resume from the snapshot of step tbeg
+            const uint4 *sp = reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G64 + l) * AL_SNAPW);
+            const uint4 x0 = sp[0], x1 = sp[1], x2 = sp[2], x3 = sp[3], x4 = sp[4], x5 = sp[5];
+            rt[0] = (int)x0.x; rt[1] = (int)x0.y; rt[2] = (int)x0.z; rt[3] = (int)x0.w; rt[4] = (int)x1.x; rt[5] = (int)x1.y; rt[6] = (int)x1.z; rt[7] = (int)x1.w;
+            rt[8] = (int)x2.x; rt[9] = (int)x2.y; hold[0] = (int)x2.z; hold[1] = (int)x2.w; hold[2] = (int)x3.x; hold[3] = (int)x3.y; hold[4] = (int)x3.z; hold[5] = (int)x3.w;
+            hold[6] = (int)x4.x; hold[7] = (int)x4.y; hold[8] = (int)x4.z; hold[9] = (int)x4.w; diag0 = (int)x5.x; dn_out = (int)x5.y;
+            h_out = hold[R - 1];
+            const int jb = tbeg - l;
+            if (jb >= 1 && jb <= m) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
+        }
+        int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
+        // the snapshot's keys are relative to the strip's base of block c; the row above, block by block, to the bases of the strip above
+        long long Bt = 0;
+        if (c > 0) Bt = bases[pl.rowi_off + (int64_t)s * pl.s_pitch + c];
+        const int r0i = rbase_const((long long)kp.o4 + TI, Bt);
+        auto boundary = [&](int cc, int &odn, int &oh, int &ob) {
+            odn = 0; oh = 0; ob = 0;
+            if (l < 16 && cc >= 1 && cc <= m) {
+                if (s == 0) {
+                    const int M3 = NEG4 + 3, I2 = r0i, D1 = NEG4 + TD;
+                    oh = max3i(M3, I2, D1);
+                    odn = max3i(M3 + OE4, I2 + OE4, D1 + E4) - RB;
+                } else {
+                    const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
+                    const int q = (cc + XB64) / CK64;
+                    const int dd = rbase_delta(bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + q], Bt);
+                    odn = v.x + dd; oh = v.y + dd;
+                }
+                ob = bp.raw(cc - 1);
+            }
+        };
+        auto base_off = [&](int raw, int cc) { int b = (l < 16 && cc >= 1 && cc <= m) ? bp.value(raw, cc - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
+        boundary(tbeg + l + 1, qdn, qh, qb);
+        qb = base_off(qb, tbeg + l + 1);
+        int wq[LW], pb_cur;
+        auto fetch = [&](int pbv, int *w) {
+            const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+#pragma unroll
+            for (int k = 0; k < LW; k++) w[k] = pw[k];
+        };
+        pb_cur = wave_shr1(qb, b_out);
+        qb = dpp_shl1(qb, qb);
+        fetch(pb_cur, wq);
+        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_dn = wave_shr1(qdn, dn_out);
+            const int up_h = wave_shr1(qh, h_out);
+            qdn = dpp_shl1(qdn, qdn);
+            qh = dpp_shl1(qh, qh);
+            if (take) qb = nqv;
+            const int pb_next = wave_shr1(qb, pb_cur);
+            qb = dpp_shl1(qb, qb);
+            int wn[LW];
+            fetch(pb_next, wn);
+            asm volatile("" ::: "memory");
+            const int j = t - l;
+            const int *w = wq;
+            if (!CHECK || (j >= 1 && j <= m)) {
+                int hd = diag0, dnu = up_dn;
+#pragma unroll
+                for (int r = 0; r < R; r++) { // the recording h-form of fill_affine_kernel (rebased keys)
+                    const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                    acc[r] = alignbit2((unsigned)hd, acc[r]);
+                    acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
+                    acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
+                    const int M3 = (hd | 3) + S4;
+                    const int I2 = (rt[r] & ~3) | TI;
+                    const int D1 = (dnu & ~3) | TD;
+                    const int hnew = max3i(M3, I2, D1);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, I2);
+                    const int dnn = max(ho, D1);
+                    hd = hold[r];
+                    hold[r] = hnew;
+                    dnu = dnn;
+                }
+                diag0 = up_h;
+                dn_out = dnu;
+                h_out = hold[R - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < LW; k++) wq[k] = wn[k];
+            pb_cur = pb_next;
+        };
+        for (int b = 0; b < nblk; b++) {
+            const int t0 = tbeg + 16 * b;
+            boundary(t0 + 16 + l + 1, ndn, nh, nb);
+            if (t0 >= G64 && t0 + 16 <= m) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+            }
+            qdn = ndn; qh = nh;
+            const int miss = (t0 + 16 - l) - m;
+            const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+#pragma unroll
+                for (int r = 0; r < R; r++) dirg[((b * 3 + k) * R + r) * G64 + l] = acc[k * R + r] >> sh;
+            }
+            if (b == nblk - 1 && t0 + 16 - l >= m) { // lanes that have passed column m hold h(i, m) of their rows
+#pragma unroll
+                for (int r = 0; r < R; r++) hcolT[l * R + r] = hold[r];
+            }
+        }
+        __syncthreads();
+        if (l == 0) {
+            int i = wi, j = wj, k = wk;
+            if (pend) { k = 3 - (hcolT[i - 1 - s * H64] & 3); pend = 0; }
+            while (true) {
+                if (i == 0 || j == 0) { wdone = 1; break; }
+                const int i0 = i - 1 - s * H64;
+                if (i0 < 0) break; // left the strip through its top edge
+                const int l2 = i0 / R, r2 = i0 - l2 * R;
+                const int t1 = j + l2 - 1 - tbeg;
+                if (t1 < tmin) break; // left the (usable part of the) tile through its skewed left edge
+                const int pos = t1 & 15;
+                const unsigned w = dirg[(((t1 >> 4) * 3 + k) * R + r2) * G64 + l2];
+                int tag = (int)((w >> (2 * pos)) & 3u);
+                if (tag == 0) { atomicOr(err, 2); wdone = 1; break; }
+                if (k == 1) { // horizontal run inside this word, see traceback_kernel
+                    int avail = min(pos + 1, j);
+                    if (t1 < 16) avail = min(avail, pos - tmin + 1);
+                    unsigned x = w ^ 0xAAAAAAAAu;
+                    if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
+                    const int lowcut = pos + 1 - avail;
+                    if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+                    int steps;
+                    if (x == 0) steps = avail;
+                    else {
+                        const int pnz = (31 - __clz((int)x)) >> 1;
+                        tag = (int)((w >> (2 * pnz)) & 3u);
+                        if (tag == 0) { atomicOr(err, 2); wdone = 1; break; }
+                        steps = pos - pnz + 1;
+                        k = 3 - tag;
+                    }
+                    emit(1, steps); j -= steps; last_op = 1;
+                    continue;
+                }
+                emit(k, 1);
+                last_op = k;
+                const bool up_exit = (li == 0);
+                li = up_exit ? tp.ci - 1 : li - 1;
+                i--;
+                if (k == 0) j--;
+                k = 3 - tag;
+                if (up_exit && i > 0 && j > 0) { // quirk Q1 (affineGap.go:305): restart in the argmax state of the entry cell (i, j)
+                    if (j < m) { // = the M-plane field of (i+1, j+1): the row the walk just left, at most one step past its cell
+                        const int l3 = (i0) / R, r3 = i0 - l3 * R, t3 = (j + 1) + l3 - 1 - tbeg;
+                        const unsigned w3 = dirg[(((t3 >> 4) * 3 + 0) * R + r3) * G64 + l3];
+                        k = 3 - (int)((w3 >> (2 * (t3 & 15))) & 3u);
+                    } else if (i - 1 - s * H64 >= 0 && m + (i - 1 - s * H64) / R - 1 - tbeg >= tmin) k = 3 - (hcolT[i - 1 - s * H64] & 3);
+                    else pend = 1; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                }
+            }
+            wi = i; wj = j; wk = k;
+        }
+    }
+    if (l == 0 && mst) {
+        mst->wi = wi; mst->wj = wj; mst->wk = wk; mst->pend = pend; mst->li = li; mst->cnt = cnt; mst->cur_run = cur_run; mst->cur_op = cur_op; mst->last_op = last_op;
+        mst->done = pexit ? 0 : 1;
+    }
+    if (l == 0 && !pexit) {
+        // Step 4 (affineGap.go:135-139) -- quirk Q2 when the corner is not the origin
+        const int64_t gi = (int64_t)wi + (wi > 0 ? row_off : 0);
+        const bool up_exit = (last_op != 1) && (gi % tp.ci == 0);
+        const bool left_exit = (last_op != 2) && ((int64_t)wj % tp.cj == 0);
+        if (!up_exit && left_exit) emit(2, gi);
+        else if (up_exit && !left_exit) emit(1, wj);
+        flush_run();
+        nops[po] = cnt;
+        score_out[po] = hfin[pl.hcol_off];
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+} // namespace

@@ -44,6 +44,7 @@
 #include "const_long_wg.hip.h"
 #include "const_long_walk.hip.h"
 #include "affine_long.hip.h"
+#include "affine_long64.hip.h"
 #include "lat_fill.hip.h"
 #include "lat_wide.hip.h"
 #include "seed_kernels.hip.h"
@@ -592,23 +593,26 @@ int run_device_fp(const gnx_params *prm, const KParams &kp, const TbParams &tp, 
 
 int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp, bool affine, int64_t n_pairs,
                     const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs, const int64_t *h_alen, const int64_t *h_blen,
-                    int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream);
+                    int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool w64);
 
 // Pairs without a stored direction matrix (const_long.hip.h; affine: affine_long.hip.h): score-only sweep that keeps the strips' bottom
 // rows and a snapshot of the wavefront every CKC / CKA steps, then one fused re-fill + walk kernel.  Every n, m >= 1 (validated by the caller).
 // Returns GNX_OK, an error, or -1 when the batch should take the general path (a single pair exceeds the workspace).
 // rebase: the REBASE instantiations (const_long.hip.h): keys relative to a base every strip moves along -- pairs of any length
+// w64 (affine, implies rebase): the whole wave on one pair, strips of 640 rows (affine_long64.hip.h) -- launches of very few pairs
 int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &tp, bool affine, int64_t n_pairs,
                      const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                      const int64_t *h_alen, const int64_t *h_blen,
-                     int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool rebase) {
+                     int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool rebase, bool w64 = false) {
     Ctx &c = g_ctx;
     int rc;
+    if (w64 && !(affine && rebase)) w64 = false;
+    const int64_t HS = w64 ? H64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair
     // snapshot spacing of the constant-gap form (const_long.hip.h): the wide tiles only when the walk will have the GPU full of long chains
     int64_t ckc = CKC_SMALL;
     {
         int64_t strips_sum = 0;
-        for (int64_t p = 0; p < n_pairs; p++) strips_sum += (h_alen[p] + H - 1) / H;
+        for (int64_t p = 0; p < n_pairs; p++) strips_sum += (h_alen[p] + HS - 1) / HS;
         if (n_pairs > 1536 && strips_sum >= 64 * n_pairs) ckc = CKC;
         if (const char *e = getenv("GNX_CL_CKC")) { const int v = atoi(e); if (v == CKC || v == CKC_SMALL) ckc = v; }
     }
@@ -621,14 +625,14 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         int64_t budget = c.ws_limit - c.ws_limit / 16;
         const int64_t rbw = affine ? 8 : 4, ck = affine ? CKA : ckc, snw = affine ? AL_SNAPW : SNAPW; // row-buffer entry bytes, snapshot spacing / dwords
         auto bytes_of = [&](int64_t rb2, int64_t sn2, int64_t sc2, int64_t bs2) { return rbw * rb2 + 4 * sn2 + (int64_t)sizeof(gnx_cigar) * sc2 + 8 * bs2; };
-        auto nq_of = [&](int64_t m) { return rebase ? (((m + 30) & ~(int64_t)15) / ck + 2) : 0; }; // K-step blocks of a strip (REBASE: one int64 base each)
+        auto nq_of = [&](int64_t m) { return rebase ? (((m + GS + 14) & ~(int64_t)15) / ck + 2) : 0; }; // K-step blocks of a strip (REBASE: one int64 base each)
         // One pair that needs more than the workspace limit (a 1 Mb x 1 Mb pair: 50 GB of bottom rows + 43 GB of snapshots) is given what
         // the device has free, plus what these buffers already hold: the limit is there to leave room for other contexts' batches, and such a
         // pair cannot run any other way (the stored matrix would be 750 GB).
         int64_t one_max = 0;
         for (int64_t p = 0; p < n_pairs; p++) {
-            const int64_t n = h_alen[p], m = h_blen[p], strips = (n + H - 1) / H;
-            one_max = std::max(one_max, bytes_of((strips - 1) * (m + 1), (m + 15) / ck * strips * G * snw, n + m + 2, strips * nq_of(m)));
+            const int64_t n = h_alen[p], m = h_blen[p], strips = (n + HS - 1) / HS;
+            one_max = std::max(one_max, bytes_of((strips - 1) * (m + 1), (m + GS - 1) / ck * strips * GS * snw, n + m + 2, strips * nq_of(m)));
         }
         if (one_max > budget) {
             size_t fr = 0, tot = 0;
@@ -640,8 +644,8 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         }
         for (int64_t p = 0; p < n_pairs; p++) {
             const int64_t n = h_alen[p], m = h_blen[p];
-            const int64_t strips = (n + H - 1) / H, ncp = (m + 15) / ck;
-            const int64_t prb = (strips - 1) * (m + 1), psn = ncp * strips * G * snw, psc = n + m + 2, pbs = strips * nq_of(m);
+            const int64_t strips = (n + HS - 1) / HS, ncp = (m + GS - 1) / ck;
+            const int64_t prb = (strips - 1) * (m + 1), psn = ncp * strips * GS * snw, psc = n + m + 2, pbs = strips * nq_of(m);
             if (bytes_of(prb, psn, psc, pbs) > budget) return -1;
             if (bytes_of(rb + prb, sn + psn, sc + psc, bs + pbs) > budget) { // new chunk, 4-aligned so that waves stay whole
                 int64_t cb = p & ~(int64_t)3;
@@ -650,7 +654,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
                 for (int64_t q2 = cb; q2 < p; q2++) {
                     PairPlan &pq = plans[(size_t)q2];
                     pq.rowbuf_off = rb; pq.ckpt_off = sn; so[(size_t)q2] = sc; pq.hcol_off = q2 - cb; pq.src = (int32_t)(q2 - cb); pq.rowi_off = bs;
-                    rb += (int64_t)(pq.strips - 1) * (pq.m + 1); sn += (int64_t)((pq.m + 15) / ck) * pq.strips * G * snw; sc += (int64_t)pq.n + pq.m + 2; bs += (int64_t)pq.strips * pq.s_pitch;
+                    rb += (int64_t)(pq.strips - 1) * (pq.m + 1); sn += (int64_t)((pq.m + GS - 1) / ck) * pq.strips * GS * snw; sc += (int64_t)pq.n + pq.m + 2; bs += (int64_t)pq.strips * pq.s_pitch;
                 }
                 chunk_begin.push_back(cb);
             }
@@ -706,7 +710,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         int64_t m_maxc = 0;
         for (int64_t q2 = b; q2 < e; q2++) { if (plans[(size_t)q2].strips > 1) multi = true; m_maxc = std::max<int64_t>(m_maxc, plans[(size_t)q2].m); }
         int64_t n_blocks = (np + 3) / 4;
-        const bool piped = multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB && !no_pipe();
+        const bool piped = w64 || (multi && n_blocks < 3072 && m_maxc >= 8 * RB_PUB && !no_pipe());
         // constant gap, int16 profile: several strips per workgroup, rows handed over through LDS (cl_sweep_wg_kernel; GNX_CL_WG=0: one strip per workgroup)
         constexpr int CLW_NW = 4;
         const bool wg = piped && !affine && p16 && !rebase && !(getenv("GNX_CL_WG") && atoi(getenv("GNX_CL_WG")) == 0);
@@ -714,8 +718,9 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         const int2 *d_smap = nullptr;
         int *d_sprog = nullptr;
         if (piped) {
-            std::vector<int2> smap; // (group, item): an item = one strip, or CLW_NW consecutive strips
-            for (int gq = 0; gq < (np + 3) / 4; gq++) {
+            std::vector<int2> smap; // (group, item): an item = one strip, or CLW_NW consecutive strips; w64: (pair, strip)
+            if (w64) for (int q3 = 0; q3 < np; q3++) for (int st2 = 0; st2 < plans[(size_t)(b + q3)].strips; st2++) smap.push_back(make_int2(q3, st2));
+            for (int gq = 0; !w64 && gq < (np + 3) / 4; gq++) {
                 int smax = 0;
                 for (int q3 = 0; q3 < 4 && gq * 4 + q3 < np; q3++) smax = std::max(smax, (int)plans[(size_t)(b + gq * 4 + q3)].strips);
                 for (int st2 = 0; st2 < (smax + per_item - 1) / per_item; st2++) smap.push_back(make_int2(gq, st2));
@@ -746,7 +751,10 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
 #define GNX_CL_SWEEP(P_, RBS_) hipLaunchKernelGGL((cl_sweep_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs)
 #define GNX_CL_FLAT(P_, RBS_) hipLaunchKernelGGL((cl_sweep_flat_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, dbs)
         if (rebase) HIPCHK(hipMemsetAsync(dbs, 0, (size_t)max_bs * 8, stream));
-        if (affine) { if (rebase) { if (p16) GNX_AL_SWEEP(true, true); else GNX_AL_SWEEP(false, true); } else { if (p16) GNX_AL_SWEEP(true, false); else GNX_AL_SWEEP(false, false); } }
+        if (w64) {
+            if (p16) hipLaunchKernelGGL((al64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            else hipLaunchKernelGGL((al64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+        } else if (affine) { if (rebase) { if (p16) GNX_AL_SWEEP(true, true); else GNX_AL_SWEEP(false, true); } else { if (p16) GNX_AL_SWEEP(true, false); else GNX_AL_SWEEP(false, false); } }
         else if (wg) hipLaunchKernelGGL(cl_sweep_wg_kernel<CLW_NW>, gridS, dim3(64 * CLW_NW), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
         else if (piped) { if (rebase) { if (p16) GNX_CL_SWEEP(true, true); else GNX_CL_SWEEP(false, true); } else { if (p16) GNX_CL_SWEEP(true, false); else GNX_CL_SWEEP(false, false); } }
         else { if (rebase) { if (p16) GNX_CL_FLAT(true, true); else GNX_CL_FLAT(false, true); } else { if (p16) GNX_CL_FLAT(true, false); else GNX_CL_FLAT(false, false); } }
@@ -757,7 +765,11 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         HIPCHK(hipEventRecord(c.ev[2], stream));
         const dim3 gridW((unsigned)((np + 3) / 4));
 #define GNX_AL_WALK(P_, RBS_) hipLaunchKernelGGL((al_walk_kernel<P_, RBS_>), gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr)
-        if (affine) { if (rebase) { if (p16) GNX_AL_WALK(true, true); else GNX_AL_WALK(false, true); } else { if (p16) GNX_AL_WALK(true, false); else GNX_AL_WALK(false, false); } }
+        if (w64) { // one pair per workgroup
+            const dim3 gw((unsigned)np);
+            if (p16) hipLaunchKernelGGL((al64_walk_kernel<true>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
+            else hipLaunchKernelGGL((al64_walk_kernel<false>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
+        } else if (affine) { if (rebase) { if (p16) GNX_AL_WALK(true, true); else GNX_AL_WALK(false, true); } else { if (p16) GNX_AL_WALK(true, false); else GNX_AL_WALK(false, false); } }
 #undef GNX_AL_WALK
         else if (rebase) { // (one pair per workgroup, plain walk)
             const dim3 gw((unsigned)np);
@@ -817,7 +829,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         fill_ms += f1; tb_ms += f2;
         for (int64_t p = b; p < e; p++) {
             const PairPlan &pl = plans[(size_t)p];
-            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + 15) / (affine ? CKA : ckc)) * pl.strips * G * (affine ? AL_SNAPW : SNAPW);
+            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + GS - 1) / (affine ? CKA : ckc)) * pl.strips * GS * (affine ? AL_SNAPW : SNAPW);
         }
     }
     HIPCHK(hipEventRecord(c.ev[2], stream));
@@ -828,7 +840,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     HIPCHK(hipEventElapsedTime(&tot, c.ev[0], c.ev[2]));
     c.timing.fill_ms = fill_ms; c.timing.traceback_ms = tb_ms; c.timing.total_ms = tot;
     c.timing.cells = cells; c.timing.n_launches = (int64_t)nchunks; c.timing.trace_bytes = trace_bytes;
-    c.timing.dominant_ms = fill_ms; c.timing.dominant_launches = (int64_t)nchunks; c.timing.fast_path = 2;
+    c.timing.dominant_ms = fill_ms; c.timing.dominant_launches = (int64_t)nchunks; c.timing.fast_path = w64 ? 6 : 2;
     int64_t total;
     memcpy(&total, reinterpret_cast<char *>(h_misc) + 16, 8);
     if (out_total) *out_total = total;
@@ -838,7 +850,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         if (t_no_pipe) { set_err("a strip waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
         if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx] a pipelined strip timed out: the call runs again with sequential strips\n");
         t_no_pipe = true;
-        rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, rebase);
+        rc = run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, rebase, false);
         t_no_pipe = false;
         return rc;
     }
@@ -857,9 +869,11 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
 int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp, bool affine, int64_t n_pairs,
                     const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
                     const int64_t *h_alen, const int64_t *h_blen,
-                    int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream) {
+                    int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool w64) {
     Ctx &c = g_ctx;
     int rc;
+    if (!affine) w64 = false;
+    const int64_t HS = w64 ? H64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair (w64: affine_long64.hip.h)
     const int np = (int)n_pairs;
     const int64_t ck = affine ? CKA : CKC_SMALL, snw = affine ? AL_SNAPW : SNAPW, rbw = affine ? 8 : 4;
     bool p16 = true;
@@ -871,9 +885,9 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
         so[(size_t)p + 1] = so[(size_t)p] + h_alen[p] + h_blen[p] + 2;
         m_hi = std::max(m_hi, h_blen[p]);
     }
-    const int64_t nq_hi = ((m_hi + 30) & ~(int64_t)15) / ck + 2;
+    const int64_t nq_hi = ((m_hi + GS + 14) & ~(int64_t)15) / ck + 2;
     const int64_t strip_fwd_hi = (m_hi + 1) * rbw + nq_hi * 8;                                   // forward pass: bottom row + bases
-    const int64_t strip_bwd_hi = strip_fwd_hi + ((m_hi + 15) / ck) * G * snw * 4;                 // backward pass: + snapshots
+    const int64_t strip_bwd_hi = strip_fwd_hi + ((m_hi + GS - 1) / ck) * GS * snw * 4;                 // backward pass: + snapshots
     const int64_t scr_b = so[(size_t)np] * (int64_t)sizeof(gnx_cigar);
     // such a pair cannot run any other way: it is given what the device has free (plus what these buffers hold already), not the workspace
     // limit that leaves room for other contexts' batches -- strips in flight are what keeps the device busy (400 strips: a quarter of it)
@@ -915,8 +929,8 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
     int64_t cells = 0, launches = 0, ws_bytes = 0;
     for (int64_t p = 0; p < n_pairs; p++) {
         const int64_t n = h_alen[p], m = h_blen[p];
-        const int64_t total_strips = (n + H - 1) / H, n_bwd = (total_strips + Sb - 1) / Sb;
-        const int64_t nq = ((m + 30) & ~(int64_t)15) / ck + 2; // K-step blocks of a strip: the pitch of the bases, the same in every panel
+        const int64_t total_strips = (n + HS - 1) / HS, n_bwd = (total_strips + Sb - 1) / Sb;
+        const int64_t nq = ((m + GS + 14) & ~(int64_t)15) / ck + 2; // K-step blocks of a strip: the pitch of the bases, the same in every panel
         const int64_t top_b = (m + 1) * rbw + nq * 8;           // one saved boundary: the row + its bases
         if ((rc = c.mega_rows.ensure((size_t)(n_bwd * top_b)))) return rc;
         char *tops = reinterpret_cast<char *>(c.mega_rows.p); // tops[b]: the row above backward panel b (b >= 1)
@@ -924,13 +938,13 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
         PairPlan pl;
         // sweep of the strips [s0, s0 + cnt) of the pair over columns 1 .. mcols; forward: no snapshots, the bottom rows of every Sb-th strip saved
         auto sweep_rows = [&](int64_t s0, int64_t cnt, int64_t mcols, bool forward) -> int {
-            const int64_t r0 = s0 * H, rows = std::min(n, (s0 + cnt) * H) - r0, virt = s0 > 0 ? H : 0;
+            const int64_t r0 = s0 * HS, rows = std::min(n, (s0 + cnt) * HS) - r0, virt = s0 > 0 ? HS : 0;
             const bool last = s0 + cnt >= total_strips;
             const int64_t local = cnt + (s0 > 0 ? 1 : 0), planned = local + (last ? 0 : 1); // (+1: the last real strip hands its row down)
             pl.n = (int32_t)(rows + virt); pl.m = (int32_t)mcols; pl.words = 0; pl.strips = (int32_t)planned;
             pl.trace_off = 0; pl.dcol_off = 0; pl.col_off = 0; pl.s_off = 0; pl.rowbuf_off = 0; pl.ckpt_off = 0;
             pl.hcol_off = (forward && last) ? 0 : 1; pl.src = 0; pl.rowi_off = 0; pl.s_pitch = nq;
-            const int64_t rb_e = (planned - 1) * (mcols + 1), sn_e = forward ? 0 : ((mcols + 15) / ck) * planned * G * snw, bs_e = planned * nq;
+            const int64_t rb_e = (planned - 1) * (mcols + 1), sn_e = forward ? 0 : ((mcols + GS - 1) / ck) * planned * GS * snw, bs_e = planned * nq;
             int r2;
             if ((r2 = c.rowbuf.ensure((size_t)std::max<int64_t>(rb_e, 1) * rbw))) return r2;
             if (!forward && (r2 = c.fp_ckpt.ensure((size_t)std::max<int64_t>(sn_e, 1) * 4))) return r2;
@@ -965,7 +979,11 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             kps.ckc = (int)ck; kps.rb_pub = RB_PUB;
             const dim3 gridS((unsigned)local);
             HIPCHK(hipEventRecord(c.ev[1], stream));
-            if (affine) {
+            if (w64) {
+                int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
+                if (p16) hipLaunchKernelGGL((al64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                else hipLaunchKernelGGL((al64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            } else if (affine) {
                 int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
                 if (p16) hipLaunchKernelGGL((al_sweep_kernel<true, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
                 else hipLaunchKernelGGL((al_sweep_kernel<false, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
@@ -993,7 +1011,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
         };
         for (int64_t s0 = 0; s0 < total_strips; s0 += Sf) if ((rc = sweep_rows(s0, std::min(Sf, total_strips - s0), m, true))) return rc; // forward
         int64_t n_local_last = 0;
-        { const int64_t s0l = ((total_strips - 1) / Sf) * Sf; n_local_last = (n - s0l * H) + (s0l > 0 ? H : 0); } // rows of the launch that wrote h(n, m)
+        { const int64_t s0l = ((total_strips - 1) / Sf) * Sf; n_local_last = (n - s0l * HS) + (s0l > 0 ? HS : 0); } // rows of the launch that wrote h(n, m)
         HIPCHK(hipMemcpyAsync(d_score + p, dhf, 8, hipMemcpyDeviceToDevice, stream)); // h(n, m) of the last forward launch ...
         { // ... un-rebased by the kernel with that launch's row count: the rows above it are still owed
             const long long owed = (long long)(affine ? prm->gap_extend : prm->gap_open) * (n - n_local_last);
@@ -1005,7 +1023,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
         int64_t jcur = m;
         for (int64_t k = n_bwd - 1; k >= 0; k--) {
             if ((rc = sweep_rows(k * Sb, std::min(Sb, total_strips - k * Sb), jcur, false))) return rc;
-            const int64_t r0 = k * Sb * H, virt = k > 0 ? H : 0;
+            const int64_t r0 = k * Sb * HS, virt = k > 0 ? HS : 0;
             st.virt = (int32_t)virt; st.row_off = r0 - virt;
             if (st.resume) { st.wi = pl.n; st.wj = (int32_t)jcur; }
             HIPCHK(hipMemcpyAsync(d_st, &st, sizeof(st), hipMemcpyHostToDevice, stream));
@@ -1014,7 +1032,11 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             const int *dsn = reinterpret_cast<const int *>(c.fp_ckpt.p);
             int64_t *d_tmp_score = dhf + 2; // (the walk writes hfin[pl.hcol_off] here when it ends: not the pair's score, see above)
             HIPCHK(hipEventRecord(c.ev[1], stream));
-            if (affine) {
+            if (w64) {
+                const int2 *drb2 = reinterpret_cast<const int2 *>(c.rowbuf.p);
+                if (p16) hipLaunchKernelGGL((al64_walk_kernel<true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                else hipLaunchKernelGGL((al64_walk_kernel<false>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+            } else if (affine) {
                 const int2 *drb2 = reinterpret_cast<const int2 *>(c.rowbuf.p);
                 if (p16) hipLaunchKernelGGL((al_walk_kernel<true, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
                 else hipLaunchKernelGGL((al_walk_kernel<false, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
@@ -1446,6 +1468,10 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const char *rbe = getenv("GNX_REBASE");
         const bool rebase = spread_ok && (oor || (rbe && rbe[0] == '1')); // GNX_REBASE=1 (tests): every pair of this path on moving bases
         if (oor && !spread_ok) use = false;
+        // the whole wave on one pair (affine_long64.hip.h): launches of up to three pairs, which would leave lane groups of al_sweep_kernel's waves idle;
+        // GNX_W64 = 0 / 2: never / for every affine launch of this path
+        const char *w64e = getenv("GNX_W64");
+        const bool w64 = affine && !no_pipe() && (int64_t)(H64 + G64 + CK64 + 64) * step4 < ((int64_t)1 << 28) && !(w64e && w64e[0] == '0') && (n_pairs <= 3 || (w64e && w64e[0] == '2'));
         long double cells_ld = 0, dir_bytes = 0, rows_ld = 0, cols_ld = 0;
         for (int64_t p = 0; use && p < n_pairs; p++) {
             if (h_alen[p] < 1 || h_blen[p] < 1) use = false;
@@ -1469,11 +1495,11 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const bool long_windows = !affine && cells_ld >= 1.4e6L * (long double)n_pairs && cols_ld >= 48.0L * rows_ld;
         const bool mega_forced = getenv("GNX_MEGA_STRIPS") != nullptr; // (tests: row panels of a few strips)
         if (use && (oor || (any_multi && big) || long_windows || (cl && cl[0] == '2') || mega_forced)) {
-            rc = (mega_forced && spread_ok) ? -1 : run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, rebase);
+            rc = (mega_forced && spread_ok) ? -1 : run_device_clong(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, rebase || w64, w64);
             if (rc != -1) return rc;
             // one pair's bottom rows + snapshots do not fit what the device has: row panels (run_device_mega; always on moving bases)
             if (spread_ok) {
-                rc = run_device_mega(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream);
+                rc = run_device_mega(prm, kp, tp, affine, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, w64);
                 if (rc != -1) return rc;
             }
             if (oor) { set_err("pair %s%lld needs more snapshot workspace than the device has free", "", (long long)first_oor); return GNX_ENOMEM; }

@@ -256,7 +256,7 @@ QUIRK_CASES = [
 
 # Route assertions.  tools/switch_matrix.sh runs the suites under switches that force another route (GNX_FASTPATH, GNX_CLONG,
 # GNX_NO_HFORM set OUTSIDE the test): results must not change, but "which path ran" legitimately does -- then only results are checked.
-OUTER_ROUTE_SWITCH = any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM", "GNX_LAT", "GNX_WIDE", "GNX_MEGA_STRIPS")) or os.environ.get("GNX_FP_SMALL") == "0"  # (at import: before any monkeypatch)
+OUTER_ROUTE_SWITCH = any(k in os.environ for k in ("GNX_FASTPATH", "GNX_CLONG", "GNX_NO_HFORM", "GNX_LAT", "GNX_WIDE", "GNX_MEGA_STRIPS", "GNX_W64")) or os.environ.get("GNX_FP_SMALL") == "0"  # (at import: before any monkeypatch)
 
 
 def shipped_small_batch_rule():
@@ -273,5 +273,7 @@ def expect_route(timing, route):
     if OUTER_ROUTE_SWITCH or (route == 1 and shipped_small_batch_rule()):
         return
     if route == 0 and timing["fast_path"] == 3:  # the stored-matrix family: small launches run it in the latency geometry (lat_fill_kernel)
+        return
+    if route == 2 and timing["fast_path"] == 6:  # the snapshot family: affine launches of up to three pairs run it with the whole wave on one pair (affine_long64.hip.h)
         return
     assert timing["fast_path"] == route, (timing["fast_path"], route)

@@ -101,7 +101,7 @@ def test_keys_beyond_int32(gpu_lib, mode):
     go, ge = (-600 * 40, -150 * 40) if mode == 0 else (-430 * 40, 0)
     p = gpu_lib.make_params(mode, sc, go, ge, 10000, 10000)
     got = gpu_lib.align_batch(p, alphas, betas)
-    assert gpu_lib.get_timing()["fast_path"] == 2
+    common.expect_route(gpu_lib.get_timing(), 2)
     exp = oracle.align_batch(mode, sc, go, ge, alphas, betas, 10000, 10000, threads=3)
     common.assert_same(got, exp)
     # what the kernels hold is 4 * (score - gapExtend * (i + j)) (ConstGap: - gapPen * (i + j)): at (n, m) beyond the 2^29 the absolute keys end at
@@ -123,7 +123,7 @@ def test_range_boundary(gpu_lib):
         p = gpu_lib.make_params(0, sc, go, ge, 10000, 10000)
         got = gpu_lib.align_batch(p, [a], [win])
         if route is not None:
-            assert gpu_lib.get_timing()["fast_path"] == route
+            common.expect_route(gpu_lib.get_timing(), route)
         exp = oracle.align_batch(0, sc, go, ge, [a], [win], 10000, 10000, threads=1)
         common.assert_same(got, exp, "n + m = %d" % total)
 
@@ -199,6 +199,64 @@ def test_row_panels_forced(gpu_lib, monkeypatch, mode, strips):
             common.assert_same(got, exp, "mode %d cs %d %s" % (mode, cs, name))
 
 
+@pytest.mark.parametrize("cs", [3, 16, 10000])
+@pytest.mark.parametrize("mode", [0, 2])  # AffineGap, AffineGap_highMem
+def test_w64_forced(gpu_lib, monkeypatch, mode, cs):
+    """GNX_CLONG=2 + GNX_W64=2: every affine pair through the snapshot path with the whole wave on one pair (affine_long64.hip.h: 64 lanes x 10
+    rows, strips of 640 rows, wave_shr moves, moving bases) -- ragged batches of one to eight strips, small checkerboards, against the oracle"""
+    monkeypatch.setenv("GNX_CLONG", "2")
+    monkeypatch.setenv("GNX_W64", "2")
+    for seed, nmax, mmax, count in ((31, 60, 400, 48), (32, 2000, 1500, 30), (33, 5000, 2600, 12), (34, 700, 9000, 10)):
+        alphas, betas = _ragged(seed + 100 * cs, count, nmax, mmax)
+        for name, go, ge in (("HumanChimpTwo", -600, -150), ("Default", -400, -30), ("HoxD55", 0, -70)):
+            p = gpu_lib.make_params(mode, MX[name], go, ge, cs, cs)
+            got = gpu_lib.align_batch(p, alphas, betas)
+            assert gpu_lib.get_timing()["fast_path"] == 6
+            exp = oracle.align_batch(mode, MX[name], go, ge, alphas, betas, cs, cs, threads=8)
+            common.assert_same(got, exp, "seed %d %s" % (seed, name))
+
+
+def test_w64_is_the_route_of_few_pairs(gpu_lib, monkeypatch):
+    """the shipped rule: affine launches of up to three pairs of the snapshot path run in the 64-lane geometry (route 6), four pairs fill the
+    lane groups of al_sweep_kernel's waves (route 2); related pairs of many strips and columns, a scaled matrix that leaves int16 (P16 off)"""
+    monkeypatch.setenv("GNX_CLONG", "2")
+    monkeypatch.delenv("GNX_W64", raising=False)
+    rng = np.random.default_rng(77)
+    pairs = [_related(rng, n, extra, sub=0.05, indel=0.03) for n, extra in ((6000, 0), (2500, 5000), (1300, 100), (4000, 300))]
+    for npairs, route in ((1, 6), (3, 6), (4, 2)):
+        alphas, betas = [x[0] for x in pairs[:npairs]], [x[1] for x in pairs[:npairs]]
+        for sc, go, ge in ((MX["HumanChimpTwo"], -600, -150), ([[25 * int(v) for v in row] for row in MX["HumanChimpTwo"]], -15000, -3750)):
+            for cs in (1000, 10000):
+                p = gpu_lib.make_params(0, sc, go, ge, cs, cs)
+                got = gpu_lib.align_batch(p, alphas, betas)
+                if not common.OUTER_ROUTE_SWITCH:
+                    assert gpu_lib.get_timing()["fast_path"] == route, (npairs, go, cs)
+                exp = oracle.align_batch(0, sc, go, ge, alphas, betas, cs, cs, threads=4)
+                common.assert_same(got, exp, "%d pairs cs %d" % (npairs, cs))
+
+
+@pytest.mark.parametrize("strips", ["2", "3"])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_w64_row_panels(gpu_lib, monkeypatch, mode, strips):
+    """row panels (run_device_mega) of k strips of 640 rows in the 64-lane geometry: the stand-in strip, MegaState across panel borders"""
+    monkeypatch.setenv("GNX_MEGA_STRIPS", strips)
+    monkeypatch.setenv("GNX_W64", "2")
+    rng = np.random.default_rng(60 + mode)
+    alphas, betas = [], []
+    for n, extra, sub, indel in ((6500, 0, 0.05, 0.03), (2700, 1900, 0.05, 0.03), (1400, 3500, 0.08, 0.05), (9000, 40, 0.02, 0.004), (150, 1200, 0.05, 0.02), (700, 700, 0.2, 0.1)):
+        a, b = _related(rng, n, extra, sub=sub, indel=indel)
+        alphas.append(a); betas.append(b)
+    w = rng.integers(0, 4, size=6000).astype(np.uint8)
+    alphas.append(common.mutate(rng, w[1200:4300], sub=0.04, indel=0.03, geo=0.5)); betas.append(w)  # a read inside a window: long leading / trailing gaps
+    for cs in ((10000, 1000, 7) if mode == 0 else (10000,)):
+        for name, go, ge in (("HumanChimpTwo", -600, -150), ("HoxD55", 0, -70)):
+            p = gpu_lib.make_params(mode, MX[name], go, ge, cs, cs)
+            got = gpu_lib.align_batch(p, alphas, betas)
+            assert gpu_lib.get_timing()["fast_path"] == 5
+            exp = oracle.align_batch(mode, MX[name], go, ge, alphas, betas, cs, cs, threads=8)
+            common.assert_same(got, exp, "mode %d cs %d %s" % (mode, cs, name))
+
+
 def _long_pairs():
     import importlib.util
     spec = importlib.util.spec_from_file_location("long_pairs", os.path.join(common.HERE, "..", "tools", "long_pairs.py"))
@@ -222,7 +280,7 @@ def test_long_pairs_equal_the_oracle(gpu_lib, case):
     p = gpu_lib.make_params(0 if affine else 1, sc, go, ge, 10000, 10000)
     gpu_lib.check(gpu_lib.lib().gnx_init(0, 0))
     score, ops, off = gpu_lib.align_batch(p, [a], [b])
-    assert gpu_lib.get_timing()["fast_path"] == 2
+    common.expect_route(gpu_lib.get_timing(), 2)
     assert lp.digest(score[0], ops) == {k: fx[k] for k in ("score", "runs", "sha256")}
 
 
@@ -240,7 +298,7 @@ def test_megabase_pairs(gpu_lib, case):
     ph = gpu_lib.make_params(2 if affine else 4, sc, go, ge)
     score_h, ops_h, _ = gpu_lib.align_batch(ph, [a], [b])
     ni, nj, total = rescore_affine(a, b, ops_h, sc, go, ge) if affine else rescore_const(a, b, ops_h, sc, go)
-    assert gpu_lib.get_timing()["fast_path"] == 2
+    common.expect_route(gpu_lib.get_timing(), 2)
     assert (ni, nj) == (a.shape[0], b.shape[0]) and total == int(score_h[0])
     # the callers' function (10 000 x 10 000 checkerboards): the same score; its CIGAR may carry the reference's quirk Q1 (a gap split where a
     # checkerboard is left upwards -- a 5 Mb pair shows it, profiles/r5_long_pairs.jsonl), so it re-scores to at most the score

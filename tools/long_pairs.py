@@ -102,7 +102,7 @@ def run_gpu(names):
         row = {"case": name, "fn": "AffineGap(HumanChimpTwo,-600,-150)" if affine else "ConstGap(HumanChimpTwo,-430)", "n": int(a.shape[0]), "m": int(b.shape[0]),
                "cells": int(a.shape[0]) * int(b.shape[0]), "call_s": round(wall, 4), "sweep_ms": round(tm["fill_ms"], 2), "walk_ms": round(tm["traceback_ms"], 2),
                "cells_per_s_call": float("%.4g" % (a.shape[0] * b.shape[0] / wall)), "cells_per_s_kernels": float("%.4g" % (a.shape[0] * b.shape[0] / (tm["total_ms"] * 1e-3))),
-               "workspace_bytes": int(tm["trace_bytes"]), "route": {2: "snapshot path", 5: "row panels"}.get(int(tm["fast_path"]), int(tm["fast_path"])), "launches": int(tm["n_launches"]), "score": int(score[0]), "runs": int(ops.shape[0]),
+               "workspace_bytes": int(tm["trace_bytes"]), "route": {2: "snapshot path", 5: "row panels", 6: "snapshot path, 64 lanes per pair"}.get(int(tm["fast_path"]), int(tm["fast_path"])), "launches": int(tm["n_launches"]), "score": int(score[0]), "runs": int(ops.shape[0]),
                "consumes_n_m": (ni, nj) == (a.shape[0], b.shape[0]), "rescored_equals_score": total == int(score[0]), "rescored_minus_score": total - int(score[0]),
                "semantics": "highMem (no checkerboards)" if highmem else "10 000 x 10 000 checkerboards (quirk Q1 can cost the CIGAR a gap open: the reference's own behaviour)"}
         if name in fx:
