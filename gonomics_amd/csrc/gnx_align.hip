@@ -45,6 +45,7 @@
 #include "const_long_walk.hip.h"
 #include "affine_long.hip.h"
 #include "affine_long64.hip.h"
+#include "const_long64.hip.h"
 #include "lat_fill.hip.h"
 #include "lat_wide.hip.h"
 #include "seed_kernels.hip.h"
@@ -606,7 +607,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
                      int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool rebase, bool w64 = false) {
     Ctx &c = g_ctx;
     int rc;
-    if (w64 && !(affine && rebase)) w64 = false;
+    if (w64 && !rebase) w64 = false;
     const int64_t HS = w64 ? H64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair
     // snapshot spacing of the constant-gap form (const_long.hip.h): the wide tiles only when the walk will have the GPU full of long chains
     int64_t ckc = CKC_SMALL;
@@ -615,6 +616,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         for (int64_t p = 0; p < n_pairs; p++) strips_sum += (h_alen[p] + HS - 1) / HS;
         if (n_pairs > 1536 && strips_sum >= 64 * n_pairs) ckc = CKC;
         if (const char *e = getenv("GNX_CL_CKC")) { const int v = atoi(e); if (v == CKC || v == CKC_SMALL) ckc = v; }
+        if (w64) ckc = CKC64;
     }
     std::vector<PairPlan> plans((size_t)n_pairs);
     std::vector<int64_t> so((size_t)n_pairs + 1, 0); // staging offsets (runs), chunk-relative; so[chunk end] is unused
@@ -751,7 +753,10 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
 #define GNX_CL_SWEEP(P_, RBS_) hipLaunchKernelGGL((cl_sweep_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs)
 #define GNX_CL_FLAT(P_, RBS_) hipLaunchKernelGGL((cl_sweep_flat_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, dbs)
         if (rebase) HIPCHK(hipMemsetAsync(dbs, 0, (size_t)max_bs * 8, stream));
-        if (w64) {
+        if (w64 && !affine) {
+            if (p16) hipLaunchKernelGGL((cl64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            else hipLaunchKernelGGL((cl64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+        } else if (w64) {
             if (p16) hipLaunchKernelGGL((al64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
             else hipLaunchKernelGGL((al64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
         } else if (affine) { if (rebase) { if (p16) GNX_AL_SWEEP(true, true); else GNX_AL_SWEEP(false, true); } else { if (p16) GNX_AL_SWEEP(true, false); else GNX_AL_SWEEP(false, false); } }
@@ -765,7 +770,11 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         HIPCHK(hipEventRecord(c.ev[2], stream));
         const dim3 gridW((unsigned)((np + 3) / 4));
 #define GNX_AL_WALK(P_, RBS_) hipLaunchKernelGGL((al_walk_kernel<P_, RBS_>), gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr)
-        if (w64) { // one pair per workgroup
+        if (w64 && !affine) { // one pair per workgroup
+            const dim3 gw((unsigned)np);
+            if (p16) hipLaunchKernelGGL((cl64_walk_kernel<true>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
+            else hipLaunchKernelGGL((cl64_walk_kernel<false>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
+        } else if (w64) {
             const dim3 gw((unsigned)np);
             if (p16) hipLaunchKernelGGL((al64_walk_kernel<true>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
             else hipLaunchKernelGGL((al64_walk_kernel<false>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
@@ -872,8 +881,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                     int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool w64) {
     Ctx &c = g_ctx;
     int rc;
-    if (!affine) w64 = false;
-    const int64_t HS = w64 ? H64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair (w64: affine_long64.hip.h)
+    const int64_t HS = w64 ? H64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair (w64: affine_long64.hip.h / const_long64.hip.h)
     const int np = (int)n_pairs;
     const int64_t ck = affine ? CKA : CKC_SMALL, snw = affine ? AL_SNAPW : SNAPW, rbw = affine ? 8 : 4;
     bool p16 = true;
@@ -979,7 +987,11 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             kps.ckc = (int)ck; kps.rb_pub = RB_PUB;
             const dim3 gridS((unsigned)local);
             HIPCHK(hipEventRecord(c.ev[1], stream));
-            if (w64) {
+            if (w64 && !affine) {
+                int *drb = reinterpret_cast<int *>(c.rowbuf.p);
+                if (p16) hipLaunchKernelGGL((cl64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                else hipLaunchKernelGGL((cl64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            } else if (w64) {
                 int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
                 if (p16) hipLaunchKernelGGL((al64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
                 else hipLaunchKernelGGL((al64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
@@ -1032,7 +1044,11 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             const int *dsn = reinterpret_cast<const int *>(c.fp_ckpt.p);
             int64_t *d_tmp_score = dhf + 2; // (the walk writes hfin[pl.hcol_off] here when it ends: not the pair's score, see above)
             HIPCHK(hipEventRecord(c.ev[1], stream));
-            if (w64) {
+            if (w64 && !affine) {
+                const int *drb = reinterpret_cast<const int *>(c.rowbuf.p);
+                if (p16) hipLaunchKernelGGL((cl64_walk_kernel<true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                else hipLaunchKernelGGL((cl64_walk_kernel<false>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+            } else if (w64) {
                 const int2 *drb2 = reinterpret_cast<const int2 *>(c.rowbuf.p);
                 if (p16) hipLaunchKernelGGL((al64_walk_kernel<true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
                 else hipLaunchKernelGGL((al64_walk_kernel<false>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
@@ -1468,10 +1484,10 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const char *rbe = getenv("GNX_REBASE");
         const bool rebase = spread_ok && (oor || (rbe && rbe[0] == '1')); // GNX_REBASE=1 (tests): every pair of this path on moving bases
         if (oor && !spread_ok) use = false;
-        // the whole wave on one pair (affine_long64.hip.h): launches of up to three pairs, which would leave lane groups of al_sweep_kernel's waves idle;
-        // GNX_W64 = 0 / 2: never / for every affine launch of this path
+        // the whole wave on one pair (affine_long64.hip.h, const_long64.hip.h): launches of up to three pairs, which would leave lane groups of the 16-lane
+        // kernels' waves idle; GNX_W64 = 0 / 2: never / for every launch of this path
         const char *w64e = getenv("GNX_W64");
-        const bool w64 = affine && !no_pipe() && (int64_t)(H64 + G64 + CK64 + 64) * step4 < ((int64_t)1 << 28) && !(w64e && w64e[0] == '0') && (n_pairs <= 3 || (w64e && w64e[0] == '2'));
+        const bool w64 = !no_pipe() && (int64_t)(H64 + G64 + CKC64 + 64) * step4 < ((int64_t)1 << 28) && !(w64e && w64e[0] == '0') && (n_pairs <= 3 || (w64e && w64e[0] == '2'));
         long double cells_ld = 0, dir_bytes = 0, rows_ld = 0, cols_ld = 0;
         for (int64_t p = 0; use && p < n_pairs; p++) {
             if (h_alen[p] < 1 || h_blen[p] < 1) use = false;

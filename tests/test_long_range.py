@@ -200,15 +200,16 @@ def test_row_panels_forced(gpu_lib, monkeypatch, mode, strips):
 
 
 @pytest.mark.parametrize("cs", [3, 16, 10000])
-@pytest.mark.parametrize("mode", [0, 2])  # AffineGap, AffineGap_highMem
+@pytest.mark.parametrize("mode", [0, 1, 2, 4])  # AffineGap, ConstGap, AffineGap_highMem, ConstGap_highMem
 def test_w64_forced(gpu_lib, monkeypatch, mode, cs):
-    """GNX_CLONG=2 + GNX_W64=2: every affine pair through the snapshot path with the whole wave on one pair (affine_long64.hip.h: 64 lanes x 10
-    rows, strips of 640 rows, wave_shr moves, moving bases) -- ragged batches of one to eight strips, small checkerboards, against the oracle"""
+    """GNX_CLONG=2 + GNX_W64=2: every pair through the snapshot path with the whole wave on one pair (affine_long64.hip.h / const_long64.hip.h:
+    64 lanes x 10 rows, strips of 640 rows, wave_shr moves, moving bases) -- ragged batches of one to eight strips, small checkerboards, against the oracle"""
     monkeypatch.setenv("GNX_CLONG", "2")
     monkeypatch.setenv("GNX_W64", "2")
+    affine = mode in (0, 2)
     for seed, nmax, mmax, count in ((31, 60, 400, 48), (32, 2000, 1500, 30), (33, 5000, 2600, 12), (34, 700, 9000, 10)):
         alphas, betas = _ragged(seed + 100 * cs, count, nmax, mmax)
-        for name, go, ge in (("HumanChimpTwo", -600, -150), ("Default", -400, -30), ("HoxD55", 0, -70)):
+        for name, go, ge in (("HumanChimpTwo", -600, -150), ("Default", -400, -30), ("HoxD55", 0, -70)) if affine else (("HumanChimpTwo", -430, 0), ("HoxD55", -100, 0)):
             p = gpu_lib.make_params(mode, MX[name], go, ge, cs, cs)
             got = gpu_lib.align_batch(p, alphas, betas)
             assert gpu_lib.get_timing()["fast_path"] == 6
@@ -216,8 +217,9 @@ def test_w64_forced(gpu_lib, monkeypatch, mode, cs):
             common.assert_same(got, exp, "seed %d %s" % (seed, name))
 
 
-def test_w64_is_the_route_of_few_pairs(gpu_lib, monkeypatch):
-    """the shipped rule: affine launches of up to three pairs of the snapshot path run in the 64-lane geometry (route 6), four pairs fill the
+@pytest.mark.parametrize("mode", [0, 1])
+def test_w64_is_the_route_of_few_pairs(gpu_lib, monkeypatch, mode):
+    """the shipped rule: launches of up to three pairs of the snapshot path run in the 64-lane geometry (route 6), four pairs fill the
     lane groups of al_sweep_kernel's waves (route 2); related pairs of many strips and columns, a scaled matrix that leaves int16 (P16 off)"""
     monkeypatch.setenv("GNX_CLONG", "2")
     monkeypatch.delenv("GNX_W64", raising=False)
@@ -225,18 +227,19 @@ def test_w64_is_the_route_of_few_pairs(gpu_lib, monkeypatch):
     pairs = [_related(rng, n, extra, sub=0.05, indel=0.03) for n, extra in ((6000, 0), (2500, 5000), (1300, 100), (4000, 300))]
     for npairs, route in ((1, 6), (3, 6), (4, 2)):
         alphas, betas = [x[0] for x in pairs[:npairs]], [x[1] for x in pairs[:npairs]]
-        for sc, go, ge in ((MX["HumanChimpTwo"], -600, -150), ([[25 * int(v) for v in row] for row in MX["HumanChimpTwo"]], -15000, -3750)):
+        x25 = [[25 * int(v) for v in row] for row in MX["HumanChimpTwo"]]
+        for sc, go, ge in ((MX["HumanChimpTwo"], -600, -150), (x25, -15000, -3750)) if mode == 0 else ((MX["HumanChimpTwo"], -430, 0), (x25, -10750, 0)):
             for cs in (1000, 10000):
-                p = gpu_lib.make_params(0, sc, go, ge, cs, cs)
+                p = gpu_lib.make_params(mode, sc, go, ge, cs, cs)
                 got = gpu_lib.align_batch(p, alphas, betas)
                 if not common.OUTER_ROUTE_SWITCH:
                     assert gpu_lib.get_timing()["fast_path"] == route, (npairs, go, cs)
-                exp = oracle.align_batch(0, sc, go, ge, alphas, betas, cs, cs, threads=4)
+                exp = oracle.align_batch(mode, sc, go, ge, alphas, betas, cs, cs, threads=4)
                 common.assert_same(got, exp, "%d pairs cs %d" % (npairs, cs))
 
 
 @pytest.mark.parametrize("strips", ["2", "3"])
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 4])
 def test_w64_row_panels(gpu_lib, monkeypatch, mode, strips):
     """row panels (run_device_mega) of k strips of 640 rows in the 64-lane geometry: the stand-in strip, MegaState across panel borders"""
     monkeypatch.setenv("GNX_MEGA_STRIPS", strips)
@@ -248,8 +251,9 @@ def test_w64_row_panels(gpu_lib, monkeypatch, mode, strips):
         alphas.append(a); betas.append(b)
     w = rng.integers(0, 4, size=6000).astype(np.uint8)
     alphas.append(common.mutate(rng, w[1200:4300], sub=0.04, indel=0.03, geo=0.5)); betas.append(w)  # a read inside a window: long leading / trailing gaps
-    for cs in ((10000, 1000, 7) if mode == 0 else (10000,)):
-        for name, go, ge in (("HumanChimpTwo", -600, -150), ("HoxD55", 0, -70)):
+    affine = mode in (0, 2)
+    for cs in ((10000, 1000, 7) if mode in (0, 1) else (10000,)):
+        for name, go, ge in ((("HumanChimpTwo", -600, -150), ("HoxD55", 0, -70)) if affine else (("HumanChimpTwo", -430, 0),)):
             p = gpu_lib.make_params(mode, MX[name], go, ge, cs, cs)
             got = gpu_lib.align_batch(p, alphas, betas)
             assert gpu_lib.get_timing()["fast_path"] == 5

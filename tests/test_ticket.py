@@ -52,6 +52,9 @@ LEGS = [
     ("lat_fill_kernel<affine> piped strips", {"GNX_LAT": "2"}, 0, "HumanChimpTwo", (-600, -150), (106, 6, 900, 1400, 2200, 2600)),
     ("lat_fill_kernel<const> piped strips", {"GNX_LAT": "2"}, 1, "Default", (-430, 0), (107, 6, 900, 1400, 2200, 2600)),
     ("lat_wide_kernel piped strips", {"GNX_WIDE": "2"}, 0, "HumanChimpTwo", (-600, -150), (108, 6, 900, 1400, 2200, 2600)),
+    # the snapshot path with the whole wave on one pair (strips of 640 rows)
+    ("al64_sweep_kernel piped strips", {"GNX_CLONG": "2", "GNX_FASTPATH": "0", "GNX_W64": "2"}, 0, "HumanChimpTwo", (-600, -150), (109, 5, 2000, 3800, 3000, 4200)),
+    ("cl64_sweep_kernel piped strips", {"GNX_CLONG": "2", "GNX_W64": "2"}, 1, "HumanChimpTwo", (-430, 0), (110, 5, 2000, 3800, 3000, 4200)),
 ]
 
 
