@@ -291,6 +291,7 @@ __global__ __launch_bounds__(64) void al64_walk_kernel(const PairPlan *__restric
         else li = (pl.n > 0) ? ((int64_t)pl.n + row_off - 1) % tp.ci : 0;
     }
 
+    int s_prof = -1;
     while (true) {
         const int ci = __builtin_amdgcn_readfirstlane(wi), cj = __builtin_amdgcn_readfirstlane(wj);
         if (__builtin_amdgcn_readfirstlane(wdone)) break;
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(64) void al64_walk_kernel(const PairPlan *__restric
         const int row0 = s * H64 + l * R;
         int rt[R], hold[R];
         unsigned acc[3 * R];
-        {
+        __syncthreads(); // table visible; the previous round's walk is over
+        if (s != s_prof) { // the strip's profile (most rounds stay in the strip of the round before: 640 rows against ~116 cells per tile)
             int a5[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -315,13 +317,13 @@ __global__ __launch_bounds__(64) void al64_walk_kernel(const PairPlan *__restric
                 if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
                 a5[r] = a * 5;
             }
-            __syncthreads(); // table visible; the previous round's walk is over
 #pragma unroll
             for (int b = 0; b < 5; b++) {
 #pragma unroll
                 for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
             }
             __syncthreads();
+            s_prof = s;
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(64) void cl64_walk_kernel(const PairPlan *__restric
         if (mst->resume) { wi = mst->wi; wj = mst->wj; cnt = mst->cnt; cur_run = mst->cur_run; cur_op = mst->cur_op; last_op = mst->last_op; }
     }
 
+    int s_prof = -1;
     while (true) {
         const int ci = __builtin_amdgcn_readfirstlane(wi), cj = __builtin_amdgcn_readfirstlane(wj);
         if (__builtin_amdgcn_readfirstlane(wdone)) break;
@@ -248,7 +249,8 @@ __global__ __launch_bounds__(64) void cl64_walk_kernel(const PairPlan *__restric
         const int row0 = s * H64 + l * R;
         int val[R];
         unsigned acc[R];
-        {
+        __syncthreads(); // table visible; the previous round's walk is over
+        if (s != s_prof) { // the strip's profile (most rounds stay in the strip of the round before: 640 rows against ~116 cells per tile)
             int a5[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -257,13 +259,13 @@ __global__ __launch_bounds__(64) void cl64_walk_kernel(const PairPlan *__restric
                 if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
                 a5[r] = a * 5;
             }
-            __syncthreads(); // table visible; the previous round's walk is over
 #pragma unroll
             for (int b = 0; b < 5; b++) {
 #pragma unroll
                 for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
             }
             __syncthreads();
+            s_prof = s;
         }
         int diag0 = 2;
 #pragma unroll

@@ -78,7 +78,8 @@ struct DevBuf {
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
         if (hipMalloc(&p, want) != hipSuccess) {
-            if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; set_err("device allocation of %s%lld bytes failed", "", (long long)bytes); return GNX_ENOMEM; }
+            (void)hipGetLastError(); // (the failed attempt must not stay behind as the "last error" a later launch check would read)
+            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; set_err("device allocation of %s%lld bytes failed", "", (long long)bytes); return GNX_ENOMEM; }
             want = bytes;
         }
         cap = want;
@@ -904,14 +905,18 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
             const int64_t avail = (int64_t)fr + (int64_t)(c.rowbuf.cap + c.fp_ckpt.cap + c.tb_scr.cap + c.cl_bases.cap + c.mega_rows.cap);
-            budget = std::max(budget, avail / 2); // (the forward pass's row buffer stays allocated under the backward pass's snapshots: 0.5 + 0.3 of what is there)
+            // half of what is there: a fresh device allocation costs ~27 ms per GB (MI355X, measured: tools/memprobe.py), which a one-call process --
+            // cmd/cigarToBed -- pays in full; panels of three quarters of the device sweep ~10 % faster and allocate 2 s longer
+            budget = std::max(budget, avail / 2);
         }
     }
-    budget -= scr_b;
-    int64_t Sb = budget / strip_bwd_hi - 3, Sf = budget / strip_fwd_hi - 3; // strips per backward / forward panel
+    budget -= scr_b + (m_hi + 1) * rbw * 16; // (the saved panel boundaries, mega_rows: one row per backward panel -- a dozen)
+    int64_t Sb = budget / (strip_bwd_hi + strip_bwd_hi / 8) - 3, Sf = budget / (strip_fwd_hi + strip_fwd_hi / 8) - 3; // strips per backward / forward panel (/ 8: DevBuf::ensure's slack)
     if (const char *e = getenv("GNX_MEGA_STRIPS")) { Sb = atoll(e); Sf = 2 * Sb; } // (tests: panels of a few strips, forward panels of two backward ones)
     if (Sb < 2) { set_err("a single strip of pair %s%lld does not fit the workspace", "", 0); return GNX_ENOMEM; }
-    Sf = std::max(Sb, Sf / Sb * Sb); // a forward panel = a whole number of backward panels: their top rows are what it saves
+    const bool forced_panels = getenv("GNX_MEGA_STRIPS") != nullptr;
+    const int64_t Sb_max = Sb, Sf_max = Sf;
+    if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx] row panels: budget %.1f GB, %lld strips per backward panel (%.1f MB each), %lld per forward panel (%.1f MB each)\n", budget / 1e9, (long long)Sb, strip_bwd_hi / 1e6, (long long)Sf, strip_fwd_hi / 1e6);
     if ((rc = c.tb_scr.ensure((size_t)scr_b))) return rc;
     if ((rc = c.tb_scr_off.ensure(((size_t)np + 1) * 8))) return rc;
     if ((rc = c.nops.ensure((size_t)np * 8))) return rc;
@@ -937,7 +942,12 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
     int64_t cells = 0, launches = 0, ws_bytes = 0;
     for (int64_t p = 0; p < n_pairs; p++) {
         const int64_t n = h_alen[p], m = h_blen[p];
-        const int64_t total_strips = (n + HS - 1) / HS, n_bwd = (total_strips + Sb - 1) / Sb;
+        // backward panels of equal size (a remainder panel of a few strips would sweep the whole width at a fraction of the device); forward
+        // panels of whole backward panels -- their top rows are what a forward panel saves -- up to 9 strips per CU (5 Mb x 5 Mb: 13 per CU sweep
+        // 0.5 s faster and take 1.4 s longer to allocate in a process's first call)
+        const int64_t total_strips = (n + HS - 1) / HS, n_bwd = (total_strips + Sb_max - 1) / Sb_max;
+        const int64_t Sb = forced_panels ? Sb_max : (total_strips + n_bwd - 1) / n_bwd;
+        const int64_t Sf = forced_panels ? Sf_max : std::max(Sb, std::min<int64_t>(Sf_max, std::max<int64_t>(Sb, 9 * c.n_cu)) / Sb * Sb);
         const int64_t nq = ((m + GS + 14) & ~(int64_t)15) / ck + 2; // K-step blocks of a strip: the pitch of the bases, the same in every panel
         const int64_t top_b = (m + 1) * rbw + nq * 8;           // one saved boundary: the row + its bases
         if ((rc = c.mega_rows.ensure((size_t)(n_bwd * top_b)))) return rc;
@@ -954,6 +964,12 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             pl.hcol_off = (forward && last) ? 0 : 1; pl.src = 0; pl.rowi_off = 0; pl.s_pitch = nq;
             const int64_t rb_e = (planned - 1) * (mcols + 1), sn_e = forward ? 0 : ((mcols + GS - 1) / ck) * planned * GS * snw, bs_e = planned * nq;
             int r2;
+            if (getenv("GNX_DEBUG")) {
+                size_t fr = 0, tot = 0;
+                (void)hipMemGetInfo(&fr, &tot);
+                fprintf(stderr, "[gnx] row panels: %s sweep of strips %lld + %lld: rows %.1f GB (held %.1f), snapshots %.1f GB (held %.1f), free %.1f GB\n", forward ? "forward" : "backward", (long long)s0, (long long)cnt,
+                        rb_e * rbw / 1e9, c.rowbuf.cap / 1e9, sn_e * 4 / 1e9, c.fp_ckpt.cap / 1e9, fr / 1e9);
+            }
             if ((r2 = c.rowbuf.ensure((size_t)std::max<int64_t>(rb_e, 1) * rbw))) return r2;
             if (!forward && (r2 = c.fp_ckpt.ensure((size_t)std::max<int64_t>(sn_e, 1) * 4))) return r2;
             if ((r2 = c.cl_bases.ensure((size_t)bs_e * 8))) return r2;
@@ -1021,6 +1037,12 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             fill_ms += f;
             return GNX_OK;
         };
+        // buffers of an earlier call (or pair) stay where what comes fits beside them: a fresh allocation of this size takes seconds
+        auto mem_free = [&]() -> int64_t { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? (int64_t)fr : 0; };
+        {
+            const int64_t need_f = (std::min(Sf, total_strips) + 2) * (m + 1) * rbw;
+            if ((int64_t)c.rowbuf.cap < need_f && mem_free() + (int64_t)c.rowbuf.cap < need_f + need_f / 6) c.fp_ckpt.release();
+        }
         for (int64_t s0 = 0; s0 < total_strips; s0 += Sf) if ((rc = sweep_rows(s0, std::min(Sf, total_strips - s0), m, true))) return rc; // forward
         int64_t n_local_last = 0;
         { const int64_t s0l = ((total_strips - 1) / Sf) * Sf; n_local_last = (n - s0l * HS) + (s0l > 0 ? HS : 0); } // rows of the launch that wrote h(n, m)
@@ -1029,7 +1051,14 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             const long long owed = (long long)(affine ? prm->gap_extend : prm->gap_open) * (n - n_local_last);
             if (owed) hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<long long *>(d_score + p), (int64_t)1, owed);
         }
-        // backward
+        // backward: the forward pass's row buffer (up to the whole budget) makes room for the snapshots
+        { // the snapshots of the largest panel, once; the forward pass's row buffer gives way only when they do not fit beside it
+            const int64_t need_sn = ((m + GS - 1) / ck) * (std::min(Sb, total_strips) + 2) * GS * snw * 4;
+            if ((int64_t)c.fp_ckpt.cap < need_sn) {
+                if (mem_free() + (int64_t)c.fp_ckpt.cap < need_sn + need_sn / 6) c.rowbuf.release();
+                if ((rc = c.fp_ckpt.ensure((size_t)need_sn))) return rc;
+            }
+        }
         MegaState st;
         memset(&st, 0, sizeof(st));
         int64_t jcur = m;
