@@ -513,4 +513,299 @@ __global__ __launch_bounds__(64) void al64_walk_kernel(const PairPlan *__restric
     if (bad) atomicOr(err, 1);
 }
 
+template <bool P16>
+__global__ __launch_bounds__(128) void al64_walk2_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                        const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                        const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                        KParams kp, TbParams tp, const int2 *__restrict__ rowbuf, const int *__restrict__ snap,
+                                                        const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                        const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
+                                                        const long long *__restrict__ bases, MegaState *__restrict__ mst) {
+    constexpr int LW = P16 ? R / 2 : R;
+    constexpr int BST = G64 * LW;
+    constexpr int TI = 2, TD = 1;
+    __shared__ int lds[32 + 5 * BST + 2 * AL64_DIRG + 2 * H64 + 8];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63; // wave 0: the walk's tile; wave 1: its left neighbour
+    if (threadIdx.x < 25) lds[threadIdx.x] = kp.sc4[threadIdx.x] - 2 * kp.e4;
+    int *prof = &lds[32];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    unsigned *dirg0 = reinterpret_cast<unsigned *>(&lds[32 + 5 * BST]), *dirg = dirg0 + w * AL64_DIRG; // the tile this wave fills
+    int *hcol0 = &lds[32 + 5 * BST + 2 * AL64_DIRG], *hcolT = hcol0 + w * H64; // keys h(i, m) of the strip's rows whose lanes have passed column m
+    int *xch = &lds[32 + 5 * BST + 2 * AL64_DIRG + 2 * H64]; // {row, column, done} of the walk, from thread 0 to everybody
+    const int p = blockIdx.x;
+    const PairPlan pl = plans[p];
+    const uint8_t *ap = a_buf + a_start[p];
+    BetaBytes bp;
+    bp.init(b_buf, kp, b_start[p], pl.m);
+    const int m = pl.m;
+    const int64_t rb_pitch = (int64_t)m + 1;
+    const int po = pl.src;
+    const int OE4 = kp.oe4, E4 = kp.e4, RB = kp.e4;
+    int vO4;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
+    int bad = 0;
+    // walker state (lane 0), as in al_walk_kernel
+    int wi = pl.n, wj = m, wk = 0, wdone = 0, pend = 1;
+    int64_t li = (pl.n > 0) ? (int64_t)(pl.n - 1) % tp.ci : 0;
+    int64_t cnt = 0, cur_run = 0;
+    int cur_op = -1, last_op = -1;
+    const int64_t sbase = scr_off[p];
+    auto flush_run = [&]() {
+        if (cur_op >= 0) {
+            gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op;
+            for (int z = 0; z < 7; z++) c._pad[z] = 0;
+            scr[sbase + cnt] = c;
+            cnt++;
+        }
+    };
+    auto emit = [&](int op, int64_t run) {
+        if (op == cur_op) cur_run += run;
+        else { flush_run(); cur_op = op; cur_run = run; }
+    };
+    // row panels (MegaState, const_long.hip.h)
+    int virt = 0;
+    int64_t row_off = 0;
+    bool pexit = false;
+    if (mst) {
+        virt = mst->virt; row_off = mst->row_off;
+        if (mst->resume) { wi = mst->wi; wj = mst->wj; wk = mst->wk; pend = mst->pend; li = mst->li; cnt = mst->cnt; cur_run = mst->cur_run; cur_op = mst->cur_op; last_op = mst->last_op; }
+        else li = (pl.n > 0) ? ((int64_t)pl.n + row_off - 1) % tp.ci : 0;
+    }
+
+    if (threadIdx.x == 0) { xch[0] = wi; xch[1] = wj; xch[2] = 0; }
+    int s_prof = -1;
+    while (true) {
+        __syncthreads(); // table and walk state visible; the previous round's walk is over
+        const int ci = xch[0], cj = xch[1];
+        if (xch[2]) break;
+        if (virt > 0 && ci <= virt) { pexit = true; break; }
+        const int s = (ci - 1) / H64;
+        const int lw = (ci - 1 - s * H64) / R;
+        const int te = cj + lw;               // step of the cell the walk is at
+        const int cA = (te >= 3) ? (te - 3) / CK64 : 0; // (the first two steps after a snapshot carry no usable plane fields, see al_walk_kernel)
+        // Wave 1 re-fills the tile to the LEFT of the walk's at the same time: a walk that leaves its tile through the skewed left edge (the usual
+        // exit: 640 rows against ~116 cells of path per tile) enters that one at step tbeg .. tbeg + 2 of its own tile, whatever its path was
+        const bool act = w == 0 || cA >= 1;
+        const int c = w == 0 ? cA : max(cA - 1, 0);
+        const int tbeg = c * CK64;
+        const int tmin = c > 0 ? 2 : 0;
+        const int tend = w == 0 ? te + 1 : cA * CK64 + 3; // one step further: quirk Q1
+        const int nblk = act ? (tend - tbeg + 15) >> 4 : 0;
+        const int row0 = s * H64 + l * R;
+        int rt[R], hold[R];
+        unsigned acc[3 * R];
+        if (s != s_prof && w == 0) { // the strip's profile (most rounds stay in the strip of the round before: 640 rows against ~116 cells per tile)
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+            }
+        }
+        if (s != s_prof) { __syncthreads(); s_prof = s; }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = row0 + r + 1;
+            const int D1c = kp.d00_4 + i * kp.ecol4 + TD - RB * i;
+            hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
+            rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;
+            acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
+        }
+        int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
+        int dn_out = 0, h_out = 0, b_out = 0;
+        if (act && c > 0) { // resume from the snapshot of step tbeg
+            const uint4 *sp = reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G64 + l) * AL_SNAPW);
+            const uint4 x0 = sp[0], x1 = sp[1], x2 = sp[2], x3 = sp[3], x4 = sp[4], x5 = sp[5];
+            rt[0] = (int)x0.x; rt[1] = (int)x0.y; rt[2] = (int)x0.z; rt[3] = (int)x0.w; rt[4] = (int)x1.x; rt[5] = (int)x1.y; rt[6] = (int)x1.z; rt[7] = (int)x1.w;
+            rt[8] = (int)x2.x; rt[9] = (int)x2.y; hold[0] = (int)x2.z; hold[1] = (int)x2.w; hold[2] = (int)x3.x; hold[3] = (int)x3.y; hold[4] = (int)x3.z; hold[5] = (int)x3.w;
+            hold[6] = (int)x4.x; hold[7] = (int)x4.y; hold[8] = (int)x4.z; hold[9] = (int)x4.w; diag0 = (int)x5.x; dn_out = (int)x5.y;
+            h_out = hold[R - 1];
+            const int jb = tbeg - l;
+            if (jb >= 1 && jb <= m) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
+        }
+        int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
+        // the snapshot's keys are relative to the strip's base of block c; the row above, block by block, to the bases of the strip above
+        long long Bt = 0;
+        if (act && c > 0) Bt = bases[pl.rowi_off + (int64_t)s * pl.s_pitch + c];
+        const int r0i = rbase_const((long long)kp.o4 + TI, Bt);
+        auto boundary = [&](int cc, int &odn, int &oh, int &ob) {
+            odn = 0; oh = 0; ob = 0;
+            if (l < 16 && cc >= 1 && cc <= m) {
+                if (s == 0) {
+                    const int M3 = NEG4 + 3, I2 = r0i, D1 = NEG4 + TD;
+                    oh = max3i(M3, I2, D1);
+                    odn = max3i(M3 + OE4, I2 + OE4, D1 + E4) - RB;
+                } else {
+                    const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
+                    const int q = (cc + XB64) / CK64;
+                    const int dd = rbase_delta(bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + q], Bt);
+                    odn = v.x + dd; oh = v.y + dd;
+                }
+                ob = bp.raw(cc - 1);
+            }
+        };
+        auto base_off = [&](int raw, int cc) { int b = (l < 16 && cc >= 1 && cc <= m) ? bp.value(raw, cc - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
+        boundary(tbeg + l + 1, qdn, qh, qb);
+        qb = base_off(qb, tbeg + l + 1);
+        int wq[LW], pb_cur;
+        auto fetch = [&](int pbv, int *w) {
+            const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+#pragma unroll
+            for (int k = 0; k < LW; k++) w[k] = pw[k];
+        };
+        pb_cur = wave_shr1(qb, b_out);
+        qb = dpp_shl1(qb, qb);
+        fetch(pb_cur, wq);
+        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_dn = wave_shr1(qdn, dn_out);
+            const int up_h = wave_shr1(qh, h_out);
+            qdn = dpp_shl1(qdn, qdn);
+            qh = dpp_shl1(qh, qh);
+            if (take) qb = nqv;
+            const int pb_next = wave_shr1(qb, pb_cur);
+            qb = dpp_shl1(qb, qb);
+            int wn[LW];
+            fetch(pb_next, wn);
+            asm volatile("" ::: "memory");
+            const int j = t - l;
+            const int *w = wq;
+            if (!CHECK || (j >= 1 && j <= m)) {
+                int hd = diag0, dnu = up_dn;
+#pragma unroll
+                for (int r = 0; r < R; r++) { // the recording h-form of fill_affine_kernel (rebased keys)
+                    const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                    acc[r] = alignbit2((unsigned)hd, acc[r]);
+                    acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
+                    acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
+                    const int M3 = (hd | 3) + S4;
+                    const int I2 = (rt[r] & ~3) | TI;
+                    const int D1 = (dnu & ~3) | TD;
+                    const int hnew = max3i(M3, I2, D1);
+                    const int ho = hnew + vO4;
+                    rt[r] = max(ho, I2);
+                    const int dnn = max(ho, D1);
+                    hd = hold[r];
+                    hold[r] = hnew;
+                    dnu = dnn;
+                }
+                diag0 = up_h;
+                dn_out = dnu;
+                h_out = hold[R - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < LW; k++) wq[k] = wn[k];
+            pb_cur = pb_next;
+        };
+        for (int b = 0; b < nblk; b++) {
+            const int t0 = tbeg + 16 * b;
+            boundary(t0 + 16 + l + 1, ndn, nh, nb);
+            if (t0 >= G64 && t0 + 16 <= m) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+            }
+            qdn = ndn; qh = nh;
+            const int miss = (t0 + 16 - l) - m;
+            const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+#pragma unroll
+                for (int r = 0; r < R; r++) dirg[((b * 3 + k) * R + r) * G64 + l] = acc[k * R + r] >> sh;
+            }
+            if (b == nblk - 1 && t0 + 16 - l >= m) { // lanes that have passed column m hold h(i, m) of their rows
+#pragma unroll
+                for (int r = 0; r < R; r++) hcolT[l * R + r] = hold[r];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // walk inside one tile; returns 0: left through the skewed left edge, 1: through the top edge of the strip, 2: the walk is over (or failed)
+            auto walk_tile = [&](const unsigned *dgX, const int *hcX, const int tbX, const int tmX) -> int {
+                int why = 2;
+                int i = wi, j = wj, k = wk;
+                if (pend) { k = 3 - (hcX[i - 1 - s * H64] & 3); pend = 0; }
+                while (true) {
+                    if (i == 0 || j == 0) { wdone = 1; break; }
+                    const int i0 = i - 1 - s * H64;
+                    if (i0 < 0) { why = 1; break; } // left the strip through its top edge
+                    const int l2 = i0 / R, r2 = i0 - l2 * R;
+                    const int t1 = j + l2 - 1 - tbX;
+                    if (t1 < tmX) { why = 0; break; } // left the (usable part of the) tile through its skewed left edge
+                    const int pos = t1 & 15;
+                    const unsigned w = dgX[(((t1 >> 4) * 3 + k) * R + r2) * G64 + l2];
+                    int tag = (int)((w >> (2 * pos)) & 3u);
+                    if (tag == 0) { atomicOr(err, 2); wdone = 1; break; }
+                    if (k == 1) { // horizontal run inside this word, see traceback_kernel
+                        int avail = min(pos + 1, j);
+                        if (t1 < 16) avail = min(avail, pos - tmX + 1);
+                        unsigned x = w ^ 0xAAAAAAAAu;
+                        if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
+                        const int lowcut = pos + 1 - avail;
+                        if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+                        int steps;
+                        if (x == 0) steps = avail;
+                        else {
+                            const int pnz = (31 - __clz((int)x)) >> 1;
+                            tag = (int)((w >> (2 * pnz)) & 3u);
+                            if (tag == 0) { atomicOr(err, 2); wdone = 1; break; }
+                            steps = pos - pnz + 1;
+                            k = 3 - tag;
+                        }
+                        emit(1, steps); j -= steps; last_op = 1;
+                        continue;
+                    }
+                    emit(k, 1);
+                    last_op = k;
+                    const bool up_exit = (li == 0);
+                    li = up_exit ? tp.ci - 1 : li - 1;
+                    i--;
+                    if (k == 0) j--;
+                    k = 3 - tag;
+                    if (up_exit && i > 0 && j > 0) { // quirk Q1 (affineGap.go:305): restart in the argmax state of the entry cell (i, j)
+                        if (j < m) { // = the M-plane field of (i+1, j+1): the row the walk just left, at most one step past its cell
+                            const int l3 = (i0) / R, r3 = i0 - l3 * R, t3 = (j + 1) + l3 - 1 - tbX;
+                            const unsigned w3 = dgX[(((t3 >> 4) * 3 + 0) * R + r3) * G64 + l3];
+                            k = 3 - (int)((w3 >> (2 * (t3 & 15))) & 3u);
+                        } else if (i - 1 - s * H64 >= 0 && m + (i - 1 - s * H64) / R - 1 - tbX >= tmX) k = 3 - (hcX[i - 1 - s * H64] & 3);
+                        else pend = 1; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                    }
+                }
+                wi = i; wj = j; wk = k;
+                return why;
+            };
+            const int tbA = cA * CK64;
+            int why = walk_tile(dirg0, hcol0, tbA, cA > 0 ? 2 : 0);
+            if (why == 0 && cA >= 1 && !pend && !wdone) why = walk_tile(dirg0 + AL64_DIRG, hcol0 + H64, tbA - CK64, cA > 1 ? 2 : 0);
+            xch[0] = wi; xch[1] = wj; xch[2] = wdone;
+        }
+    }
+    if (threadIdx.x == 0 && mst) {
+        mst->wi = wi; mst->wj = wj; mst->wk = wk; mst->pend = pend; mst->li = li; mst->cnt = cnt; mst->cur_run = cur_run; mst->cur_op = cur_op; mst->last_op = last_op;
+        mst->done = pexit ? 0 : 1;
+    }
+    if (threadIdx.x == 0 && !pexit) {
+        // Step 4 (affineGap.go:135-139) -- quirk Q2 when the corner is not the origin
+        const int64_t gi = (int64_t)wi + (wi > 0 ? row_off : 0);
+        const bool up_exit = (last_op != 1) && (gi % tp.ci == 0);
+        const bool left_exit = (last_op != 2) && ((int64_t)wj % tp.cj == 0);
+        if (!up_exit && left_exit) emit(2, gi);
+        else if (up_exit && !left_exit) emit(1, wj);
+        flush_run();
+        nops[po] = cnt;
+        score_out[po] = hfin[pl.hcol_off];
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+
 } // namespace

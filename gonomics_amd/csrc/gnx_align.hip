@@ -149,6 +149,7 @@ thread_local bool t_no_pipe = false;
 thread_local bool t_no_lat = false; // set while a call is re-run without the latency geometry (its bug trap fired)
 thread_local int64_t t_min_cols = 0; // != 0: the fast path takes windows of at least this many columns (set by a mixed batch for its groups, see run_device)
 bool no_pipe() { return t_no_pipe || getenv("GNX_NO_PIPE") != nullptr; }
+bool w64_two_waves() { const char *e = getenv("GNX_W64_SPEC"); return !(e && e[0] == '0'); }
 Ctx &ctx_at(int k) {
     std::lock_guard<std::mutex> lk(g_ctxs_mu);
     while ((int)g_ctxs.size() <= k) { Ctx *c = new Ctx; c->index = (int)g_ctxs.size(); g_ctxs.push_back(c); }
@@ -777,7 +778,11 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             else hipLaunchKernelGGL((cl64_walk_kernel<false>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
         } else if (w64) {
             const dim3 gw((unsigned)np);
-            if (p16) hipLaunchKernelGGL((al64_walk_kernel<true>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
+            if (w64_two_waves()) { // (the tile to the left re-filled by a second wave while the first re-fills the walk's: GNX_W64_SPEC=0 switches it off)
+                if (p16) hipLaunchKernelGGL((al64_walk2_kernel<true>), gw, dim3(128), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
+                else hipLaunchKernelGGL((al64_walk2_kernel<false>), gw, dim3(128), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
+            }
+            else if (p16) hipLaunchKernelGGL((al64_walk_kernel<true>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
             else hipLaunchKernelGGL((al64_walk_kernel<false>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
         } else if (affine) { if (rebase) { if (p16) GNX_AL_WALK(true, true); else GNX_AL_WALK(false, true); } else { if (p16) GNX_AL_WALK(true, false); else GNX_AL_WALK(false, false); } }
 #undef GNX_AL_WALK
@@ -1079,7 +1084,11 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                 else hipLaunchKernelGGL((cl64_walk_kernel<false>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
             } else if (w64) {
                 const int2 *drb2 = reinterpret_cast<const int2 *>(c.rowbuf.p);
-                if (p16) hipLaunchKernelGGL((al64_walk_kernel<true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                if (w64_two_waves()) {
+                    if (p16) hipLaunchKernelGGL((al64_walk2_kernel<true>), dim3(1), dim3(128), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                    else hipLaunchKernelGGL((al64_walk2_kernel<false>), dim3(1), dim3(128), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                }
+                else if (p16) hipLaunchKernelGGL((al64_walk_kernel<true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
                 else hipLaunchKernelGGL((al64_walk_kernel<false>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
             } else if (affine) {
                 const int2 *drb2 = reinterpret_cast<const int2 *>(c.rowbuf.p);

@@ -51,7 +51,7 @@ bash tools/pmc_env_ab.sh gpurun_out/$tag/c5_ab "--no-cpu --no-host --no-extras -
 timeout 300 python tools/pair_latency.py 300 > $out/pair_latency.jsonl 2>> $out/bench.err
 # round 5: pairs beyond the static int32 range (snapshot path on moving bases; the 2 Mb / 5 Mb row-panel runs are in profiles/r5_long_pairs.jsonl),
 # the latency geometry against the general path, the whole cmd/faChunkAlign command, the graph aligner at genome scale
-timeout 600 python tools/long_pairs.py gpu const_150k affine_340k affine_1M const_300k_2M > $out/long_pairs.jsonl 2>> $out/bench.err
+timeout 900 python tools/long_pairs.py gpu const_150k affine_340k affine_1M const_300k_2M affine_2M affine_5M > $out/long_pairs.jsonl 2>> $out/bench.err
 timeout 600 python tools/lat_crossover.py affine > $out/lat_crossover.jsonl 2>> $out/bench.err
 timeout 600 python tools/lat_crossover.py const >> $out/lat_crossover.jsonl 2>> $out/bench.err
 timeout 600 python tools/bench_n1_cmd.py 8 30000 3 > $out/n1_cmd.json 2>> $out/bench.err
