@@ -399,4 +399,233 @@ __global__ __launch_bounds__(64) void cl64_walk_kernel(const PairPlan *__restric
     if (bad) atomicOr(err, 1);
 }
 
+template <bool P16>
+__global__ __launch_bounds__(128) void cl64_walk2_kernel(const PairPlan *__restrict__ plans, int n_pairs,
+                                                        const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                        const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                        KParams kp, TbParams tp, const int *__restrict__ rowbuf, const int *__restrict__ snap,
+                                                        const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                        const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
+                                                        const long long *__restrict__ bases, MegaState *__restrict__ mst) {
+    constexpr int LW = P16 ? R / 2 : R;
+    constexpr int BST = G64 * LW;
+    constexpr int CK = CKC64;
+    constexpr int DIRG = (CK / 16) * R * G64;
+    __shared__ int lds[32 + 5 * BST + 2 * DIRG + 8];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63; // wave 0: the walk's tile; wave 1: its left neighbour (see al64_walk2_kernel)
+    if (threadIdx.x < 25) lds[threadIdx.x] = kp.sc4[threadIdx.x] - 2 * kp.g4 + 1; // pre-tagged diagonal candidate (tag 3), see fill_const_kernel
+    int *prof = &lds[32];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    unsigned *dirg0 = reinterpret_cast<unsigned *>(&lds[32 + 5 * BST]), *dirg = dirg0 + w * DIRG; // the tile this wave fills
+    int *xch = &lds[32 + 5 * BST + 2 * DIRG]; // {row, column, done} of the walk, from thread 0 to everybody
+    const int p = blockIdx.x;
+    const PairPlan pl = plans[p];
+    const uint8_t *ap = a_buf + a_start[p];
+    BetaBytes bp;
+    bp.init(b_buf, kp, b_start[p], pl.m);
+    const int m = pl.m;
+    const int64_t rb_pitch = (int64_t)m + 1;
+    const int po = pl.src;
+    int bad = 0;
+    int wi = pl.n, wj = m, wdone = 0;
+    int64_t cnt = 0, cur_run = 0;
+    int cur_op = -1, last_op = -1;
+    const int64_t sbase = scr_off[p];
+    auto flush_run = [&]() {
+        if (cur_op >= 0) {
+            gnx_cigar c; c.run_length = cur_run; c.op = (uint8_t)cur_op;
+            for (int z = 0; z < 7; z++) c._pad[z] = 0;
+            scr[sbase + cnt] = c;
+            cnt++;
+        }
+    };
+    auto emit = [&](int op, int64_t run) {
+        if (op == cur_op) cur_run += run;
+        else { flush_run(); cur_op = op; cur_run = run; }
+    };
+    int virt = 0;
+    int64_t row_off = 0;
+    bool pexit = false;
+    if (mst) {
+        virt = mst->virt; row_off = mst->row_off;
+        if (mst->resume) { wi = mst->wi; wj = mst->wj; cnt = mst->cnt; cur_run = mst->cur_run; cur_op = mst->cur_op; last_op = mst->last_op; }
+    }
+
+    if (threadIdx.x == 0) { xch[0] = wi; xch[1] = wj; xch[2] = 0; }
+    int s_prof = -1;
+    while (true) {
+        __syncthreads(); // table and walk state visible; the previous round's walk is over
+        const int ci = xch[0], cj = xch[1];
+        if (xch[2]) break;
+        if (virt > 0 && ci <= virt) { pexit = true; break; }
+        const int s = (ci - 1) / H64;
+        const int lw = (ci - 1 - s * H64) / R;
+        const int te = cj + lw;     // step of the cell the walk is at
+        const int cA = (te - 1) / CK;
+        // wave 1: the whole tile to the left -- a walk that leaves its tile through the skewed left edge enters that one at its last step or the one before
+        const bool act = w == 0 || cA >= 1;
+        const int c = w == 0 ? cA : max(cA - 1, 0);
+        const int tbeg = c * CK;
+        const int tend = w == 0 ? te : cA * CK;
+        const int nblk = act ? (tend - tbeg + 15) >> 4 : 0;
+        const int row0 = s * H64 + l * R;
+        int val[R];
+        unsigned acc[R];
+        if (s != s_prof && w == 0) { // the strip's profile (most rounds stay in the strip of the round before: 640 rows against ~116 cells per tile)
+            int a5[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = row0 + r;
+                int a = 0;
+                if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+                a5[r] = a * 5;
+            }
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+#pragma unroll
+                for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+            }
+        }
+        if (s != s_prof) { __syncthreads(); s_prof = s; }
+        int diag0 = 2;
+#pragma unroll
+        for (int r = 0; r < R; r++) { val[r] = 2; acc[r] = 0; }
+        int v_out = 0, b_out = 0;
+        if (act && c > 0) { // resume from the snapshot of step tbeg
+            const uint4 *sp = reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G64 + l) * SNAPW);
+            const uint4 x0 = sp[0], x1 = sp[1], x2 = sp[2];
+            val[0] = (int)x0.x; val[1] = (int)x0.y; val[2] = (int)x0.z; val[3] = (int)x0.w;
+            val[4] = (int)x1.x; val[5] = (int)x1.y; val[6] = (int)x1.z; val[7] = (int)x1.w;
+            val[8] = (int)x2.x; val[9] = (int)x2.y; diag0 = (int)x2.z;
+            v_out = val[R - 1];
+            const int jb = tbeg - l; // the column this lane processed at step tbeg: its base goes to the next lane
+            if (jb >= 1 && jb <= m) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
+        }
+        int qv, qb, nv = 0, nb = 0;
+        long long Bt = 0;
+        if (act && c > 0) Bt = bases[pl.rowi_off + (int64_t)s * pl.s_pitch + c];
+        const int r0v = rbase_const(2, Bt);
+        auto boundary = [&](int cc, int &ov, int &ob) {
+            ov = 0;
+            int b = 0;
+            if (l < 16 && cc >= 1 && cc <= m) {
+                if (s == 0) ov = r0v;
+                else {
+                    const int q = (cc + XB64) / CK;
+                    ov = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc] + rbase_delta(bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + q], Bt);
+                }
+                b = bp.at(cc - 1);
+                if (b >= 5) { bad = 1; b = 4; }
+            }
+            ob = b * (BST * 4);
+        };
+        boundary(tbeg + l + 1, qv, qb);
+        auto step = [&](const int t, auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int up_v = wave_shr1(qv, v_out);
+            const int pb = wave_shr1(qb, b_out);
+            qv = dpp_shl1(qv, qv);
+            qb = dpp_shl1(qb, qb);
+            const int j = t - l;
+            b_out = pb;
+            if (!CHECK || (j >= 1 && j <= m)) {
+                const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
+                int w[LW];
+#pragma unroll
+                for (int k = 0; k < LW; k++) w[k] = pw[k];
+                int vd = diag0, vu = up_v;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                    const int k = max3i(vd + S4, val[r], vu - 1);
+                    acc[r] = alignbit2((unsigned)k, acc[r]);
+                    vd = val[r];
+                    val[r] = (k & ~3) | 2;
+                    vu = val[r];
+                }
+                diag0 = up_v;
+                v_out = vu;
+            }
+        };
+        for (int b = 0; b < nblk; b++) {
+            const int t0 = tbeg + 16 * b;
+            boundary(t0 + 16 + l + 1, nv, nb);
+            if (t0 >= G64 && t0 + 16 <= m) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+            }
+            qv = nv; qb = nb;
+            const int miss = (t0 + 16 - l) - m; // steps this lane sat idle after its last column
+            const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) dirg[(b * R + r) * G64 + l] = acc[r] >> sh;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // walk inside one tile; returns 0: left through the skewed left edge, 1: through the top edge of the strip, 2: the walk is over (or failed)
+            auto walk_tile = [&](const unsigned *dgX, const int tbX) -> int {
+                int why = 2;
+                int i = wi, j = wj;
+                while (true) {
+                    if (i == 0 || j == 0) { wdone = 1; break; }
+                    const int i0 = i - 1 - s * H64;
+                    if (i0 < 0) { why = 1; break; } // left the strip through its top edge
+                    const int l2 = i0 / R, r2 = i0 - l2 * R;
+                    const int t1 = j + l2 - 1 - tbX;
+                    if (t1 < 0) { why = 0; break; } // left the tile through its (skewed) left edge
+                    const int pos = t1 & 15;
+                    const unsigned w = dgX[((t1 >> 4) * R + r2) * G64 + l2];
+                    int tag = (int)((w >> (2 * pos)) & 3u);
+                    if (tag == 0) { atomicOr(err, 2); wdone = 1; break; }
+                    const int op = 3 - tag;
+                    if (op == 1) { // horizontal run: count the fields "came from the left" below pos with one xor + clz
+                        const int avail = min(pos + 1, j);
+                        unsigned x = w ^ 0xAAAAAAAAu;
+                        if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
+                        const int lowcut = pos + 1 - avail;
+                        if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+                        int steps;
+                        if (x == 0) steps = avail;
+                        else {
+                            const int pnz = (31 - __clz((int)x)) >> 1;
+                            if (((w >> (2 * pnz)) & 3u) == 0) { atomicOr(err, 2); wdone = 1; break; }
+                            steps = pos - pnz;
+                        }
+                        emit(1, steps); j -= steps; last_op = 1;
+                        continue;
+                    }
+                    emit(op, 1);
+                    last_op = op;
+                    i--;
+                    if (op == 0) j--;
+                }
+                wi = i; wj = j;
+                return why;
+            };
+            int why = walk_tile(dirg0, cA * CK);
+            if (why == 0 && cA >= 1 && !wdone) why = walk_tile(dirg0 + DIRG, (cA - 1) * CK);
+            xch[0] = wi; xch[1] = wj; xch[2] = wdone;
+        }
+    }
+    if (threadIdx.x == 0 && mst) {
+        mst->wi = wi; mst->wj = wj; mst->cnt = cnt; mst->cur_run = cur_run; mst->cur_op = cur_op; mst->last_op = last_op; mst->done = pexit ? 0 : 1;
+    }
+    if (threadIdx.x == 0 && !pexit) {
+        // Step 4 (constGap.go:59-63), quirk Q2
+        const int64_t gi = (int64_t)wi + (wi > 0 ? row_off : 0);
+        const bool up_exit = (last_op != 1) && (gi % tp.ci == 0);
+        const bool left_exit = (last_op != 2) && ((int64_t)wj % tp.cj == 0);
+        if (!up_exit && left_exit) emit(2, gi);
+        else if (up_exit && !left_exit) emit(1, wj);
+        flush_run();
+        nops[po] = cnt;
+        score_out[po] = hfin[pl.hcol_off];
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+
 } // namespace

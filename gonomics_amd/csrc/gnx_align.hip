@@ -774,7 +774,11 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
 #define GNX_AL_WALK(P_, RBS_) hipLaunchKernelGGL((al_walk_kernel<P_, RBS_>), gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr)
         if (w64 && !affine) { // one pair per workgroup
             const dim3 gw((unsigned)np);
-            if (p16) hipLaunchKernelGGL((cl64_walk_kernel<true>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
+            if (w64_two_waves()) {
+                if (p16) hipLaunchKernelGGL((cl64_walk2_kernel<true>), gw, dim3(128), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
+                else hipLaunchKernelGGL((cl64_walk2_kernel<false>), gw, dim3(128), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
+            }
+            else if (p16) hipLaunchKernelGGL((cl64_walk_kernel<true>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
             else hipLaunchKernelGGL((cl64_walk_kernel<false>), gw, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
         } else if (w64) {
             const dim3 gw((unsigned)np);
@@ -1080,7 +1084,11 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             HIPCHK(hipEventRecord(c.ev[1], stream));
             if (w64 && !affine) {
                 const int *drb = reinterpret_cast<const int *>(c.rowbuf.p);
-                if (p16) hipLaunchKernelGGL((cl64_walk_kernel<true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                if (w64_two_waves()) {
+                    if (p16) hipLaunchKernelGGL((cl64_walk2_kernel<true>), dim3(1), dim3(128), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                    else hipLaunchKernelGGL((cl64_walk2_kernel<false>), dim3(1), dim3(128), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
+                }
+                else if (p16) hipLaunchKernelGGL((cl64_walk_kernel<true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
                 else hipLaunchKernelGGL((cl64_walk_kernel<false>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
             } else if (w64) {
                 const int2 *drb2 = reinterpret_cast<const int2 *>(c.rowbuf.p);

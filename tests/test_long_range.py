@@ -200,7 +200,7 @@ def test_row_panels_forced(gpu_lib, monkeypatch, mode, strips):
 
 
 @pytest.mark.parametrize("cs", [3, 16, 10000])
-@pytest.mark.parametrize("walk", ["two_waves", "one_wave"])  # affine: al64_walk2_kernel (the left neighbour tile re-filled by a second wave) / al64_walk_kernel
+@pytest.mark.parametrize("walk", ["two_waves", "one_wave"])  # al64_walk2_kernel / cl64_walk2_kernel (the left neighbour tile re-filled by a second wave) or the one-wave kernels
 @pytest.mark.parametrize("mode", [0, 1, 2, 4])  # AffineGap, ConstGap, AffineGap_highMem, ConstGap_highMem
 def test_w64_forced(gpu_lib, monkeypatch, mode, cs, walk):
     """GNX_CLONG=2 + GNX_W64=2: every pair through the snapshot path with the whole wave on one pair (affine_long64.hip.h / const_long64.hip.h:
@@ -209,8 +209,6 @@ def test_w64_forced(gpu_lib, monkeypatch, mode, cs, walk):
     monkeypatch.setenv("GNX_W64", "2")
     affine = mode in (0, 2)
     if walk == "one_wave":
-        if not affine:
-            pytest.skip("the constant-gap walk has one form")
         monkeypatch.setenv("GNX_W64_SPEC", "0")
     for seed, nmax, mmax, count in ((31, 60, 400, 48), (32, 2000, 1500, 30), (33, 5000, 2600, 12), (34, 700, 9000, 10)):
         alphas, betas = _ragged(seed + 100 * cs, count, nmax, mmax)
@@ -248,8 +246,6 @@ def test_w64_is_the_route_of_few_pairs(gpu_lib, monkeypatch, mode):
 def test_w64_row_panels(gpu_lib, monkeypatch, mode, strips):
     """row panels (run_device_mega) of k strips of 640 rows in the 64-lane geometry: the stand-in strip, MegaState across panel borders"""
     if strips.endswith(":one_wave"):
-        if mode in (1, 4):
-            pytest.skip("the constant-gap walk has one form")
         monkeypatch.setenv("GNX_W64_SPEC", "0")
     monkeypatch.setenv("GNX_MEGA_STRIPS", strips.split(":")[0])
     monkeypatch.setenv("GNX_W64", "2")
