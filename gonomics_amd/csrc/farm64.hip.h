@@ -1,0 +1,617 @@
+// farm64.hip.h -- the walk of ONE long pair on many CUs: tiles re-filled ahead of the walk, a round at a time
+// Part of libgonomics_align_hip.so; included by gnx_align.hip (one translation unit).
+#pragma once
+#include "affine_long64.hip.h"
+#include "const_long64.hip.h"
+
+namespace {
+// ------------------------------------------------------------------------------------------------------
+// al64_walk_kernel / cl64_walk_kernel alternate, on one wave (two with the speculative left tile), "re-fill the tile the walk is in" (640 rows x
+// <= 132 steps of the recording recurrence: ~60 us of a lone wave) and "walk ~116 cells": 0.54 s per 1e6 cells of path, 60 % of a 1 Mb x 1 Mb
+// call (align/affineGap.go:59-68 is what cmd/cigarToBed/cigarToBed.go:86 calls; one pair, nothing else on the device).  But a re-fill does not
+// depend on the path at all -- snapshot + boundary row in, direction planes out -- only WHICH tiles are needed does, and a global alignment
+// of related sequences runs along a diagonal.  So a round is two launches on the call's stream, no host round trip:
+//   *_farm_fill_kernel   grid = (tiles, pairs): workgroup q re-fills tile ctl.tile[q] = {strip, block} completely (every step of the block,
+//                        all three planes) into planes[q] in global memory (69 KB, L2-resident) -- the fill code of al64_walk_kernel.
+//   farm_walk_kernel     one workgroup per pair: while the tile of the walk's cell is one of the round's, copy the <= 24 lanes of it above the
+//                        cell into LDS (4 waves), walk it on wave 0 with the walk state in SGPRs (quirks Q1 / Q2, MegaState for row panels:
+//                        the code of al64_walk_kernel); in state M all 64 lanes look at the next 64 cells of the diagonal at once and the
+//                        walk takes the leading run of "from M" fields in one step.  Then it leaves the next round's tiles in ctl: the
+//                        tiles of the straight diagonal through the cell it stopped at.  A tile that was not predicted ends the round; the
+//                        first tile of a round is always the walk's own, so every round moves.
+// The planes are the ones a round of al64_walk_kernel computes (same snapshot, same recurrence, the steps beyond the walk's are never read), the
+// walk is the same automaton: results identical.  GNX_W64_FARM=0: off; =k: k tiles per round (default 16, at most 32).
+// ------------------------------------------------------------------------------------------------------
+constexpr int FARM_MAX = 32; // tiles per round and pair, at most
+constexpr int FARM_NLC = 24; // lanes of a tile the walker holds in LDS (a diagonal leaves a tile after ~15)
+
+struct FarmCtl {
+    int32_t fin, n, rounds, hits;
+    int32_t acc_i, acc_j, pad0, pad1; // rows / columns the walk moved lately (each round: halved, plus the round's)
+    int2 tile[FARM_MAX]; // {strip, block}
+};
+
+template <bool AFF>
+struct FarmGeo {
+    static constexpr int CK = AFF ? CK64 : CKC64;
+    static constexpr int NPL = AFF ? 3 : 1;                   // planes
+    static constexpr int WORDS = AFF ? AL64_WORDS : CK / 16; // direction words per plane row
+    static constexpr int ROWS = WORDS * NPL * R;              // plane rows of G64 dwords
+    static constexpr int TILE_DW = ROWS * G64 + H64;          // + the keys h(i, m) of the rows that have passed column m (affine)
+    static __device__ __forceinline__ int block_of(int te) { return AFF ? (te >= 3 ? (te - 3) / CK : 0) : (te - 1) / CK; }
+    static __device__ __forceinline__ int tmin_of(int c) { return AFF ? (c > 0 ? 2 : 0) : 0; }
+};
+
+// the tiles of the straight line through cell (i, j) whose direction is what the walk did lately ((da, db) rows / columns; the diagonal while
+// nothing is known), the cell's own tile first.  A line, not the diagonal: a global alignment of sequences of unequal length (300 kb x 2 Mb: 450 000
+// runs) is a staircase that looks like a line of its mean slope at the scale of a tile.  Float arithmetic decides where the line leaves a tile;
+// what comes out is only a guess at the tiles worth re-filling -- a wrong one costs its re-fill, never a result.
+template <bool AFF>
+__device__ __forceinline__ int farm_predict(int2 *tile, int i, int j, const int virt, const int nt, const bool store, const int da, const int db) {
+    using Geo = FarmGeo<AFF>;
+    float fa = 1.0f, fb = 1.0f;
+    if (da > 0 || db > 0) { const float mx = (float)max(da, db); fa = (float)da / mx; fb = (float)db / mx; }
+    const float den = fb + fa * (1.0f / R); // steps of the wavefront the line crosses per unit
+    int n = 0, ps = -1, pc = -1;
+    for (int guard = 0; guard < 4 * nt && n < nt && i > 0 && j > 0 && !(virt > 0 && i <= virt); guard++) {
+        const int s = (i - 1) / H64, i0 = i - 1 - s * H64, lw = i0 / R, te = j + lw;
+        const int c = Geo::block_of(te), tbeg = c * Geo::CK, tmin = Geo::tmin_of(c);
+        if (s == ps && c == pc) { // (rounding left the line inside the tile it was to leave)
+            if (fb >= fa) j -= 2; else i -= 2;
+            continue;
+        }
+        if (store) tile[n] = make_int2(s, c);
+        n++; ps = s; pc = c;
+        // units until the line is above the strip (xt), left of column 1 (xc), or at a step of the tile before tmin (xl)
+        const float xl = (float)(te - 1 - tbeg - tmin + 1) / den;
+        const float xt = fa > 0.0f ? (float)(i0 + 1) / fa : 3.0e9f;
+        const float xc = fb > 0.0f ? (float)j / fb : 3.0e9f;
+        const float x = fminf(xl, fminf(xt, xc));
+        int di = (int)(fa * x + 0.999f), dj = (int)(fb * x + 0.999f);
+        if (di + dj == 0) { di = fa >= fb; dj = fb > fa; }
+        i -= min(di, i0 + 1); j -= dj;
+    }
+    return n;
+}
+
+template <bool AFF>
+__global__ __launch_bounds__(64) void farm_init_kernel(const PairPlan *__restrict__ plans, int n_pairs, TbParams tp, MegaState *__restrict__ mst, FarmCtl *__restrict__ ctl, int nt) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= n_pairs) return;
+    MegaState *st = mst + p;
+    const PairPlan pl = plans[p];
+    if (!st->resume) {
+        st->wi = pl.n; st->wj = pl.m; st->wk = 0; st->pend = 1;
+        st->li = (pl.n > 0) ? ((int64_t)pl.n + st->row_off - 1) % tp.ci : 0;
+        st->cnt = 0; st->cur_run = 0; st->cur_op = -1; st->last_op = -1;
+    }
+    st->done = 0;
+    FarmCtl *cp = ctl + p;
+    cp->fin = 0; cp->rounds = 0; cp->hits = 0; cp->acc_i = 0; cp->acc_j = 0;
+    cp->n = farm_predict<AFF>(cp->tile, st->wi, st->wj, st->virt, nt, true, 0, 0);
+}
+
+// ---- affine: the fill of al64_walk_kernel, tile {s, c} completely, planes to global memory ----
+template <bool P16>
+__global__ __launch_bounds__(64) void al64_farm_fill_kernel(const PairPlan *__restrict__ plans,
+                                                            const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                            const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                            KParams kp, const int2 *__restrict__ rowbuf, const int *__restrict__ snap,
+                                                            int *__restrict__ err, const long long *__restrict__ bases,
+                                                            const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes) {
+    using Geo = FarmGeo<true>;
+    constexpr int LW = P16 ? R / 2 : R;
+    constexpr int BST = G64 * LW;
+    constexpr int TI = 2, TD = 1;
+    __shared__ int lds[32 + 5 * BST];
+    const int p = blockIdx.y, q = blockIdx.x;
+    const FarmCtl *cp = ctl + p;
+    if (cp->fin || q >= cp->n) return;
+    const int s = cp->tile[q].x, c = cp->tile[q].y;
+    unsigned *dirg = planes + ((int64_t)p * FARM_MAX + q) * Geo::TILE_DW;
+    int *hcolT = reinterpret_cast<int *>(dirg + Geo::ROWS * G64);
+    const int l = threadIdx.x;
+    if (l < 25) lds[l] = kp.sc4[l] - 2 * kp.e4;
+    int *prof = &lds[32];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    const PairPlan pl = plans[p];
+    const uint8_t *ap = a_buf + a_start[p];
+    BetaBytes bp;
+    bp.init(b_buf, kp, b_start[p], pl.m);
+    const int m = pl.m;
+    const int64_t rb_pitch = (int64_t)m + 1;
+    const int OE4 = kp.oe4, E4 = kp.e4, RB = kp.e4;
+    int vO4;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
+    int bad = 0;
+    const int tbeg = c * CK64;
+    const int nblk = min(AL64_WORDS, (m + G64 - tbeg + 15) >> 4); // (no walk stands beyond step m + 63)
+    const int row0 = s * H64 + l * R;
+    int rt[R], hold[R];
+    unsigned acc[3 * R];
+    __syncthreads();
+    {
+        int a5[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i0 = row0 + r;
+            int a = 0;
+            if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+            a5[r] = a * 5;
+        }
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+#pragma unroll
+            for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = row0 + r + 1;
+        const int D1c = kp.d00_4 + i * kp.ecol4 + TD - RB * i;
+        hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
+        rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;
+        acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
+    }
+    int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
+    int dn_out = 0, h_out = 0, b_out = 0;
+    if (c > 0) { // resume from the snapshot of step tbeg
+        const uint4 *sp = reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G64 + l) * AL_SNAPW);
+        const uint4 x0 = sp[0], x1 = sp[1], x2 = sp[2], x3 = sp[3], x4 = sp[4], x5 = sp[5];
+        rt[0] = (int)x0.x; rt[1] = (int)x0.y; rt[2] = (int)x0.z; rt[3] = (int)x0.w; rt[4] = (int)x1.x; rt[5] = (int)x1.y; rt[6] = (int)x1.z; rt[7] = (int)x1.w;
+        rt[8] = (int)x2.x; rt[9] = (int)x2.y; hold[0] = (int)x2.z; hold[1] = (int)x2.w; hold[2] = (int)x3.x; hold[3] = (int)x3.y; hold[4] = (int)x3.z; hold[5] = (int)x3.w;
+        hold[6] = (int)x4.x; hold[7] = (int)x4.y; hold[8] = (int)x4.z; hold[9] = (int)x4.w; diag0 = (int)x5.x; dn_out = (int)x5.y;
+        h_out = hold[R - 1];
+        const int jb = tbeg - l;
+        if (jb >= 1 && jb <= m) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
+    }
+    int qdn, qh, qb, ndn = 0, nh = 0, nb = 0;
+    long long Bt = 0;
+    if (c > 0) Bt = bases[pl.rowi_off + (int64_t)s * pl.s_pitch + c];
+    const int r0i = rbase_const((long long)kp.o4 + TI, Bt);
+    auto boundary = [&](int cc, int &odn, int &oh, int &ob) {
+        odn = 0; oh = 0; ob = 0;
+        if (l < 16 && cc >= 1 && cc <= m) {
+            if (s == 0) {
+                const int M3 = NEG4 + 3, I2 = r0i, D1 = NEG4 + TD;
+                oh = max3i(M3, I2, D1);
+                odn = max3i(M3 + OE4, I2 + OE4, D1 + E4) - RB;
+            } else {
+                const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
+                const int qq = (cc + XB64) / CK64;
+                const int dd = rbase_delta(bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + qq], Bt);
+                odn = v.x + dd; oh = v.y + dd;
+            }
+            ob = bp.raw(cc - 1);
+        }
+    };
+    auto base_off = [&](int raw, int cc) { int b = (l < 16 && cc >= 1 && cc <= m) ? bp.value(raw, cc - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
+    boundary(tbeg + l + 1, qdn, qh, qb);
+    qb = base_off(qb, tbeg + l + 1);
+    int wq[LW], pb_cur;
+    auto fetch = [&](int pbv, int *w) {
+        const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+#pragma unroll
+        for (int k = 0; k < LW; k++) w[k] = pw[k];
+    };
+    pb_cur = wave_shr1(qb, b_out);
+    qb = dpp_shl1(qb, qb);
+    fetch(pb_cur, wq);
+    auto step = [&](const int t, auto chk, const bool take, const int nqv) {
+        constexpr bool CHECK = decltype(chk)::value;
+        const int up_dn = wave_shr1(qdn, dn_out);
+        const int up_h = wave_shr1(qh, h_out);
+        qdn = dpp_shl1(qdn, qdn);
+        qh = dpp_shl1(qh, qh);
+        if (take) qb = nqv;
+        const int pb_next = wave_shr1(qb, pb_cur);
+        qb = dpp_shl1(qb, qb);
+        int wn[LW];
+        fetch(pb_next, wn);
+        asm volatile("" ::: "memory");
+        const int j = t - l;
+        const int *w = wq;
+        if (!CHECK || (j >= 1 && j <= m)) {
+            int hd = diag0, dnu = up_dn;
+#pragma unroll
+            for (int r = 0; r < R; r++) { // the recording h-form of fill_affine_kernel (rebased keys)
+                const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                acc[r] = alignbit2((unsigned)hd, acc[r]);
+                acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
+                acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
+                const int M3 = (hd | 3) + S4;
+                const int I2 = (rt[r] & ~3) | TI;
+                const int D1 = (dnu & ~3) | TD;
+                const int hnew = max3i(M3, I2, D1);
+                const int ho = hnew + vO4;
+                rt[r] = max(ho, I2);
+                const int dnn = max(ho, D1);
+                hd = hold[r];
+                hold[r] = hnew;
+                dnu = dnn;
+            }
+            diag0 = up_h;
+            dn_out = dnu;
+            h_out = hold[R - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < LW; k++) wq[k] = wn[k];
+        pb_cur = pb_next;
+    };
+    for (int b = 0; b < nblk; b++) {
+        const int t0 = tbeg + 16 * b;
+        boundary(t0 + 16 + l + 1, ndn, nh, nb);
+        if (t0 >= G64 && t0 + 16 <= m) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+        }
+        qdn = ndn; qh = nh;
+        const int miss = (t0 + 16 - l) - m;
+        const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) dirg[((b * 3 + k) * R + r) * G64 + l] = acc[k * R + r] >> sh;
+        }
+        if (b == nblk - 1 && t0 + 16 - l >= m) { // lanes that have passed column m hold h(i, m) of their rows
+#pragma unroll
+            for (int r = 0; r < R; r++) hcolT[l * R + r] = hold[r];
+        }
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+// ---- constant gap: the fill of cl64_walk_kernel, tile {s, c} completely, its one plane to global memory ----
+template <bool P16>
+__global__ __launch_bounds__(64) void cl64_farm_fill_kernel(const PairPlan *__restrict__ plans,
+                                                            const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                            const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                            KParams kp, const int *__restrict__ rowbuf, const int *__restrict__ snap,
+                                                            int *__restrict__ err, const long long *__restrict__ bases,
+                                                            const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes) {
+    using Geo = FarmGeo<false>;
+    constexpr int LW = P16 ? R / 2 : R;
+    constexpr int BST = G64 * LW;
+    constexpr int CK = CKC64;
+    __shared__ int lds[32 + 5 * BST];
+    const int p = blockIdx.y, q = blockIdx.x;
+    const FarmCtl *cp = ctl + p;
+    if (cp->fin || q >= cp->n) return;
+    const int s = cp->tile[q].x, c = cp->tile[q].y;
+    unsigned *dirg = planes + ((int64_t)p * FARM_MAX + q) * Geo::TILE_DW;
+    const int l = threadIdx.x;
+    if (l < 25) lds[l] = kp.sc4[l] - 2 * kp.g4 + 1; // pre-tagged diagonal candidate (tag 3), see fill_const_kernel
+    int *prof = &lds[32];
+    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    const PairPlan pl = plans[p];
+    const uint8_t *ap = a_buf + a_start[p];
+    BetaBytes bp;
+    bp.init(b_buf, kp, b_start[p], pl.m);
+    const int m = pl.m;
+    const int64_t rb_pitch = (int64_t)m + 1;
+    int bad = 0;
+    const int tbeg = c * CK;
+    const int nblk = min(CK / 16, (m + (G64 - 1) - tbeg + 15) >> 4); // (no walk stands beyond step m + 63)
+    const int row0 = s * H64 + l * R;
+    int val[R];
+    unsigned acc[R];
+    __syncthreads();
+    {
+        int a5[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i0 = row0 + r;
+            int a = 0;
+            if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
+            a5[r] = a * 5;
+        }
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+#pragma unroll
+            for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
+        }
+        __syncthreads();
+    }
+    int diag0 = 2;
+#pragma unroll
+    for (int r = 0; r < R; r++) { val[r] = 2; acc[r] = 0; }
+    int v_out = 0, b_out = 0;
+    if (c > 0) { // resume from the snapshot of step tbeg
+        const uint4 *sp = reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G64 + l) * SNAPW);
+        const uint4 x0 = sp[0], x1 = sp[1], x2 = sp[2];
+        val[0] = (int)x0.x; val[1] = (int)x0.y; val[2] = (int)x0.z; val[3] = (int)x0.w;
+        val[4] = (int)x1.x; val[5] = (int)x1.y; val[6] = (int)x1.z; val[7] = (int)x1.w;
+        val[8] = (int)x2.x; val[9] = (int)x2.y; diag0 = (int)x2.z;
+        v_out = val[R - 1];
+        const int jb = tbeg - l;
+        if (jb >= 1 && jb <= m) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
+    }
+    int qv, qb, nv = 0, nb = 0;
+    long long Bt = 0;
+    if (c > 0) Bt = bases[pl.rowi_off + (int64_t)s * pl.s_pitch + c];
+    const int r0v = rbase_const(2, Bt);
+    auto boundary = [&](int cc, int &ov, int &ob) {
+        ov = 0;
+        int b = 0;
+        if (l < 16 && cc >= 1 && cc <= m) {
+            if (s == 0) ov = r0v;
+            else {
+                const int qq = (cc + XB64) / CK;
+                ov = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc] + rbase_delta(bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + qq], Bt);
+            }
+            b = bp.at(cc - 1);
+            if (b >= 5) { bad = 1; b = 4; }
+        }
+        ob = b * (BST * 4);
+    };
+    boundary(tbeg + l + 1, qv, qb);
+    auto step = [&](const int t, auto chk) {
+        constexpr bool CHECK = decltype(chk)::value;
+        const int up_v = wave_shr1(qv, v_out);
+        const int pb = wave_shr1(qb, b_out);
+        qv = dpp_shl1(qv, qv);
+        qb = dpp_shl1(qb, qb);
+        const int j = t - l;
+        b_out = pb;
+        if (!CHECK || (j >= 1 && j <= m)) {
+            const int *pw = reinterpret_cast<const int *>(prof_lane + pb);
+            int w[LW];
+#pragma unroll
+            for (int k = 0; k < LW; k++) w[k] = pw[k];
+            int vd = diag0, vu = up_v;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
+                const int k = max3i(vd + S4, val[r], vu - 1);
+                acc[r] = alignbit2((unsigned)k, acc[r]);
+                vd = val[r];
+                val[r] = (k & ~3) | 2;
+                vu = val[r];
+            }
+            diag0 = up_v;
+            v_out = vu;
+        }
+    };
+    for (int b = 0; b < nblk; b++) {
+        const int t0 = tbeg + 16 * b;
+        boundary(t0 + 16 + l + 1, nv, nb);
+        if (t0 >= G64 && t0 + 16 <= m) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) step(t0 + u + 1, std::false_type{});
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < 16; u++) step(t0 + u + 1, std::true_type{});
+        }
+        qv = nv; qb = nb;
+        const int miss = (t0 + 16 - l) - m; // steps this lane sat idle after its last column
+        const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) dirg[(b * R + r) * G64 + l] = acc[r] >> sh;
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+__device__ __forceinline__ int64_t farm_rfl64(int64_t v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffLL));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// ---- the walk of one round: wave 0 walks (state uniform: SGPRs), all four waves copy the tile's window into LDS ----
+template <bool AFF>
+__global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restrict__ plans, TbParams tp,
+                                                        const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                        const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
+                                                        MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all,
+                                                        const unsigned *__restrict__ planes, int nt) {
+    using Geo = FarmGeo<AFF>;
+    constexpr int CK = Geo::CK, NPL = Geo::NPL, ROWS = Geo::ROWS, NLC = FARM_NLC;
+    __shared__ unsigned win[ROWS * NLC];
+    __shared__ int xch[4];
+    const int p = blockIdx.x;
+    FarmCtl *ctl = ctl_all + p;
+    MegaState *mst = mst_all + p;
+    const int tid = threadIdx.x, l = tid & 63;
+    const bool w0 = tid < 64;
+    if (__builtin_amdgcn_readfirstlane(ctl->fin)) return;
+    const PairPlan pl = plans[p];
+    const int m = pl.m, po = pl.src;
+#define GNX_RFL(x_) __builtin_amdgcn_readfirstlane(x_)
+    int wi = GNX_RFL(mst->wi), wj = GNX_RFL(mst->wj), wk = GNX_RFL(mst->wk), pend = GNX_RFL(mst->pend), wdone = 0;
+    int cur_op = GNX_RFL(mst->cur_op), last_op = GNX_RFL(mst->last_op);
+    int64_t li = farm_rfl64(mst->li), cnt = farm_rfl64(mst->cnt), cur_run = farm_rfl64(mst->cur_run);
+    const int virt = GNX_RFL(mst->virt);
+    const int64_t row_off = farm_rfl64(mst->row_off);
+    const int64_t sbase = scr_off[p];
+    const int n_list = GNX_RFL(ctl->n);
+    const int wi_in = wi, wj_in = wj;
+    int2 mytile = make_int2(-1, -1);
+    if (l < n_list) mytile = ctl->tile[l];
+    auto flush_run = [&]() {
+        if (cur_op >= 0) {
+            if (tid == 0) {
+                gnx_cigar cg; cg.run_length = cur_run; cg.op = (uint8_t)cur_op;
+                for (int z = 0; z < 7; z++) cg._pad[z] = 0;
+                scr[sbase + cnt] = cg;
+            }
+            cnt++;
+        }
+    };
+    auto emit = [&](int op, int64_t run) {
+        if (op == cur_op) cur_run += run;
+        else { flush_run(); cur_op = op; cur_run = run; }
+    };
+    bool pexit = false;
+    int hits = 0;
+    while (true) {
+        int slot = -1, s = 0, c = 0, lw = 0, lo = 0;
+        if (w0) {
+            if (wi == 0 || wj == 0) wdone = 1;
+            if (!wdone && virt > 0 && wi <= virt) pexit = true;
+            if (!wdone && !pexit) {
+                s = (wi - 1) / H64;
+                lw = (wi - 1 - s * H64) / R;
+                c = Geo::block_of(wj + lw);
+                const unsigned long long bal = __ballot(mytile.x == s && mytile.y == c);
+                slot = bal ? (int)__builtin_ctzll(bal) : -1;
+                lo = max(0, lw - (NLC - 1));
+            }
+            if (tid == 0) { xch[0] = slot; xch[1] = lo; xch[2] = lw; }
+        }
+        __syncthreads();
+        slot = xch[0]; lo = xch[1];
+        const int hi = xch[2];
+        if (slot < 0) break;
+        const unsigned *src = planes + ((int64_t)p * FARM_MAX + slot) * Geo::TILE_DW;
+        for (int idx = tid; idx < ROWS * NLC; idx += 256) {
+            const int row = idx / NLC, ll = idx - row * NLC;
+            win[idx] = (lo + ll <= hi) ? src[row * G64 + lo + ll] : 0u;
+        }
+        __syncthreads();
+        if (w0) {
+            hits++;
+            const int tbX = c * CK, tmX = Geo::tmin_of(c);
+            int i = wi, j = wj, k = wk;
+            if constexpr (AFF) {
+                const int *hcX = reinterpret_cast<const int *>(src + ROWS * G64);
+                if (pend) { k = 3 - (GNX_RFL(hcX[i - 1 - s * H64]) & 3); pend = 0; }
+                while (true) {
+                    if (i == 0 || j == 0) { wdone = 1; break; }
+                    const int i0 = i - 1 - s * H64;
+                    if (i0 < 0) break; // left the strip through its top edge
+                    const int l2 = i0 / R, r2 = i0 - l2 * R;
+                    if (l2 < lo) break; // above the window: the next copy follows
+                    const int t1 = j + l2 - 1 - tbX;
+                    if (t1 < tmX) break; // left the (usable part of the) tile through its skewed left edge
+                    if (k == 0) { // state M: the leading run of cells (i - x, j - x) whose M field says "from M" -- one step (no checkerboard edge inside: x < li)
+                        const int ix = i0 - l;
+                        const int ixc = max(ix, 0);
+                        const int l2x = ixc / R, r2x = ixc - l2x * R;
+                        const int t1x = (j - l) + l2x - 1 - tbX;
+                        const bool in = ix >= 0 && j - l >= 1 && (int64_t)l < li && t1x >= tmX && l2x >= lo;
+                        const unsigned wv = in ? win[(((t1x >> 4) * 3 + 0) * R + r2x) * NLC + (l2x - lo)] : 0u;
+                        const bool ok = in && ((wv >> (2 * (t1x & 15))) & 3u) == 3u;
+                        const unsigned long long nbal = ~__ballot(ok);
+                        const int nb = nbal ? (int)__builtin_ctzll(nbal) : 64;
+                        if (nb > 0) { emit(0, nb); last_op = 0; li -= nb; i -= nb; j -= nb; continue; }
+                    }
+                    const int pos = t1 & 15;
+                    const unsigned w = (unsigned)GNX_RFL((int)win[(((t1 >> 4) * 3 + k) * R + r2) * NLC + (l2 - lo)]);
+                    int tag = (int)((w >> (2 * pos)) & 3u);
+                    if (tag == 0) { if (tid == 0) atomicOr(err, 2); wdone = 1; break; }
+                    if (k == 1) { // horizontal run inside this word, see traceback_kernel
+                        int avail = min(pos + 1, j);
+                        if (t1 < 16) avail = min(avail, pos - tmX + 1);
+                        unsigned x = w ^ 0xAAAAAAAAu;
+                        if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
+                        const int lowcut = pos + 1 - avail;
+                        if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+                        int steps;
+                        if (x == 0) steps = avail;
+                        else {
+                            const int pnz = (31 - __clz((int)x)) >> 1;
+                            tag = (int)((w >> (2 * pnz)) & 3u);
+                            if (tag == 0) { if (tid == 0) atomicOr(err, 2); wdone = 1; break; }
+                            steps = pos - pnz + 1;
+                            k = 3 - tag;
+                        }
+                        emit(1, steps); j -= steps; last_op = 1;
+                        continue;
+                    }
+                    emit(k, 1);
+                    last_op = k;
+                    const bool up_exit = (li == 0);
+                    li = up_exit ? tp.ci - 1 : li - 1;
+                    i--;
+                    if (k == 0) j--;
+                    k = 3 - tag;
+                    if (up_exit && i > 0 && j > 0) { // quirk Q1 (affineGap.go:305): restart in the argmax state of the entry cell (i, j)
+                        if (j < m) { // = the M-plane field of (i+1, j+1): the row the walk just left, at most one step past its cell
+                            const int t3 = (j + 1) + l2 - 1 - tbX;
+                            const unsigned w3 = (unsigned)GNX_RFL((int)win[(((t3 >> 4) * 3 + 0) * R + r2) * NLC + (l2 - lo)]);
+                            k = 3 - (int)((w3 >> (2 * (t3 & 15))) & 3u);
+                        } else if (i - 1 - s * H64 >= 0 && m + (i - 1 - s * H64) / R - 1 - tbX >= tmX) k = 3 - (GNX_RFL(hcX[i - 1 - s * H64]) & 3);
+                        else pend = 1; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                    }
+                }
+            } else {
+                while (true) {
+                    if (i == 0 || j == 0) { wdone = 1; break; }
+                    const int i0 = i - 1 - s * H64;
+                    if (i0 < 0) break; // left the strip through its top edge
+                    const int l2 = i0 / R, r2 = i0 - l2 * R;
+                    if (l2 < lo) break; // above the window
+                    const int t1 = j + l2 - 1 - tbX;
+                    if (t1 < 0) break; // left the tile through its (skewed) left edge
+                    { // the leading run of diagonal fields along (i - x, j - x), one step
+                        const int ix = i0 - l;
+                        const int ixc = max(ix, 0);
+                        const int l2x = ixc / R, r2x = ixc - l2x * R;
+                        const int t1x = (j - l) + l2x - 1 - tbX;
+                        const bool in = ix >= 0 && j - l >= 1 && t1x >= 0 && l2x >= lo;
+                        const unsigned wv = in ? win[((t1x >> 4) * R + r2x) * NLC + (l2x - lo)] : 0u;
+                        const bool ok = in && ((wv >> (2 * (t1x & 15))) & 3u) == 3u;
+                        const unsigned long long nbal = ~__ballot(ok);
+                        const int nb = nbal ? (int)__builtin_ctzll(nbal) : 64;
+                        if (nb > 0) { emit(0, nb); last_op = 0; i -= nb; j -= nb; continue; }
+                    }
+                    const int pos = t1 & 15;
+                    const unsigned w = (unsigned)GNX_RFL((int)win[((t1 >> 4) * R + r2) * NLC + (l2 - lo)]);
+                    const int tag = (int)((w >> (2 * pos)) & 3u);
+                    if (tag == 0) { if (tid == 0) atomicOr(err, 2); wdone = 1; break; }
+                    const int op = 3 - tag;
+                    if (op == 1) { // horizontal run: count the fields "came from the left" below pos with one xor + clz
+                        const int avail = min(pos + 1, j);
+                        unsigned x = w ^ 0xAAAAAAAAu;
+                        if (pos < 15) x &= (1u << (2 * pos + 2)) - 1u;
+                        const int lowcut = pos + 1 - avail;
+                        if (lowcut > 0) x &= ~((1u << (2 * lowcut)) - 1u);
+                        int steps;
+                        if (x == 0) steps = avail;
+                        else {
+                            const int pnz = (31 - __clz((int)x)) >> 1;
+                            if (((w >> (2 * pnz)) & 3u) == 0) { if (tid == 0) atomicOr(err, 2); wdone = 1; break; }
+                            steps = pos - pnz;
+                        }
+                        emit(1, steps); j -= steps; last_op = 1;
+                        continue;
+                    }
+                    emit(op, 1);
+                    last_op = op;
+                    i--;
+                    if (op == 0) j--;
+                }
+            }
+            wi = i; wj = j; wk = k;
+        }
+    }
+    if (!w0) return;
+    if (tid == 0) {
+        mst->wi = wi; mst->wj = wj; mst->wk = wk; mst->pend = pend; mst->li = li; mst->cnt = cnt; mst->cur_run = cur_run; mst->cur_op = cur_op; mst->last_op = last_op;
+        ctl->rounds += 1; ctl->hits += hits;
+    }
+    if (wdone || pexit) {
+        if (tid == 0) { mst->done = pexit ? 0 : 1; ctl->fin = 1; ctl->n = 0; }
+        if (!pexit) {
+            // Step 4 (affineGap.go:135-139 / constGap.go:59-63) -- quirk Q2 when the corner is not the origin
+            const int64_t gi = (int64_t)wi + (wi > 0 ? row_off : 0);
+            const bool up_exit = (last_op != 1) && (gi % tp.ci == 0);
+            const bool left_exit = (last_op != 2) && ((int64_t)wj % tp.cj == 0);
+            if (!up_exit && left_exit) emit(2, gi);
+            else if (up_exit && !left_exit) emit(1, wj);
+            flush_run();
+            if (tid == 0) { nops[po] = cnt; score_out[po] = hfin[pl.hcol_off]; }
+        }
+    } else {
+        const int da = GNX_RFL(ctl->acc_i) / 2 + (wi_in - wi), db = GNX_RFL(ctl->acc_j) / 2 + (wj_in - wj);
+        const int n = farm_predict<AFF>(ctl->tile, wi, wj, virt, nt, tid == 0, da, db);
+        if (tid == 0) { ctl->n = n; ctl->acc_i = da; ctl->acc_j = db; }
+    }
+#undef GNX_RFL
+}
+
+} // namespace

@@ -46,6 +46,7 @@
 #include "affine_long.hip.h"
 #include "affine_long64.hip.h"
 #include "const_long64.hip.h"
+#include "farm64.hip.h"
 #include "lat_fill.hip.h"
 #include "lat_wide.hip.h"
 #include "seed_kernels.hip.h"
@@ -125,7 +126,7 @@ struct Ctx {
     PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
     // the resident reference, PACKED (gnx_host.hip.h: pack_reference): `ref` = 2 bits per base, ref_flag / ref_rank / ref_exc = the
     // sparse list of bases that are not A C G T (KParams::b2 / bflag / brank / bexc)
-    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off, cl_bases, sc_prof_a, sc_prof_b, mega_rows, mega_state;
+    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off, cl_bases, sc_prof_a, sc_prof_b, mega_rows, mega_state, farm;
     int64_t ref_len = -1;  // >= 0: a reference of that many bases is resident
     int64_t ref_nexc = 0;  // 64-base blocks with an exception
     int64_t ref_epoch = 0; // which gnx_set_reference call filled it (contexts created later are brought up to date on first use)
@@ -598,6 +599,55 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                     const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs, const int64_t *h_alen, const int64_t *h_blen,
                     int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool w64);
 
+// tiles per round of the walk farm (farm64.hip.h); 0: the one-workgroup walks
+int w64_farm_tiles() { const char *e = getenv("GNX_W64_FARM"); if (!e) return 16; const int v = atoi(e); return v <= 0 ? 0 : std::min(v, (int)FARM_MAX); }
+
+// The walk of the 64-lane snapshot path as rounds of {re-fill the tiles ahead of the walk on many CUs, walk them} (farm64.hip.h).
+// d_st: np MegaStates the caller has prepared (zeroed for a whole pair; the panel's state for row panels).  Launches rounds until every
+// pair's walk is over (or has left its panel): the first batch sized by the path's length, no host round trip inside a batch.
+int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan *dpl, const uint8_t *d_a, const int64_t *d_as, const uint8_t *d_b, const int64_t *d_bs,
+                  const KParams &kp, const TbParams &tp, const void *drb, const int *dsn, const int64_t *dhf, int64_t *d_score, int64_t *dn, const int64_t *d_so,
+                  gnx_cigar *d_scr, int *d_err, const long long *dbs, MegaState *d_st, int64_t path_cells, hipStream_t stream) {
+    int rc;
+    const size_t tile_dw = affine ? (size_t)FarmGeo<true>::TILE_DW : (size_t)FarmGeo<false>::TILE_DW;
+    const size_t planes_bytes = (size_t)np * FARM_MAX * tile_dw * 4;
+    if ((rc = c.farm.ensure(planes_bytes + (size_t)np * sizeof(FarmCtl)))) return rc;
+    unsigned *d_planes = reinterpret_cast<unsigned *>(c.farm.p);
+    FarmCtl *d_ctl = reinterpret_cast<FarmCtl *>(reinterpret_cast<char *>(c.farm.p) + planes_bytes);
+    if (affine) hipLaunchKernelGGL(farm_init_kernel<true>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt);
+    else hipLaunchKernelGGL(farm_init_kernel<false>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt);
+    const dim3 gf((unsigned)nt, (unsigned)np), gw((unsigned)np);
+    int64_t batch = path_cells / ((int64_t)100 * nt) + 8; // (~116 cells of path per tile; a round that finds the walk over costs a few us)
+    std::vector<FarmCtl> h_ctl((size_t)np);
+    int64_t rounds = 0;
+    while (true) {
+        for (int64_t r = 0; r < batch; r++) {
+            if (affine) {
+                const int2 *drb2 = reinterpret_cast<const int2 *>(drb);
+                if (p16) hipLaunchKernelGGL((al64_farm_fill_kernel<true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes);
+                else hipLaunchKernelGGL((al64_farm_fill_kernel<false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes);
+                hipLaunchKernelGGL(farm_walk_kernel<true>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt);
+            } else {
+                const int *drb1 = reinterpret_cast<const int *>(drb);
+                if (p16) hipLaunchKernelGGL((cl64_farm_fill_kernel<true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes);
+                else hipLaunchKernelGGL((cl64_farm_fill_kernel<false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes);
+                hipLaunchKernelGGL(farm_walk_kernel<false>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt);
+            }
+        }
+        rounds += batch;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_ctl.data(), d_ctl, (size_t)np * sizeof(FarmCtl), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        bool all = true;
+        for (int p = 0; p < np; p++) all = all && h_ctl[(size_t)p].fin;
+        if (all) break;
+        if (rounds > path_cells + 64) { set_err("internal: the walk farm does not end%s", ""); return GNX_ETRACE; }
+        batch = 16;
+    }
+    if (getenv("GNX_DEBUG")) for (int p = 0; p < np; p++) fprintf(stderr, "[gnx] walk farm: pair %d, %d tiles per round, %d rounds walked %d tiles (%lld launched)\n", p, nt, h_ctl[(size_t)p].rounds, h_ctl[(size_t)p].hits, (long long)rounds);
+    return GNX_OK;
+}
+
 // Pairs without a stored direction matrix (const_long.hip.h; affine: affine_long.hip.h): score-only sweep that keeps the strips' bottom
 // rows and a snapshot of the wavefront every CKC / CKA steps, then one fused re-fill + walk kernel.  Every n, m >= 1 (validated by the caller).
 // Returns GNX_OK, an error, or -1 when the batch should take the general path (a single pair exceeds the workspace).
@@ -772,7 +822,15 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         HIPCHK(hipEventRecord(c.ev[2], stream));
         const dim3 gridW((unsigned)((np + 3) / 4));
 #define GNX_AL_WALK(P_, RBS_) hipLaunchKernelGGL((al_walk_kernel<P_, RBS_>), gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr)
-        if (w64 && !affine) { // one pair per workgroup
+        const int farm_nt = w64 ? w64_farm_tiles() : 0;
+        if (farm_nt > 0) { // the walk as rounds of tiles re-filled ahead of it on many CUs (farm64.hip.h)
+            int64_t path = 0;
+            for (int64_t p = b; p < e; p++) path = std::max(path, (int64_t)plans[(size_t)p].n + plans[(size_t)p].m);
+            if ((rc = c.mega_state.ensure(256 + (size_t)np * sizeof(MegaState)))) return rc;
+            MegaState *d_fst = reinterpret_cast<MegaState *>(reinterpret_cast<char *>(c.mega_state.p) + 256);
+            HIPCHK(hipMemsetAsync(d_fst, 0, (size_t)np * sizeof(MegaState), stream));
+            if ((rc = run_walk_farm(c, affine, p16, (int)np, farm_nt, dpl, d_a, d_as + b, d_b, d_bs + b, kp, tp, affine ? (const void *)drb2 : (const void *)drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, d_fst, path / 2, stream))) return rc;
+        } else if (w64 && !affine) { // one pair per workgroup
             const dim3 gw((unsigned)np);
             if (w64_two_waves()) {
                 if (p16) hipLaunchKernelGGL((cl64_walk2_kernel<true>), gw, dim3(128), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr);
@@ -1082,7 +1140,11 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             const int *dsn = reinterpret_cast<const int *>(c.fp_ckpt.p);
             int64_t *d_tmp_score = dhf + 2; // (the walk writes hfin[pl.hcol_off] here when it ends: not the pair's score, see above)
             HIPCHK(hipEventRecord(c.ev[1], stream));
-            if (w64 && !affine) {
+            const int farm_nt = w64 ? w64_farm_tiles() : 0;
+            if (farm_nt > 0) {
+                if ((rc = run_walk_farm(c, affine, p16, 1, farm_nt, dpl, d_a, d_starts, d_b, d_starts + 1, kp, tp, c.rowbuf.p, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st,
+                                        std::min<int64_t>((int64_t)pl.n + jcur, 2 * (int64_t)pl.n) / 2, stream))) return rc;
+            } else if (w64 && !affine) {
                 const int *drb = reinterpret_cast<const int *>(c.rowbuf.p);
                 if (w64_two_waves()) {
                     if (p16) hipLaunchKernelGGL((cl64_walk2_kernel<true>), dim3(1), dim3(128), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
@@ -2190,7 +2252,7 @@ void gnx_shutdown(void) {
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,
-                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.cl_bases, &c.sc_prof_a, &c.sc_prof_b, &c.mega_rows, &c.mega_state, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
+                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.cl_bases, &c.sc_prof_a, &c.sc_prof_b, &c.mega_rows, &c.mega_state, &c.farm, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
                           &c.sd_tmp[0], &c.sd_tmp[1], &c.sd_tmp[2], &c.sd_tmp[3], &c.sd_tmp[4], &c.sd_tmp[5], &c.sd_tmp[6], &c.sd_tmp[7]};
         for (DevBuf *b : bufs) b->release();
         PinBuf *pins[] = {&c.h_plans, &c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};
