@@ -22,13 +22,16 @@ namespace {
 // The planes are the ones a round of al64_walk_kernel computes (same snapshot, same recurrence, the steps beyond the walk's are never read), the
 // walk is the same automaton: results identical.  GNX_W64_FARM=0: off; =k: k tiles per round (default 16, at most 32).
 // ------------------------------------------------------------------------------------------------------
+// the fill of a tile is ONE wave: its LDS traffic is ordered by a fence, not a workgroup barrier (the overlapped rounds run it inside 256-thread workgroups)
+#define FARM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 constexpr int FARM_MAX = 32; // tiles per round and pair, at most
 constexpr int FARM_NLC = 24; // lanes of a tile the walker holds in LDS (a diagonal leaves a tile after ~15)
 
 struct FarmCtl {
-    int32_t fin, n, rounds, hits;
-    int32_t acc_i, acc_j, pad0, pad1; // rows / columns the walk moved lately (each round: halved, plus the round's)
-    int2 tile[FARM_MAX]; // {strip, block}
+    int32_t fin, rounds, hits, pad0;
+    int32_t acc_i, acc_j;      // rows / columns the walk moved lately (each round: halved, plus the round's)
+    int32_t n[2];              // tiles of the two sets (the plain rounds use set 0 only)
+    int2 tile[2][FARM_MAX];    // {strip, block}
 };
 
 template <bool AFF>
@@ -46,22 +49,30 @@ struct FarmGeo {
 // nothing is known), the cell's own tile first.  A line, not the diagonal: a global alignment of sequences of unequal length (300 kb x 2 Mb: 450 000
 // runs) is a staircase that looks like a line of its mean slope at the scale of a tile.  Float arithmetic decides where the line leaves a tile;
 // what comes out is only a guess at the tiles worth re-filling -- a wrong one costs its re-fill, never a result.
-template <bool AFF>
-__device__ __forceinline__ int farm_predict(int2 *tile, int i, int j, const int virt, const int nt, const bool store, const int da, const int db) {
+template <bool AFF, typename Skip>
+__device__ __forceinline__ int farm_predict(int2 *tile, int i, int j, const int virt, const int nt, const bool store, const int da, const int db, Skip skip) {
     using Geo = FarmGeo<AFF>;
     float fa = 1.0f, fb = 1.0f;
     if (da > 0 || db > 0) { const float mx = (float)max(da, db); fa = (float)da / mx; fb = (float)db / mx; }
     const float den = fb + fa * (1.0f / R); // steps of the wavefront the line crosses per unit
     int n = 0, ps = -1, pc = -1;
-    for (int guard = 0; guard < 4 * nt && n < nt && i > 0 && j > 0 && !(virt > 0 && i <= virt); guard++) {
+    bool taking = false;
+    for (int guard = 0; guard < 6 * nt && n < nt && i > 0 && j > 0 && !(virt > 0 && i <= virt); guard++) {
         const int s = (i - 1) / H64, i0 = i - 1 - s * H64, lw = i0 / R, te = j + lw;
         const int c = Geo::block_of(te), tbeg = c * Geo::CK, tmin = Geo::tmin_of(c);
         if (s == ps && c == pc) { // (rounding left the line inside the tile it was to leave)
             if (fb >= fa) j -= 2; else i -= 2;
             continue;
         }
-        if (store) tile[n] = make_int2(s, c);
-        n++; ps = s; pc = c;
+        ps = s; pc = c;
+        // overlapped rounds: the line's leading tiles that are in the set being re-filled right now are what the next walk will have; from the first one
+        // it will not have on, EVERY tile is taken -- a set is a contiguous piece of the line (the next walk stops at that tile, and the one after
+        // it finds nothing of today's other set left), so one wrong guess costs the rest of one round and the sets are in step again
+        if (taking || !skip(s, c)) {
+            taking = true;
+            if (store) tile[n] = make_int2(s, c);
+            n++;
+        }
         // units until the line is above the strip (xt), left of column 1 (xc), or at a step of the tile before tmin (xl)
         const float xl = (float)(te - 1 - tbeg - tmin + 1) / den;
         const float xt = fa > 0.0f ? (float)(i0 + 1) / fa : 3.0e9f;
@@ -88,27 +99,29 @@ __global__ __launch_bounds__(64) void farm_init_kernel(const PairPlan *__restric
     st->done = 0;
     FarmCtl *cp = ctl + p;
     cp->fin = 0; cp->rounds = 0; cp->hits = 0; cp->acc_i = 0; cp->acc_j = 0;
-    cp->n = farm_predict<AFF>(cp->tile, st->wi, st->wj, st->virt, nt, true, 0, 0);
+    const int n0 = farm_predict<AFF>(cp->tile[0], st->wi, st->wj, st->virt, nt, true, 0, 0, [](int, int) { return false; });
+    cp->n[0] = n0;
+    // (overlapped rounds: the second set continues the line behind the first)
+    cp->n[1] = farm_predict<AFF>(cp->tile[1], st->wi, st->wj, st->virt, nt, true, 0, 0, [&](int s, int c) { for (int x = 0; x < n0; x++) if (cp->tile[0][x].x == s && cp->tile[0][x].y == c) return true; return false; });
 }
 
 // ---- affine: the fill of al64_walk_kernel, tile {s, c} completely, planes to global memory ----
 template <bool P16>
-__global__ __launch_bounds__(64) void al64_farm_fill_kernel(const PairPlan *__restrict__ plans,
-                                                            const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
-                                                            const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                                            KParams kp, const int2 *__restrict__ rowbuf, const int *__restrict__ snap,
-                                                            int *__restrict__ err, const long long *__restrict__ bases,
-                                                            const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes) {
+__device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__ plans,
+                                                    const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                    const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                    const KParams &kp, const int2 *__restrict__ rowbuf, const int *__restrict__ snap,
+                                                    int *__restrict__ err, const long long *__restrict__ bases,
+                                                    const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, const int p, const int q, const int par) {
     using Geo = FarmGeo<true>;
     constexpr int LW = P16 ? R / 2 : R;
     constexpr int BST = G64 * LW;
     constexpr int TI = 2, TD = 1;
     __shared__ int lds[32 + 5 * BST];
-    const int p = blockIdx.y, q = blockIdx.x;
     const FarmCtl *cp = ctl + p;
-    if (cp->fin || q >= cp->n) return;
-    const int s = cp->tile[q].x, c = cp->tile[q].y;
-    unsigned *dirg = planes + ((int64_t)p * FARM_MAX + q) * Geo::TILE_DW;
+    if (cp->fin || q >= cp->n[par]) return;
+    const int s = cp->tile[par][q].x, c = cp->tile[par][q].y;
+    unsigned *dirg = planes + (((int64_t)p * 2 + par) * FARM_MAX + q) * Geo::TILE_DW;
     int *hcolT = reinterpret_cast<int *>(dirg + Geo::ROWS * G64);
     const int l = threadIdx.x;
     if (l < 25) lds[l] = kp.sc4[l] - 2 * kp.e4;
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(64) void al64_farm_fill_kernel(const PairPlan *__re
     const int row0 = s * H64 + l * R;
     int rt[R], hold[R];
     unsigned acc[3 * R];
-    __syncthreads();
+    FARM_WAVE_SYNC();
     {
         int a5[R];
 #pragma unroll
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(64) void al64_farm_fill_kernel(const PairPlan *__re
 #pragma unroll
             for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
         }
-        __syncthreads();
+        FARM_WAVE_SYNC();
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -267,22 +280,21 @@ __global__ __launch_bounds__(64) void al64_farm_fill_kernel(const PairPlan *__re
 
 // ---- constant gap: the fill of cl64_walk_kernel, tile {s, c} completely, its one plane to global memory ----
 template <bool P16>
-__global__ __launch_bounds__(64) void cl64_farm_fill_kernel(const PairPlan *__restrict__ plans,
-                                                            const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
-                                                            const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
-                                                            KParams kp, const int *__restrict__ rowbuf, const int *__restrict__ snap,
-                                                            int *__restrict__ err, const long long *__restrict__ bases,
-                                                            const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes) {
+__device__ __forceinline__ void cl64_farm_fill_body(const PairPlan *__restrict__ plans,
+                                                    const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                    const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
+                                                    const KParams &kp, const int *__restrict__ rowbuf, const int *__restrict__ snap,
+                                                    int *__restrict__ err, const long long *__restrict__ bases,
+                                                    const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, const int p, const int q, const int par) {
     using Geo = FarmGeo<false>;
     constexpr int LW = P16 ? R / 2 : R;
     constexpr int BST = G64 * LW;
     constexpr int CK = CKC64;
     __shared__ int lds[32 + 5 * BST];
-    const int p = blockIdx.y, q = blockIdx.x;
     const FarmCtl *cp = ctl + p;
-    if (cp->fin || q >= cp->n) return;
-    const int s = cp->tile[q].x, c = cp->tile[q].y;
-    unsigned *dirg = planes + ((int64_t)p * FARM_MAX + q) * Geo::TILE_DW;
+    if (cp->fin || q >= cp->n[par]) return;
+    const int s = cp->tile[par][q].x, c = cp->tile[par][q].y;
+    unsigned *dirg = planes + (((int64_t)p * 2 + par) * FARM_MAX + q) * Geo::TILE_DW;
     const int l = threadIdx.x;
     if (l < 25) lds[l] = kp.sc4[l] - 2 * kp.g4 + 1; // pre-tagged diagonal candidate (tag 3), see fill_const_kernel
     int *prof = &lds[32];
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(64) void cl64_farm_fill_kernel(const PairPlan *__re
     const int row0 = s * H64 + l * R;
     int val[R];
     unsigned acc[R];
-    __syncthreads();
+    FARM_WAVE_SYNC();
     {
         int a5[R];
 #pragma unroll
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(64) void cl64_farm_fill_kernel(const PairPlan *__re
 #pragma unroll
             for (int k = 0; k < LW; k++) prof[b * BST + l * LW + k] = P16 ? ((lds[a5[2 * k] + b] & 0xffff) | (lds[a5[2 * k + 1] + b] << 16)) : lds[a5[k] + b];
         }
-        __syncthreads();
+        FARM_WAVE_SYNC();
     }
     int diag0 = 2;
 #pragma unroll
@@ -402,17 +414,18 @@ __device__ __forceinline__ int64_t farm_rfl64(int64_t v) {
 }
 
 // ---- the walk of one round: wave 0 walks (state uniform: SGPRs), all four waves copy the tile's window into LDS ----
-template <bool AFF>
-__global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restrict__ plans, TbParams tp,
-                                                        const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
-                                                        const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
-                                                        MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all,
-                                                        const unsigned *__restrict__ planes, int nt) {
+// par: the set this round walks (and, walked, replaces by a new one).  PIPE: the other set is being re-filled by this launch's other workgroups --
+// the new set continues the line behind it.
+template <bool AFF, bool PIPE>
+__device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plans, const TbParams &tp,
+                                               const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                               const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
+                                               MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all,
+                                               const unsigned *__restrict__ planes, const int nt, const int p, const int par) {
     using Geo = FarmGeo<AFF>;
     constexpr int CK = Geo::CK, NPL = Geo::NPL, ROWS = Geo::ROWS, NLC = FARM_NLC;
     __shared__ unsigned win[ROWS * NLC];
     __shared__ int xch[4];
-    const int p = blockIdx.x;
     FarmCtl *ctl = ctl_all + p;
     MegaState *mst = mst_all + p;
     const int tid = threadIdx.x, l = tid & 63;
@@ -427,10 +440,11 @@ __global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restri
     const int virt = GNX_RFL(mst->virt);
     const int64_t row_off = farm_rfl64(mst->row_off);
     const int64_t sbase = scr_off[p];
-    const int n_list = GNX_RFL(ctl->n);
+    const int n_list = GNX_RFL(ctl->n[par]);
     const int wi_in = wi, wj_in = wj;
-    int2 mytile = make_int2(-1, -1);
-    if (l < n_list) mytile = ctl->tile[l];
+    int2 mytile = make_int2(-1, -1), optile = make_int2(-1, -1); // lane l: tile l of the round's set / of the set being re-filled
+    if (l < n_list) mytile = ctl->tile[par][l];
+    if (PIPE && l < GNX_RFL(ctl->n[par ^ 1])) optile = ctl->tile[par ^ 1][l];
     auto flush_run = [&]() {
         if (cur_op >= 0) {
             if (tid == 0) {
@@ -466,10 +480,18 @@ __global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restri
         slot = xch[0]; lo = xch[1];
         const int hi = xch[2];
         if (slot < 0) break;
-        const unsigned *src = planes + ((int64_t)p * FARM_MAX + slot) * Geo::TILE_DW;
-        for (int idx = tid; idx < ROWS * NLC; idx += 256) {
-            const int row = idx / NLC, ll = idx - row * NLC;
-            win[idx] = (lo + ll <= hi) ? src[row * G64 + lo + ll] : 0u;
+        const unsigned *src = planes + (((int64_t)p * 2 + par) * FARM_MAX + slot) * Geo::TILE_DW;
+        { // (every load of the copy in flight before the first LDS store: the window costs one trip to L2, not one per element)
+            constexpr int NIT = (ROWS * NLC + 255) / 256;
+            unsigned tmp[NIT];
+#pragma unroll
+            for (int u = 0; u < NIT; u++) {
+                const int idx = tid + u * 256;
+                const int row = idx / NLC, ll = idx - row * NLC;
+                tmp[u] = (idx < ROWS * NLC && lo + ll <= hi) ? src[row * G64 + lo + ll] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < NIT; u++) { const int idx = tid + u * 256; if (idx < ROWS * NLC) win[idx] = tmp[u]; }
         }
         __syncthreads();
         if (w0) {
@@ -481,26 +503,31 @@ __global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restri
                 if (pend) { k = 3 - (GNX_RFL(hcX[i - 1 - s * H64]) & 3); pend = 0; }
                 while (true) {
                     if (i == 0 || j == 0) { wdone = 1; break; }
-                    const int i0 = i - 1 - s * H64;
+                    int i0 = i - 1 - s * H64;
                     if (i0 < 0) break; // left the strip through its top edge
-                    const int l2 = i0 / R, r2 = i0 - l2 * R;
+                    int l2 = i0 / R, r2 = i0 - l2 * R;
                     if (l2 < lo) break; // above the window: the next copy follows
-                    const int t1 = j + l2 - 1 - tbX;
+                    int t1 = j + l2 - 1 - tbX;
                     if (t1 < tmX) break; // left the (usable part of the) tile through its skewed left edge
-                    if (k == 0) { // state M: the leading run of cells (i - x, j - x) whose M field says "from M" -- one step (no checkerboard edge inside: x < li)
-                        const int ix = i0 - l;
-                        const int ixc = max(ix, 0);
+                    unsigned w;
+                    if (k == 0) { // state M: all 64 lanes read the M fields of the cells (i - x, j - x); the leading run that says "from M" is one step
+                        const int ix = i0 - l;                                  // (no checkerboard edge inside it: x < li); the word of the cell the run
+                        const int ixc = max(ix, 0);                             // ends at serves the scalar step that follows
                         const int l2x = ixc / R, r2x = ixc - l2x * R;
                         const int t1x = (j - l) + l2x - 1 - tbX;
-                        const bool in = ix >= 0 && j - l >= 1 && (int64_t)l < li && t1x >= tmX && l2x >= lo;
+                        const bool in = ix >= 0 && j - l >= 1 && t1x >= tmX && l2x >= lo;
                         const unsigned wv = in ? win[(((t1x >> 4) * 3 + 0) * R + r2x) * NLC + (l2x - lo)] : 0u;
-                        const bool ok = in && ((wv >> (2 * (t1x & 15))) & 3u) == 3u;
+                        const bool ok = in && (int64_t)l < li && ((wv >> (2 * (t1x & 15))) & 3u) == 3u;
                         const unsigned long long nbal = ~__ballot(ok);
                         const int nb = nbal ? (int)__builtin_ctzll(nbal) : 64;
-                        if (nb > 0) { emit(0, nb); last_op = 0; li -= nb; i -= nb; j -= nb; continue; }
-                    }
+                        if (nb > 0) {
+                            emit(0, nb); last_op = 0; li -= nb; i -= nb; j -= nb;
+                            if (nb == 64 || !((__ballot(in) >> nb) & 1ull)) continue;
+                            i0 = i - 1 - s * H64; l2 = i0 / R; r2 = i0 - l2 * R; t1 = j + l2 - 1 - tbX;
+                        }
+                        w = (unsigned)__builtin_amdgcn_readlane((int)wv, nb);
+                    } else w = (unsigned)GNX_RFL((int)win[(((t1 >> 4) * 3 + k) * R + r2) * NLC + (l2 - lo)]);
                     const int pos = t1 & 15;
-                    const unsigned w = (unsigned)GNX_RFL((int)win[(((t1 >> 4) * 3 + k) * R + r2) * NLC + (l2 - lo)]);
                     int tag = (int)((w >> (2 * pos)) & 3u);
                     if (tag == 0) { if (tid == 0) atomicOr(err, 2); wdone = 1; break; }
                     if (k == 1) { // horizontal run inside this word, see traceback_kernel
@@ -541,13 +568,14 @@ __global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restri
             } else {
                 while (true) {
                     if (i == 0 || j == 0) { wdone = 1; break; }
-                    const int i0 = i - 1 - s * H64;
+                    int i0 = i - 1 - s * H64;
                     if (i0 < 0) break; // left the strip through its top edge
-                    const int l2 = i0 / R, r2 = i0 - l2 * R;
+                    int l2 = i0 / R, r2 = i0 - l2 * R;
                     if (l2 < lo) break; // above the window
-                    const int t1 = j + l2 - 1 - tbX;
+                    int t1 = j + l2 - 1 - tbX;
                     if (t1 < 0) break; // left the tile through its (skewed) left edge
-                    { // the leading run of diagonal fields along (i - x, j - x), one step
+                    unsigned w;
+                    { // all 64 lanes read the fields of the cells (i - x, j - x): the leading run of diagonal fields is one step, the word of the cell it ends at serves the scalar step
                         const int ix = i0 - l;
                         const int ixc = max(ix, 0);
                         const int l2x = ixc / R, r2x = ixc - l2x * R;
@@ -557,10 +585,14 @@ __global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restri
                         const bool ok = in && ((wv >> (2 * (t1x & 15))) & 3u) == 3u;
                         const unsigned long long nbal = ~__ballot(ok);
                         const int nb = nbal ? (int)__builtin_ctzll(nbal) : 64;
-                        if (nb > 0) { emit(0, nb); last_op = 0; i -= nb; j -= nb; continue; }
+                        if (nb > 0) {
+                            emit(0, nb); last_op = 0; i -= nb; j -= nb;
+                            if (nb == 64 || !((__ballot(in) >> nb) & 1ull)) continue;
+                            i0 = i - 1 - s * H64; l2 = i0 / R; r2 = i0 - l2 * R; t1 = j + l2 - 1 - tbX;
+                        }
+                        w = (unsigned)__builtin_amdgcn_readlane((int)wv, nb);
                     }
                     const int pos = t1 & 15;
-                    const unsigned w = (unsigned)GNX_RFL((int)win[((t1 >> 4) * R + r2) * NLC + (l2 - lo)]);
                     const int tag = (int)((w >> (2 * pos)) & 3u);
                     if (tag == 0) { if (tid == 0) atomicOr(err, 2); wdone = 1; break; }
                     const int op = 3 - tag;
@@ -595,7 +627,7 @@ __global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restri
         ctl->rounds += 1; ctl->hits += hits;
     }
     if (wdone || pexit) {
-        if (tid == 0) { mst->done = pexit ? 0 : 1; ctl->fin = 1; ctl->n = 0; }
+        if (tid == 0) { mst->done = pexit ? 0 : 1; ctl->fin = 1; ctl->n[0] = 0; ctl->n[1] = 0; }
         if (!pexit) {
             // Step 4 (affineGap.go:135-139 / constGap.go:59-63) -- quirk Q2 when the corner is not the origin
             const int64_t gi = (int64_t)wi + (wi > 0 ? row_off : 0);
@@ -608,10 +640,60 @@ __global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restri
         }
     } else {
         const int da = GNX_RFL(ctl->acc_i) / 2 + (wi_in - wi), db = GNX_RFL(ctl->acc_j) / 2 + (wj_in - wj);
-        const int n = farm_predict<AFF>(ctl->tile, wi, wj, virt, nt, tid == 0, da, db);
-        if (tid == 0) { ctl->n = n; ctl->acc_i = da; ctl->acc_j = db; }
+        const int n = farm_predict<AFF>(ctl->tile[par], wi, wj, virt, nt, tid == 0, da, db,
+                                        [&](int s, int c) { return PIPE && __ballot(optile.x == s && optile.y == c) != 0ull; });
+        if (tid == 0) { ctl->n[par] = n; ctl->acc_i = da; ctl->acc_j = db; }
     }
 #undef GNX_RFL
+}
+
+// plain rounds: launch {fill set 0, walk set 0} a round
+template <bool P16>
+__global__ __launch_bounds__(64) void al64_farm_fill_kernel(const PairPlan *__restrict__ plans, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                            const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp,
+                                                            const int2 *__restrict__ rowbuf, const int *__restrict__ snap, int *__restrict__ err,
+                                                            const long long *__restrict__ bases, const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, int par) {
+    al64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl, planes, blockIdx.y, blockIdx.x, par);
+}
+template <bool P16>
+__global__ __launch_bounds__(64) void cl64_farm_fill_kernel(const PairPlan *__restrict__ plans, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                            const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp,
+                                                            const int *__restrict__ rowbuf, const int *__restrict__ snap, int *__restrict__ err,
+                                                            const long long *__restrict__ bases, const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, int par) {
+    cl64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl, planes, blockIdx.y, blockIdx.x, par);
+}
+template <bool AFF>
+__global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restrict__ plans, TbParams tp,
+                                                        const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
+                                                        const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
+                                                        MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all,
+                                                        const unsigned *__restrict__ planes, int nt) {
+    farm_walk_body<AFF, false>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, blockIdx.x, 0);
+}
+
+// overlapped rounds: ONE launch a round -- workgroup 0 of a pair walks set `par` (re-filled by the launch before), workgroups 1 .. nt re-fill
+// the other set (asked for by the walk of the launch before) meanwhile, on their own CUs; the walk then asks for the set after that one.
+// The walk's own tile is in one of the two sets at the latest two rounds after a wrong guess (the first tile of a line that starts at the
+// walk's cell is either being re-filled or asked for), so the rounds still move.
+template <bool P16>
+__global__ __launch_bounds__(256) void al64_farm_round_kernel(const PairPlan *__restrict__ plans, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                              const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp, TbParams tp,
+                                                              const int2 *__restrict__ rowbuf, const int *__restrict__ snap, const int64_t *__restrict__ hfin,
+                                                              int64_t *__restrict__ score_out, int64_t *__restrict__ nops, const int64_t *__restrict__ scr_off,
+                                                              gnx_cigar *__restrict__ scr, int *__restrict__ err, const long long *__restrict__ bases,
+                                                              MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all, unsigned *__restrict__ planes, int nt, int par) {
+    if (blockIdx.x == 0) farm_walk_body<true, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, blockIdx.y, par);
+    else if (threadIdx.x < 64) al64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl_all, planes, blockIdx.y, (int)blockIdx.x - 1, par ^ 1);
+}
+template <bool P16>
+__global__ __launch_bounds__(256) void cl64_farm_round_kernel(const PairPlan *__restrict__ plans, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
+                                                              const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp, TbParams tp,
+                                                              const int *__restrict__ rowbuf, const int *__restrict__ snap, const int64_t *__restrict__ hfin,
+                                                              int64_t *__restrict__ score_out, int64_t *__restrict__ nops, const int64_t *__restrict__ scr_off,
+                                                              gnx_cigar *__restrict__ scr, int *__restrict__ err, const long long *__restrict__ bases,
+                                                              MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all, unsigned *__restrict__ planes, int nt, int par) {
+    if (blockIdx.x == 0) farm_walk_body<false, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, blockIdx.y, par);
+    else if (threadIdx.x < 64) cl64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl_all, planes, blockIdx.y, (int)blockIdx.x - 1, par ^ 1);
 }
 
 } // namespace

@@ -610,28 +610,45 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
                   gnx_cigar *d_scr, int *d_err, const long long *dbs, MegaState *d_st, int64_t path_cells, hipStream_t stream) {
     int rc;
     const size_t tile_dw = affine ? (size_t)FarmGeo<true>::TILE_DW : (size_t)FarmGeo<false>::TILE_DW;
-    const size_t planes_bytes = (size_t)np * FARM_MAX * tile_dw * 4;
+    const size_t planes_bytes = (size_t)np * 2 * FARM_MAX * tile_dw * 4;
     if ((rc = c.farm.ensure(planes_bytes + (size_t)np * sizeof(FarmCtl)))) return rc;
     unsigned *d_planes = reinterpret_cast<unsigned *>(c.farm.p);
     FarmCtl *d_ctl = reinterpret_cast<FarmCtl *>(reinterpret_cast<char *>(c.farm.p) + planes_bytes);
+    const bool pipe = !(getenv("GNX_W64_FARM_PIPE") && getenv("GNX_W64_FARM_PIPE")[0] == '0'); // overlapped rounds (one launch each); 0: {fill, walk} launches
     if (affine) hipLaunchKernelGGL(farm_init_kernel<true>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt);
     else hipLaunchKernelGGL(farm_init_kernel<false>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt);
-    const dim3 gf((unsigned)nt, (unsigned)np), gw((unsigned)np);
+    const dim3 gf((unsigned)nt, (unsigned)np), gw((unsigned)np), gr((unsigned)nt + 1, (unsigned)np);
+    const int2 *drb2 = reinterpret_cast<const int2 *>(drb);
+    const int *drb1 = reinterpret_cast<const int *>(drb);
+    auto launch_fill = [&](int par) {
+        if (affine) {
+            if (p16) hipLaunchKernelGGL((al64_farm_fill_kernel<true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes, par);
+            else hipLaunchKernelGGL((al64_farm_fill_kernel<false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes, par);
+        } else {
+            if (p16) hipLaunchKernelGGL((cl64_farm_fill_kernel<true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes, par);
+            else hipLaunchKernelGGL((cl64_farm_fill_kernel<false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes, par);
+        }
+    };
+    auto launch_round = [&](int par) {
+        if (affine) {
+            if (p16) hipLaunchKernelGGL((al64_farm_round_kernel<true>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb2, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
+            else hipLaunchKernelGGL((al64_farm_round_kernel<false>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb2, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
+        } else {
+            if (p16) hipLaunchKernelGGL((cl64_farm_round_kernel<true>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb1, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
+            else hipLaunchKernelGGL((cl64_farm_round_kernel<false>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb1, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
+        }
+    };
     int64_t batch = path_cells / ((int64_t)100 * nt) + 8; // (~116 cells of path per tile; a round that finds the walk over costs a few us)
     std::vector<FarmCtl> h_ctl((size_t)np);
     int64_t rounds = 0;
+    if (pipe) launch_fill(0);
     while (true) {
         for (int64_t r = 0; r < batch; r++) {
-            if (affine) {
-                const int2 *drb2 = reinterpret_cast<const int2 *>(drb);
-                if (p16) hipLaunchKernelGGL((al64_farm_fill_kernel<true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes);
-                else hipLaunchKernelGGL((al64_farm_fill_kernel<false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes);
-                hipLaunchKernelGGL(farm_walk_kernel<true>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt);
-            } else {
-                const int *drb1 = reinterpret_cast<const int *>(drb);
-                if (p16) hipLaunchKernelGGL((cl64_farm_fill_kernel<true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes);
-                else hipLaunchKernelGGL((cl64_farm_fill_kernel<false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes);
-                hipLaunchKernelGGL(farm_walk_kernel<false>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt);
+            if (pipe) launch_round((int)((rounds + r) & 1));
+            else {
+                launch_fill(0);
+                if (affine) hipLaunchKernelGGL(farm_walk_kernel<true>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt);
+                else hipLaunchKernelGGL(farm_walk_kernel<false>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt);
             }
         }
         rounds += batch;
@@ -641,10 +658,10 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
         bool all = true;
         for (int p = 0; p < np; p++) all = all && h_ctl[(size_t)p].fin;
         if (all) break;
-        if (rounds > path_cells + 64) { set_err("internal: the walk farm does not end%s", ""); return GNX_ETRACE; }
+        if (rounds > 3 * path_cells + 64) { set_err("internal: the walk farm does not end%s", ""); return GNX_ETRACE; }
         batch = 16;
     }
-    if (getenv("GNX_DEBUG")) for (int p = 0; p < np; p++) fprintf(stderr, "[gnx] walk farm: pair %d, %d tiles per round, %d rounds walked %d tiles (%lld launched)\n", p, nt, h_ctl[(size_t)p].rounds, h_ctl[(size_t)p].hits, (long long)rounds);
+    if (getenv("GNX_DEBUG")) for (int p = 0; p < np; p++) fprintf(stderr, "[gnx] walk farm%s: pair %d, %d tiles per round, %d rounds walked %d tiles (%lld launched)\n", pipe ? " (overlapped)" : "", p, nt, h_ctl[(size_t)p].rounds, h_ctl[(size_t)p].hits, (long long)rounds);
     return GNX_OK;
 }
 
