@@ -1610,9 +1610,13 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const bool rebase = spread_ok && (oor || (rbe && rbe[0] == '1')); // GNX_REBASE=1 (tests): every pair of this path on moving bases
         if (oor && !spread_ok) use = false;
         // the whole wave on one pair (affine_long64.hip.h, const_long64.hip.h): launches of up to three pairs, which would leave lane groups of the 16-lane
-        // kernels' waves idle; GNX_W64 = 0 / 2: never / for every launch of this path
+        // kernels' waves idle -- and, since the walk farm (farm64.hip.h), launches of up to 64 pairs of at least two 640-row strips each: the sweeps
+        // are level, the walk of a pair is rounds on 17 workgroups instead of one wave (16 x AffineGap 200 kb x 200 kb: 0.69 -> 0.15 s; ConstGap
+        // 64 x (20 kb x 100 kb) 55 -> 49 ms, 128 pairs still 76 -> 70; tools/few_long_pairs.py).  GNX_W64 = 0 / 2: never / for every launch of this path
         const char *w64e = getenv("GNX_W64");
-        const bool w64 = !no_pipe() && (int64_t)(H64 + G64 + CKC64 + 64) * step4 < ((int64_t)1 << 28) && !(w64e && w64e[0] == '0') && (n_pairs <= 3 || (w64e && w64e[0] == '2'));
+        bool few_long = n_pairs <= 64 && w64_farm_tiles() > 0;
+        for (int64_t p = 0; few_long && p < n_pairs; p++) if (h_alen[p] < 2 * H64) few_long = false;
+        const bool w64 = !no_pipe() && (int64_t)(H64 + G64 + CKC64 + 64) * step4 < ((int64_t)1 << 28) && !(w64e && w64e[0] == '0') && (n_pairs <= 3 || few_long || (w64e && w64e[0] == '2'));
         long double cells_ld = 0, dir_bytes = 0, rows_ld = 0, cols_ld = 0;
         for (int64_t p = 0; use && p < n_pairs; p++) {
             if (h_alen[p] < 1 || h_blen[p] < 1) use = false;

@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 MX = common.matrices()
 
 
+@pytest.fixture(autouse=True)
+def _sixteen_lane_kernels(monkeypatch):
+    """this suite is the 16-lane snapshot kernels' (cl_sweep_wg_kernel / cl_sweep_kernel / cl_walk_*): launches of up to 64 long pairs would go to the 64-lane
+    kernels + walk farm (tests/test_long_range.py has their suites) unless GNX_W64 says otherwise -- tools/switch_matrix.sh runs this file under GNX_W64=2 too"""
+    if "GNX_W64" not in os.environ:
+        monkeypatch.setenv("GNX_W64", "0")
+
+
 def _ragged(seed, count, nmax, mmax):
     rng = np.random.default_rng(seed)
     alphas, betas = [], []

@@ -53,6 +53,7 @@ def test_rebase_forced(gpu_lib, monkeypatch, mode, cs):
     batches of one to several strips, small checkerboards (quirks Q1 / Q2) -- bit-exact against the oracle"""
     monkeypatch.setenv("GNX_CLONG", "2")
     monkeypatch.setenv("GNX_REBASE", "1")
+    monkeypatch.setenv("GNX_W64", "0")  # (the 16-lane REBASE kernels; the 64-lane ones: test_w64_*)
     affine = mode in (0, 2)
     for seed, nmax, mmax, count in ((21, 60, 400, 64), (22, 700, 1500, 40), (23, 400, 2600, 24)):
         alphas, betas = _ragged(seed + 100 * cs, count, nmax, mmax)
@@ -72,6 +73,7 @@ def test_rebase_forced_long_strips(gpu_lib, monkeypatch, piped):
     """the same with pairs of many strips and many blocks (piped: the strips of a pair as separate workgroups, bases handed over through memory)"""
     monkeypatch.setenv("GNX_CLONG", "2")
     monkeypatch.setenv("GNX_REBASE", "1")
+    monkeypatch.setenv("GNX_W64", "0")  # (the 16-lane REBASE kernels; the 64-lane ones: test_w64_*)
     if piped == "0":
         monkeypatch.setenv("GNX_NO_PIPE", "1")
     rng = np.random.default_rng(5)
@@ -231,13 +233,15 @@ def test_w64_forced(gpu_lib, monkeypatch, mode, cs, walk):
 
 @pytest.mark.parametrize("mode", [0, 1])
 def test_w64_is_the_route_of_few_pairs(gpu_lib, monkeypatch, mode):
-    """the shipped rule: launches of up to three pairs of the snapshot path run in the 64-lane geometry (route 6), four pairs fill the
-    lane groups of al_sweep_kernel's waves (route 2); related pairs of many strips and columns, a scaled matrix that leaves int16 (P16 off)"""
+    """the shipped rule: launches of up to three pairs of the snapshot path, and of up to 64 pairs of two or more 640-row strips each, run in the
+    64-lane geometry with the walk farm (route 6); a batch of more than three with a shorter pair in it fills the lane groups of al_sweep_kernel's
+    waves (route 2); related pairs of many strips and columns, a scaled matrix that leaves int16 (P16 off)"""
     monkeypatch.setenv("GNX_CLONG", "2")
     monkeypatch.delenv("GNX_W64", raising=False)
+    monkeypatch.delenv("GNX_W64_FARM", raising=False)
     rng = np.random.default_rng(77)
-    pairs = [_related(rng, n, extra, sub=0.05, indel=0.03) for n, extra in ((6000, 0), (2500, 5000), (1300, 100), (4000, 300))]
-    for npairs, route in ((1, 6), (3, 6), (4, 2)):
+    pairs = [_related(rng, n, extra, sub=0.05, indel=0.03) for n, extra in ((6000, 0), (2500, 5000), (1300, 100), (4000, 300), (700, 900))]
+    for npairs, route in ((1, 6), (3, 6), (4, 6), (5, 2)):
         alphas, betas = [x[0] for x in pairs[:npairs]], [x[1] for x in pairs[:npairs]]
         x25 = [[25 * int(v) for v in row] for row in MX["HumanChimpTwo"]]
         for sc, go, ge in ((MX["HumanChimpTwo"], -600, -150), (x25, -15000, -3750)) if mode == 0 else ((MX["HumanChimpTwo"], -430, 0), (x25, -10750, 0)):

@@ -44,9 +44,9 @@ def _pairs(seed, n_pairs, n_lo, n_hi, m_lo, m_hi):
 LEGS = [
     ("fill_affine_kernel<MULTI> piped strips", {"GNX_FASTPATH": "0", "GNX_LAT": "0"}, 0, "HumanChimpTwo", (-600, -150), (101, 6, 900, 1400, 2200, 2600)),
     ("fill_const_kernel<MULTI> piped strips", {"GNX_CLONG": "0", "GNX_LAT": "0"}, 1, "Default", (-430, 0), (102, 6, 900, 1400, 2200, 2600)),
-    ("cl_sweep_wg_kernel piped items of 5 strips", {"GNX_CLONG": "2"}, 1, "HumanChimpTwo", (-430, 0), (103, 6, 1700, 2500, 2200, 2600)),
-    ("cl_sweep_kernel piped strips", {"GNX_CLONG": "2", "GNX_CL_WG": "0"}, 1, "HumanChimpTwo", (-430, 0), (103, 6, 900, 1400, 2200, 2600)),
-    ("al_sweep_kernel piped strips", {"GNX_CLONG": "2", "GNX_FASTPATH": "0"}, 0, "HumanChimpTwo", (-600, -150), (104, 6, 900, 1400, 2200, 2600)),
+    ("cl_sweep_wg_kernel piped items of 5 strips", {"GNX_CLONG": "2", "GNX_W64": "0"}, 1, "HumanChimpTwo", (-430, 0), (103, 6, 1700, 2500, 2200, 2600)),
+    ("cl_sweep_kernel piped strips", {"GNX_CLONG": "2", "GNX_CL_WG": "0", "GNX_W64": "0"}, 1, "HumanChimpTwo", (-430, 0), (103, 6, 900, 1400, 2200, 2600)),
+    ("al_sweep_kernel piped strips", {"GNX_CLONG": "2", "GNX_FASTPATH": "0", "GNX_W64": "0"}, 0, "HumanChimpTwo", (-600, -150), (104, 6, 900, 1400, 2200, 2600)),
     ("fp_sweep_levels_kernel (row blocks)", {"GNX_FASTPATH": "2"}, 0, "HumanChimpTwo", (-600, -150), (105, 96, 500, 800, 1500, 1800)),
     # round 5: the latency geometry's strips (one wave per strip, rows handed over through sentinel-marked memory) and its int64 form
     ("lat_fill_kernel<affine> piped strips", {"GNX_LAT": "2"}, 0, "HumanChimpTwo", (-600, -150), (106, 6, 900, 1400, 2200, 2600)),
