@@ -7,20 +7,27 @@
 namespace {
 // ------------------------------------------------------------------------------------------------------
 // al64_walk_kernel / cl64_walk_kernel alternate, on one wave (two with the speculative left tile), "re-fill the tile the walk is in" (640 rows x
-// <= 132 steps of the recording recurrence: ~60 us of a lone wave) and "walk ~116 cells": 0.54 s per 1e6 cells of path, 60 % of a 1 Mb x 1 Mb
+// <= 132 steps of the recording recurrence: ~50 us of a lone wave) and "walk ~116 cells": 0.54 s per 1e6 cells of path, 60 % of a 1 Mb x 1 Mb
 // call (align/affineGap.go:59-68 is what cmd/cigarToBed/cigarToBed.go:86 calls; one pair, nothing else on the device).  But a re-fill does not
-// depend on the path at all -- snapshot + boundary row in, direction planes out -- only WHICH tiles are needed does, and a global alignment
-// of related sequences runs along a diagonal.  So a round is two launches on the call's stream, no host round trip:
-//   *_farm_fill_kernel   grid = (tiles, pairs): workgroup q re-fills tile ctl.tile[q] = {strip, block} completely (every step of the block,
-//                        all three planes) into planes[q] in global memory (69 KB, L2-resident) -- the fill code of al64_walk_kernel.
-//   farm_walk_kernel     one workgroup per pair: while the tile of the walk's cell is one of the round's, copy the <= 24 lanes of it above the
-//                        cell into LDS (4 waves), walk it on wave 0 with the walk state in SGPRs (quirks Q1 / Q2, MegaState for row panels:
-//                        the code of al64_walk_kernel); in state M all 64 lanes look at the next 64 cells of the diagonal at once and the
-//                        walk takes the leading run of "from M" fields in one step.  Then it leaves the next round's tiles in ctl: the
-//                        tiles of the straight diagonal through the cell it stopped at.  A tile that was not predicted ends the round; the
-//                        first tile of a round is always the walk's own, so every round moves.
-// The planes are the ones a round of al64_walk_kernel computes (same snapshot, same recurrence, the steps beyond the walk's are never read), the
-// walk is the same automaton: results identical.  GNX_W64_FARM=0: off; =k: k tiles per round (default 16, at most 32).
+// depend on the path at all -- snapshot + boundary row in, direction planes out -- only WHICH tiles are needed does, and at the scale of a tile
+// a global alignment is a line.  So the walk becomes ROUNDS on the call's stream, no host round trip inside a batch of them:
+//   *_farm_fill_body     one wave re-fills tile {strip, block} of the round's set completely (every step of the block, all planes) into
+//                        planes[set][q] in global memory (69 KB, L2-resident) -- the fill code of al64_walk_kernel / cl64_walk_kernel.
+//   farm_walk_body       one workgroup per pair: while the tile of the walk's cell is one of the set, copy the <= 24 lanes of it above the cell
+//                        into LDS (4 waves, every load in flight at once), walk it on wave 0 with the walk state in SGPRs (quirks Q1 / Q2,
+//                        MegaState for row panels: the automaton of al64_walk_kernel); all 64 lanes read the fields of the next 64 cells of the
+//                        diagonal at once, the walk takes the leading run of "from the diagonal" fields in one step and the word of the cell the
+//                        run ends at serves the scalar step that follows.  Then it asks for the next set: the tiles of the straight line through
+//                        the cell it stopped at whose direction is what the walk did lately (farm_predict).
+//   overlapped rounds    (default) ONE launch a round, *_farm_round_kernel: workgroup 0 walks set `par` while workgroups 1 .. k re-fill the other
+//                        set on their own CUs; the set the walk asks for continues the line behind the set being re-filled.
+//   plain rounds         (GNX_W64_FARM_PIPE=0) two launches a round: re-fill set 0, walk set 0.
+// A tile that was not asked for ends the walk's round; the walk's own tile is the first of the next set (overlapped: of one of the next two),
+// so the rounds always move, and a wrong guess costs the rest of one round -- never a result: the planes are the ones a round of al64_walk_kernel
+// computes (same snapshot, same recurrence; the steps beyond the walk's are never read), the walk is the same automaton.
+// GNX_W64_FARM=0: off (the one-workgroup walks); =k: k tiles per round (default 16, at most 32).
+// Measured (profiles/r5_long_pairs.jsonl, r5_experiments.md section 10): AffineGap 1 Mb x 1 Mb walk 538 -> 37 ms (call 0.86 -> 0.35 s), 340 kb x 340 kb
+// 0.30 -> 0.089 s, ConstGap 150 kb x 180 kb 0.092 -> 0.036 s, 300 kb x 2 Mb (450 000 runs: the scalar steps of the walk) 0.57 -> 0.43 s.
 // ------------------------------------------------------------------------------------------------------
 // the fill of a tile is ONE wave: its LDS traffic is ordered by a fence, not a workgroup barrier (the overlapped rounds run it inside 256-thread workgroups)
 #define FARM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)

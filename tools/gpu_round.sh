@@ -56,10 +56,17 @@ timeout 600 python tools/lat_crossover.py affine > $out/lat_crossover.jsonl 2>> 
 timeout 600 python tools/lat_crossover.py const >> $out/lat_crossover.jsonl 2>> $out/bench.err
 timeout 600 python tools/bench_n1_cmd.py 8 30000 3 > $out/n1_cmd.json 2>> $out/bench.err
 timeout 900 python tools/bench_gsw_genome.py 100000000 300000 2>> $out/bench.err | grep "^{" > $out/gsw_genome.jsonl
-timeout 1500 python tools/bench_gsw_genome.py 3000000000 200000 2>> $out/bench.err | grep "^{" >> $out/gsw_genome.jsonl
+[ -z "$GNX_SKIP_GENOME" ] && timeout 1500 python tools/bench_gsw_genome.py 3000000000 200000 2>> $out/bench.err | grep "^{" >> $out/gsw_genome.jsonl
+# a handful of long pairs per batch call: the 16-lane snapshot kernels against the 64-lane kernels + walk farm (the shipped rule: up to 64 pairs)
+(timeout 300 python tools/few_long_pairs.py affine 200000 2 4 16; timeout 300 python tools/few_long_pairs.py const 120000 4 32; FLP_EXTRA=80000 timeout 300 python tools/few_long_pairs.py const 20000 16 64 128) > $out/few_long_pairs.jsonl 2>> $out/bench.err
+# the walk farm's switches on the long pairs (tiles per round, plain rounds, the one-workgroup walks)
+for sw in "GNX_W64_FARM=8" "GNX_W64_FARM=32" "GNX_W64_FARM_PIPE=0" "GNX_W64_FARM=0" "GNX_W64_FARM=0 GNX_W64_SPEC=0"; do
+  env $sw timeout 300 python tools/long_pairs.py gpu const_150k affine_340k affine_1M const_300k_2M 2>> $out/bench.err | sed "s/^{/{\"switch\": \"$sw\", /" >> $out/long_pairs_farm_ab.jsonl
+done
 timeout 600 python tools/gsw_threads.py 2>> $out/bench.err | grep "^{" > $out/gsw_threads.jsonl
 tools/wg_occupancy.bin > $out/wg_occupancy.txt 2>> $out/bench.err
 timeout 700 python tools/stress.py ${GNX_STRESS_S:-420} 77 > $out/stress.log 2>&1
-[ -n "$GNX_SWITCH_MATRIX" ] && bash tools/switch_matrix.sh > $out/switch_matrix.log 2>&1
+[ "$GNX_SWITCH_MATRIX" = "1" ] && bash tools/switch_matrix.sh > $out/switch_matrix.log 2>&1
+[ "$GNX_SWITCH_MATRIX" = "farm" ] && bash tools/switch_matrix.sh farm > $out/switch_matrix_farm.log 2>&1
 find $out -name '*.db' -size +20M -delete
 tail -3 $out/pytest_gpu.log; tail -1 $out/smoke.log; cat $out/bench.json | cut -c1-400; cat $out/bench_long.json | cut -c1-400
