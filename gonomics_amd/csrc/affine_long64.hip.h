@@ -12,8 +12,9 @@ namespace {
 // DPP moves (lat_fill.hip.h), everything else is affine_long's scheme on moving bases (REBASE, const_long.hip.h):
 //   al64_sweep_kernel  score only (add, max3, add, max, max per cell; a lane's last row keeps its tags), strips piped through the row buffer
 //                      with progress words and claims, the bottom row {dn, h} of every strip (8 B per column and 640 rows), a snapshot of
-//                      the wavefront every CK64 = 128 steps (24 dwords per lane), bases[strip][block].  A column of the bottom row is written
-//                      by lane 63 at step c + 63: its block is (c + 62) / CK64.
+//                      the wavefront every K steps (24 dwords per lane; K = KParams::ckc: CK64 = 128 for the walk kernels below, up to 512 when the walk
+//                      farm of farm64.hip.h re-fills the tiles), bases[strip][block].  A column of the bottom row is written by lane 63 at step c + 63:
+//                      its block is (c + 62) / K.
 //   al64_walk_kernel   one wave per pair: re-fill the tile (strip, <= CK64 + 4 steps) with the recording recurrence into three 2-bit planes
 //                      in LDS (69 KB: one workgroup per CU may declare up to 160 KB), walk inside it (quirks Q1 / Q2, run merging, MegaState for row panels: affine_long's code with 64 lanes).
 // Always on moving bases (the pairs that come here are long).  Chosen by the host for launches of few pairs (GNX_W64=0 / 2: never / always).
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
     const int m = pl.m;
     const int Tend = (m + (G64 - 1) + 15) & ~15;
     const int OE4 = kp.oe4, E4 = kp.e4, RB = kp.e4;
+    const int CKR = kp.ckc, cksh = 31 - __clz(kp.ckc); // snapshot (and rebase) spacing of this call: CK64, or a wider power of two for the walk farm (farm64.hip.h)
     int vO4;
     asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
     int bad = 0;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
         int qdn = 0, qh = 0, qb = 0, ndn = 0, nh = 0, nb = 0;
         // moving bases (REBASE, const_long.hip.h): mine; the strip above's for the two blocks the columns being loaded were written in
         long long Bown = 0;
-        int dlo = 0, dhi = 0, qp = 0, edge = CK64, r0i = kp.o4 + TI;
+        int dlo = 0, dhi = 0, qp = 0, edge = CKR, r0i = kp.o4 + TI;
         bool dhi_ok = false;
         long long *my_bases = bases + pl.rowi_off + (int64_t)s * pl.s_pitch;
         auto bprod = [&](int q) -> long long { return s == 0 ? 0LL : rbase_load(my_bases - pl.s_pitch + q, true); };
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
-            if (t0 > 0 && t0 % CK64 == 0) { // move the base, then the snapshot
+            if (t0 > 0 && (t0 & (CKR - 1)) == 0) { // move the base, then the snapshot
                 const int rep = __builtin_amdgcn_readfirstlane(hold[0]);
                 const bool rb_on = t0 <= m + (G64 - 1); // (while some lane still has columns)
                 const int d = rb_on ? (rep & ~3) : 0;
@@ -192,9 +194,9 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
                 diag0 -= d; dn_out -= d; h_out -= d; qdn -= d; qh -= d;
                 Bown += d; dlo -= d; dhi -= d;
                 r0i = rbase_const((long long)kp.o4 + TI, Bown);
-                if (rb_on && l == 0) rbase_store(my_bases + t0 / CK64, Bown, true);
+                if (rb_on && l == 0) rbase_store(my_bases + (t0 >> cksh), Bown, true);
                 if (rb_on && snap != nullptr) { // snapshot: the state the wave resumes from at step t0
-                    uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / CK64 - 1) * pl.strips + s) * G64 + l) * AL_SNAPW);
+                    uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)((t0 >> cksh) - 1) * pl.strips + s) * G64 + l) * AL_SNAPW);
                     dst[0] = make_uint4((unsigned)rt[0], (unsigned)rt[1], (unsigned)rt[2], (unsigned)rt[3]);
                     dst[1] = make_uint4((unsigned)rt[4], (unsigned)rt[5], (unsigned)rt[6], (unsigned)rt[7]);
                     dst[2] = make_uint4((unsigned)rt[8], (unsigned)rt[9], (unsigned)hold[0], (unsigned)hold[1]);
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
             }
             wait_rows(min(t0 + 2 * 16, m));
             if (s > 0) { // the columns loaded now are t0 + 17 .. t0 + 32: written by the strip above in its blocks (c + XB64) / CK64
-                while (t0 + 17 + XB64 >= edge) { qp++; edge += CK64; dlo = dhi_ok ? dhi : rbase_delta(bprod(qp), Bown); dhi_ok = false; }
+                while (t0 + 17 + XB64 >= edge) { qp++; edge += CKR; dlo = dhi_ok ? dhi : rbase_delta(bprod(qp), Bown); dhi_ok = false; }
                 if (!dhi_ok && t0 + 32 + XB64 >= edge) { dhi = rbase_delta(bprod(qp + 1), Bown); dhi_ok = true; }
             }
             boundary(t0 + 16 + l + 1, ndn, nh, nb);

@@ -25,15 +25,18 @@ namespace {
 // A tile that was not asked for ends the walk's round; the walk's own tile is the first of the next set (overlapped: of one of the next two),
 // so the rounds always move, and a wrong guess costs the rest of one round -- never a result: the planes are the ones a round of al64_walk_kernel
 // computes (same snapshot, same recurrence; the steps beyond the walk's are never read), the walk is the same automaton.
-// GNX_W64_FARM=0: off (the one-workgroup walks); =k: k tiles per round (default 16, at most 32).
-// Measured (profiles/r5_long_pairs.jsonl, r5_experiments.md section 10): AffineGap 1 Mb x 1 Mb walk 538 -> 37 ms (call 0.86 -> 0.35 s), 340 kb x 340 kb
-// 0.30 -> 0.089 s, ConstGap 150 kb x 180 kb 0.092 -> 0.036 s, 300 kb x 2 Mb (450 000 runs: the scalar steps of the walk) 0.57 -> 0.43 s.
+// GNX_W64_FARM=0: off (the one-workgroup walks); =k: k tiles per round (default 16, at most 32).  GNX_W64_CK=128 / 256 / 512: the affine snapshot spacing (below).
+// Measured (profiles/r5_long_pairs.jsonl, r5_experiments.md section 10): AffineGap 1 Mb x 1 Mb walk 538 -> 41 ms (call 0.86 -> 0.35 s, workspace 87 -> 31 GB),
+// 340 kb x 340 kb 0.30 -> 0.089 s, 2 Mb x 2 Mb 3.5 -> 1.1 s (no row panels any more), ConstGap 150 kb x 180 kb 0.092 -> 0.036 s, 300 kb x 2 Mb (450 000 runs: the
+// scalar steps of the walk) 0.57 -> 0.43 s.
 // ------------------------------------------------------------------------------------------------------
 // the fill of a tile is ONE wave: its LDS traffic is ordered by a fence, not a workgroup barrier (the overlapped rounds run it inside 256-thread workgroups)
 #define FARM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 constexpr int FARM_MAX = 32; // tiles per round and pair, at most
-constexpr int FARM_NLC = 24; // lanes of a tile the walker holds in LDS (a diagonal leaves a tile after ~15)
+constexpr int FARM_NLC = 24; // lanes of a tile the walker holds in LDS (a diagonal leaves a 128-step tile after ~15)
+constexpr int FARM_WW = 18;  // ... and words of 16 steps (affine; a diagonal through 24 lanes crosses 240 + 24 steps = 17 words)
 
+static_assert(sizeof(gnx_cigar) == 16, "farm_walk_body stores a run as one 16-byte word");
 struct FarmCtl {
     int32_t fin, rounds, hits, pad0;
     int32_t acc_i, acc_j;      // rows / columns the walk moved lately (each round: halved, plus the round's)
@@ -41,14 +44,22 @@ struct FarmCtl {
     int2 tile[2][FARM_MAX];    // {strip, block}
 };
 
+// The affine sweep's snapshot spacing is a run-time power of two for the farm (KParams::ckc): its re-fills run beside the walk, so a tile of 512 steps costs
+// the walk nothing per cell of path -- and the snapshots of a pair shrink from 0.075 to 0.019 B per cell (1 Mb x 1 Mb: 75 -> 19 GB, and what a process's
+// first call pays to allocate them; 2 Mb x 2 Mb fits the device without row panels).  The constant-gap tiles keep CKC64 = 224 steps (12 dwords per lane and snapshot).
+constexpr int FARM_CK_MAX = 512; // (the walk's LDS window: 24 lanes x 33 words x 3 planes x 10 rows = 95 KB)
 template <bool AFF>
 struct FarmGeo {
-    static constexpr int CK = AFF ? CK64 : CKC64;
-    static constexpr int NPL = AFF ? 3 : 1;                   // planes
-    static constexpr int WORDS = AFF ? AL64_WORDS : CK / 16; // direction words per plane row
-    static constexpr int ROWS = WORDS * NPL * R;              // plane rows of G64 dwords
-    static constexpr int TILE_DW = ROWS * G64 + H64;          // + the keys h(i, m) of the rows that have passed column m (affine)
-    static __device__ __forceinline__ int block_of(int te) { return AFF ? (te >= 3 ? (te - 3) / CK : 0) : (te - 1) / CK; }
+    static constexpr int NPL = AFF ? 3 : 1;                                   // planes
+    static constexpr int WORDS_MAX = AFF ? FARM_CK_MAX / 16 + 1 : CKC64 / 16; // direction words per plane row, at most
+    static constexpr int ROWS_MAX = WORDS_MAX * NPL * R;
+    int ck, sh;                                                               // snapshot spacing in steps; its log2 (affine)
+    __host__ __device__ __forceinline__ explicit FarmGeo(int ckr) : ck(AFF ? ckr : CKC64), sh(0) { while ((1 << sh) < ck) sh++; }
+    __host__ __device__ __forceinline__ int words() const { return AFF ? (ck >> 4) + 1 : CKC64 / 16; }
+    __host__ __device__ __forceinline__ int rows() const { return words() * NPL * R; }                  // plane rows of G64 dwords
+    __host__ __device__ __forceinline__ int tile_dw() const { return rows() * G64 + H64; }              // + the keys h(i, m) of the rows that have passed column m (affine)
+    __device__ __forceinline__ int block_of(int te) const { return AFF ? (te >= 3 ? (te - 3) >> sh : 0) : (te - 1) / CKC64; }
+    __device__ __forceinline__ int tbeg_of(int c) const { return AFF ? c << sh : c * CKC64; }
     static __device__ __forceinline__ int tmin_of(int c) { return AFF ? (c > 0 ? 2 : 0) : 0; }
 };
 
@@ -57,8 +68,7 @@ struct FarmGeo {
 // runs) is a staircase that looks like a line of its mean slope at the scale of a tile.  Float arithmetic decides where the line leaves a tile;
 // what comes out is only a guess at the tiles worth re-filling -- a wrong one costs its re-fill, never a result.
 template <bool AFF, typename Skip>
-__device__ __forceinline__ int farm_predict(int2 *tile, int i, int j, const int virt, const int nt, const bool store, const int da, const int db, Skip skip) {
-    using Geo = FarmGeo<AFF>;
+__device__ __forceinline__ int farm_predict(const FarmGeo<AFF> geo, int2 *tile, int i, int j, const int virt, const int nt, const bool store, const int da, const int db, Skip skip) {
     float fa = 1.0f, fb = 1.0f;
     if (da > 0 || db > 0) { const float mx = (float)max(da, db); fa = (float)da / mx; fb = (float)db / mx; }
     const float den = fb + fa * (1.0f / R); // steps of the wavefront the line crosses per unit
@@ -66,7 +76,7 @@ __device__ __forceinline__ int farm_predict(int2 *tile, int i, int j, const int 
     bool taking = false;
     for (int guard = 0; guard < 6 * nt && n < nt && i > 0 && j > 0 && !(virt > 0 && i <= virt); guard++) {
         const int s = (i - 1) / H64, i0 = i - 1 - s * H64, lw = i0 / R, te = j + lw;
-        const int c = Geo::block_of(te), tbeg = c * Geo::CK, tmin = Geo::tmin_of(c);
+        const int c = geo.block_of(te), tbeg = geo.tbeg_of(c), tmin = FarmGeo<AFF>::tmin_of(c);
         if (s == ps && c == pc) { // (rounding left the line inside the tile it was to leave)
             if (fb >= fa) j -= 2; else i -= 2;
             continue;
@@ -93,7 +103,8 @@ __device__ __forceinline__ int farm_predict(int2 *tile, int i, int j, const int 
 }
 
 template <bool AFF>
-__global__ __launch_bounds__(64) void farm_init_kernel(const PairPlan *__restrict__ plans, int n_pairs, TbParams tp, MegaState *__restrict__ mst, FarmCtl *__restrict__ ctl, int nt) {
+__global__ __launch_bounds__(64) void farm_init_kernel(const PairPlan *__restrict__ plans, int n_pairs, TbParams tp, MegaState *__restrict__ mst, FarmCtl *__restrict__ ctl, int nt, int ckr) {
+    const FarmGeo<AFF> geo(ckr);
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= n_pairs) return;
     MegaState *st = mst + p;
@@ -106,10 +117,10 @@ __global__ __launch_bounds__(64) void farm_init_kernel(const PairPlan *__restric
     st->done = 0;
     FarmCtl *cp = ctl + p;
     cp->fin = 0; cp->rounds = 0; cp->hits = 0; cp->acc_i = 0; cp->acc_j = 0;
-    const int n0 = farm_predict<AFF>(cp->tile[0], st->wi, st->wj, st->virt, nt, true, 0, 0, [](int, int) { return false; });
+    const int n0 = farm_predict<AFF>(geo, cp->tile[0], st->wi, st->wj, st->virt, nt, true, 0, 0, [](int, int) { return false; });
     cp->n[0] = n0;
     // (overlapped rounds: the second set continues the line behind the first)
-    cp->n[1] = farm_predict<AFF>(cp->tile[1], st->wi, st->wj, st->virt, nt, true, 0, 0, [&](int s, int c) { for (int x = 0; x < n0; x++) if (cp->tile[0][x].x == s && cp->tile[0][x].y == c) return true; return false; });
+    cp->n[1] = farm_predict<AFF>(geo, cp->tile[1], st->wi, st->wj, st->virt, nt, true, 0, 0, [&](int s, int c) { for (int x = 0; x < n0; x++) if (cp->tile[0][x].x == s && cp->tile[0][x].y == c) return true; return false; });
 }
 
 // ---- affine: the fill of al64_walk_kernel, tile {s, c} completely, planes to global memory ----
@@ -120,7 +131,7 @@ __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__
                                                     const KParams &kp, const int2 *__restrict__ rowbuf, const int *__restrict__ snap,
                                                     int *__restrict__ err, const long long *__restrict__ bases,
                                                     const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, const int p, const int q, const int par) {
-    using Geo = FarmGeo<true>;
+    const FarmGeo<true> geo(kp.ckc);
     constexpr int LW = P16 ? R / 2 : R;
     constexpr int BST = G64 * LW;
     constexpr int TI = 2, TD = 1;
@@ -128,8 +139,8 @@ __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__
     const FarmCtl *cp = ctl + p;
     if (cp->fin || q >= cp->n[par]) return;
     const int s = cp->tile[par][q].x, c = cp->tile[par][q].y;
-    unsigned *dirg = planes + (((int64_t)p * 2 + par) * FARM_MAX + q) * Geo::TILE_DW;
-    int *hcolT = reinterpret_cast<int *>(dirg + Geo::ROWS * G64);
+    unsigned *dirg = planes + (((int64_t)p * 2 + par) * FARM_MAX + q) * geo.tile_dw();
+    int *hcolT = reinterpret_cast<int *>(dirg + geo.rows() * G64);
     const int l = threadIdx.x;
     if (l < 25) lds[l] = kp.sc4[l] - 2 * kp.e4;
     int *prof = &lds[32];
@@ -144,8 +155,8 @@ __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__
     int vO4;
     asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
     int bad = 0;
-    const int tbeg = c * CK64;
-    const int nblk = min(AL64_WORDS, (m + G64 - tbeg + 15) >> 4); // (no walk stands beyond step m + 63)
+    const int tbeg = c << geo.sh;
+    const int nblk = min(geo.words(), (m + G64 - tbeg + 15) >> 4); // (no walk stands beyond step m + 63)
     const int row0 = s * H64 + l * R;
     int rt[R], hold[R];
     unsigned acc[3 * R];
@@ -199,7 +210,7 @@ __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__
                 odn = max3i(M3 + OE4, I2 + OE4, D1 + E4) - RB;
             } else {
                 const int2 v = rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + cc];
-                const int qq = (cc + XB64) / CK64;
+                const int qq = (cc + XB64) >> geo.sh;
                 const int dd = rbase_delta(bases[pl.rowi_off + (int64_t)(s - 1) * pl.s_pitch + qq], Bt);
                 odn = v.x + dd; oh = v.y + dd;
             }
@@ -293,7 +304,7 @@ __device__ __forceinline__ void cl64_farm_fill_body(const PairPlan *__restrict__
                                                     const KParams &kp, const int *__restrict__ rowbuf, const int *__restrict__ snap,
                                                     int *__restrict__ err, const long long *__restrict__ bases,
                                                     const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, const int p, const int q, const int par) {
-    using Geo = FarmGeo<false>;
+    const FarmGeo<false> geo(0);
     constexpr int LW = P16 ? R / 2 : R;
     constexpr int BST = G64 * LW;
     constexpr int CK = CKC64;
@@ -301,7 +312,7 @@ __device__ __forceinline__ void cl64_farm_fill_body(const PairPlan *__restrict__
     const FarmCtl *cp = ctl + p;
     if (cp->fin || q >= cp->n[par]) return;
     const int s = cp->tile[par][q].x, c = cp->tile[par][q].y;
-    unsigned *dirg = planes + (((int64_t)p * 2 + par) * FARM_MAX + q) * Geo::TILE_DW;
+    unsigned *dirg = planes + (((int64_t)p * 2 + par) * FARM_MAX + q) * geo.tile_dw();
     const int l = threadIdx.x;
     if (l < 25) lds[l] = kp.sc4[l] - 2 * kp.g4 + 1; // pre-tagged diagonal candidate (tag 3), see fill_const_kernel
     int *prof = &lds[32];
@@ -428,11 +439,12 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
                                                const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
                                                MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all,
-                                               const unsigned *__restrict__ planes, const int nt, const int p, const int par) {
-    using Geo = FarmGeo<AFF>;
-    constexpr int CK = Geo::CK, NPL = Geo::NPL, ROWS = Geo::ROWS, NLC = FARM_NLC;
-    __shared__ unsigned win[ROWS * NLC];
-    __shared__ int xch[4];
+                                               const unsigned *__restrict__ planes, const int nt, const int ckr, const int p, const int par) {
+    const FarmGeo<AFF> geo(ckr);
+    constexpr int NPL = FarmGeo<AFF>::NPL, NLC = FARM_NLC;
+    constexpr int WW = AFF ? FARM_WW : CKC64 / 16; // direction words (16 steps each) of a tile the window holds: the walk's and the WW - 1 before it
+    __shared__ unsigned win[WW * NPL * R * NLC];
+    __shared__ int xch[8];
     FarmCtl *ctl = ctl_all + p;
     MegaState *mst = mst_all + p;
     const int tid = threadIdx.x, l = tid & 63;
@@ -454,10 +466,8 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
     if (PIPE && l < GNX_RFL(ctl->n[par ^ 1])) optile = ctl->tile[par ^ 1][l];
     auto flush_run = [&]() {
         if (cur_op >= 0) {
-            if (tid == 0) {
-                gnx_cigar cg; cg.run_length = cur_run; cg.op = (uint8_t)cur_op;
-                for (int z = 0; z < 7; z++) cg._pad[z] = 0;
-                scr[sbase + cnt] = cg;
+            if (tid == 0) { // {int64 run_length; uint8 op; 7 zero bytes}: one 16-byte store
+                *reinterpret_cast<longlong2 *>(&scr[sbase + cnt]) = make_longlong2((long long)cur_run, (long long)(cur_op & 0xff));
             }
             cnt++;
         }
@@ -476,37 +486,46 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
             if (!wdone && !pexit) {
                 s = (wi - 1) / H64;
                 lw = (wi - 1 - s * H64) / R;
-                c = Geo::block_of(wj + lw);
+                c = geo.block_of(wj + lw);
                 const unsigned long long bal = __ballot(mytile.x == s && mytile.y == c);
                 slot = bal ? (int)__builtin_ctzll(bal) : -1;
                 lo = max(0, lw - (NLC - 1));
             }
-            if (tid == 0) { xch[0] = slot; xch[1] = lo; xch[2] = lw; }
+            if (tid == 0) { xch[0] = slot; xch[1] = lo; xch[2] = lw; xch[3] = c; xch[4] = wj; }
         }
         __syncthreads();
-        slot = xch[0]; lo = xch[1];
-        const int hi = xch[2];
+        // (every thread of a wave reads the same word: made uniform, so that what the walk derives from them stays in SGPRs)
+        slot = GNX_RFL(xch[0]); lo = GNX_RFL(xch[1]);
+        const int hi = GNX_RFL(xch[2]), cT = GNX_RFL(xch[3]), wjT = GNX_RFL(xch[4]);
         if (slot < 0) break;
-        const unsigned *src = planes + (((int64_t)p * 2 + par) * FARM_MAX + slot) * Geo::TILE_DW;
-        { // (every load of the copy in flight before the first LDS store: the window costs one trip to L2, not one per element)
-            constexpr int NIT = (ROWS * NLC + 255) / 256;
-            unsigned tmp[NIT];
+        const unsigned *src = planes + (((int64_t)p * 2 + par) * FARM_MAX + slot) * geo.tile_dw();
+        // the window: lanes lo .. hi, words wlo .. whi of the tile (the walk only moves to earlier steps; the step after its cell: quirk Q1)
+        const int tbX = geo.tbeg_of(cT), tmX = FarmGeo<AFF>::tmin_of(cT);
+        const int whi = min(geo.words() - 1, (wjT + hi - tbX) >> 4), wlo = max(0, whi - (WW - 1)); // (the walk's cell is at step t1 = wj + hi - 1 - tbX of the tile)
+        { // the loads of the copy in flight, NIT per thread at a time, before their LDS stores: a window costs a trip or two to L2, not one per element.
+          // Straight-line: an index beyond the window is clamped to its last element (loaded and stored again, the same value) and the lanes
+          // lo + ll <= 63 beyond hi are copied with the rest -- a branch per element makes the compiler wait for every load where it stands
+            constexpr int NIT = AFF ? 26 : 14;
+            const int total = (whi - wlo + 1) * NPL * R * NLC;
+            const unsigned *srcw = src + wlo * (NPL * R) * G64 + lo;
+            for (int base = 0; base < total; base += NIT * 256) {
+                unsigned tmp[NIT];
 #pragma unroll
-            for (int u = 0; u < NIT; u++) {
-                const int idx = tid + u * 256;
-                const int row = idx / NLC, ll = idx - row * NLC;
-                tmp[u] = (idx < ROWS * NLC && lo + ll <= hi) ? src[row * G64 + lo + ll] : 0u;
+                for (int u = 0; u < NIT; u++) {
+                    const int idx = min(base + tid + u * 256, total - 1);
+                    const int row = idx / NLC, ll = idx - row * NLC;
+                    tmp[u] = srcw[row * G64 + ll];
+                }
+#pragma unroll
+                for (int u = 0; u < NIT; u++) win[min(base + tid + u * 256, total - 1)] = tmp[u];
             }
-#pragma unroll
-            for (int u = 0; u < NIT; u++) { const int idx = tid + u * 256; if (idx < ROWS * NLC) win[idx] = tmp[u]; }
         }
         __syncthreads();
         if (w0) {
             hits++;
-            const int tbX = c * CK, tmX = Geo::tmin_of(c);
             int i = wi, j = wj, k = wk;
             if constexpr (AFF) {
-                const int *hcX = reinterpret_cast<const int *>(src + ROWS * G64);
+                const int *hcX = reinterpret_cast<const int *>(src + geo.rows() * G64);
                 if (pend) { k = 3 - (GNX_RFL(hcX[i - 1 - s * H64]) & 3); pend = 0; }
                 while (true) {
                     if (i == 0 || j == 0) { wdone = 1; break; }
@@ -516,14 +535,15 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
                     if (l2 < lo) break; // above the window: the next copy follows
                     int t1 = j + l2 - 1 - tbX;
                     if (t1 < tmX) break; // left the (usable part of the) tile through its skewed left edge
+                    if ((t1 >> 4) < wlo) break; // left of the window's words (a long horizontal run): the next copy follows
                     unsigned w;
                     if (k == 0) { // state M: all 64 lanes read the M fields of the cells (i - x, j - x); the leading run that says "from M" is one step
                         const int ix = i0 - l;                                  // (no checkerboard edge inside it: x < li); the word of the cell the run
                         const int ixc = max(ix, 0);                             // ends at serves the scalar step that follows
                         const int l2x = ixc / R, r2x = ixc - l2x * R;
                         const int t1x = (j - l) + l2x - 1 - tbX;
-                        const bool in = ix >= 0 && j - l >= 1 && t1x >= tmX && l2x >= lo;
-                        const unsigned wv = in ? win[(((t1x >> 4) * 3 + 0) * R + r2x) * NLC + (l2x - lo)] : 0u;
+                        const bool in = ix >= 0 && j - l >= 1 && t1x >= tmX && l2x >= lo && (t1x >> 4) >= wlo;
+                        const unsigned wv = in ? win[((((t1x >> 4) - wlo) * 3 + 0) * R + r2x) * NLC + (l2x - lo)] : 0u;
                         const bool ok = in && (int64_t)l < li && ((wv >> (2 * (t1x & 15))) & 3u) == 3u;
                         const unsigned long long nbal = ~__ballot(ok);
                         const int nb = nbal ? (int)__builtin_ctzll(nbal) : 64;
@@ -533,7 +553,7 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
                             i0 = i - 1 - s * H64; l2 = i0 / R; r2 = i0 - l2 * R; t1 = j + l2 - 1 - tbX;
                         }
                         w = (unsigned)__builtin_amdgcn_readlane((int)wv, nb);
-                    } else w = (unsigned)GNX_RFL((int)win[(((t1 >> 4) * 3 + k) * R + r2) * NLC + (l2 - lo)]);
+                    } else w = (unsigned)GNX_RFL((int)win[((((t1 >> 4) - wlo) * 3 + k) * R + r2) * NLC + (l2 - lo)]);
                     const int pos = t1 & 15;
                     int tag = (int)((w >> (2 * pos)) & 3u);
                     if (tag == 0) { if (tid == 0) atomicOr(err, 2); wdone = 1; break; }
@@ -566,7 +586,7 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
                     if (up_exit && i > 0 && j > 0) { // quirk Q1 (affineGap.go:305): restart in the argmax state of the entry cell (i, j)
                         if (j < m) { // = the M-plane field of (i+1, j+1): the row the walk just left, at most one step past its cell
                             const int t3 = (j + 1) + l2 - 1 - tbX;
-                            const unsigned w3 = (unsigned)GNX_RFL((int)win[(((t3 >> 4) * 3 + 0) * R + r2) * NLC + (l2 - lo)]);
+                            const unsigned w3 = (unsigned)GNX_RFL((int)win[((((t3 >> 4) - wlo) * 3 + 0) * R + r2) * NLC + (l2 - lo)]);
                             k = 3 - (int)((w3 >> (2 * (t3 & 15))) & 3u);
                         } else if (i - 1 - s * H64 >= 0 && m + (i - 1 - s * H64) / R - 1 - tbX >= tmX) k = 3 - (GNX_RFL(hcX[i - 1 - s * H64]) & 3);
                         else pend = 1; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
@@ -647,7 +667,7 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
         }
     } else {
         const int da = GNX_RFL(ctl->acc_i) / 2 + (wi_in - wi), db = GNX_RFL(ctl->acc_j) / 2 + (wj_in - wj);
-        const int n = farm_predict<AFF>(ctl->tile[par], wi, wj, virt, nt, tid == 0, da, db,
+        const int n = farm_predict<AFF>(geo, ctl->tile[par], wi, wj, virt, nt, tid == 0, da, db,
                                         [&](int s, int c) { return PIPE && __ballot(optile.x == s && optile.y == c) != 0ull; });
         if (tid == 0) { ctl->n[par] = n; ctl->acc_i = da; ctl->acc_j = db; }
     }
@@ -674,8 +694,8 @@ __global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restri
                                                         const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                         const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
                                                         MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all,
-                                                        const unsigned *__restrict__ planes, int nt) {
-    farm_walk_body<AFF, false>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, blockIdx.x, 0);
+                                                        const unsigned *__restrict__ planes, int nt, int ckr) {
+    farm_walk_body<AFF, false>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, ckr, blockIdx.x, 0);
 }
 
 // overlapped rounds: ONE launch a round -- workgroup 0 of a pair walks set `par` (re-filled by the launch before), workgroups 1 .. nt re-fill
@@ -689,7 +709,7 @@ __global__ __launch_bounds__(256) void al64_farm_round_kernel(const PairPlan *__
                                                               int64_t *__restrict__ score_out, int64_t *__restrict__ nops, const int64_t *__restrict__ scr_off,
                                                               gnx_cigar *__restrict__ scr, int *__restrict__ err, const long long *__restrict__ bases,
                                                               MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all, unsigned *__restrict__ planes, int nt, int par) {
-    if (blockIdx.x == 0) farm_walk_body<true, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, blockIdx.y, par);
+    if (blockIdx.x == 0) farm_walk_body<true, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, kp.ckc, blockIdx.y, par);
     else if (threadIdx.x < 64) al64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl_all, planes, blockIdx.y, (int)blockIdx.x - 1, par ^ 1);
 }
 template <bool P16>
@@ -699,7 +719,7 @@ __global__ __launch_bounds__(256) void cl64_farm_round_kernel(const PairPlan *__
                                                               int64_t *__restrict__ score_out, int64_t *__restrict__ nops, const int64_t *__restrict__ scr_off,
                                                               gnx_cigar *__restrict__ scr, int *__restrict__ err, const long long *__restrict__ bases,
                                                               MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all, unsigned *__restrict__ planes, int nt, int par) {
-    if (blockIdx.x == 0) farm_walk_body<false, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, blockIdx.y, par);
+    if (blockIdx.x == 0) farm_walk_body<false, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, 0, blockIdx.y, par);
     else if (threadIdx.x < 64) cl64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl_all, planes, blockIdx.y, (int)blockIdx.x - 1, par ^ 1);
 }
 

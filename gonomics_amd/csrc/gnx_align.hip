@@ -147,6 +147,7 @@ thread_local Ctx *t_ctx = nullptr;
 // set while a call is re-run with sequential strips after a pipelined launch timed out waiting for a row buffer (a bug trap: nobody
 // waits for an item that has not been claimed, claim_items; should the trap ever fire, the call still returns right results)
 thread_local bool t_no_pipe = false;
+thread_local int t_w64_ck = 128; // snapshot spacing of the 64-lane affine sweep chosen by the routing for this call (farm64.hip.h: 128 .. 512)
 thread_local bool t_no_lat = false; // set while a call is re-run without the latency geometry (its bug trap fired)
 thread_local int64_t t_min_cols = 0; // != 0: the fast path takes windows of at least this many columns (set by a mixed batch for its groups, see run_device)
 bool no_pipe() { return t_no_pipe || getenv("GNX_NO_PIPE") != nullptr; }
@@ -600,6 +601,8 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                     int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool w64);
 
 // tiles per round of the walk farm (farm64.hip.h); 0: the one-workgroup walks
+// snapshot spacing of the 64-lane affine sweep when the farm walks (farm64.hip.h): 512 steps (GNX_W64_CK = 128 / 256 / 512); the one-workgroup walks need CKA
+int w64_farm_ck() { const char *e = getenv("GNX_W64_CK"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }
 int w64_farm_tiles() { const char *e = getenv("GNX_W64_FARM"); if (!e) return 16; const int v = atoi(e); return v <= 0 ? 0 : std::min(v, (int)FARM_MAX); }
 
 // The walk of the 64-lane snapshot path as rounds of {re-fill the tiles ahead of the walk on many CUs, walk them} (farm64.hip.h).
@@ -609,14 +612,15 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
                   const KParams &kp, const TbParams &tp, const void *drb, const int *dsn, const int64_t *dhf, int64_t *d_score, int64_t *dn, const int64_t *d_so,
                   gnx_cigar *d_scr, int *d_err, const long long *dbs, MegaState *d_st, int64_t path_cells, hipStream_t stream) {
     int rc;
-    const size_t tile_dw = affine ? (size_t)FarmGeo<true>::TILE_DW : (size_t)FarmGeo<false>::TILE_DW;
+    const int ckr = affine ? kp.ckc : 0; // (the affine sweep's snapshot spacing of this call, w64_farm_ck; the constant-gap tiles are CKC64 steps)
+    const size_t tile_dw = affine ? (size_t)FarmGeo<true>(ckr).tile_dw() : (size_t)FarmGeo<false>(0).tile_dw();
     const size_t planes_bytes = (size_t)np * 2 * FARM_MAX * tile_dw * 4;
     if ((rc = c.farm.ensure(planes_bytes + (size_t)np * sizeof(FarmCtl)))) return rc;
     unsigned *d_planes = reinterpret_cast<unsigned *>(c.farm.p);
     FarmCtl *d_ctl = reinterpret_cast<FarmCtl *>(reinterpret_cast<char *>(c.farm.p) + planes_bytes);
     const bool pipe = !(getenv("GNX_W64_FARM_PIPE") && getenv("GNX_W64_FARM_PIPE")[0] == '0'); // overlapped rounds (one launch each); 0: {fill, walk} launches
-    if (affine) hipLaunchKernelGGL(farm_init_kernel<true>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt);
-    else hipLaunchKernelGGL(farm_init_kernel<false>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt);
+    if (affine) hipLaunchKernelGGL(farm_init_kernel<true>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt, ckr);
+    else hipLaunchKernelGGL(farm_init_kernel<false>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt, 0);
     const dim3 gf((unsigned)nt, (unsigned)np), gw((unsigned)np), gr((unsigned)nt + 1, (unsigned)np);
     const int2 *drb2 = reinterpret_cast<const int2 *>(drb);
     const int *drb1 = reinterpret_cast<const int *>(drb);
@@ -638,7 +642,7 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
             else hipLaunchKernelGGL((cl64_farm_round_kernel<false>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb1, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
         }
     };
-    int64_t batch = path_cells / ((int64_t)100 * nt) + 8; // (~116 cells of path per tile; a round that finds the walk over costs a few us)
+    int64_t batch = path_cells / ((int64_t)(affine ? ckr * 3 / 4 : 100) * nt) + 8; // (a diagonal crosses ~0.9 of a tile's steps; a round that finds the walk over costs a few us)
     std::vector<FarmCtl> h_ctl((size_t)np);
     int64_t rounds = 0;
     if (pipe) launch_fill(0);
@@ -647,8 +651,8 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
             if (pipe) launch_round((int)((rounds + r) & 1));
             else {
                 launch_fill(0);
-                if (affine) hipLaunchKernelGGL(farm_walk_kernel<true>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt);
-                else hipLaunchKernelGGL(farm_walk_kernel<false>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt);
+                if (affine) hipLaunchKernelGGL(farm_walk_kernel<true>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt, ckr);
+                else hipLaunchKernelGGL(farm_walk_kernel<false>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt, 0);
             }
         }
         rounds += batch;
@@ -687,6 +691,8 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         if (const char *e = getenv("GNX_CL_CKC")) { const int v = atoi(e); if (v == CKC || v == CKC_SMALL) ckc = v; }
         if (w64) ckc = CKC64;
     }
+    // affine snapshot spacing: CKA; the 64-lane sweep under the walk farm: wider (farm64.hip.h) -- a quarter of the snapshots to allocate and to write
+    const int64_t ck_aff = (w64 && affine && w64_farm_tiles() > 0) ? t_w64_ck : CKA;
     std::vector<PairPlan> plans((size_t)n_pairs);
     std::vector<int64_t> so((size_t)n_pairs + 1, 0); // staging offsets (runs), chunk-relative; so[chunk end] is unused
     std::vector<int64_t> chunk_begin{0};
@@ -694,7 +700,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     {
         int64_t rb = 0, sn = 0, sc = 0, bs = 0;
         int64_t budget = c.ws_limit - c.ws_limit / 16;
-        const int64_t rbw = affine ? 8 : 4, ck = affine ? CKA : ckc, snw = affine ? AL_SNAPW : SNAPW; // row-buffer entry bytes, snapshot spacing / dwords
+        const int64_t rbw = affine ? 8 : 4, ck = affine ? ck_aff : ckc, snw = affine ? AL_SNAPW : SNAPW; // row-buffer entry bytes, snapshot spacing / dwords
         auto bytes_of = [&](int64_t rb2, int64_t sn2, int64_t sc2, int64_t bs2) { return rbw * rb2 + 4 * sn2 + (int64_t)sizeof(gnx_cigar) * sc2 + 8 * bs2; };
         auto nq_of = [&](int64_t m) { return rebase ? (((m + GS + 14) & ~(int64_t)15) / ck + 2) : 0; }; // K-step blocks of a strip (REBASE: one int64 base each)
         // One pair that needs more than the workspace limit (a 1 Mb x 1 Mb pair: 50 GB of bottom rows + 43 GB of snapshots) is given what
@@ -812,8 +818,9 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         // workgroups on 5 120 wave slots) a publish every block instead of every fourth hides its cost (the wait for the stores'
         // acknowledgement) behind the other waves and shortens the ramp -- 2048 pairs 437 -> 400 ms; a launch that does not fill the GPU
         // pays for every publish with its own latency (64 pairs of C5: 17.4 -> 19.2 ms) and keeps the coarse interval.
-        KParams kps = kp;
+        KParams kps = kp, kpa = kp;
         kps.ckc = (int)ckc;
+        kpa.ckc = (int)ck_aff; // (al64_sweep_kernel, the farm's re-fills)
         kps.rb_pub = n_blocks * per_item >= (int64_t)40 * c.n_cu ? 16 : RB_PUB; // (twice the wave slots of the piped sweep: 20 per CU)
         if (const char *e = getenv("GNX_CL_PUB")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) kps.rb_pub = v; }
         int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
@@ -826,8 +833,8 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             if (p16) hipLaunchKernelGGL((cl64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
             else hipLaunchKernelGGL((cl64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
         } else if (w64) {
-            if (p16) hipLaunchKernelGGL((al64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
-            else hipLaunchKernelGGL((al64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            if (p16) hipLaunchKernelGGL((al64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kpa, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            else hipLaunchKernelGGL((al64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kpa, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
         } else if (affine) { if (rebase) { if (p16) GNX_AL_SWEEP(true, true); else GNX_AL_SWEEP(false, true); } else { if (p16) GNX_AL_SWEEP(true, false); else GNX_AL_SWEEP(false, false); } }
         else if (wg) hipLaunchKernelGGL(cl_sweep_wg_kernel<CLW_NW>, gridS, dim3(64 * CLW_NW), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
         else if (piped) { if (rebase) { if (p16) GNX_CL_SWEEP(true, true); else GNX_CL_SWEEP(false, true); } else { if (p16) GNX_CL_SWEEP(true, false); else GNX_CL_SWEEP(false, false); } }
@@ -846,7 +853,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             if ((rc = c.mega_state.ensure(256 + (size_t)np * sizeof(MegaState)))) return rc;
             MegaState *d_fst = reinterpret_cast<MegaState *>(reinterpret_cast<char *>(c.mega_state.p) + 256);
             HIPCHK(hipMemsetAsync(d_fst, 0, (size_t)np * sizeof(MegaState), stream));
-            if ((rc = run_walk_farm(c, affine, p16, (int)np, farm_nt, dpl, d_a, d_as + b, d_b, d_bs + b, kp, tp, affine ? (const void *)drb2 : (const void *)drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, d_fst, path / 2, stream))) return rc;
+            if ((rc = run_walk_farm(c, affine, p16, (int)np, farm_nt, dpl, d_a, d_as + b, d_b, d_bs + b, kpa, tp, affine ? (const void *)drb2 : (const void *)drb, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, d_fst, path / 2, stream))) return rc;
         } else if (w64 && !affine) { // one pair per workgroup
             const dim3 gw((unsigned)np);
             if (w64_two_waves()) {
@@ -923,7 +930,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         fill_ms += f1; tb_ms += f2;
         for (int64_t p = b; p < e; p++) {
             const PairPlan &pl = plans[(size_t)p];
-            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + GS - 1) / (affine ? CKA : ckc)) * pl.strips * GS * (affine ? AL_SNAPW : SNAPW);
+            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + GS - 1) / (affine ? ck_aff : ckc)) * pl.strips * GS * (affine ? AL_SNAPW : SNAPW);
         }
     }
     HIPCHK(hipEventRecord(c.ev[2], stream));
@@ -968,7 +975,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
     int rc;
     const int64_t HS = w64 ? H64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair (w64: affine_long64.hip.h / const_long64.hip.h)
     const int np = (int)n_pairs;
-    const int64_t ck = affine ? CKA : CKC_SMALL, snw = affine ? AL_SNAPW : SNAPW, rbw = affine ? 8 : 4;
+    const int64_t ck = affine ? ((w64 && w64_farm_tiles() > 0) ? t_w64_ck : CKA) : CKC_SMALL, snw = affine ? AL_SNAPW : SNAPW, rbw = affine ? 8 : 4;
     bool p16 = true;
     for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * (affine ? prm->gap_extend : prm->gap_open)) + 1; if (v > 32767 || v < -32768) p16 = false; }
     std::vector<int64_t> so((size_t)np + 1, 0), h_start((size_t)np * 2);
@@ -1159,7 +1166,9 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             HIPCHK(hipEventRecord(c.ev[1], stream));
             const int farm_nt = w64 ? w64_farm_tiles() : 0;
             if (farm_nt > 0) {
-                if ((rc = run_walk_farm(c, affine, p16, 1, farm_nt, dpl, d_a, d_starts, d_b, d_starts + 1, kp, tp, c.rowbuf.p, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st,
+                KParams kpf = kp;
+                kpf.ckc = (int)ck;
+                if ((rc = run_walk_farm(c, affine, p16, 1, farm_nt, dpl, d_a, d_starts, d_b, d_starts + 1, kpf, tp, c.rowbuf.p, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st,
                                         std::min<int64_t>((int64_t)pl.n + jcur, 2 * (int64_t)pl.n) / 2, stream))) return rc;
             } else if (w64 && !affine) {
                 const int *drb = reinterpret_cast<const int *>(c.rowbuf.p);
@@ -1616,7 +1625,11 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const char *w64e = getenv("GNX_W64");
         bool few_long = n_pairs <= 64 && w64_farm_tiles() > 0;
         for (int64_t p = 0; few_long && p < n_pairs; p++) if (h_alen[p] < 2 * H64) few_long = false;
-        const bool w64 = !no_pipe() && (int64_t)(H64 + G64 + CKC64 + 64) * step4 < ((int64_t)1 << 28) && !(w64e && w64e[0] == '0') && (n_pairs <= 3 || few_long || (w64e && w64e[0] == '2'));
+        // (steps between two moves of a strip's base: the widest snapshot spacing the keys' spread admits, for the farm's affine sweep)
+        t_w64_ck = CKA;
+        if (affine && w64_farm_tiles() > 0) for (int v = w64_farm_ck(); v > CKA; v >>= 1) if ((int64_t)(H64 + G64 + v + 64) * step4 < ((int64_t)1 << 28)) { t_w64_ck = v; break; }
+        const int64_t ck_w64 = std::max<int64_t>(CKC64, t_w64_ck);
+        const bool w64 = !no_pipe() && (int64_t)(H64 + G64 + ck_w64 + 64) * step4 < ((int64_t)1 << 28) && !(w64e && w64e[0] == '0') && (n_pairs <= 3 || few_long || (w64e && w64e[0] == '2'));
         long double cells_ld = 0, dir_bytes = 0, rows_ld = 0, cols_ld = 0;
         for (int64_t p = 0; use && p < n_pairs; p++) {
             if (h_alen[p] < 1 || h_blen[p] < 1) use = false;
