@@ -274,6 +274,6 @@ def expect_route(timing, route):
         return
     if route == 0 and timing["fast_path"] == 3:  # the stored-matrix family: small launches run it in the latency geometry (lat_fill_kernel)
         return
-    if route == 2 and timing["fast_path"] == 6:  # the snapshot family: affine launches of up to three pairs run it with the whole wave on one pair (affine_long64.hip.h)
+    if route == 2 and timing["fast_path"] == 6:  # the snapshot family: launches of up to three pairs (up to 64 long ones) run it with the whole wave on one pair (affine_long64.hip.h, const_long64.hip.h, farm64.hip.h)
         return
     assert timing["fast_path"] == route, (timing["fast_path"], route)
