@@ -432,6 +432,20 @@ def extra_n1(_lib, L, scores, chunk_h, dev, torch):
     return out
 
 
+def extra_long_pairs(_lib, L, scores, chunk_h, dev, torch):
+    """ONE long pair per call -- what cmd/cigarToBed (cigarToBed.go:86) and cmd/globalAlignment (globalAlignment.go:84) hand to align.AffineGap / ConstGap: the 64-lane
+    snapshot kernels + walk farm.  AffineGap 340 kb x 340 kb and ConstGap 150 kb x 180 kb against the digests of the CPU oracle's results
+    (tests/golden/long_pairs.json: 895 s / 185 s of one core), AffineGap 1 Mb x 1 Mb (1e12 cells) by what its CIGAR must satisfy (tools/long_pairs.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import long_pairs
+    rows = list(long_pairs.gpu_rows(["const_150k", "affine_340k", "affine_1M"], reps=2))
+    keep = ("case", "fn", "n", "m", "cells", "call_s", "first_call_s", "sweep_ms", "walk_ms", "cells_per_s_call", "workspace_bytes", "route", "score", "runs", "consumes_n_m", "rescored_equals_score", "equals_oracle")
+    ok = all(r["consumes_n_m"] and r.get("equals_oracle", True) and r["rescored_minus_score"] % 600 == 0 for r in rows)
+    return {"entry": "gnx_align_batch (one pair per call, host buffers)", "pairs": [{k: r[k] for k in keep if k in r} for r in rows], "bit_exact_sample": bool(ok),
+            "checked_against": "sha256 of the CPU oracle's CIGAR (const_150k, affine_340k); consumed lengths and int64 re-score (affine_1M: no oracle finishes it)"}
+
+
 def one_process_flow(_lib, L, world, params, reads_h, chunk_h, n_pairs, same, steps, share_gpu=False):
     """SURVEY 8e, second form: ONE host process, one context per GPU behind the C ABI (what a Go program gets).  Rank 0 runs it on
     all `world` GPUs after the other ranks have released theirs: `world` x n_pairs reads against the shared chunk (broadcast over
@@ -483,7 +497,7 @@ def main():
     ap.add_argument("--ws-gb", type=float, default=150.0, help="workspace limit per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host_entry and cold_plan legs")
-    ap.add_argument("--no-extras", action="store_true", help="skip the north_star_1M / c3 / c5 sub-objects (and one_process under --gpus N)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the north_star_1M / c3 / c5 / n1 / gsw_reads / long_pairs sub-objects (and one_process under --gpus N)")
     ap.add_argument("--verify", type=int, default=-1, help="pairs checked bit-exactly against the oracle after timing (default 32; 2 for --series long)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU (with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 (flow check of the N>1 path on a 1-GPU box)")
@@ -806,7 +820,7 @@ def main():
             d_ops = None  # the extra legs need the memory (C3: 10 M reads of results on the device; C5: 70 GB of snapshots)
             torch.cuda.empty_cache()
             failed = []
-            for name, fn in (("north_star_1M", extra_north_star), ("c3", extra_c3), ("c3_10M", extra_c3_10m), ("c5", extra_c5), ("n1", extra_n1), ("gsw_reads", extra_gsw)):
+            for name, fn in (("north_star_1M", extra_north_star), ("c3", extra_c3), ("c3_10M", extra_c3_10m), ("c5", extra_c5), ("n1", extra_n1), ("gsw_reads", extra_gsw), ("long_pairs", extra_long_pairs)):
                 t1 = time.perf_counter()
                 try:
                     out[name] = fn(_lib, L, scores, chunk_h, dev, torch)

@@ -78,7 +78,8 @@ def run_oracle(names):
             json.dump(fx, fh, indent=1, sort_keys=True)
 
 
-def run_gpu(names):
+def gpu_rows(names, reps=None):
+    """one row (dict) per case: the pair through the library, timed, with the checks a CIGAR of that size admits"""
     from gonomics_amd import _lib
     from test_const_long import rescore_const
     from test_long_range import rescore_affine
@@ -90,7 +91,7 @@ def run_gpu(names):
         highmem = os.environ.get("LONG_PAIRS_HIGHMEM") == "1"  # AffineGap_highMem / ConstGap_highMem semantics: no checkerboard quirks
         p = _lib.make_params((_lib.GNX_AFFINE_GAP_HIGHMEM if affine else _lib.GNX_CONST_GAP_HIGHMEM) if highmem else (_lib.GNX_AFFINE_GAP if affine else _lib.GNX_CONST_GAP), sc, go, ge, 10000, 10000)
         best, first = None, 0.0
-        for rep in range(3 if a.shape[0] * b.shape[0] < 2e12 else 2):  # (the first call of a process also allocates its workspace: ~27 ms per GB)
+        for rep in range(reps or (3 if a.shape[0] * b.shape[0] < 2e12 else 2)):  # (the first call of a process also allocates its workspace: ~27 ms per GB)
             t0 = time.perf_counter()
             score, ops, off = _lib.align_batch(p, [a], [b])
             wall = time.perf_counter() - t0
@@ -108,6 +109,11 @@ def run_gpu(names):
                "semantics": "highMem (no checkerboards)" if highmem else "10 000 x 10 000 checkerboards (quirk Q1 can cost the CIGAR a gap open: the reference's own behaviour)"}
         if name in fx:
             row["equals_oracle"] = digest(score[0], ops) == {k: fx[name][k] for k in ("score", "runs", "sha256")}
+        yield row
+
+
+def run_gpu(names):
+    for row in gpu_rows(names):
         print(json.dumps(row), flush=True)
 
 
