@@ -432,6 +432,21 @@ def extra_n1(_lib, L, scores, chunk_h, dev, torch):
     return out
 
 
+def long_pair_roofline(d):
+    """HBM roofline of the score-only sweep of ONE long pair on the 64-lane snapshot kernels, from the leg's own timing: algorithmic bytes =
+    the bottom row of every 640-row strip but the last, written and read once (AffineGap 8 B per column: {dn, h}; ConstGap 4 B), + a snapshot of the wavefront
+    (AffineGap 24 dwords x 64 lanes every 512 steps; ConstGap 12 dwords every 224).  The fraction is small by construction -- the kernel is bound by the VALU issue of
+    its ~1 wave per SIMD (profiles/r5_pmc_long_pair.txt) -- and is reported because the contract asks for it."""
+    affine = d["fn"].startswith("AffineGap")
+    strips = -(-d["n"] // 640)
+    rows = (8 if affine else 4) * (d["m"] + 1) * max(strips - 1, 0) * 2
+    snaps = ((d["m"] + 63) // (512 if affine else 224)) * strips * 64 * (24 if affine else 12) * 4
+    secs = d["sweep_ms"] * 1e-3
+    ach = (rows + snaps) / secs / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "algorithmic_bytes_per_launch": rows + snaps,
+            "cells_per_s_kernel": d["cells"] / secs, "waves": strips, "note": "binding ceiling: VALU issue at ~1 wave per SIMD (strips / 1024 SIMDs)"}
+
+
 def extra_long_pairs(_lib, L, scores, chunk_h, dev, torch):
     """ONE long pair per call -- what cmd/cigarToBed (cigarToBed.go:86) and cmd/globalAlignment (globalAlignment.go:84) hand to align.AffineGap / ConstGap: the 64-lane
     snapshot kernels + walk farm.  AffineGap 340 kb x 340 kb and ConstGap 150 kb x 180 kb against the digests of the CPU oracle's results
@@ -442,7 +457,10 @@ def extra_long_pairs(_lib, L, scores, chunk_h, dev, torch):
     rows = list(long_pairs.gpu_rows(["const_150k", "affine_340k", "affine_1M"], reps=2))
     keep = ("case", "fn", "n", "m", "cells", "call_s", "first_call_s", "sweep_ms", "walk_ms", "cells_per_s_call", "workspace_bytes", "route", "score", "runs", "consumes_n_m", "rescored_equals_score", "equals_oracle")
     ok = all(r["consumes_n_m"] and r.get("equals_oracle", True) and r["rescored_minus_score"] % 600 == 0 for r in rows)
-    return {"entry": "gnx_align_batch (one pair per call, host buffers)", "pairs": [{k: r[k] for k in keep if k in r} for r in rows], "bit_exact_sample": bool(ok),
+    pairs = [{k: r[k] for k in keep if k in r} for r in rows]
+    for d in pairs:
+        d["sweep_roofline"] = long_pair_roofline(d)
+    return {"entry": "gnx_align_batch (one pair per call, host buffers)", "pairs": pairs, "bit_exact_sample": bool(ok),
             "checked_against": "sha256 of the CPU oracle's CIGAR (const_150k, affine_340k); consumed lengths and int64 re-score (affine_1M: no oracle finishes it)"}
 
 
