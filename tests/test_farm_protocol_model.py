@@ -28,3 +28,15 @@ def test_overlapped_rounds_stay_in_step(tmp_path):
         assert over <= 1.03 * plain + 2                 # a wrong guess costs the rest of one round, not the protocol
     first, _ = _rounds(exe, 16, 1, 1)                   # the first protocol (kept in the model): sets become each other's complements
     assert first > 2 * _rounds(exe, 16, 1)[0]
+
+
+def test_long_pair_roofline_bytes():
+    """bench.py's long_pairs leg: the algorithmic bytes of a one-pair sweep (1 Mb x 1 Mb = 12.5 GB of bottom rows written + read, 18.8 GB of snapshots)"""
+    import sys
+    sys.path.insert(0, os.path.join(common.HERE, ".."))
+    import bench
+    r = bench.long_pair_roofline({"fn": "AffineGap(HumanChimpTwo,-600,-150)", "n": 1000000, "m": 999886, "cells": 999886000000, "sweep_ms": 312.0})
+    assert r["waves"] == 1563 and abs(r["algorithmic_bytes_per_launch"] - 43.74e9) < 0.05e9
+    assert abs(r["frac"] - 43.74e9 / 0.312 / 8e12) < 1e-4
+    c = bench.long_pair_roofline({"fn": "ConstGap(HumanChimpTwo,-430)", "n": 150000, "m": 180009, "cells": 27001350000, "sweep_ms": 25.7})
+    assert c["waves"] == 235 and c["algorithmic_bytes_per_launch"] == 4 * 180010 * 234 * 2 + (180072 // 224) * 235 * 64 * 12 * 4
