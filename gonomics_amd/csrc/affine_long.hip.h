@@ -289,6 +289,7 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
     // walker state (lane 0 of the pair); pend: the state k is taken from the argmax tag of h(wi, m) once its tile is there (the start,
     // and quirk Q1 when a checkerboard is left upwards in the last column into another strip)
     int wi = pl.n, wj = pl.m, wk = 0, wdone = valid ? 0 : 1, pend = 1;
+    int q1n = 0, q1c = 0; // quirk-Q1 restarts met / that changed the state (gnx_debug_counter(3 / 4))
     int64_t li = (pl.n > 0) ? (int64_t)(pl.n - 1) % tp.ci : 0;
     int64_t cnt = 0, cur_run = 0;
     int cur_op = -1, last_op = -1;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
         __syncthreads();
         if (l == 0 && gact) {
             int i = wi, j = wj, k = wk;
-            if (pend) { k = 3 - (hcolT[i - 1 - s * H] & 3); pend = 0; } // (the tile of (i, m) has just been filled: its lane has passed m)
+            if (pend) { const int kn = 3 - (hcolT[i - 1 - s * H] & 3); if (pend == 2) { q1n++; q1c += (kn != k); } k = kn; pend = 0; } // (the tile of (i, m) has just been filled: its lane has passed m)
             while (true) {
                 if (i == 0 || j == 0) { wdone = 1; break; }
                 const int i0 = i - 1 - s * H;
@@ -517,18 +518,21 @@ __global__ __launch_bounds__(64) void al_walk_kernel(const PairPlan *__restrict_
                 i--;
                 if (k == 0) j--;
                 k = 3 - tag;
+                const int kt = k; // (the traced state)
                 if (up_exit && i > 0 && j > 0) { // quirk Q1 (affineGap.go:305): restart in the argmax state of the entry cell (i, j)
                     if (j < pl.m) { // = the M-plane field of (i+1, j+1): the row the walk just left, at most one step past its cell
                         const int l3 = (i0) / R, r3 = i0 - l3 * R, t3 = (j + 1) + l3 - 1 - tbeg;
                         const unsigned w3 = dirg[(((t3 >> 4) * 3 + 0) * R + r3) * G + l3];
                         k = 3 - (int)((w3 >> (2 * (t3 & 15))) & 3u);
                     } else if (i - 1 - s * H >= 0 && pl.m + (i - 1 - s * H) / R - 1 - tbeg >= tmin) k = 3 - (hcolT[i - 1 - s * H] & 3);
-                    else pend = 1; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                    else pend = 2; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                    if (pend != 2) { q1n++; q1c += (k != kt); }
                 }
             }
             wi = i; wj = j; wk = k;
         }
     }
+    if (l == 0 && valid) q1_report(q1n, q1c);
     if (l == 0 && valid && REBASE && mst) {
         mst->wi = wi; mst->wj = wj; mst->wk = wk; mst->pend = pend; mst->li = li; mst->cnt = cnt; mst->cur_run = cur_run; mst->cur_op = cur_op; mst->last_op = last_op;
         mst->done = pexit ? 0 : 1;

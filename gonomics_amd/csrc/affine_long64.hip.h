@@ -25,15 +25,48 @@ constexpr int CK64 = CKA;                            // snapshot spacing in wave
 constexpr int AL64_WORDS = CK64 / 16 + 1;            // direction words per plane row of a tile
 constexpr int AL64_DIRG = AL64_WORDS * 3 * R * G64;  // LDS dwords of the tile
 constexpr int XB64 = G64 - 2;                        // a bottom-row column c is stored in the 16-step block of step c + 63: block index (c + XB64) / CK64
+// Rows per lane of the 64-lane AFFINE sweep and of the walk farm's re-fills (round 6): RW = 6 / 8 / 10 / 16 -- strips of 384 / 512 / 640 / 1 024 rows.  One long pair is
+// strips(RW) waves on 1 024 SIMDs, paced by the SIMD that holds most of them: the host picks the RW whose strip count fills whole rounds of the SIMDs (w64_pick_rows,
+// gnx_align.hip).  The one-workgroup walks above (GNX_W64_FARM=0) and the constant-gap twins stay at R = 10.
+__host__ __device__ constexpr int al64_snapw(int rw) { return (2 * rw + 2 + 3) & ~3; } // dwords per lane and snapshot: rt[RW], hold[RW], diag0, dn_out (RW = 10: AL_SNAPW)
+static_assert(al64_snapw(R) == AL_SNAPW, "the walk kernels of this file read the sweep's snapshots at RW = R");
+template <int RW>
+__device__ __forceinline__ void al64_snap_store(uint4 *dst, const int (&rt)[RW], const int (&hold)[RW], int diag0, int dn_out) {
+    constexpr int SW = al64_snapw(RW);
+    unsigned v[SW];
+#pragma unroll
+    for (int r = 0; r < RW; r++) { v[r] = (unsigned)rt[r]; v[RW + r] = (unsigned)hold[r]; }
+    v[2 * RW] = (unsigned)diag0; v[2 * RW + 1] = (unsigned)dn_out;
+#pragma unroll
+    for (int k = 2 * RW + 2; k < SW; k++) v[k] = 0u;
+#pragma unroll
+    for (int q = 0; q < SW / 4; q++) dst[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+template <int RW>
+__device__ __forceinline__ void al64_snap_load(const uint4 *sp, int (&rt)[RW], int (&hold)[RW], int &diag0, int &dn_out) {
+    constexpr int SW = al64_snapw(RW);
+    unsigned v[SW];
+    uint4 x[SW / 4];
+#pragma unroll
+    for (int q = 0; q < SW / 4; q++) x[q] = sp[q]; // (every load in flight before the first use)
+#pragma unroll
+    for (int q = 0; q < SW / 4; q++) { v[4 * q] = x[q].x; v[4 * q + 1] = x[q].y; v[4 * q + 2] = x[q].z; v[4 * q + 3] = x[q].w; }
+#pragma unroll
+    for (int r = 0; r < RW; r++) { rt[r] = (int)v[r]; hold[r] = (int)v[RW + r]; }
+    diag0 = (int)v[2 * RW]; dn_out = (int)v[2 * RW + 1];
+}
 
-template <bool P16>
+template <int RW, bool P16>
 __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                         const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                         const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                         KParams kp, int2 *__restrict__ rowbuf, int *__restrict__ snap, int64_t *__restrict__ hfin,
                                                         int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog,
                                                         long long *__restrict__ bases) {
-    constexpr int LW = P16 ? R / 2 : R;       // profile dwords per lane and base
+    static_assert(!P16 || RW % 2 == 0, "the int16 profile packs two rows per dword");
+    constexpr int HW = G64 * RW;              // rows per strip
+    constexpr int SW = al64_snapw(RW);        // dwords per lane and snapshot
+    constexpr int LW = P16 ? RW / 2 : RW;     // profile dwords per lane and base
     constexpr int BST = G64 * LW;             // dwords per base plane (a multiple of 32)
     constexpr int TI = 2, TD = 1;
     __shared__ int lds[32 + 5 * BST];
@@ -60,12 +93,12 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
     for (int s = s_own - n_stolen; s <= s_own; s++) {
         const int bid = (int)blockIdx.x - s_own + s; // block index of strip s of this pair = its slot in strip_prog
         const bool store_row = s + 1 < pl.strips;
-        const int row0 = s * H64 + l * R;
-        int rt[R], hold[R];
+        const int row0 = s * HW + l * RW;
+        int rt[RW], hold[RW];
         {
-            int a5[R];
+            int a5[RW];
 #pragma unroll
-            for (int r = 0; r < R; r++) {
+            for (int r = 0; r < RW; r++) {
                 const int i0 = row0 + r;
                 int a = 0;
                 if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
@@ -80,7 +113,7 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
             __syncthreads();
         }
 #pragma unroll
-        for (int r = 0; r < R; r++) { // column 0: M = I = -inf, D = D00 + i*ecol, rebased (a global alignment: the same constant in every row)
+        for (int r = 0; r < RW; r++) { // column 0: M = I = -inf, D = D00 + i*ecol, rebased (a global alignment: the same constant in every row)
             const int i = row0 + r + 1;
             const int D1c = kp.d00_4 + i * kp.ecol4 + TD - RB * i;
             hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
@@ -150,7 +183,7 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
             if (!CHECK || (j >= 1 && j <= m)) {
                 int hd = diag0, dnu = up_dn;
 #pragma unroll
-                for (int r = 0; r < R - 1; r++) {
+                for (int r = 0; r < RW - 1; r++) {
                     const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
                     const int hnew = max3i(hd + S4, rt[r], dnu);
                     const int ho = hnew + vO4;
@@ -161,7 +194,7 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
                     dnu = dnn;
                 }
                 { // the lane's last row with argmax tags: the row buffer's entries carry them (affine_long.hip.h)
-                    constexpr int r = R - 1;
+                    constexpr int r = RW - 1;
                     int S4;
                     if constexpr (P16) S4 = (r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff); else S4 = w[r];
                     const int M3 = (hd | 3) + S4;
@@ -175,7 +208,7 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
                 }
                 diag0 = up_h;
                 dn_out = dnu;
-                h_out = hold[R - 1];
+                h_out = hold[RW - 1];
             }
             sq_dn = dpp_shl1(dn_out, sq_dn); // (row 3 of the wave: lane 63 inserts, lanes 48 .. 63 hold the last 16 columns of the bottom row)
             sq_h = dpp_shl1(h_out, sq_h);
@@ -190,19 +223,14 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
                 const bool rb_on = t0 <= m + (G64 - 1); // (while some lane still has columns)
                 const int d = rb_on ? (rep & ~3) : 0;
 #pragma unroll
-                for (int r = 0; r < R; r++) { rt[r] -= d; hold[r] -= d; }
+                for (int r = 0; r < RW; r++) { rt[r] -= d; hold[r] -= d; }
                 diag0 -= d; dn_out -= d; h_out -= d; qdn -= d; qh -= d;
                 Bown += d; dlo -= d; dhi -= d;
                 r0i = rbase_const((long long)kp.o4 + TI, Bown);
                 if (rb_on && l == 0) rbase_store(my_bases + (t0 >> cksh), Bown, true);
                 if (rb_on && snap != nullptr) { // snapshot: the state the wave resumes from at step t0
-                    uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)((t0 >> cksh) - 1) * pl.strips + s) * G64 + l) * AL_SNAPW);
-                    dst[0] = make_uint4((unsigned)rt[0], (unsigned)rt[1], (unsigned)rt[2], (unsigned)rt[3]);
-                    dst[1] = make_uint4((unsigned)rt[4], (unsigned)rt[5], (unsigned)rt[6], (unsigned)rt[7]);
-                    dst[2] = make_uint4((unsigned)rt[8], (unsigned)rt[9], (unsigned)hold[0], (unsigned)hold[1]);
-                    dst[3] = make_uint4((unsigned)hold[2], (unsigned)hold[3], (unsigned)hold[4], (unsigned)hold[5]);
-                    dst[4] = make_uint4((unsigned)hold[6], (unsigned)hold[7], (unsigned)hold[8], (unsigned)hold[9]);
-                    dst[5] = make_uint4((unsigned)diag0, (unsigned)dn_out, 0u, 0u);
+                    uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)((t0 >> cksh) - 1) * pl.strips + s) * G64 + l) * SW);
+                    al64_snap_store<RW>(dst, rt, hold, diag0, dn_out);
                 }
             }
             wait_rows(min(t0 + 2 * 16, m));
@@ -224,11 +252,11 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
                 const int x = l - (G64 - 16), c = t0 + x + 1 - (G64 - 1); // lanes 48 .. 63: slot x holds what lane 63 handed down at step t0 + 1 + x
                 if (x >= 0 && c >= 1 && c <= m) rb_store(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_dn, sq_h, true);
             }
-            if (((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[bid], t0 + 1 - (G64 - 16), l); // the bottom row is out up to column t0 + 1 - 48
+            if (((t0 + 16) & (kp.rb_pub - 1)) == 0) rb_publish(&strip_prog[bid], t0 + 1 - (G64 - 16), l); // the bottom row is out up to column t0 + 1 - 48
         }
         if (m >= 1) {
 #pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (Bown + (int64_t)hold[r] + (int64_t)RB * ((int64_t)pl.n + m)) >> 2; // plain score h(n, m)
+            for (int r = 0; r < RW; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (Bown + (int64_t)hold[r] + (int64_t)RB * ((int64_t)pl.n + m)) >> 2; // plain score h(n, m)
         }
         rb_publish(&strip_prog[bid], 0x7fffffff, l);
     }
@@ -266,7 +294,8 @@ __global__ __launch_bounds__(64) void al64_walk_kernel(const PairPlan *__restric
     asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
     int bad = 0;
     // walker state (lane 0), as in al_walk_kernel
-    int wi = pl.n, wj = m, wk = 0, wdone = 0, pend = 1;
+    int wi = pl.n, wj = m, wk = 0, wdone = 0, pend = 1; // (pend: 1 the walk's first state, 2 a quirk-Q1 restart whose entry cell the next tile holds)
+    int q1n = 0, q1c = 0;
     int64_t li = (pl.n > 0) ? (int64_t)(pl.n - 1) % tp.ci : 0;
     int64_t cnt = 0, cur_run = 0;
     int cur_op = -1, last_op = -1;
@@ -447,7 +476,7 @@ __global__ __launch_bounds__(64) void al64_walk_kernel(const PairPlan *__restric
         __syncthreads();
         if (l == 0) {
             int i = wi, j = wj, k = wk;
-            if (pend) { k = 3 - (hcolT[i - 1 - s * H64] & 3); pend = 0; }
+            if (pend) { const int kn = 3 - (hcolT[i - 1 - s * H64] & 3); if (pend == 2) { q1n++; q1c += (kn != k); } k = kn; pend = 0; }
             while (true) {
                 if (i == 0 || j == 0) { wdone = 1; break; }
                 const int i0 = i - 1 - s * H64;
@@ -485,18 +514,21 @@ __global__ __launch_bounds__(64) void al64_walk_kernel(const PairPlan *__restric
                 i--;
                 if (k == 0) j--;
                 k = 3 - tag;
+                const int kt = k; // (the traced state)
                 if (up_exit && i > 0 && j > 0) { // quirk Q1 (affineGap.go:305): restart in the argmax state of the entry cell (i, j)
                     if (j < m) { // = the M-plane field of (i+1, j+1): the row the walk just left, at most one step past its cell
                         const int l3 = (i0) / R, r3 = i0 - l3 * R, t3 = (j + 1) + l3 - 1 - tbeg;
                         const unsigned w3 = dirg[(((t3 >> 4) * 3 + 0) * R + r3) * G64 + l3];
                         k = 3 - (int)((w3 >> (2 * (t3 & 15))) & 3u);
                     } else if (i - 1 - s * H64 >= 0 && m + (i - 1 - s * H64) / R - 1 - tbeg >= tmin) k = 3 - (hcolT[i - 1 - s * H64] & 3);
-                    else pend = 1; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                    else pend = 2; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                    if (pend != 2) { q1n++; q1c += (k != kt); }
                 }
             }
             wi = i; wj = j; wk = k;
         }
     }
+    if (l == 0) q1_report(q1n, q1c);
     if (l == 0 && mst) {
         mst->wi = wi; mst->wj = wj; mst->wk = wk; mst->pend = pend; mst->li = li; mst->cnt = cnt; mst->cur_run = cur_run; mst->cur_op = cur_op; mst->last_op = last_op;
         mst->done = pexit ? 0 : 1;
@@ -547,7 +579,8 @@ __global__ __launch_bounds__(128) void al64_walk2_kernel(const PairPlan *__restr
     asm volatile("v_mov_b32 %0, %1" : "=v"(vO4) : "s"(kp.o4));
     int bad = 0;
     // walker state (lane 0), as in al_walk_kernel
-    int wi = pl.n, wj = m, wk = 0, wdone = 0, pend = 1;
+    int wi = pl.n, wj = m, wk = 0, wdone = 0, pend = 1; // (pend: 1 the walk's first state, 2 a quirk-Q1 restart whose entry cell the next tile holds)
+    int q1n = 0, q1c = 0;
     int64_t li = (pl.n > 0) ? (int64_t)(pl.n - 1) % tp.ci : 0;
     int64_t cnt = 0, cur_run = 0;
     int cur_op = -1, last_op = -1;
@@ -735,7 +768,7 @@ __global__ __launch_bounds__(128) void al64_walk2_kernel(const PairPlan *__restr
             auto walk_tile = [&](const unsigned *dgX, const int *hcX, const int tbX, const int tmX) -> int {
                 int why = 2;
                 int i = wi, j = wj, k = wk;
-                if (pend) { k = 3 - (hcX[i - 1 - s * H64] & 3); pend = 0; }
+                if (pend) { const int kn = 3 - (hcX[i - 1 - s * H64] & 3); if (pend == 2) { q1n++; q1c += (kn != k); } k = kn; pend = 0; }
                 while (true) {
                     if (i == 0 || j == 0) { wdone = 1; break; }
                     const int i0 = i - 1 - s * H64;
@@ -773,13 +806,15 @@ __global__ __launch_bounds__(128) void al64_walk2_kernel(const PairPlan *__restr
                     i--;
                     if (k == 0) j--;
                     k = 3 - tag;
+                    const int kt = k; // (the traced state)
                     if (up_exit && i > 0 && j > 0) { // quirk Q1 (affineGap.go:305): restart in the argmax state of the entry cell (i, j)
                         if (j < m) { // = the M-plane field of (i+1, j+1): the row the walk just left, at most one step past its cell
                             const int l3 = (i0) / R, r3 = i0 - l3 * R, t3 = (j + 1) + l3 - 1 - tbX;
                             const unsigned w3 = dgX[(((t3 >> 4) * 3 + 0) * R + r3) * G64 + l3];
                             k = 3 - (int)((w3 >> (2 * (t3 & 15))) & 3u);
                         } else if (i - 1 - s * H64 >= 0 && m + (i - 1 - s * H64) / R - 1 - tbX >= tmX) k = 3 - (hcX[i - 1 - s * H64] & 3);
-                        else pend = 1; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                        else pend = 2; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                        if (pend != 2) { q1n++; q1c += (k != kt); }
                     }
                 }
                 wi = i; wj = j; wk = k;
@@ -791,6 +826,7 @@ __global__ __launch_bounds__(128) void al64_walk2_kernel(const PairPlan *__restr
             xch[0] = wi; xch[1] = wj; xch[2] = wdone;
         }
     }
+    if (threadIdx.x == 0) q1_report(q1n, q1c);
     if (threadIdx.x == 0 && mst) {
         mst->wi = wi; mst->wj = wj; mst->wk = wk; mst->pend = pend; mst->li = li; mst->cnt = cnt; mst->cur_run = cur_run; mst->cur_op = cur_op; mst->last_op = last_op;
         mst->done = pexit ? 0 : 1;

@@ -33,7 +33,7 @@ namespace {
 // the fill of a tile is ONE wave: its LDS traffic is ordered by a fence, not a workgroup barrier (the overlapped rounds run it inside 256-thread workgroups)
 #define FARM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 constexpr int FARM_MAX = 32; // tiles per round and pair, at most
-constexpr int FARM_NLC = 24; // lanes of a tile the walker holds in LDS (a diagonal leaves a 128-step tile after ~15)
+constexpr int FARM_NLC = 24; // lanes (of 10 rows) of a tile the walker holds in LDS (a diagonal leaves a 128-step tile after ~15)
 constexpr int FARM_WW = 18;  // ... and words of 16 steps (affine; a diagonal through 24 lanes crosses 240 + 24 steps = 17 words)
 
 static_assert(sizeof(gnx_cigar) == 16, "farm_walk_body stores a run as one 16-byte word");
@@ -48,16 +48,18 @@ struct FarmCtl {
 // the walk nothing per cell of path -- and the snapshots of a pair shrink from 0.075 to 0.019 B per cell (1 Mb x 1 Mb: 75 -> 19 GB, and what a process's
 // first call pays to allocate them; 2 Mb x 2 Mb fits the device without row panels).  The constant-gap tiles keep CKC64 = 224 steps (12 dwords per lane and snapshot).
 constexpr int FARM_CK_MAX = 512; // (the walk's LDS window: 24 lanes x 33 words x 3 planes x 10 rows = 95 KB)
-template <bool AFF>
+constexpr int farm_nlc(int rw) { return 240 / rw; } // ... = 24 lanes of 10 rows: the window's 240 rows whatever the lane holds (RW = 6 / 8 / 16: 40 / 30 / 15 lanes)
+template <bool AFF, int RW = R>
 struct FarmGeo {
+    static constexpr int HW = G64 * RW;                                       // rows per strip
     static constexpr int NPL = AFF ? 3 : 1;                                   // planes
     static constexpr int WORDS_MAX = AFF ? FARM_CK_MAX / 16 + 1 : CKC64 / 16; // direction words per plane row, at most
-    static constexpr int ROWS_MAX = WORDS_MAX * NPL * R;
+    static constexpr int ROWS_MAX = WORDS_MAX * NPL * RW;
     int ck, sh;                                                               // snapshot spacing in steps; its log2 (affine)
     __host__ __device__ __forceinline__ explicit FarmGeo(int ckr) : ck(AFF ? ckr : CKC64), sh(0) { while ((1 << sh) < ck) sh++; }
     __host__ __device__ __forceinline__ int words() const { return AFF ? (ck >> 4) + 1 : CKC64 / 16; }
-    __host__ __device__ __forceinline__ int rows() const { return words() * NPL * R; }                  // plane rows of G64 dwords
-    __host__ __device__ __forceinline__ int tile_dw() const { return rows() * G64 + H64; }              // + the keys h(i, m) of the rows that have passed column m (affine)
+    __host__ __device__ __forceinline__ int rows() const { return words() * NPL * RW; }                 // plane rows of G64 dwords
+    __host__ __device__ __forceinline__ int tile_dw() const { return rows() * G64 + HW; }              // + the keys h(i, m) of the rows that have passed column m (affine)
     __device__ __forceinline__ int block_of(int te) const { return AFF ? (te >= 3 ? (te - 3) >> sh : 0) : (te - 1) / CKC64; }
     __device__ __forceinline__ int tbeg_of(int c) const { return AFF ? c << sh : c * CKC64; }
     static __device__ __forceinline__ int tmin_of(int c) { return AFF ? (c > 0 ? 2 : 0) : 0; }
@@ -67,16 +69,17 @@ struct FarmGeo {
 // nothing is known), the cell's own tile first.  A line, not the diagonal: a global alignment of sequences of unequal length (300 kb x 2 Mb: 450 000
 // runs) is a staircase that looks like a line of its mean slope at the scale of a tile.  Float arithmetic decides where the line leaves a tile;
 // what comes out is only a guess at the tiles worth re-filling -- a wrong one costs its re-fill, never a result.
-template <bool AFF, typename Skip>
-__device__ __forceinline__ int farm_predict(const FarmGeo<AFF> geo, int2 *tile, int i, int j, const int virt, const int nt, const bool store, const int da, const int db, Skip skip) {
+template <bool AFF, int RW, typename Skip>
+__device__ __forceinline__ int farm_predict(const FarmGeo<AFF, RW> geo, int2 *tile, int i, int j, const int virt, const int nt, const bool store, const int da, const int db, Skip skip) {
     float fa = 1.0f, fb = 1.0f;
     if (da > 0 || db > 0) { const float mx = (float)max(da, db); fa = (float)da / mx; fb = (float)db / mx; }
-    const float den = fb + fa * (1.0f / R); // steps of the wavefront the line crosses per unit
+    constexpr int HW = G64 * RW;
+    const float den = fb + fa * (1.0f / RW); // steps of the wavefront the line crosses per unit
     int n = 0, ps = -1, pc = -1;
     bool taking = false;
     for (int guard = 0; guard < 6 * nt && n < nt && i > 0 && j > 0 && !(virt > 0 && i <= virt); guard++) {
-        const int s = (i - 1) / H64, i0 = i - 1 - s * H64, lw = i0 / R, te = j + lw;
-        const int c = geo.block_of(te), tbeg = geo.tbeg_of(c), tmin = FarmGeo<AFF>::tmin_of(c);
+        const int s = (i - 1) / HW, i0 = i - 1 - s * HW, lw = i0 / RW, te = j + lw;
+        const int c = geo.block_of(te), tbeg = geo.tbeg_of(c), tmin = FarmGeo<AFF, RW>::tmin_of(c);
         if (s == ps && c == pc) { // (rounding left the line inside the tile it was to leave)
             if (fb >= fa) j -= 2; else i -= 2;
             continue;
@@ -102,9 +105,9 @@ __device__ __forceinline__ int farm_predict(const FarmGeo<AFF> geo, int2 *tile, 
     return n;
 }
 
-template <bool AFF>
+template <bool AFF, int RW>
 __global__ __launch_bounds__(64) void farm_init_kernel(const PairPlan *__restrict__ plans, int n_pairs, TbParams tp, MegaState *__restrict__ mst, FarmCtl *__restrict__ ctl, int nt, int ckr) {
-    const FarmGeo<AFF> geo(ckr);
+    const FarmGeo<AFF, RW> geo(ckr);
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= n_pairs) return;
     MegaState *st = mst + p;
@@ -117,22 +120,23 @@ __global__ __launch_bounds__(64) void farm_init_kernel(const PairPlan *__restric
     st->done = 0;
     FarmCtl *cp = ctl + p;
     cp->fin = 0; cp->rounds = 0; cp->hits = 0; cp->acc_i = 0; cp->acc_j = 0;
-    const int n0 = farm_predict<AFF>(geo, cp->tile[0], st->wi, st->wj, st->virt, nt, true, 0, 0, [](int, int) { return false; });
+    const int n0 = farm_predict<AFF, RW>(geo, cp->tile[0], st->wi, st->wj, st->virt, nt, true, 0, 0, [](int, int) { return false; });
     cp->n[0] = n0;
     // (overlapped rounds: the second set continues the line behind the first)
-    cp->n[1] = farm_predict<AFF>(geo, cp->tile[1], st->wi, st->wj, st->virt, nt, true, 0, 0, [&](int s, int c) { for (int x = 0; x < n0; x++) if (cp->tile[0][x].x == s && cp->tile[0][x].y == c) return true; return false; });
+    cp->n[1] = farm_predict<AFF, RW>(geo, cp->tile[1], st->wi, st->wj, st->virt, nt, true, 0, 0, [&](int s, int c) { for (int x = 0; x < n0; x++) if (cp->tile[0][x].x == s && cp->tile[0][x].y == c) return true; return false; });
 }
 
 // ---- affine: the fill of al64_walk_kernel, tile {s, c} completely, planes to global memory ----
-template <bool P16>
+template <int RW, bool P16>
 __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__ plans,
                                                     const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                     const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                     const KParams &kp, const int2 *__restrict__ rowbuf, const int *__restrict__ snap,
                                                     int *__restrict__ err, const long long *__restrict__ bases,
                                                     const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, const int p, const int q, const int par) {
-    const FarmGeo<true> geo(kp.ckc);
-    constexpr int LW = P16 ? R / 2 : R;
+    const FarmGeo<true, RW> geo(kp.ckc);
+    constexpr int HW = G64 * RW, SW = al64_snapw(RW);
+    constexpr int LW = P16 ? RW / 2 : RW;
     constexpr int BST = G64 * LW;
     constexpr int TI = 2, TD = 1;
     __shared__ int lds[32 + 5 * BST];
@@ -157,14 +161,14 @@ __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__
     int bad = 0;
     const int tbeg = c << geo.sh;
     const int nblk = min(geo.words(), (m + G64 - tbeg + 15) >> 4); // (no walk stands beyond step m + 63)
-    const int row0 = s * H64 + l * R;
-    int rt[R], hold[R];
-    unsigned acc[3 * R];
+    const int row0 = s * HW + l * RW;
+    int rt[RW], hold[RW];
+    unsigned acc[3 * RW];
     FARM_WAVE_SYNC();
     {
-        int a5[R];
+        int a5[RW];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
+        for (int r = 0; r < RW; r++) {
             const int i0 = row0 + r;
             int a = 0;
             if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
@@ -178,22 +182,18 @@ __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__
         FARM_WAVE_SYNC();
     }
 #pragma unroll
-    for (int r = 0; r < R; r++) {
+    for (int r = 0; r < RW; r++) {
         const int i = row0 + r + 1;
         const int D1c = kp.d00_4 + i * kp.ecol4 + TD - RB * i;
         hold[r] = max3i(NEG4 + 3, NEG4 + TI, D1c);
         rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;
-        acc[r] = 0; acc[R + r] = 0; acc[2 * R + r] = 0;
+        acc[r] = 0; acc[RW + r] = 0; acc[2 * RW + r] = 0;
     }
     int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
     int dn_out = 0, h_out = 0, b_out = 0;
     if (c > 0) { // resume from the snapshot of step tbeg
-        const uint4 *sp = reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G64 + l) * AL_SNAPW);
-        const uint4 x0 = sp[0], x1 = sp[1], x2 = sp[2], x3 = sp[3], x4 = sp[4], x5 = sp[5];
-        rt[0] = (int)x0.x; rt[1] = (int)x0.y; rt[2] = (int)x0.z; rt[3] = (int)x0.w; rt[4] = (int)x1.x; rt[5] = (int)x1.y; rt[6] = (int)x1.z; rt[7] = (int)x1.w;
-        rt[8] = (int)x2.x; rt[9] = (int)x2.y; hold[0] = (int)x2.z; hold[1] = (int)x2.w; hold[2] = (int)x3.x; hold[3] = (int)x3.y; hold[4] = (int)x3.z; hold[5] = (int)x3.w;
-        hold[6] = (int)x4.x; hold[7] = (int)x4.y; hold[8] = (int)x4.z; hold[9] = (int)x4.w; diag0 = (int)x5.x; dn_out = (int)x5.y;
-        h_out = hold[R - 1];
+        al64_snap_load<RW>(reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G64 + l) * SW), rt, hold, diag0, dn_out);
+        h_out = hold[RW - 1];
         const int jb = tbeg - l;
         if (jb >= 1 && jb <= m) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
     }
@@ -246,11 +246,11 @@ __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__
         if (!CHECK || (j >= 1 && j <= m)) {
             int hd = diag0, dnu = up_dn;
 #pragma unroll
-            for (int r = 0; r < R; r++) { // the recording h-form of fill_affine_kernel (rebased keys)
+            for (int r = 0; r < RW; r++) { // the recording h-form of fill_affine_kernel (rebased keys)
                 const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
                 acc[r] = alignbit2((unsigned)hd, acc[r]);
-                acc[R + r] = alignbit2((unsigned)rt[r], acc[R + r]);
-                acc[2 * R + r] = alignbit2((unsigned)dnu, acc[2 * R + r]);
+                acc[RW + r] = alignbit2((unsigned)rt[r], acc[RW + r]);
+                acc[2 * RW + r] = alignbit2((unsigned)dnu, acc[2 * RW + r]);
                 const int M3 = (hd | 3) + S4;
                 const int I2 = (rt[r] & ~3) | TI;
                 const int D1 = (dnu & ~3) | TD;
@@ -264,7 +264,7 @@ __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__
             }
             diag0 = up_h;
             dn_out = dnu;
-            h_out = hold[R - 1];
+            h_out = hold[RW - 1];
         }
 #pragma unroll
         for (int k = 0; k < LW; k++) wq[k] = wn[k];
@@ -286,11 +286,11 @@ __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__
 #pragma unroll
         for (int k = 0; k < 3; k++) {
 #pragma unroll
-            for (int r = 0; r < R; r++) dirg[((b * 3 + k) * R + r) * G64 + l] = acc[k * R + r] >> sh;
+            for (int r = 0; r < RW; r++) dirg[((b * 3 + k) * RW + r) * G64 + l] = acc[k * RW + r] >> sh;
         }
         if (b == nblk - 1 && t0 + 16 - l >= m) { // lanes that have passed column m hold h(i, m) of their rows
 #pragma unroll
-            for (int r = 0; r < R; r++) hcolT[l * R + r] = hold[r];
+            for (int r = 0; r < RW; r++) hcolT[l * RW + r] = hold[r];
         }
     }
     if (bad) atomicOr(err, 1);
@@ -434,16 +434,17 @@ __device__ __forceinline__ int64_t farm_rfl64(int64_t v) {
 // ---- the walk of one round: wave 0 walks (state uniform: SGPRs), all four waves copy the tile's window into LDS ----
 // par: the set this round walks (and, walked, replaces by a new one).  PIPE: the other set is being re-filled by this launch's other workgroups --
 // the new set continues the line behind it.
-template <bool AFF, bool PIPE>
+template <bool AFF, int RW, bool PIPE>
 __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plans, const TbParams &tp,
                                                const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
                                                MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all,
                                                const unsigned *__restrict__ planes, const int nt, const int ckr, const int p, const int par) {
-    const FarmGeo<AFF> geo(ckr);
-    constexpr int NPL = FarmGeo<AFF>::NPL, NLC = FARM_NLC;
+    const FarmGeo<AFF, RW> geo(ckr);
+    constexpr int HW = G64 * RW;
+    constexpr int NPL = FarmGeo<AFF, RW>::NPL, NLC = farm_nlc(RW);
     constexpr int WW = AFF ? FARM_WW : CKC64 / 16; // direction words (16 steps each) of a tile the window holds: the walk's and the WW - 1 before it
-    __shared__ unsigned win[WW * NPL * R * NLC];
+    __shared__ unsigned win[WW * NPL * RW * NLC];
     __shared__ int xch[8];
     FarmCtl *ctl = ctl_all + p;
     MegaState *mst = mst_all + p;
@@ -477,15 +478,15 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
         else { flush_run(); cur_op = op; cur_run = run; }
     };
     bool pexit = false;
-    int hits = 0;
+    int hits = 0, q1n = 0, q1c = 0;
     while (true) {
         int slot = -1, s = 0, c = 0, lw = 0, lo = 0;
         if (w0) {
             if (wi == 0 || wj == 0) wdone = 1;
             if (!wdone && virt > 0 && wi <= virt) pexit = true;
             if (!wdone && !pexit) {
-                s = (wi - 1) / H64;
-                lw = (wi - 1 - s * H64) / R;
+                s = (wi - 1) / HW;
+                lw = (wi - 1 - s * HW) / RW;
                 c = geo.block_of(wj + lw);
                 const unsigned long long bal = __ballot(mytile.x == s && mytile.y == c);
                 slot = bal ? (int)__builtin_ctzll(bal) : -1;
@@ -500,14 +501,14 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
         if (slot < 0) break;
         const unsigned *src = planes + (((int64_t)p * 2 + par) * FARM_MAX + slot) * geo.tile_dw();
         // the window: lanes lo .. hi, words wlo .. whi of the tile (the walk only moves to earlier steps; the step after its cell: quirk Q1)
-        const int tbX = geo.tbeg_of(cT), tmX = FarmGeo<AFF>::tmin_of(cT);
+        const int tbX = geo.tbeg_of(cT), tmX = FarmGeo<AFF, RW>::tmin_of(cT);
         const int whi = min(geo.words() - 1, (wjT + hi - tbX) >> 4), wlo = max(0, whi - (WW - 1)); // (the walk's cell is at step t1 = wj + hi - 1 - tbX of the tile)
         { // the loads of the copy in flight, NIT per thread at a time, before their LDS stores: a window costs a trip or two to L2, not one per element.
           // Straight-line: an index beyond the window is clamped to its last element (loaded and stored again, the same value) and the lanes
           // lo + ll <= 63 beyond hi are copied with the rest -- a branch per element makes the compiler wait for every load where it stands
             constexpr int NIT = AFF ? 26 : 14;
-            const int total = (whi - wlo + 1) * NPL * R * NLC;
-            const unsigned *srcw = src + wlo * (NPL * R) * G64 + lo;
+            const int total = (whi - wlo + 1) * NPL * RW * NLC;
+            const unsigned *srcw = src + wlo * (NPL * RW) * G64 + lo;
             for (int base = 0; base < total; base += NIT * 256) {
                 unsigned tmp[NIT];
 #pragma unroll
@@ -526,12 +527,12 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
             int i = wi, j = wj, k = wk;
             if constexpr (AFF) {
                 const int *hcX = reinterpret_cast<const int *>(src + geo.rows() * G64);
-                if (pend) { k = 3 - (GNX_RFL(hcX[i - 1 - s * H64]) & 3); pend = 0; }
+                if (pend) { const int kn = 3 - (GNX_RFL(hcX[i - 1 - s * HW]) & 3); if (pend == 2) { q1n++; q1c += (kn != k); } k = kn; pend = 0; }
                 while (true) {
                     if (i == 0 || j == 0) { wdone = 1; break; }
-                    int i0 = i - 1 - s * H64;
+                    int i0 = i - 1 - s * HW;
                     if (i0 < 0) break; // left the strip through its top edge
-                    int l2 = i0 / R, r2 = i0 - l2 * R;
+                    int l2 = i0 / RW, r2 = i0 - l2 * RW;
                     if (l2 < lo) break; // above the window: the next copy follows
                     int t1 = j + l2 - 1 - tbX;
                     if (t1 < tmX) break; // left the (usable part of the) tile through its skewed left edge
@@ -540,20 +541,20 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
                     if (k == 0) { // state M: all 64 lanes read the M fields of the cells (i - x, j - x); the leading run that says "from M" is one step
                         const int ix = i0 - l;                                  // (no checkerboard edge inside it: x < li); the word of the cell the run
                         const int ixc = max(ix, 0);                             // ends at serves the scalar step that follows
-                        const int l2x = ixc / R, r2x = ixc - l2x * R;
+                        const int l2x = ixc / RW, r2x = ixc - l2x * RW;
                         const int t1x = (j - l) + l2x - 1 - tbX;
                         const bool in = ix >= 0 && j - l >= 1 && t1x >= tmX && l2x >= lo && (t1x >> 4) >= wlo;
-                        const unsigned wv = in ? win[((((t1x >> 4) - wlo) * 3 + 0) * R + r2x) * NLC + (l2x - lo)] : 0u;
+                        const unsigned wv = in ? win[((((t1x >> 4) - wlo) * 3 + 0) * RW + r2x) * NLC + (l2x - lo)] : 0u;
                         const bool ok = in && (int64_t)l < li && ((wv >> (2 * (t1x & 15))) & 3u) == 3u;
                         const unsigned long long nbal = ~__ballot(ok);
                         const int nb = nbal ? (int)__builtin_ctzll(nbal) : 64;
                         if (nb > 0) {
                             emit(0, nb); last_op = 0; li -= nb; i -= nb; j -= nb;
                             if (nb == 64 || !((__ballot(in) >> nb) & 1ull)) continue;
-                            i0 = i - 1 - s * H64; l2 = i0 / R; r2 = i0 - l2 * R; t1 = j + l2 - 1 - tbX;
+                            i0 = i - 1 - s * HW; l2 = i0 / RW; r2 = i0 - l2 * RW; t1 = j + l2 - 1 - tbX;
                         }
                         w = (unsigned)__builtin_amdgcn_readlane((int)wv, nb);
-                    } else w = (unsigned)GNX_RFL((int)win[((((t1 >> 4) - wlo) * 3 + k) * R + r2) * NLC + (l2 - lo)]);
+                    } else w = (unsigned)GNX_RFL((int)win[((((t1 >> 4) - wlo) * 3 + k) * RW + r2) * NLC + (l2 - lo)]);
                     const int pos = t1 & 15;
                     int tag = (int)((w >> (2 * pos)) & 3u);
                     if (tag == 0) { if (tid == 0) atomicOr(err, 2); wdone = 1; break; }
@@ -583,21 +584,23 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
                     i--;
                     if (k == 0) j--;
                     k = 3 - tag;
+                    const int kt = k; // (the traced state)
                     if (up_exit && i > 0 && j > 0) { // quirk Q1 (affineGap.go:305): restart in the argmax state of the entry cell (i, j)
                         if (j < m) { // = the M-plane field of (i+1, j+1): the row the walk just left, at most one step past its cell
                             const int t3 = (j + 1) + l2 - 1 - tbX;
-                            const unsigned w3 = (unsigned)GNX_RFL((int)win[((((t3 >> 4) - wlo) * 3 + 0) * R + r2) * NLC + (l2 - lo)]);
+                            const unsigned w3 = (unsigned)GNX_RFL((int)win[((((t3 >> 4) - wlo) * 3 + 0) * RW + r2) * NLC + (l2 - lo)]);
                             k = 3 - (int)((w3 >> (2 * (t3 & 15))) & 3u);
-                        } else if (i - 1 - s * H64 >= 0 && m + (i - 1 - s * H64) / R - 1 - tbX >= tmX) k = 3 - (GNX_RFL(hcX[i - 1 - s * H64]) & 3);
-                        else pend = 1; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                        } else if (i - 1 - s * HW >= 0 && m + (i - 1 - s * HW) / RW - 1 - tbX >= tmX) k = 3 - (GNX_RFL(hcX[i - 1 - s * HW]) & 3);
+                        else pend = 2; // row i belongs to the strip above, or its lane passed column m before this tile began: the next tile has it
+                        if (pend != 2) { q1n++; q1c += (k != kt); }
                     }
                 }
             } else {
                 while (true) {
                     if (i == 0 || j == 0) { wdone = 1; break; }
-                    int i0 = i - 1 - s * H64;
+                    int i0 = i - 1 - s * HW;
                     if (i0 < 0) break; // left the strip through its top edge
-                    int l2 = i0 / R, r2 = i0 - l2 * R;
+                    int l2 = i0 / RW, r2 = i0 - l2 * RW;
                     if (l2 < lo) break; // above the window
                     int t1 = j + l2 - 1 - tbX;
                     if (t1 < 0) break; // left the tile through its (skewed) left edge
@@ -605,17 +608,17 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
                     { // all 64 lanes read the fields of the cells (i - x, j - x): the leading run of diagonal fields is one step, the word of the cell it ends at serves the scalar step
                         const int ix = i0 - l;
                         const int ixc = max(ix, 0);
-                        const int l2x = ixc / R, r2x = ixc - l2x * R;
+                        const int l2x = ixc / RW, r2x = ixc - l2x * RW;
                         const int t1x = (j - l) + l2x - 1 - tbX;
                         const bool in = ix >= 0 && j - l >= 1 && t1x >= 0 && l2x >= lo;
-                        const unsigned wv = in ? win[((t1x >> 4) * R + r2x) * NLC + (l2x - lo)] : 0u;
+                        const unsigned wv = in ? win[((t1x >> 4) * RW + r2x) * NLC + (l2x - lo)] : 0u;
                         const bool ok = in && ((wv >> (2 * (t1x & 15))) & 3u) == 3u;
                         const unsigned long long nbal = ~__ballot(ok);
                         const int nb = nbal ? (int)__builtin_ctzll(nbal) : 64;
                         if (nb > 0) {
                             emit(0, nb); last_op = 0; i -= nb; j -= nb;
                             if (nb == 64 || !((__ballot(in) >> nb) & 1ull)) continue;
-                            i0 = i - 1 - s * H64; l2 = i0 / R; r2 = i0 - l2 * R; t1 = j + l2 - 1 - tbX;
+                            i0 = i - 1 - s * HW; l2 = i0 / RW; r2 = i0 - l2 * RW; t1 = j + l2 - 1 - tbX;
                         }
                         w = (unsigned)__builtin_amdgcn_readlane((int)wv, nb);
                     }
@@ -652,6 +655,7 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
     if (tid == 0) {
         mst->wi = wi; mst->wj = wj; mst->wk = wk; mst->pend = pend; mst->li = li; mst->cnt = cnt; mst->cur_run = cur_run; mst->cur_op = cur_op; mst->last_op = last_op;
         ctl->rounds += 1; ctl->hits += hits;
+        q1_report(q1n, q1c);
     }
     if (wdone || pexit) {
         if (tid == 0) { mst->done = pexit ? 0 : 1; ctl->fin = 1; ctl->n[0] = 0; ctl->n[1] = 0; }
@@ -667,7 +671,7 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
         }
     } else {
         const int da = GNX_RFL(ctl->acc_i) / 2 + (wi_in - wi), db = GNX_RFL(ctl->acc_j) / 2 + (wj_in - wj);
-        const int n = farm_predict<AFF>(geo, ctl->tile[par], wi, wj, virt, nt, tid == 0, da, db,
+        const int n = farm_predict<AFF, RW>(geo, ctl->tile[par], wi, wj, virt, nt, tid == 0, da, db,
                                         [&](int s, int c) { return PIPE && __ballot(optile.x == s && optile.y == c) != 0ull; });
         if (tid == 0) { ctl->n[par] = n; ctl->acc_i = da; ctl->acc_j = db; }
     }
@@ -675,12 +679,12 @@ __device__ __forceinline__ void farm_walk_body(const PairPlan *__restrict__ plan
 }
 
 // plain rounds: launch {fill set 0, walk set 0} a round
-template <bool P16>
+template <int RW, bool P16>
 __global__ __launch_bounds__(64) void al64_farm_fill_kernel(const PairPlan *__restrict__ plans, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                             const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp,
                                                             const int2 *__restrict__ rowbuf, const int *__restrict__ snap, int *__restrict__ err,
                                                             const long long *__restrict__ bases, const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, int par) {
-    al64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl, planes, blockIdx.y, blockIdx.x, par);
+    al64_farm_fill_body<RW, P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl, planes, blockIdx.y, blockIdx.x, par);
 }
 template <bool P16>
 __global__ __launch_bounds__(64) void cl64_farm_fill_kernel(const PairPlan *__restrict__ plans, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
@@ -689,28 +693,28 @@ __global__ __launch_bounds__(64) void cl64_farm_fill_kernel(const PairPlan *__re
                                                             const long long *__restrict__ bases, const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, int par) {
     cl64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl, planes, blockIdx.y, blockIdx.x, par);
 }
-template <bool AFF>
+template <bool AFF, int RW>
 __global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restrict__ plans, TbParams tp,
                                                         const int64_t *__restrict__ hfin, int64_t *__restrict__ score_out, int64_t *__restrict__ nops,
                                                         const int64_t *__restrict__ scr_off, gnx_cigar *__restrict__ scr, int *__restrict__ err,
                                                         MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all,
                                                         const unsigned *__restrict__ planes, int nt, int ckr) {
-    farm_walk_body<AFF, false>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, ckr, blockIdx.x, 0);
+    farm_walk_body<AFF, RW, false>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, ckr, blockIdx.x, 0);
 }
 
 // overlapped rounds: ONE launch a round -- workgroup 0 of a pair walks set `par` (re-filled by the launch before), workgroups 1 .. nt re-fill
 // the other set (asked for by the walk of the launch before) meanwhile, on their own CUs; the walk then asks for the set after that one.
 // The walk's own tile is in one of the two sets at the latest two rounds after a wrong guess (the first tile of a line that starts at the
 // walk's cell is either being re-filled or asked for), so the rounds still move.
-template <bool P16>
+template <int RW, bool P16>
 __global__ __launch_bounds__(256) void al64_farm_round_kernel(const PairPlan *__restrict__ plans, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                               const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp, TbParams tp,
                                                               const int2 *__restrict__ rowbuf, const int *__restrict__ snap, const int64_t *__restrict__ hfin,
                                                               int64_t *__restrict__ score_out, int64_t *__restrict__ nops, const int64_t *__restrict__ scr_off,
                                                               gnx_cigar *__restrict__ scr, int *__restrict__ err, const long long *__restrict__ bases,
                                                               MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all, unsigned *__restrict__ planes, int nt, int par) {
-    if (blockIdx.x == 0) farm_walk_body<true, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, kp.ckc, blockIdx.y, par);
-    else if (threadIdx.x < 64) al64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl_all, planes, blockIdx.y, (int)blockIdx.x - 1, par ^ 1);
+    if (blockIdx.x == 0) farm_walk_body<true, RW, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, kp.ckc, blockIdx.y, par);
+    else if (threadIdx.x < 64) al64_farm_fill_body<RW, P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl_all, planes, blockIdx.y, (int)blockIdx.x - 1, par ^ 1);
 }
 template <bool P16>
 __global__ __launch_bounds__(256) void cl64_farm_round_kernel(const PairPlan *__restrict__ plans, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(256) void cl64_farm_round_kernel(const PairPlan *__
                                                               int64_t *__restrict__ score_out, int64_t *__restrict__ nops, const int64_t *__restrict__ scr_off,
                                                               gnx_cigar *__restrict__ scr, int *__restrict__ err, const long long *__restrict__ bases,
                                                               MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all, unsigned *__restrict__ planes, int nt, int par) {
-    if (blockIdx.x == 0) farm_walk_body<false, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, 0, blockIdx.y, par);
+    if (blockIdx.x == 0) farm_walk_body<false, R, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, 0, blockIdx.y, par);
     else if (threadIdx.x < 64) cl64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl_all, planes, blockIdx.y, (int)blockIdx.x - 1, par ^ 1);
 }
 

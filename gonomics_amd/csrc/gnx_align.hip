@@ -148,6 +148,8 @@ thread_local Ctx *t_ctx = nullptr;
 // waits for an item that has not been claimed, claim_items; should the trap ever fire, the call still returns right results)
 thread_local bool t_no_pipe = false;
 thread_local int t_w64_ck = 128; // snapshot spacing of the 64-lane affine sweep chosen by the routing for this call (farm64.hip.h: 128 .. 512)
+std::atomic<int64_t> g_last_w64_r{0}, g_last_w64_ck{0}; // what the last 64-lane affine sweep ran with (gnx_debug_counter(5 / 6): bench.py prices its bytes with them)
+thread_local int t_w64_r = R;    // rows per lane of the 64-lane AFFINE sweep + farm chosen by the routing for this call (w64_pick_rows: 6 / 8 / 10 / 16)
 thread_local bool t_no_lat = false; // set while a call is re-run without the latency geometry (its bug trap fired)
 thread_local int64_t t_min_cols = 0; // != 0: the fast path takes windows of at least this many columns (set by a mixed batch for its groups, see run_device)
 bool no_pipe() { return t_no_pipe || getenv("GNX_NO_PIPE") != nullptr; }
@@ -603,7 +605,49 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
 // tiles per round of the walk farm (farm64.hip.h); 0: the one-workgroup walks
 // snapshot spacing of the 64-lane affine sweep when the farm walks (farm64.hip.h): 512 steps (GNX_W64_CK = 128 / 256 / 512); the one-workgroup walks need CKA
 int w64_farm_ck() { const char *e = getenv("GNX_W64_CK"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }
+// how often a strip of the 64-lane sweeps publishes its bottom row (steps; the strip below runs ~63 + 32 + this many steps behind): GNX_W64_PUB = 16 / 32 / 64
+int w64_pub() { const char *e = getenv("GNX_W64_PUB"); const int v = e ? atoi(e) : RB_PUB; return (v == 16 || v == 32 || v == 64) ? v : RB_PUB; }
 int w64_farm_tiles() { const char *e = getenv("GNX_W64_FARM"); if (!e) return 16; const int v = atoi(e); return v <= 0 ? 0 : std::min(v, (int)FARM_MAX); }
+
+// Rows per lane of the affine 64-lane sweep (affine_long64.hip.h): call f with the compile-time constant of the instantiation
+template <typename F>
+void w64_rows_dispatch(int rw, F &&f) {
+    switch (rw) {
+    case 6: f(std::integral_constant<int, 6>{}); break;
+    case 8: f(std::integral_constant<int, 8>{}); break;
+    case 16: f(std::integral_constant<int, 16>{}); break;
+    default: f(std::integral_constant<int, R>{}); break;
+    }
+}
+constexpr int W64_ROWS[4] = {6, 8, R, 16};
+// One long pair is strips(RW) = n / (64 RW) waves piped through the row buffer, each ~lag steps behind the one above it; a SIMD that holds w of
+// them issues w x (5 RW + ~18) instructions per step of the pipeline, and the pipeline moves at the pace of the fullest SIMD.  1 Mb x 1 Mb at RW = 10:
+// 1 563 waves on 1 024 SIMDs -- half of the SIMDs hold two, the others wait for them (valu_busy 0.56, profiles/r5_pmc_long_pair.txt); at RW = 8: 1 954,
+// two on (nearly) every SIMD, 54 instead of 64 instructions per wave and step.  Per instruction: ~2.75 ns for a wave alone on its SIMD, ~1.9 ns each
+// for two, ~1.75 from three on (tools/valu_ubench*.hip; the lone wave: profiles/r5_experiments.md section 2).  The model below is that arithmetic;
+// GNX_W64_R = 6 / 8 / 10 / 16 overrides it (tests, A/B runs).  `strips_cap` > 0: row panels -- at most that many strips are in flight.
+int w64_pick_rows(const Ctx &c, int64_t n_pairs, const int64_t *h_alen, const int64_t *h_blen, int64_t step4, int ck, int64_t strips_cap = 0) {
+    if (const char *e = getenv("GNX_W64_R")) { const int v = atoi(e); for (int x : W64_ROWS) if (x == v) return v; }
+    const double simds = 4.0 * c.n_cu, lag = 110.0;
+    double best = 0;
+    int best_rw = R;
+    for (int rw : W64_ROWS) {
+        if ((int64_t)(G64 * rw + G64 + ck + 64) * step4 >= ((int64_t)1 << 28)) continue; // (the keys' spread around a strip's moving base)
+        double strips = 0, steps = 0, rows = 0;
+        for (int64_t p = 0; p < n_pairs; p++) {
+            const double sp = (double)((h_alen[p] + G64 * rw - 1) / (G64 * rw));
+            strips += sp; rows += (double)h_alen[p];
+            steps = std::max(steps, (double)h_blen[p] + std::min(sp, strips_cap > 0 ? (double)strips_cap : sp) * lag);
+        }
+        double passes = 1.0;
+        if (strips_cap > 0 && strips > (double)strips_cap) { passes = strips / (double)strips_cap; strips = (double)strips_cap; }
+        const double w = std::ceil(strips / simds);
+        const double ns = w <= 1.0 ? 2.75 : (w <= 2.0 ? 1.9 : 1.75);
+        const double cost = passes * w * (5.0 * rw + 18.0) * ns * steps;
+        if (best == 0 || cost < best) { best = cost; best_rw = rw; }
+    }
+    return best_rw;
+}
 
 // The walk of the 64-lane snapshot path as rounds of {re-fill the tiles ahead of the walk on many CUs, walk them} (farm64.hip.h).
 // d_st: np MegaStates the caller has prepared (zeroed for a whole pair; the panel's state for row panels).  Launches rounds until every
@@ -613,21 +657,26 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
                   gnx_cigar *d_scr, int *d_err, const long long *dbs, MegaState *d_st, int64_t path_cells, hipStream_t stream) {
     int rc;
     const int ckr = affine ? kp.ckc : 0; // (the affine sweep's snapshot spacing of this call, w64_farm_ck; the constant-gap tiles are CKC64 steps)
-    const size_t tile_dw = affine ? (size_t)FarmGeo<true>(ckr).tile_dw() : (size_t)FarmGeo<false>(0).tile_dw();
+    const int rw = affine ? t_w64_r : R; // rows per lane of the sweep that wrote the snapshots (affine: w64_pick_rows)
+    size_t tile_dw = (size_t)FarmGeo<false>(0).tile_dw();
+    if (affine) w64_rows_dispatch(rw, [&](auto rwc) { tile_dw = (size_t)FarmGeo<true, decltype(rwc)::value>(ckr).tile_dw(); });
     const size_t planes_bytes = (size_t)np * 2 * FARM_MAX * tile_dw * 4;
     if ((rc = c.farm.ensure(planes_bytes + (size_t)np * sizeof(FarmCtl)))) return rc;
     unsigned *d_planes = reinterpret_cast<unsigned *>(c.farm.p);
     FarmCtl *d_ctl = reinterpret_cast<FarmCtl *>(reinterpret_cast<char *>(c.farm.p) + planes_bytes);
     const bool pipe = !(getenv("GNX_W64_FARM_PIPE") && getenv("GNX_W64_FARM_PIPE")[0] == '0'); // overlapped rounds (one launch each); 0: {fill, walk} launches
-    if (affine) hipLaunchKernelGGL(farm_init_kernel<true>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt, ckr);
-    else hipLaunchKernelGGL(farm_init_kernel<false>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt, 0);
+    if (affine) w64_rows_dispatch(rw, [&](auto rwc) { hipLaunchKernelGGL((farm_init_kernel<true, decltype(rwc)::value>), dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt, ckr); });
+    else hipLaunchKernelGGL((farm_init_kernel<false, R>), dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt, 0);
     const dim3 gf((unsigned)nt, (unsigned)np), gw((unsigned)np), gr((unsigned)nt + 1, (unsigned)np);
     const int2 *drb2 = reinterpret_cast<const int2 *>(drb);
     const int *drb1 = reinterpret_cast<const int *>(drb);
     auto launch_fill = [&](int par) {
         if (affine) {
-            if (p16) hipLaunchKernelGGL((al64_farm_fill_kernel<true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes, par);
-            else hipLaunchKernelGGL((al64_farm_fill_kernel<false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes, par);
+            w64_rows_dispatch(rw, [&](auto rwc) {
+                constexpr int RW = decltype(rwc)::value;
+                if (p16) hipLaunchKernelGGL((al64_farm_fill_kernel<RW, true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes, par);
+                else hipLaunchKernelGGL((al64_farm_fill_kernel<RW, false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes, par);
+            });
         } else {
             if (p16) hipLaunchKernelGGL((cl64_farm_fill_kernel<true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes, par);
             else hipLaunchKernelGGL((cl64_farm_fill_kernel<false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes, par);
@@ -635,8 +684,11 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
     };
     auto launch_round = [&](int par) {
         if (affine) {
-            if (p16) hipLaunchKernelGGL((al64_farm_round_kernel<true>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb2, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
-            else hipLaunchKernelGGL((al64_farm_round_kernel<false>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb2, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
+            w64_rows_dispatch(rw, [&](auto rwc) {
+                constexpr int RW = decltype(rwc)::value;
+                if (p16) hipLaunchKernelGGL((al64_farm_round_kernel<RW, true>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb2, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
+                else hipLaunchKernelGGL((al64_farm_round_kernel<RW, false>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb2, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
+            });
         } else {
             if (p16) hipLaunchKernelGGL((cl64_farm_round_kernel<true>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb1, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
             else hipLaunchKernelGGL((cl64_farm_round_kernel<false>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb1, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
@@ -651,8 +703,8 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
             if (pipe) launch_round((int)((rounds + r) & 1));
             else {
                 launch_fill(0);
-                if (affine) hipLaunchKernelGGL(farm_walk_kernel<true>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt, ckr);
-                else hipLaunchKernelGGL(farm_walk_kernel<false>, gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt, 0);
+                if (affine) w64_rows_dispatch(rw, [&](auto rwc) { hipLaunchKernelGGL((farm_walk_kernel<true, decltype(rwc)::value>), gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt, ckr); });
+                else hipLaunchKernelGGL((farm_walk_kernel<false, R>), gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt, 0);
             }
         }
         rounds += batch;
@@ -681,7 +733,8 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     Ctx &c = g_ctx;
     int rc;
     if (w64 && !rebase) w64 = false;
-    const int64_t HS = w64 ? H64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair
+    const int rw64 = (w64 && affine && w64_farm_tiles() > 0) ? t_w64_r : R; // rows per lane of the 64-lane kernels (the one-workgroup walks and ConstGap: R)
+    const int64_t HS = w64 ? (int64_t)G64 * rw64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair
     // snapshot spacing of the constant-gap form (const_long.hip.h): the wide tiles only when the walk will have the GPU full of long chains
     int64_t ckc = CKC_SMALL;
     {
@@ -700,7 +753,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     {
         int64_t rb = 0, sn = 0, sc = 0, bs = 0;
         int64_t budget = c.ws_limit - c.ws_limit / 16;
-        const int64_t rbw = affine ? 8 : 4, ck = affine ? ck_aff : ckc, snw = affine ? AL_SNAPW : SNAPW; // row-buffer entry bytes, snapshot spacing / dwords
+        const int64_t rbw = affine ? 8 : 4, ck = affine ? ck_aff : ckc, snw = affine ? (w64 ? al64_snapw(rw64) : AL_SNAPW) : SNAPW; // row-buffer entry bytes, snapshot spacing / dwords
         auto bytes_of = [&](int64_t rb2, int64_t sn2, int64_t sc2, int64_t bs2) { return rbw * rb2 + 4 * sn2 + (int64_t)sizeof(gnx_cigar) * sc2 + 8 * bs2; };
         auto nq_of = [&](int64_t m) { return rebase ? (((m + GS + 14) & ~(int64_t)15) / ck + 2) : 0; }; // K-step blocks of a strip (REBASE: one int64 base each)
         // One pair that needs more than the workspace limit (a 1 Mb x 1 Mb pair: 50 GB of bottom rows + 43 GB of snapshots) is given what
@@ -821,6 +874,8 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         KParams kps = kp, kpa = kp;
         kps.ckc = (int)ckc;
         kpa.ckc = (int)ck_aff; // (al64_sweep_kernel, the farm's re-fills)
+        if (w64 && affine) { g_last_w64_r = rw64; g_last_w64_ck = ck_aff; }
+        kpa.rb_pub = w64_pub();
         kps.rb_pub = n_blocks * per_item >= (int64_t)40 * c.n_cu ? 16 : RB_PUB; // (twice the wave slots of the piped sweep: 20 per CU)
         if (const char *e = getenv("GNX_CL_PUB")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) kps.rb_pub = v; }
         int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
@@ -833,8 +888,11 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
             if (p16) hipLaunchKernelGGL((cl64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
             else hipLaunchKernelGGL((cl64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
         } else if (w64) {
-            if (p16) hipLaunchKernelGGL((al64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kpa, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
-            else hipLaunchKernelGGL((al64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kpa, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            w64_rows_dispatch(rw64, [&](auto rwc) {
+                constexpr int RW = decltype(rwc)::value;
+                if (p16) hipLaunchKernelGGL((al64_sweep_kernel<RW, true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kpa, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                else hipLaunchKernelGGL((al64_sweep_kernel<RW, false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kpa, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            });
         } else if (affine) { if (rebase) { if (p16) GNX_AL_SWEEP(true, true); else GNX_AL_SWEEP(false, true); } else { if (p16) GNX_AL_SWEEP(true, false); else GNX_AL_SWEEP(false, false); } }
         else if (wg) hipLaunchKernelGGL(cl_sweep_wg_kernel<CLW_NW>, gridS, dim3(64 * CLW_NW), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
         else if (piped) { if (rebase) { if (p16) GNX_CL_SWEEP(true, true); else GNX_CL_SWEEP(false, true); } else { if (p16) GNX_CL_SWEEP(true, false); else GNX_CL_SWEEP(false, false); } }
@@ -930,7 +988,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         fill_ms += f1; tb_ms += f2;
         for (int64_t p = b; p < e; p++) {
             const PairPlan &pl = plans[(size_t)p];
-            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + GS - 1) / (affine ? ck_aff : ckc)) * pl.strips * GS * (affine ? AL_SNAPW : SNAPW);
+            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + GS - 1) / (affine ? ck_aff : ckc)) * pl.strips * GS * (affine ? (w64 ? al64_snapw(rw64) : AL_SNAPW) : SNAPW);
         }
     }
     HIPCHK(hipEventRecord(c.ev[2], stream));
@@ -973,9 +1031,10 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                     int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool w64) {
     Ctx &c = g_ctx;
     int rc;
-    const int64_t HS = w64 ? H64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair (w64: affine_long64.hip.h / const_long64.hip.h)
+    const int rw64 = (w64 && affine && w64_farm_tiles() > 0) ? t_w64_r : R; // rows per lane of the 64-lane kernels (the one-workgroup walks and ConstGap: R)
+    const int64_t HS = w64 ? (int64_t)G64 * rw64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair (w64: affine_long64.hip.h / const_long64.hip.h)
     const int np = (int)n_pairs;
-    const int64_t ck = affine ? ((w64 && w64_farm_tiles() > 0) ? t_w64_ck : CKA) : CKC_SMALL, snw = affine ? AL_SNAPW : SNAPW, rbw = affine ? 8 : 4;
+    const int64_t ck = affine ? ((w64 && w64_farm_tiles() > 0) ? t_w64_ck : CKA) : CKC_SMALL, snw = affine ? (w64 ? al64_snapw(rw64) : AL_SNAPW) : SNAPW, rbw = affine ? 8 : 4;
     bool p16 = true;
     for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * (affine ? prm->gap_extend : prm->gap_open)) + 1; if (v > 32767 || v < -32768) p16 = false; }
     std::vector<int64_t> so((size_t)np + 1, 0), h_start((size_t)np * 2);
@@ -1091,7 +1150,8 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             long long *dbs = reinterpret_cast<long long *>(c.cl_bases.p);
             int *dsn = forward ? nullptr : reinterpret_cast<int *>(c.fp_ckpt.p); // (null: the sweep keeps no snapshots)
             KParams kps = kp;
-            kps.ckc = (int)ck; kps.rb_pub = RB_PUB;
+            kps.ckc = (int)ck; kps.rb_pub = w64 ? w64_pub() : RB_PUB;
+            if (w64 && affine) { g_last_w64_r = rw64; g_last_w64_ck = ck; }
             const dim3 gridS((unsigned)local);
             HIPCHK(hipEventRecord(c.ev[1], stream));
             if (w64 && !affine) {
@@ -1100,8 +1160,11 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                 else hipLaunchKernelGGL((cl64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
             } else if (w64) {
                 int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
-                if (p16) hipLaunchKernelGGL((al64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
-                else hipLaunchKernelGGL((al64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                w64_rows_dispatch(rw64, [&](auto rwc) {
+                    constexpr int RW = decltype(rwc)::value;
+                    if (p16) hipLaunchKernelGGL((al64_sweep_kernel<RW, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                    else hipLaunchKernelGGL((al64_sweep_kernel<RW, false>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                });
             } else if (affine) {
                 int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
                 if (p16) hipLaunchKernelGGL((al_sweep_kernel<true, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
@@ -1614,7 +1677,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // moving bases: what a strip holds at one time -- 160 rows x 16 columns of an anti-diagonal band, the row above, the snapshot -- must fit
         // int32 around the strip's base: neighbouring cells differ by at most one substitution score + two gap opens + two extensions
         const int64_t step4 = 4 * (max_abs_pen(prm, false) + 2 * llabs((long long)prm->gap_open) + (affine ? 2 * llabs((long long)prm->gap_extend) : 0));
-        const bool spread_ok = (int64_t)(H + G + 64) * step4 < ((int64_t)1 << 28);
+        const bool spread_ok = (int64_t)(H + G + std::max(CKC, CKA) + 64) * step4 < ((int64_t)1 << 28); // (a strip moves its base every snapshot: the keys drift that many steps in between)
         const char *rbe = getenv("GNX_REBASE");
         const bool rebase = spread_ok && (oor || (rbe && rbe[0] == '1')); // GNX_REBASE=1 (tests): every pair of this path on moving bases
         if (oor && !spread_ok) use = false;
@@ -1625,11 +1688,13 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const char *w64e = getenv("GNX_W64");
         bool few_long = n_pairs <= 64 && w64_farm_tiles() > 0;
         for (int64_t p = 0; few_long && p < n_pairs; p++) if (h_alen[p] < 2 * H64) few_long = false;
+        t_w64_r = R;
         // (steps between two moves of a strip's base: the widest snapshot spacing the keys' spread admits, for the farm's affine sweep)
         t_w64_ck = CKA;
         if (affine && w64_farm_tiles() > 0) for (int v = w64_farm_ck(); v > CKA; v >>= 1) if ((int64_t)(H64 + G64 + v + 64) * step4 < ((int64_t)1 << 28)) { t_w64_ck = v; break; }
         const int64_t ck_w64 = std::max<int64_t>(CKC64, t_w64_ck);
         const bool w64 = !no_pipe() && (int64_t)(H64 + G64 + ck_w64 + 64) * step4 < ((int64_t)1 << 28) && !(w64e && w64e[0] == '0') && (n_pairs <= 3 || few_long || (w64e && w64e[0] == '2'));
+        if (w64 && affine && w64_farm_tiles() > 0) t_w64_r = w64_pick_rows(c, n_pairs, h_alen, h_blen, step4, t_w64_ck);
         long double cells_ld = 0, dir_bytes = 0, rows_ld = 0, cols_ld = 0;
         for (int64_t p = 0; use && p < n_pairs; p++) {
             if (h_alen[p] < 1 || h_blen[p] < 1) use = false;
@@ -2826,17 +2891,25 @@ int gnx_debug_counter(int which, int reset, int64_t *out) {
     std::lock_guard<std::mutex> api(g_api_mu);
     CtxScope sc(ctx_at(0));
     g_err[0] = 0;
-    if (which < 0 || which > 2 || !out) { set_err("bad argument%s", ""); return GNX_EINVAL; }
-    if (which > 0) { // combined gnx_align_pair batches run / pairs served by them
+    if (which < 0 || which > 6 || !out) { set_err("bad argument%s", ""); return GNX_EINVAL; }
+    if (which == 1 || which == 2) { // combined gnx_align_pair batches run / pairs served by them
         *out = which == 1 ? g_pq_batches.load() : g_pq_pairs.load();
         if (reset) { if (which == 1) g_pq_batches = 0; else g_pq_pairs = 0; }
         return GNX_OK;
     }
+    if (which >= 5) { *out = which == 5 ? g_last_w64_r.load() : g_last_w64_ck.load(); return GNX_OK; } // geometry of the last 64-lane affine sweep
     int rc = ensure_init();
     if (rc) return rc;
     HIPCHK(hipSetDevice(g_ctx.device));
     HIPCHK(hipDeviceSynchronize());
     unsigned long long v = 0;
+    if (which >= 3) { // quirk-Q1 restarts of the snapshot path's affine walks: 3 = those that changed the state, 4 = all
+        unsigned long long q[2] = {0, 0};
+        HIPCHK(hipMemcpyFromSymbol(q, HIP_SYMBOL(g_dev_q1), sizeof(q)));
+        if (reset) { const unsigned long long z[2] = {0, 0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dev_q1), z, sizeof(z))); }
+        *out = (int64_t)(which == 3 ? q[1] : q[0]);
+        return GNX_OK;
+    }
     HIPCHK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_dev_claims_stolen), sizeof(v)));
     if (reset) { const unsigned long long z = 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dev_claims_stolen), &z, sizeof(z))); }
     *out = (int64_t)v;

@@ -199,6 +199,14 @@ __device__ __forceinline__ int rb_progress(const int *prog) {
 #define GNX_CLAIM_GRACE_US 20000
 #endif
 constexpr long long CLAIM_GRACE_TICKS = 100LL * GNX_CLAIM_GRACE_US; // ticks of the 100 MHz wall clock
+// quirk Q1 (align/affineGap.go:305) as the walks of the snapshot path met it: [0] checkerboard edges crossed upwards with the restart rule applied, [1] those where the
+// argmax state of the entry cell differed from the traced state -- the crossings that change the CIGAR (gnx_debug_counter(3 / 4); tests/test_long_range.py bounds the
+// re-score deficit of a megabase CIGAR with it)
+__device__ unsigned long long g_dev_q1[2];
+__device__ __forceinline__ void q1_report(int n, int changed) {
+    if (n > 0) atomicAdd(&g_dev_q1[0], (unsigned long long)n);
+    if (changed > 0) atomicAdd(&g_dev_q1[1], (unsigned long long)changed);
+}
 __device__ unsigned long long g_dev_claims_stolen; // items run by a workgroup other than their own (gnx_debug_counter(0): the tests prove the abnormal paths ran)
 // The test switch word cw[n_items]: bits 0-15 = GNX_TICKET_DELAY (sleep units of the lower half of the grid), bits 16-31 =
 // GNX_CLAIM_GRACE_US (a grace period in microseconds for this launch instead of the compiled-in 20 ms: a delay longer than the grace

@@ -193,6 +193,10 @@ int gnx_debug_occupy(int n_workgroups, int milliseconds); /* refused with GNX_EI
 /* Diagnostics: which = 0: number of items of pipelined launches (strips, row-block levels) that were run by a workgroup other
  * than their own since the last reset -- the abnormal path of the claim protocol, which tests/test_ticket.py forces and then
  * proves to have run.  which = 1 / 2: combined batches run for concurrent gnx_align_pair calls / pairs served by them.
+ * which = 3 / 4: checkerboard edges the affine walks of the snapshot path crossed upwards where the restart rule of
+ * /root/reference/align/affineGap.go:305 (quirk Q1) changed the state / all such crossings -- each of the former can cost the CIGAR
+ * at most one gap open against the score, which is what the tests of megabase pairs (no oracle finishes them) check.
+ * which = 5 / 6: rows per lane / snapshot spacing of the last 64-lane affine sweep (bench.py prices its design bytes with them).
  * reset != 0 zeroes the counter after reading. */
 int gnx_debug_counter(int which, int reset, int64_t *out);
 

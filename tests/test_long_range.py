@@ -202,7 +202,7 @@ def test_row_panels_forced(gpu_lib, monkeypatch, mode, strips):
 
 
 @pytest.mark.parametrize("cs", [3, 16, 10000])
-@pytest.mark.parametrize("walk", ["farm", "farm1", "farm3", "farm32", "farm:seq", "farm3:seq", "farm:ck128", "farm3:ck256", "two_waves", "one_wave"])  # the walk farm (farm64.hip.h: 16 / 1 / 3 / 32 tiles per round, overlapped rounds or {fill, walk} launches), al64_walk2_kernel / cl64_walk2_kernel (the left neighbour tile re-filled by a second wave) or the one-wave kernels
+@pytest.mark.parametrize("walk", ["farm", "farm1", "farm3", "farm32", "farm:seq", "farm3:seq", "farm:ck128", "farm3:ck256", "farm:r6", "farm:r8", "farm:r16", "farm3:r6:seq", "farm1:r16:ck128", "farm32:r8:ck256", "two_waves", "one_wave"])  # the walk farm (farm64.hip.h: 16 / 1 / 3 / 32 tiles per round, overlapped rounds or {fill, walk} launches), al64_walk2_kernel / cl64_walk2_kernel (the left neighbour tile re-filled by a second wave) or the one-wave kernels
 @pytest.mark.parametrize("mode", [0, 1, 2, 4])  # AffineGap, ConstGap, AffineGap_highMem, ConstGap_highMem
 def test_w64_forced(gpu_lib, monkeypatch, mode, cs, walk):
     """GNX_CLONG=2 + GNX_W64=2: every pair through the snapshot path with the whole wave on one pair (affine_long64.hip.h / const_long64.hip.h:
@@ -213,9 +213,13 @@ def test_w64_forced(gpu_lib, monkeypatch, mode, cs, walk):
     monkeypatch.delenv("GNX_W64_FARM", raising=False)
     monkeypatch.delenv("GNX_W64_FARM_PIPE", raising=False)
     monkeypatch.delenv("GNX_W64_CK", raising=False)
+    monkeypatch.setenv("GNX_W64_R", "10")  # rows per lane of the affine sweep + farm (round 6: 6 / 8 / 10 / 16, strips of 384 .. 1 024 rows; w64_pick_rows chooses by the strip count)
     if walk.endswith(":seq"):
         monkeypatch.setenv("GNX_W64_FARM_PIPE", "0")
         walk = walk[:-4]
+    if ":r" in walk:
+        monkeypatch.setenv("GNX_W64_R", walk.split(":r")[1].split(":")[0])
+        walk = walk.replace(":r" + walk.split(":r")[1].split(":")[0], "")
     if ":ck" in walk:  # snapshot spacing of the affine sweep under the farm (default 512 steps)
         monkeypatch.setenv("GNX_W64_CK", walk.split(":ck")[1])
         walk = walk.split(":ck")[0]
@@ -258,7 +262,7 @@ def test_w64_is_the_route_of_few_pairs(gpu_lib, monkeypatch, mode):
                 common.assert_same(got, exp, "%d pairs cs %d" % (npairs, cs))
 
 
-@pytest.mark.parametrize("strips", ["2", "3", "3:farm2", "2:farm_seq", "2:farm_ck128", "2:two_waves", "2:one_wave"])
+@pytest.mark.parametrize("strips", ["2", "3", "3:farm2", "2:farm_seq", "2:farm_ck128", "2:farm_r6", "3:farm_r8", "2:farm_r16", "2:two_waves", "2:one_wave"])
 @pytest.mark.parametrize("mode", [0, 1, 2, 4])
 def test_w64_row_panels(gpu_lib, monkeypatch, mode, strips):
     """row panels (run_device_mega) of k strips of 640 rows in the 64-lane geometry: the stand-in strip, MegaState across panel borders;
@@ -266,6 +270,7 @@ def test_w64_row_panels(gpu_lib, monkeypatch, mode, strips):
     monkeypatch.delenv("GNX_W64_FARM", raising=False)
     monkeypatch.delenv("GNX_W64_FARM_PIPE", raising=False)
     monkeypatch.delenv("GNX_W64_CK", raising=False)
+    monkeypatch.setenv("GNX_W64_R", strips.split(":farm_r")[1] if ":farm_r" in strips else "10")  # rows per lane of the affine sweep + farm
     if strips.endswith(":farm_ck128"):
         monkeypatch.setenv("GNX_W64_CK", "128")
     if strips.endswith(":farm_seq"):

@@ -19,7 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-FIXTURE = os.path.join(ROOT, "tests", "golden", "long_pairs.json")
+FIXTURE = os.environ.get("LONG_PAIRS_FIXTURE") or os.path.join(ROOT, "tests", "golden", "long_pairs.json")
 
 # name -> (affine, n, extra columns, seed).  The static bound: 4 * (score - e (i + j)) grows by up to 4 * (100 + 2 * 150) per diagonal step
 # (ConstGap: 4 * (100 + 2 * 430)), so the keys pass 2^29 from min(n, m) = 335 544 (ConstGap: 139 810) on.
@@ -30,9 +30,12 @@ CASES = {
     "const_300k_2M": (False, 300000, 0, 1235),
     "affine_2M": (True, 2000000, 0, 1236),      # 4e12 cells: bottom rows + snapshots of all strips would be 500 GB -> row panels (run_device_mega)
     "affine_5M": (True, 5000000, 0, 1237),      # 2.5e13 cells: the size of the cmd/cigarToBed fixture the reference ships (.MISSING_LARGE_BLOBS:1-3)
+    # quirk Q1 on purpose (align/affineGap.go:305): beta lacks the bases of alpha around EVERY row 10 000 k, so the walk crosses each checkerboard
+    # edge upwards inside a D run and restarts in the argmax state of the entry cell (29 crossings; the CIGAR re-scores below the score)
+    "affine_q1_300k": (True, 300000, 0, 1238),
 }
 DEFAULT_GPU_CASES = ("const_150k", "affine_340k", "affine_1M", "const_300k_2M", "affine_2M")
-ORACLE_CASES = ("affine_340k", "const_150k")
+ORACLE_CASES = ("affine_340k", "const_150k", "affine_q1_300k", "affine_1M")
 
 
 def gen(name):
@@ -44,6 +47,13 @@ def gen(name):
         a = common.mutate(rng, win[700000:700000 + n + 3000], sub=0.03, indel=0.004, geo=0.5)[:n]
         return affine, a, win
     a = rng.integers(0, 4, size=n).astype(np.uint8)
+    if name == "affine_q1_300k":
+        keep = np.ones(n, dtype=bool)
+        for k in range(1, (n - 5000) // 10000 + 1):
+            run = int(rng.integers(3, 120))
+            below = int(rng.integers(1, run))  # rows of the run below the edge (alpha[10 000 k] is row 10 000 k + 1)
+            keep[10000 * k - (run - below):10000 * k + below] = False
+        return affine, a, common.mutate(rng, a[keep], sub=0.01, indel=0.0005, geo=0.4)
     b = common.mutate(rng, a, sub=0.02, indel=0.002, geo=0.4)
     if extra:
         b = np.concatenate([b, rng.integers(0, 4, size=extra).astype(np.uint8)])
@@ -64,7 +74,6 @@ def params(affine):
 
 def run_oracle(names):
     import oracle
-    fx = json.load(open(FIXTURE)) if os.path.exists(FIXTURE) else {}
     for name in names:
         affine, a, b = gen(name)
         sc, go, ge = params(affine)
@@ -72,6 +81,7 @@ def run_oracle(names):
         s, ops, off = oracle.align_batch(oracle.MODE_AFFINE if affine else oracle.MODE_CONST, sc, go, ge, [a], [b], 10000, 10000, threads=1)
         d = digest(s[0], ops)
         d.update({"n": int(a.shape[0]), "m": int(b.shape[0]), "oracle_s": round(time.time() - t0, 1)})
+        fx = json.load(open(FIXTURE)) if os.path.exists(FIXTURE) else {}  # (read again: several of these may run side by side, hours each)
         fx[name] = d
         print(name, d, flush=True)
         with open(FIXTURE, "w") as fh:
