@@ -372,7 +372,21 @@ def extra_c5(_lib, L, scores, chunk_h, dev, torch, n_pairs=1024, n=20000, m=1000
     return {"entry": "gnx_align_batch_device (GNX_CONST_GAP)", "pairs": n_pairs, "value": cells / dt, "unit": "DP cells/s", "ms_per_step": dt * 1e3,
             "path": {0: "general_path", 1: "fast_path", 2: "const_long", 3: "latency_geometry", 4: "int64_fallback", 5: "row_panels", 6: "const_long_w64"}[tm["fast_path"]], "bit_exact_sample": okk, "bit_exact_pairs_checked": int(pick.shape[0]),
             "kernel_ms": {"sweep": tm["dominant_ms"], "walk_and_rest": tm["traceback_ms"]},
-            "roofline": _roofline_of(tm, n, m, 2, n_pairs, int(off[-1]))}
+            "roofline": _roofline_of(tm, n, m, 2, n_pairs, int(off[-1])),
+            # the BINDING ceiling of the constant-gap sweep: VALU issue.  The floor of the recurrence is two instructions per cell
+            # (add_sdwa, max3 -- both half rate: 1.84 ns per wave-instruction slot and SIMD at >= 2 waves, profiles/r3_valu_ubench4.txt); a 20 kb read is
+            # 125 strips of 160 rows = 10 rows in each of 16 lanes, four pairs share a wave
+            "roofline_valu": _c5_valu_floor(tm, n, m, n_pairs, torch.cuda.get_device_properties(dev).multi_processor_count)}
+
+
+def _c5_valu_floor(tm, n, m, n_pairs, n_cu):
+    strips = -(-n // 160)
+    slots = n_pairs * strips * (m + 15) * 10 * 2 / 4.0  # wave-instruction slots of the floor: (steps of a strip) x 10 rows x 2 instructions, 4 pairs per wave
+    floor_ms = slots * 1.84e-9 / (4 * n_cu) * 1e3
+    return {"bound": "valu", "floor_ms": floor_ms, "frac_of_floor": floor_ms / tm["dominant_ms"],
+            "floor_model": "2 instructions per cell (add_sdwa, max3) x 1.84 ns per wave-instruction slot and SIMD (measured issue rate of half-rate VALU instructions at >= 2 waves per "
+                           "SIMD, profiles/r3_valu_ubench4.txt) / (4 SIMDs x %d CUs); the kernel's own block of 16 steps is 1 DPP move + 10 x (add, max3) + ring address per step "
+                           "(const_long_wg.hip.h): ~2.3 instructions per cell" % n_cu}
 
 
 def extra_gsw(_lib, L, scores, chunk_h, dev, torch, n_reads=20000, n_check=48):
@@ -432,36 +446,55 @@ def extra_n1(_lib, L, scores, chunk_h, dev, torch):
     return out
 
 
-def long_pair_roofline(d):
-    """HBM roofline of the score-only sweep of ONE long pair on the 64-lane snapshot kernels, from the leg's own timing: algorithmic bytes =
-    the bottom row of every 640-row strip but the last, written and read once (AffineGap 8 B per column: {dn, h}; ConstGap 4 B), + a snapshot of the wavefront
-    (AffineGap 24 dwords x 64 lanes every 512 steps; ConstGap 12 dwords every 224).  The fraction is small by construction -- the kernel is bound by the VALU issue of
-    its ~1 wave per SIMD (profiles/r5_pmc_long_pair.txt) -- and is reported because the contract asks for it."""
+def long_pair_roofline(d, geo=None, pmc=None):
+    """HBM roofline of ONE long pair on the 64-lane snapshot kernels with the bytes of SURVEY 8d, like every other leg: n + m input bases +
+    ceil(b n m / 8) direction bits (b = 6 AffineGap, 2 ConstGap) + ceil(b (n + m) / 8) read along the path + 8 (score) + 16 per CIGAR run -- `frac` over the sweep
+    kernel's time (the dominant kernel), `frac_call` over the whole call.  `traffic_model`: the bytes THIS design moves instead of a direction matrix -- the bottom
+    row of every strip but the last, written and read once (AffineGap 8 B per column: {dn, h}; ConstGap 4 B), + a snapshot of the wavefront per strip every K steps
+    ((2 RW + 2 -> multiple of 4) dwords x 64 lanes; geo = (rows per lane, K) of the call, gnx_debug_counter(5 / 6)); `traffic`: the PMC bytes per launch when the
+    committed counters belong to these kernel sources.  The binding ceiling is the VALU issue of the pair's strips (one wave each), not memory."""
     affine = d["fn"].startswith("AffineGap")
-    strips = -(-d["n"] // 640)
-    rows = (8 if affine else 4) * (d["m"] + 1) * max(strips - 1, 0) * 2
-    snaps = ((d["m"] + 63) // (512 if affine else 224)) * strips * 64 * (24 if affine else 12) * 4
+    bits = 6 if affine else 2
+    n, m = d["n"], d["m"]
+    rw, ck = geo if (affine and geo) else (10, 512 if affine else 224)
+    strips = -(-n // (64 * rw))
+    rows = (8 if affine else 4) * (m + 1) * max(strips - 1, 0) * 2
+    snaps = ((m + 63) // ck) * strips * 64 * (((2 * rw + 2 + 3) & ~3) if affine else 12) * 4
+    alg = n + m + -(-bits * n * m // 8) + -(-bits * (n + m) // 8) + 8 + 16 * d["runs"]
     secs = d["sweep_ms"] * 1e-3
-    ach = (rows + snaps) / secs / 1e9
-    return {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "algorithmic_bytes_per_launch": rows + snaps,
-            "cells_per_s_kernel": d["cells"] / secs, "waves": strips, "note": "binding ceiling: VALU issue at ~1 wave per SIMD (strips / 1024 SIMDs)"}
+    ach = alg / secs / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "frac_call": alg / d["call_s"] / 8e12, "algorithmic_bytes_per_launch": alg,
+            "bytes_model": "SURVEY 8d: n + m + ceil(%d n m / 8) + ceil(%d (n + m) / 8) + 8 + 16 |cigar|" % (bits, bits),
+            "traffic_model": {"bytes_per_launch": rows + snaps, "GB_per_s": (rows + snaps) / secs / 1e9, "rows_per_lane": rw, "snapshot_steps": ck,
+                              "what": "bottom rows of the strips written + read once, wavefront snapshots written (this design keeps no direction matrix)"},
+            "traffic": pmc, "cells_per_s_kernel": d["cells"] / secs, "waves": strips,
+            "note": "binding ceiling: VALU issue of the pair's strips (one wave each on 1 024 SIMDs), see DESIGN 4.13"}
 
 
 def extra_long_pairs(_lib, L, scores, chunk_h, dev, torch):
     """ONE long pair per call -- what cmd/cigarToBed (cigarToBed.go:86) and cmd/globalAlignment (globalAlignment.go:84) hand to align.AffineGap / ConstGap: the 64-lane
-    snapshot kernels + walk farm.  AffineGap 340 kb x 340 kb and ConstGap 150 kb x 180 kb against the digests of the CPU oracle's results
-    (tests/golden/long_pairs.json: 895 s / 185 s of one core), AffineGap 1 Mb x 1 Mb (1e12 cells) by what its CIGAR must satisfy (tools/long_pairs.py)."""
+    snapshot kernels + walk farm.  Every pair that has a CPU-oracle digest in tests/golden/long_pairs.json must equal it (ConstGap 150 kb x 180 kb,
+    AffineGap 340 kb x 340 kb, the quirk-Q1 pair 300 kb x 298 kb, AffineGap 1 Mb x 1 Mb: 185 s .. 2 h of one core each); without one, the CIGAR must consume both
+    sequences and re-score (int64) to within 600 x (quirk-Q1 restarts that changed the walk's state) below the score -- and to the score itself when there was none."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import long_pairs
-    rows = list(long_pairs.gpu_rows(["const_150k", "affine_340k", "affine_1M"], reps=2))
-    keep = ("case", "fn", "n", "m", "cells", "call_s", "first_call_s", "sweep_ms", "walk_ms", "cells_per_s_call", "workspace_bytes", "route", "score", "runs", "consumes_n_m", "rescored_equals_score", "equals_oracle")
-    ok = all(r["consumes_n_m"] and r.get("equals_oracle", True) and r["rescored_minus_score"] % 600 == 0 for r in rows)
+    rows = list(long_pairs.gpu_rows(["const_150k", "affine_340k", "affine_q1_300k", "affine_1M"], reps=2))
+    keep = ("case", "fn", "n", "m", "cells", "call_s", "first_call_s", "sweep_ms", "walk_ms", "cells_per_s_call", "workspace_bytes", "route", "score", "runs", "consumes_n_m",
+            "rescored_equals_score", "rescored_minus_score", "q1_restarts", "q1_restarts_changed", "equals_oracle", "rows_per_lane", "snapshot_steps")
+    ok = all(long_pairs.row_ok(r) for r in rows)
     pairs = [{k: r[k] for k in keep if k in r} for r in rows]
+    pmc = None
+    try:  # HBM bytes per launch of the 1 Mb sweep from the committed counter passes, if they belong to these kernel sources
+        with open(os.path.join(ROOT, "profiles", "r6_pmc_long_pair.json")) as fh:
+            pj = json.load(fh)
+        pmc = pj if pj.get("kernel_source_hash") == kernel_source_hash() else {"stale": "collected from other kernel sources (commit %s)" % pj.get("commit")}
+    except (OSError, ValueError):
+        pass
     for d in pairs:
-        d["sweep_roofline"] = long_pair_roofline(d)
+        d["sweep_roofline"] = long_pair_roofline(d, (d.get("rows_per_lane", 10), d.get("snapshot_steps", 512)), (pmc or {}).get(d["case"]) if pmc and "stale" not in pmc else pmc)
     return {"entry": "gnx_align_batch (one pair per call, host buffers)", "pairs": pairs, "bit_exact_sample": bool(ok),
-            "checked_against": "sha256 of the CPU oracle's CIGAR (const_150k, affine_340k); consumed lengths and int64 re-score (affine_1M: no oracle finishes it)"}
+            "checked_against": "sha256 of the CPU oracle's CIGAR where tests/golden/long_pairs.json holds one; else consumed lengths + int64 re-score bounded by the quirk-Q1 restarts the walk reports"}
 
 
 def one_process_flow(_lib, L, world, params, reads_h, chunk_h, n_pairs, same, steps, share_gpu=False):
@@ -566,7 +599,12 @@ def main():
         h_bs = np.zeros(n_pairs, dtype=np.int64)
         beta_h = chunk_h
     else:
-        # C5: every pair has its own window (independent pairs; nothing to broadcast)
+        # C5: every pair has its own window (independent pairs; nothing to broadcast).  ONE shared list of world x n_pairs pairs, cut into contiguous blocks
+        # of equal DP cells (shard.partition_by_cells); block r of the list is generated from seed 5 + 1000 r, so a rank builds only its own
+        shared_alen = np.full(n_pairs * world, READ_LEN, dtype=np.int64)
+        shared_blen = np.full(n_pairs * world, CHUNK_LEN, dtype=np.int64)
+        bounds = shard.partition_by_cells(shared_alen, shared_blen, world) if world > 1 else np.asarray([0, n_pairs])
+        assert int(bounds[rank]) == rank * n_pairs and int(bounds[rank + 1]) == (rank + 1) * n_pairs, bounds  # (equal pairs: equal counts)
         reads_h, wins_h = make_long_workload(5 + 1000 * rank, n_pairs, READ_LEN, CHUNK_LEN)
         d_chunk = torch.from_numpy(wins_h.reshape(-1)).to(dev)
         h_bs = np.arange(n_pairs, dtype=np.int64) * CHUNK_LEN
@@ -721,6 +759,7 @@ def main():
     # ---- after the timed region: verification + the other legs (rank 0) ----
     ok = True
     gathered_pairs = n_pairs
+    gather_order_ok = None
     if n_verify > 0:
         import oracle
         k = min(n_verify, n_pairs)
@@ -733,9 +772,22 @@ def main():
         # final gather of scores / CIGAR offsets / CIGAR blob on rank 0, in input order (outside the timed region)
         n_ops_local = int(d_off[n_pairs].item())
         gathered = shard.gather_results(d_score, d_ops[: n_ops_local * 16], d_off, dst=0)
+        # the gathered arrays are in INPUT order (rank r's block at pairs [r n, (r + 1) n)): every rank reports its block's first / last score, run counts and
+        # a sum of its run lengths; rank 0 finds them at those places of what it gathered
+        ops_local = d_ops[: n_ops_local * 16].view(torch.int64).view(-1, 2)[:, 0] if n_ops_local else torch.zeros(0, dtype=torch.int64, device=dev)
+        sig = torch.stack([d_score[0], d_score[n_pairs - 1], d_off[1] - d_off[0], d_off[n_pairs] - d_off[n_pairs - 1], ops_local.sum()]).to(torch.int64)
+        sigs = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
         if rank == 0:
             gathered_pairs = int(gathered[0].numel())
             ok = ok and gathered_pairs == n_pairs * world and int(gathered[2][-1].item()) * 16 == gathered[1].numel()
+            gather_order_ok = gathered_pairs == n_pairs * world
+            g_sc, g_ops, g_off = gathered[0], gathered[1].view(torch.int64).view(-1, 2)[:, 0], gathered[2]
+            for r in range(world if gather_order_ok else 0):
+                b0, b1 = r * n_pairs, (r + 1) * n_pairs
+                mine = torch.stack([g_sc[b0], g_sc[b1 - 1], g_off[b0 + 1] - g_off[b0], g_off[b1] - g_off[b1 - 1], g_ops[int(g_off[b0].item()):int(g_off[b1].item())].sum()])
+                gather_order_ok = gather_order_ok and bool(torch.equal(mine, sigs[r]))
+            ok = ok and gather_order_ok
     if rank == 0:
         cells_per_step = n_pairs * READ_LEN * CHUNK_LEN * world
         value = cells_per_step * args.steps / dt
@@ -750,7 +802,8 @@ def main():
         kernel = {0: "fill_affine_kernel (full direction matrix)" if S["bits"] == 6 else "fill_const_kernel (full direction matrix)",
                   1: "fp_sweep_kernel<%d, %s> (fast-path forward sweep)" % (19 if READ_LEN <= 152 else 20, "true" if swap else "false"),
                   2: "cl_sweep_wg_kernel<4> (score-only constant-gap sweep with wavefront snapshots, four strips per workgroup handing rows over through LDS)",
-                  3: "lat_fill_kernel (one pair per wave, 64 lanes x 2 rows, full direction matrix)", 4: "lat_wide_kernel (int64 keys)"}[fast_path]
+                  3: "lat_fill_kernel (one pair per wave, 64 lanes x 2 rows, full direction matrix)", 4: "lat_wide_kernel (int64 keys)",
+                  5: "al64_sweep_kernel / cl64_sweep_kernel in row panels (run_device_mega)", 6: "al64_sweep_kernel / cl64_sweep_kernel (64 lanes per pair, score only, snapshots)"}.get(fast_path, path)
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), valid
         # only for the kernel sources they were taken from
         traffic, traffic_note, pmc = None, None, None
@@ -780,7 +833,7 @@ def main():
             "pairs_per_s": n_pairs * world * args.steps / dt,
             "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms,
                                      "note": "each rank's own K steps / K, before the closing barrier (ms_per_step is the max-over-ranks clock around both barriers)"},
-            "gathered_pairs": gathered_pairs,
+            "gathered_pairs": gathered_pairs, "gather_order_ok": (gather_order_ok if world > 1 else None),
             "value_definition": ("SURVEY 8d: sum n*m over pairs / wall time of K calls of the host-buffer entry point (H2D of reads, windows and offset tables + plans + "
                                  "kernels + D2H of scores / offsets / CIGAR runs into pinned host arrays); the chunk upload is part of every call")
                                 if host_timed else "inputs and outputs resident in HBM (gnx_align_batch_device)",

@@ -1060,8 +1060,25 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             budget = std::max(budget, avail / 2);
         }
     }
-    budget -= scr_b + (m_hi + 1) * rbw * 16; // (the saved panel boundaries, mega_rows: one row per backward panel -- a dozen)
-    int64_t Sb = budget / (strip_bwd_hi + strip_bwd_hi / 8) - 3, Sf = budget / (strip_fwd_hi + strip_fwd_hi / 8) - 3; // strips per backward / forward panel (/ 8: DevBuf::ensure's slack)
+    budget -= scr_b;
+    // the saved panel boundaries (mega_rows: one row + its bases per backward panel) come out of the same budget: size the panels, count them, size again
+    int64_t Sb = 0, Sf = 0, rows_hi = 0;
+    {
+        int64_t n_hi = 1;
+        for (int64_t p = 0; p < n_pairs; p++) n_hi = std::max(n_hi, h_alen[p]);
+        const int64_t strips_hi = (n_hi + HS - 1) / HS, top_hi = (m_hi + 1) * rbw + nq_hi * 8;
+        int64_t tops = 16 * top_hi;
+        for (int pass = 0; pass < 3; pass++) {
+            const int64_t b2 = budget - tops - tops / 8;
+            Sb = b2 / (strip_bwd_hi + strip_bwd_hi / 8) - 3; Sf = b2 / (strip_fwd_hi + strip_fwd_hi / 8) - 3; // strips per backward / forward panel (/ 8: DevBuf::ensure's slack)
+            if (Sb < 2) break;
+            const int64_t need = ((strips_hi + Sb - 1) / Sb) * top_hi;
+            if (need <= tops) break;
+            tops = need;
+        }
+        rows_hi = tops;
+    }
+    (void)rows_hi;
     if (const char *e = getenv("GNX_MEGA_STRIPS")) { Sb = atoll(e); Sf = 2 * Sb; } // (tests: panels of a few strips, forward panels of two backward ones)
     if (Sb < 2) { set_err("a single strip of pair %s%lld does not fit the workspace", "", 0); return GNX_ENOMEM; }
     const bool forced_panels = getenv("GNX_MEGA_STRIPS") != nullptr;

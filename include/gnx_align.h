@@ -40,7 +40,11 @@ extern "C" {
 #define GNX_EINVAL 1    /* bad argument (null pointer, negative size, unknown mode) */
 #define GNX_EBASE 2     /* a base >= 5: the Go code would panic */
 #define GNX_EEMPTY 3    /* empty sequence in a low-memory mode: the Go code would never terminate */
-#define GNX_ERANGE 4    /* lengths x penalties exceed the int32 range of a mode that keeps absolute keys (AffineGapLocal, gapOpen > 0, chunk / graph variants; global AffineGap / ConstGap have no length limit) */
+#define GNX_ERANGE 4    /* lengths x penalties exceed the int32 range of a mode that keeps absolute keys (the chunk / graph-extension variants).  The align functions
+                         * proper (AffineGap*, ConstGap*, AffineGapLocal) have no range limit: what bounds them is (a) 2^30 - 1 bases per sequence -- longer: GNX_EINVAL --
+                         * and (b) device memory: a pair whose bottom rows + snapshots fit neither the snapshot path nor row panels, or whose stored matrix (the int64
+                         * kernel: AffineGapLocal, gapOpen > 0 beyond int32) does not fit, returns GNX_ENOMEM, not GNX_ERANGE.  A single oversize pair is given what the
+                         * device has free, beyond the workspace limit of gnx_init (it cannot run any other way). */
 #define GNX_EDEVICE 5   /* no HIP device / HIP runtime error */
 #define GNX_ENOMEM 6    /* host or device allocation failed / workspace too small for one pair */
 #define GNX_ECAPACITY 7 /* caller-provided device CIGAR buffer too small (device entry point) */
@@ -197,7 +201,7 @@ int gnx_debug_occupy(int n_workgroups, int milliseconds); /* refused with GNX_EI
  * /root/reference/align/affineGap.go:305 (quirk Q1) changed the state / all such crossings -- each of the former can cost the CIGAR
  * at most one gap open against the score, which is what the tests of megabase pairs (no oracle finishes them) check.
  * which = 5 / 6: rows per lane / snapshot spacing of the last 64-lane affine sweep (bench.py prices its design bytes with them).
- * reset != 0 zeroes the counter after reading. */
+ * reset != 0 zeroes the counter after reading (3 and 4 together). */
 int gnx_debug_counter(int which, int reset, int64_t *out);
 
 /* ---- "next" row N1: chunk and multiple-alignment variants (what cmd/faChunkAlign and popgen/dunn.go run) ---- */

@@ -35,32 +35,134 @@ type HipGraph struct {
 	h *C.gnx_gsw_graph
 }
 
-// NewHipGraph hands the nodes and the edges of gg to the library.  Edges go over in the order of the nodes' Next lists; the library
-// rebuilds Next and Prev with AddEdge (genomeGraph.go:118-121).  The left traversals try their branches in the order of the Prev lists,
-// so a graph whose Prev lists were NOT filled in that same edge order (none of the reference's readers builds one) is refused here
-// instead of being aligned with another branch order (ADVICE r4).
+// hipEdge is one edge of the graph as AddEdge(u, v) would add it; occ counts parallel edges u -> v (the k-th such entry of u.Next is the k-th of v.Prev).
+type hipEdge struct {
+	u, v uint32
+	occ  int
+}
+
+// hipEdgeOrder returns the edges of gg in AN order of AddEdge calls (genomeGraph.go:118-121) that rebuilds every node's Next AND Prev list
+// exactly as they are.  The traversals try a node's branches in list order (RightAlignTraversal: Next, LeftAlignTraversal: Prev, search.go:166-232),
+// so both orders are part of the graph -- and the reference's own constructors do not add edges node by node: VariantGraph calls
+// AddEdge(altAllele, currMatch) before AddEdge(refAllele, currMatch) (graphTools.go:100-108), so the match node after a SNP has Prev = [k+2, k+1].
+// The order is a topological order of the edges under "before its successor in u's Next list" and "before its successor in v's Prev list"
+// (the smallest ready edge first: graphs built node by node come back in their original order).  Lists that no sequence of AddEdge calls
+// produces (a Prev entry without its Next entry, or a cycle between the two orders) panic: the library could not rebuild them.
+func hipEdgeOrder(gg *GenomeGraph) []hipEdge {
+	var edges []hipEdge
+	slot := make(map[hipEdge]int)
+	for i := range gg.Nodes {
+		seen := make(map[uint32]int)
+		for _, e := range gg.Nodes[i].Next {
+			seen[e.Dest.Id]++
+			k := hipEdge{gg.Nodes[i].Id, e.Dest.Id, seen[e.Dest.Id]}
+			slot[k] = len(edges)
+			edges = append(edges, k)
+		}
+	}
+	succ := make([][]int, len(edges))
+	indeg := make([]int, len(edges))
+	for x := 1; x < len(edges); x++ { // the order inside one node's Next list
+		if edges[x].u == edges[x-1].u {
+			succ[x-1] = append(succ[x-1], x)
+			indeg[x]++
+		}
+	}
+	nPrev := 0
+	for i := range gg.Nodes {
+		seen := make(map[uint32]int)
+		last := -1
+		for _, e := range gg.Nodes[i].Prev {
+			seen[e.Dest.Id]++
+			x, ok := slot[hipEdge{e.Dest.Id, gg.Nodes[i].Id, seen[e.Dest.Id]}]
+			if !ok {
+				log.Panicf("genomeGraph (hip): the Prev edge %d -> %d has no Next edge", e.Dest.Id, gg.Nodes[i].Id)
+			}
+			if last >= 0 {
+				succ[last] = append(succ[last], x)
+				indeg[x]++
+			}
+			last = x
+			nPrev++
+		}
+	}
+	if nPrev != len(edges) {
+		log.Panicf("genomeGraph (hip): the Next lists hold %d edges, the Prev lists %d", len(edges), nPrev)
+	}
+	// Kahn's algorithm with the smallest ready edge first (a binary min-heap of edge indices)
+	var heap []int
+	push := func(x int) {
+		heap = append(heap, x)
+		for c := len(heap) - 1; c > 0; {
+			p := (c - 1) / 2
+			if heap[p] <= heap[c] {
+				break
+			}
+			heap[p], heap[c] = heap[c], heap[p]
+			c = p
+		}
+	}
+	pop := func() int {
+		top := heap[0]
+		n := len(heap) - 1
+		heap[0] = heap[n]
+		heap = heap[:n]
+		for p := 0; ; {
+			c := 2*p + 1
+			if c >= n {
+				break
+			}
+			if c+1 < n && heap[c+1] < heap[c] {
+				c++
+			}
+			if heap[p] <= heap[c] {
+				break
+			}
+			heap[p], heap[c] = heap[c], heap[p]
+			p = c
+		}
+		return top
+	}
+	for x := range edges {
+		if indeg[x] == 0 {
+			push(x)
+		}
+	}
+	out := make([]hipEdge, 0, len(edges))
+	for len(heap) > 0 {
+		x := pop()
+		out = append(out, edges[x])
+		for _, y := range succ[x] {
+			indeg[y]--
+			if indeg[y] == 0 {
+				push(y)
+			}
+		}
+	}
+	if len(out) != len(edges) {
+		log.Panicf("genomeGraph (hip): no order of AddEdge calls builds these Next and Prev lists (%d of %d edges ordered)", len(out), len(edges))
+	}
+	return out
+}
+
+// NewHipGraph hands the nodes and the edges of gg to the library, the edges in an order of AddEdge calls that rebuilds the Next AND the
+// Prev lists as they are (hipEdgeOrder): in-memory graphs of VariantGraph (a SNP: Prev = [alt, ref]) or of cmd/cigarToBed-style builders
+// that add (i-1 -> i) before (i-2 -> i) align with the reference's branch order (ADVICE r5; before: only graphs whose Prev lists were in
+// the order of the Next lists -- what Read builds -- were accepted).
 func NewHipGraph(gg *GenomeGraph, seedLen int, stepSize int) *HipGraph {
 	off := make([]C.int64_t, len(gg.Nodes)+1)
 	var cat []dna.Base
-	var from, to []C.int32_t
-	prevSim := make([][]uint32, len(gg.Nodes)) // the Prev lists AddEdge will build on the other side
 	for i := range gg.Nodes {
+		if gg.Nodes[i].Id != uint32(i) {
+			log.Panicf("genomeGraph (hip): node %d has Id %d (the library addresses nodes by their index)", i, gg.Nodes[i].Id)
+		}
 		cat = append(cat, gg.Nodes[i].Seq...)
 		off[i+1] = C.int64_t(len(cat))
-		for _, e := range gg.Nodes[i].Next {
-			from, to = append(from, C.int32_t(gg.Nodes[i].Id)), append(to, C.int32_t(e.Dest.Id))
-			prevSim[e.Dest.Id] = append(prevSim[e.Dest.Id], gg.Nodes[i].Id)
-		}
 	}
-	for i := range gg.Nodes {
-		if len(prevSim[i]) != len(gg.Nodes[i].Prev) {
-			log.Panicf("genomeGraph (hip): node %d has %d Prev edges but %d Next edges point at it", i, len(gg.Nodes[i].Prev), len(prevSim[i]))
-		}
-		for k, e := range gg.Nodes[i].Prev {
-			if e.Dest.Id != prevSim[i][k] {
-				log.Panicf("genomeGraph (hip): the Prev list of node %d is not in the order of the Next lists (edge %d): the library cannot rebuild it", i, k)
-			}
-		}
+	order := hipEdgeOrder(gg)
+	from, to := make([]C.int32_t, len(order)), make([]C.int32_t, len(order))
+	for k, e := range order {
+		from[k], to[k] = C.int32_t(e.u), C.int32_t(e.v)
 	}
 	var fp, tp *C.int32_t
 	if len(from) > 0 {

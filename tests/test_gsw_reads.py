@@ -275,3 +275,38 @@ def test_edge_list_of_a_graph():
     g3.Nodes[0].Next.reverse()   # now 0 -> 3 before 0 -> 2, but 0 -> 2 before 1 -> 2 before 1 -> 3 before 0 -> 3: a cycle
     with pytest.raises(ValueError):
         gg._edge_list(g3)
+
+
+def test_edge_list_of_the_reference_constructors_graphs():
+    """the reference's own in-memory constructors do not add edges node by node -- VariantGraph adds (altAllele -> match) before
+    (refAllele -> match) (genomeGraph/graphTools.go:100-108: the match node after a SNP has Prev = [k+2, k+1]), cmd/cigarToBed-style builders add
+    (i-1 -> i) before (i-2 -> i).  The edge order handed to the library (here _edge_list; shim/genomeGraph/routines_hip.go hipEdgeOrder is its
+    transliteration) must rebuild BOTH lists of every node exactly."""
+    def rebuilt(g):
+        order = gg._edge_list(g)
+        nxt, prv = {k: [] for k in range(len(g.Nodes))}, {k: [] for k in range(len(g.Nodes))}
+        for u, v in order:
+            nxt[u].append(v); prv[v].append(u)
+        ids = {id(n): k for k, n in enumerate(g.Nodes)}
+        for k, n in enumerate(g.Nodes):
+            assert nxt[k] == [ids[id(e.Dest)] for e in n.Next], (k, nxt[k])
+            assert prv[k] == [ids[id(e.Dest)] for e in n.Prev], (k, prv[k])
+        return order
+    # two SNPs in a row, as VariantGraph builds them: match0, ref1, alt2, match3, ref4, alt5, match6
+    g = gg.GenomeGraph()
+    for k in range(7):
+        gg.AddNode(g, gg.Node(k, np.zeros(30, np.uint8)))
+    for u, v in ((0, 1), (0, 2), (2, 3), (1, 3), (3, 4), (3, 5), (5, 6), (4, 6)):
+        gg.AddEdge(g.Nodes[u], g.Nodes[v])
+    assert [gg_id for gg_id in ([g.Nodes.index(e.Dest) for e in g.Nodes[3].Prev])] == [2, 1]
+    order = rebuilt(g)
+    assert order.index((2, 3)) < order.index((1, 3)) and order.index((5, 6)) < order.index((4, 6))
+    # (i-1 -> i) before (i-2 -> i)
+    g2 = gg.GenomeGraph()
+    for k in range(6):
+        gg.AddNode(g2, gg.Node(k, np.zeros(30, np.uint8)))
+    for i in range(1, 6):
+        gg.AddEdge(g2.Nodes[i - 1], g2.Nodes[i])
+        if i >= 2:
+            gg.AddEdge(g2.Nodes[i - 2], g2.Nodes[i])
+    rebuilt(g2)

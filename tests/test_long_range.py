@@ -308,10 +308,12 @@ def _long_pairs():
     return mod
 
 
-@pytest.mark.parametrize("case", ["const_150k", "affine_340k"])
+@pytest.mark.parametrize("case", ["const_150k", "affine_340k", "affine_q1_300k", "affine_1M"])
 def test_long_pairs_equal_the_oracle(gpu_lib, case):
     """the callers' own parameters at lengths where the keys leave int32 (ConstGap 150 000 x 180 009: 4 (score - g (n + m)) = 5.7e8;
-    AffineGap 340 000 x 339 906: 5.3e8): score, number of runs and sha256 of the CIGAR equal what the CPU oracle produced in 185 s / 895 s
+    AffineGap 340 000 x 339 906: 5.3e8), a 300 kb pair built so that quirk Q1 fires at EVERY 10 000-row checkerboard edge (beta lacks the bases of
+    alpha around each row 10 000 k: the walk crosses the edge inside a D run, align/affineGap.go:305), and the megabase regime itself, AffineGap
+    1 Mb x 1 Mb (1e12 cells): score, number of runs and sha256 of the CIGAR equal what the CPU oracle produced in 185 s / 895 s / ~700 s / ~2 h
     of one core (tests/golden/long_pairs.json, written by `python tools/long_pairs.py oracle`; the pairs are seeded, tools/long_pairs.py gen)"""
     import json
     lp = _long_pairs()
@@ -322,18 +324,19 @@ def test_long_pairs_equal_the_oracle(gpu_lib, case):
     sc, go, ge = lp.params(affine)
     p = gpu_lib.make_params(0 if affine else 1, sc, go, ge, 10000, 10000)
     gpu_lib.check(gpu_lib.lib().gnx_init(0, 0))
+    gpu_lib.debug_counter(3, reset=True)
     score, ops, off = gpu_lib.align_batch(p, [a], [b])
     common.expect_route(gpu_lib.get_timing(), 2)
     assert lp.digest(score[0], ops) == {k: fx[k] for k in ("score", "runs", "sha256")}
+    if affine and gpu_lib.get_timing()["fast_path"] in (5, 6):  # what the walk reports about quirk Q1 bounds the CIGAR's re-score (the check of the pairs no oracle finishes)
+        changed = gpu_lib.debug_counter(3, reset=False)
+        ni, nj, total = rescore_affine(a, b, ops, sc, go, ge)
+        assert (ni, nj) == (a.shape[0], b.shape[0]) and 0 <= int(score[0]) - total <= -go * changed
+        if case == "affine_q1_300k":
+            assert changed >= 3 and total < int(score[0])  # the pair does what it was built for
 
 
-@pytest.mark.parametrize("case", ["affine_1M", "const_300k_2M"])
-def test_megabase_pairs(gpu_lib, case):
-    """one 1 Mb x 1 Mb AffineGap pair (1e12 cells) and one 300 kb x 2 Mb ConstGap pair (6e11 cells), the callers' parameters and
-    10 000 x 10 000 checkerboards (cmd/cigarToBed/cigarToBed.go:86; .MISSING_LARGE_BLOBS:1-3 lists a 5 Mb fixture the reference ships):
-    no oracle finishes these -- the CIGAR consumes both sequences and re-scores in int64 to the returned score (timings: tools/long_pairs.py gpu
-    -> profiles/r5_long_pairs.jsonl)"""
-    lp = _long_pairs()
+def _megabase_check(gpu_lib, lp, case, route):
     affine, a, b = lp.gen(case)
     sc, go, ge = lp.params(affine)
     gpu_lib.check(gpu_lib.lib().gnx_init(0, 0))
@@ -341,12 +344,40 @@ def test_megabase_pairs(gpu_lib, case):
     ph = gpu_lib.make_params(2 if affine else 4, sc, go, ge)
     score_h, ops_h, _ = gpu_lib.align_batch(ph, [a], [b])
     ni, nj, total = rescore_affine(a, b, ops_h, sc, go, ge) if affine else rescore_const(a, b, ops_h, sc, go)
-    common.expect_route(gpu_lib.get_timing(), 2)
+    common.expect_route(gpu_lib.get_timing(), route)
     assert (ni, nj) == (a.shape[0], b.shape[0]) and total == int(score_h[0])
-    # the callers' function (10 000 x 10 000 checkerboards): the same score; its CIGAR may carry the reference's quirk Q1 (a gap split where a
-    # checkerboard is left upwards -- a 5 Mb pair shows it, profiles/r5_long_pairs.jsonl), so it re-scores to at most the score
+    # the callers' function (10 000 x 10 000 checkerboards): the same score; its CIGAR may carry the reference's quirk Q1 -- where the walk leaves a
+    # checkerboard upwards it restarts in the argmax state X of the entry cell (align/affineGap.go:305); when that is not the traced gap state the part of
+    # the gap below the edge is paid as a new gap: a deficit of gapOpen - (X - D) in [0, gapOpen] per such restart.  The walk counts them
+    # (gnx_debug_counter(3)): the CIGAR re-scores to within gapOpen x that count below the score -- exactly to it when there was none (ConstGap has no state: always)
     p = gpu_lib.make_params(0 if affine else 1, sc, go, ge, 10000, 10000)
+    gpu_lib.debug_counter(3, reset=True)
     score, ops, off = gpu_lib.align_batch(p, [a], [b])
+    changed = gpu_lib.debug_counter(3, reset=False) if affine else 0
     ni, nj, total = rescore_affine(a, b, ops, sc, go, ge) if affine else rescore_const(a, b, ops, sc, go)
     assert int(score[0]) == int(score_h[0])
-    assert (ni, nj) == (a.shape[0], b.shape[0]) and total <= int(score[0])
+    assert (ni, nj) == (a.shape[0], b.shape[0]) and 0 <= int(score[0]) - total <= (-go if affine else 0) * changed, (int(score[0]) - total, changed)
+
+
+@pytest.mark.parametrize("case", ["const_300k_2M"])
+def test_megabase_pairs(gpu_lib, case):
+    """one 300 kb x 2 Mb ConstGap pair (6e11 cells; 450 000 runs), the callers' parameters and 10 000 x 10 000 checkerboards (cmd/globalAlignment/globalAlignment.go:84):
+    no oracle finishes it -- the CIGAR consumes both sequences and re-scores in int64 to the returned score.  (AffineGap 1 Mb x 1 Mb has an oracle digest since
+    round 6: test_long_pairs_equal_the_oracle.)"""
+    _megabase_check(gpu_lib, _long_pairs(), case, 2)
+
+
+def test_row_panels_at_their_natural_size(gpu_lib, monkeypatch):
+    """AffineGap 2 Mb x 2 Mb (4e12 cells) with a snapshot every 128 steps: 350 GB of bottom rows + snapshots -- more than the device has, so run_device_mega
+    cuts the pair into row panels of the size IT chooses (no GNX_MEGA_STRIPS; ~2 s of kernels): forward panels, backward panels re-swept with snapshots, the walk
+    farm crossing panel borders with MegaState (.MISSING_LARGE_BLOBS:1-3: the reference ships a 5 Mb x 5 Mb fixture for cmd/cigarToBed)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    fr, tot = ctypes.c_size_t(), ctypes.c_size_t()
+    gpu_lib.check(gpu_lib.lib().gnx_init(0, 0))
+    assert hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(tot)) == 0
+    free = fr.value + 0  # (plus what the library's context already holds: it re-uses it)
+    if free < 150 * 2 ** 30:
+        pytest.skip("needs a device with 150 GB free")
+    monkeypatch.setenv("GNX_W64_CK", "128")
+    _megabase_check(gpu_lib, _long_pairs(), "affine_2M", 5)

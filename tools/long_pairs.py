@@ -34,7 +34,7 @@ CASES = {
     # edge upwards inside a D run and restarts in the argmax state of the entry cell (29 crossings; the CIGAR re-scores below the score)
     "affine_q1_300k": (True, 300000, 0, 1238),
 }
-DEFAULT_GPU_CASES = ("const_150k", "affine_340k", "affine_1M", "const_300k_2M", "affine_2M")
+DEFAULT_GPU_CASES = ("const_150k", "affine_340k", "affine_q1_300k", "affine_1M", "const_300k_2M", "affine_2M")
 ORACLE_CASES = ("affine_340k", "const_150k", "affine_q1_300k", "affine_1M")
 
 
@@ -101,25 +101,44 @@ def gpu_rows(names, reps=None):
         highmem = os.environ.get("LONG_PAIRS_HIGHMEM") == "1"  # AffineGap_highMem / ConstGap_highMem semantics: no checkerboard quirks
         p = _lib.make_params((_lib.GNX_AFFINE_GAP_HIGHMEM if affine else _lib.GNX_CONST_GAP_HIGHMEM) if highmem else (_lib.GNX_AFFINE_GAP if affine else _lib.GNX_CONST_GAP), sc, go, ge, 10000, 10000)
         best, first = None, 0.0
+        _lib.debug_counter(3, reset=True)  # (3 and 4 are one pair of counters: a reset zeroes both)
+        ncalls = 0
         for rep in range(reps or (3 if a.shape[0] * b.shape[0] < 2e12 else 2)):  # (the first call of a process also allocates its workspace: ~27 ms per GB)
             t0 = time.perf_counter()
             score, ops, off = _lib.align_batch(p, [a], [b])
             wall = time.perf_counter() - t0
             tm = _lib.get_timing()
+            ncalls += 1
             first = wall if rep == 0 else first
             if best is None or wall < best[0]:
                 best = (wall, tm)
         wall, tm = best
+        q1c, q1n = _lib.debug_counter(3, reset=False) // ncalls, _lib.debug_counter(4, reset=True) // ncalls  # quirk-Q1 restarts of ONE call: that changed the state / all
         ni, nj, total = rescore_affine(a, b, ops, sc, go, ge) if affine else rescore_const(a, b, ops, sc, go)
         row = {"case": name, "fn": "AffineGap(HumanChimpTwo,-600,-150)" if affine else "ConstGap(HumanChimpTwo,-430)", "n": int(a.shape[0]), "m": int(b.shape[0]),
                "cells": int(a.shape[0]) * int(b.shape[0]), "call_s": round(wall, 4), "first_call_s": round(first, 4), "sweep_ms": round(tm["fill_ms"], 2), "walk_ms": round(tm["traceback_ms"], 2),
                "cells_per_s_call": float("%.4g" % (a.shape[0] * b.shape[0] / wall)), "cells_per_s_kernels": float("%.4g" % (a.shape[0] * b.shape[0] / (tm["total_ms"] * 1e-3))),
                "workspace_bytes": int(tm["trace_bytes"]), "route": {2: "snapshot path", 5: "row panels", 6: "snapshot path, 64 lanes per pair"}.get(int(tm["fast_path"]), int(tm["fast_path"])), "launches": int(tm["n_launches"]), "score": int(score[0]), "runs": int(ops.shape[0]),
                "consumes_n_m": (ni, nj) == (a.shape[0], b.shape[0]), "rescored_equals_score": total == int(score[0]), "rescored_minus_score": total - int(score[0]),
+               "q1_restarts": int(q1n), "q1_restarts_changed": int(q1c),
                "semantics": "highMem (no checkerboards)" if highmem else "10 000 x 10 000 checkerboards (quirk Q1 can cost the CIGAR a gap open: the reference's own behaviour)"}
-        if name in fx:
+        if affine and int(tm["fast_path"]) in (5, 6):
+            row["rows_per_lane"], row["snapshot_steps"] = int(_lib.debug_counter(5, reset=False)), int(_lib.debug_counter(6, reset=False))
+        if name in fx and not highmem:
             row["equals_oracle"] = digest(score[0], ops) == {k: fx[name][k] for k in ("score", "runs", "sha256")}
+        row["ok"] = row_ok(row)
         yield row
+
+
+def row_ok(r, gap_open=600):
+    """what a row must satisfy: the oracle's digest where there is one; always: the CIGAR consumes both sequences and re-scores to the score minus at most one gap
+    open per quirk-Q1 restart that changed the walk's state (align/affineGap.go:305: the walk re-enters the tile above in the argmax state X of the entry cell
+    instead of the traced gap state -- the part of the gap below the edge is paid as a new gap, a deficit of gapOpen - (X - D) in [0, gapOpen]) -- so exactly
+    to the score when the walk reports none (ConstGap: always; highMem semantics: always)"""
+    if not r["consumes_n_m"] or not r.get("equals_oracle", True):
+        return False
+    deficit = -r["rescored_minus_score"]
+    return 0 <= deficit <= gap_open * r["q1_restarts_changed"]
 
 
 def run_gpu(names):
