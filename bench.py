@@ -456,10 +456,10 @@ def long_pair_roofline(d, geo=None, pmc=None):
     affine = d["fn"].startswith("AffineGap")
     bits = 6 if affine else 2
     n, m = d["n"], d["m"]
-    rw, ck = geo if (affine and geo) else (10, 512 if affine else 224)
+    rw, ck = geo if geo else (10, 512 if affine else 224)
     strips = -(-n // (64 * rw))
     rows = (8 if affine else 4) * (m + 1) * max(strips - 1, 0) * 2
-    snaps = ((m + 63) // ck) * strips * 64 * (((2 * rw + 2 + 3) & ~3) if affine else 12) * 4
+    snaps = ((m + 63) // ck) * strips * 64 * (((2 * rw + 2 + 3) & ~3) if affine else ((rw + 1 + 3) & ~3)) * 4
     alg = n + m + -(-bits * n * m // 8) + -(-bits * (n + m) // 8) + 8 + 16 * d["runs"]
     secs = d["sweep_ms"] * 1e-3
     ach = alg / secs / 1e9
@@ -492,7 +492,7 @@ def extra_long_pairs(_lib, L, scores, chunk_h, dev, torch):
     except (OSError, ValueError):
         pass
     for d in pairs:
-        d["sweep_roofline"] = long_pair_roofline(d, (d.get("rows_per_lane", 10), d.get("snapshot_steps", 512)), (pmc or {}).get(d["case"]) if pmc and "stale" not in pmc else pmc)
+        d["sweep_roofline"] = long_pair_roofline(d, (d["rows_per_lane"], d["snapshot_steps"]) if "rows_per_lane" in d else None, (pmc or {}).get(d["case"]) if pmc and "stale" not in pmc else pmc)
     return {"entry": "gnx_align_batch (one pair per call, host buffers)", "pairs": pairs, "bit_exact_sample": bool(ok),
             "checked_against": "sha256 of the CPU oracle's CIGAR where tests/golden/long_pairs.json holds one; else consumed lengths + int64 re-score bounded by the quirk-Q1 restarts the walk reports"}
 

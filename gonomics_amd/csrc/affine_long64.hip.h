@@ -56,6 +56,22 @@ __device__ __forceinline__ void al64_snap_load(const uint4 *sp, int (&rt)[RW], i
     diag0 = (int)v[2 * RW]; dn_out = (int)v[2 * RW + 1];
 }
 
+template <typename F, int... Us>
+__device__ __forceinline__ void al64_unrolled_block(std::integer_sequence<int, Us...>, F &&f) { (f(std::integral_constant<int, Us>{}), ...); }
+// lane 0 <- lane U of its row of 16 (U = 0: a copy): the boundary / base queues of a block stay where they were loaded, the unrolled step U reads its entry
+template <int U>
+__device__ __forceinline__ int dpp_row_shl(int src) {
+    if constexpr (U == 0) return src;
+    else return __builtin_amdgcn_update_dpp(0, src, 0x100 + U, 0xf, 0xf, true); // (bound_ctrl: no `old` operand to copy; lane 0's source lane U always exists)
+}
+// lanes >= 1: src[l - 1] + inc, lane 0: oldv -- one v_add_u32_dpp (the profile offset of a column travels down the wave and gains a lane's stride per hop, so
+// that it IS the LDS address).  s_nop: a DPP read of a VGPR needs two wait states after the VALU write of it, and the compiler does not look inside this statement.
+__device__ __forceinline__ int wave_shr1_add(int oldv, int src, int inc) {
+    int r = oldv;
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(src), "v"(inc));
+    return r;
+}
+
 template <int RW, bool P16>
 __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                         const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
@@ -73,7 +89,9 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
     const int l = threadIdx.x;
     if (l < 25) lds[l] = kp.sc4[l] - 2 * kp.e4; // rebased diagonal move: 4*(s - 2e)
     int *prof = &lds[32];
-    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    const char *prof_bytes = reinterpret_cast<const char *>(prof); // a column's profile offset = base plane + lane stride, accumulated hop by hop (wave_shr1_add)
+    int vinc;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vinc) : "s"(LW * 4));
     const int s_own = strip_map[blockIdx.x].y;
     const int n_stolen = claim_items(strip_prog + gridDim.x, 1, s_own);
     if (n_stolen < 0) return;
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
             rt[r] = max3i(NEG4 + 3 + OE4, NEG4 + TI + E4, D1c + OE4) - RB;
         }
         int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
-        int dn_out = 0, h_out = 0, b_out = 0, sq_dn = 0, sq_h = 0;
+        int dn_out = 0, h_out = 0, b_out = l * (LW * 4), sq_dn = 0, sq_h = 0;
         int qdn = 0, qh = 0, qb = 0, ndn = 0, nh = 0, nb = 0;
         // moving bases (REBASE, const_long.hip.h): mine; the strip above's for the two blocks the columns being loaded were written in
         long long Bown = 0;
@@ -159,22 +177,33 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
         qb = base_off(qb, l + 1);
         int wq[LW], pb_cur;
         auto fetch = [&](int pbv, int *w) {
-            const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+            const int *pw = reinterpret_cast<const int *>(prof_bytes + pbv);
 #pragma unroll
             for (int k = 0; k < LW; k++) w[k] = pw[k];
         };
-        pb_cur = wave_shr1(qb, b_out);
+        pb_cur = wave_shr1_add(qb, b_out, vinc);
         qb = dpp_shl1(qb, qb);
         fetch(pb_cur, wq);
-        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
+        // uc: the step's position U in its block as a compile-time constant (the unrolled blocks: the queues stay in place, lane 0 takes entry U with one
+        // row_shl:U move -- no shift of the queue, no copy for the move's `old` operand), or -1 (the ramps' rolled loop: the queues shift by one per step)
+        auto step = [&](const int t, auto chk, auto uc, const bool take, const int nqv) {
             constexpr bool CHECK = decltype(chk)::value;
-            const int up_dn = wave_shr1(qdn, dn_out);
-            const int up_h = wave_shr1(qh, h_out);
-            qdn = dpp_shl1(qdn, qdn);
-            qh = dpp_shl1(qh, qh);
-            if (take) qb = nqv;
-            const int pb_next = wave_shr1(qb, pb_cur);
-            qb = dpp_shl1(qb, qb);
+            constexpr int U = decltype(uc)::value;
+            int up_dn, up_h, pb_next;
+            if constexpr (U >= 0) {
+                up_dn = wave_shr1(dpp_row_shl<U>(qdn), dn_out);
+                up_h = wave_shr1(dpp_row_shl<U>(qh), h_out);
+                if constexpr (U == 15) { pb_next = wave_shr1_add(nqv, pb_cur, vinc); qb = dpp_shl1(nqv, nqv); } // (the base queue runs one step ahead: the next block's takes over)
+                else pb_next = wave_shr1_add(dpp_row_shl<U>(qb), pb_cur, vinc);
+            } else {
+                up_dn = wave_shr1(qdn, dn_out);
+                up_h = wave_shr1(qh, h_out);
+                qdn = dpp_shl1(qdn, qdn);
+                qh = dpp_shl1(qh, qh);
+                if (take) qb = nqv;
+                pb_next = wave_shr1_add(qb, pb_cur, vinc);
+                qb = dpp_shl1(qb, qb);
+            }
             int wn[LW];
             fetch(pb_next, wn);
             asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic
@@ -240,11 +269,13 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
             }
             boundary(t0 + 16 + l + 1, ndn, nh, nb);
             if (t0 >= G64 && t0 + 16 <= m) {
-#pragma unroll
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+                al64_unrolled_block(std::make_integer_sequence<int, 16>{}, [&](auto uc) {
+                    if constexpr (decltype(uc)::value == 15) nb = base_off(nb, t0 + 16 + l + 1); // (as late as possible: the boundary loads of the block have a block's time to arrive)
+                    step(t0 + decltype(uc)::value + 1, std::false_type{}, uc, decltype(uc)::value == 15, nb);
+                });
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, std::integral_constant<int, -1>{}, u == 15, nb); }
             }
             asm volatile("" :: "v"(ndn), "v"(nh));
             qdn = ndn; qh = nh;

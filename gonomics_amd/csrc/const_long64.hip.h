@@ -16,20 +16,55 @@ namespace {
 // ------------------------------------------------------------------------------------------------------
 constexpr int CKC64 = CKC_SMALL;
 
-template <bool P16>
+// Rows per lane of the 64-lane CONSTANT-GAP sweep and of the farm's re-fills (round 6): RW = 4 / 10 -- strips of 256 / 640 rows.  cmd/globalAlignment's one ConstGap call on
+// 150 kb x 180 kb is 235 strips of 640 rows: a quarter of a wave per SIMD; at RW = 4 it is 586 waves whose step is 8 + 9 instead of 20 + 9 instructions.  The host picks
+// (w64_pick_rows, gnx_align.hip); the one-workgroup walks below stay at R = 10.
+__host__ __device__ constexpr int cl64_snapw(int rw) { return (rw + 1 + 3) & ~3; } // dwords per lane and snapshot: val[RW], diag0 (RW = 10: SNAPW)
+static_assert(cl64_snapw(R) == SNAPW, "the walk kernels of this file read the sweep's snapshots at RW = R");
+template <int RW>
+__device__ __forceinline__ void cl64_snap_store(uint4 *dst, const int (&val)[RW], int diag0) {
+    constexpr int SW = cl64_snapw(RW);
+    unsigned v[SW];
+#pragma unroll
+    for (int r = 0; r < RW; r++) v[r] = (unsigned)val[r];
+    v[RW] = (unsigned)diag0;
+#pragma unroll
+    for (int q = RW + 1; q < SW; q++) v[q] = 0u;
+#pragma unroll
+    for (int q = 0; q < SW / 4; q++) dst[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+template <int RW>
+__device__ __forceinline__ void cl64_snap_load(const uint4 *sp, int (&val)[RW], int &diag0) {
+    constexpr int SW = cl64_snapw(RW);
+    unsigned v[SW];
+    uint4 x[SW / 4];
+#pragma unroll
+    for (int q = 0; q < SW / 4; q++) x[q] = sp[q];
+#pragma unroll
+    for (int q = 0; q < SW / 4; q++) { v[4 * q] = x[q].x; v[4 * q + 1] = x[q].y; v[4 * q + 2] = x[q].z; v[4 * q + 3] = x[q].w; }
+#pragma unroll
+    for (int r = 0; r < RW; r++) val[r] = (int)v[r];
+    diag0 = (int)v[RW];
+}
+
+template <int RW, bool P16>
 __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                         const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                         const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                         KParams kp, int *__restrict__ rowbuf, int *__restrict__ snap, int64_t *__restrict__ hfin,
                                                         int *__restrict__ err, const int2 *__restrict__ strip_map, int *__restrict__ strip_prog,
                                                         long long *__restrict__ bases) {
-    constexpr int LW = P16 ? R / 2 : R;
+    static_assert(!P16 || RW % 2 == 0, "the int16 profile packs two rows per dword");
+    constexpr int HW = G64 * RW, SW = cl64_snapw(RW);
+    constexpr int LW = P16 ? RW / 2 : RW;
     constexpr int BST = G64 * LW;
     __shared__ int lds[32 + 5 * BST];
     const int l = threadIdx.x;
     if (l < 25) lds[l] = kp.sc4[l] - 2 * kp.g4; // rebased diagonal move: 4*(s - 2g); every value carries tag 2
     int *prof = &lds[32];
-    const char *prof_lane = reinterpret_cast<const char *>(prof + l * LW);
+    const char *prof_bytes = reinterpret_cast<const char *>(prof); // a column's profile offset = base plane + lane stride, accumulated hop by hop (wave_shr1_add, affine_long64.hip.h)
+    int vinc;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vinc) : "s"(LW * 4));
     const int s_own = strip_map[blockIdx.x].y;
     const int n_stolen = claim_items(strip_prog + gridDim.x, 1, s_own);
     if (n_stolen < 0) return;
@@ -45,12 +80,12 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
     for (int s = s_own - n_stolen; s <= s_own; s++) {
         const int bid = (int)blockIdx.x - s_own + s;
         const bool store_row = s + 1 < pl.strips;
-        const int row0 = s * H64 + l * R;
-        int val[R];
+        const int row0 = s * HW + l * RW;
+        int val[RW];
         {
-            int a5[R];
+            int a5[RW];
 #pragma unroll
-            for (int r = 0; r < R; r++) {
+            for (int r = 0; r < RW; r++) {
                 const int i0 = row0 + r;
                 int a = 0;
                 if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
@@ -65,9 +100,9 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
             __syncthreads();
         }
 #pragma unroll
-        for (int r = 0; r < R; r++) val[r] = 2; // column 0, rebased: 0 (tag 2)
+        for (int r = 0; r < RW; r++) val[r] = 2; // column 0, rebased: 0 (tag 2)
         int diag0 = 2;
-        int v_out = 0, b_out = 0, sq_v = 0;
+        int v_out = 0, b_out = l * (LW * 4), sq_v = 0;
         int qv = 0, qb = 0, nv = 0, nb = 0;
         long long Bown = 0;
         int dlo = 0, dhi = 0, qp = 0, edge = CKC64, r0v = 2;
@@ -98,20 +133,29 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
         qb = base_off(qb, l + 1);
         int wq[LW], pb_cur;
         auto fetch = [&](int pbv, int *w) {
-            const int *pw = reinterpret_cast<const int *>(prof_lane + pbv);
+            const int *pw = reinterpret_cast<const int *>(prof_bytes + pbv);
 #pragma unroll
             for (int k = 0; k < LW; k++) w[k] = pw[k];
         };
-        pb_cur = wave_shr1(qb, b_out);
+        pb_cur = wave_shr1_add(qb, b_out, vinc);
         qb = dpp_shl1(qb, qb);
         fetch(pb_cur, wq);
-        auto step = [&](const int t, auto chk, const bool take, const int nqv) {
+        // uc: the step's position in its block as a compile-time constant (unrolled blocks: the queues stay in place, lane 0 takes its entry with one row_shl move), or -1 (the ramps)
+        auto step = [&](const int t, auto chk, auto uc, const bool take, const int nqv) {
             constexpr bool CHECK = decltype(chk)::value;
-            const int up_v = wave_shr1(qv, v_out);
-            qv = dpp_shl1(qv, qv);
-            if (take) qb = nqv;
-            const int pb_next = wave_shr1(qb, pb_cur);
-            qb = dpp_shl1(qb, qb);
+            constexpr int U = decltype(uc)::value;
+            int up_v, pb_next;
+            if constexpr (U >= 0) {
+                up_v = wave_shr1(dpp_row_shl<U>(qv), v_out);
+                if constexpr (U == 15) { pb_next = wave_shr1_add(nqv, pb_cur, vinc); qb = dpp_shl1(nqv, nqv); }
+                else pb_next = wave_shr1_add(dpp_row_shl<U>(qb), pb_cur, vinc);
+            } else {
+                up_v = wave_shr1(qv, v_out);
+                qv = dpp_shl1(qv, qv);
+                if (take) qb = nqv;
+                pb_next = wave_shr1_add(qb, pb_cur, vinc);
+                qb = dpp_shl1(qb, qb);
+            }
             int wn[LW];
             fetch(pb_next, wn);
             asm volatile("" ::: "memory"); // the reads stay HERE, ahead of the arithmetic
@@ -120,7 +164,7 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
             if (!CHECK || (j >= 1 && j <= m)) {
                 int vd = diag0, vu = up_v;
 #pragma unroll
-                for (int r = 0; r < R; r++) {
+                for (int r = 0; r < RW; r++) {
                     const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
                     const int k = max3i(vd + S4, val[r], vu);
                     vd = val[r];
@@ -142,16 +186,14 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
                 const bool rb_on = t0 <= m + (G64 - 1);
                 const int d = rb_on ? (rep & ~3) : 0;
 #pragma unroll
-                for (int r = 0; r < R; r++) val[r] -= d;
+                for (int r = 0; r < RW; r++) val[r] -= d;
                 diag0 -= d; v_out -= d; qv -= d;
                 Bown += d; dlo -= d; dhi -= d;
                 r0v = rbase_const(2, Bown);
                 if (rb_on && l == 0) rbase_store(my_bases + t0 / CKC64, Bown, true);
                 if (rb_on && snap != nullptr) {
-                    uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / CKC64 - 1) * pl.strips + s) * G64 + l) * SNAPW);
-                    dst[0] = make_uint4((unsigned)val[0], (unsigned)val[1], (unsigned)val[2], (unsigned)val[3]);
-                    dst[1] = make_uint4((unsigned)val[4], (unsigned)val[5], (unsigned)val[6], (unsigned)val[7]);
-                    dst[2] = make_uint4((unsigned)val[8], (unsigned)val[9], (unsigned)diag0, 0u);
+                    uint4 *dst = reinterpret_cast<uint4 *>(snap + pl.ckpt_off + (((int64_t)(t0 / CKC64 - 1) * pl.strips + s) * G64 + l) * SW);
+                    cl64_snap_store<RW>(dst, val, diag0);
                 }
             }
             wait_rows(min(t0 + 32, m));
@@ -161,11 +203,13 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
             }
             boundary(t0 + 16 + l + 1, nv, nb);
             if (t0 >= G64 && t0 + 16 <= m) {
-#pragma unroll
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::false_type{}, u == 15, nb); }
+                al64_unrolled_block(std::make_integer_sequence<int, 16>{}, [&](auto uc) {
+                    if constexpr (decltype(uc)::value == 15) nb = base_off(nb, t0 + 16 + l + 1);
+                    step(t0 + decltype(uc)::value + 1, std::false_type{}, uc, decltype(uc)::value == 15, nb);
+                });
             } else {
 #pragma unroll 1
-                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, std::integral_constant<int, -1>{}, u == 15, nb); }
             }
             asm volatile("" :: "v"(nv));
             qv = nv;
@@ -177,7 +221,7 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
         }
         if (m >= 1) {
 #pragma unroll
-            for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (Bown >> 2) + (int64_t)(val[r] >> 2) + (int64_t)(kp.g4 >> 2) * ((int64_t)pl.n + m); // plain V(n, m)
+            for (int r = 0; r < RW; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (Bown >> 2) + (int64_t)(val[r] >> 2) + (int64_t)(kp.g4 >> 2) * ((int64_t)pl.n + m); // plain V(n, m)
         }
         rb_publish(&strip_prog[bid], 0x7fffffff, l);
     }

@@ -297,15 +297,16 @@ __device__ __forceinline__ void al64_farm_fill_body(const PairPlan *__restrict__
 }
 
 // ---- constant gap: the fill of cl64_walk_kernel, tile {s, c} completely, its one plane to global memory ----
-template <bool P16>
+template <int RW, bool P16>
 __device__ __forceinline__ void cl64_farm_fill_body(const PairPlan *__restrict__ plans,
                                                     const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                     const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                     const KParams &kp, const int *__restrict__ rowbuf, const int *__restrict__ snap,
                                                     int *__restrict__ err, const long long *__restrict__ bases,
                                                     const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, const int p, const int q, const int par) {
-    const FarmGeo<false> geo(0);
-    constexpr int LW = P16 ? R / 2 : R;
+    const FarmGeo<false, RW> geo(0);
+    constexpr int HW = G64 * RW, SW = cl64_snapw(RW);
+    constexpr int LW = P16 ? RW / 2 : RW;
     constexpr int BST = G64 * LW;
     constexpr int CK = CKC64;
     __shared__ int lds[32 + 5 * BST];
@@ -326,14 +327,14 @@ __device__ __forceinline__ void cl64_farm_fill_body(const PairPlan *__restrict__
     int bad = 0;
     const int tbeg = c * CK;
     const int nblk = min(CK / 16, (m + (G64 - 1) - tbeg + 15) >> 4); // (no walk stands beyond step m + 63)
-    const int row0 = s * H64 + l * R;
-    int val[R];
-    unsigned acc[R];
+    const int row0 = s * HW + l * RW;
+    int val[RW];
+    unsigned acc[RW];
     FARM_WAVE_SYNC();
     {
-        int a5[R];
+        int a5[RW];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
+        for (int r = 0; r < RW; r++) {
             const int i0 = row0 + r;
             int a = 0;
             if (i0 < pl.n) { a = ap[i0]; if (a >= 5) { bad = 1; a = 4; } }
@@ -348,15 +349,11 @@ __device__ __forceinline__ void cl64_farm_fill_body(const PairPlan *__restrict__
     }
     int diag0 = 2;
 #pragma unroll
-    for (int r = 0; r < R; r++) { val[r] = 2; acc[r] = 0; }
+    for (int r = 0; r < RW; r++) { val[r] = 2; acc[r] = 0; }
     int v_out = 0, b_out = 0;
     if (c > 0) { // resume from the snapshot of step tbeg
-        const uint4 *sp = reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G64 + l) * SNAPW);
-        const uint4 x0 = sp[0], x1 = sp[1], x2 = sp[2];
-        val[0] = (int)x0.x; val[1] = (int)x0.y; val[2] = (int)x0.z; val[3] = (int)x0.w;
-        val[4] = (int)x1.x; val[5] = (int)x1.y; val[6] = (int)x1.z; val[7] = (int)x1.w;
-        val[8] = (int)x2.x; val[9] = (int)x2.y; diag0 = (int)x2.z;
-        v_out = val[R - 1];
+        cl64_snap_load<RW>(reinterpret_cast<const uint4 *>(snap + pl.ckpt_off + (((int64_t)(c - 1) * pl.strips + s) * G64 + l) * SW), val, diag0);
+        v_out = val[RW - 1];
         const int jb = tbeg - l;
         if (jb >= 1 && jb <= m) { int b = bp.at(jb - 1); if (b >= 5) { bad = 1; b = 4; } b_out = b * (BST * 4); }
     }
@@ -394,7 +391,7 @@ __device__ __forceinline__ void cl64_farm_fill_body(const PairPlan *__restrict__
             for (int k = 0; k < LW; k++) w[k] = pw[k];
             int vd = diag0, vu = up_v;
 #pragma unroll
-            for (int r = 0; r < R; r++) {
+            for (int r = 0; r < RW; r++) {
                 const int S4 = P16 ? ((r & 1) ? (w[r >> 1] >> 16) : (int)(short)(w[r >> 1] & 0xffff)) : w[r];
                 const int k = max3i(vd + S4, val[r], vu - 1);
                 acc[r] = alignbit2((unsigned)k, acc[r]);
@@ -420,7 +417,7 @@ __device__ __forceinline__ void cl64_farm_fill_body(const PairPlan *__restrict__
         const int miss = (t0 + 16 - l) - m; // steps this lane sat idle after its last column
         const int sh = (miss > 0 && miss < 16) ? 2 * miss : 0;
 #pragma unroll
-        for (int r = 0; r < R; r++) dirg[(b * R + r) * G64 + l] = acc[r] >> sh;
+        for (int r = 0; r < RW; r++) dirg[(b * RW + r) * G64 + l] = acc[r] >> sh;
     }
     if (bad) atomicOr(err, 1);
 }
@@ -686,12 +683,12 @@ __global__ __launch_bounds__(64) void al64_farm_fill_kernel(const PairPlan *__re
                                                             const long long *__restrict__ bases, const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, int par) {
     al64_farm_fill_body<RW, P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl, planes, blockIdx.y, blockIdx.x, par);
 }
-template <bool P16>
+template <int RW, bool P16>
 __global__ __launch_bounds__(64) void cl64_farm_fill_kernel(const PairPlan *__restrict__ plans, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                             const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp,
                                                             const int *__restrict__ rowbuf, const int *__restrict__ snap, int *__restrict__ err,
                                                             const long long *__restrict__ bases, const FarmCtl *__restrict__ ctl, unsigned *__restrict__ planes, int par) {
-    cl64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl, planes, blockIdx.y, blockIdx.x, par);
+    cl64_farm_fill_body<RW, P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl, planes, blockIdx.y, blockIdx.x, par);
 }
 template <bool AFF, int RW>
 __global__ __launch_bounds__(256) void farm_walk_kernel(const PairPlan *__restrict__ plans, TbParams tp,
@@ -716,15 +713,15 @@ __global__ __launch_bounds__(256) void al64_farm_round_kernel(const PairPlan *__
     if (blockIdx.x == 0) farm_walk_body<true, RW, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, kp.ckc, blockIdx.y, par);
     else if (threadIdx.x < 64) al64_farm_fill_body<RW, P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl_all, planes, blockIdx.y, (int)blockIdx.x - 1, par ^ 1);
 }
-template <bool P16>
+template <int RW, bool P16>
 __global__ __launch_bounds__(256) void cl64_farm_round_kernel(const PairPlan *__restrict__ plans, const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                               const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start, KParams kp, TbParams tp,
                                                               const int *__restrict__ rowbuf, const int *__restrict__ snap, const int64_t *__restrict__ hfin,
                                                               int64_t *__restrict__ score_out, int64_t *__restrict__ nops, const int64_t *__restrict__ scr_off,
                                                               gnx_cigar *__restrict__ scr, int *__restrict__ err, const long long *__restrict__ bases,
                                                               MegaState *__restrict__ mst_all, FarmCtl *__restrict__ ctl_all, unsigned *__restrict__ planes, int nt, int par) {
-    if (blockIdx.x == 0) farm_walk_body<false, R, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, 0, blockIdx.y, par);
-    else if (threadIdx.x < 64) cl64_farm_fill_body<P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl_all, planes, blockIdx.y, (int)blockIdx.x - 1, par ^ 1);
+    if (blockIdx.x == 0) farm_walk_body<false, RW, true>(plans, tp, hfin, score_out, nops, scr_off, scr, err, mst_all, ctl_all, planes, nt, 0, blockIdx.y, par);
+    else if (threadIdx.x < 64) cl64_farm_fill_body<RW, P16>(plans, a_buf, a_start, b_buf, b_start, kp, rowbuf, snap, err, bases, ctl_all, planes, blockIdx.y, (int)blockIdx.x - 1, par ^ 1);
 }
 
 } // namespace

@@ -74,12 +74,24 @@ void set_err_hip(hipError_t e, const char *file, int line) { snprintf(g_err, siz
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // What an allocation costs on this system (tools/alloc_probe.hip, profiles/r6_alloc_probe.txt): ~0.02 ms per GB when the driver hands out memory that has been
+    // free for a while, 20 - 55 ms per GB when it hands out memory that was freed a moment ago (by this process or the one before it) -- freed memory is cleared in
+    // the background and an allocation waits for the clearing of what it gets.  So a buffer that grows is allocated BEFORE the old one is freed (the new one comes
+    // from memory that has long been clean; free-then-allocate got the just-freed pages back and waited: the "27 ms per GB" of round 5), and big buffers take no
+    // 1/8 of slack along.
     int ensure(size_t bytes) {
         if (bytes <= cap) return GNX_OK;
+        size_t want = bytes + (bytes < ((size_t)1 << 30) ? bytes / 8 + 256 : bytes / 64);
+        void *q = nullptr;
+        if (hipMalloc(&q, want) == hipSuccess) { // beside the old buffer
+            if (p) (void)hipFree(p);
+            p = q; cap = want;
+            return GNX_OK;
+        }
+        (void)hipGetLastError(); // (the failed attempt must not stay behind as the "last error" a later launch check would read)
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
         if (hipMalloc(&p, want) != hipSuccess) {
-            (void)hipGetLastError(); // (the failed attempt must not stay behind as the "last error" a later launch check would read)
+            (void)hipGetLastError();
             if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; set_err("device allocation of %s%lld bytes failed", "", (long long)bytes); return GNX_ENOMEM; }
             want = bytes;
         }
@@ -126,7 +138,7 @@ struct Ctx {
     PinBuf st_a[2], st_as[2], st_b[2], st_bs[2];
     // the resident reference, PACKED (gnx_host.hip.h: pack_reference): `ref` = 2 bits per base, ref_flag / ref_rank / ref_exc = the
     // sparse list of bases that are not A C G T (KParams::b2 / bflag / brank / bexc)
-    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off, cl_bases, sc_prof_a, sc_prof_b, mega_rows, mega_state, farm;
+    DevBuf ref_flag, ref_rank, ref_exc, unpk_b, unpk_off, cl_bases, sc_prof_a, sc_prof_b, mega_rows, mega_state, farm, mega_arena;
     int64_t ref_len = -1;  // >= 0: a reference of that many bases is resident
     int64_t ref_nexc = 0;  // 64-base blocks with an exception
     int64_t ref_epoch = 0; // which gnx_set_reference call filled it (contexts created later are brought up to date on first use)
@@ -149,6 +161,8 @@ thread_local Ctx *t_ctx = nullptr;
 thread_local bool t_no_pipe = false;
 thread_local int t_w64_ck = 128; // snapshot spacing of the 64-lane affine sweep chosen by the routing for this call (farm64.hip.h: 128 .. 512)
 std::atomic<int64_t> g_last_w64_r{0}, g_last_w64_ck{0}; // what the last 64-lane affine sweep ran with (gnx_debug_counter(5 / 6): bench.py prices its bytes with them)
+thread_local bool t_scored_wide = false; // run_host_scored: this call's score matrices are plain 4 * s entries for the int64 kernel (a pair beyond the int32 range)
+thread_local int t_w64_rc = R;   // ... and of the 64-lane CONSTANT-GAP sweep + farm (4 / 10)
 thread_local int t_w64_r = R;    // rows per lane of the 64-lane AFFINE sweep + farm chosen by the routing for this call (w64_pick_rows: 6 / 8 / 10 / 16)
 thread_local bool t_no_lat = false; // set while a call is re-run without the latency geometry (its bug trap fired)
 thread_local int64_t t_min_cols = 0; // != 0: the fast path takes windows of at least this many columns (set by a mixed batch for its groups, see run_device)
@@ -619,19 +633,27 @@ void w64_rows_dispatch(int rw, F &&f) {
     default: f(std::integral_constant<int, R>{}); break;
     }
 }
+template <typename F>
+void w64c_rows_dispatch(int rw, F &&f) { // (the constant-gap twins: const_long64.hip.h)
+    if (rw == 4) f(std::integral_constant<int, 4>{});
+    else f(std::integral_constant<int, R>{});
+}
 constexpr int W64_ROWS[4] = {6, 8, R, 16};
+constexpr int W64C_ROWS[2] = {4, R};
 // One long pair is strips(RW) = n / (64 RW) waves piped through the row buffer, each ~lag steps behind the one above it; a SIMD that holds w of
 // them issues w x (5 RW + ~18) instructions per step of the pipeline, and the pipeline moves at the pace of the fullest SIMD.  1 Mb x 1 Mb at RW = 10:
 // 1 563 waves on 1 024 SIMDs -- half of the SIMDs hold two, the others wait for them (valu_busy 0.56, profiles/r5_pmc_long_pair.txt); at RW = 8: 1 954,
 // two on (nearly) every SIMD, 54 instead of 64 instructions per wave and step.  Per instruction: ~2.75 ns for a wave alone on its SIMD, ~1.9 ns each
 // for two, ~1.75 from three on (tools/valu_ubench*.hip; the lone wave: profiles/r5_experiments.md section 2).  The model below is that arithmetic;
 // GNX_W64_R = 6 / 8 / 10 / 16 overrides it (tests, A/B runs).  `strips_cap` > 0: row panels -- at most that many strips are in flight.
-int w64_pick_rows(const Ctx &c, int64_t n_pairs, const int64_t *h_alen, const int64_t *h_blen, int64_t step4, int ck, int64_t strips_cap = 0) {
-    if (const char *e = getenv("GNX_W64_R")) { const int v = atoi(e); for (int x : W64_ROWS) if (x == v) return v; }
+int w64_pick_rows(const Ctx &c, bool affine, int64_t n_pairs, const int64_t *h_alen, const int64_t *h_blen, int64_t step4, int ck, int64_t strips_cap = 0) {
+    // (constant gap: 2 RW + ~9 instructions per step; rows per lane 4 / 10, GNX_W64_RC)
+    if (const char *e = getenv(affine ? "GNX_W64_R" : "GNX_W64_RC")) { const int v = atoi(e); if (affine) { for (int x : W64_ROWS) if (x == v) return v; } else { for (int x : W64C_ROWS) if (x == v) return v; } }
     const double simds = 4.0 * c.n_cu, lag = 110.0;
     double best = 0;
     int best_rw = R;
-    for (int rw : W64_ROWS) {
+    for (int rw : {4, 6, 8, (int)R, 16}) {
+        if (affine ? rw == 4 : (rw != 4 && rw != R)) continue;
         if ((int64_t)(G64 * rw + G64 + ck + 64) * step4 >= ((int64_t)1 << 28)) continue; // (the keys' spread around a strip's moving base)
         double strips = 0, steps = 0, rows = 0;
         for (int64_t p = 0; p < n_pairs; p++) {
@@ -643,7 +665,7 @@ int w64_pick_rows(const Ctx &c, int64_t n_pairs, const int64_t *h_alen, const in
         if (strips_cap > 0 && strips > (double)strips_cap) { passes = strips / (double)strips_cap; strips = (double)strips_cap; }
         const double w = std::ceil(strips / simds);
         const double ns = w <= 1.0 ? 2.75 : (w <= 2.0 ? 1.9 : 1.75);
-        const double cost = passes * w * (5.0 * rw + 18.0) * ns * steps;
+        const double cost = passes * w * (affine ? 5.0 * rw + 15.0 : 2.0 * rw + 9.0) * ns * steps;
         if (best == 0 || cost < best) { best = cost; best_rw = rw; }
     }
     return best_rw;
@@ -657,16 +679,17 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
                   gnx_cigar *d_scr, int *d_err, const long long *dbs, MegaState *d_st, int64_t path_cells, hipStream_t stream) {
     int rc;
     const int ckr = affine ? kp.ckc : 0; // (the affine sweep's snapshot spacing of this call, w64_farm_ck; the constant-gap tiles are CKC64 steps)
-    const int rw = affine ? t_w64_r : R; // rows per lane of the sweep that wrote the snapshots (affine: w64_pick_rows)
-    size_t tile_dw = (size_t)FarmGeo<false>(0).tile_dw();
+    const int rw = affine ? t_w64_r : t_w64_rc; // rows per lane of the sweep that wrote the snapshots (w64_pick_rows)
+    size_t tile_dw = 0;
     if (affine) w64_rows_dispatch(rw, [&](auto rwc) { tile_dw = (size_t)FarmGeo<true, decltype(rwc)::value>(ckr).tile_dw(); });
+    else w64c_rows_dispatch(rw, [&](auto rwc) { tile_dw = (size_t)FarmGeo<false, decltype(rwc)::value>(0).tile_dw(); });
     const size_t planes_bytes = (size_t)np * 2 * FARM_MAX * tile_dw * 4;
     if ((rc = c.farm.ensure(planes_bytes + (size_t)np * sizeof(FarmCtl)))) return rc;
     unsigned *d_planes = reinterpret_cast<unsigned *>(c.farm.p);
     FarmCtl *d_ctl = reinterpret_cast<FarmCtl *>(reinterpret_cast<char *>(c.farm.p) + planes_bytes);
     const bool pipe = !(getenv("GNX_W64_FARM_PIPE") && getenv("GNX_W64_FARM_PIPE")[0] == '0'); // overlapped rounds (one launch each); 0: {fill, walk} launches
     if (affine) w64_rows_dispatch(rw, [&](auto rwc) { hipLaunchKernelGGL((farm_init_kernel<true, decltype(rwc)::value>), dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt, ckr); });
-    else hipLaunchKernelGGL((farm_init_kernel<false, R>), dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt, 0);
+    else w64c_rows_dispatch(rw, [&](auto rwc) { hipLaunchKernelGGL((farm_init_kernel<false, decltype(rwc)::value>), dim3((unsigned)((np + 63) / 64)), dim3(64), 0, stream, dpl, np, tp, d_st, d_ctl, nt, 0); });
     const dim3 gf((unsigned)nt, (unsigned)np), gw((unsigned)np), gr((unsigned)nt + 1, (unsigned)np);
     const int2 *drb2 = reinterpret_cast<const int2 *>(drb);
     const int *drb1 = reinterpret_cast<const int *>(drb);
@@ -678,8 +701,11 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
                 else hipLaunchKernelGGL((al64_farm_fill_kernel<RW, false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb2, dsn, d_err, dbs, d_ctl, d_planes, par);
             });
         } else {
-            if (p16) hipLaunchKernelGGL((cl64_farm_fill_kernel<true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes, par);
-            else hipLaunchKernelGGL((cl64_farm_fill_kernel<false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes, par);
+            w64c_rows_dispatch(rw, [&](auto rwc) {
+                constexpr int RW = decltype(rwc)::value;
+                if (p16) hipLaunchKernelGGL((cl64_farm_fill_kernel<RW, true>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes, par);
+                else hipLaunchKernelGGL((cl64_farm_fill_kernel<RW, false>), gf, dim3(64), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, drb1, dsn, d_err, dbs, d_ctl, d_planes, par);
+            });
         }
     };
     auto launch_round = [&](int par) {
@@ -690,8 +716,11 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
                 else hipLaunchKernelGGL((al64_farm_round_kernel<RW, false>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb2, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
             });
         } else {
-            if (p16) hipLaunchKernelGGL((cl64_farm_round_kernel<true>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb1, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
-            else hipLaunchKernelGGL((cl64_farm_round_kernel<false>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb1, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
+            w64c_rows_dispatch(rw, [&](auto rwc) {
+                constexpr int RW = decltype(rwc)::value;
+                if (p16) hipLaunchKernelGGL((cl64_farm_round_kernel<RW, true>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb1, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
+                else hipLaunchKernelGGL((cl64_farm_round_kernel<RW, false>), gr, dim3(256), 0, stream, dpl, d_a, d_as, d_b, d_bs, kp, tp, drb1, dsn, dhf, d_score, dn, d_so, d_scr, d_err, dbs, d_st, d_ctl, d_planes, nt, par);
+            });
         }
     };
     int64_t batch = path_cells / ((int64_t)(affine ? ckr * 3 / 4 : 100) * nt) + 8; // (a diagonal crosses ~0.9 of a tile's steps; a round that finds the walk over costs a few us)
@@ -704,7 +733,7 @@ int run_walk_farm(Ctx &c, bool affine, bool p16, int np, int nt, const PairPlan 
             else {
                 launch_fill(0);
                 if (affine) w64_rows_dispatch(rw, [&](auto rwc) { hipLaunchKernelGGL((farm_walk_kernel<true, decltype(rwc)::value>), gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt, ckr); });
-                else hipLaunchKernelGGL((farm_walk_kernel<false, R>), gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt, 0);
+                else w64c_rows_dispatch(rw, [&](auto rwc) { hipLaunchKernelGGL((farm_walk_kernel<false, decltype(rwc)::value>), gw, dim3(256), 0, stream, dpl, tp, dhf, d_score, dn, d_so, d_scr, d_err, d_st, d_ctl, d_planes, nt, 0); });
             }
         }
         rounds += batch;
@@ -733,7 +762,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     Ctx &c = g_ctx;
     int rc;
     if (w64 && !rebase) w64 = false;
-    const int rw64 = (w64 && affine && w64_farm_tiles() > 0) ? t_w64_r : R; // rows per lane of the 64-lane kernels (the one-workgroup walks and ConstGap: R)
+    const int rw64 = (w64 && w64_farm_tiles() > 0) ? (affine ? t_w64_r : t_w64_rc) : R; // rows per lane of the 64-lane kernels (the one-workgroup walks: R)
     const int64_t HS = w64 ? (int64_t)G64 * rw64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair
     // snapshot spacing of the constant-gap form (const_long.hip.h): the wide tiles only when the walk will have the GPU full of long chains
     int64_t ckc = CKC_SMALL;
@@ -753,7 +782,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
     {
         int64_t rb = 0, sn = 0, sc = 0, bs = 0;
         int64_t budget = c.ws_limit - c.ws_limit / 16;
-        const int64_t rbw = affine ? 8 : 4, ck = affine ? ck_aff : ckc, snw = affine ? (w64 ? al64_snapw(rw64) : AL_SNAPW) : SNAPW; // row-buffer entry bytes, snapshot spacing / dwords
+        const int64_t rbw = affine ? 8 : 4, ck = affine ? ck_aff : ckc, snw = affine ? (w64 ? al64_snapw(rw64) : AL_SNAPW) : (w64 ? cl64_snapw(rw64) : SNAPW); // row-buffer entry bytes, snapshot spacing / dwords
         auto bytes_of = [&](int64_t rb2, int64_t sn2, int64_t sc2, int64_t bs2) { return rbw * rb2 + 4 * sn2 + (int64_t)sizeof(gnx_cigar) * sc2 + 8 * bs2; };
         auto nq_of = [&](int64_t m) { return rebase ? (((m + GS + 14) & ~(int64_t)15) / ck + 2) : 0; }; // K-step blocks of a strip (REBASE: one int64 base each)
         // One pair that needs more than the workspace limit (a 1 Mb x 1 Mb pair: 50 GB of bottom rows + 43 GB of snapshots) is given what
@@ -874,7 +903,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         KParams kps = kp, kpa = kp;
         kps.ckc = (int)ckc;
         kpa.ckc = (int)ck_aff; // (al64_sweep_kernel, the farm's re-fills)
-        if (w64 && affine) { g_last_w64_r = rw64; g_last_w64_ck = ck_aff; }
+        if (w64) { g_last_w64_r = rw64; g_last_w64_ck = affine ? ck_aff : ckc; }
         kpa.rb_pub = w64_pub();
         kps.rb_pub = n_blocks * per_item >= (int64_t)40 * c.n_cu ? 16 : RB_PUB; // (twice the wave slots of the piped sweep: 20 per CU)
         if (const char *e = getenv("GNX_CL_PUB")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) kps.rb_pub = v; }
@@ -885,8 +914,11 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
 #define GNX_CL_FLAT(P_, RBS_) hipLaunchKernelGGL((cl_sweep_flat_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, dbs)
         if (rebase) HIPCHK(hipMemsetAsync(dbs, 0, (size_t)max_bs * 8, stream));
         if (w64 && !affine) {
-            if (p16) hipLaunchKernelGGL((cl64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
-            else hipLaunchKernelGGL((cl64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            w64c_rows_dispatch(rw64, [&](auto rwc) {
+                constexpr int RW = decltype(rwc)::value;
+                if (p16) hipLaunchKernelGGL((cl64_sweep_kernel<RW, true>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                else hipLaunchKernelGGL((cl64_sweep_kernel<RW, false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+            });
         } else if (w64) {
             w64_rows_dispatch(rw64, [&](auto rwc) {
                 constexpr int RW = decltype(rwc)::value;
@@ -988,7 +1020,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         fill_ms += f1; tb_ms += f2;
         for (int64_t p = b; p < e; p++) {
             const PairPlan &pl = plans[(size_t)p];
-            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + GS - 1) / (affine ? ck_aff : ckc)) * pl.strips * GS * (affine ? (w64 ? al64_snapw(rw64) : AL_SNAPW) : SNAPW);
+            trace_bytes += (affine ? 8 : 4) * (int64_t)(pl.strips - 1) * (pl.m + 1) + 4 * (int64_t)((pl.m + GS - 1) / (affine ? ck_aff : ckc)) * pl.strips * GS * (affine ? (w64 ? al64_snapw(rw64) : AL_SNAPW) : (w64 ? cl64_snapw(rw64) : SNAPW));
         }
     }
     HIPCHK(hipEventRecord(c.ev[2], stream));
@@ -1031,10 +1063,21 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                     int64_t *d_score, gnx_cigar *d_ops, int64_t ops_capacity, int64_t *d_ops_off, int64_t *out_total, hipStream_t stream, bool w64) {
     Ctx &c = g_ctx;
     int rc;
-    const int rw64 = (w64 && affine && w64_farm_tiles() > 0) ? t_w64_r : R; // rows per lane of the 64-lane kernels (the one-workgroup walks and ConstGap: R)
+    const int rw64 = (w64 && w64_farm_tiles() > 0) ? (affine ? t_w64_r : t_w64_rc) : R; // rows per lane of the 64-lane kernels (the one-workgroup walks: R)
     const int64_t HS = w64 ? (int64_t)G64 * rw64 : H, GS = w64 ? G64 : G; // rows per strip, lanes per pair (w64: affine_long64.hip.h / const_long64.hip.h)
     const int np = (int)n_pairs;
-    const int64_t ck = affine ? ((w64 && w64_farm_tiles() > 0) ? t_w64_ck : CKA) : CKC_SMALL, snw = affine ? (w64 ? al64_snapw(rw64) : AL_SNAPW) : SNAPW, rbw = affine ? 8 : 4;
+    // Snapshot spacing of the affine 64-lane sweep in row panels: what a backward panel holds per strip is its bottom row (8 B per column) + its snapshots
+    // (4 (2 RW + 2) / K B per column and lane), and the strips that fit the budget are the waves that sweep: 5 Mb x 5 Mb at RW = 16, K = 512: 814 strips a
+    // panel (0.8 waves per SIMD), K = 2 048: 1 690.  The farm's re-fills run beside the walk, so a tile of 2 048 steps costs the walk nothing per cell of path
+    // (its planes: 1.6 MB, 64 of them).  The widest power of two the keys' spread around a strip's base admits, GNX_W64_CK_MEGA = 128 .. 2048 (default 2 048).
+    int64_t ck_mega = t_w64_ck;
+    if (affine && w64 && w64_farm_tiles() > 0) {
+        const int64_t step4 = 4 * (max_abs_pen(prm, false) + 2 * llabs((long long)prm->gap_open) + 2 * llabs((long long)prm->gap_extend));
+        int want = 2048;
+        if (const char *e = getenv("GNX_W64_CK_MEGA")) { const int v = atoi(e); if (v == 128 || v == 256 || v == 512 || v == 1024 || v == 2048) want = v; }
+        for (int v = want; v >= CKA; v >>= 1) if ((int64_t)((int64_t)G64 * rw64 + G64 + v + 64) * step4 < ((int64_t)1 << 28)) { ck_mega = v; break; }
+    }
+    const int64_t ck = affine ? ((w64 && w64_farm_tiles() > 0) ? ck_mega : CKA) : CKC_SMALL, snw = affine ? (w64 ? al64_snapw(rw64) : AL_SNAPW) : (w64 ? cl64_snapw(rw64) : SNAPW), rbw = affine ? 8 : 4;
     bool p16 = true;
     for (int x = 0; x < 25; x++) { const int64_t v = 4 * (prm->scores[x] - 2 * (affine ? prm->gap_extend : prm->gap_open)) + 1; if (v > 32767 || v < -32768) p16 = false; }
     std::vector<int64_t> so((size_t)np + 1, 0), h_start((size_t)np * 2);
@@ -1054,7 +1097,9 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
     {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
-            const int64_t avail = (int64_t)fr + (int64_t)(c.rowbuf.cap + c.fp_ckpt.cap + c.tb_scr.cap + c.cl_bases.cap + c.mega_rows.cap);
+            // (the snapshot path's buffers of earlier calls -- up to what the device has -- give way to a pair that needs row panels)
+            if (c.rowbuf.cap + c.fp_ckpt.cap + c.cl_bases.cap > ((size_t)1 << 30)) { c.rowbuf.release(); c.fp_ckpt.release(); c.cl_bases.release(); (void)hipMemGetInfo(&fr, &tot); }
+            const int64_t avail = (int64_t)fr + (int64_t)(c.mega_arena.cap + c.tb_scr.cap + c.mega_rows.cap);
             // half of what is there: a fresh device allocation costs ~27 ms per GB (MI355X, measured: tools/memprobe.py), which a one-call process --
             // cmd/cigarToBed -- pays in full; panels of three quarters of the device sweep ~10 % faster and allocate 2 s longer
             budget = std::max(budget, avail / 2);
@@ -1121,6 +1166,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
         char *tops = reinterpret_cast<char *>(c.mega_rows.p); // tops[b]: the row above backward panel b (b >= 1)
         cells += n * m;
         PairPlan pl;
+        char *ar_rows = nullptr, *ar_bases = nullptr, *ar_snap = nullptr; // this launch's slices of the arena
         // sweep of the strips [s0, s0 + cnt) of the pair over columns 1 .. mcols; forward: no snapshots, the bottom rows of every Sb-th strip saved
         auto sweep_rows = [&](int64_t s0, int64_t cnt, int64_t mcols, bool forward) -> int {
             const int64_t r0 = s0 * HS, rows = std::min(n, (s0 + cnt) * HS) - r0, virt = s0 > 0 ? HS : 0;
@@ -1135,11 +1181,14 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                 size_t fr = 0, tot = 0;
                 (void)hipMemGetInfo(&fr, &tot);
                 fprintf(stderr, "[gnx] row panels: %s sweep of strips %lld + %lld: rows %.1f GB (held %.1f), snapshots %.1f GB (held %.1f), free %.1f GB\n", forward ? "forward" : "backward", (long long)s0, (long long)cnt,
-                        rb_e * rbw / 1e9, c.rowbuf.cap / 1e9, sn_e * 4 / 1e9, c.fp_ckpt.cap / 1e9, fr / 1e9);
+                        rb_e * rbw / 1e9, c.mega_arena.cap / 1e9, sn_e * 4 / 1e9, c.mega_arena.cap / 1e9, fr / 1e9);
             }
-            if ((r2 = c.rowbuf.ensure((size_t)std::max<int64_t>(rb_e, 1) * rbw))) return r2;
-            if (!forward && (r2 = c.fp_ckpt.ensure((size_t)std::max<int64_t>(sn_e, 1) * 4))) return r2;
-            if ((r2 = c.cl_bases.ensure((size_t)bs_e * 8))) return r2;
+            // rows | bases | snapshots of this launch, carved from the call's ONE arena (sized below for the biggest launch of either pass): no buffer is freed
+            // and allocated again between the passes (round 5 released the forward pass's rows to make room for the snapshots in EVERY call, and waited for
+            // the driver to clear what it got back: seconds per call at 5 Mb x 5 Mb)
+            const size_t o_bases = ((size_t)std::max<int64_t>(rb_e, 1) * rbw + 255) & ~(size_t)255, o_snap = (o_bases + (size_t)bs_e * 8 + 255) & ~(size_t)255;
+            if (o_snap + (size_t)std::max<int64_t>(sn_e, 1) * 4 > c.mega_arena.cap) { set_err("internal: a row panel needs %s%lld bytes, more than its arena", "", (long long)(o_snap + sn_e * 4)); return GNX_ENOMEM; }
+            ar_rows = reinterpret_cast<char *>(c.mega_arena.p); ar_bases = ar_rows + o_bases; ar_snap = ar_rows + o_snap;
             if ((r2 = c.strip_map.ensure((size_t)local * 16 + 8))) return r2;
             ws_bytes = std::max(ws_bytes, rb_e * rbw + sn_e * 4 + bs_e * 8);
             std::vector<int2> smap((size_t)local);
@@ -1150,7 +1199,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)local * 8, hipMemcpyHostToDevice, stream));
             HIPCHK(hipMemcpyAsync(d_starts, starts, 16, hipMemcpyHostToDevice, stream));
             HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)local * 8 + 8, stream));
-            HIPCHK(hipMemsetAsync(c.cl_bases.p, 0, (size_t)bs_e * 8, stream));
+            HIPCHK(hipMemsetAsync(ar_bases, 0, (size_t)bs_e * 8, stream));
             if (s0 > 0) { // the stand-in strip 0: done and claimed; its bottom row and bases = what the strip above handed down
                 // (no conversion: the keys are V' = V - e (i + j) with the PAIR's row i in every panel -- the recurrences never look at i, and
                 // column 0 of a global alignment is the same constant in every row; only the final un-rebasing used the panel's row count, below)
@@ -1158,36 +1207,39 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                 const char *top = tops + (s0 / Sb) * top_b;
                 HIPCHK(hipMemcpyAsync(d_sprog, pre, 4, hipMemcpyHostToDevice, stream));
                 HIPCHK(hipMemcpyAsync(d_sprog + local, one, 4, hipMemcpyHostToDevice, stream));
-                HIPCHK(hipMemcpyAsync(c.rowbuf.p, top, (size_t)(mcols + 1) * rbw, hipMemcpyDeviceToDevice, stream));
-                HIPCHK(hipMemcpyAsync(c.cl_bases.p, top + (m + 1) * rbw, (size_t)nq * 8, hipMemcpyDeviceToDevice, stream));
+                HIPCHK(hipMemcpyAsync(ar_rows, top, (size_t)(mcols + 1) * rbw, hipMemcpyDeviceToDevice, stream));
+                HIPCHK(hipMemcpyAsync(ar_bases, top + (m + 1) * rbw, (size_t)nq * 8, hipMemcpyDeviceToDevice, stream));
             }
             HIPCHK(hipStreamSynchronize(stream)); // (pl, smap, starts are locals)
             const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
             const int2 *d_smap = reinterpret_cast<const int2 *>(c.strip_map.p);
-            long long *dbs = reinterpret_cast<long long *>(c.cl_bases.p);
-            int *dsn = forward ? nullptr : reinterpret_cast<int *>(c.fp_ckpt.p); // (null: the sweep keeps no snapshots)
+            long long *dbs = reinterpret_cast<long long *>(ar_bases);
+            int *dsn = forward ? nullptr : reinterpret_cast<int *>(ar_snap); // (null: the sweep keeps no snapshots)
             KParams kps = kp;
             kps.ckc = (int)ck; kps.rb_pub = w64 ? w64_pub() : RB_PUB;
-            if (w64 && affine) { g_last_w64_r = rw64; g_last_w64_ck = ck; }
+            if (w64) { g_last_w64_r = rw64; g_last_w64_ck = ck; }
             const dim3 gridS((unsigned)local);
             HIPCHK(hipEventRecord(c.ev[1], stream));
             if (w64 && !affine) {
-                int *drb = reinterpret_cast<int *>(c.rowbuf.p);
-                if (p16) hipLaunchKernelGGL((cl64_sweep_kernel<true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
-                else hipLaunchKernelGGL((cl64_sweep_kernel<false>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                int *drb = reinterpret_cast<int *>(ar_rows);
+                w64c_rows_dispatch(rw64, [&](auto rwc) {
+                    constexpr int RW = decltype(rwc)::value;
+                    if (p16) hipLaunchKernelGGL((cl64_sweep_kernel<RW, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                    else hipLaunchKernelGGL((cl64_sweep_kernel<RW, false>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
+                });
             } else if (w64) {
-                int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
+                int2 *drb2 = reinterpret_cast<int2 *>(ar_rows);
                 w64_rows_dispatch(rw64, [&](auto rwc) {
                     constexpr int RW = decltype(rwc)::value;
                     if (p16) hipLaunchKernelGGL((al64_sweep_kernel<RW, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
                     else hipLaunchKernelGGL((al64_sweep_kernel<RW, false>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
                 });
             } else if (affine) {
-                int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
+                int2 *drb2 = reinterpret_cast<int2 *>(ar_rows);
                 if (p16) hipLaunchKernelGGL((al_sweep_kernel<true, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
                 else hipLaunchKernelGGL((al_sweep_kernel<false, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
             } else {
-                int *drb = reinterpret_cast<int *>(c.rowbuf.p);
+                int *drb = reinterpret_cast<int *>(ar_rows);
                 if (p16) hipLaunchKernelGGL((cl_sweep_kernel<true, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
                 else hipLaunchKernelGGL((cl_sweep_kernel<false, true>), gridS, dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs);
             }
@@ -1198,8 +1250,8 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                 for (int64_t e = s0 + Sb; e <= s0 + cnt && e < total_strips; e += Sb) {
                     const int64_t sl = (e - 1 - s0) + (s0 > 0 ? 1 : 0); // that strip's slot in this launch
                     char *top = tops + (e / Sb) * top_b;
-                    HIPCHK(hipMemcpyAsync(top, reinterpret_cast<char *>(c.rowbuf.p) + (size_t)(sl * (m + 1)) * rbw, (size_t)(m + 1) * rbw, hipMemcpyDeviceToDevice, stream));
-                    HIPCHK(hipMemcpyAsync(top + (m + 1) * rbw, reinterpret_cast<char *>(c.cl_bases.p) + (size_t)(sl * nq) * 8, (size_t)nq * 8, hipMemcpyDeviceToDevice, stream));
+                    HIPCHK(hipMemcpyAsync(top, reinterpret_cast<char *>(ar_rows) + (size_t)(sl * (m + 1)) * rbw, (size_t)(m + 1) * rbw, hipMemcpyDeviceToDevice, stream));
+                    HIPCHK(hipMemcpyAsync(top + (m + 1) * rbw, reinterpret_cast<char *>(ar_bases) + (size_t)(sl * nq) * 8, (size_t)nq * 8, hipMemcpyDeviceToDevice, stream));
                 }
             }
             HIPCHK(hipEventSynchronize(c.ev[2]));
@@ -1208,11 +1260,10 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             fill_ms += f;
             return GNX_OK;
         };
-        // buffers of an earlier call (or pair) stay where what comes fits beside them: a fresh allocation of this size takes seconds
-        auto mem_free = [&]() -> int64_t { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? (int64_t)fr : 0; };
-        {
-            const int64_t need_f = (std::min(Sf, total_strips) + 2) * (m + 1) * rbw;
-            if ((int64_t)c.rowbuf.cap < need_f && mem_free() + (int64_t)c.rowbuf.cap < need_f + need_f / 6) c.fp_ckpt.release();
+        { // the arena: the biggest launch of the forward pass (rows + bases of Sf + 2 strips) or of the backward pass (+ snapshots, Sb + 2 strips)
+            const int64_t lf = std::min(Sf, total_strips) + 2, lb = std::min(Sb, total_strips) + 2;
+            const int64_t need_f = lf * (m + 1) * rbw + lf * nq * 8 + 1024, need_b = lb * (m + 1) * rbw + lb * nq * 8 + ((m + GS - 1) / ck) * lb * GS * snw * 4 + 1024;
+            if ((rc = c.mega_arena.ensure((size_t)std::max(need_f, need_b)))) return rc;
         }
         for (int64_t s0 = 0; s0 < total_strips; s0 += Sf) if ((rc = sweep_rows(s0, std::min(Sf, total_strips - s0), m, true))) return rc; // forward
         int64_t n_local_last = 0;
@@ -1221,14 +1272,6 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
         { // ... un-rebased by the kernel with that launch's row count: the rows above it are still owed
             const long long owed = (long long)(affine ? prm->gap_extend : prm->gap_open) * (n - n_local_last);
             if (owed) hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<long long *>(d_score + p), (int64_t)1, owed);
-        }
-        // backward: the forward pass's row buffer (up to the whole budget) makes room for the snapshots
-        { // the snapshots of the largest panel, once; the forward pass's row buffer gives way only when they do not fit beside it
-            const int64_t need_sn = ((m + GS - 1) / ck) * (std::min(Sb, total_strips) + 2) * GS * snw * 4;
-            if ((int64_t)c.fp_ckpt.cap < need_sn) {
-                if (mem_free() + (int64_t)c.fp_ckpt.cap < need_sn + need_sn / 6) c.rowbuf.release();
-                if ((rc = c.fp_ckpt.ensure((size_t)need_sn))) return rc;
-            }
         }
         MegaState st;
         memset(&st, 0, sizeof(st));
@@ -1240,18 +1283,18 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             if (st.resume) { st.wi = pl.n; st.wj = (int32_t)jcur; }
             HIPCHK(hipMemcpyAsync(d_st, &st, sizeof(st), hipMemcpyHostToDevice, stream));
             const PairPlan *dpl = reinterpret_cast<const PairPlan *>(c.plans.p);
-            const long long *dbs = reinterpret_cast<const long long *>(c.cl_bases.p);
-            const int *dsn = reinterpret_cast<const int *>(c.fp_ckpt.p);
+            const long long *dbs = reinterpret_cast<const long long *>(ar_bases);
+            const int *dsn = reinterpret_cast<const int *>(ar_snap);
             int64_t *d_tmp_score = dhf + 2; // (the walk writes hfin[pl.hcol_off] here when it ends: not the pair's score, see above)
             HIPCHK(hipEventRecord(c.ev[1], stream));
             const int farm_nt = w64 ? w64_farm_tiles() : 0;
             if (farm_nt > 0) {
                 KParams kpf = kp;
                 kpf.ckc = (int)ck;
-                if ((rc = run_walk_farm(c, affine, p16, 1, farm_nt, dpl, d_a, d_starts, d_b, d_starts + 1, kpf, tp, c.rowbuf.p, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st,
+                if ((rc = run_walk_farm(c, affine, p16, 1, farm_nt, dpl, d_a, d_starts, d_b, d_starts + 1, kpf, tp, ar_rows, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st,
                                         std::min<int64_t>((int64_t)pl.n + jcur, 2 * (int64_t)pl.n) / 2, stream))) return rc;
             } else if (w64 && !affine) {
-                const int *drb = reinterpret_cast<const int *>(c.rowbuf.p);
+                const int *drb = reinterpret_cast<const int *>(ar_rows);
                 if (w64_two_waves()) {
                     if (p16) hipLaunchKernelGGL((cl64_walk2_kernel<true>), dim3(1), dim3(128), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
                     else hipLaunchKernelGGL((cl64_walk2_kernel<false>), dim3(1), dim3(128), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
@@ -1259,7 +1302,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                 else if (p16) hipLaunchKernelGGL((cl64_walk_kernel<true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
                 else hipLaunchKernelGGL((cl64_walk_kernel<false>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
             } else if (w64) {
-                const int2 *drb2 = reinterpret_cast<const int2 *>(c.rowbuf.p);
+                const int2 *drb2 = reinterpret_cast<const int2 *>(ar_rows);
                 if (w64_two_waves()) {
                     if (p16) hipLaunchKernelGGL((al64_walk2_kernel<true>), dim3(1), dim3(128), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
                     else hipLaunchKernelGGL((al64_walk2_kernel<false>), dim3(1), dim3(128), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
@@ -1267,11 +1310,11 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
                 else if (p16) hipLaunchKernelGGL((al64_walk_kernel<true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
                 else hipLaunchKernelGGL((al64_walk_kernel<false>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
             } else if (affine) {
-                const int2 *drb2 = reinterpret_cast<const int2 *>(c.rowbuf.p);
+                const int2 *drb2 = reinterpret_cast<const int2 *>(ar_rows);
                 if (p16) hipLaunchKernelGGL((al_walk_kernel<true, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
                 else hipLaunchKernelGGL((al_walk_kernel<false, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb2, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
             } else {
-                const int *drb = reinterpret_cast<const int *>(c.rowbuf.p);
+                const int *drb = reinterpret_cast<const int *>(ar_rows);
                 if (p16) hipLaunchKernelGGL((cl_walk_kernel<true, 1, CKC_SMALL, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
                 else hipLaunchKernelGGL((cl_walk_kernel<false, 1, CKC_SMALL, true>), dim3(1), dim3(64), 0, stream, dpl, 1, d_a, d_starts, d_b, d_starts + 1, kp, tp, drb, dsn, dhf, d_tmp_score, dn + p, d_so + p, d_scr, d_err, dbs, d_st);
             }
@@ -1399,7 +1442,8 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
         const long long o4w = 4 * (long long)prm->gap_open, e4w = affine ? 4 * (long long)prm->gap_extend : 0;
         const long long d00w = local ? 0 : o4w, ecolw = local ? 0 : e4w;
 #define GNX_WIDE(A_, L_) hipLaunchKernelGGL((lat_wide_kernel<A_, L_>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, o4w, e4w, d00w, ecolw, dtrace, dh, d_s64, drw, ddc, d_err, d_smap, d_claims)
-        if (affine) { if (local) GNX_WIDE(true, true); else GNX_WIDE(true, false); }
+        if (d_smat) hipLaunchKernelGGL((lat_wide_kernel<true, false, true>), gridF, blk, 0, stream, dpl, np, d_a, d_as, d_b, d_bs, kp, o4w, e4w, d00w, ecolw, dtrace, dh, d_s64, drw, ddc, d_err, d_smap, d_claims, d_smat);
+        else if (affine) { if (local) GNX_WIDE(true, true); else GNX_WIDE(true, false); }
         else GNX_WIDE(false, false);
 #undef GNX_WIDE
     }
@@ -1485,6 +1529,13 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         // beyond the STATIC int32 range of the kernels' keys (4 * score, absolute): such pairs take the snapshot path with moving bases
         // (REBASE, const_long.hip.h), which has no length limit -- see the clong block below; the reference is int64 throughout (align/align.go:8)
         if ((n + m + 2) * std::max<int64_t>(maxpen, 1) >= ((int64_t)1 << 27) && first_oor < 0) first_oor = p;
+    }
+    // ---- the chunk / multiple-alignment variants with a pair beyond the int32 range (run_host_scored built plain 4 * s matrices): the int64 kernel ----
+    if (!gsw && d_smat && t_scored_wide) {
+        rc = run_device_lat(prm, kp, tp, affine, local, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, d_smat, h_soff, false, true);
+        if (rc >= 0) return rc;
+        if (rc == -2) { set_err("a strip of the int64 kernel waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
+        set_err("the direction matrices of a chunk / multiple-alignment call beyond the int32 range do not fit the workspace (or a sequence is empty)%s", ""); return GNX_ENOMEM;
     }
     // ---- GNX_WIDE=2 (tests): everything through the int64 kernel (lat_wide.hip.h) ----
     if (!gsw && !d_smat && !c.beta_packed) {
@@ -1705,13 +1756,13 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         const char *w64e = getenv("GNX_W64");
         bool few_long = n_pairs <= 64 && w64_farm_tiles() > 0;
         for (int64_t p = 0; few_long && p < n_pairs; p++) if (h_alen[p] < 2 * H64) few_long = false;
-        t_w64_r = R;
+        t_w64_r = R; t_w64_rc = R;
         // (steps between two moves of a strip's base: the widest snapshot spacing the keys' spread admits, for the farm's affine sweep)
         t_w64_ck = CKA;
         if (affine && w64_farm_tiles() > 0) for (int v = w64_farm_ck(); v > CKA; v >>= 1) if ((int64_t)(H64 + G64 + v + 64) * step4 < ((int64_t)1 << 28)) { t_w64_ck = v; break; }
         const int64_t ck_w64 = std::max<int64_t>(CKC64, t_w64_ck);
         const bool w64 = !no_pipe() && (int64_t)(H64 + G64 + ck_w64 + 64) * step4 < ((int64_t)1 << 28) && !(w64e && w64e[0] == '0') && (n_pairs <= 3 || few_long || (w64e && w64e[0] == '2'));
-        if (w64 && affine && w64_farm_tiles() > 0) t_w64_r = w64_pick_rows(c, n_pairs, h_alen, h_blen, step4, t_w64_ck);
+        if (w64 && w64_farm_tiles() > 0) { if (affine) t_w64_r = w64_pick_rows(c, true, n_pairs, h_alen, h_blen, step4, t_w64_ck); else t_w64_rc = w64_pick_rows(c, false, n_pairs, h_alen, h_blen, step4, CKC64); }
         long double cells_ld = 0, dir_bytes = 0, rows_ld = 0, cols_ld = 0;
         for (int64_t p = 0; use && p < n_pairs; p++) {
             if (h_alen[p] < 1 || h_blen[p] < 1) use = false;
@@ -1748,14 +1799,15 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
     if (oor) {
         // what is left has absolute int32 keys -- AffineGapLocal, gapOpen > 0, scores too big for moving bases: the int64 kernel (lat_wide.hip.h),
         // limited by the workspace its stored direction matrix needs (1 B per cell), not by a range.  The chunk / graph variants keep int32.
-        if (!gsw && !d_smat && (n_pairs == 0 || (long double)(h_alen[first_oor] + h_blen[first_oor] + 2) * (long double)std::max<int64_t>(maxpen, 1) < 1.0e17L)) {
-            rc = run_device_lat(prm, kp, tp, affine, local, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, nullptr, nullptr, false, true);
+        // (round 6: the chunk / multiple-alignment variants too -- their explicit score matrices must then hold plain 4 * s int32 entries: run_host_scored)
+        if (!gsw && !(d_smat && smat16) && (n_pairs == 0 || (long double)(h_alen[first_oor] + h_blen[first_oor] + 2) * (long double)std::max<int64_t>(maxpen, 1) < 1.0e17L)) {
+            rc = run_device_lat(prm, kp, tp, affine, local, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, d_smat, h_soff, false, true);
             if (rc >= 0) return rc;
             if (rc == -2) { set_err("a strip of the int64 kernel waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
             set_err("pair %s%lld is beyond the int32 range of its mode and its direction matrix does not fit the workspace (or a sequence is empty)", "", (long long)first_oor);
             return GNX_ENOMEM;
         }
-        set_err("pair %s%lld exceeds the int32 DP range of this variant (chunk / graph-extension DPs)", "", (long long)first_oor);
+        set_err("pair %s%lld exceeds the int32 DP range of this variant (graph-extension DPs)", "", (long long)first_oor);
         return GNX_ERANGE;
     }
     // ---- plan ----
@@ -2030,9 +2082,19 @@ int run_host_scored(const gnx_params *prm, int64_t chunk, bool groups, int64_t n
     int64_t smax = 0; // int16 score matrix when every 4 * cell score fits (a cell is a sum of `chunk` scores, or of averages of scores)
     for (int x = 0; x < 25; x++) smax = std::max<int64_t>(smax, llabs((long long)prm->scores[x]));
     // the fill's h-form works on rebased keys: the matrix entries carry the -2e of the diagonal move (e = gapExtend * chunk)
-    const bool hform_sc = prm2.gap_open <= 0 && !getenv("GNX_NO_HFORM");
+    // a pair beyond the static int32 range of the keys sends the whole call to the int64 kernel (lat_wide_kernel<.., SCORED>): plain int32 entries 4 * s
+    bool wide_sc = false;
+    {
+        const int64_t maxpen2 = max_abs_pen(&prm2, true);
+        for (int64_t p = 0; p < n_pairs; p++) if ((sp[(size_t)p].nc + sp[(size_t)p].mc + 2) * std::max<int64_t>(maxpen2, 1) >= ((int64_t)1 << 27)) wide_sc = true;
+        if (getenv("GNX_WIDE") && getenv("GNX_WIDE")[0] == '2') wide_sc = true; // (tests: every call)
+        if (wide_sc && 4 * chunk * smax > 0x3fffffff) { set_err("chunk score out of range%s", ""); return GNX_ERANGE; }
+    }
+    t_scored_wide = wide_sc;
+    struct ScoredWideReset { ~ScoredWideReset() { t_scored_wide = false; } } scored_wide_reset;
+    const bool hform_sc = !wide_sc && prm2.gap_open <= 0 && !getenv("GNX_NO_HFORM");
     const int64_t bias4 = hform_sc ? -8 * prm2.gap_extend : 0;
-    const bool s16 = 4 * chunk * smax + llabs((long long)bias4) <= 32767;
+    const bool s16 = !wide_sc && 4 * chunk * smax + llabs((long long)bias4) <= 32767;
     std::vector<int64_t> hn((size_t)n_pairs), hm((size_t)n_pairs), hso((size_t)n_pairs);
     int64_t stot = 0, worst = 0, maxcols = 1, maxrows = 1, prof_a = 0, prof_b = 0, max_nseq = 1;
     for (int64_t p = 0; p < n_pairs; p++) {
@@ -2368,7 +2430,7 @@ void gnx_shutdown(void) {
                           &c.fp_wplans[0], &c.fp_wplans[1], &c.fp_active[0], &c.fp_active[1], &c.trace, &c.hcol, &c.rowbuf, &c.dcol, &c.plans, &c.nops, &c.misc, &c.in_a, &c.in_b,
                           &c.in_as, &c.in_al, &c.in_bs, &c.in_bl, &c.out_score, &c.out_off, &c.out_ops, &c.out_end, &c.sc_pairs, &c.sc_mat, &c.sc_err,
                           &c.pin_a[0], &c.pin_a[1], &c.pin_as[0], &c.pin_as[1], &c.pin_b[0], &c.pin_b[1], &c.pin_bs[0], &c.pin_bs[1], &c.res_score, &c.res_off, &c.res_ops,
-                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.cl_bases, &c.sc_prof_a, &c.sc_prof_b, &c.mega_rows, &c.mega_state, &c.farm, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
+                          &c.ref, &c.ref_flag, &c.ref_rank, &c.ref_exc, &c.unpk_b, &c.unpk_off, &c.cl_bases, &c.sc_prof_a, &c.sc_prof_b, &c.mega_rows, &c.mega_state, &c.farm, &c.mega_arena, &c.gat_score, &c.gat_off, &c.gat_ops, &c.sd_keys, &c.sd_locs, &c.sd_nodes, &c.sd_node_off, &c.sd_word_off, &c.sd_words,
                           &c.sd_tmp[0], &c.sd_tmp[1], &c.sd_tmp[2], &c.sd_tmp[3], &c.sd_tmp[4], &c.sd_tmp[5], &c.sd_tmp[6], &c.sd_tmp[7]};
         for (DevBuf *b : bufs) b->release();
         PinBuf *pins[] = {&c.h_plans, &c.st_a[0], &c.st_a[1], &c.st_as[0], &c.st_as[1], &c.st_b[0], &c.st_b[1], &c.st_bs[0], &c.st_bs[1]};

@@ -31,14 +31,18 @@ __device__ __forceinline__ void wide_store(k64 *p, k64 v) { __hip_atomic_store(p
 __device__ __forceinline__ k64 wide_load(const k64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // rowbuf: k64 entries, AFFINE: {dn, h} per column (2 entries), constant gap: 1 entry; pl.rowbuf_off in entries
-template <bool AFFINE, bool LOCAL>
+// SCORED (round 6: the chunk / multiple-alignment variants beyond the int32 range, align/affineGap_highMem.go:227-353 is int64 there too): the substitution score of
+// a cell comes from the pair's explicit matrix in HBM (column-major int32 entries 4 * s, no bias: S[s_off + (j-1) s_pitch + (i-1)]), loaded sixteen steps ahead into a
+// register ring exactly as lat_fill_kernel<.., SCORED> does; sequences are not read.
+template <bool AFFINE, bool LOCAL, bool SCORED = false>
 __global__ __launch_bounds__(64) void lat_wide_kernel(const PairPlan *__restrict__ plans, int n_pairs,
                                                       const uint8_t *__restrict__ a_buf, const int64_t *__restrict__ a_start,
                                                       const uint8_t *__restrict__ b_buf, const int64_t *__restrict__ b_start,
                                                       KParams kp, long long o4w, long long e4w, long long d00w, long long ecolw,
                                                       uint4 *__restrict__ trace, int *__restrict__ hcol, int64_t *__restrict__ score64,
                                                       k64 *__restrict__ rowbuf, unsigned *__restrict__ dcol, int *__restrict__ err,
-                                                      const int2 *__restrict__ strip_map, int *__restrict__ claims) {
+                                                      const int2 *__restrict__ strip_map, int *__restrict__ claims, const int *__restrict__ smat = nullptr) {
+    static_assert(!SCORED || (AFFINE && !LOCAL), "the scored variants have AffineGap_highMem semantics");
     // o4w / e4w / d00w / ecolw: 4 * gapOpen (constant gap: 4 * gapPen), 4 * gapExtend, 4 * D(0,0), 4 * (column-0 extension) in int64; kp.sc4 = 4 * scores (int32: |score| <= 2^26)
     static_assert(AFFINE || !LOCAL, "free end gaps are an affine mode");
     constexpr int TI = 2, TD = 1;
@@ -56,9 +60,9 @@ __global__ __launch_bounds__(64) void lat_wide_kernel(const PairPlan *__restrict
     if (n_stolen < 0) return;
     const int p = strip_map[blockIdx.x].x;
     const PairPlan pl = plans[p];
-    const uint8_t *ap = a_buf + a_start[pl.src];
+    const uint8_t *ap = SCORED ? nullptr : a_buf + a_start[pl.src];
     BetaBytes bp;
-    bp.init(b_buf, kp, b_start[pl.src], pl.m);
+    bp.init(b_buf, kp, SCORED ? 0 : b_start[pl.src], SCORED ? 0 : pl.m);
     const int m = pl.m;
     const int Tend = (m + (LG - 1) + 15) & ~15;
     const k64 O4 = o4w, E4 = e4w, OE4 = o4w + e4w;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(64) void lat_wide_kernel(const PairPlan *__restrict
     for (int s = s_own - n_stolen; s <= s_own; s++) {
         const bool store_row = s + 1 < pl.strips;
         const int row0 = s * LH + l * LR;
-        {
+        if (!SCORED) {
             int a5[LR];
 #pragma unroll
             for (int r = 0; r < LR; r++) {
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(64) void lat_wide_kernel(const PairPlan *__restrict
                     const k64 *src = &rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + (int64_t)c * RBW];
                     odn = wide_load(src); if (AFFINE) oh = wide_load(src + 1);
                 }
-                ob = bp.raw(c - 1);
+                if (!SCORED) ob = bp.raw(c - 1);
             }
         };
         auto settle = [&](int c, k64 &odn, k64 &oh) {
@@ -142,7 +146,20 @@ __global__ __launch_bounds__(64) void lat_wide_kernel(const PairPlan *__restrict
                 }
             }
         };
-        auto base_off = [&](int raw, int c) { int b = (l < 16 && c >= 1 && c <= m) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
+        auto base_off = [&](int raw, int c) { if (SCORED) return 0; int b = (l < 16 && c >= 1 && c <= m) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
+        // SCORED: the ring of score entries, slot u = the step at position u of a block (lat_fill.hip.h: no branch around the load, a lane outside its columns loads
+        // the entry of the nearest one it has and never uses it)
+        int ring[16][LR];
+        auto ring_load = [&](int t, int u) {
+            const int j = min(max(t - l, 1), m);
+            const int2 v = *reinterpret_cast<const int2 *>(smat + pl.s_off + (int64_t)(j - 1) * pl.s_pitch + row0);
+            ring[u][0] = v.x + 3; ring[u][1] = v.y + 3; // (the diagonal candidate's tag rides on the entry, like on the profile's)
+        };
+        static_assert(LR == 2, "the ring loads two adjacent rows as one 8-byte entry");
+        if (SCORED) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) ring_load(u + 1, u);
+        }
         issue(l + 1, qdn, qh, qb);
         settle(l + 1, qdn, qh);
         qb = base_off(qb, l + 1);
@@ -152,19 +169,27 @@ __global__ __launch_bounds__(64) void lat_wide_kernel(const PairPlan *__restrict
 #pragma unroll
             for (int k = 0; k < LR; k++) w[k] = pw[k];
         };
-        pb_cur = wave_shr1(qb, b_out);
-        qb = dpp_shl1(qb, qb);
-        fetch(pb_cur, wq);
-        auto step = [&](const int t, const bool take, const int nqv) {
+        pb_cur = 0;
+        if (!SCORED) {
+            pb_cur = wave_shr1(qb, b_out);
+            qb = dpp_shl1(qb, qb);
+            fetch(pb_cur, wq);
+        }
+        auto step = [&](const int t, const bool take, const int nqv, const int u = 0) {
             const k64 up_dn = wave_shr1_64(qdn, dn_out);
             const k64 up_h = AFFINE ? wave_shr1_64(qh, h_out) : 0;
             qdn = row_shl1_64(qdn, qdn);
             if (AFFINE) qh = row_shl1_64(qh, qh);
-            if (take) qb = nqv;
-            const int pb_next = wave_shr1(qb, pb_cur);
-            qb = dpp_shl1(qb, qb);
-            int wn[LR];
-            fetch(pb_next, wn);
+            int wn[LR], pb_next = 0;
+            if (!SCORED) {
+                if (take) qb = nqv;
+                pb_next = wave_shr1(qb, pb_cur);
+                qb = dpp_shl1(qb, qb);
+                fetch(pb_next, wn);
+            } else {
+#pragma unroll
+                for (int k = 0; k < LR; k++) { wq[k] = ring[u][k]; wn[k] = 0; }
+            }
             const int j = t - l;
             if (j >= 1 && j <= m) {
                 if (AFFINE) {
@@ -205,15 +230,22 @@ __global__ __launch_bounds__(64) void lat_wide_kernel(const PairPlan *__restrict
             }
             sq_dn = row_shl1_64(dn_out, sq_dn);
             if (AFFINE) sq_h = row_shl1_64(h_out, sq_h);
+            if (!SCORED) {
 #pragma unroll
-            for (int k = 0; k < LR; k++) wq[k] = wn[k];
-            pb_cur = pb_next;
+                for (int k = 0; k < LR; k++) wq[k] = wn[k];
+                pb_cur = pb_next;
+            }
         };
 
         for (int t0 = 0; t0 < Tend; t0 += 16) {
             issue(t0 + 16 + l + 1, ndn, nh, nb);
+            if (SCORED) { // (the ring is indexed by the position in the block: unrolled; the slot of step u is re-loaded right after step u has used it)
+#pragma unroll
+                for (int u = 0; u < 16; u++) { step(t0 + u + 1, false, 0, u); ring_load(t0 + 16 + u + 1, u); }
+            } else {
 #pragma unroll 4
-            for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, u == 15, nb); }
+                for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, u == 15, nb); }
+            }
             settle(t0 + 16 + l + 1, ndn, nh);
             qdn = ndn; qh = nh;
             const int w = t0 >> 4;

@@ -64,10 +64,10 @@ BUDGET = [
     # rounds 5 / 6: the latency geometry, the int64 kernel, the 64-lane snapshot kernels (rows per lane 6 / 8 / 10 / 16: the sweep of ONE long pair is
     # strips(RW) waves on 1 024 SIMDs, up to 2 605 of them at RW = 6 -- three per SIMD must fit) and the walk farm
     ("lat_fill_kernel<false, false, false, false>", 8), ("lat_fill_kernel<true, false, false, false>", 6), ("lat_fill_kernel<true, true, false, false>", 5),
-    ("lat_fill_kernel<true, false, true, false>", 3), ("lat_fill_kernel<true, false, true, true>", 4), ("lat_wide_kernel<false", 8), ("lat_wide_kernel<true", 5),
+    ("lat_fill_kernel<true, false, true, false>", 3), ("lat_fill_kernel<true, false, true, true>", 4), ("lat_wide_kernel<false", 8), ("lat_wide_kernel<true", 5), ("lat_wide_kernel<true, false, true>", 3),
     ("al64_sweep_kernel<6, true>", 5), ("al64_sweep_kernel<6, false>", 4), ("al64_sweep_kernel<8, true>", 4), ("al64_sweep_kernel<8, false>", 4),
     ("al64_sweep_kernel<10, true>", 4), ("al64_sweep_kernel<10, false>", 3), ("al64_sweep_kernel<16, true>", 3), ("al64_sweep_kernel<16, false>", 2),
-    ("cl64_sweep_kernel<true>", 5), ("cl64_sweep_kernel<false>", 4),
+    ("cl64_sweep_kernel<10, true>", 5), ("cl64_sweep_kernel<10, false>", 4), ("cl64_sweep_kernel<4", 7),
     ("al64_farm_round_kernel<6", 3), ("al64_farm_round_kernel<8", 3), ("al64_farm_round_kernel<10", 2), ("al64_farm_round_kernel<16", 2), ("cl64_farm_round_kernel", 6),
     ("farm_walk_kernel<true", 3), ("farm_walk_kernel<false", 6), ("al64_walk_kernel", 2), ("al64_walk2_kernel", 3), ("cl64_walk_kernel", 4), ("cl64_walk2_kernel", 5),
 ]
@@ -82,7 +82,7 @@ LDS_GRANULES = [("fp_sweep_kernel", 11), ("fp_sweep_levels_kernel", 11), ("cl_sw
                 # rounds 5 / 6: the sweeps of one long pair hold a wave's profile only; a round of the farm (walk window 52 KB + one re-fill's profile) and the
                 # one-workgroup walks (one / two tiles of three direction planes in LDS) must stay inside the 64 KB / 160 KB a workgroup may declare
                 ("al64_sweep_kernel<6, true>", 4), ("al64_sweep_kernel<8, true>", 5), ("al64_sweep_kernel<10, true>", 6), ("al64_sweep_kernel<16, true>", 9), ("al64_sweep_kernel<16, false>", 17),
-                ("cl64_sweep_kernel<true>", 6), ("lat_fill_kernel", 3), ("lat_wide_kernel", 3),
+                ("cl64_sweep_kernel<10, true>", 6), ("cl64_sweep_kernel<4, true>", 3), ("lat_fill_kernel", 3), ("lat_wide_kernel", 3),
                 ("al64_farm_round_kernel", 57), ("cl64_farm_round_kernel", 21), ("farm_walk_kernel", 41), ("al64_walk_kernel", 67), ("al64_walk2_kernel", 125), ("cl64_walk2_kernel", 67)]
 
 

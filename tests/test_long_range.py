@@ -217,6 +217,7 @@ def test_w64_forced(gpu_lib, monkeypatch, mode, cs, walk):
     if walk.endswith(":seq"):
         monkeypatch.setenv("GNX_W64_FARM_PIPE", "0")
         walk = walk[:-4]
+    monkeypatch.setenv("GNX_W64_RC", "4" if ":r" in walk else "10")  # ... of the constant-gap sweep + farm (4 / 10: strips of 256 / 640 rows)
     if ":r" in walk:
         monkeypatch.setenv("GNX_W64_R", walk.split(":r")[1].split(":")[0])
         walk = walk.replace(":r" + walk.split(":r")[1].split(":")[0], "")
@@ -271,8 +272,13 @@ def test_w64_row_panels(gpu_lib, monkeypatch, mode, strips):
     monkeypatch.delenv("GNX_W64_FARM_PIPE", raising=False)
     monkeypatch.delenv("GNX_W64_CK", raising=False)
     monkeypatch.setenv("GNX_W64_R", strips.split(":farm_r")[1] if ":farm_r" in strips else "10")  # rows per lane of the affine sweep + farm
+    monkeypatch.setenv("GNX_W64_RC", "4" if ":farm_r" in strips else "10")  # ... of the constant-gap one
+    monkeypatch.delenv("GNX_W64_CK_MEGA", raising=False)  # (default: 2 048 steps between the snapshots of a row panel's strips)
     if strips.endswith(":farm_ck128"):
         monkeypatch.setenv("GNX_W64_CK", "128")
+        monkeypatch.setenv("GNX_W64_CK_MEGA", "128")
+    if strips.endswith(":farm_r8"):
+        monkeypatch.setenv("GNX_W64_CK_MEGA", "1024")
     if strips.endswith(":farm_seq"):
         monkeypatch.setenv("GNX_W64_FARM_PIPE", "0")
     if strips.endswith(":farm2"):
@@ -379,5 +385,6 @@ def test_row_panels_at_their_natural_size(gpu_lib, monkeypatch):
     free = fr.value + 0  # (plus what the library's context already holds: it re-uses it)
     if free < 150 * 2 ** 30:
         pytest.skip("needs a device with 150 GB free")
-    monkeypatch.setenv("GNX_W64_CK", "128")
+    monkeypatch.setenv("GNX_W64_CK", "128")       # (the one-launch path: 350 GB -> row panels)
+    monkeypatch.setenv("GNX_W64_CK_MEGA", "128")  # (and the panels keep that spacing: several backward panels instead of one)
     _megabase_check(gpu_lib, _long_pairs(), "affine_2M", 5)

@@ -151,3 +151,76 @@ def test_fa_chunk_align_command(gpu_lib, tmp_path):  # cmd/faChunkAlign/faChunkA
     exp = align.AllSeqAffineChunk(records, align.HumanChimpTwoScoreMatrix, -300, -40, 2)
     assert fasta.AllAreEqualIgnoreOrder(got, exp) and fasta.AllAreEqualIgnoreOrder(fasta.Read(out), exp)
     assert len({len(r.Seq) for r in got}) == 1  # an alignment: equal lengths
+
+
+def _n1_got(sc, ops, off, k):
+    return (int(sc[k]), [(int(r), int(o)) for r, o in zip(ops["run_length"][off[k]:off[k + 1]], ops["op"][off[k]:off[k + 1]])])
+
+
+def test_n1_beyond_int32(gpu_lib, geometry):
+    """round 6: the chunk / multiple-alignment variants have no GNX_ERANGE any more -- the reference is int64 there too
+    (align/affineGap_highMem.go:227-353).  A call with a pair whose keys 4 * score leave the static int32 range runs on the int64 kernel with explicit
+    score matrices (lat_wide_kernel<.., SCORED>): scores x 4 000 (keys to 6e9) on ragged pairs, one pair of 2e6 chunk cells, groups with scaled scores --
+    all against the oracle."""
+    if geometry == "general":
+        pytest.skip("the int64 kernel has one geometry")
+    rng = np.random.default_rng(88)
+    x1000 = [[v * 4000 for v in row] for row in align.HumanChimpTwoScoreMatrix]  # (x 4 000: the name is from the first draft)
+    chunk = 3
+    alphas, betas = [], []
+    for k in range(24):
+        na, nb = int(rng.integers(0, 300)), int(rng.integers(1, 400))
+        a = rng.integers(0, 5, size=na * chunk).astype(np.uint8)
+        b = common.mutate(rng, a, sub=0.1, indel=0.05, geo=0.4, alphabet=5) if rng.random() < 0.7 and na else rng.integers(0, 5, size=nb * chunk).astype(np.uint8)
+        b = b[:(len(b) // chunk) * chunk]
+        alphas.append(a); betas.append(b)
+    # one pair of 1400 x 1450 chunk cells (2.0e6): seven strips of the int64 kernel, related sequences
+    a = rng.integers(0, 4, size=1400 * chunk).astype(np.uint8)
+    b = common.mutate(rng, a, sub=0.05, indel=0.01, geo=0.4, alphabet=4)
+    b = np.concatenate([b, rng.integers(0, 4, size=1450 * chunk).astype(np.uint8)])[:1450 * chunk]
+    alphas.append(a); betas.append(b)
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_HIGHMEM, x1000, -2400000, -600000)
+    sc, ops, off = gpu_lib.affine_gap_chunk_batch(p, chunk, alphas, betas)
+    assert int(np.abs(sc).max()) * 4 > 2 ** 31  # the keys really leave int32
+    for k, (a, b) in enumerate(zip(alphas, betas)):
+        assert _n1_got(sc, ops, off, k) == oracle.affine_gap_chunk(x1000, -2400000, -600000, chunk, a, b), k
+    # positive gapOpen (no h-form anywhere) at the same scale
+    p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_HIGHMEM, x1000, 200000, -600000)
+    sc, ops, off = gpu_lib.affine_gap_chunk_batch(p, chunk, alphas[:12], betas[:12])
+    for k in range(12):
+        assert _n1_got(sc, ops, off, k) == oracle.affine_gap_chunk(x1000, 200000, -600000, chunk, alphas[k], betas[k]), ("gapOpen > 0", k)
+    # groups (column averages with Go's truncating division, lower case, gaps) with the default matrix x 20 000
+    big = [[v * 20000 for v in row] for row in align.DefaultScoreMatrix]
+    for ch in (1, 2):
+        groups = []
+        for _ in range(6):
+            nseq, ln = int(rng.integers(1, 5)), int(rng.integers(1, 260)) * ch
+            blk = rng.integers(0, 10, size=(nseq, ln)).astype(np.uint8)
+            blk[rng.random(blk.shape) < 0.1] = dna.Gap
+            blk[0, blk[0] == dna.Gap] = 1
+            groups.append(blk)
+        pairs = [(x, y) for x in range(len(groups)) for y in range(len(groups)) if x != y]
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_HIGHMEM, big, -8000000, -600000)
+        sc, ops, off = gpu_lib.multiple_affine_gap_batch(p, ch, groups, pairs)
+        for k, (x, y) in enumerate(pairs):
+            assert _n1_got(sc, ops, off, k) == oracle.multiple_affine_gap(big, -8000000, -600000, ch, groups[x], groups[y]), (ch, x, y)
+
+
+def test_n1_int64_kernel_forced(gpu_lib, geometry, monkeypatch):
+    """GNX_WIDE=2: the ordinary N1 fuzz shapes through the int64 kernel (plain 4 * s score matrices, literal recurrences) -- same answers"""
+    if geometry == "general":
+        pytest.skip("the int64 kernel has one geometry")
+    monkeypatch.setenv("GNX_WIDE", "2")
+    rng = np.random.default_rng(8)
+    for chunk in (1, 3):
+        alphas, betas = [], []
+        for _ in range(40):
+            na, nb = int(rng.integers(0, 70)), int(rng.integers(0, 90))
+            a = rng.integers(0, 5, size=na * chunk).astype(np.uint8)
+            b = common.mutate(rng, a, sub=0.1, indel=0.05, geo=0.4, alphabet=5) if rng.random() < 0.6 and na else rng.integers(0, 5, size=nb * chunk).astype(np.uint8)
+            b = b[:(len(b) // chunk) * chunk]
+            alphas.append(a); betas.append(b)
+        p = gpu_lib.make_params(gpu_lib.GNX_AFFINE_GAP_HIGHMEM, align.HumanChimpTwoScoreMatrix, -600, -150)
+        sc, ops, off = gpu_lib.affine_gap_chunk_batch(p, chunk, alphas, betas)
+        for k, (a, b) in enumerate(zip(alphas, betas)):
+            assert _n1_got(sc, ops, off, k) == oracle.affine_gap_chunk(MX["HumanChimpTwo"], -600, -150, chunk, a, b), (chunk, k)

@@ -122,7 +122,7 @@ def gpu_rows(names, reps=None):
                "consumes_n_m": (ni, nj) == (a.shape[0], b.shape[0]), "rescored_equals_score": total == int(score[0]), "rescored_minus_score": total - int(score[0]),
                "q1_restarts": int(q1n), "q1_restarts_changed": int(q1c),
                "semantics": "highMem (no checkerboards)" if highmem else "10 000 x 10 000 checkerboards (quirk Q1 can cost the CIGAR a gap open: the reference's own behaviour)"}
-        if affine and int(tm["fast_path"]) in (5, 6):
+        if int(tm["fast_path"]) in (5, 6):
             row["rows_per_lane"], row["snapshot_steps"] = int(_lib.debug_counter(5, reset=False)), int(_lib.debug_counter(6, reset=False))
         if name in fx and not highmem:
             row["equals_oracle"] = digest(score[0], ops) == {k: fx[name][k] for k in ("score", "runs", "sha256")}
