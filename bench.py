@@ -46,7 +46,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0   # ... 6.29 TB/s measured copy bandwidth
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r5_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r6_hbm_traffic.json")
 
 # series -> (gnx mode, oracle mode, gapOpen / gapPen, gapExtend, read length, window length, direction bits per cell, default pairs)
 SERIES = {

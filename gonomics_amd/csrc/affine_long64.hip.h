@@ -56,6 +56,26 @@ __device__ __forceinline__ void al64_snap_load(const uint4 *sp, int (&rt)[RW], i
     diag0 = (int)v[2 * RW]; dn_out = (int)v[2 * RW + 1];
 }
 
+// Hand-over between the piped strips of the 64-lane sweeps WITHOUT a progress word (round 6).  Round 5: a strip stored its bottom row with write-through stores, waited
+// for their acknowledgement (s_waitcnt vmcnt(0): a trip to memory, ~2 - 3 us) every 64 steps and advanced a progress word the strip below polled -- a wave alone on its
+// SIMD (what the strips of ONE long pair are) sat out that wait in full: its step cost ~100 - 150 ns whatever its instruction count (ConstGap 150 kb x 180 kb: 24.1 ms at 10
+// rows per lane, 24.3 ms at 4).  Now every datum says for itself whether it is there (the protocol of lat_fill_kernel): the host fills the row buffer and the bases with
+// 0x80 bytes before the launch (W64_SENT / W64_BSENT: below every key, not a base), the producer just stores, the consumer re-loads an entry that still reads as the
+// sentinel.  An entry is one aligned 8-byte (ConstGap: 4-byte) store and a base one 8-byte store: never torn; nobody relies on the ORDER of two stores.
+constexpr int W64_SENT = (int)0x80808080;
+constexpr long long W64_BSENT = (long long)0x8080808080808080ULL;
+__device__ __forceinline__ long long w64_base_wait(const long long *p, int *err) {
+    long long v = rbase_load(p, true);
+    if (v == W64_BSENT) {
+        const long long t_begin = wall_clock64();
+        while ((v = rbase_load(p, true)) == W64_BSENT) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); v = 0; break; }
+        }
+    }
+    return v;
+}
+
 template <typename F, int... Us>
 __device__ __forceinline__ void al64_unrolled_block(std::integer_sequence<int, Us...>, F &&f) { (f(std::integral_constant<int, Us>{}), ...); }
 // lane 0 <- lane U of its row of 16 (U = 0: a copy): the boundary / base queues of a block stay where they were loaded, the unrolled step U reads its entry
@@ -109,7 +129,6 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
     int bad = 0;
     const int64_t rb_pitch = (int64_t)m + 1;
     for (int s = s_own - n_stolen; s <= s_own; s++) {
-        const int bid = (int)blockIdx.x - s_own + s; // block index of strip s of this pair = its slot in strip_prog
         const bool store_row = s + 1 < pl.strips;
         const int row0 = s * HW + l * RW;
         int rt[RW], hold[RW];
@@ -139,15 +158,17 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
         }
         int diag0 = (row0 == 0) ? max3i(3, kp.o4 + TI, kp.d00_4 + TD) : max3i(NEG4 + 3, NEG4 + TI, kp.d00_4 + row0 * kp.ecol4 + TD - RB * row0);
         int dn_out = 0, h_out = 0, b_out = l * (LW * 4), sq_dn = 0, sq_h = 0;
-        int qdn = 0, qh = 0, qb = 0, ndn = 0, nh = 0, nb = 0;
+        int qdn = 0, qh = 0, qb = 0, ndn = 0, nh = 0, nb = 0, ndd = 0;
         // moving bases (REBASE, const_long.hip.h): mine; the strip above's for the two blocks the columns being loaded were written in
         long long Bown = 0;
         int dlo = 0, dhi = 0, qp = 0, edge = CKR, r0i = kp.o4 + TI;
         bool dhi_ok = false;
         long long *my_bases = bases + pl.rowi_off + (int64_t)s * pl.s_pitch;
-        auto bprod = [&](int q) -> long long { return s == 0 ? 0LL : rbase_load(my_bases - pl.s_pitch + q, true); };
-        auto boundary = [&](int c, int &odn, int &oh, int &ob) { // lanes 0 .. 15: column c of the row above the strip, the base of column c
-            odn = 0; oh = 0; ob = 0;
+        // the base of block q of the strip above (a block nobody needs -- its first column lies beyond m -- is never stored: 0)
+        auto bprod = [&](int q) -> long long { return (s == 0 || (int64_t)q * CKR > (int64_t)m + XB64) ? 0LL : w64_base_wait(my_bases - pl.s_pitch + q, err); };
+        // lanes 0 .. 15: column c of the row above the strip as it is in memory (odn, oh; s > 0: to be settled, then shifted by odd to my base), the base of column c
+        auto boundary = [&](int c, int &odn, int &oh, int &ob, int &odd) {
+            odn = 0; oh = 0; ob = 0; odd = 0;
             if (l < 16 && c >= 1 && c <= m) {
                 if (s == 0) {
                     const int M3 = NEG4 + 3, I2 = r0i, D1 = NEG4 + TD; // row 0: I(0,c) = gapOpen + c*gapExtend, rebased, relative to my base
@@ -155,25 +176,34 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
                     odn = max3i(M3 + OE4, I2 + OE4, D1 + E4) - RB;
                 } else {
                     const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], true);
-                    const int dd = (c + XB64 >= edge) ? dhi : dlo;
-                    odn = v.x + dd; oh = v.y + dd;
+                    odn = v.x; oh = v.y;
+                    odd = (c + XB64 >= edge) ? dhi : dlo;
                 }
                 ob = bp.raw(c - 1);
             }
         };
-        auto base_off = [&](int raw, int c) { int b = (l < 16 && c >= 1 && c <= m) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
-        int rb_seen = 0;
-        auto wait_rows = [&](int cmax) { // until the strip above has published the columns <= cmax
-            if (s > 0 && rb_seen < cmax) {
-                const long long t_begin = wall_clock64();
-                while ((rb_seen = rb_progress(&strip_prog[bid - 1])) < cmax) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; }
+        // ... until the strip above has stored them: an entry that still reads as the launch's fill is loaded again
+        auto settle = [&](int c, int &odn, int &oh, const int odd) {
+            if (s > 0) {
+                const bool mine = l < 16 && c >= 1 && c <= m;
+                if (__any(mine && (odn == W64_SENT || oh == W64_SENT))) {
+                    const long long t_begin = wall_clock64();
+                    while (true) {
+                        if (mine && (odn == W64_SENT || oh == W64_SENT)) {
+                            const int2 v = rb_load(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], true);
+                            odn = v.x; oh = v.y;
+                        }
+                        if (!__any(mine && (odn == W64_SENT || oh == W64_SENT))) break;
+                        __builtin_amdgcn_s_sleep(4);
+                        if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); if (mine && (odn == W64_SENT || oh == W64_SENT)) { odn = 0; oh = 0; } break; }
+                    }
                 }
+                odn += odd; oh += odd;
             }
         };
-        wait_rows(min(16, m));
-        boundary(l + 1, qdn, qh, qb);
+        auto base_off = [&](int raw, int c) { int b = (l < 16 && c >= 1 && c <= m) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
+        boundary(l + 1, qdn, qh, qb, ndd);
+        settle(l + 1, qdn, qh, ndd);
         qb = base_off(qb, l + 1);
         int wq[LW], pb_cur;
         auto fetch = [&](int pbv, int *w) {
@@ -262,12 +292,11 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
                     al64_snap_store<RW>(dst, rt, hold, diag0, dn_out);
                 }
             }
-            wait_rows(min(t0 + 2 * 16, m));
             if (s > 0) { // the columns loaded now are t0 + 17 .. t0 + 32: written by the strip above in its blocks (c + XB64) / CK64
                 while (t0 + 17 + XB64 >= edge) { qp++; edge += CKR; dlo = dhi_ok ? dhi : rbase_delta(bprod(qp), Bown); dhi_ok = false; }
                 if (!dhi_ok && t0 + 32 + XB64 >= edge) { dhi = rbase_delta(bprod(qp + 1), Bown); dhi_ok = true; }
             }
-            boundary(t0 + 16 + l + 1, ndn, nh, nb);
+            boundary(t0 + 16 + l + 1, ndn, nh, nb, ndd);
             if (t0 >= G64 && t0 + 16 <= m) {
                 al64_unrolled_block(std::make_integer_sequence<int, 16>{}, [&](auto uc) {
                     if constexpr (decltype(uc)::value == 15) nb = base_off(nb, t0 + 16 + l + 1); // (as late as possible: the boundary loads of the block have a block's time to arrive)
@@ -278,18 +307,17 @@ __global__ __launch_bounds__(64) void al64_sweep_kernel(const PairPlan *__restri
                 for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, std::integral_constant<int, -1>{}, u == 15, nb); }
             }
             asm volatile("" :: "v"(ndn), "v"(nh));
+            settle(t0 + 16 + l + 1, ndn, nh, ndd);
             qdn = ndn; qh = nh;
             if (store_row) {
                 const int x = l - (G64 - 16), c = t0 + x + 1 - (G64 - 1); // lanes 48 .. 63: slot x holds what lane 63 handed down at step t0 + 1 + x
                 if (x >= 0 && c >= 1 && c <= m) rb_store(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_dn, sq_h, true);
             }
-            if (((t0 + 16) & (kp.rb_pub - 1)) == 0) rb_publish(&strip_prog[bid], t0 + 1 - (G64 - 16), l); // the bottom row is out up to column t0 + 1 - 48
         }
         if (m >= 1) {
 #pragma unroll
             for (int r = 0; r < RW; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (Bown + (int64_t)hold[r] + (int64_t)RB * ((int64_t)pl.n + m)) >> 2; // plain score h(n, m)
         }
-        rb_publish(&strip_prog[bid], 0x7fffffff, l);
     }
     if (bad) atomicOr(err, 1);
 }

@@ -78,7 +78,6 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
     int bad = 0;
     const int64_t rb_pitch = (int64_t)m + 1;
     for (int s = s_own - n_stolen; s <= s_own; s++) {
-        const int bid = (int)blockIdx.x - s_own + s;
         const bool store_row = s + 1 < pl.strips;
         const int row0 = s * HW + l * RW;
         int val[RW];
@@ -103,33 +102,39 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
         for (int r = 0; r < RW; r++) val[r] = 2; // column 0, rebased: 0 (tag 2)
         int diag0 = 2;
         int v_out = 0, b_out = l * (LW * 4), sq_v = 0;
-        int qv = 0, qb = 0, nv = 0, nb = 0;
+        int qv = 0, qb = 0, nv = 0, nb = 0, ndd = 0;
         long long Bown = 0;
         int dlo = 0, dhi = 0, qp = 0, edge = CKC64, r0v = 2;
         bool dhi_ok = false;
         long long *my_bases = bases + pl.rowi_off + (int64_t)s * pl.s_pitch;
-        auto bprod = [&](int q) -> long long { return s == 0 ? 0LL : rbase_load(my_bases - pl.s_pitch + q, true); };
-        auto boundary = [&](int c, int &ov, int &ob) { // lanes 0 .. 15: column c of the row above the strip, the (raw) base of column c
-            ov = 0; ob = 0;
+        // (the hand-over without a progress word: affine_long64.hip.h, W64_SENT)
+        auto bprod = [&](int q) -> long long { return (s == 0 || (int64_t)q * CKC64 > (int64_t)m + XB64) ? 0LL : w64_base_wait(my_bases - pl.s_pitch + q, err); };
+        auto boundary = [&](int c, int &ov, int &ob, int &odd) { // lanes 0 .. 15: column c of the row above the strip as it is in memory (s > 0: to be settled, then shifted by odd), the (raw) base of column c
+            ov = 0; ob = 0; odd = 0;
             if (l < 16 && c >= 1 && c <= m) {
                 if (s == 0) ov = r0v;
-                else ov = rb_load32(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], true) + ((c + XB64 >= edge) ? dhi : dlo);
+                else { ov = rb_load32(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], true); odd = (c + XB64 >= edge) ? dhi : dlo; }
                 ob = bp.raw(c - 1);
             }
         };
-        auto base_off = [&](int raw, int c) { int b = (l < 16 && c >= 1 && c <= m) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
-        int rb_seen = 0;
-        auto wait_rows = [&](int cmax) {
-            if (s > 0 && rb_seen < cmax) {
-                const long long t_begin = wall_clock64();
-                while ((rb_seen = rb_progress(&strip_prog[bid - 1])) < cmax) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); break; }
+        auto settle = [&](int c, int &ov, const int odd) {
+            if (s > 0) {
+                const bool mine = l < 16 && c >= 1 && c <= m;
+                if (__any(mine && ov == W64_SENT)) {
+                    const long long t_begin = wall_clock64();
+                    while (true) {
+                        if (mine && ov == W64_SENT) ov = rb_load32(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], true);
+                        if (!__any(mine && ov == W64_SENT)) break;
+                        __builtin_amdgcn_s_sleep(4);
+                        if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); if (mine && ov == W64_SENT) ov = 0; break; }
+                    }
                 }
+                ov += odd;
             }
         };
-        wait_rows(min(16, m));
-        boundary(l + 1, qv, qb);
+        auto base_off = [&](int raw, int c) { int b = (l < 16 && c >= 1 && c <= m) ? bp.value(raw, c - 1) : 0; if (b >= 5) { bad = 1; b = 4; } return b * (BST * 4); };
+        boundary(l + 1, qv, qb, ndd);
+        settle(l + 1, qv, ndd);
         qb = base_off(qb, l + 1);
         int wq[LW], pb_cur;
         auto fetch = [&](int pbv, int *w) {
@@ -196,12 +201,11 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
                     cl64_snap_store<RW>(dst, val, diag0);
                 }
             }
-            wait_rows(min(t0 + 32, m));
             if (s > 0) { // the columns loaded now are t0 + 17 .. t0 + 32: written by the strip above in its blocks (c + XB64) / CKC64
                 while (t0 + 17 + XB64 >= edge) { qp++; edge += CKC64; dlo = dhi_ok ? dhi : rbase_delta(bprod(qp), Bown); dhi_ok = false; }
                 if (!dhi_ok && t0 + 32 + XB64 >= edge) { dhi = rbase_delta(bprod(qp + 1), Bown); dhi_ok = true; }
             }
-            boundary(t0 + 16 + l + 1, nv, nb);
+            boundary(t0 + 16 + l + 1, nv, nb, ndd);
             if (t0 >= G64 && t0 + 16 <= m) {
                 al64_unrolled_block(std::make_integer_sequence<int, 16>{}, [&](auto uc) {
                     if constexpr (decltype(uc)::value == 15) nb = base_off(nb, t0 + 16 + l + 1);
@@ -212,18 +216,17 @@ __global__ __launch_bounds__(64) void cl64_sweep_kernel(const PairPlan *__restri
                 for (int u = 0; u < 16; u++) { if (u == 15) nb = base_off(nb, t0 + 16 + l + 1); step(t0 + u + 1, std::true_type{}, std::integral_constant<int, -1>{}, u == 15, nb); }
             }
             asm volatile("" :: "v"(nv));
+            settle(t0 + 16 + l + 1, nv, ndd);
             qv = nv;
             if (store_row) {
                 const int x = l - (G64 - 16), c = t0 + x + 1 - (G64 - 1); // lanes 48 .. 63: slot x holds what lane 63 handed down at step t0 + 1 + x
                 if (x >= 0 && c >= 1 && c <= m) rb_store32(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], sq_v, true);
             }
-            if (((t0 + 16) & (RB_PUB - 1)) == 0) rb_publish(&strip_prog[bid], t0 + 1 - (G64 - 16), l);
         }
         if (m >= 1) {
 #pragma unroll
             for (int r = 0; r < RW; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (Bown >> 2) + (int64_t)(val[r] >> 2) + (int64_t)(kp.g4 >> 2) * ((int64_t)pl.n + m); // plain V(n, m)
         }
-        rb_publish(&strip_prog[bid], 0x7fffffff, l);
     }
     if (bad) atomicOr(err, 1);
 }

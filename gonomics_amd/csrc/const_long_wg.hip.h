@@ -33,6 +33,38 @@ namespace {
 // LDS per workgroup: score table 128 B + 4 profiles x 6400 B + 5 rings x 1024 B + 4 base rings x 256 B + flags = 31 928 B = 25 granules
 // of 1280 B: 5 workgroups = 20 waves per CU, what the one-strip kernel's registers allowed (5 per SIMD at <= 96 registers).
 // ------------------------------------------------------------------------------------------------------
+// Round 6 experiment: the ITEM boundary -- the one hand-over through memory, every NW strips -- without a progress word.  Shipped form: the item's last wave stored its bottom row
+// with write-through stores, waited for their acknowledgement (s_waitcnt vmcnt(0)) and advanced a progress word every rb_pub steps; the next item's first wave polled
+// that word with s_sleep(32) between polls.  The four waves of an item are rate-coupled through their LDS rings, so the publishing wave's memory round trips paced
+// all of them -- that was the hypothesis (SQ_WAIT_ANY 0.31 of the wave-cycles at 4.4 waves per SIMD, profiles/r5_hbm_traffic.json).  In the experiment the boundary rows start as CLW_SENT (clw_fill_sentinel_kernel,
+// before the launch), the producer just stores, the consumer re-loads an entry that still reads as the fill (lat_fill_kernel's protocol): a 4-byte store is never torn,
+// nobody relies on the order of two stores.  MEASURED AND NOT SHIPPED (-DGNX_CLW_SENT=1 builds it): 1 024 pairs of C5 sweep in 154.1 ms with it (150 ms + 4 ms of fill) against 153.6 ms with the
+// progress words -- with 4.4 waves per SIMD the publishing wave's round trips were already hidden; the waits of this kernel are the LDS flag polls between the waves of an item
+// (profiles/r6_experiments.md section 7).
+#ifndef GNX_CLW_SENT
+#define GNX_CLW_SENT 0
+#endif
+constexpr int CLW_SENT = (int)0x80808080;  // "not written yet": below every key of the static range (> -2^29), not the "-inf" NEG4 either
+// the bottom rows of the strips that END an item (strip NW k + NW - 1 of every pair, when another strip follows): grid (items, pairs)
+__global__ __launch_bounds__(256) void clw_fill_sentinel_kernel(const PairPlan *__restrict__ plans, int n_pairs, int nw, int *__restrict__ rowbuf) {
+    const int p = blockIdx.y;
+    if (p >= n_pairs) return;
+    const PairPlan pl = plans[p];
+    const int s = (int)blockIdx.x * nw + nw - 1;
+    if (s + 1 >= pl.strips) return; // (the last strip of a pair hands nothing down)
+    int4 *row = reinterpret_cast<int4 *>(rowbuf + pl.rowbuf_off + (int64_t)s * ((int64_t)pl.m + 1));
+    // (whole int4s where the row is aligned; the ragged ends as ints)
+    int *ri = rowbuf + pl.rowbuf_off + (int64_t)s * ((int64_t)pl.m + 1);
+    const int n = pl.m + 1;
+    const int head = (int)((4 - ((reinterpret_cast<uintptr_t>(ri) >> 2) & 3)) & 3);
+    for (int x = threadIdx.x; x < min(head, n); x += 256) ri[x] = CLW_SENT;
+    const int nq = max(n - head, 0) >> 2;
+    int4 *rq = reinterpret_cast<int4 *>(ri + head);
+    for (int x = threadIdx.x; x < nq; x += 256) rq[x] = make_int4(CLW_SENT, CLW_SENT, CLW_SENT, CLW_SENT);
+    for (int x = head + 4 * nq + threadIdx.x; x < n; x += 256) ri[x] = CLW_SENT;
+    (void)row;
+}
+
 constexpr int CLW_RC = 64;                 // columns (positions) per hand-over ring and pair
 constexpr int CLW_NSLOT = CLW_RC / 16;     // blocks per ring
 
@@ -161,6 +193,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5, 5)))
             }
         };
         auto row_above = [&](int c) { return (c >= 1 && c <= m_eff) ? rb_load32(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], true) : 0; };
+        // (GNX_CLW_SENT) ... until the item above has stored it: an entry that still reads as the launch's fill is loaded again
+        auto settle_above = [&](int c, int &v) {
+            if (!GNX_CLW_SENT || !from_mem) return;
+            const bool mine = c >= 1 && c <= m_eff;
+            if (__any(mine && v == CLW_SENT)) {
+                const long long t_begin = wall_clock64();
+                while (true) {
+                    if (mine && v == CLW_SENT) v = rb_load32(&rowbuf[pl.rowbuf_off + (int64_t)(s - 1) * rb_pitch + c], true);
+                    if (!__any(mine && v == CLW_SENT)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t_begin > 500000000LL) { atomicOr(err, 16); if (mine && v == CLW_SENT) v = 0; break; }
+                }
+            }
+        };
 
         // ---- prologue: the input ring's blocks 0 and 1 (columns <= 17), the base ring's columns 1 .. 16 ----
         if (w == 0) {
@@ -168,9 +214,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5, 5)))
 #pragma unroll
                 for (int x = 0; x < NSLOT; x++) rin[l + 16 * x] = 2; // (every position: the rotation does not matter)
             } else {
-                wait_rows(18);
-                rin[(l + rot) & (RC - 1)] = row_above(l - 14);          // block 0: only position 15 (column 1) is ever read
-                rin[(16 + l + rot) & (RC - 1)] = row_above(l + 2);      // block 1: columns 2 .. 17
+                if (!GNX_CLW_SENT) wait_rows(18);
+                int v0 = row_above(l - 14), v1 = row_above(l + 2);
+                settle_above(l - 14, v0); settle_above(l + 2, v1);
+                rin[(l + rot) & (RC - 1)] = v0;          // block 0: only position 15 (column 1) is ever read
+                rin[(16 + l + rot) & (RC - 1)] = v1;     // block 1: columns 2 .. 17
             }
         } else {
             clw_wait_ge(prod_in, 2, err);
@@ -231,7 +279,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5, 5)))
             // pacing (see the header): the input ring's block k + 1 must be complete, the output ring's slot of block k free
             if (w > 0 && k + 1 < K) clw_wait_ge(prod_in, k + 2, err);
             if (has_cons && k > NSLOT) clw_wait_ge(cons_out, k - NSLOT, err); // (the slot's old content, ring block k - NSLOT, was read during the consumer's block k - NSLOT - 1)
-            if (from_mem) { wait_rows(t0 + 33); nv = row_above(t0 + 18 + l); } // input ring block k + 2 (columns t0 + 18 .. t0 + 33), written at the end of this block
+            if (from_mem) { if (!GNX_CLW_SENT) wait_rows(t0 + 33); nv = row_above(t0 + 18 + l); } // input ring block k + 2 (columns t0 + 18 .. t0 + 33), written at the end of this block
             nraw = base_raw(t0 + 17 + l);                                        // bases of the next block's new columns
             asm volatile("" ::: "memory");
             const int *rin_n = rin + ((t0 + 16 + rot) & (RC - 1));
@@ -251,7 +299,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5, 5)))
                 }
             }
             asm volatile("" ::: "memory");
-            if (from_mem) rin[(t0 + 32 + l + rot) & (RC - 1)] = nv;
+            if (from_mem) { settle_above(t0 + 18 + l, nv); rin[(t0 + 32 + l + rot) & (RC - 1)] = nv; }
             // the block's 16 bottom-row values, one per lane: column t0 + l - 14 (position t0 + l)
             const int dv = rout_b[l];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's ring writes are done (and dv is here)
@@ -263,14 +311,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5, 5)))
                 const int c = t0 + l - 14;
                 if (c >= 1 && c <= m_eff) rb_store32(&rowbuf[pl.rowbuf_off + (int64_t)s * rb_pitch + c], dv, to_mem);
             }
-            if (to_mem && ((t0 + 16) & (kp.rb_pub - 1)) == 0) rb_publish(&item_prog[bid], t0 + 1, lane);
+            if (!GNX_CLW_SENT && to_mem && ((t0 + 16) & (kp.rb_pub - 1)) == 0) rb_publish(&item_prog[bid], t0 + 1, lane);
         }
         if (has_cons && lane == 0) __hip_atomic_store(prod_out, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (gact && m_eff >= 1) {
 #pragma unroll
             for (int r = 0; r < R; r++) if (row0 + r + 1 == pl.n) hfin[pl.hcol_off] = (int64_t)((val[r] >> 2) + (kp.g4 >> 2) * (pl.n + m_eff)); // plain V(n, m) (this kernel only runs pairs inside the static int32 range)
         }
-        if (to_mem) rb_publish(&item_prog[bid], 0x7fffffff, lane);
+        if (!GNX_CLW_SENT && to_mem) rb_publish(&item_prog[bid], 0x7fffffff, lane);
     }
     if (bad) atomicOr(err, 1);
 }

@@ -619,8 +619,6 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
 // tiles per round of the walk farm (farm64.hip.h); 0: the one-workgroup walks
 // snapshot spacing of the 64-lane affine sweep when the farm walks (farm64.hip.h): 512 steps (GNX_W64_CK = 128 / 256 / 512); the one-workgroup walks need CKA
 int w64_farm_ck() { const char *e = getenv("GNX_W64_CK"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }
-// how often a strip of the 64-lane sweeps publishes its bottom row (steps; the strip below runs ~63 + 32 + this many steps behind): GNX_W64_PUB = 16 / 32 / 64
-int w64_pub() { const char *e = getenv("GNX_W64_PUB"); const int v = e ? atoi(e) : RB_PUB; return (v == 16 || v == 32 || v == 64) ? v : RB_PUB; }
 int w64_farm_tiles() { const char *e = getenv("GNX_W64_FARM"); if (!e) return 16; const int v = atoi(e); return v <= 0 ? 0 : std::min(v, (int)FARM_MAX); }
 
 // Rows per lane of the affine 64-lane sweep (affine_long64.hip.h): call f with the compile-time constant of the instantiation
@@ -904,7 +902,6 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         kps.ckc = (int)ckc;
         kpa.ckc = (int)ck_aff; // (al64_sweep_kernel, the farm's re-fills)
         if (w64) { g_last_w64_r = rw64; g_last_w64_ck = affine ? ck_aff : ckc; }
-        kpa.rb_pub = w64_pub();
         kps.rb_pub = n_blocks * per_item >= (int64_t)40 * c.n_cu ? 16 : RB_PUB; // (twice the wave slots of the piped sweep: 20 per CU)
         if (const char *e = getenv("GNX_CL_PUB")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) kps.rb_pub = v; }
         int2 *drb2 = reinterpret_cast<int2 *>(c.rowbuf.p);
@@ -912,7 +909,14 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
 #define GNX_AL_SWEEP(P_, RBS_) hipLaunchKernelGGL((al_sweep_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs)
 #define GNX_CL_SWEEP(P_, RBS_) hipLaunchKernelGGL((cl_sweep_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog, dbs)
 #define GNX_CL_FLAT(P_, RBS_) hipLaunchKernelGGL((cl_sweep_flat_kernel<P_, RBS_>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, dbs)
-        if (rebase) HIPCHK(hipMemsetAsync(dbs, 0, (size_t)max_bs * 8, stream));
+        if (rebase && !w64) HIPCHK(hipMemsetAsync(dbs, 0, (size_t)max_bs * 8, stream));
+        if (w64) { // the 64-lane sweeps hand rows over without a progress word (affine_long64.hip.h, W64_SENT): row buffer and bases start as "not written yet", block 0 of every strip's bases as 0
+            int64_t rb_used = 0, bs_used = 0;
+            for (int64_t q2 = b; q2 < e; q2++) { const PairPlan &pq = plans[(size_t)q2]; rb_used = std::max(rb_used, pq.rowbuf_off + (int64_t)(pq.strips - 1) * (pq.m + 1)); bs_used = std::max(bs_used, pq.rowi_off + (int64_t)pq.strips * pq.s_pitch); }
+            if (rb_used > 0) HIPCHK(hipMemsetAsync(c.rowbuf.p, 0x80, (size_t)rb_used * (affine ? 8 : 4), stream));
+            if (bs_used > 0) HIPCHK(hipMemsetAsync(dbs, 0x80, (size_t)bs_used * 8, stream));
+            for (int64_t q2 = b; q2 < e; q2++) { const PairPlan &pq = plans[(size_t)q2]; HIPCHK(hipMemset2DAsync(dbs + pq.rowi_off, (size_t)pq.s_pitch * 8, 0, 8, (size_t)pq.strips, stream)); }
+        }
         if (w64 && !affine) {
             w64c_rows_dispatch(rw64, [&](auto rwc) {
                 constexpr int RW = decltype(rwc)::value;
@@ -926,7 +930,15 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
                 else hipLaunchKernelGGL((al64_sweep_kernel<RW, false>), gridS, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kpa, drb2, dsn, dhf, d_err, d_smap, d_sprog, dbs);
             });
         } else if (affine) { if (rebase) { if (p16) GNX_AL_SWEEP(true, true); else GNX_AL_SWEEP(false, true); } else { if (p16) GNX_AL_SWEEP(true, false); else GNX_AL_SWEEP(false, false); } }
-        else if (wg) hipLaunchKernelGGL(cl_sweep_wg_kernel<CLW_NW>, gridS, dim3(64 * CLW_NW), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        else if (wg) {
+            if (GNX_CLW_SENT) { // the item boundaries' rows start as "not written yet" (const_long_wg.hip.h)
+                int smax_all = 0;
+                for (int64_t q2 = b; q2 < e; q2++) smax_all = std::max(smax_all, (int)plans[(size_t)q2].strips);
+                const dim3 gfs((unsigned)std::max((smax_all + CLW_NW - 1) / CLW_NW, 1), (unsigned)np);
+                hipLaunchKernelGGL(clw_fill_sentinel_kernel, gfs, dim3(256), 0, stream, dpl, np, CLW_NW, drb);
+            }
+            hipLaunchKernelGGL(cl_sweep_wg_kernel<CLW_NW>, gridS, dim3(64 * CLW_NW), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kps, drb, dsn, dhf, d_err, d_smap, d_sprog);
+        }
         else if (piped) { if (rebase) { if (p16) GNX_CL_SWEEP(true, true); else GNX_CL_SWEEP(false, true); } else { if (p16) GNX_CL_SWEEP(true, false); else GNX_CL_SWEEP(false, false); } }
         else { if (rebase) { if (p16) GNX_CL_FLAT(true, true); else GNX_CL_FLAT(false, true); } else { if (p16) GNX_CL_FLAT(true, false); else GNX_CL_FLAT(false, false); } }
 #undef GNX_AL_SWEEP
@@ -1157,8 +1169,16 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
         // backward panels of equal size (a remainder panel of a few strips would sweep the whole width at a fraction of the device); forward
         // panels of whole backward panels -- their top rows are what a forward panel saves -- up to 9 strips per CU (5 Mb x 5 Mb: 13 per CU sweep
         // 0.5 s faster and take 1.4 s longer to allocate in a process's first call)
-        const int64_t total_strips = (n + HS - 1) / HS, n_bwd = (total_strips + Sb_max - 1) / Sb_max;
-        const int64_t Sb = forced_panels ? Sb_max : (total_strips + n_bwd - 1) / n_bwd;
+        // ... unless whole rounds of the SIMDs fit: a launch is paced by the SIMD that holds most strips (one wave each), so 2 048 strips cost what 1 628 do -- panels of
+        // k x 1 024 strips and one remainder panel (5 Mb x 5 Mb at 1 024-row strips: 2 048 + 2 048 + 787 instead of 3 x 1 628), when the remainder is not a sliver
+        const int64_t total_strips = (n + HS - 1) / HS, simds = 4 * (int64_t)c.n_cu;
+        int64_t n_bwd = (total_strips + Sb_max - 1) / Sb_max, Sb_pick = (total_strips + n_bwd - 1) / n_bwd;
+        if (w64 && Sb_max >= simds && total_strips > Sb_max) {
+            const int64_t Sq = Sb_max / simds * simds, rem = total_strips % Sq;
+            if (rem == 0 || rem >= simds / 4) { Sb_pick = Sq; n_bwd = (total_strips + Sq - 1) / Sq; }
+        }
+        const int64_t Sb = forced_panels ? Sb_max : Sb_pick;
+        if (forced_panels) n_bwd = (total_strips + Sb_max - 1) / Sb_max;
         const int64_t Sf = forced_panels ? Sf_max : std::max(Sb, std::min<int64_t>(Sf_max, std::max<int64_t>(Sb, 9 * c.n_cu)) / Sb * Sb);
         const int64_t nq = ((m + GS + 14) & ~(int64_t)15) / ck + 2; // K-step blocks of a strip: the pitch of the bases, the same in every panel
         const int64_t top_b = (m + 1) * rbw + nq * 8;           // one saved boundary: the row + its bases
@@ -1199,7 +1219,11 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             HIPCHK(hipMemcpyAsync(c.strip_map.p, smap.data(), (size_t)local * 8, hipMemcpyHostToDevice, stream));
             HIPCHK(hipMemcpyAsync(d_starts, starts, 16, hipMemcpyHostToDevice, stream));
             HIPCHK(hipMemsetAsync(d_sprog, 0, (size_t)local * 8 + 8, stream));
-            HIPCHK(hipMemsetAsync(ar_bases, 0, (size_t)bs_e * 8, stream));
+            if (w64) { // (the hand-over without a progress word: everything starts as "not written yet", block 0 of every strip's bases as 0; the stand-in strip's row and bases come below)
+                if (rb_e > 0) HIPCHK(hipMemsetAsync(ar_rows, 0x80, (size_t)rb_e * rbw, stream));
+                HIPCHK(hipMemsetAsync(ar_bases, 0x80, (size_t)bs_e * 8, stream));
+                HIPCHK(hipMemset2DAsync(ar_bases, (size_t)nq * 8, 0, 8, (size_t)planned, stream));
+            } else HIPCHK(hipMemsetAsync(ar_bases, 0, (size_t)bs_e * 8, stream));
             if (s0 > 0) { // the stand-in strip 0: done and claimed; its bottom row and bases = what the strip above handed down
                 // (no conversion: the keys are V' = V - e (i + j) with the PAIR's row i in every panel -- the recurrences never look at i, and
                 // column 0 of a global alignment is the same constant in every row; only the final un-rebasing used the panel's row count, below)
@@ -1216,7 +1240,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             long long *dbs = reinterpret_cast<long long *>(ar_bases);
             int *dsn = forward ? nullptr : reinterpret_cast<int *>(ar_snap); // (null: the sweep keeps no snapshots)
             KParams kps = kp;
-            kps.ckc = (int)ck; kps.rb_pub = w64 ? w64_pub() : RB_PUB;
+            kps.ckc = (int)ck; kps.rb_pub = RB_PUB;
             if (w64) { g_last_w64_r = rw64; g_last_w64_ck = ck; }
             const dim3 gridS((unsigned)local);
             HIPCHK(hipEventRecord(c.ev[1], stream));
@@ -1258,6 +1282,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             float f = 0;
             HIPCHK(hipEventElapsedTime(&f, c.ev[1], c.ev[2]));
             fill_ms += f;
+            if (getenv("GNX_DEBUG")) fprintf(stderr, "[gnx] row panels: %s sweep of %lld strips x %lld columns: %.1f ms (%.3g cells/s)\n", forward ? "forward" : "backward", (long long)cnt, (long long)mcols, f, (double)rows * (double)mcols / (f * 1e-3));
             return GNX_OK;
         };
         { // the arena: the biggest launch of the forward pass (rows + bases of Sf + 2 strips) or of the backward pass (+ snapshots, Sb + 2 strips)
@@ -1375,7 +1400,12 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
     const int np = (int)n_pairs;
     const int Q = affine ? LQA : LQC;
     int64_t n_blocks = 0;
-    for (int64_t p = 0; p < n_pairs; p++) { if (h_alen[p] < 1 || h_blen[p] < 1) return -1; n_blocks += (h_alen[p] + LH - 1) / LH; }
+    // (the scored int64 kernel takes empty sequences along -- AffineGap_highMem semantics: no strip to fill, traceback_kernel's closed forms -- it has no other route)
+    const bool empties_ok = wide && d_smat != nullptr;
+    for (int64_t p = 0; p < n_pairs; p++) {
+        if (h_alen[p] < 1 || h_blen[p] < 1) { if (!empties_ok) return -1; continue; }
+        n_blocks += (h_alen[p] + LH - 1) / LH;
+    }
     if (n_blocks > 0x3fffffff) return -1;
     // plans, staging offsets and the strip map are built in ONE pinned host block and go up in one copy (a single pair per call is the
     // common case here: every separate copy or synchronisation is ~10 us of a ~200 us call); the claim words follow them on the device
@@ -1392,12 +1422,12 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
         const int64_t n = h_alen[p], m = h_blen[p];
         PairPlan &pl = plans[(size_t)p];
         pl.n = (int32_t)n; pl.m = (int32_t)m;
-        pl.strips = (int32_t)((n + LH - 1) / LH);
+        pl.strips = (n < 1 || m < 1) ? 0 : (int32_t)((n + LH - 1) / LH);
         pl.words = (int32_t)((m + (LG - 1) + 15) / 16);
         pl.trace_off = toff; pl.hcol_off = hoff; pl.rowbuf_off = roff; pl.dcol_off = doff;
         pl.src = (int32_t)p; pl.col_off = 0; pl.ckpt_off = 0; pl.rowi_off = 0; pl.s_off = 0; pl.s_pitch = 0;
         if (h_soff) { pl.s_off = h_soff[p]; pl.s_pitch = (int64_t)((n + H - 1) / H) * H; } // (the matrices are laid out for the general path's 160-row strips)
-        toff += (int64_t)pl.strips * pl.words * Q * LG; hoff += n; roff += (int64_t)(pl.strips - 1) * (m + 1) * rbw; doff += (int64_t)pl.strips * LG;
+        toff += (int64_t)pl.strips * pl.words * Q * LG; hoff += n; roff += (int64_t)std::max(pl.strips - 1, 0) * (m + 1) * rbw; doff += (int64_t)pl.strips * LG;
         so[(size_t)p + 1] = so[(size_t)p] + n + m + 2;
         cells += n * m;
         for (int st = 0; st < pl.strips; st++) smap[(size_t)nb++] = make_int2((int)p, st);
@@ -1459,7 +1489,7 @@ int run_device_lat(const gnx_params *prm, const KParams &kp, const TbParams &tp,
     if (affine) hipLaunchKernelGGL((traceback_kernel<true, false, true, true, LG, LR>), gridP, blk, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score, dn, d_so, d_scr, (int64_t)0, d_err);
     else hipLaunchKernelGGL((traceback_kernel<false, false, true, true, LG, LR>), gridP, blk, 0, stream, dpl, np, dtrace, dh, ddc, tp, d_score, dn, d_so, d_scr, (int64_t)0, d_err);
     HIPCHK(hipGetLastError());
-    if (wide) hipLaunchKernelGGL(wide_scores_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const int64_t *>(c.mx_score.p), d_score, np);
+    if (wide) hipLaunchKernelGGL(wide_scores_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, dpl, reinterpret_cast<const int64_t *>(c.mx_score.p), d_score, np);
     if ((rc = launch_scan(dn, np, d_ops_off, d_carry, stream))) return rc;
     hipLaunchKernelGGL(reverse_runs_kernel, gridP, dim3(256), 0, stream, dpl, np, d_scr, d_so, dn, d_ops_off, d_ops, ops_capacity, d_err);
     HIPCHK(hipGetLastError());
@@ -1535,7 +1565,7 @@ int run_device(const gnx_params *prm, int64_t n_pairs,
         rc = run_device_lat(prm, kp, tp, affine, local, n_pairs, d_a, d_as, d_b, d_bs, h_alen, h_blen, d_score, d_ops, ops_capacity, d_ops_off, out_total, stream, d_smat, h_soff, false, true);
         if (rc >= 0) return rc;
         if (rc == -2) { set_err("a strip of the int64 kernel waited more than 5 s for the strip above it%s", ""); return GNX_EDEVICE; }
-        set_err("the direction matrices of a chunk / multiple-alignment call beyond the int32 range do not fit the workspace (or a sequence is empty)%s", ""); return GNX_ENOMEM;
+        set_err("the direction matrices of a chunk / multiple-alignment call beyond the int32 range do not fit the workspace%s", ""); return GNX_ENOMEM;
     }
     // ---- GNX_WIDE=2 (tests): everything through the int64 kernel (lat_wide.hip.h) ----
     if (!gsw && !d_smat && !c.beta_packed) {

@@ -287,9 +287,9 @@ __global__ __launch_bounds__(64) void lat_wide_kernel(const PairPlan *__restrict
 }
 
 // the scores of the wide path leave in int64 (traceback_kernel reads its start state from the tags in hcol and writes tag >> 2 as "score")
-__global__ __launch_bounds__(256) void wide_scores_kernel(const int64_t *__restrict__ score64, int64_t *__restrict__ score_out, int n) {
+__global__ __launch_bounds__(256) void wide_scores_kernel(const PairPlan *__restrict__ plans, const int64_t *__restrict__ score64, int64_t *__restrict__ score_out, int n) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) score_out[p] = score64[p];
+    if (p < n && plans[p].n > 0 && plans[p].m > 0) score_out[p] = score64[p]; // (an empty sequence: traceback_kernel's closed form stays)
 }
 
 } // namespace

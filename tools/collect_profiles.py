@@ -141,7 +141,9 @@ def main():
                     ("shapes_affine.jsonl", "_shapes_affine.jsonl"), ("shapes_const.jsonl", "_shapes_const.jsonl"), ("shapes_local.jsonl", "_shapes_local.jsonl"), ("gsw_reads.jsonl", "_gsw_reads.jsonl"), ("cabi_n1_n2.jsonl", "_cabi_n1_n2.jsonl"),
                     ("pytest_gpu.log", "_pytest_gpu.log"), ("bench_2ranks_shared_gpu.json", "_bench_2ranks_shared_gpu.json"), ("lds_occupancy.txt", "_lds_occupancy.txt"), ("stress.log", "_stress.log"), ("switch_matrix.log", "_switch_matrix.log"), ("concurrent_pairs.json", "_concurrent_pairs.json"), ("pmc_c5_wg_ab.txt", "_pmc_c5_wg_ab.txt"), ("wg_occupancy.txt", "_wg_occupancy.txt"), ("pair_latency.jsonl", "_pair_latency.jsonl"), ("n1_cmd.json", "_n1_cmd.json"), ("gsw_threads.jsonl", "_gsw_threads.jsonl"),
                     ("lat_crossover.jsonl", "_lat_crossover.jsonl"), ("gsw_genome.jsonl", "_gsw_genome.jsonl"), ("few_long_pairs.jsonl", "_few_long_pairs.jsonl"),
-                    ("long_pairs_farm_ab.jsonl", "_long_pairs_farm_ab.jsonl"), ("switch_matrix_farm.log", "_switch_matrix_farm.log")):
+                    ("long_pairs_farm_ab.jsonl", "_long_pairs_farm_ab.jsonl"), ("switch_matrix_farm.log", "_switch_matrix_farm.log"),
+                    ("long_pairs.jsonl", "_long_pairs.jsonl"), ("long_pairs_first_call.jsonl", "_long_pairs_first_call.jsonl"), ("pmc_long_pair.txt", "_pmc_long_pair.txt"), ("pmc_long_pair.json", "_pmc_long_pair.json"),
+                    ("kernel_stats_long_pair_affine_1M.csv", "_kernel_stats_long_pair.csv"), ("alloc_probe.txt", "_alloc_probe_round_end.txt"), ("stress_routes.log", "_stress_routes.log")):
         if nm == "gsw_genome.jsonl" and os.path.exists(os.path.join(src, nm)) and sum(1 for _ in open(os.path.join(src, nm))) < 2:
             continue  # (a run with GNX_SKIP_GENOME=1 holds the 1e8-base line only: the committed file keeps its 1e9 / 3e9 lines)
         p = os.path.join(src, nm)

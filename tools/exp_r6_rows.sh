@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: rows per lane of the 64-lane affine sweep (GNX_W64_R) and its publish interval (GNX_W64_PUB) on the long pairs; one box
+# round 6: rows per lane of the 64-lane affine sweep (GNX_W64_R) and its publish interval (GNX_W64_PUB: a switch of the build this ran on -- the progress words it spaced are gone, profiles/r6_experiments.md section 4) on the long pairs; one box
 out=gpurun_out/r6_rows; mkdir -p $out
 timeout 1200 python -m pytest tests/test_long_range.py -k "w64" -x -q > $out/pytest_w64.log 2>&1; tail -3 $out/pytest_w64.log
 : > $out/rows.jsonl

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-end GPU sequence: parity suite, smoke, bench lines, rocprofv3 kernel stats + HBM / SQ PMC passes (separate runs, as the
 # MI355X guide prescribes).  Usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tag]; then, in the build container,
-# python tools/collect_profiles.py gpurun_out/<tag> r5
-tag=${1:-r5}
+# python tools/collect_profiles.py gpurun_out/<tag> r6
+tag=${1:-r6}
 repo=$PWD
 out=$repo/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
@@ -51,7 +51,13 @@ bash tools/pmc_env_ab.sh gpurun_out/$tag/c5_ab "--no-cpu --no-host --no-extras -
 timeout 300 python tools/pair_latency.py 300 > $out/pair_latency.jsonl 2>> $out/bench.err
 # round 5: pairs beyond the static int32 range (snapshot path on moving bases; the 2 Mb / 5 Mb row-panel runs are in profiles/r5_long_pairs.jsonl),
 # the latency geometry against the general path, the whole cmd/faChunkAlign command, the graph aligner at genome scale
-timeout 900 python tools/long_pairs.py gpu const_150k affine_340k affine_1M const_300k_2M affine_2M affine_5M > $out/long_pairs.jsonl 2>> $out/bench.err
+timeout 900 python tools/long_pairs.py gpu const_150k affine_340k affine_q1_300k affine_1M const_300k_2M affine_2M affine_5M > $out/long_pairs.jsonl 2>> $out/bench.err
+# round 6: a one-call process (cmd/cigarToBed): every case in a process of its own after the device has been idle for a while (an allocation waits for the driver's
+# clearing of memory that was freed a moment ago -- profiles/r6_alloc_probe.txt -- so what the first call of a process costs depends on what ran before it)
+for c in affine_1M affine_2M; do sleep 20; timeout 300 python tools/long_pairs.py gpu $c >> $out/long_pairs_first_call.jsonl 2>> $out/bench.err; done
+# counters of the sweep of one long pair (valu_busy, waves per SIMD, HBM bytes): profiles/r6_pmc_long_pair.{txt,json}
+bash tools/pmc_long_pair.sh gpurun_out/$tag affine_1M affine_340k const_150k > /dev/null 2>> $out/bench.err
+timeout 120 tools/alloc_probe.bin 48 > $out/alloc_probe.txt 2>&1
 timeout 600 python tools/lat_crossover.py affine > $out/lat_crossover.jsonl 2>> $out/bench.err
 timeout 600 python tools/lat_crossover.py const >> $out/lat_crossover.jsonl 2>> $out/bench.err
 timeout 600 python tools/bench_n1_cmd.py 8 30000 3 > $out/n1_cmd.json 2>> $out/bench.err
@@ -68,5 +74,6 @@ tools/wg_occupancy.bin > $out/wg_occupancy.txt 2>> $out/bench.err
 timeout 700 python tools/stress.py ${GNX_STRESS_S:-420} 77 > $out/stress.log 2>&1
 [ "$GNX_SWITCH_MATRIX" = "1" ] && bash tools/switch_matrix.sh > $out/switch_matrix.log 2>&1
 [ "$GNX_SWITCH_MATRIX" = "farm" ] && bash tools/switch_matrix.sh farm > $out/switch_matrix_farm.log 2>&1
+[ "$GNX_STRESS_ROUTES" = "1" ] && bash tools/stress_routes.sh > $out/stress_routes.log 2>&1
 find $out -name '*.db' -size +20M -delete
 tail -3 $out/pytest_gpu.log; tail -1 $out/smoke.log; cat $out/bench.json | cut -c1-400; cat $out/bench_long.json | cut -c1-400

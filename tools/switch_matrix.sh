@@ -1,7 +1,7 @@
 #!/bin/bash
 # The GPU parity suites under the switches that change routes or kernels (results must not change): bash tools/switch_matrix.sh [farm]
 # (farm: only the legs of the 64-lane snapshot path and its walks -- farm64.hip.h)
-FARM="GNX_CLONG=2@GNX_W64=2 GNX_CLONG=2@GNX_W64=2@GNX_W64_FARM=0 GNX_CLONG=2@GNX_W64=2@GNX_W64_FARM_PIPE=0 GNX_CLONG=2@GNX_W64=2@GNX_W64_FARM=3 GNX_MEGA_STRIPS=3@GNX_W64=2 GNX_MEGA_STRIPS=3@GNX_W64=2@GNX_W64_FARM=0"
+FARM="GNX_CLONG=2@GNX_W64=2 GNX_CLONG=2@GNX_W64=2@GNX_W64_FARM=0 GNX_CLONG=2@GNX_W64=2@GNX_W64_FARM_PIPE=0 GNX_CLONG=2@GNX_W64=2@GNX_W64_FARM=3 GNX_MEGA_STRIPS=3@GNX_W64=2 GNX_MEGA_STRIPS=3@GNX_W64=2@GNX_W64_FARM=0 GNX_CLONG=2@GNX_W64=2@GNX_W64_R=6@GNX_W64_RC=4 GNX_CLONG=2@GNX_W64=2@GNX_W64_R=16@GNX_W64_RC=4 GNX_MEGA_STRIPS=3@GNX_W64=2@GNX_W64_R=8@GNX_W64_RC=4"
 if [ "$1" = "farm" ]; then
   for swa in $FARM; do
     sw=${swa//@/ }
