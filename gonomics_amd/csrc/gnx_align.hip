@@ -619,7 +619,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
 // tiles per round of the walk farm (farm64.hip.h); 0: the one-workgroup walks
 // snapshot spacing of the 64-lane affine sweep when the farm walks (farm64.hip.h): 512 steps (GNX_W64_CK = 128 / 256 / 512); the one-workgroup walks need CKA
 int w64_farm_ck() { const char *e = getenv("GNX_W64_CK"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }
-int w64_farm_tiles() { const char *e = getenv("GNX_W64_FARM"); if (!e) return 16; const int v = atoi(e); return v <= 0 ? 0 : std::min(v, (int)FARM_MAX); }
+int w64_farm_tiles() { const char *e = getenv("GNX_W64_FARM"); if (!e) return 24; const int v = atoi(e); return v <= 0 ? 0 : std::min(v, (int)FARM_MAX); }
 
 // Rows per lane of the affine 64-lane sweep (affine_long64.hip.h): call f with the compile-time constant of the instantiation
 template <typename F>

@@ -202,7 +202,7 @@ def test_row_panels_forced(gpu_lib, monkeypatch, mode, strips):
 
 
 @pytest.mark.parametrize("cs", [3, 16, 10000])
-@pytest.mark.parametrize("walk", ["farm", "farm1", "farm3", "farm32", "farm:seq", "farm3:seq", "farm:ck128", "farm3:ck256", "farm:r6", "farm:r8", "farm:r16", "farm3:r6:seq", "farm1:r16:ck128", "farm32:r8:ck256", "two_waves", "one_wave"])  # the walk farm (farm64.hip.h: 16 / 1 / 3 / 32 tiles per round, overlapped rounds or {fill, walk} launches), al64_walk2_kernel / cl64_walk2_kernel (the left neighbour tile re-filled by a second wave) or the one-wave kernels
+@pytest.mark.parametrize("walk", ["farm", "farm1", "farm3", "farm32", "farm:seq", "farm3:seq", "farm:ck128", "farm3:ck256", "farm:r6", "farm:r8", "farm:r16", "farm3:r6:seq", "farm1:r16:ck128", "farm32:r8:ck256", "two_waves", "one_wave"])  # the walk farm (farm64.hip.h: 24 (the default) / 1 / 3 / 32 tiles per round, overlapped rounds or {fill, walk} launches), al64_walk2_kernel / cl64_walk2_kernel (the left neighbour tile re-filled by a second wave) or the one-wave kernels
 @pytest.mark.parametrize("mode", [0, 1, 2, 4])  # AffineGap, ConstGap, AffineGap_highMem, ConstGap_highMem
 def test_w64_forced(gpu_lib, monkeypatch, mode, cs, walk):
     """GNX_CLONG=2 + GNX_W64=2: every pair through the snapshot path with the whole wave on one pair (affine_long64.hip.h / const_long64.hip.h:

@@ -8,7 +8,7 @@ out=$repo/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 python -c 'import bench; print(bench.kernel_source_hash())' > $out/kernel_source_hash.txt   # what the counters below are taken from
 echo "${GNX_COMMIT:-unknown}" > $out/commit.txt                                            # (the box has no .git: pass GNX_COMMIT=$(git rev-parse --short HEAD))
-timeout 1500 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -x -q $GNX_PYTEST_EXTRA > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest_gpu.log
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > $out/smoke.log 2>&1
 timeout 900 python bench.py > $out/bench.json 2> $out/bench.err
 timeout 900 python bench.py --series long --no-extras > $out/bench_long.json 2>> $out/bench.err
