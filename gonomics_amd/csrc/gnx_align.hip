@@ -641,8 +641,8 @@ constexpr int W64C_ROWS[2] = {4, R};
 // One long pair is strips(RW) = n / (64 RW) waves piped through the row buffer, each ~lag steps behind the one above it; a SIMD that holds w of
 // them issues w x (5 RW + ~18) instructions per step of the pipeline, and the pipeline moves at the pace of the fullest SIMD.  1 Mb x 1 Mb at RW = 10:
 // 1 563 waves on 1 024 SIMDs -- half of the SIMDs hold two, the others wait for them (valu_busy 0.56, profiles/r5_pmc_long_pair.txt); at RW = 8: 1 954,
-// two on (nearly) every SIMD, 54 instead of 64 instructions per wave and step.  Per instruction: ~2.75 ns for a wave alone on its SIMD, ~1.9 ns each
-// for two, ~1.75 from three on (tools/valu_ubench*.hip; the lone wave: profiles/r5_experiments.md section 2).  The model below is that arithmetic;
+// two on (nearly) every SIMD, 52 instead of 62 instructions per wave and step.  Per instruction: ~2.6 ns for a wave alone on its SIMD, ~2.05 ns each
+// for two, ~1.75 for three, ~1.65 from four on (fitted to profiles/r6_rows_per_lane_after.jsonl: 2 Mb x 2 Mb is fastest at RW = 8 -- 3 907 strips, four per SIMD: 850 ms against 915 at RW = 16).  The model below is that arithmetic;
 // GNX_W64_R = 6 / 8 / 10 / 16 overrides it (tests, A/B runs).  `strips_cap` > 0: row panels -- at most that many strips are in flight.
 int w64_pick_rows(const Ctx &c, bool affine, int64_t n_pairs, const int64_t *h_alen, const int64_t *h_blen, int64_t step4, int ck, int64_t strips_cap = 0) {
     // (constant gap: 2 RW + ~9 instructions per step; rows per lane 4 / 10, GNX_W64_RC)
@@ -662,8 +662,10 @@ int w64_pick_rows(const Ctx &c, bool affine, int64_t n_pairs, const int64_t *h_a
         double passes = 1.0;
         if (strips_cap > 0 && strips > (double)strips_cap) { passes = strips / (double)strips_cap; strips = (double)strips_cap; }
         const double w = std::ceil(strips / simds);
-        const double ns = w <= 1.0 ? 2.75 : (w <= 2.0 ? 1.9 : 1.75);
-        const double cost = passes * w * (affine ? 5.0 * rw + 15.0 : 2.0 * rw + 9.0) * ns * steps;
+        // ns per instruction and SIMD, fitted to profiles/r6_rows_per_lane_after.jsonl (340 kb / 1 Mb / 2 Mb at RW = 6 / 8 / 10 / 16 after the hand-over lost its progress word):
+        // a wave alone 2.6, two waves 1.9 + 0.02 RW each (the longer step of a taller strip overlaps worse), three 1.75, four or more 1.65
+        const double ns = w <= 1.0 ? 2.6 : (w <= 2.0 ? 1.9 + 0.02 * rw : (w <= 3.0 ? 1.75 : 1.65));
+        const double cost = passes * w * (affine ? 5.0 * rw + 12.4 : 2.0 * rw + 9.0) * ns * steps;
         if (best == 0 || cost < best) { best = cost; best_rw = rw; }
     }
     return best_rw;
