@@ -647,6 +647,10 @@ constexpr int W64C_ROWS[2] = {4, R};
 int w64_pick_rows(const Ctx &c, bool affine, int64_t n_pairs, const int64_t *h_alen, const int64_t *h_blen, int64_t step4, int ck, int64_t strips_cap = 0) {
     // (constant gap: 2 RW + ~9 instructions per step; rows per lane 4 / 10, GNX_W64_RC)
     if (const char *e = getenv(affine ? "GNX_W64_R" : "GNX_W64_RC")) { const int v = atoi(e); if (affine) { for (int x : W64_ROWS) if (x == v) return v; } else { for (int x : W64C_ROWS) if (x == v) return v; } }
+    // constant gap: the short strips only for the single-pair callers (cmd/globalAlignment: one ConstGap call on two whole sequences).  A tile of the farm is 64 RW rows x 224 steps, so a
+    // path crosses n / 256 + m / 224 tiles at RW = 4 instead of n / 640 + m / 224: 16 ... 64 pairs of 20 kb x 100 kb sweep 2 ms faster and walk 10 ms longer (profiles/r6_few_long_pairs.jsonl of the
+    // first round-end run: 38 -> 48 ms, 49 -> 60 ms per call), while ONE pair of 150 kb ... 2 Mb sweeps 1 - 30 ms faster and walks 0.5 - 3 ms longer
+    if (!affine && n_pairs > 3) return R;
     const double simds = 4.0 * c.n_cu, lag = 110.0;
     double best = 0;
     int best_rw = R;
