@@ -25,7 +25,7 @@ namespace {
 // A tile that was not asked for ends the walk's round; the walk's own tile is the first of the next set (overlapped: of one of the next two),
 // so the rounds always move, and a wrong guess costs the rest of one round -- never a result: the planes are the ones a round of al64_walk_kernel
 // computes (same snapshot, same recurrence; the steps beyond the walk's are never read), the walk is the same automaton.
-// GNX_W64_FARM=0: off (the one-workgroup walks); =k: k tiles per round (default 24 since round 6 -- at 512-step tiles a round is bound by its re-fills, so more of them side by side pay; at most 32).  GNX_W64_CK=128 / 256 / 512: the affine snapshot spacing (below).
+// GNX_W64_FARM=0: off (the one-workgroup walks); =k: k tiles per round (default: 24 for launches of one or two AffineGap pairs since round 6 -- at 512-step tiles a round is bound by its re-fills, so more of them side by side pay --, 16 otherwise; at most 32).  GNX_W64_CK=128 / 256 / 512: the affine snapshot spacing (below).
 // Measured (profiles/r5_long_pairs.jsonl, r5_experiments.md section 10): AffineGap 1 Mb x 1 Mb walk 538 -> 41 ms (call 0.86 -> 0.35 s, workspace 87 -> 31 GB),
 // 340 kb x 340 kb 0.30 -> 0.089 s, 2 Mb x 2 Mb 3.5 -> 1.1 s (no row panels any more), ConstGap 150 kb x 180 kb 0.092 -> 0.036 s, 300 kb x 2 Mb (450 000 runs: the
 // scalar steps of the walk) 0.57 -> 0.43 s.

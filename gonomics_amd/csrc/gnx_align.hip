@@ -619,7 +619,15 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
 // tiles per round of the walk farm (farm64.hip.h); 0: the one-workgroup walks
 // snapshot spacing of the 64-lane affine sweep when the farm walks (farm64.hip.h): 512 steps (GNX_W64_CK = 128 / 256 / 512); the one-workgroup walks need CKA
 int w64_farm_ck() { const char *e = getenv("GNX_W64_CK"); const int v = e ? atoi(e) : 512; return (v == 128 || v == 256 || v == 512) ? v : 512; }
-int w64_farm_tiles() { const char *e = getenv("GNX_W64_FARM"); if (!e) return 24; const int v = atoi(e); return v <= 0 ? 0 : std::min(v, (int)FARM_MAX); }
+// (affine, pairs of the launch given: the tiles a round of that launch re-fills per pair.  24 for one or two AffineGap pairs -- at 512-step tiles a round is bound by its re-fills, more of them side by
+// side pay: 1 Mb x 1 Mb walk 37 -> 30 ms --, 16 otherwise: with four pairs and more, or the constant-gap 224-step tiles, the extra re-fills of a wrong guess cost more than they buy
+// (profiles/r6_few_long_pairs_24_tiles_everywhere.jsonl: 16 / 64 ConstGap pairs of 20 kb x 100 kb walked 28 / 31 ms at 24 tiles a round against 22 / 23 at 16, 4 AffineGap pairs of 200 kb 14.0 against 11.8))
+int w64_farm_tiles(bool affine = false, int64_t n_pairs = 1 << 20) {
+    const char *e = getenv("GNX_W64_FARM");
+    if (!e) return (affine && n_pairs <= 2) ? 24 : 16;
+    const int v = atoi(e);
+    return v <= 0 ? 0 : std::min(v, (int)FARM_MAX);
+}
 
 // Rows per lane of the affine 64-lane sweep (affine_long64.hip.h): call f with the compile-time constant of the instantiation
 template <typename F>
@@ -954,7 +962,7 @@ int run_device_clong(const gnx_params *prm, const KParams &kp, const TbParams &t
         HIPCHK(hipEventRecord(c.ev[2], stream));
         const dim3 gridW((unsigned)((np + 3) / 4));
 #define GNX_AL_WALK(P_, RBS_) hipLaunchKernelGGL((al_walk_kernel<P_, RBS_>), gridW, dim3(64), 0, stream, dpl, np, d_a, d_as + b, d_b, d_bs + b, kp, tp, drb2, dsn, dhf, d_score + b, dn, d_so, d_scr, d_err, dbs, (MegaState *)nullptr)
-        const int farm_nt = w64 ? w64_farm_tiles() : 0;
+        const int farm_nt = w64 ? w64_farm_tiles(affine, np) : 0;
         if (farm_nt > 0) { // the walk as rounds of tiles re-filled ahead of it on many CUs (farm64.hip.h)
             int64_t path = 0;
             for (int64_t p = b; p < e; p++) path = std::max(path, (int64_t)plans[(size_t)p].n + plans[(size_t)p].m);
@@ -1318,7 +1326,7 @@ int run_device_mega(const gnx_params *prm, const KParams &kp, const TbParams &tp
             const int *dsn = reinterpret_cast<const int *>(ar_snap);
             int64_t *d_tmp_score = dhf + 2; // (the walk writes hfin[pl.hcol_off] here when it ends: not the pair's score, see above)
             HIPCHK(hipEventRecord(c.ev[1], stream));
-            const int farm_nt = w64 ? w64_farm_tiles() : 0;
+            const int farm_nt = w64 ? w64_farm_tiles(affine, 1) : 0;
             if (farm_nt > 0) {
                 KParams kpf = kp;
                 kpf.ckc = (int)ck;
